@@ -1,0 +1,14 @@
+"""pytest configuration: registers the `gpu` marker and puts the product package root
+(`nope-nerf_amd/`, which plays the role of the reference's repository root: `import model`)
+and `oracle/` on sys.path."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "nope-nerf_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

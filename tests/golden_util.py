@@ -1,0 +1,96 @@
+"""Helpers shared by the parity tests: load a golden case (tests/golden/*.npz, produced by
+oracle/gen_golden.py from the real reference) and run the oracle on it."""
+import os
+
+import numpy as np
+import torch
+
+import nerf_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GRAD_CASES = ["tanks_d128", "llff_ndc_d128", "uniform_distalpha_masked_d128", "white_nonorm_d128", "zero_pose_d128",
+              "tanks_d256_n192"]
+EVAL_CASES = ["tanks_eval_d128", "masked_inf_eval_d128"]
+N_CAMS = 4
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    case = {k: z[k] for k in z.files}
+    w = np.load(os.path.join(GOLDEN, str(case["cfg.weights_file"])))
+    weights = {k: torch.from_numpy(w[k]) for k in w.files}
+    for k in list(case):
+        if k.startswith("w."):
+            weights[k[2:]] = torch.from_numpy(case[k])
+    case["weights"] = weights
+    return case
+
+
+def render_cfg(case):
+    return {
+        "num_points": int(case["cfg.N"]), "dist_alpha": bool(case["cfg.dist_alpha"]),
+        "sample_option": "ndc" if int(case["cfg.ndc"]) else "uniform",
+        "depth_range": [float(case["cfg.near"]), float(case["cfg.far"])],
+        "normalise_ray": bool(case["cfg.normalise_ray"]), "white_background": bool(case["cfg.white"]),
+        "use_ray_dir": True, "normal_loss": False, "outside_steps": 0, "n_max_network_queries": 64000,
+        "occ_activation": "softplus",
+    }
+
+
+def tensors(case):
+    t = {k[3:]: torch.from_numpy(case[k]) for k in case if k.startswith("in.")}
+    t.setdefault("jitter", None)
+    return t
+
+
+def run_oracle(case, weights=None):
+    """Returns (out, grads) from the oracle for a golden case (grads empty for eval cases)."""
+    weights = weights or case["weights"]
+    t = tensors(case)
+    cfg = render_cfg(case)
+    h, w, cam = int(case["cfg.h"]), int(case["cfg.w"]), int(case["cfg.cam"])
+    params = {k: v.clone().requires_grad_(True) for k, v in weights.items()}
+    leaves = {k: t[k].clone().requires_grad_(True) for k in ("pose_r", "pose_t", "scales", "shifts")}
+    if int(case["cfg.eval"]):
+        with torch.no_grad():
+            c2w = orc.pose_c2w(leaves["pose_r"][cam], leaves["pose_t"][cam])
+            sc, sh = orc.distortion(leaves["scales"], leaves["shifts"], cam, N_CAMS)
+            depth = orc.nearest_gather(t["depth_img"] * sc + sh, (h, w), t["ray_idx"])
+            out = orc.render(params, orc.pixel_grid(h, w)[:, t["ray_idx"]], depth, t["K"],
+                             torch.inverse(c2w).unsqueeze(0), torch.eye(4).unsqueeze(0), cfg, jitter=None, eval_=True)
+        return out, {}
+    loss, out = orc.train_step_scope(params, leaves["pose_r"], leaves["pose_t"], leaves["scales"], leaves["shifts"],
+                                     cam, t["K"], t["depth_img"], t["img"], (h, w), t["ray_idx"], t["jitter"], cfg)
+    loss.backward()
+    out["loss"] = loss.detach()
+    grads = {"w." + k: v.grad for k, v in params.items()}
+    grads.update({k: v.grad for k, v in leaves.items()})
+    return out, grads
+
+
+def golden_grads(case):
+    """name -> (kind, array): kind 'full' or 'sub' (strided subsample + L2 norm)."""
+    out = {}
+    for k in case:
+        if k.startswith("g."):
+            out[k[2:]] = ("full", case[k], None)
+        elif k.startswith("gsub."):
+            out[k[5:]] = ("sub", case[k], float(case["gnorm." + k[5:]]))
+    return out
+
+
+def compare_grad(name, got, kind, ref, norm, tol):
+    """Max-abs comparison after normalising by the golden tensor's max-abs when that exceeds 1
+    (SURVEY.md section 8d parity thresholds)."""
+    got = got.detach().cpu().double().numpy()
+    if kind == "sub":
+        stride = got.size // ref.size
+        got_cmp = got.reshape(-1)[::stride][: ref.size]
+        assert abs(np.linalg.norm(got) - norm) <= tol * max(1.0, norm) * 10, name
+    else:
+        got_cmp = got
+    ref = ref.astype(np.float64)
+    scale = max(1.0, np.abs(ref).max())
+    err = np.abs(got_cmp.reshape(ref.shape) - ref).max() / scale
+    assert err <= tol, f"{name}: {err:.3e} > {tol}"
+    return err
