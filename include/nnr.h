@@ -1,0 +1,134 @@
+/*
+ * nnr.h -- C ABI of libnnr.so: the MI355X (gfx950) native volumetric-rendering hot path of NoPe-NeRF.
+ *
+ * The reference (ActiveVisionLab/nope-nerf) is pure Python on PyTorch and has no FFI of its own;
+ * the drop-in boundary is the Python class surface `model.Renderer.nope_nerf`
+ * (reference model/rendering.py:36-167) and the MLP it calls, `model.OfficialStaticNerf.forward`
+ * (reference model/official_nerf.py:60-96).  This header is the C-ABI those two replace their bodies
+ * with: plain device pointers and sizes, no torch types, no C++ types, no exceptions.  The ctypes
+ * binding a maintainer adds on the reference side is shown in INTEGRATION.md and lives in
+ * nope-nerf_amd/nnr/lib.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, and
+ *     keeps no global state; all memory is owned and allocated by the caller;
+ *   - return value 0 == NNR_OK, negative == error (nnr_strerror gives the text);
+ *   - fp32 throughout; ray / sample indices are produced by the caller (torch.randperm / torch.rand
+ *     stay in the host framework so indices and jitter are bit-identical to the reference's).
+ */
+#ifndef NNR_H
+#define NNR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNR_ABI_VERSION 1
+
+/* error codes */
+#define NNR_OK 0
+#define NNR_E_BADCFG (-1)      /* inconsistent sizes / null pointer */
+#define NNR_E_UNSUPPORTED (-2) /* hidden width other than 128/256, encoding levels other than 10/4 ... */
+#define NNR_E_ALIGN (-3)       /* a pointer is not 16-byte aligned */
+#define NNR_E_HIP (-4)         /* a HIP runtime call failed (see nnr_last_hip_error) */
+
+/* flags (nnr_cfg.flags) -- each mirrors a key of the reference's `rendering:` / `model:` YAML section */
+#define NNR_F_DIST_ALPHA 1u /* rendering.dist_alpha   (model/rendering.py:121-128, official_nerf.py:82-83) */
+#define NNR_F_WHITE_BG 2u   /* rendering.white_background (model/rendering.py:145-147) */
+#define NNR_F_RELU_SIGMA 4u /* model.occ_activation != 'softplus' (model/official_nerf.py:77-80) */
+#define NNR_F_TRAIN 8u      /* keep what the backward needs (activation stash, ReLU masks) */
+
+/* Problem description.  POD, passed by pointer, read on the host only. */
+typedef struct nnr_cfg {
+    int32_t n_rays;    /* R: rays in this call                       (training.n_training_points) */
+    int32_t n_samples; /* N: samples per ray                         (rendering.num_points)       */
+    int32_t hidden;    /* D: MLP width, 128 or 256                   (model.hidden_dim)           */
+    uint32_t flags;    /* NNR_F_*                                                                 */
+} nnr_cfg;
+
+/* The 12 nn.Linear layers of OfficialStaticNerf in state_dict order (model/official_nerf.py:20-37):
+ * layers0.{0,2,4,6}, layers1.{0,2,4,6}, fc_density, fc_feature, rgb_layers.0, fc_rgb.
+ * weight[i] is (out,in) row-major exactly as nn.Linear stores it; bias[i] is (out). */
+#define NNR_N_LAYERS 12
+typedef struct nnr_params {
+    const float* weight[NNR_N_LAYERS];
+    const float* bias[NNR_N_LAYERS];
+} nnr_params;
+typedef struct nnr_param_grads { /* accumulated into (+=); caller zero-fills or passes .grad storage */
+    float* weight[NNR_N_LAYERS];
+    float* bias[NNR_N_LAYERS];
+} nnr_param_grads;
+
+int nnr_abi_version(void);
+const char* nnr_strerror(int code);
+int nnr_last_hip_error(void); /* hipError_t of the most recent NNR_E_HIP on this thread */
+
+/* --- sizes (host-side, no GPU work) ------------------------------------------------------------- */
+/* floats in the packed-weight buffer (MFMA-fragment order, forward + transposed copies + biases) */
+size_t nnr_packed_floats(const nnr_cfg* cfg);
+/* floats of scratch the forward(+backward, if NNR_F_TRAIN) needs; contents are opaque except via nnr_ws_plane */
+size_t nnr_workspace_floats(const nnr_cfg* cfg);
+/* bytes of the weight-gradient work plan (a table of wave jobs); build on the host, upload once per cfg */
+size_t nnr_plan_bytes(const nnr_cfg* cfg);
+int nnr_plan_build(const nnr_cfg* cfg, void* plan_host);
+
+/* --- weights ------------------------------------------------------------------------------------ */
+/* Re-pack the nn.Linear tensors into fragment order.  Call after every optimiser step (one launch).
+ * Replaces nothing in the reference: it is the layout change that lets the MLP read 1 KiB coalesced
+ * fragments instead of (out,in) rows.  `packed` must be 16-byte aligned. */
+int nnr_pack_weights(const nnr_cfg* cfg, const nnr_params* params_host, float* packed, void* stream);
+
+/* --- forward ------------------------------------------------------------------------------------
+ * Replaces the body of Renderer.nope_nerf from sampling to compositing (model/rendering.py:95-132,
+ * 145-147) and OfficialStaticNerf.forward (model/official_nerf.py:60-96) it calls in 64 000-sample chunks.
+ *   pts_o, pts_d : (R,3) sampling origin / direction of each ray: world-space (o, d_hat) for
+ *                  sample_option 'uniform', the NDC-warped (o', d') for 'ndc'   (rendering.py:170-178,191-192)
+ *   view_d       : (R,3) direction fed to the colour branch (= -d_hat, rendering.py:177-178,194-195)
+ *   z_lo, z_hi   : (N) per-sample interval; z = z_lo + (z_hi - z_lo) * u  (rendering.py:184-190)
+ *   jitter       : (R,N) u in [0,1) or NULL (z = z_lo)                    (torch.rand at rendering.py:189)
+ * outputs
+ *   rgb (R,3), dist (R) = sum w*z (rendering.py:131-132); opt_alpha (R,N) and opt_z (R,N) may be NULL.
+ */
+int nnr_render_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, const float* view_d,
+                   const float* z_lo, const float* z_hi, const float* jitter, const float* packed,
+                   float* rgb, float* dist, float* opt_alpha, float* opt_z, float* workspace, void* stream);
+
+/* --- backward -----------------------------------------------------------------------------------
+ * Replaces autograd through the same region (loss.backward(), model/training.py:89).  Must follow an
+ * nnr_render_fwd with NNR_F_TRAIN on the same workspace.  d_rgb (R,3), d_dist (R) are the upstream
+ * gradients from the loss heads (model/losses.py:27-32,59-64).  Gradients w.r.t. the 24 parameter
+ * tensors are ACCUMULATED into `grads`; d_pts_o/d_pts_d/d_view (R,3) are overwritten.  `plan` is the
+ * device copy of nnr_plan_build's table. */
+int nnr_render_bwd(const nnr_cfg* cfg, const float* packed, const float* d_rgb, const float* d_dist,
+                   const nnr_param_grads* grads_host, float* d_pts_o, float* d_pts_d, float* d_view,
+                   const void* plan, float* workspace, void* stream);
+
+/* --- introspection for parity tests ---------------------------------------------------------------
+ * Offset (in floats) and row pitch of a workspace plane; returns <0 for an unknown plane.
+ * Planes: 0 sample outputs (S,4: rgb, sigma_raw)   1 z (S)   2 d(sample outputs) (S,4)
+ *         3 d(point) (S,4)  4 d(view) (S,4)   10 posenc (S,64)   11..18 hidden activations 1..8 (S,D)
+ *         19 [feature|direnc] (S,D+32)   20 colour hidden (S,D/2)
+ *         31..38 d(pre-activation) of hidden 1..8 (S,D)   39 d(feature) (S,D)   40 d(colour hidden) (S,D/2) */
+int64_t nnr_ws_plane(const nnr_cfg* cfg, int plane, int32_t* pitch_out);
+
+/* Individual stages, exported for profiling and bench.py's per-kernel roofline timing.  Same arguments
+ * and workspace contract as the fused entry points above. */
+int nnr_mlp_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, const float* view_d,
+                const float* z_lo, const float* z_hi, const float* jitter, const float* packed,
+                float* workspace, void* stream);
+int nnr_composite_fwd(const nnr_cfg* cfg, float* rgb, float* dist, float* opt_alpha, float* opt_z,
+                      float* workspace, void* stream);
+int nnr_composite_bwd(const nnr_cfg* cfg, const float* d_rgb, const float* d_dist, float* workspace, void* stream);
+int nnr_mlp_dgrad(const nnr_cfg* cfg, const float* packed, float* workspace, void* stream);
+int nnr_mlp_wgrad(const nnr_cfg* cfg, const nnr_param_grads* grads_host, const void* plan, float* workspace,
+                  void* stream);
+int nnr_ray_reduce(const nnr_cfg* cfg, float* d_pts_o, float* d_pts_d, float* d_view, float* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNR_H */

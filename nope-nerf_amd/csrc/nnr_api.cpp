@@ -1,0 +1,346 @@
+// nnr_api.cpp -- the extern "C" surface of libnnr.so (include/nnr.h): argument checking, workspace carving, the
+// weight-gradient plan, and kernel sequencing.  No global state; every call is asynchronous on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../include/nnr.h"
+#include "nnr_kernels.h"
+#include "nnr_layout.h"
+
+using namespace nnr;
+
+namespace {
+
+thread_local int g_last_hip = 0;
+
+int hip_fail(hipError_t e) {
+    g_last_hip = (int)e;
+    return NNR_E_HIP;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_cfg(const nnr_cfg* c) {
+    if (!c || c->n_rays <= 0 || c->n_samples <= 0) return NNR_E_BADCFG;
+    if (c->hidden != 128 && c->hidden != 256) return NNR_E_UNSUPPORTED;
+    if ((c->flags & NNR_F_TRAIN) && c->n_samples > 1024) return NNR_E_UNSUPPORTED;
+    return NNR_OK;
+}
+
+WsLayout ws_layout(const nnr_cfg* c) {
+    WsLayout w;
+    w.S = (int64_t)c->n_rays * c->n_samples;
+    w.S_pad = (w.S + kBlockSamples - 1) / kBlockSamples * kBlockSamples;
+    w.D = c->hidden;
+    w.train = (c->flags & NNR_F_TRAIN) != 0;
+    return w;
+}
+
+int64_t plane(const WsLayout& w, int id) {
+    int pitch;
+    return w.plane(id, &pitch);
+}
+
+size_t packed_floats(int D) { return D == 256 ? (size_t)Layout<256>::packed_floats : (size_t)Layout<128>::packed_floats; }
+
+// ---- weight-gradient plan -------------------------------------------------------------------------------------------
+struct Unit {  // a wave tile before the split over samples
+    WgradJob j;
+    int group;  // units of one group share operands: same-k jobs are placed in one workgroup
+};
+
+std::vector<Unit> wgrad_units(int D) {
+    std::vector<Unit> u;
+    const int nb = D / 128;  // 128-wide blocks per D
+    int group = 0;
+    auto add = [&](int layer, int MI, int NI, int dpl, int dcol, int dvalid, int xpl, int xcol, int xvalid, int row0, int wcol0,
+                   int rows_real, int cols_real, int ldw, int bias) {
+        Unit x{};
+        x.j = WgradJob{layer, MI, NI, dpl, dcol, dvalid, xpl, xcol, xvalid, row0, wcol0, rows_real, cols_real, ldw, 0, 0, bias};
+        x.group = group;
+        u.push_back(x);
+    };
+    // D x D layers: hidden 2,3,4,6,7,8 (params 1,2,3,5,6,7) and the h-part of hidden 5 (param 4), feature (param 9)
+    auto dxd = [&](int layer, int dpl, int xpl, int ldw, int cols_real) {
+        for (int a = 0; a < nb; ++a)
+            for (int b = 0; b < nb; ++b)
+                add(layer, 4, 4, dpl, 128 * a, D - 128 * a, xpl, 128 * b, D - 128 * b, 128 * a, 128 * b, D, cols_real, ldw, b == 0);
+        ++group;
+    };
+    // posenc-input parts: hidden 1 (param 0) and the e-part of hidden 5 (param 4, columns D..D+62)
+    auto dxe = [&](int layer, int dpl, int wcol0, int ldw, int cols_real, int bias) {
+        for (int a = 0; a < nb; ++a)
+            add(layer, 4, 2, dpl, 128 * a, D - 128 * a, P_XE, 0, kPosPad, 128 * a, wcol0, D, cols_real, ldw, bias);
+        ++group;
+    };
+    dxe(0, P_DH1 + 0, 0, kPosReal, kPosReal, 1);
+    dxd(1, P_DH1 + 1, P_XH1 + 0, D, D);
+    dxd(2, P_DH1 + 2, P_XH1 + 1, D, D);
+    dxd(3, P_DH1 + 3, P_XH1 + 2, D, D);
+    dxd(4, P_DH1 + 4, P_XH1 + 3, D + kPosReal, D + kPosReal);
+    dxe(4, P_DH1 + 4, D, D + kPosReal, D + kPosReal, 0);
+    dxd(5, P_DH1 + 5, P_XH1 + 4, D, D);
+    dxd(6, P_DH1 + 6, P_XH1 + 5, D, D);
+    dxd(7, P_DH1 + 7, P_XH1 + 6, D, D);
+    dxd(9, P_DF, P_XH1 + 7, D, D);
+    // density head (param 8): 1 x D, gradient operand = column 3 of the per-sample output gradients
+    for (int b = 0; b < nb; ++b) add(8, 1, 4, P_DOUT4, 3, 1, P_XH1 + 7, 128 * b, D - 128 * b, 0, 128 * b, 1, D, D, b == 0);
+    ++group;
+    // colour hidden (param 10): D/2 x (D + 27)
+    const int mi_g = D == 256 ? 4 : 2;
+    for (int b = 0; b < nb; ++b)
+        add(10, mi_g, 4, P_DG, 0, D / 2, P_XF, 128 * b, D - 128 * b, 0, 128 * b, D / 2, D + kDirReal, D + kDirReal, b == 0);
+    add(10, mi_g, 1, P_DG, 0, D / 2, P_XF, D, kDirPad, 0, D, D / 2, D + kDirReal, D + kDirReal, 0);
+    ++group;
+    // rgb (param 11): 3 x D/2, gradient operand = columns 0..2 of the per-sample output gradients
+    add(11, 1, D == 256 ? 4 : 2, P_DOUT4, 0, 3, P_XG, 0, D / 2, 0, 0, 3, D / 2, D / 2, 1);
+    ++group;
+    return u;
+}
+
+constexpr int kTargetWaves = 1024;  // 256 CUs x 4 SIMDs, one 256-accumulator wave each
+constexpr int kGranule = 8;         // samples per pipeline stage of the wgrad kernel (2 * kU)
+
+std::vector<WgradJob> build_plan(const nnr_cfg* c) {
+    const WsLayout w = ws_layout(c);
+    std::vector<Unit> units = wgrad_units(c->hidden);
+    int64_t cost = 0;
+    for (auto& u : units) cost += u.j.MI * u.j.NI;
+    const int64_t granules = w.S_pad / kGranule;
+    std::vector<WgradJob> jobs;
+    size_t i = 0;
+    while (i < units.size()) {
+        size_t e = i;
+        while (e < units.size() && units[e].group == units[i].group) ++e;
+        // every unit of a group has the same cost by construction except the colour-hidden tail; split by the first
+        int64_t q = std::max<int64_t>(1, (units[i].j.MI * units[i].j.NI * (int64_t)kTargetWaves + cost / 2) / cost);
+        q = std::min(q, granules);
+        if ((e - i) == 4)  // a 4-tile group starts on a workgroup boundary: its same-range tiles share L1/L2
+            while (jobs.size() % 4 != 0) {
+                WgradJob idle{};
+                idle.layer = -1;
+                jobs.push_back(idle);
+            }
+        for (int64_t s = 0; s < q; ++s) {
+            const int64_t g0 = granules * s / q, g1 = granules * (s + 1) / q;
+            for (size_t t = i; t < e; ++t) {
+                WgradJob j = units[t].j;
+                j.k0 = (int32_t)(g0 * kGranule);
+                j.k1 = (int32_t)(g1 * kGranule);
+                if (j.k1 > j.k0) jobs.push_back(j);
+            }
+        }
+        i = e;
+    }
+    while (jobs.size() % 4 != 0) {
+        WgradJob idle{};
+        idle.layer = -1;
+        jobs.push_back(idle);
+    }
+    return jobs;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nnr_abi_version(void) { return NNR_ABI_VERSION; }
+
+const char* nnr_strerror(int code) {
+    switch (code) {
+        case NNR_OK: return "ok";
+        case NNR_E_BADCFG: return "bad configuration or null pointer";
+        case NNR_E_UNSUPPORTED: return "unsupported configuration (hidden must be 128 or 256; N <= 1024 when training)";
+        case NNR_E_ALIGN: return "pointer not 16-byte aligned";
+        case NNR_E_HIP: return "HIP runtime error";
+        default: return "unknown error";
+    }
+}
+
+int nnr_last_hip_error(void) { return g_last_hip; }
+
+size_t nnr_packed_floats(const nnr_cfg* cfg) {
+    if (check_cfg(cfg) != NNR_OK) return 0;
+    return packed_floats(cfg->hidden);
+}
+
+size_t nnr_workspace_floats(const nnr_cfg* cfg) {
+    if (check_cfg(cfg) != NNR_OK) return 0;
+    return (size_t)ws_layout(cfg).total();
+}
+
+int64_t nnr_ws_plane(const nnr_cfg* cfg, int pl, int32_t* pitch_out) {
+    if (check_cfg(cfg) != NNR_OK) return -1;
+    int pitch = 0;
+    const int64_t o = ws_layout(cfg).plane(pl, &pitch);
+    if (pitch_out) *pitch_out = pitch;
+    return pl < 0 ? -1 : o;
+}
+
+size_t nnr_plan_bytes(const nnr_cfg* cfg) {
+    if (check_cfg(cfg) != NNR_OK) return 0;
+    return build_plan(cfg).size() * sizeof(WgradJob);
+}
+
+int nnr_plan_build(const nnr_cfg* cfg, void* plan_host) {
+    int rc = check_cfg(cfg);
+    if (rc != NNR_OK) return rc;
+    if (!plan_host) return NNR_E_BADCFG;
+    const std::vector<WgradJob> jobs = build_plan(cfg);
+    std::memcpy(plan_host, jobs.data(), jobs.size() * sizeof(WgradJob));
+    return NNR_OK;
+}
+
+int nnr_pack_weights(const nnr_cfg* cfg, const nnr_params* p, float* packed, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != NNR_OK) return rc;
+    if (!p || !packed) return NNR_E_BADCFG;
+    if (!aligned16(packed)) return NNR_E_ALIGN;
+    PackArgs a;
+    for (int i = 0; i < 12; ++i) {
+        if (!p->weight[i] || !p->bias[i]) return NNR_E_BADCFG;
+        a.w[i] = p->weight[i];
+        a.b[i] = p->bias[i];
+    }
+    a.packed = packed;
+    hipError_t e = launch_pack(cfg->hidden, a, (hipStream_t)stream);
+    return e == hipSuccess ? NNR_OK : hip_fail(e);
+}
+
+int nnr_mlp_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, const float* view_d, const float* z_lo,
+                const float* z_hi, const float* jitter, const float* packed, float* ws, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != NNR_OK) return rc;
+    if (!pts_o || !pts_d || !view_d || !z_lo || !z_hi || !packed || !ws) return NNR_E_BADCFG;
+    if (!aligned16(packed) || !aligned16(ws)) return NNR_E_ALIGN;
+    const WsLayout w = ws_layout(cfg);
+    MlpFwdArgs a{};
+    a.pts_o = pts_o; a.pts_d = pts_d; a.view_d = view_d; a.z_lo = z_lo; a.z_hi = z_hi; a.jitter = jitter;
+    a.packed = packed;
+    a.ws_out4 = ws + plane(w, P_OUT4);
+    a.ws_z = ws + plane(w, P_Z);
+    if (w.train) {
+        a.ws_xe = ws + plane(w, P_XE);
+        a.ws_xh = ws + plane(w, P_XH1);
+        a.ws_xf = ws + plane(w, P_XF);
+        a.ws_xg = ws + plane(w, P_XG);
+        a.ws_mask = reinterpret_cast<uint32_t*>(ws + plane(w, P_MASK));
+    }
+    a.S = w.S; a.S_pad = w.S_pad; a.N = cfg->n_samples;
+    hipError_t e = launch_mlp_fwd(cfg->hidden, a, w.train, (hipStream_t)stream);
+    return e == hipSuccess ? NNR_OK : hip_fail(e);
+}
+
+int nnr_composite_fwd(const nnr_cfg* cfg, float* rgb, float* dist, float* opt_alpha, float* opt_z, float* ws, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != NNR_OK) return rc;
+    if (!rgb || !dist || !ws) return NNR_E_BADCFG;
+    const WsLayout w = ws_layout(cfg);
+    CompositeArgs a{};
+    a.ws_out4 = ws + plane(w, P_OUT4);
+    a.ws_z = ws + plane(w, P_Z);
+    a.rgb = rgb; a.dist = dist; a.opt_alpha = opt_alpha; a.opt_z = opt_z;
+    a.R = cfg->n_rays; a.N = cfg->n_samples; a.flags = cfg->flags;
+    hipError_t e = launch_composite_fwd(a, (hipStream_t)stream);
+    return e == hipSuccess ? NNR_OK : hip_fail(e);
+}
+
+int nnr_render_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, const float* view_d, const float* z_lo,
+                   const float* z_hi, const float* jitter, const float* packed, float* rgb, float* dist, float* opt_alpha,
+                   float* opt_z, float* ws, void* stream) {
+    int rc = nnr_mlp_fwd(cfg, pts_o, pts_d, view_d, z_lo, z_hi, jitter, packed, ws, stream);
+    if (rc != NNR_OK) return rc;
+    return nnr_composite_fwd(cfg, rgb, dist, opt_alpha, opt_z, ws, stream);
+}
+
+int nnr_composite_bwd(const nnr_cfg* cfg, const float* d_rgb, const float* d_dist, float* ws, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != NNR_OK) return rc;
+    if (!(cfg->flags & NNR_F_TRAIN) || !d_rgb || !d_dist || !ws) return NNR_E_BADCFG;
+    const WsLayout w = ws_layout(cfg);
+    CompositeArgs a{};
+    a.ws_out4 = ws + plane(w, P_OUT4);
+    a.ws_z = ws + plane(w, P_Z);
+    a.ws_dout4 = ws + plane(w, P_DOUT4);
+    a.d_rgb = d_rgb; a.d_dist = d_dist;
+    a.R = cfg->n_rays; a.N = cfg->n_samples; a.flags = cfg->flags;
+    hipError_t e = launch_composite_bwd(a, (hipStream_t)stream);
+    return e == hipSuccess ? NNR_OK : hip_fail(e);
+}
+
+int nnr_mlp_dgrad(const nnr_cfg* cfg, const float* packed, float* ws, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != NNR_OK) return rc;
+    if (!(cfg->flags & NNR_F_TRAIN) || !packed || !ws) return NNR_E_BADCFG;
+    if (!aligned16(packed) || !aligned16(ws)) return NNR_E_ALIGN;
+    const WsLayout w = ws_layout(cfg);
+    MlpDgradArgs a{};
+    a.packed = packed;
+    a.ws_dout4 = ws + plane(w, P_DOUT4);
+    a.ws_xe = ws + plane(w, P_XE);
+    a.ws_xf = ws + plane(w, P_XF);
+    a.ws_mask = reinterpret_cast<const uint32_t*>(ws + plane(w, P_MASK));
+    a.ws_dh = ws + plane(w, P_DH1);
+    a.ws_df = ws + plane(w, P_DF);
+    a.ws_dg = ws + plane(w, P_DG);
+    a.ws_dpts = ws + plane(w, P_DPTS);
+    a.ws_dview = ws + plane(w, P_DVIEW);
+    a.S = w.S; a.S_pad = w.S_pad;
+    hipError_t e = launch_mlp_dgrad(cfg->hidden, a, (hipStream_t)stream);
+    return e == hipSuccess ? NNR_OK : hip_fail(e);
+}
+
+int nnr_mlp_wgrad(const nnr_cfg* cfg, const nnr_param_grads* g, const void* plan, float* ws, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != NNR_OK) return rc;
+    if (!(cfg->flags & NNR_F_TRAIN) || !g || !plan || !ws) return NNR_E_BADCFG;
+    const WsLayout w = ws_layout(cfg);
+    WgradArgs a{};
+    for (int i = 0; i < 12; ++i) {
+        if (!g->weight[i] || !g->bias[i]) return NNR_E_BADCFG;
+        a.gw[i] = g->weight[i];
+        a.gb[i] = g->bias[i];
+    }
+    a.jobs = static_cast<const WgradJob*>(plan);
+    a.ws = ws;
+    for (int p = 0; p < 48; ++p) {
+        int pitch = 0;
+        a.plane_off[p] = w.plane(p, &pitch);
+        a.plane_pitch[p] = pitch;
+    }
+    a.n_jobs = (int)(nnr_plan_bytes(cfg) / sizeof(WgradJob));
+    hipError_t e = launch_wgrad(a, (hipStream_t)stream);
+    return e == hipSuccess ? NNR_OK : hip_fail(e);
+}
+
+int nnr_ray_reduce(const nnr_cfg* cfg, float* d_pts_o, float* d_pts_d, float* d_view, float* ws, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != NNR_OK) return rc;
+    if (!(cfg->flags & NNR_F_TRAIN) || !d_pts_o || !d_pts_d || !d_view || !ws) return NNR_E_BADCFG;
+    const WsLayout w = ws_layout(cfg);
+    RayReduceArgs a{};
+    a.ws_dpts = ws + plane(w, P_DPTS);
+    a.ws_dview = ws + plane(w, P_DVIEW);
+    a.ws_z = ws + plane(w, P_Z);
+    a.d_pts_o = d_pts_o; a.d_pts_d = d_pts_d; a.d_view = d_view;
+    a.R = cfg->n_rays; a.N = cfg->n_samples;
+    hipError_t e = launch_ray_reduce(a, (hipStream_t)stream);
+    return e == hipSuccess ? NNR_OK : hip_fail(e);
+}
+
+int nnr_render_bwd(const nnr_cfg* cfg, const float* packed, const float* d_rgb, const float* d_dist,
+                   const nnr_param_grads* grads, float* d_pts_o, float* d_pts_d, float* d_view, const void* plan, float* ws,
+                   void* stream) {
+    int rc = nnr_composite_bwd(cfg, d_rgb, d_dist, ws, stream);
+    if (rc != NNR_OK) return rc;
+    rc = nnr_mlp_dgrad(cfg, packed, ws, stream);
+    if (rc != NNR_OK) return rc;
+    rc = nnr_mlp_wgrad(cfg, grads, plan, ws, stream);
+    if (rc != NNR_OK) return rc;
+    return nnr_ray_reduce(cfg, d_pts_o, d_pts_d, d_view, ws, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+// nnr_layout.h -- data layout shared by every kernel and by the host-side planners.
+//
+// Register ("fragment") layout of a feature vector, used for every activation / gradient that lives in
+// VGPRs between MFMA layers.  A wave owns a chunk of 32 samples.  Lane l = (half h = l>>5, sample
+// column c = l&31).  A vector of 32*T features of sample c is held in 16*T registers; register
+// r = 16*t + rho (tile t, rho in [0,16)) holds feature
+//        f(r,h) = 32*t + (rho&3) + 8*(rho>>2) + 4*h
+// which is exactly the C/D layout of v_mfma_f32_32x32x2_f32 (row = (rho&3)+8*(rho>>2)+4*(lane>>5),
+// col = lane&31) when the layer is computed transposed:  out^T[feature][sample] = W[feature][k] * in^T[k][sample].
+// Because B[k][col] of that instruction is "lane l holds k = l>>5", register r of the *previous* layer's output is
+// directly the B operand of two k-values (one per half) -- activations never leave registers between layers.
+// Four consecutive registers r = 4g..4g+3 hold features 8g+4h+{0,1,2,3}: four consecutive k.
+//
+// Packed weights ("A fragments"): for a layer part with A[Mp=32*MT][Kp=32*KT] the fragment (g, mt), g in [0,4*KT),
+// is 64 lanes x 4 floats = 1 KiB, lane l holding A[32*mt + (l&31)][8*g + 4*(l>>5) + i], i = 0..3, and fragments are
+// stored in consumption order  index = g*MT + mt.  A wave's 16-byte-per-lane load of one fragment is one contiguous
+// 1 KiB read and feeds 4 MFMAs.
+#pragma once
+#include <stdint.h>
+
+#ifndef __HIPCC__
+#define NNR_HD
+#else
+#define NNR_HD __host__ __device__
+#endif
+
+namespace nnr {
+
+constexpr int kChunk = 32;         // samples per wave
+constexpr int kWavesPerBlock = 4;  // one wave per SIMD
+constexpr int kBlockSamples = kChunk * kWavesPerBlock;
+constexpr int kPosLevels = 10, kDirLevels = 4;  // hard-wired in the reference (model/official_nerf.py:61,87)
+constexpr int kPosReal = 63, kDirReal = 27;     // (2L+1)*3
+constexpr int kPosPad = 64, kDirPad = 32;
+
+// ---- packed weight buffer -------------------------------------------------------------------------------------
+// Forward parts in stream order, backward (transposed) parts in stream order, then padded biases.
+enum FwdPart { F_L1 = 0, F_L2, F_L3, F_L4, F_L5H, F_L5E, F_L6, F_L7, F_L8, F_SIG, F_FEAT, F_RGBH_F, F_RGBH_D, F_RGB, F_NPARTS };
+enum BwdPart { B_RGB = 0, B_RGBH, B_FEAT, B_SIG, B_L8, B_L7, B_L6, B_L5, B_L4, B_L3, B_L2, B_L1, B_NPARTS };
+
+struct PartDesc {
+    int layer;      // index into nnr_params (state_dict order)
+    int transpose;  // 0: A[m][k] = W[m][koff+k]   1: A[m][k] = W[k][moff+m]
+    int KT, MT;     // tiles of 32 along k and m
+    int m_real, k_real;  // valid rows / cols of A (rest is zero padding)
+    int off;        // column offset into W's in-dimension (koff or moff)
+    int ld;         // W row pitch (= in_features)
+};
+
+NNR_HD constexpr int part_floats(int KT, int MT) { return 4 * KT * MT * 256; }
+
+template <int D>
+struct Layout {
+    static constexpr int DT = D / 32;
+    static constexpr int HT = D / 64;  // colour-hidden tiles (D/2 wide)
+    static_assert(D == 128 || D == 256, "hidden width must be 128 or 256");
+
+    NNR_HD static constexpr PartDesc fwd(int p) {
+        switch (p) {
+            case F_L1: return {0, 0, 2, DT, D, kPosReal, 0, kPosReal};
+            case F_L2: return {1, 0, DT, DT, D, D, 0, D};
+            case F_L3: return {2, 0, DT, DT, D, D, 0, D};
+            case F_L4: return {3, 0, DT, DT, D, D, 0, D};
+            case F_L5H: return {4, 0, DT, DT, D, D, 0, D + kPosReal};
+            case F_L5E: return {4, 0, 2, DT, D, kPosReal, D, D + kPosReal};
+            case F_L6: return {5, 0, DT, DT, D, D, 0, D};
+            case F_L7: return {6, 0, DT, DT, D, D, 0, D};
+            case F_L8: return {7, 0, DT, DT, D, D, 0, D};
+            case F_SIG: return {8, 0, DT, 1, 1, D, 0, D};
+            case F_FEAT: return {9, 0, DT, DT, D, D, 0, D};
+            case F_RGBH_F: return {10, 0, DT, HT, D / 2, D, 0, D + kDirReal};
+            case F_RGBH_D: return {10, 0, 1, HT, D / 2, kDirReal, D, D + kDirReal};
+            default: return {11, 0, HT, 1, 3, D / 2, 0, D / 2};
+        }
+    }
+    NNR_HD static constexpr PartDesc bwd(int p) {
+        switch (p) {
+            case B_RGB: return {11, 1, 1, HT, D / 2, 3, 0, D / 2};
+            case B_RGBH: return {10, 1, HT, DT + 1, D + kDirReal, D / 2, 0, D + kDirReal};
+            case B_FEAT: return {9, 1, DT, DT, D, D, 0, D};
+            case B_SIG: return {8, 1, 1, DT, D, 1, 0, D};
+            case B_L8: return {7, 1, DT, DT, D, D, 0, D};
+            case B_L7: return {6, 1, DT, DT, D, D, 0, D};
+            case B_L6: return {5, 1, DT, DT, D, D, 0, D};
+            case B_L5: return {4, 1, DT, DT + 2, D + kPosReal, D, 0, D + kPosReal};
+            case B_L4: return {3, 1, DT, DT, D, D, 0, D};
+            case B_L3: return {2, 1, DT, DT, D, D, 0, D};
+            case B_L2: return {1, 1, DT, DT, D, D, 0, D};
+            default: return {0, 1, DT, 2, kPosReal, D, 0, kPosReal};
+        }
+    }
+    NNR_HD static constexpr int fwd_off(int p) {
+        int o = 0;
+        for (int i = 0; i < p; ++i) o += part_floats(fwd(i).KT, fwd(i).MT);
+        return o;
+    }
+    NNR_HD static constexpr int bwd_off(int p) {
+        int o = fwd_off(F_NPARTS);
+        for (int i = 0; i < p; ++i) o += part_floats(bwd(i).KT, bwd(i).MT);
+        return o;
+    }
+    // biases, each padded to a multiple of 32 floats: hidden 1..8, sigma, feature, colour hidden, rgb
+    static constexpr int bias_base = bwd_off(B_NPARTS);
+    NNR_HD static constexpr int bias_off(int layer) {  // layer in state_dict order
+        int o = bias_base;
+        for (int i = 0; i < layer; ++i) o += bias_pad(i);
+        return o;
+    }
+    NNR_HD static constexpr int bias_pad(int layer) { return layer == 8 || layer == 11 ? 32 : (layer == 10 ? (D / 2 + 31) / 32 * 32 : D); }
+    NNR_HD static constexpr int bias_real(int layer) { return layer == 8 ? 1 : layer == 11 ? 3 : layer == 10 ? D / 2 : D; }
+    static constexpr int packed_floats = bias_off(12);
+
+    // ---- workspace planes (floats), S_pad = samples rounded up to a multiple of kBlockSamples ----
+    static constexpr int x_width = kPosPad + 8 * D + (D + kDirPad) + D / 2;  // per-sample activation stash
+    static constexpr int d_width = 8 * D + D + D / 2;                       // per-sample gradient stash
+    static constexpr int mask_words = DT / 2;                                // uint32 per lane per masked layer
+    static constexpr int n_mask_layers = 9;                                  // hidden 1..8 + colour hidden
+};
+
+// workspace plane ids (nnr_ws_plane)
+enum Plane {
+    P_OUT4 = 0, P_Z = 1, P_DOUT4 = 2, P_DPTS = 3, P_DVIEW = 4,
+    P_XE = 10, P_XH1 = 11, /* .. P_XH8 = 18 */ P_XF = 19, P_XG = 20,
+    P_MASK = 25,
+    P_DH1 = 31, /* .. P_DH8 = 38 */ P_DF = 39, P_DG = 40,
+};
+
+struct WsLayout {
+    int64_t S, S_pad;
+    int D;
+    bool train;
+    NNR_HD int64_t plane(int p, int* pitch) const {
+        int64_t o = 0;
+        int w = 0;
+        auto step = [&](int id, int width) -> bool {
+            if (id == p) { w = width; return true; }
+            o += S_pad * (int64_t)width;
+            return false;
+        };
+        if (step(P_OUT4, 4) || step(P_Z, 1)) { *pitch = w; return o; }
+        if (!train) return -1;
+        if (step(P_DOUT4, 4) || step(P_DPTS, 4) || step(P_DVIEW, 4) || step(P_XE, kPosPad)) { *pitch = w; return o; }
+        for (int l = 0; l < 8; ++l)
+            if (step(P_XH1 + l, D)) { *pitch = w; return o; }
+        if (step(P_XF, D + kDirPad) || step(P_XG, D / 2)) { *pitch = w; return o; }
+        // masks: [S_pad/32 chunks][9 layers][64 lanes][D/64 words]  == S_pad * 9 * 2 * (D/64) / ... words per sample: 9*2*(D/64)
+        if (step(P_MASK, 9 * 2 * (D / 64))) { *pitch = w; return o; }
+        for (int l = 0; l < 8; ++l)
+            if (step(P_DH1 + l, D)) { *pitch = w; return o; }
+        if (step(P_DF, D) || step(P_DG, D / 2)) { *pitch = w; return o; }
+        if (p == -1) { *pitch = 0; return o; }  // total
+        return -1;
+    }
+    NNR_HD int64_t total() const {
+        int pitch;
+        if (!train) {
+            return S_pad * 5;
+        }
+        return plane(-1, &pitch);
+    }
+};
+
+// ---- weight-gradient plan: one entry per wave job ---------------------------------------------------------------
+// dW[layer][row0 + MI*m + i][wcol0 + NI*n + j] += sum_{s in [k0,k1)} Dlt[s][dcol0 + MI*m + i] * X[s][xcol0 + NI*n + j]
+// (m, n in [0,32), i < MI, j < NI): a wave tile of 32*MI rows x 32*NI cols with interleaved sub-tiles, so one
+// MI-wide and one NI-wide vector load per lane feed MI*NI MFMAs.
+struct WgradJob {
+    int32_t layer;           // parameter index (state_dict order), -1 = idle wave
+    int32_t MI, NI;          // 1, 2 or 4
+    int32_t d_plane, d_col0, d_valid;  // gradient operand: workspace plane id, first column, valid columns from d_col0
+    int32_t x_plane, x_col0, x_valid;  // activation operand
+    int32_t row0, wcol0;     // destination offsets in W (rows = out features, cols = in features)
+    int32_t rows_real, cols_real, ldw;  // bounds and pitch of W
+    int32_t k0, k1;          // sample range (multiples of 8)
+    int32_t bias;            // 1: this job also reduces d(bias)[row] = sum_s Dlt[s][row]
+};
+
+}  // namespace nnr

@@ -1,0 +1,197 @@
+// nnr_mlp_dgrad.hip -- fused input-gradient chain of the NeRF MLP for gfx950.
+// Replaces autograd's AddmmBackward/ReluBackward/SigmoidBackward/... chain through model/official_nerf.py:60-96 for
+// the *data* path: from d(rgb_pre), d(sigma_raw) per sample down to d(point), d(view dir), leaving every layer's
+// pre-activation gradient in the workspace for the weight-gradient kernel.  Same structure as the forward: one wave =
+// 32 samples, gradients stay in VGPRs between layers as MFMA B operands, A fragments are the transposed packed weights.
+// ReLU masks come from the 1-bit-per-activation stash written by the forward (32x less traffic than re-reading h).
+#include "nnr_device.h"
+#include "nnr_kernels.h"
+
+namespace nnr {
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
+    using L = Layout<D>;
+    constexpr int DT = L::DT, HT = L::HT;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const int64_t s = (int64_t)blockIdx.x * kBlockSamples + wave * kChunk + col;
+    const bool live = s < a.S;  // padded samples carry zero gradients so they add nothing to the weight gradients
+
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed) + lane;
+    auto frag = [&](int part) { return wp + L::bwd_off(part) / 4; };
+    const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t* mask_base = a.ws_mask + ((chunk * L::n_mask_layers) * 64 + lane) * L::mask_words;
+
+    f32x4 dout = {0.f, 0.f, 0.f, 0.f};
+    if (live) dout = *reinterpret_cast<const f32x4*>(a.ws_dout4 + 4 * s);
+
+    // ---- colour branch ----
+    // d rgb_pre (3, padded to one 32-row tile): rows 0..2 = registers 0..2 of half 0
+    float drgb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) drgb[r] = 0.f;
+    drgb[0] = half == 0 ? dout[0] : 0.f;
+    drgb[1] = half == 0 ? dout[1] : 0.f;
+    drgb[2] = half == 0 ? dout[2] : 0.f;
+    float dg[16 * HT];
+    {
+        f32x16 acc[HT];
+        zero_acc(acc);
+        gemm_part<1, HT>(acc, drgb, frag(B_RGB));
+        uint32_t mw[L::mask_words];
+        const uint32_t* m = mask_base + (int64_t)8 * 64 * L::mask_words;
+#pragma unroll
+        for (int w = 0; w < L::mask_words; ++w) mw[w] = m[w];
+        float* o = a.ws_dg + s * (D / 2) + 4 * half;
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 16 * t + 4 * q + i;
+                    const float x = ((mw[r >> 5] >> (r & 31)) & 1u) ? acc[t][4 * q + i] : 0.f;
+                    dg[r] = x;
+                    v[i] = x;
+                }
+                *reinterpret_cast<f32x4*>(o + 32 * t + 8 * q) = v;
+            }
+    }
+    float d[16 * DT];  // current D-wide gradient (d feature, then d pre-activation of hidden 8..1)
+    {
+        f32x16 acc[DT + 1];
+        zero_acc(acc);
+        gemm_part<HT, DT + 1>(acc, dg, frag(B_RGBH));
+        float* o = a.ws_df + s * D + 4 * half;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[t][4 * q + i];
+                    d[16 * t + 4 * q + i] = v[i];
+                }
+                *reinterpret_cast<f32x4*>(o + 32 * t + 8 * q) = v;
+            }
+        // direction-encoding backward: d v = sum_f d gamma_4(v)_f/dv * grad_f, using the stored encoding for the
+        // sin<->cos partner values (model/official_nerf.py:112-118)
+        const float* enc = a.ws_xf + (live ? s : 0) * (D + kDirPad) + D;
+        float gv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = frag_feature(r, half);
+            int c, partner;
+            float sc;
+            enc_feature_meta(f, kDirReal, c, sc, partner);
+            const float pv = partner >= 0 ? enc[partner] : 1.f;
+            const float contrib = acc[DT][r] * sc * pv;
+            gv[0] += c == 0 ? contrib : 0.f;
+            gv[1] += c == 1 ? contrib : 0.f;
+            gv[2] += c == 2 ? contrib : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gv[c] += __shfl_xor(gv[c], 32, 64);
+        if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dview + 4 * s) = f32x4{gv[0], gv[1], gv[2], 0.f};
+    }
+
+    // ---- trunk ----
+    f32x16 acc[DT + 2];
+    auto masked_layer = [&](int hidden_idx /*0..7*/) {  // d <- acc .* relu'(h_idx); stash
+        uint32_t mw[L::mask_words];
+        const uint32_t* m = mask_base + (int64_t)hidden_idx * 64 * L::mask_words;
+#pragma unroll
+        for (int w = 0; w < L::mask_words; ++w) mw[w] = m[w];
+        float* o = a.ws_dh + ((int64_t)hidden_idx * a.S_pad + s) * D + 4 * half;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 16 * t + 4 * q + i;
+                    const float x = ((mw[r >> 5] >> (r & 31)) & 1u) ? acc[t][4 * q + i] : 0.f;
+                    d[r] = x;
+                    v[i] = x;
+                }
+                *reinterpret_cast<f32x4*>(o + 32 * t + 8 * q) = v;
+            }
+    };
+    // d h8 = Wf^T d feat + w_sigma^T d sigma_raw
+    float dsig[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dsig[r] = 0.f;
+    dsig[0] = half == 0 ? dout[3] : 0.f;
+    zero_acc(acc);
+    gemm_part<DT, DT>(acc, d, frag(B_FEAT));
+    gemm_part<1, DT>(acc, dsig, frag(B_SIG));
+    masked_layer(7);
+    // hidden 8,7,6 -> d pre-activation of 7,6,5
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+        zero_acc(acc);
+        gemm_part<DT, DT>(acc, d, wp + (L::bwd_off(B_L8) + l * part_floats(DT, DT)) / 4);
+        masked_layer(6 - l);
+    }
+    // hidden 5 (skip layer): rows [0,D) -> d h4, rows [D, D+64) -> d posenc (kept for the end)
+    zero_acc(acc);
+    gemm_part<DT, DT + 2>(acc, d, frag(B_L5));
+    float de[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) de[r] = acc[DT + (r >> 4)][r & 15];
+    masked_layer(3);
+    // hidden 4,3,2 -> d pre-activation of 3,2,1
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+        zero_acc(acc);
+        gemm_part<DT, DT>(acc, d, wp + (L::bwd_off(B_L4) + l * part_floats(DT, DT)) / 4);
+        masked_layer(2 - l);
+    }
+    // hidden 1: d posenc += W1^T d1
+    {
+        f32x16 acc2[2];
+        zero_acc(acc2);
+        gemm_part<DT, 2>(acc2, d, frag(B_L1));
+#pragma unroll
+        for (int r = 0; r < 32; ++r) de[r] += acc2[r >> 4][r & 15];
+    }
+    // positional-encoding backward -> d point
+    {
+        const float* enc = a.ws_xe + (live ? s : 0) * kPosPad;
+        float gp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int f = frag_feature(r, half);
+            int c, partner;
+            float sc;
+            enc_feature_meta(f, kPosReal, c, sc, partner);
+            const float pv = partner >= 0 ? enc[partner] : 1.f;
+            const float contrib = de[r] * sc * pv;
+            gp[0] += c == 0 ? contrib : 0.f;
+            gp[1] += c == 1 ? contrib : 0.f;
+            gp[2] += c == 2 ? contrib : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gp[c] += __shfl_xor(gp[c], 32, 64);
+        if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dpts + 4 * s) = f32x4{gp[0], gp[1], gp[2], 0.f};
+    }
+}
+
+template <int D>
+static hipError_t launch(const MlpDgradArgs& a, hipStream_t st) {
+    dim3 grid((unsigned)(a.S_pad / kBlockSamples)), block(256);
+    hipLaunchKernelGGL((mlp_dgrad_kernel<D>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st) {
+    return D == 256 ? launch<256>(a, st) : launch<128>(a, st);
+}
+
+}  // namespace nnr

@@ -1,0 +1,76 @@
+// nnr_pack.hip -- re-pack the 12 nn.Linear tensors of OfficialStaticNerf (model/official_nerf.py:20-37, (out,in)
+// row-major) into MFMA A-fragment order (nnr_layout.h), once forward-oriented (A = W) and once transposed (A = W^T, for
+// the input-gradient chain), plus zero-padded biases.  One launch, ~5 MB written; runs after every optimiser step.
+#include "nnr_device.h"
+#include "nnr_kernels.h"
+
+namespace nnr {
+
+template <int D>
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+    using L = Layout<D>;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per packed float4
+    const int64_t n_frag4 = L::bias_base / 4;
+    if (gid < n_frag4) {
+        // locate the part
+        int64_t f = gid * 4;  // float offset
+        PartDesc pd{};
+        int64_t base = 0;
+        bool found = false;
+#pragma unroll
+        for (int p = 0; p < F_NPARTS; ++p) {
+            const PartDesc d = L::fwd(p);
+            const int64_t sz = part_floats(d.KT, d.MT);
+            if (!found && f < base + sz) { pd = d; found = true; }
+            if (!found) base += sz;
+        }
+#pragma unroll
+        for (int p = 0; p < B_NPARTS; ++p) {
+            const PartDesc d = L::bwd(p);
+            const int64_t sz = part_floats(d.KT, d.MT);
+            if (!found && f < base + sz) { pd = d; found = true; }
+            if (!found) base += sz;
+        }
+        const int64_t local = (f - base) / 4;       // float4 index inside the part: (g*MT + mt)*64 + lane
+        const int lane = (int)(local & 63);
+        const int fi = (int)(local >> 6);
+        const int mt = fi % pd.MT, g = fi / pd.MT;
+        const int m = 32 * mt + (lane & 31);
+        const int k0 = 8 * g + 4 * (lane >> 5);
+        const float* W = a.w[pd.layer];
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + i;
+            float x = 0.f;
+            if (m < pd.m_real && k < pd.k_real) x = pd.transpose ? W[(int64_t)k * pd.ld + pd.off + m] : W[(int64_t)m * pd.ld + pd.off + k];
+            v[i] = x;
+        }
+        reinterpret_cast<f32x4*>(a.packed)[gid] = v;
+    } else {
+        const int64_t bi = (gid - n_frag4);  // one thread per bias float here (tail threads)
+        int64_t o = 0;
+#pragma unroll
+        for (int l = 0; l < 12; ++l) {
+            const int pad = L::bias_pad(l);
+            if (bi >= o && bi < o + pad) {
+                const int j = (int)(bi - o);
+                a.packed[L::bias_base + bi] = j < L::bias_real(l) ? a.b[l][j] : 0.f;
+            }
+            o += pad;
+        }
+    }
+}
+
+template <int D>
+static hipError_t launch(const PackArgs& a, hipStream_t st) {
+    using L = Layout<D>;
+    const int64_t threads = L::bias_base / 4 + (L::packed_floats - L::bias_base);
+    dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    hipLaunchKernelGGL((pack_kernel<D>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(int D, const PackArgs& a, hipStream_t st) { return D == 256 ? launch<256>(a, st) : launch<128>(a, st); }
+
+}  // namespace nnr

@@ -1,0 +1,34 @@
+"""nope_nerf -- the object `get_model` returns; thin wrapper that picks the per-ray mono-depth values and calls the
+renderer (reference model/network.py:8-33)."""
+import torch
+import torch.nn as nn
+
+
+def nearest_source_index(dst_idx, dst_size, src_size):
+    """Source index F.interpolate(mode='nearest') reads for destination index `dst_idx` along one axis:
+    floor(dst * (src/dst_size)) computed in float32 like ATen's nearest kernel, clamped to the source."""
+    scale = torch.tensor(float(src_size) / float(dst_size), dtype=torch.float32, device=dst_idx.device)
+    src = torch.floor(dst_idx.to(torch.float32) * scale).long()
+    return torch.clamp(src, max=src_size - 1)
+
+
+class nope_nerf(nn.Module):
+    def __init__(self, cfg, renderer, depth_estimator=None, device=None, **kwargs):
+        super().__init__()
+        self.renderer = renderer.to(device)
+        self.depth_estimator = depth_estimator.to(device) if depth_estimator is not None else None
+        self.device = device
+
+    def forward(self, p, ray_idx, camera_mat, world_mat, scale_mat, rendering_technique, it=0, eval_mode=False,
+                depth_img=None, add_noise=True, img_size=None):
+        depth = None
+        if rendering_technique == 'nope_nerf':
+            # The reference nearest-resizes the whole depth map to the image size every step and then gathers R
+            # values (network.py:22-24).  Gather-then-nothing is the same thing: index the source pixel directly.
+            h, w = img_size
+            hd, wd = depth_img.shape[-2:]
+            ys = nearest_source_index(torch.div(ray_idx, w, rounding_mode='floor'), h, hd)
+            xs = nearest_source_index(ray_idx % w, w, wd)
+            depth = depth_img[0, 0][ys, xs].view(1, -1, 1)
+        return self.renderer(p, depth, camera_mat, world_mat, scale_mat, rendering_technique, eval_=eval_mode, it=it,
+                             add_noise=add_noise)

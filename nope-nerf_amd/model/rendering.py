@@ -1,0 +1,134 @@
+"""Renderer -- host side of the volumetric-rendering hot path.
+
+Same constructor, `forward` dispatch and output dictionary as the reference's model/rendering.py:11-34,159-166, but
+the body of `nope_nerf` (reference :36-167) is: a few O(R) torch ops that turn (pixels, depth, K, W, S) into per-ray
+sampling origins/directions inside the autograd graph (so gradients reach the learnable pose / focal / depth
+distortion exactly as they do through the reference's matrix inverses), and ONE call into the fused HIP operator
+`nnr.render_rays` for everything per-sample: stratified / NDC sampling, positional encoding, the 12-layer MLP,
+alpha-compositing, and their backward.
+
+Not provided (outside the hot path): the phong / ray-marching visualiser
+(`phong_renderer`, `ray_marching`, `secant`) and the normal-loss branch; they raise NotImplementedError.
+"""
+import torch
+import torch.nn as nn
+
+import nnr
+from .common import get_ndc_rays_fxfy, pixel_to_world_matrix
+
+epsilon = 1e-6   # the transmittance epsilon of the reference (rendering.py:9) -- applied inside the composite kernel
+
+
+class Renderer(nn.Module):
+    def __init__(self, model, cfg, device=None, **kwargs):
+        super().__init__()
+        self._device = device
+        self.depth_range = cfg['depth_range']
+        self.n_max_network_queries = cfg['n_max_network_queries']   # kept for API parity; the fused kernel needs no chunking
+        self.white_background = cfg['white_background']
+        self.cfg = cfg
+        self.model = model.to(device)
+        self._z_cache = {}
+        self.jitter_window = None   # (first ray, rays in the whole step) when this process renders a shard
+
+    def forward(self, pixels, depth, camera_mat, world_mat, scale_mat, rendering_technique, add_noise=True,
+                eval_=False, it=1000000):
+        if rendering_technique == 'nope_nerf':
+            return self.nope_nerf(pixels, depth, camera_mat, world_mat, scale_mat, it=it, add_noise=add_noise, eval_=eval_)
+        if rendering_technique == 'phong_renderer':
+            return self.phong_renderer(pixels, camera_mat, world_mat, scale_mat, it=it)
+        raise ValueError('unknown rendering technique %r' % (rendering_technique,))
+
+    # ------------------------------------------------------------------------------------------------ z tables
+    def _z_tables(self, n_samples, near, far, stratified, device):
+        """Per-sample interval [lo_j, hi_j]; z_j = lo_j + (hi_j - lo_j) * u_j (reference rendering.py:95-96,184-190).
+        Built once per configuration on the CPU (bit-identical to the reference's CPU arithmetic), then cached on the
+        device; the kernel applies the jitter."""
+        key = (n_samples, float(near), float(far), bool(stratified), str(device))
+        hit = self._z_cache.get(key)
+        if hit is None:
+            rng = torch.tensor([near, far])
+            z = torch.linspace(0., 1., steps=n_samples)
+            z = rng[0] * (1. - z) + rng[1] * z
+            if stratified:
+                mid = .5 * (z[1:] + z[:-1])
+                lo, hi = torch.cat([z[:1], mid]), torch.cat([mid, z[-1:]])
+            else:
+                lo = hi = z
+            hit = (lo.contiguous().to(device), hi.contiguous().to(device))
+            self._z_cache[key] = hit
+        return hit
+
+    # ------------------------------------------------------------------------------------------------ hot path
+    def nope_nerf(self, pixels, depth, camera_mat, world_mat, scale_mat, add_noise=False, it=100000, eval_=False):
+        cfg = self.cfg
+        batch_size, n_rays, _ = pixels.shape
+        if batch_size != 1:
+            raise NotImplementedError("batch size 1 is baked into the reference (rendering.py:86-87); so it is here")
+        if cfg['normal_loss'] and not eval_:
+            raise NotImplementedError("rendering.normal_loss needs second-order MLP gradients (reference "
+                                      "rendering.py:133-143); not part of the HIP hot path")
+        n_samples = cfg['num_points'] - cfg['outside_steps']
+        device = pixels.device
+
+        # --- rays (reference :54-72).  inv(S) inv(W) inv(K) stays inside autograd: pose / focal gradients flow here ---
+        m = pixel_to_world_matrix(camera_mat, world_mat, scale_mat)[0]             # (4,4)
+        cam = m[:3, 3]                                                              # camera centre
+        pix_h = torch.cat([pixels[0], torch.ones(n_rays, 1, device=device)], dim=-1)   # (R,3) = (x', y', 1)
+        ray = pix_h @ m[:3, :3].t()                                                 # pixels_world - camera_world
+        ray_norm = ray.norm(2, -1)
+        d_gt = (ray * depth[0]).norm(2, -1)                                         # |points_world - camera_world|
+        if cfg['normalise_ray']:
+            ray = ray / ray_norm.unsqueeze(-1)
+        else:
+            d_gt = d_gt / ray_norm
+        object_mask = torch.isfinite(d_gt) & (d_gt != 0)                            # :73-87
+
+        # --- per-ray sampling frame ---
+        view = -ray if cfg['use_ray_dir'] else torch.ones_like(ray)                 # :104-105,194-195
+        origin = cam.unsqueeze(0).expand(n_rays, 3)
+        jitter = None
+        if cfg['sample_option'] == 'ndc':                                           # :168-180
+            focal = torch.cat([camera_mat[:, 0, 0], camera_mat[:, 1, 1]])
+            pts_o, pts_d = get_ndc_rays_fxfy(focal, 1.0, rays_o=origin, rays_d=ray)
+            z_lo, z_hi = self._z_tables(n_samples, 0., 1., False, device)
+        elif cfg['sample_option'] == 'uniform':                                     # :182-197
+            pts_o, pts_d = origin, ray
+            z_lo, z_hi = self._z_tables(n_samples, self.depth_range[0], self.depth_range[1], bool(add_noise), device)
+            if add_noise:
+                if self.jitter_window is None:
+                    jitter = torch.rand(batch_size, n_rays, n_samples, device=device)   # same draw as the reference (:189)
+                else:   # data-parallel shard: draw the whole step's jitter, keep this rank's rows (model/training.py)
+                    lo, total = self.jitter_window
+                    jitter = torch.rand(batch_size, total, n_samples, device=device)[:, lo:lo + n_rays].contiguous()
+        else:
+            raise ValueError('unknown sample_option %r' % (cfg['sample_option'],))
+
+        net = self.model
+        rgb, dist_pred, alpha, z_val = nnr.render_rays(
+            pts_o, pts_d, view, z_lo, z_hi, jitter, net.weights(), net.biases(), hidden=net.hidden_dim,
+            dist_alpha=bool(cfg['dist_alpha']), white_bg=bool(self.white_background),
+            relu_sigma=(net.occ_activation != 'softplus'))
+
+        if eval_ and cfg['normalise_ray']:                                          # distance -> depth for evaluation (:150-154)
+            dist_pred = dist_pred / ray_norm
+            d_gt = d_gt / ray_norm
+        depth_gt = d_gt[object_mask]
+        if cfg['sample_option'] == 'ndc':
+            depth_gt = 1 - 1 / depth_gt
+        return {
+            'rgb': rgb.reshape(batch_size, -1, 3),
+            'z_vals': z_val,
+            'normal': None,
+            'depth_pred': dist_pred[object_mask],
+            'depth_gt': depth_gt,
+            'alpha': alpha,
+        }
+
+    # ------------------------------------------------------------------------------------------------ not on the hot path
+    def phong_renderer(self, *args, **kwargs):
+        raise NotImplementedError("phong_renderer (geometry visualisation, reference rendering.py:202-274) is outside the "
+                                  "HIP hot path; set training.vis_geo: False")
+
+    def ray_marching(self, *args, **kwargs):
+        raise NotImplementedError("ray_marching / secant (reference rendering.py:277-418) serve only phong_renderer")

@@ -1,0 +1,283 @@
+"""Trainer -- the per-iteration training step; constructor, `train_step`, `render_visdata` and the returned dict keys
+follow reference model/training.py:14-378 so that train.py drives it unchanged.
+
+What is different underneath:
+  * the render call (training.py:266-274) lands in the fused HIP operator through model.Renderer;
+  * data-parallel training: when torch.distributed is initialised, every rank sees the same image, the same
+    `ray_idx` permutation and the same jitter stream (same seed), renders only its contiguous slice of the rays, scales
+    the per-ray losses by the *global* ray / valid-depth counts, and ONE flat all-reduce (RCCL over xGMI) of all
+    gradients after backward reproduces the single-GPU gradient.  Per-image auxiliary losses are
+    computed redundantly and weighted 1/world_size.
+The auxiliary point-cloud / reprojection losses (training.py:280-365) are stock torch, as in the reference.
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+from torch.nn import functional as F
+
+from model.common import arange_pixels, get_tensor_values, project_to_cam, transform_to_world
+from model.losses import Loss
+from nnr import parallel
+
+logger_py = logging.getLogger(__name__)
+
+_WEIGHT_KEYS = ('rgb_weight', 'depth_weight', 'pc_weight', 'rgb_s_weight', 'depth_consistency_weight',
+                'weight_dist_2nd_loss', 'weight_dist_1st_loss')
+_CFG_KEYS = ('detach_gt_depth', 'pc_ratio', 'match_method', 'shift_first', 'detach_ref_img', 'scale_pcs',
+             'detach_rgbs_scale', 'vis_reprojection_every', 'nearest_limit', 'annealing_epochs')
+
+
+def _save_png(arr_u8, path):
+    Image.fromarray(arr_u8).save(path)
+
+
+class Trainer(object):
+    def __init__(self, model, optimizer, cfg, device=None, optimizer_pose=None, pose_param_net=None,
+                 optimizer_focal=None, focal_net=None, optimizer_distortion=None, distortion_net=None, **kwargs):
+        self.model, self.optimizer, self.device = model, optimizer, device
+        self.optimizer_pose, self.pose_param_net = optimizer_pose, pose_param_net
+        self.optimizer_focal, self.focal_net = optimizer_focal, focal_net
+        self.optimizer_distortion, self.distortion_net = optimizer_distortion, distortion_net
+        self.n_training_points = cfg['n_training_points']
+        self.rendering_technique = cfg['type']
+        self.vis_geo = cfg['vis_geo']
+        for k in _CFG_KEYS + _WEIGHT_KEYS:
+            setattr(self, k, cfg[k])
+        self.loss = Loss(cfg)
+        self._warned_geo = False
+
+    # ------------------------------------------------------------------------------------------------ step
+    def _groups(self):
+        return [(self.pose_param_net, self.optimizer_pose), (self.focal_net, self.optimizer_focal),
+                (self.distortion_net, self.optimizer_distortion)]
+
+    def train_step(self, data, it=None, epoch=None, scheduling_start=None, render_path=None):
+        self.model.train()
+        self.optimizer.zero_grad()
+        for net, opt in self._groups():
+            if net:
+                net.train()
+                opt.zero_grad()
+        loss_dict = self.compute_loss(data, it=it, epoch=epoch, scheduling_start=scheduling_start,
+                                      out_render_path=render_path)
+        loss_dict['loss'].backward()
+        if parallel.world_size() > 1:
+            nets = [self.model] + [n for n, _ in self._groups() if n]
+            parallel.allreduce_gradients([p for n in nets for p in n.parameters()], loss_dict)
+        self.optimizer.step()
+        for net, opt in self._groups():
+            if opt:
+                opt.step()
+        return loss_dict
+
+    # ------------------------------------------------------------------------------------------------ data
+    def process_data_dict(self, data):
+        dev = self.device
+        return (data.get('img').to(dev), data.get('img.dpt').to(dev).unsqueeze(1), data.get('img.camera_mat').to(dev),
+                data.get('img.scale_mat').to(dev), data.get('img.idx'))
+
+    def process_data_reference(self, data):
+        dev = self.device
+        return (data.get('img.ref_imgs').to(dev), data.get('img.ref_dpts').to(dev).unsqueeze(1), data.get('img.ref_idxs'))
+
+    def anneal(self, start_weight, end_weight, anneal_start_epoch, anneal_epoches, current):
+        if current <= anneal_start_epoch:
+            return start_weight
+        if current >= anneal_start_epoch + anneal_epoches:
+            return end_weight
+        return start_weight + (end_weight - start_weight) * (current - anneal_start_epoch) / anneal_epoches
+
+    def _camera_from_focal(self, device):
+        fxfy = self.focal_net(0)
+        k = torch.zeros(4, 4, device=device)
+        k[0, 0], k[1, 1], k[2, 2], k[3, 3] = fxfy[0], -fxfy[1], -1.0, 1.0
+        return fxfy, k.unsqueeze(0)
+
+    # ------------------------------------------------------------------------------------------------ loss
+    def compute_loss(self, data, eval_mode=False, it=None, epoch=None, scheduling_start=None, out_render_path=None):
+        weights = {k: self.anneal(getattr(self, k)[0], getattr(self, k)[1], scheduling_start, self.annealing_epochs, epoch)
+                   for k in _WEIGHT_KEYS}
+        rgb_loss_type = 'l1' if epoch < self.annealing_epochs + scheduling_start else 'l2'
+        render_model = weights['rgb_weight'] != 0.0 or weights['depth_weight'] != 0.0
+        use_ref_imgs = weights['pc_weight'] != 0.0 or weights['rgb_s_weight'] != 0.0
+        world, rank = parallel.world_size(), parallel.rank()
+
+        img, depth_input, camera_mat_gt, scale_mat, img_idx = self.process_data_dict(data)
+        device = self.device
+        batch_size, _, h, w = img.shape
+        h_depth, w_depth = depth_input.shape[-2:]
+        kwargs = {'t_list': self.pose_param_net.get_t(), 'weights': weights, 'rgb_loss_type': rgb_loss_type}
+
+        num_cams = self.pose_param_net.num_cams
+        world_mat = torch.inverse(self.pose_param_net(img_idx)).unsqueeze(0)
+        scale_input = shift_input = None
+        if self.distortion_net is not None:
+            scale_input, shift_input = self.distortion_net(img_idx)
+            depth_input = (depth_input + shift_input) * scale_input if self.shift_first \
+                else depth_input * scale_input + shift_input
+        if self.optimizer_focal:
+            fxfy, camera_mat = self._camera_from_focal(device)
+        else:
+            camera_mat = camera_mat_gt
+
+        # pixel pick: the permutation is drawn exactly as the reference does (training.py:257), so indices are bit-identical
+        n_points = self.n_training_points
+        ray_idx = torch.randperm(h * w, device=device)[:n_points]
+        n_total = ray_idx.shape[0]
+        lo, hi = parallel.shard_bounds(n_total, rank, world)
+        ray_loc = ray_idx[lo:hi]
+        rgb_gt = img.view(batch_size, 3, h * w).permute(0, 2, 1)[:, ray_loc]
+        xs = (ray_loc % w).float()
+        ys = torch.div(ray_loc, w, rounding_mode='floor').float()
+        p = torch.stack([2.0 * xs / (w - 1) - 1.0, 2.0 * ys / (h - 1) - 1.0], dim=-1).unsqueeze(0)   # == arange_pixels()[1][:, idx]
+
+        rendered_rgb = rendered_depth = gt_depth = None
+        if render_model:
+            renderer = self.model.renderer
+            renderer.jitter_window = (lo, n_total) if world > 1 else None
+            out = self.model(p, ray_loc, camera_mat, world_mat, scale_mat, self.rendering_technique, it=it,
+                             eval_mode=eval_mode, depth_img=depth_input, img_size=(h, w))
+            renderer.jitter_window = None
+            rendered_rgb, rendered_depth, gt_depth = out['rgb'], out['depth_pred'], out['depth_gt']
+            if self.detach_gt_depth:
+                gt_depth = gt_depth.detach()
+
+        if use_ref_imgs:
+            self._reference_terms(kwargs, data, img, depth_input, camera_mat, world_mat, scale_input, img_idx, num_cams,
+                                  h_depth, w_depth, weights, it, out_render_path)
+
+        if world > 1:
+            loss_dict = self._sharded_loss(rendered_rgb, rgb_gt, rendered_depth, gt_depth, n_total, ray_idx, depth_input,
+                                           (h, w), kwargs, world)
+        else:
+            loss_dict = self.loss(rendered_rgb, rgb_gt, rendered_depth, gt_depth, **kwargs)
+        if self.optimizer_focal:
+            loss_dict['focalx'] = fxfy[0] / camera_mat_gt[0, 0, 0]
+            loss_dict['focaly'] = fxfy[1] / camera_mat_gt[0, 1, 1]
+        loss_dict['scale'] = scale_input
+        loss_dict['shift'] = shift_input
+        return loss_dict
+
+    def _sharded_loss(self, rgb, rgb_gt, depth_pred, depth_gt, n_total, ray_idx, depth_input, img_size, kwargs, world):
+        """Local share of the loss such that SUM over ranks == the single-process loss: per-ray terms are divided by the
+        GLOBAL ray / valid-depth counts, per-image terms by world_size."""
+        from model.network import nearest_source_index
+        w = kwargs['weights']
+        h_img, w_img = img_size
+        hd, wd = depth_input.shape[-2:]
+        with torch.no_grad():   # global count of rays with a usable mono depth (finite, non-zero): no collective needed
+            ys = nearest_source_index(torch.div(ray_idx, w_img, rounding_mode='floor'), h_img, hd)
+            xs = nearest_source_index(ray_idx % w_img, w_img, wd)
+            d_all = depth_input[0, 0][ys, xs]
+            m_total = int((torch.isfinite(d_all) & (d_all != 0)).sum())
+        kw = dict(kwargs)
+        kw['weights'] = dict(w, rgb_weight=0.0, depth_weight=0.0)     # per-image terms only
+        out = self.loss(rgb, rgb_gt, depth_pred, depth_gt, **kw)
+        aux = out['loss'] / world
+        for k in ('loss_pc', 'loss_rgb_s', 'loss_dist_1st', 'loss_dist_2nd', 'loss_depth_consistency'):
+            out[k] = out[k] / world
+        zero = torch.zeros((), device=rgb_gt.device)
+        lrgb = ldep = zero
+        if w['rgb_weight'] != 0.0:
+            diff = rgb - rgb_gt
+            lrgb = (diff.abs().sum() if kwargs['rgb_loss_type'] == 'l1' else (diff * diff).sum()) / float(n_total)
+        if w['depth_weight'] != 0.0:
+            if self.loss.depth_loss_type != 'l1':
+                raise NotImplementedError("depth_loss_type 'invariant' takes a median over all rays of the step "
+                                          "(losses.py:42-46); it needs an all-gather and is not sharded yet")
+            ldep = (depth_pred - depth_gt).abs().sum() / float(max(m_total, 1))
+        out['loss_rgb'], out['loss_depth'] = lrgb, ldep
+        out['l2_mean'] = ((rgb - rgb_gt) ** 2).sum() / float(3 * n_total)
+        out['loss'] = w['rgb_weight'] * lrgb + w['depth_weight'] * ldep + aux
+        return out
+
+    def _reference_terms(self, kwargs, data, img, depth_input, camera_mat, world_mat, scale_input, img_idx, num_cams,
+                         h_depth, w_depth, weights, it, out_render_path):
+        """Inputs of the point-cloud and surface-reprojection losses between this frame and its reference frame
+        (reference training.py:280-365)."""
+        device = self.device
+        nl = self.nearest_limit
+        ref_img, depth_ref, ref_idx = self.process_data_reference(data)
+        c2w_ref = self.pose_param_net(ref_idx)
+        scale_ref = shift_ref = None
+        if self.distortion_net is not None:
+            scale_ref, shift_ref = self.distortion_net(ref_idx)
+            depth_ref = scale_ref * (depth_ref + shift_ref) if self.shift_first else scale_ref * depth_ref + shift_ref
+        if self.detach_ref_img:
+            c2w_ref, depth_ref = c2w_ref.detach(), depth_ref.detach()
+            if scale_ref is not None:
+                scale_ref, shift_ref = scale_ref.detach(), shift_ref.detach()
+        ref_rt = torch.inverse(c2w_ref).unsqueeze(0)
+        if img_idx < (num_cams - 1):
+            d1, d2, img1, img2 = depth_input, depth_ref, img, ref_img
+            rel = ref_rt @ torch.inverse(world_mat)
+            scale2 = scale_ref
+        else:
+            d1, d2, img1, img2 = depth_ref, depth_input, ref_img, img
+            rel = world_mat @ torch.inverse(ref_rt)
+            scale2 = scale_input
+        r_rel, t_rel = rel[:, :3, :3], rel[:, :3, 3]
+
+        res = (int(h_depth / self.pc_ratio), int(w_depth / self.pc_ratio))
+        pixel_locations, p_pc = arange_pixels(resolution=res, device=device)
+        d1 = F.interpolate(d1, res, mode='nearest')
+        d2 = F.interpolate(d2, res, mode='nearest')
+        d1[d1 < nl] = nl
+        d2[d2 < nl] = nl
+        pc1 = transform_to_world(p_pc, d1.view(1, -1, 1), camera_mat)
+        pc2 = transform_to_world(p_pc, d2.view(1, -1, 1), camera_mat)
+
+        if weights['rgb_s_weight'] != 0.0:
+            img1 = F.interpolate(img1, res, mode='bilinear')
+            img2 = F.interpolate(img2, res, mode='bilinear')
+            rgb_pc1 = get_tensor_values(img1, p_pc, mode='bilinear', scale=False, detach=False, detach_p=False,
+                                        align_corners=True)
+            src = pc1.detach().clone() if self.detach_rgbs_scale else pc1
+            pc1_rot = src @ r_rel.transpose(1, 2) + t_rel
+            behind = (-pc1_rot[:, :, 2:] < nl).expand_as(pc1_rot)
+            pc1_rot[behind] = nl
+            p_reproj, valid = project_to_cam(pc1_rot, camera_mat, device)
+            rgb_proj = get_tensor_values(img2, p_reproj, mode='bilinear', scale=False, detach=False, detach_p=False,
+                                         align_corners=True)
+            shape = (img.shape[0], res[0], res[1])
+            kwargs['rgb_pc1'] = rgb_pc1.view(*shape, 3)
+            kwargs['rgb_pc1_proj'] = rgb_proj.view(*shape, 3)
+            kwargs['valid_points'] = valid.view(*shape, 1)
+            if (it % self.vis_reprojection_every) == 0 and out_render_path is not None:
+                for tag, t in (('img1', kwargs['rgb_pc1']), ('img2', kwargs['rgb_pc1_proj'])):
+                    _save_png((t[0] * 255).detach().cpu().numpy().astype(np.uint8),
+                              os.path.join(out_render_path, '%d_%04d_%s.png' % (it, img_idx, tag)))
+        pc1 = pc1 @ r_rel.transpose(1, 2) + t_rel          # transform before scaling
+        if self.scale_pcs:
+            pc1, pc2 = pc1 / scale2, pc2 / scale2
+        kwargs.update(X=pc1, Y=pc2, sample_resolution=res, p_2d=pixel_locations)
+
+    # ------------------------------------------------------------------------------------------------ visual dumps
+    def render_visdata(self, data, resolution, it, out_render_path):
+        img, dpt, camera_mat, scale_mat, img_idx = self.process_data_dict(data)
+        h, w = resolution
+        world_mat = torch.inverse(self.pose_param_net(img_idx)).unsqueeze(0)
+        if self.optimizer_focal:
+            _, camera_mat = self._camera_from_focal(self.device)
+        p_idx = torch.arange(h * w, device=self.device)
+        pixels = arange_pixels(resolution=(h, w), device=self.device)[1]
+        with torch.no_grad():
+            rgb, depth = [], []
+            for pix_i, idx_i in zip(torch.split(pixels, 1024, dim=1), torch.split(p_idx, 1024, dim=0)):
+                out = self.model(pix_i, idx_i, camera_mat, world_mat, scale_mat, self.rendering_technique, add_noise=False,
+                                 eval_mode=True, it=it, depth_img=dpt, img_size=(h, w))
+                rgb.append(out['rgb'])
+                depth.append(out['depth_pred'])
+            rgb = torch.cat(rgb, dim=1).view(h, w, 3).cpu().numpy()
+            depth = torch.cat(depth, dim=0).view(h, w).cpu().numpy()
+        img_out = (rgb * 255).astype(np.uint8)
+        depth_u8 = np.clip(255.0 / depth.max() * (depth - depth.min()), 0, 255).astype(np.uint8)
+        _save_png(depth_u8, os.path.join(out_render_path, '%04d_depth.png' % img_idx))
+        Image.fromarray(img_out).convert("RGB").save(os.path.join(out_render_path, '%04d_img.png' % img_idx))
+        if self.vis_geo and not self._warned_geo:
+            logger_py.warning("training.vis_geo: the phong geometry visualiser is outside the HIP hot path; skipping *_geo.png")
+            self._warned_geo = True
+        return img_out

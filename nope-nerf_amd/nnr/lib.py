@@ -1,0 +1,114 @@
+"""ctypes binding of libnnr.so (include/nnr.h).
+
+This is the stub a maintainer of the reference would add: plain pointers and sizes,
+no torch types cross the boundary.  There is deliberately NO fallback: if the shared library is missing or
+a call fails, a RuntimeError is raised -- the product path never silently runs anything but the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnnr.so")
+
+NNR_F_DIST_ALPHA = 1
+NNR_F_WHITE_BG = 2
+NNR_F_RELU_SIGMA = 4
+NNR_F_TRAIN = 8
+N_LAYERS = 12
+
+#: state_dict order of the 12 nn.Linear layers (reference model/official_nerf.py:20-37)
+LAYER_NAMES = ("layers0.0", "layers0.2", "layers0.4", "layers0.6", "layers1.0", "layers1.2", "layers1.4",
+               "layers1.6", "fc_density", "fc_feature", "rgb_layers.0", "fc_rgb")
+
+EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_floats", "nnr_workspace_floats",
+           "nnr_plan_bytes", "nnr_plan_build", "nnr_pack_weights", "nnr_render_fwd", "nnr_render_bwd", "nnr_ws_plane",
+           "nnr_mlp_fwd", "nnr_composite_fwd", "nnr_composite_bwd", "nnr_mlp_dgrad", "nnr_mlp_wgrad", "nnr_ray_reduce")
+
+
+class Cfg(C.Structure):
+    _fields_ = [("n_rays", C.c_int32), ("n_samples", C.c_int32), ("hidden", C.c_int32), ("flags", C.c_uint32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("weight", C.c_void_p * N_LAYERS), ("bias", C.c_void_p * N_LAYERS)]
+
+
+class WgradJob(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("layer", "MI", "NI", "d_plane", "d_col0", "d_valid", "x_plane", "x_col0",
+                                         "x_valid", "row0", "wcol0", "rows_real", "cols_real", "ldw", "k0", "k1", "bias")]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libnnr.so (built by nope-nerf_amd/csrc/build.py).  Raises if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first (python nope-nerf_amd/csrc/build.py or "
+            "__graft_entry__.build()).  There is no CPU fallback for the render path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, cfgp, i64 = C.c_void_p, C.POINTER(Cfg), C.c_int64
+    lib.nnr_abi_version.restype = C.c_int
+    lib.nnr_strerror.restype = C.c_char_p
+    lib.nnr_strerror.argtypes = [C.c_int]
+    lib.nnr_last_hip_error.restype = C.c_int
+    for n in ("nnr_packed_floats", "nnr_workspace_floats", "nnr_plan_bytes"):
+        getattr(lib, n).restype = C.c_size_t
+        getattr(lib, n).argtypes = [cfgp]
+    lib.nnr_plan_build.argtypes = [cfgp, vp]
+    lib.nnr_pack_weights.argtypes = [cfgp, C.POINTER(Params), vp, vp]
+    lib.nnr_render_fwd.argtypes = [cfgp] + [vp] * 13
+    lib.nnr_render_bwd.argtypes = [cfgp, vp, vp, vp, C.POINTER(Params), vp, vp, vp, vp, vp, vp]
+    lib.nnr_ws_plane.restype = i64
+    lib.nnr_ws_plane.argtypes = [cfgp, C.c_int, C.POINTER(C.c_int32)]
+    lib.nnr_mlp_fwd.argtypes = [cfgp] + [vp] * 9
+    lib.nnr_composite_fwd.argtypes = [cfgp] + [vp] * 6
+    lib.nnr_composite_bwd.argtypes = [cfgp] + [vp] * 4
+    lib.nnr_mlp_dgrad.argtypes = [cfgp, vp, vp, vp]
+    lib.nnr_mlp_wgrad.argtypes = [cfgp, C.POINTER(Params), vp, vp, vp]
+    lib.nnr_ray_reduce.argtypes = [cfgp] + [vp] * 5
+    for n in EXPORTS:
+        if not hasattr(lib, n):
+            raise RuntimeError(f"libnnr.so does not export {n}")
+    if lib.nnr_abi_version() != 1:
+        raise RuntimeError("libnnr.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        lib = load()
+        msg = lib.nnr_strerror(rc).decode()
+        if rc == -4:
+            msg += f" (hipError {lib.nnr_last_hip_error()})"
+        raise RuntimeError(f"{what} failed: {msg}")
+
+
+def make_cfg(n_rays: int, n_samples: int, hidden: int, *, dist_alpha=False, white_bg=False, relu_sigma=False,
+             train=False) -> Cfg:
+    flags = (NNR_F_DIST_ALPHA if dist_alpha else 0) | (NNR_F_WHITE_BG if white_bg else 0) | \
+            (NNR_F_RELU_SIGMA if relu_sigma else 0) | (NNR_F_TRAIN if train else 0)
+    return Cfg(int(n_rays), int(n_samples), int(hidden), flags)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL).  The tensor must be contiguous fp32/int32 storage."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "nnr: tensors crossing the C ABI must be contiguous"
+    return C.c_void_p(t.data_ptr())
+
+
+def params_struct(weights, biases) -> Params:
+    p = Params()
+    for i in range(N_LAYERS):
+        p.weight[i] = weights[i].data_ptr()
+        p.bias[i] = biases[i].data_ptr()
+    return p

@@ -1,0 +1,224 @@
+"""torch.autograd glue around the C ABI of libnnr.so.
+
+`render_rays` is the one differentiable operator the host-side `model.Renderer` calls: sampling along rays,
+the positional-encoded MLP and alpha-compositing, forward and backward, entirely in the HIP kernels
+(reference model/rendering.py:95-132 + model/official_nerf.py:60-96 and autograd through them).
+PyTorch is used for device memory, the current stream and the autograd graph edge -- nothing is computed here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+def _require_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("nnr: the render path runs only on an AMD GPU (HIP); got a CPU tensor and there is no CPU fallback")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# packed weights: re-packed only when a parameter tensor changed (optimizer.step bumps tensor._version)
+# ----------------------------------------------------------------------------------------------------------------------
+class _PackCache:
+    def __init__(self):
+        self.key = None
+        self.packed = None
+
+    def get(self, cfg: L.Cfg, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> torch.Tensor:
+        key = (cfg.hidden,) + tuple((t.data_ptr(), t._version) for t in (*weights, *biases))
+        if key != self.key or self.packed is None:
+            lib = L.load()
+            n = lib.nnr_packed_floats(C.byref(cfg))
+            packed = torch.empty(n, dtype=torch.float32, device=weights[0].device)
+            ps = L.params_struct(weights, biases)
+            L.check(lib.nnr_pack_weights(C.byref(cfg), C.byref(ps), L.ptr(packed),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_pack_weights")
+            self.key, self.packed = key, packed
+        return self.packed
+
+
+_pack_caches = {}   # (device, data_ptr of the first weight) -> cache; a handful of models at most
+
+
+def _packed_for(cfg, weights, biases):
+    anchor = (str(weights[0].device), weights[0].data_ptr())
+    cache = _pack_caches.get(anchor)
+    if cache is None:
+        if len(_pack_caches) >= 8:
+            _pack_caches.pop(next(iter(_pack_caches)))
+        cache = _pack_caches[anchor] = _PackCache()
+    return cache.get(cfg, weights, biases)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# workspaces and plans, cached per (device, shape); a training workspace is held by the autograd node until backward
+# ----------------------------------------------------------------------------------------------------------------------
+_ws_pool = {}
+_plan_cache = {}
+
+
+def _cfg_key(cfg: L.Cfg, device):
+    return (str(device), cfg.n_rays, cfg.n_samples, cfg.hidden, cfg.flags)
+
+
+def _take_workspace(cfg: L.Cfg, device) -> torch.Tensor:
+    key = _cfg_key(cfg, device)
+    pool = _ws_pool.setdefault(key, [])
+    if pool:
+        return pool.pop()
+    n = L.load().nnr_workspace_floats(C.byref(cfg))
+    if n == 0:
+        raise RuntimeError("nnr: unsupported configuration (hidden_dim must be 128 or 256; num_points <= 1024 for training)")
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def _give_workspace(cfg: L.Cfg, device, ws: torch.Tensor):
+    pool = _ws_pool.setdefault(_cfg_key(cfg, device), [])
+    if len(pool) < 2:
+        pool.append(ws)
+
+
+def _plan_for(cfg: L.Cfg, device) -> torch.Tensor:
+    key = _cfg_key(cfg, device)
+    plan = _plan_cache.get(key)
+    if plan is None:
+        lib = L.load()
+        nbytes = lib.nnr_plan_bytes(C.byref(cfg))
+        host = np.zeros(nbytes, dtype=np.uint8)
+        L.check(lib.nnr_plan_build(C.byref(cfg), host.ctypes.data_as(C.c_void_p)), "nnr_plan_build")
+        plan = torch.from_numpy(host).to(device)
+        _plan_cache[key] = plan
+    return plan
+
+
+def plan_jobs(cfg: L.Cfg):
+    """Host copy of the weight-gradient plan as a list of WgradJob (for tests / DESIGN inspection)."""
+    lib = L.load()
+    nbytes = lib.nnr_plan_bytes(C.byref(cfg))
+    n = nbytes // C.sizeof(L.WgradJob)
+    buf = (L.WgradJob * n)()
+    L.check(lib.nnr_plan_build(C.byref(cfg), C.cast(buf, C.c_void_p)), "nnr_plan_build")
+    return list(buf)
+
+
+def workspace_plane(cfg: L.Cfg, ws: torch.Tensor, plane: int, n_rows: Optional[int] = None) -> torch.Tensor:
+    """View of one workspace plane as (rows, pitch) -- used by the parity tests to localise a mismatch."""
+    pitch = C.c_int32(0)
+    off = L.load().nnr_ws_plane(C.byref(cfg), plane, C.byref(pitch))
+    if off < 0:
+        raise KeyError(plane)
+    S = cfg.n_rays * cfg.n_samples
+    s_pad = (S + 127) // 128 * 128
+    v = ws[off: off + s_pad * pitch.value].view(s_pad, pitch.value)
+    return v[: (n_rows if n_rows is not None else S)]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the operator
+# ----------------------------------------------------------------------------------------------------------------------
+class _RenderRays(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts_o, pts_d, view_d, z_lo, z_hi, jitter, opts, *params):
+        weights, biases = params[:L.N_LAYERS], params[L.N_LAYERS:]
+        _require_gpu(pts_o)
+        dev = pts_o.device
+        R, N = pts_o.shape[0], z_lo.shape[0]
+        need_grad = any(ctx.needs_input_grad)
+        cfg = L.make_cfg(R, N, opts["hidden"], dist_alpha=opts["dist_alpha"], white_bg=opts["white_bg"],
+                         relu_sigma=opts["relu_sigma"], train=need_grad)
+        lib = L.load()
+        f32 = dict(dtype=torch.float32, device=dev)
+        pts_o, pts_d, view_d = (t.detach().contiguous().float() for t in (pts_o, pts_d, view_d))
+        z_lo, z_hi = z_lo.detach().contiguous().float(), z_hi.detach().contiguous().float()
+        jit = jitter.detach().contiguous().float().view(R, N) if jitter is not None else None
+        weights = [w.detach() for w in weights]
+        biases = [b.detach() for b in biases]
+        packed = _packed_for(cfg, weights, biases)
+        ws = _take_workspace(cfg, dev)
+        rgb = torch.empty(R, 3, **f32)
+        dist = torch.empty(R, **f32)
+        alpha = torch.empty(R, N, **f32)
+        zv = torch.empty(R, N, **f32)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(lib.nnr_render_fwd(C.byref(cfg), L.ptr(pts_o), L.ptr(pts_d), L.ptr(view_d), L.ptr(z_lo), L.ptr(z_hi),
+                                   L.ptr(jit), L.ptr(packed), L.ptr(rgb), L.ptr(dist), L.ptr(alpha), L.ptr(zv), L.ptr(ws), st),
+                "nnr_render_fwd")
+        if need_grad:
+            ctx.cfg, ctx.ws, ctx.packed, ctx.dev = cfg, ws, packed, dev
+            ctx.shapes = [tuple(p.shape) for p in params]
+        else:
+            _give_workspace(cfg, dev, ws)
+        ctx.mark_non_differentiable(alpha, zv)
+        return rgb, dist, alpha, zv
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_dist, _da, _dz):
+        cfg, ws, dev = ctx.cfg, ctx.ws, ctx.dev
+        if ws is None:
+            raise RuntimeError("nnr: backward called twice on the same render (workspace already released)")
+        lib = L.load()
+        R = cfg.n_rays
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_rgb = (d_rgb if d_rgb is not None else torch.zeros(R, 3, **f32)).contiguous().float()
+        d_dist = (d_dist if d_dist is not None else torch.zeros(R, **f32)).contiguous().float()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        need_w = any(ctx.needs_input_grad[7:])
+        need_rays = any(ctx.needs_input_grad[:3])
+        L.check(lib.nnr_composite_bwd(C.byref(cfg), L.ptr(d_rgb), L.ptr(d_dist), L.ptr(ws), st), "nnr_composite_bwd")
+        L.check(lib.nnr_mlp_dgrad(C.byref(cfg), L.ptr(ctx.packed), L.ptr(ws), st), "nnr_mlp_dgrad")
+        grads: List[Optional[torch.Tensor]] = [None] * (2 * L.N_LAYERS)
+        if need_w:
+            sizes = [int(np.prod(s)) for s in ctx.shapes]
+            offs = np.cumsum([0] + [(n + 3) // 4 * 4 for n in sizes])          # keep every view 16-byte aligned
+            flat = torch.zeros(int(offs[-1]), **f32)
+            views = [flat[offs[i]: offs[i] + sizes[i]].view(ctx.shapes[i]) for i in range(2 * L.N_LAYERS)]
+            gs = L.params_struct(views[:L.N_LAYERS], views[L.N_LAYERS:])
+            L.check(lib.nnr_mlp_wgrad(C.byref(cfg), C.byref(gs), L.ptr(_plan_for(cfg, dev)), L.ptr(ws), st), "nnr_mlp_wgrad")
+            grads = [v if ctx.needs_input_grad[7 + i] else None for i, v in enumerate(views)]
+        d_o = d_d = d_v = None
+        if need_rays:
+            d_o, d_d, d_v = (torch.empty(R, 3, **f32) for _ in range(3))
+            L.check(lib.nnr_ray_reduce(C.byref(cfg), L.ptr(d_o), L.ptr(d_d), L.ptr(d_v), L.ptr(ws), st), "nnr_ray_reduce")
+        ctx.ws = None
+        _give_workspace(cfg, dev, ws)
+        return (d_o, d_d, d_v, None, None, None, None, *grads)
+
+
+def render_rays(pts_o: torch.Tensor, pts_d: torch.Tensor, view_d: torch.Tensor, z_lo: torch.Tensor, z_hi: torch.Tensor,
+                jitter: Optional[torch.Tensor], weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], *,
+                hidden: int, dist_alpha: bool, white_bg: bool, relu_sigma: bool):
+    """(R,3) sampling origin / direction / view direction, (N) z interval tables, optional (R,N) jitter, the 12
+    nn.Linear weights and biases in state_dict order  ->  rgb (R,3), dist (R), alpha (R,N), z (R,N).
+    Differentiable w.r.t. pts_o, pts_d, view_d, weights, biases."""
+    opts = dict(hidden=hidden, dist_alpha=dist_alpha, white_bg=white_bg, relu_sigma=relu_sigma)
+    if not torch.is_grad_enabled():
+        # forward-only (eval / visualisation inside torch.no_grad): no stash, small workspace
+        return _RenderRays.apply(pts_o.detach(), pts_d.detach(), view_d.detach(), z_lo, z_hi, jitter, opts,
+                                 *[w.detach() for w in weights], *[b.detach() for b in biases])
+    return _RenderRays.apply(pts_o, pts_d, view_d, z_lo, z_hi, jitter, opts, *weights, *biases)
+
+
+def mlp_points(pts: torch.Tensor, view: torch.Tensor, weights, biases, *, hidden: int):
+    """Forward-only evaluation of the MLP on free-standing points: (S,3),(S,3) -> rgb (S,3), sigma_raw (S,).
+    Each point is rendered as a one-sample ray (origin = point, direction = 0) through the same fused kernel."""
+    _require_gpu(pts)
+    S, dev = pts.shape[0], pts.device
+    cfg = L.make_cfg(S, 1, hidden)
+    lib = L.load()
+    pts = pts.detach().contiguous().float()
+    view = view.detach().contiguous().float()
+    zeros3 = torch.zeros_like(pts)
+    z0 = torch.zeros(1, dtype=torch.float32, device=dev)
+    packed = _packed_for(cfg, [w.detach() for w in weights], [b.detach() for b in biases])
+    ws = _take_workspace(cfg, dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.nnr_mlp_fwd(C.byref(cfg), L.ptr(pts), L.ptr(zeros3), L.ptr(view), L.ptr(z0), L.ptr(z0), None,
+                            L.ptr(packed), L.ptr(ws), st), "nnr_mlp_fwd")
+    out = workspace_plane(cfg, ws, 0).clone()
+    _give_workspace(cfg, dev, ws)
+    return out[:, :3], out[:, 3]

@@ -1,0 +1,170 @@
+"""CPU tests of the host side: the `model` package mirrors the reference's API surface, parameter names and O(R) glue
+arithmetic; the render path itself refuses to run without the HIP kernels."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_util as gu
+import nerf_oracle as orc
+import oracle_backend
+
+
+def make_cfg(hidden=128, **rend):
+    cfg = {
+        'model': {'hidden_dim': hidden, 'pos_enc_levels': 10, 'dir_enc_levels': 4, 'occ_activation': 'softplus'},
+        'rendering': {'type': 'nope_nerf', 'n_max_network_queries': 64000, 'white_background': False, 'radius': 4.0,
+                      'num_points': 64, 'depth_range': [0.01, 10], 'dist_alpha': False, 'use_ray_dir': True,
+                      'normalise_ray': True, 'normal_loss': False, 'sample_option': 'uniform', 'outside_steps': 0},
+        'depth': {'type': 'None'},
+        'distortion': {'fix_scaleN': True},
+    }
+    cfg['rendering'].update(rend)
+    return cfg
+
+
+def test_public_surface_and_state_dict_names():
+    import model as mdl
+    for name in ("CheckpointIO", "nope_nerf", "Trainer", "Renderer", "get_model", "OfficialStaticNerf", "LearnPose",
+                 "LearnFocal", "Trainer_pose", "Learn_Distortion"):
+        assert hasattr(mdl, name), name                       # reference model/__init__.py:1-10
+    for hidden in (128, 256):
+        cfg = make_cfg(hidden)
+        net = mdl.OfficialStaticNerf(cfg)
+        model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device='cpu'), cfg, device='cpu')
+        ref = np.load(gu.GOLDEN + f"/weights_d{hidden}.npz")
+        sd = net.state_dict()
+        assert set(sd) == set(ref.files)                      # reference state_dict keys
+        for k in ref.files:
+            assert tuple(sd[k].shape) == ref[k].shape, k
+        assert all(k.startswith("renderer.model.") for k in model.state_dict())
+        assert float(net.fc_density.bias) == pytest.approx(0.1) and float(net.fc_rgb.bias[0]) == pytest.approx(0.02)
+        assert sum(isinstance(m, torch.nn.Linear) for m in model.modules()) == 12   # train.py:342-344 walks these
+        net.load_state_dict({k: torch.from_numpy(ref[k]) for k in ref.files})      # reference checkpoints load
+
+
+def test_no_cpu_fallback():
+    import model as mdl
+    cfg = make_cfg()
+    net = mdl.OfficialStaticNerf(cfg)
+    model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device='cpu'), cfg, device='cpu')
+    p = torch.zeros(1, 8, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(p, torch.arange(8), torch.eye(4)[None], torch.eye(4)[None], torch.eye(4)[None], 'nope_nerf',
+              depth_img=torch.ones(1, 1, 4, 4), img_size=(4, 4))
+    with pytest.raises(NotImplementedError):
+        model.renderer(p, None, torch.eye(4)[None], torch.eye(4)[None], torch.eye(4)[None], 'phong_renderer')
+
+
+def test_pixel_and_pose_helpers_match_oracle():
+    from model.common import arange_pixels, make_c2w, transform_to_world, origin_to_world, get_ndc_rays_fxfy
+    _, scaled = arange_pixels((7, 11))
+    assert torch.equal(scaled, orc.pixel_grid(7, 11))
+    g = torch.Generator().manual_seed(0)
+    r, t = torch.randn(3, generator=g) * 0.1, torch.randn(3, generator=g)
+    assert torch.allclose(make_c2w(r, t), orc.pose_c2w(r, t), atol=0, rtol=0)
+    assert torch.allclose(make_c2w(torch.zeros(3), t)[:3, :3], torch.eye(3))
+    K = torch.diag(torch.tensor([1.4, -2.5, -1.0, 1.0]))[None]
+    W = torch.inverse(orc.pose_c2w(r, t))[None]
+    S = torch.eye(4)[None]
+    pix = torch.rand(1, 9, 2, generator=g) * 2 - 1
+    d = torch.rand(1, 9, 1, generator=g) + 0.5
+    assert torch.allclose(transform_to_world(pix, d, K, W, S), orc.unproject(pix, d, K, W, S), atol=1e-6)
+    assert torch.allclose(origin_to_world(9, K, W, S), orc.camera_origin(9, K, W, S), atol=1e-7)
+    o, dd = torch.randn(5, 3, generator=g) + torch.tensor([0, 0, 3.0]), torch.randn(5, 3, generator=g)
+    a = get_ndc_rays_fxfy(torch.tensor([1.4, -2.5]), 1.0, o, dd)
+    b = orc.ndc_rays(torch.tensor([1.4, -2.5]), 1.0, o, dd)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("dst,src", [((60, 80), (30, 40)), ((540, 960), (384, 672)), ((75, 100), (756, 1008)),
+                                       ((60, 80), (60, 80)), ((33, 17), (7, 50))])
+def test_nearest_gather_equals_interpolate(dst, src):
+    """Gather-at-source == F.interpolate(nearest) + gather (reference model/network.py:22-24)."""
+    from model.network import nearest_source_index
+    h, w = dst
+    img = torch.rand(1, 1, *src)
+    idx = torch.randperm(h * w)[:500]
+    ref = F.interpolate(img, dst, mode='nearest').view(-1)[idx]
+    ys = nearest_source_index(torch.div(idx, w, rounding_mode='floor'), h, src[0])
+    xs = nearest_source_index(idx % w, w, src[1])
+    assert torch.equal(img[0, 0][ys, xs], ref)
+
+
+def test_distortion_semantics():
+    from model.distortions import Learn_Distortion
+    d = Learn_Distortion(3, True, True, {'distortion': {'fix_scaleN': True}})
+    with torch.no_grad():
+        d.global_scales[0] = 0.001
+        d.global_scales[2] = 5.0
+    s0, _ = d(0)
+    s2, _ = d(2)
+    assert float(s0) == pytest.approx(0.01) and not s0.requires_grad        # clamped to a constant
+    assert float(s2) == 1.0                                                 # last camera pinned
+    assert d(1)[0].requires_grad
+
+
+def test_z_tables_match_reference_sampling():
+    import model as mdl
+    cfg = make_cfg()
+    r = mdl.Renderer(mdl.OfficialStaticNerf(cfg), cfg['rendering'], device='cpu')
+    u = torch.rand(1, 5, 64)
+    lo, hi = r._z_tables(64, 0.01, 10, True, 'cpu')
+    assert torch.equal(lo + (hi - lo) * u[0], orc.sample_z(5, 64, 0.01, 10, u)[0])
+    lo, hi = r._z_tables(64, 0.0, 1.0, False, 'cpu')
+    assert torch.equal(lo, orc.sample_z(1, 64, 0.0, 1.0, None)[0, 0]) and lo is hi or torch.equal(lo, hi)
+
+
+@pytest.mark.parametrize("name", ["tanks_d128", "llff_ndc_d128", "uniform_distalpha_masked_d128", "white_nonorm_d128",
+                                  "zero_pose_d128"])
+def test_renderer_host_glue_against_reference_golden(name, monkeypatch):
+    """model.Renderer / nope_nerf / LearnPose / Learn_Distortion with the kernels swapped for the CPU oracle must
+    reproduce the reference's outputs and gradients: pins the O(R) host arithmetic (ray generation through the matrix
+    inverses, masks, NDC warp, depth_gt) and the autograd edges to pose and distortion."""
+    import model as mdl
+    import model.rendering as rendering
+    monkeypatch.setattr(rendering.nnr, "render_rays", oracle_backend.render_rays)
+    case = gu.load_case(name)
+    t = gu.tensors(case)
+    rc = gu.render_cfg(case)
+    cfg = make_cfg(int(case["cfg.hidden"]), **{k: rc[k] for k in ('num_points', 'dist_alpha', 'sample_option', 'depth_range',
+                                                                  'normalise_ray', 'white_background')})
+    net = mdl.OfficialStaticNerf(cfg)
+    net.load_state_dict(case["weights"])
+    model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device='cpu'), cfg, device='cpu')
+    pose = mdl.LearnPose(gu.N_CAMS, True, True, cfg)
+    dist = mdl.Learn_Distortion(gu.N_CAMS, True, True, cfg)
+    with torch.no_grad():
+        pose.r.copy_(t["pose_r"]); pose.t.copy_(t["pose_t"])
+        dist.global_scales.copy_(t["scales"]); dist.global_shifts.copy_(t["shifts"])
+    h, w, cam = int(case["cfg.h"]), int(case["cfg.w"]), int(case["cfg.cam"])
+    world_mat = torch.inverse(pose(cam)).unsqueeze(0)
+    sc, sh = dist(cam)
+    depth_in = t["depth_img"] * sc + sh
+    from model.common import arange_pixels
+    p = arange_pixels((h, w))[1][:, t["ray_idx"]]
+    torch.manual_seed(43)   # the renderer's torch.rand(1,R,N) then equals the fixture's jitter
+    out = model(p, t["ray_idx"], t["K"], world_mat, torch.eye(4)[None], 'nope_nerf', it=0, depth_img=depth_in,
+                add_noise=t["jitter"] is not None, img_size=(h, w))
+    for k in ("rgb", "depth_pred", "depth_gt", "alpha", "z_vals"):
+        np.testing.assert_allclose(out[k].detach().numpy(), case["out." + k], rtol=0, atol=2e-6, err_msg=k)
+    rgb_gt = t["img"].view(1, 3, h * w).permute(0, 2, 1)[:, t["ray_idx"]]
+    from model.losses import Loss
+    crit = Loss({'depth_loss_type': 'l1'})
+    loss = crit.get_rgb_full_loss(out['rgb'], rgb_gt, 'l1') + 0.04 * crit.get_depth_loss(out['depth_pred'], out['depth_gt'])
+    assert float(loss) == pytest.approx(float(case["out.loss"]), abs=1e-6)
+    loss.backward()
+    got = {"w." + k: v.grad for k, v in net.named_parameters()}
+    got.update(pose_r=pose.r.grad, pose_t=pose.t.grad, scales=dist.global_scales.grad, shifts=dist.global_shifts.grad)
+    for k, (kind, ref, norm) in gu.golden_grads(case).items():
+        gu.compare_grad(k, got[k], kind, ref, norm, 3e-5)
+
+
+def test_shard_bounds_cover():
+    from nnr.parallel import shard_bounds
+    for n in (1, 7, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
