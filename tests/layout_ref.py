@@ -1,0 +1,115 @@
+"""numpy restatement of the device data layouts (nope-nerf_amd/csrc/nnr_layout.h): the packed A-fragment order and the
+register layout of activations, plus an emulation of v_mfma_f32_32x32x2_f32's operand/result mapping as documented in
+the CDNA4 guide (A: lane l holds A[l&31][l>>5]; B: lane l holds B[l>>5][l&31]; D register rho of lane l is
+D[(rho&3)+8*(rho>>2)+4*(l>>5)][l&31]).  Used by CPU tests to prove the index algebra closes (pack -> chained layers
+-> wgrad tiles reproduce plain matmuls) and by the GPU tests to check the pack kernel bit-exactly."""
+import numpy as np
+
+LAYERS = ("layers0.0", "layers0.2", "layers0.4", "layers0.6", "layers1.0", "layers1.2", "layers1.4", "layers1.6",
+          "fc_density", "fc_feature", "rgb_layers.0", "fc_rgb")
+
+
+def fwd_parts(D):
+    DT, HT = D // 32, D // 64
+    return [  # (layer, transpose, KT, MT, m_real, k_real, off)
+        (0, 0, 2, DT, D, 63, 0), (1, 0, DT, DT, D, D, 0), (2, 0, DT, DT, D, D, 0), (3, 0, DT, DT, D, D, 0),
+        (4, 0, DT, DT, D, D, 0), (4, 0, 2, DT, D, 63, D), (5, 0, DT, DT, D, D, 0), (6, 0, DT, DT, D, D, 0),
+        (7, 0, DT, DT, D, D, 0), (8, 0, DT, 1, 1, D, 0), (9, 0, DT, DT, D, D, 0), (10, 0, DT, HT, D // 2, D, 0),
+        (10, 0, 1, HT, D // 2, 27, D), (11, 0, HT, 1, 3, D // 2, 0)]
+
+
+def bwd_parts(D):
+    DT, HT = D // 32, D // 64
+    return [
+        (11, 1, 1, HT, D // 2, 3, 0), (10, 1, HT, DT + 1, D + 27, D // 2, 0), (9, 1, DT, DT, D, D, 0), (8, 1, 1, DT, D, 1, 0),
+        (7, 1, DT, DT, D, D, 0), (6, 1, DT, DT, D, D, 0), (5, 1, DT, DT, D, D, 0), (4, 1, DT, DT + 2, D + 63, D, 0),
+        (3, 1, DT, DT, D, D, 0), (2, 1, DT, DT, D, D, 0), (1, 1, DT, DT, D, D, 0), (0, 1, DT, 2, 63, D, 0)]
+
+
+def bias_pads(D):
+    return [D] * 8 + [32, D, (D // 2 + 31) // 32 * 32, 32]
+
+
+def part_matrix(W, part):
+    """Dense zero-padded A[32*MT][32*KT] of a part."""
+    layer, tr, KT, MT, m_real, k_real, off = part
+    A = np.zeros((32 * MT, 32 * KT), dtype=np.float32)
+    if tr:
+        A[:m_real, :k_real] = W[:k_real, off:off + m_real].T
+    else:
+        A[:m_real, :k_real] = W[:m_real, off:off + k_real]
+    return A
+
+
+def pack_part(A, KT, MT):
+    """[4*KT][MT][64 lanes][4] with lane l -> A[32*mt + (l&31)][8*g + 4*(l>>5) + i]."""
+    out = np.zeros((4 * KT, MT, 64, 4), dtype=np.float32)
+    lane = np.arange(64)
+    for g in range(4 * KT):
+        for mt in range(MT):
+            rows = 32 * mt + (lane & 31)
+            for i in range(4):
+                out[g, mt, :, i] = A[rows, 8 * g + 4 * (lane >> 5) + i]
+    return out.reshape(-1)
+
+
+def pack_all(weights, biases, D):
+    """weights/biases: lists of 12 numpy arrays in state_dict order -> the packed buffer nnr_pack_weights produces."""
+    chunks = []
+    for part in fwd_parts(D) + bwd_parts(D):
+        chunks.append(pack_part(part_matrix(weights[part[0]], part), part[2], part[3]))
+    for b, pad in zip(biases, bias_pads(D)):
+        v = np.zeros(pad, dtype=np.float32)
+        v[:b.size] = b
+        chunks.append(v)
+    return np.concatenate(chunks)
+
+
+# ---- register layout + MFMA emulation -------------------------------------------------------------------------------
+def frag_feature(r, h):
+    return 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h
+
+
+def to_regs(X):
+    """X[features 32*T][32 samples] -> regs[16*T][64 lanes]."""
+    T = X.shape[0] // 32
+    regs = np.zeros((16 * T, 64), dtype=X.dtype)
+    for r in range(16 * T):
+        for l in range(64):
+            regs[r, l] = X[frag_feature(r, l >> 5), l & 31]
+    return regs
+
+
+def from_regs(regs):
+    T = regs.shape[0] // 16
+    X = np.zeros((32 * T, 32), dtype=regs.dtype)
+    for r in range(16 * T):
+        for l in range(64):
+            X[frag_feature(r, l >> 5), l & 31] = regs[r, l]
+    return X
+
+
+def mfma32(a, b, c):
+    """a, b: (64,) per-lane operands; c: (16, 64) accumulator registers. Returns the updated accumulator."""
+    A = np.zeros((32, 2), dtype=np.float64)
+    B = np.zeros((2, 32), dtype=np.float64)
+    lane = np.arange(64)
+    A[lane & 31, lane >> 5] = a
+    B[lane >> 5, lane & 31] = b
+    Dm = A @ B
+    out = c.copy()
+    for rho in range(16):
+        rows = (rho & 3) + 8 * (rho >> 2) + 4 * (lane >> 5)
+        out[rho] += Dm[rows, lane & 31]
+    return out
+
+
+def gemm_part_emulated(packed_part, in_regs, KT, MT):
+    """Mirror of nnr_device.h::gemm_part: returns acc[MT][16][64]."""
+    frag = packed_part.reshape(4 * KT, MT, 64, 4)
+    acc = np.zeros((MT, 16, 64), dtype=np.float64)
+    for g in range(4 * KT):
+        for i in range(4):
+            for mt in range(MT):
+                acc[mt] = mfma32(frag[g, mt, :, i], in_regs[4 * g + i], acc[mt])
+    return acc

@@ -1,0 +1,209 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI via the `model` package exactly as train.py would,
+against (a) the golden vectors minted from the real reference and (b) the CPU oracle on the same seeded inputs.
+Tolerance: 1e-4 max-abs for rgb / depth / gradients (gradients normalised by the golden tensor's max-abs when that
+exceeds 1) -- the fp32 bar of BASELINE.json; indices, masks and z-samples must agree to 1e-6."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import layout_ref as lr
+import nerf_oracle as orc
+import trace_util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _loaded_native():
+    maps = open("/proc/self/maps").read()
+    return "libnnr.so" in maps
+
+
+def build(case, device):
+    import model as mdl
+    from test_host_logic import make_cfg
+    rc = gu.render_cfg(case)
+    cfg = make_cfg(int(case["cfg.hidden"]), **{k: rc[k] for k in ('num_points', 'dist_alpha', 'sample_option', 'depth_range',
+                                                                  'normalise_ray', 'white_background')})
+    net = mdl.OfficialStaticNerf(cfg)
+    net.load_state_dict(case["weights"])
+    model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device=device), cfg, device=device)
+    pose = mdl.LearnPose(gu.N_CAMS, True, True, cfg).to(device)
+    dist = mdl.Learn_Distortion(gu.N_CAMS, True, True, cfg).to(device)
+    t = gu.tensors(case)
+    with torch.no_grad():
+        pose.r.copy_(t["pose_r"]); pose.t.copy_(t["pose_t"])
+        dist.global_scales.copy_(t["scales"]); dist.global_shifts.copy_(t["shifts"])
+    return net, model, pose, dist, t
+
+
+def run_hip(case, eval_=False):
+    dev = torch.device("cuda")
+    net, model, pose, dist, t = build(case, dev)
+    from model.common import arange_pixels
+    from model.losses import Loss
+    h, w, cam = int(case["cfg.h"]), int(case["cfg.w"]), int(case["cfg.cam"])
+    ray_idx = t["ray_idx"].to(dev)
+    world_mat = torch.inverse(pose(cam)).unsqueeze(0)
+    sc, sh = dist(cam)
+    depth_in = t["depth_img"].to(dev) * sc + sh
+    p = arange_pixels((h, w), device=dev)[1][:, ray_idx]
+    renderer = model.renderer
+    jit = t["jitter"]
+    if jit is not None:
+        # feed the fixture's jitter instead of a fresh torch.rand draw (GPU and CPU generators differ)
+        orig = torch.rand
+        torch.rand = lambda *a, **k: jit.to(dev)
+    try:
+        ctx = torch.no_grad() if eval_ else torch.enable_grad()
+        with ctx:
+            out = model(p, ray_idx, t["K"].to(dev), world_mat, torch.eye(4, device=dev)[None], 'nope_nerf', it=0,
+                        eval_mode=eval_, depth_img=depth_in, add_noise=jit is not None, img_size=(h, w))
+    finally:
+        if jit is not None:
+            torch.rand = orig
+    grads = {}
+    if not eval_:
+        rgb_gt = t["img"].to(dev).view(1, 3, h * w).permute(0, 2, 1)[:, ray_idx]
+        crit = Loss({'depth_loss_type': 'l1'})
+        loss = crit.get_rgb_full_loss(out['rgb'], rgb_gt, 'l1') + 0.04 * crit.get_depth_loss(out['depth_pred'], out['depth_gt'])
+        loss.backward()
+        out["loss"] = loss.detach()
+        grads = {"w." + k: v.grad for k, v in net.named_parameters()}
+        grads.update(pose_r=pose.r.grad, pose_t=pose.t.grad, scales=dist.global_scales.grad, shifts=dist.global_shifts.grad)
+    return out, grads
+
+
+@pytest.mark.parametrize("D", [128, 256])
+def test_pack_kernel_is_bit_exact(D):
+    from nnr import lib as L
+    dev = torch.device("cuda")
+    params = orc.init_params(D, 3)
+    w = [params[n + ".weight"] for n in L.LAYER_NAMES]
+    b = [params[n + ".bias"] for n in L.LAYER_NAMES]
+    cfg = L.make_cfg(1, 1, D)
+    lib = L.load()
+    packed = torch.empty(lib.nnr_packed_floats(C.byref(cfg)), device=dev)
+    wd, bd = [x.to(dev) for x in w], [x.to(dev) for x in b]
+    ps = L.params_struct(wd, bd)
+    L.check(lib.nnr_pack_weights(C.byref(cfg), C.byref(ps), L.ptr(packed),
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "pack")
+    ref = lr.pack_all([x.numpy() for x in w], [x.numpy() for x in b], D)
+    assert np.array_equal(packed.cpu().numpy(), ref)
+    assert _loaded_native()
+
+
+@pytest.mark.parametrize("name", gu.GRAD_CASES)
+def test_training_step_matches_reference_golden(name):
+    case = gu.load_case(name)
+    out, grads = run_hip(case)
+    assert _loaded_native()
+    np.testing.assert_allclose(out["z_vals"].cpu().numpy(), case["out.z_vals"], rtol=0, atol=1e-6)
+    for k in ("rgb", "depth_pred", "depth_gt", "alpha"):
+        got = out[k].detach().cpu().numpy()
+        assert got.shape == case["out." + k].shape, k         # same mask -> same number of valid depths
+        np.testing.assert_allclose(got, case["out." + k], rtol=0, atol=TOL, err_msg=k)
+    assert abs(float(out["loss"]) - float(case["out.loss"])) <= TOL
+    for k, (kind, ref, norm) in gu.golden_grads(case).items():
+        gu.compare_grad(k, grads[k], kind, ref, norm, TOL)
+
+
+@pytest.mark.parametrize("name", gu.EVAL_CASES)
+def test_eval_render_matches_reference_golden(name):
+    case = gu.load_case(name)
+    out, _ = run_hip(case, eval_=True)
+    for k in ("rgb", "depth_pred", "depth_gt", "alpha", "z_vals"):
+        got = out[k].detach().cpu().numpy()
+        assert got.shape == case["out." + k].shape, k
+        np.testing.assert_allclose(got, case["out." + k], rtol=0, atol=TOL, err_msg=k)
+
+
+def test_against_live_oracle_full_gradients():
+    """Same check against the oracle run live on this host (full tensors for the D=256 case, not the subsample)."""
+    case = gu.load_case("tanks_d256_n192")
+    out, grads = run_hip(case)
+    oout, ograds = gu.run_oracle(case)
+    np.testing.assert_allclose(out["rgb"].detach().cpu().numpy(), oout["rgb"].detach().numpy(), rtol=0, atol=TOL)
+    for k, g in ograds.items():
+        ref = g.detach().double().numpy()
+        got = grads[k].detach().cpu().double().numpy()
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(got - ref).max() / scale <= TOL, k
+
+
+def _synthetic(D, R, N, seed=0, dist_alpha=False):
+    g = torch.Generator().manual_seed(seed)
+    params = orc.init_params(D, seed + 1)
+    d = torch.randn(R, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    o = (torch.randn(3, generator=g) * 0.1).expand(R, 3).contiguous()
+    z = torch.linspace(0, 1, N)
+    z = 0.01 * (1 - z) + 10 * z
+    mid = 0.5 * (z[1:] + z[:-1])
+    return params, o, d, torch.cat([z[:1], mid]), torch.cat([mid, z[-1:]]), torch.rand(R, N, generator=g)
+
+
+def _hip_render(params, o, d, lo, hi, jit, D, d_rgb=None, d_dist=None, dist_alpha=False):
+    import nnr
+    dev = torch.device("cuda")
+    from nnr import lib as L
+    w = [params[n + ".weight"].to(dev).requires_grad_(True) for n in L.LAYER_NAMES]
+    b = [params[n + ".bias"].to(dev).requires_grad_(True) for n in L.LAYER_NAMES]
+    oo, dd = o.to(dev).requires_grad_(True), d.to(dev).requires_grad_(True)
+    vv = (-d).to(dev).requires_grad_(True)
+    rgb, dist, alpha, z = nnr.render_rays(oo, dd, vv, lo.to(dev), hi.to(dev), jit.to(dev) if jit is not None else None, w, b,
+                                          hidden=D, dist_alpha=dist_alpha, white_bg=False, relu_sigma=False)
+    grads = None
+    if d_rgb is not None:
+        (rgb * d_rgb.to(dev)).sum().add((dist * d_dist.to(dev)).sum()).backward()
+        grads = [oo.grad, dd.grad, vv.grad] + [x.grad for x in w] + [x.grad for x in b]
+    return rgb.detach(), dist.detach(), alpha, grads
+
+
+def test_full_size_properties():
+    """BASELINE.json config 2 (1024 rays x 192 samples, D=256): size-independent properties of the path --
+    determinism, ray-permutation equivariance, alpha/weight bounds, linearity of the backward in the upstream
+    gradient, and shard additivity (sum of half-batch gradients == full-batch gradient: the data-parallel identity)."""
+    D, R, N = 256, 1024, 192
+    params, o, d, lo, hi, jit = _synthetic(D, R, N)
+    g = torch.Generator().manual_seed(5)
+    d_rgb, d_dist = torch.randn(R, 3, generator=g) / R, torch.randn(R, generator=g) / R
+    rgb, dist, alpha, grads = _hip_render(params, o, d, lo, hi, jit, D, d_rgb, d_dist)
+    rgb2, dist2, _, _ = _hip_render(params, o, d, lo, hi, jit, D)
+    assert torch.equal(rgb, rgb2) and torch.equal(dist, dist2)                      # forward is deterministic
+    assert torch.all((alpha >= 0) & (alpha <= 1)) and torch.all((rgb > 0) & (rgb < 1.0 + 1e-5))
+    assert torch.all(dist >= 0) and torch.all(dist <= 10.0 * (1 + 1e-4))
+    perm = torch.randperm(R, generator=g)
+    rgb_p, dist_p, _, _ = _hip_render(params, o[perm], d[perm], lo, hi, jit[perm], D)
+    assert torch.equal(rgb_p, rgb[perm.cuda()]) and torch.equal(dist_p, dist[perm.cuda()])   # rays are independent
+    # linearity: grads(2 g) == 2 grads(g)
+    _, _, _, grads2 = _hip_render(params, o, d, lo, hi, jit, D, 2 * d_rgb, 2 * d_dist)
+    for a, b2 in zip(grads, grads2):
+        scale = max(1.0, float(a.abs().max()))
+        assert float((2 * a - b2).abs().max()) / scale <= 2e-5
+    # shard additivity
+    half = R // 2
+    _, _, _, ga = _hip_render(params, o[:half], d[:half], lo, hi, jit[:half], D, d_rgb[:half], d_dist[:half])
+    _, _, _, gb = _hip_render(params, o[half:], d[half:], lo, hi, jit[half:], D, d_rgb[half:], d_dist[half:])
+    for full, x, y in zip(grads[3:], ga[3:], gb[3:]):
+        scale = max(1.0, float(full.abs().max()))
+        assert float((full - (x + y)).abs().max()) / scale <= 2e-5
+    assert torch.allclose(torch.cat([ga[0], gb[0]]), grads[0], atol=1e-6) and torch.allclose(torch.cat([ga[1], gb[1]]), grads[1], atol=1e-5)
+
+
+def test_full_size_against_oracle_sample():
+    """Config-2 shape on the HIP path vs the oracle on a 16-ray subset (rays are independent, so the subset's forward
+    must agree exactly with the same rays inside the big batch)."""
+    D, R, N = 256, 1024, 192
+    params, o, d, lo, hi, jit = _synthetic(D, R, N, seed=3)
+    rgb, dist, _, _ = _hip_render(params, o, d, lo, hi, jit, D)
+    sel = torch.arange(0, R, 64)
+    P = {k: v for k, v in params.items()}
+    with torch.no_grad():
+        orgb, odist, _ = trace_util.traced_render(P, o[sel], d[sel], -d[sel], lo, hi, jit[sel], dist_alpha=False, white_bg=False)
+    assert float((rgb[sel.cuda()].cpu() - orgb).abs().max()) <= TOL
+    assert float((dist[sel.cuda()].cpu() - odist).abs().max()) <= TOL * 10      # distances reach 10
