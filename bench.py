@@ -160,7 +160,7 @@ def cpu_baseline(sample_rays=192, steps=3):
     sample of the same workload: `sample_rays` rays x 192 samples, D=256, forward + loss heads + backward."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as orc
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)   # the GEMMs here are (12k x 256) x (256 x 256): more threads only add sync cost
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     params = {k: v.requires_grad_(True) for k, v in orc.init_params(HIDDEN, 1).items()}

@@ -102,7 +102,7 @@ std::vector<Unit> wgrad_units(int D) {
 }
 
 constexpr int kTargetWaves = 1024;  // 256 CUs x 4 SIMDs, one 256-accumulator wave each
-constexpr int kGranule = 8;         // samples per pipeline stage of the wgrad kernel (2 * kU)
+constexpr int kGranule = 16;        // samples per loop iteration of the wgrad kernel (two stages of kU = 4 sample pairs)
 
 std::vector<WgradJob> build_plan(const nnr_cfg* c) {
     const WsLayout w = ws_layout(c);

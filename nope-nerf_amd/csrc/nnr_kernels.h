@@ -25,7 +25,7 @@ struct MlpFwdArgs {
 
 struct MlpDgradArgs {
     const float* packed;
-    const float* ws_dout4;  // (S_pad,4): d rgb_pre[3], d sigma_raw
+    float* ws_dout4;        // (S_pad,4): d rgb_pre[3], d sigma_raw (rows >= S are zero-filled here)
     const float* ws_xe;     // posenc stash (for d gamma/dp)
     const float* ws_xf;     // [feature|direnc] stash (direnc part used)
     const uint32_t* ws_mask;

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
 
     f32x4 dout = {0.f, 0.f, 0.f, 0.f};
     if (live) dout = *reinterpret_cast<const f32x4*>(a.ws_dout4 + 4 * s);
+    else if (half == 0) *reinterpret_cast<f32x4*>(a.ws_dout4 + 4 * s) = dout;   // padded rows feed the weight-gradient kernel: zero them
 
     // ---- colour branch ----
     // d rgb_pre (3, padded to one 32-row tile): rows 0..2 = registers 0..2 of half 0

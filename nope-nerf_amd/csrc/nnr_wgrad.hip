@@ -18,17 +18,22 @@ namespace nnr {
 template <int W>
 struct Vec { float v[W]; };
 
+// Unconditional vector load, no masking of the value.  A lane outside the valid column range reads a valid address (its
+// pointer is clamped to column 0 by the caller); what it contributes lands only in its own row / column of the MFMA
+// result, which the flush never writes.  Neither a branch around the load nor a select on the loaded value is allowed
+// here: both make hipcc wait for the just-issued prefetch (vmcnt(0) at the join / before the v_cndmask) and serialise
+// the pipeline (cdna_hip_programming.md, "three .s-level traps" (c)).
 template <int W>
-__device__ __forceinline__ Vec<W> load_vec(const float* p, bool ok) {
+__device__ __forceinline__ Vec<W> load_vec(const float* p) {
     Vec<W> r;
     if constexpr (W == 4) {
-        f32x4 t = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
         r.v[0] = t[0]; r.v[1] = t[1]; r.v[2] = t[2]; r.v[3] = t[3];
     } else if constexpr (W == 2) {
-        f32x2 t = ok ? *reinterpret_cast<const f32x2*>(p) : f32x2{0.f, 0.f};
+        const f32x2 t = *reinterpret_cast<const f32x2*>(p);
         r.v[0] = t[0]; r.v[1] = t[1];
     } else {
-        r.v[0] = ok ? *p : 0.f;
+        r.v[0] = *p;
     }
     return r;
 }
@@ -40,8 +45,8 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
     const int half = lane >> 5, m = lane & 31;
     const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
     const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
-    const float* dptr = a.ws + a.plane_off[jb.d_plane] + jb.d_col0 + MI * m + (int64_t)half * dp;
-    const float* xptr = a.ws + a.plane_off[jb.x_plane] + jb.x_col0 + NI * m + (int64_t)half * xp;
+    const float* dptr = a.ws + a.plane_off[jb.d_plane] + jb.d_col0 + (dok ? MI * m : 0) + (int64_t)half * dp;
+    const float* xptr = a.ws + a.plane_off[jb.x_plane] + jb.x_col0 + (xok ? NI * m : 0) + (int64_t)half * xp;
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -54,34 +59,42 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
 #pragma unroll
     for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
 
-    Vec<MI> dc[kU], dn[kU];
-    Vec<NI> xc[kU], xn[kU];
-    int64_t k = jb.k0;
+    // Two register stages (A, B) of kU k-steps each, explicitly ping-ponged: the loads of one stage are issued before
+    // the 16*kU MFMAs of the other, and no register copies sit between a load and its first use (a rotating
+    // "cur = next" copy makes hipcc wait for the prefetch right after issuing it).  Sample ranges are multiples of
+    // 4*kU = 16 samples (kGranule in nnr_api.cpp).
+    Vec<MI> dA[kU], dB[kU];
+    Vec<NI> xA[kU], xB[kU];
+    auto load_stage = [&](Vec<MI>(&d)[kU], Vec<NI>(&x)[kU], int64_t kk) {
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
-        dc[u] = load_vec<MI>(dptr + (k + 2 * u) * dp, dok);
-        xc[u] = load_vec<NI>(xptr + (k + 2 * u) * xp, xok);
-    }
-    for (; k < jb.k1; k += 2 * kU) {
-        const int64_t kn = k + 2 * kU;
-        if (kn < jb.k1) {
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                dn[u] = load_vec<MI>(dptr + (kn + 2 * u) * dp, dok);
-                xn[u] = load_vec<NI>(xptr + (kn + 2 * u) * xp, xok);
-            }
+        for (int u = 0; u < kU; ++u) {
+            d[u] = load_vec<MI>(dptr + (kk + 2 * u) * dp);
+            x[u] = load_vec<NI>(xptr + (kk + 2 * u) * xp);
         }
+    };
+    auto compute = [&](const Vec<MI>(&d)[kU], const Vec<NI>(&x)[kU]) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = mfma32(dc[u].v[i], xc[u].v[j], acc[i][j]);
-                bsum[i] += dc[u].v[i];
+                for (int j = 0; j < NI; ++j) acc[i][j] = mfma32(d[u].v[i], x[u].v[j], acc[i][j]);
+                bsum[i] += d[u].v[i];
             }
         }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) { dc[u] = dn[u]; xc[u] = xn[u]; }
+    };
+    load_stage(dA, xA, jb.k0);
+    for (int64_t k = jb.k0; k < jb.k1; k += 4 * kU) {
+        // sched_barrier(0): nothing moves across.  Without it the scheduler sinks each load down to its first use
+        // (load; vmcnt(0); mfma) and the 4096-cycle MFMA block no longer covers the memory latency.
+        load_stage(dB, xB, k + 2 * kU);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(dA, xA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(dA, xA, (k + 4 * kU < jb.k1) ? k + 4 * kU : k);   // the last refill re-reads (unused): no branch around loads
+        __builtin_amdgcn_sched_barrier(0);
+        compute(dB, xB);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // flush: D[row m'][col n] of sub-tile (i,j) -> dW[row0 + MI*m' + i][wcol0 + NI*n + j]
@@ -96,7 +109,7 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
             for (int r = 0; r < 16; ++r) {
                 const int mr = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int row = jb.row0 + MI * mr + i;
-                if (cok && row < jb.rows_real) unsafeAtomicAdd(gw + (int64_t)row * jb.ldw + colw, acc[i][j][r]);
+                if (cok && MI * mr + i < jb.d_valid && row < jb.rows_real) unsafeAtomicAdd(gw + (int64_t)row * jb.ldw + colw, acc[i][j][r]);
             }
         }
     if (jb.bias) {

@@ -102,7 +102,8 @@ def run(D, R, N, dist_alpha, white_bg, seed=0):
     # backward
     loss = (orgb * d_rgb).sum() + (odist * d_dist).sum()
     loss.backward()
-    L.check(lib.nnr_composite_bwd(C.byref(cfg), L.ptr(cu(d_rgb)), L.ptr(cu(d_dist)), L.ptr(ws), st), "composite_bwd")
+    d_rgb_d, d_dist_d = cu(d_rgb), cu(d_dist)      # keep the device copies alive until the kernels ran
+    L.check(lib.nnr_composite_bwd(C.byref(cfg), L.ptr(d_rgb_d), L.ptr(d_dist_d), L.ptr(ws), st), "composite_bwd")
     L.check(lib.nnr_mlp_dgrad(C.byref(cfg), L.ptr(packed), L.ptr(ws), st), "mlp_dgrad")
     gw = [torch.zeros_like(w) for w in w_d]
     gb = [torch.zeros_like(b) for b in b_d]

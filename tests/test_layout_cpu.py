@@ -100,7 +100,7 @@ def test_wgrad_plan_covers_every_weight_once(D, R, N):
     bias_cover = [np.zeros(s[0], dtype=np.int64) for s in shapes]
     m = np.arange(32)
     for j in jobs:
-        assert j.k0 % 8 == 0 and j.k1 % 8 == 0 and 0 <= j.k0 < j.k1 <= S_pad
+        assert j.k0 % 16 == 0 and j.k1 % 16 == 0 and 0 <= j.k0 < j.k1 <= S_pad
         assert j.ldw == shapes[j.layer][1] and j.rows_real == shapes[j.layer][0]
         rows = (j.row0 + j.MI * m[:, None] + np.arange(j.MI)[None, :]).reshape(-1)
         dvalid = (j.MI * m[:, None] + np.arange(j.MI)[None, :]).reshape(-1) < j.d_valid

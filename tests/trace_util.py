@@ -7,6 +7,11 @@ import nerf_oracle as orc
 from nnr import LAYER_NAMES
 
 
+def keep(t):
+    if t.requires_grad:
+        t.retain_grad()
+
+
 def traced_mlp(params, pts, view):
     """Returns dict of activations; pre-activations are leaves of interest (retain_grad)."""
     t = {}
@@ -19,25 +24,25 @@ def traced_mlp(params, pts, view):
         if i == 4:
             h = torch.cat([h, e], dim=-1)
         pre = lin(n, h)
-        pre.retain_grad()
+        keep(pre)
         t[f"pre{i + 1}"] = pre
         h = F.relu(pre)
         t[f"h{i + 1}"] = h
     raw = lin("fc_density", h)
-    raw.retain_grad()
+    keep(raw)
     t["raw"] = raw
     f = lin("fc_feature", h)
-    f.retain_grad()
+    keep(f)
     t["f"] = f
     dirv = orc.posenc(view, 4)
     t["dir"] = dirv
     gpre = lin("rgb_layers.0", torch.cat([f, dirv], dim=-1))
-    gpre.retain_grad()
+    keep(gpre)
     t["gpre"] = gpre
     g = F.relu(gpre)
     t["g"] = g
     rgbpre = lin("fc_rgb", g)
-    rgbpre.retain_grad()
+    keep(rgbpre)
     t["rgbpre"] = rgbpre
     t["rgb"] = torch.sigmoid(rgbpre)
     return t
@@ -50,7 +55,7 @@ def traced_render(params, pts_o, pts_d, view_d, z_lo, z_hi, jitter, *, dist_alph
     if jitter is not None:
         z = z_lo + (z_hi - z_lo) * jitter.view(R, N)
     pts = (pts_o.unsqueeze(1) + pts_d.unsqueeze(1) * z.unsqueeze(-1)).reshape(-1, 3)
-    pts.retain_grad() if pts.requires_grad else None
+    keep(pts)
     view = view_d.unsqueeze(1).expand(R, N, 3).reshape(-1, 3)
     if view.requires_grad:
         view.retain_grad()
