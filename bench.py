@@ -129,6 +129,10 @@ def kernel_roofline(net, device, reps=5):
         'mlp_dgrad': lambda: lib.nnr_mlp_dgrad(C.byref(cfg), L.ptr(packed), L.ptr(ws), st),
         'mlp_wgrad': lambda: lib.nnr_mlp_wgrad(C.byref(cfg), C.byref(gs), L.ptr(plan), L.ptr(ws), st),
     }
+    cfg_inf = L.make_cfg(R, N, D)      # forward-only variant (eval / visualisation): no stash
+    ws_inf = torch.empty(lib.nnr_workspace_floats(C.byref(cfg_inf)), device=device)
+    stages['mlp_fwd_infer'] = lambda: lib.nnr_mlp_fwd(C.byref(cfg_inf), L.ptr(o), L.ptr(d), L.ptr(view), L.ptr(lo), L.ptr(hi),
+                                                      L.ptr(jit), L.ptr(packed), L.ptr(ws_inf), st)
     times = {}
     for name, fn in stages.items():
         L.check(fn(), name)            # warm-up + makes the workspace valid for the next stage

@@ -16,12 +16,18 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 // acc[mt] += A_part[32*mt.., :] * in   for one layer part.
-//   in   : 16*KT registers in fragment layout (this wave's 32 samples)
-//   frag : packed A fragments of the part, [4*KT][MT][64] float4, already offset by +lane
+//   in    : 16*KT registers in fragment layout (this wave's 32 samples)
+//   frag  : packed A fragments of the part, [4*KT][MT][64] float4, already offset by +lane
+//   stash : optional (sample, feature) row-major destination of `in` (row of this lane's sample, + 4*half): the four
+//           registers consumed by k-group g are features 8g+4h..+3, i.e. one 16-byte store per k-group, issued *inside*
+//           the MFMA stream.  Stashing a layer's input here -- instead of its output in the epilogue -- spreads the
+//           10 KB/sample of training stash evenly over the kernel; in an epilogue burst every CU of the chip stores at
+//           once and each wave then sits in s_waitcnt vmcnt (stores count) until HBM has drained 32 MB.
 // Fragments are fetched straight from L2/L1 one k-group ahead (1 KiB coalesced per wave-load, 4 MFMAs each); all
-// waves of the chip stream the same 2.4 MB so the working set is L2 resident.
-template <int KT, int MT, int NACC, int NIN>
-__device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const f32x4* __restrict__ frag) {
+// waves of the chip stream the same 2.4 MB so the working set is L2 resident and the 4 waves of a CU share L1 lines.
+template <int KT, int MT, bool STASH = false, int NACC, int NIN>
+__device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const f32x4* __restrict__ frag,
+                                          float* stash = nullptr) {
     static_assert(MT <= NACC && 16 * KT <= NIN, "tile counts exceed the register arrays");
     constexpr int G = 4 * KT;
     f32x4 cur[MT], nxt[MT];
@@ -33,6 +39,7 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) nxt[mt] = frag[((g + 1) * MT + mt) * 64];
         }
+        if constexpr (STASH) *reinterpret_cast<f32x4*>(stash + 8 * g) = f32x4{in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll

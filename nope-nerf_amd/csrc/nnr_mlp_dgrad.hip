@@ -46,40 +46,18 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
         const uint32_t* m = mask_base + (int64_t)8 * 64 * L::mask_words;
 #pragma unroll
         for (int w = 0; w < L::mask_words; ++w) mw[w] = m[w];
-        float* o = a.ws_dg + s * (D / 2) + 4 * half;
 #pragma unroll
-        for (int t = 0; t < HT; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 16 * t + 4 * q + i;
-                    const float x = ((mw[r >> 5] >> (r & 31)) & 1u) ? acc[t][4 * q + i] : 0.f;
-                    dg[r] = x;
-                    v[i] = x;
-                }
-                *reinterpret_cast<f32x4*>(o + 32 * t + 8 * q) = v;
-            }
+        for (int r = 0; r < 16 * HT; ++r) dg[r] = ((mw[r >> 5] >> (r & 31)) & 1u) ? acc[r >> 4][r & 15] : 0.f;
     }
     float d[16 * DT];  // current D-wide gradient (d feature, then d pre-activation of hidden 8..1)
     {
         f32x16 acc[DT + 1];
         zero_acc(acc);
-        gemm_part<HT, DT + 1>(acc, dg, frag(B_RGBH));
-        float* o = a.ws_df + s * D + 4 * half;
+        // every gradient vector is stashed by the gemm that consumes it (one 16-byte store per k-group, inside the
+        // MFMA stream) -- see gemm_part
+        gemm_part<HT, DT + 1, true>(acc, dg, frag(B_RGBH), a.ws_dg + s * (D / 2) + 4 * half);
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = acc[t][4 * q + i];
-                    d[16 * t + 4 * q + i] = v[i];
-                }
-                *reinterpret_cast<f32x4*>(o + 32 * t + 8 * q) = v;
-            }
+        for (int r = 0; r < 16 * DT; ++r) d[r] = acc[r >> 4][r & 15];
         // direction-encoding backward: d v = sum_f d gamma_4(v)_f/dv * grad_f, using the stored encoding for the
         // sin<->cos partner values (model/official_nerf.py:112-118)
         const float* enc = a.ws_xf + (live ? s : 0) * (D + kDirPad) + D;
@@ -103,46 +81,34 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
 
     // ---- trunk ----
     f32x16 acc[DT + 2];
-    auto masked_layer = [&](int hidden_idx /*0..7*/) {  // d <- acc .* relu'(h_idx); stash
+    auto masked_layer = [&](int hidden_idx /*0..7*/) {  // d <- acc .* relu'(h_idx)
         uint32_t mw[L::mask_words];
         const uint32_t* m = mask_base + (int64_t)hidden_idx * 64 * L::mask_words;
 #pragma unroll
         for (int w = 0; w < L::mask_words; ++w) mw[w] = m[w];
-        float* o = a.ws_dh + ((int64_t)hidden_idx * a.S_pad + s) * D + 4 * half;
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 16 * t + 4 * q + i;
-                    const float x = ((mw[r >> 5] >> (r & 31)) & 1u) ? acc[t][4 * q + i] : 0.f;
-                    d[r] = x;
-                    v[i] = x;
-                }
-                *reinterpret_cast<f32x4*>(o + 32 * t + 8 * q) = v;
-            }
+        for (int r = 0; r < 16 * DT; ++r) d[r] = ((mw[r >> 5] >> (r & 31)) & 1u) ? acc[r >> 4][r & 15] : 0.f;
     };
+    auto dh = [&](int hidden_idx /*0..7*/) -> float* { return a.ws_dh + ((int64_t)hidden_idx * a.S_pad + s) * D + 4 * half; };
     // d h8 = Wf^T d feat + w_sigma^T d sigma_raw
     float dsig[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dsig[r] = 0.f;
     dsig[0] = half == 0 ? dout[3] : 0.f;
     zero_acc(acc);
-    gemm_part<DT, DT>(acc, d, frag(B_FEAT));
+    gemm_part<DT, DT, true>(acc, d, frag(B_FEAT), a.ws_df + s * D + 4 * half);
     gemm_part<1, DT>(acc, dsig, frag(B_SIG));
     masked_layer(7);
     // hidden 8,7,6 -> d pre-activation of 7,6,5
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         zero_acc(acc);
-        gemm_part<DT, DT>(acc, d, wp + (L::bwd_off(B_L8) + l * part_floats(DT, DT)) / 4);
+        gemm_part<DT, DT, true>(acc, d, wp + (L::bwd_off(B_L8) + l * part_floats(DT, DT)) / 4, dh(7 - l));
         masked_layer(6 - l);
     }
     // hidden 5 (skip layer): rows [0,D) -> d h4, rows [D, D+64) -> d posenc (kept for the end)
     zero_acc(acc);
-    gemm_part<DT, DT + 2>(acc, d, frag(B_L5));
+    gemm_part<DT, DT + 2, true>(acc, d, frag(B_L5), dh(4));
     float de[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) de[r] = acc[DT + (r >> 4)][r & 15];
@@ -151,14 +117,14 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         zero_acc(acc);
-        gemm_part<DT, DT>(acc, d, wp + (L::bwd_off(B_L4) + l * part_floats(DT, DT)) / 4);
+        gemm_part<DT, DT, true>(acc, d, wp + (L::bwd_off(B_L4) + l * part_floats(DT, DT)) / 4, dh(3 - l));
         masked_layer(2 - l);
     }
     // hidden 1: d posenc += W1^T d1
     {
         f32x16 acc2[2];
         zero_acc(acc2);
-        gemm_part<DT, 2>(acc2, d, frag(B_L1));
+        gemm_part<DT, 2, true>(acc2, d, frag(B_L1), dh(0));
 #pragma unroll
         for (int r = 0; r < 32; ++r) de[r] += acc2[r >> 4][r & 15];
     }

@@ -54,38 +54,31 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         // masks: [chunk][layer][lane][mask_words]
         int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave;
         mask_base = a.ws_mask + ((chunk * L::n_mask_layers) * 64 + lane) * L::mask_words;
-        // posenc stash (S,64)
-        float* xe = a.ws_xe + s * kPosPad + 4 * half;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4*>(xe + 8 * q) = f32x4{e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]};
     }
 
     float h[16 * DT];
     f32x16 acc[DT];
 
-    // epilogue of a D-wide ReLU layer: h = relu(acc + b); stash activations + sign bits
+    // epilogue of a D-wide ReLU layer: h = relu(acc + b); keep the sign bits (the activations themselves are stashed
+    // by the *next* layer's gemm, interleaved with its MFMAs)
     auto relu_layer = [&](int layer_idx /*0..7*/) {
         const float* b = bias + L::bias_off(layer_idx) + 4 * half;
         uint32_t mw[L::mask_words];
 #pragma unroll
         for (int w = 0; w < L::mask_words; ++w) mw[w] = 0;
-        float* xh = TRAIN ? a.ws_xh + ((int64_t)layer_idx * a.S_pad + s) * D + 4 * half : nullptr;
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 bb = *reinterpret_cast<const f32x4*>(b + 32 * t + 8 * q);
-                f32x4 v;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float x = acc[t][4 * q + i] + bb[i];
                     x = fmaxf(x, 0.f);
-                    v[i] = x;
                     const int r = 16 * t + 4 * q + i;
                     h[r] = x;
                     if (TRAIN) mw[r >> 5] |= (x > 0.f ? 1u : 0u) << (r & 31);
                 }
-                if (TRAIN) *reinterpret_cast<f32x4*>(xh + 32 * t + 8 * q) = v;
             }
         }
         if (TRAIN) {
@@ -97,25 +90,29 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 
     // hidden 1: 63 -> D
     zero_acc(acc);
-    gemm_part<2, DT>(acc, e, frag(F_L1));
+    float* const xe = TRAIN ? a.ws_xe + s * kPosPad + 4 * half : nullptr;
+    auto xh = [&](int hidden_idx /*0..7*/) -> float* {
+        return TRAIN ? a.ws_xh + ((int64_t)hidden_idx * a.S_pad + s) * D + 4 * half : nullptr;
+    };
+    gemm_part<2, DT, TRAIN>(acc, e, frag(F_L1), xe);
     relu_layer(0);
     // hidden 2..4
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         zero_acc(acc);
-        gemm_part<DT, DT>(acc, h, wp + (L::fwd_off(F_L2) + l * part_floats(DT, DT)) / 4);
+        gemm_part<DT, DT, TRAIN>(acc, h, wp + (L::fwd_off(F_L2) + l * part_floats(DT, DT)) / 4, xh(l));
         relu_layer(1 + l);
     }
     // hidden 5: [h4 ; e] -> D   (skip connection, input order [h, posenc]: model/official_nerf.py:63)
     zero_acc(acc);
-    gemm_part<DT, DT>(acc, h, frag(F_L5H));
+    gemm_part<DT, DT, TRAIN>(acc, h, frag(F_L5H), xh(3));
     gemm_part<2, DT>(acc, e, frag(F_L5E));
     relu_layer(4);
     // hidden 6..8
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         zero_acc(acc);
-        gemm_part<DT, DT>(acc, h, wp + (L::fwd_off(F_L6) + l * part_floats(DT, DT)) / 4);
+        gemm_part<DT, DT, TRAIN>(acc, h, wp + (L::fwd_off(F_L6) + l * part_floats(DT, DT)) / 4, xh(4 + l));
         relu_layer(5 + l);
     }
     // density head: D -> 1 (row 0 of a 32-row tile)
@@ -125,38 +122,27 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     const float sigma_raw = acc1[0][0] + bias[L::bias_off(8)];
     // feature: D -> D, no activation
     zero_acc(acc);
-    gemm_part<DT, DT>(acc, h, frag(F_FEAT));
+    gemm_part<DT, DT, TRAIN>(acc, h, frag(F_FEAT), xh(7));
+    float* const xf = TRAIN ? a.ws_xf + s * (D + kDirPad) + 4 * half : nullptr;
     {
         const float* b = bias + L::bias_off(9) + 4 * half;
-        float* xf = TRAIN ? a.ws_xf + s * (D + kDirPad) + 4 * half : nullptr;
 #pragma unroll
         for (int t = 0; t < DT; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 bb = *reinterpret_cast<const f32x4*>(b + 32 * t + 8 * q);
-                f32x4 v;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = acc[t][4 * q + i] + bb[i];
-                    h[16 * t + 4 * q + i] = v[i];
-                }
-                if (TRAIN) *reinterpret_cast<f32x4*>(xf + 32 * t + 8 * q) = v;
+                for (int i = 0; i < 4; ++i) h[16 * t + 4 * q + i] = acc[t][4 * q + i] + bb[i];
             }
-        if (TRAIN) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<f32x4*>(xf + D + 8 * q) = f32x4{dirv[4 * q], dirv[4 * q + 1], dirv[4 * q + 2], dirv[4 * q + 3]};
-        }
     }
     // colour hidden: [feat ; gamma_4(v)] -> D/2, ReLU   (input order [feat, dir_enc]: model/official_nerf.py:89)
     f32x16 accg[HT];
     zero_acc(accg);
-    gemm_part<DT, HT>(accg, h, frag(F_RGBH_F));
-    gemm_part<1, HT>(accg, dirv, frag(F_RGBH_D));
+    gemm_part<DT, HT, TRAIN>(accg, h, frag(F_RGBH_F), xf);
+    gemm_part<1, HT, TRAIN>(accg, dirv, frag(F_RGBH_D), TRAIN ? xf + D : nullptr);
     float g[16 * HT];
     {
         const float* b = bias + L::bias_off(10) + 4 * half;
-        float* xg = TRAIN ? a.ws_xg + s * (D / 2) + 4 * half : nullptr;
         uint32_t mw[L::mask_words];
 #pragma unroll
         for (int w = 0; w < L::mask_words; ++w) mw[w] = 0;
@@ -165,16 +151,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 bb = *reinterpret_cast<const f32x4*>(b + 32 * t + 8 * q);
-                f32x4 v;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float x = fmaxf(accg[t][4 * q + i] + bb[i], 0.f);
-                    v[i] = x;
                     const int r = 16 * t + 4 * q + i;
                     g[r] = x;
                     if (TRAIN) mw[r >> 5] |= (x > 0.f ? 1u : 0u) << (r & 31);
                 }
-                if (TRAIN) *reinterpret_cast<f32x4*>(xg + 32 * t + 8 * q) = v;
             }
         if (TRAIN) {
             uint32_t* m = mask_base + (int64_t)8 * 64 * L::mask_words;
@@ -184,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     }
     // rgb: D/2 -> 3, sigmoid (rows 0..2 of a 32-row tile live in registers 0..2 of half 0)
     zero_acc(acc1);
-    gemm_part<HT, 1>(acc1, g, frag(F_RGB));
+    gemm_part<HT, 1, TRAIN>(acc1, g, frag(F_RGB), TRAIN ? a.ws_xg + s * (D / 2) + 4 * half : nullptr);
     if (half == 0 && s < a.S) {
         const float* b = bias + L::bias_off(11);
         f32x4 o;
