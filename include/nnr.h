@@ -128,6 +128,53 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const nnr_param_grads* grads_host, const v
                   void* stream);
 int nnr_ray_reduce(const nnr_cfg* cfg, float* d_pts_o, float* d_pts_d, float* d_view, float* workspace, void* stream);
 
+/* --- camera front end / loss heads --------------------------------------------------------------------------------
+ * One launch each for the O(1) / O(R) bookkeeping around the render call (the reference spends ~300 tiny ATen kernels
+ * and four rocSOLVER LU inverses per step here).  All matrices are 4x4 row-major fp32 on the device. */
+
+/* c2w = [[Exp(r_i), t_i],[0,0,0,1]] for camera `idx` of the (n_cams,3) tables -- LearnPose.forward
+ * (model/poses.py:23-31) -> make_c2w / Exp (model/common.py:290-310).  The backward writes FULL (n_cams,3) gradient
+ * tables (zero outside row idx), which is what autograd hands to the pose optimiser. */
+int nnr_se3_exp_fwd(const float* r_all, const float* t_all, int32_t idx, float* c2w, void* stream);
+int nnr_se3_exp_bwd(const float* r_all, int32_t idx, int32_t n_cams, const float* d_c2w, float* d_r_all, float* d_t_all,
+                    void* stream);
+
+/* batched 4x4 inverse and its backward dA = -Y^T dY Y^T -- torch.inverse at model/training.py:238 and the three
+ * inverses of model/common.py:139-141,206-208 */
+int nnr_inv4_fwd(const float* a, float* y, int32_t batch, void* stream);
+int nnr_inv4_bwd(const float* y, const float* d_y, float* d_a, int32_t batch, void* stream);
+
+/* Ray generation of Renderer.nope_nerf (model/rendering.py:54-87,194-195) for batch size 1: from pixels (R,2), per-ray
+ * mono depth (R, may be NULL == 1), camera_mat K, world_mat W, scale_mat S:
+ *   pts_o (R,3) camera centre, dir (R,3) ray direction (unit if `normalise`), view (R,3) = -dir (or ones if !use_dir),
+ *   ray_norm (R) = |pixels_world - camera_world|, d_gt (R) = |points_world - camera_world| (divided by ray_norm if
+ *   !normalise), mask (R, bytes) = finite(d_gt) && d_gt != 0.
+ * Backward: upstream gradients (any may be NULL) -> d_depth (R, may be NULL), dK, dW, dS (16 each).
+ * `scratch` = 12 floats. */
+int nnr_ray_setup_fwd(const float* pixels, const float* depth, const float* K, const float* W, const float* S, int32_t n_rays,
+                      int32_t normalise, int32_t use_dir, float* pts_o, float* dir, float* view, float* ray_norm, float* d_gt,
+                      uint8_t* mask, void* stream);
+int nnr_ray_setup_bwd(const float* pixels, const float* depth, const float* K, const float* W, const float* S, int32_t n_rays,
+                      int32_t normalise, int32_t use_dir, const float* g_pts_o, const float* g_dir, const float* g_view,
+                      const float* g_ray_norm, const float* g_d_gt, float* d_depth, float* dK, float* dW, float* dS,
+                      float* scratch, void* stream);
+
+/* depth = nearest-resize(depth_img (hd,wd) -> (h,w)).flatten()[ray_idx]  (model/network.py:22-24) without materialising
+ * the resized image; backward scatter-adds into a zero-filled (hd,wd) gradient image. */
+int nnr_depth_gather_fwd(const float* depth_img, const int64_t* ray_idx, float* out, int32_t n_rays, int32_t h, int32_t w,
+                         int32_t hd, int32_t wd, void* stream);
+int nnr_depth_gather_bwd(const float* g_out, const int64_t* ray_idx, float* g_img, int32_t n_rays, int32_t h, int32_t w,
+                         int32_t hd, int32_t wd, void* stream);
+
+/* Loss heads feeding the backward (model/losses.py:27-32,59-64,196-202): out[0] = w_rgb * L_rgb + w_depth * L_depth,
+ * out[1] = L_rgb = sum|rgb - gt| (or squared if rgb_l2) / r_total, out[2] = L_depth = sum_valid |dist - d_gt| / m_total,
+ * out[3] = mean squared rgb error, out[4] = number of valid depths in this call.  m_total < 0 means "this call's count";
+ * data-parallel callers pass the global counts.  ndc applies depth_gt = 1 - 1/d_gt (rendering.py:157-158).  The
+ * gradients of out[0] w.r.t. rgb, dist, d_gt are written to g_rgb (R,3), g_dist (R), g_d_gt (R). */
+int nnr_render_loss(const float* rgb, const float* rgb_gt, const float* dist, const float* d_gt, const uint8_t* mask,
+                    int32_t n_rays, float r_total, float m_total, float w_rgb, float w_depth, int32_t rgb_l2, int32_t ndc,
+                    int32_t detach_gt, float* out5, float* g_rgb, float* g_dist, float* g_d_gt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

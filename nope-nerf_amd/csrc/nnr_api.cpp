@@ -354,4 +354,67 @@ int nnr_render_bwd(const nnr_cfg* cfg, const float* packed, const float* d_rgb, 
     return nnr_ray_reduce(cfg, d_pts_o, d_pts_d, d_view, ws, stream);
 }
 
+#define NNR_LAUNCH(expr) do { hipError_t e_ = (expr); return e_ == hipSuccess ? NNR_OK : hip_fail(e_); } while (0)
+
+int nnr_se3_exp_fwd(const float* r_all, const float* t_all, int32_t idx, float* c2w, void* stream) {
+    if (!r_all || !t_all || !c2w || idx < 0) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_se3_exp_fwd(r_all, t_all, idx, c2w, (hipStream_t)stream));
+}
+int nnr_se3_exp_bwd(const float* r_all, int32_t idx, int32_t n_cams, const float* d_c2w, float* d_r_all, float* d_t_all,
+                    void* stream) {
+    if (!r_all || !d_c2w || !d_r_all || !d_t_all || idx < 0 || idx >= n_cams) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_se3_exp_bwd(r_all, idx, n_cams, d_c2w, d_r_all, d_t_all, (hipStream_t)stream));
+}
+int nnr_inv4_fwd(const float* a, float* y, int32_t batch, void* stream) {
+    if (!a || !y || batch <= 0) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_inv4(a, y, batch, (hipStream_t)stream));
+}
+int nnr_inv4_bwd(const float* y, const float* d_y, float* d_a, int32_t batch, void* stream) {
+    if (!y || !d_y || !d_a || batch <= 0) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_inv4_bwd(y, d_y, d_a, batch, (hipStream_t)stream));
+}
+int nnr_ray_setup_fwd(const float* pixels, const float* depth, const float* K, const float* W, const float* S, int32_t n_rays,
+                      int32_t normalise, int32_t use_dir, float* pts_o, float* dir, float* view, float* ray_norm, float* d_gt,
+                      uint8_t* mask, void* stream) {
+    if (!pixels || !K || !W || !S || !pts_o || !dir || !view || !ray_norm || !d_gt || !mask || n_rays <= 0) return NNR_E_BADCFG;
+    RaySetupArgs a{};
+    a.pixels = pixels; a.depth = depth; a.K = K; a.W = W; a.S = S;
+    a.pts_o = pts_o; a.dir = dir; a.view = view; a.ray_norm = ray_norm; a.d_gt = d_gt; a.mask = mask;
+    a.R = n_rays; a.normalise = normalise; a.use_dir = use_dir;
+    NNR_LAUNCH(launch_ray_setup_fwd(a, (hipStream_t)stream));
+}
+int nnr_ray_setup_bwd(const float* pixels, const float* depth, const float* K, const float* W, const float* S, int32_t n_rays,
+                      int32_t normalise, int32_t use_dir, const float* g_pts_o, const float* g_dir, const float* g_view,
+                      const float* g_ray_norm, const float* g_d_gt, float* d_depth, float* dK, float* dW, float* dS,
+                      float* scratch, void* stream) {
+    if (!pixels || !K || !W || !S || !dK || !dW || !dS || !scratch || n_rays <= 0) return NNR_E_BADCFG;
+    RaySetupArgs a{};
+    a.pixels = pixels; a.depth = depth; a.K = K; a.W = W; a.S = S;
+    a.g_o = g_pts_o; a.g_dir = g_dir; a.g_view = g_view; a.g_norm = g_ray_norm; a.g_dgt = g_d_gt;
+    a.g_depth = d_depth; a.acc = scratch; a.gK = dK; a.gW = dW; a.gS = dS;
+    a.R = n_rays; a.normalise = normalise; a.use_dir = use_dir;
+    NNR_LAUNCH(launch_ray_setup_bwd(a, (hipStream_t)stream));
+}
+int nnr_depth_gather_fwd(const float* depth_img, const int64_t* ray_idx, float* out, int32_t n_rays, int32_t h, int32_t w,
+                         int32_t hd, int32_t wd, void* stream) {
+    if (!depth_img || !ray_idx || !out || n_rays <= 0 || h <= 0 || w <= 0 || hd <= 0 || wd <= 0) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_depth_gather_fwd(depth_img, ray_idx, out, n_rays, h, w, hd, wd, (hipStream_t)stream));
+}
+int nnr_depth_gather_bwd(const float* g_out, const int64_t* ray_idx, float* g_img, int32_t n_rays, int32_t h, int32_t w,
+                         int32_t hd, int32_t wd, void* stream) {
+    if (!g_out || !ray_idx || !g_img || n_rays <= 0 || h <= 0 || w <= 0 || hd <= 0 || wd <= 0) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_depth_gather_bwd(g_out, ray_idx, g_img, n_rays, h, w, hd, wd, (hipStream_t)stream));
+}
+int nnr_render_loss(const float* rgb, const float* rgb_gt, const float* dist, const float* d_gt, const uint8_t* mask,
+                    int32_t n_rays, float r_total, float m_total, float w_rgb, float w_depth, int32_t rgb_l2, int32_t ndc,
+                    int32_t detach_gt, float* out5, float* g_rgb, float* g_dist, float* g_d_gt, void* stream) {
+    if (!rgb || !rgb_gt || !dist || !d_gt || !mask || !out5 || !g_rgb || !g_dist || !g_d_gt || n_rays <= 0 || r_total <= 0.f)
+        return NNR_E_BADCFG;
+    LossArgs a{};
+    a.rgb = rgb; a.rgb_gt = rgb_gt; a.dist = dist; a.d_gt = d_gt; a.mask = mask; a.out = out5;
+    a.g_rgb = g_rgb; a.g_dist = g_dist; a.g_dgt = g_d_gt; a.R = n_rays; a.r_total = r_total; a.m_total = m_total;
+    a.w_rgb = w_rgb; a.w_depth = w_depth; a.rgb_l2 = rgb_l2; a.ndc = ndc; a.detach_gt = detach_gt;
+    NNR_LAUNCH(launch_render_loss(a, (hipStream_t)stream));
+}
+
 }  // extern "C"

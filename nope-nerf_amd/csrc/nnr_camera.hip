@@ -1,0 +1,399 @@
+// nnr_camera.hip -- the O(1)/O(R) front and back ends of a training step, each as ONE launch instead of the dozens of
+// tiny ATen kernels (and four rocSOLVER 4x4 LU inverses) the reference's formulation costs per step:
+//   se3_exp     LearnPose.forward -> make_c2w -> Exp           reference model/poses.py:23-31, model/common.py:277-310
+//   inv4        torch.inverse on (B,4,4)                        reference model/training.py:238, model/common.py:139-141
+//   ray_setup   origin_to_world / transform_to_world / image_points_to_world + norms, masks, view dir
+//                                                               reference model/rendering.py:54-87,194-195, common.py:112-237
+//   depth_gather  F.interpolate(nearest) + gather at ray_idx    reference model/network.py:22-24
+//   render_loss   rgb L1|L2 sum / R  +  depth L1 sum / M         reference model/losses.py:27-32,59-64,196-202
+// All of them are latency-bound bookkeeping (<= a few KB); the point is launch count, not bandwidth.
+#include "nnr_device.h"
+#include "nnr_kernels.h"
+
+namespace nnr {
+
+// ------------------------------------------------------------------------------------------------ 4x4 helpers
+struct M4 { float m[16]; };
+
+__device__ __forceinline__ M4 mul4(const M4& a, const M4& b) {
+    M4 c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += a.m[4 * i + k] * b.m[4 * k + j];
+            c.m[4 * i + j] = s;
+        }
+    return c;
+}
+__device__ __forceinline__ M4 transpose4(const M4& a) {
+    M4 c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c.m[4 * i + j] = a.m[4 * j + i];
+    return c;
+}
+// general 4x4 inverse by cofactors (adjugate / determinant)
+__device__ __forceinline__ M4 inv4(const M4& a) {
+    const float* m = a.m;
+    float inv[16];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    const float rdet = 1.0f / det;
+    M4 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.m[i] = inv[i] * rdet;
+    return r;
+}
+__device__ __forceinline__ M4 load4(const float* p) {
+    M4 a;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a.m[i] = p[i];
+    return a;
+}
+// dL/dA for Y = A^-1:  -Y^T (dL/dY) Y^T
+__device__ __forceinline__ M4 inv_backward(const M4& y, const M4& dy) {
+    const M4 yt = transpose4(y);
+    M4 r = mul4(mul4(yt, dy), yt);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.m[i] = -r.m[i];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ SE(3) exp
+// R = I + sin(th)/th K + (1-cos(th))/th^2 K^2, th = |r| + 1e-15 (model/common.py:290-299), c2w = [[R,t],[0,0,0,1]].
+__global__ void se3_exp_fwd_kernel(const float* r_all, const float* t_all, int idx, float* c2w) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float* r = r_all + 3 * idx;
+    const float* t = t_all + 3 * idx;
+    const float x = r[0], y = r[1], z = r[2];
+    const float n = sqrtf(x * x + y * y + z * z);
+    const float th = n + 1e-15f;
+    const float a = sinf(th) / th, b = (1.f - cosf(th)) / (th * th);
+    const float K[9] = {0.f, -z, y, z, 0.f, -x, -y, x, 0.f};
+    float K2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) c2w[4 * i + j] = (i == j ? 1.f : 0.f) + a * K[3 * i + j] + b * K2[3 * i + j];
+        c2w[4 * i + 3] = t[i];
+    }
+    c2w[12] = 0.f; c2w[13] = 0.f; c2w[14] = 0.f; c2w[15] = 1.f;
+}
+
+// gradients into full (n_cams,3) tables: zero everywhere except row idx
+__global__ void se3_exp_bwd_kernel(const float* r_all, int idx, int n_cams, const float* d_c2w, float* d_r_all, float* d_t_all) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * n_cams && i / 3 != idx) { d_r_all[i] = 0.f; d_t_all[i] = 0.f; }
+    if (i != 0) return;
+    const float* r = r_all + 3 * idx;
+    const float x = r[0], y = r[1], z = r[2];
+    const float n = sqrtf(x * x + y * y + z * z);
+    const float th = n + 1e-15f;
+    const float s = sinf(th), c = cosf(th);
+    const float a = s / th, b = (1.f - c) / (th * th);
+    const float da = c / th - s / (th * th);                                   // d(sin th / th)/d th, as autograd forms it
+    const float db = s / (th * th) - 2.f * (1.f - c) / (th * th * th);         // d((1-cos th)/th^2)/d th
+    const float K[9] = {0.f, -z, y, z, 0.f, -x, -y, x, 0.f};
+    float K2[9], G[9];
+    for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) {
+            K2[3 * p + q] = K[3 * p] * K[q] + K[3 * p + 1] * K[3 + q] + K[3 * p + 2] * K[6 + q];
+            G[3 * p + q] = d_c2w[4 * p + q];
+        }
+    float ga = 0.f, gb = 0.f;
+    for (int p = 0; p < 9; ++p) { ga += G[p] * K[p]; gb += G[p] * K2[p]; }
+    // dL/dK = a G + b (G K^T + K^T G)
+    float gK[9];
+    for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) {
+            float gkT = 0.f, kTg = 0.f;
+            for (int k = 0; k < 3; ++k) { gkT += G[3 * p + k] * K[3 * q + k]; kTg += K[3 * k + p] * G[3 * k + q]; }
+            gK[3 * p + q] = a * G[3 * p + q] + b * (gkT + kTg);
+        }
+    const float gth = ga * da + gb * db;
+    const float inv_n = n > 0.f ? 1.f / n : 0.f;                              // d|r|/dr = r/|r|, subgradient 0 at r = 0
+    d_r_all[3 * idx + 0] = gK[7] - gK[5] + gth * x * inv_n;
+    d_r_all[3 * idx + 1] = gK[2] - gK[6] + gth * y * inv_n;
+    d_r_all[3 * idx + 2] = gK[3] - gK[1] + gth * z * inv_n;
+    d_t_all[3 * idx + 0] = d_c2w[3];
+    d_t_all[3 * idx + 1] = d_c2w[7];
+    d_t_all[3 * idx + 2] = d_c2w[11];
+}
+
+// ------------------------------------------------------------------------------------------------ batched 4x4 inverse
+__global__ void inv4_fwd_kernel(const float* a, float* y, int batch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    const M4 r = inv4(load4(a + 16 * i));
+    for (int k = 0; k < 16; ++k) y[16 * i + k] = r.m[k];
+}
+__global__ void inv4_bwd_kernel(const float* y, const float* dy, float* da, int batch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    const M4 r = inv_backward(load4(y + 16 * i), load4(dy + 16 * i));
+    for (int k = 0; k < 16; ++k) da[16 * i + k] = r.m[k];
+}
+
+// ------------------------------------------------------------------------------------------------ ray setup
+__device__ __forceinline__ void pixel_to_world(const RaySetupArgs& a, M4& kinv, M4& winv, M4& sinv, M4& m) {
+    kinv = inv4(load4(a.K));
+    winv = inv4(load4(a.W));
+    sinv = inv4(load4(a.S));
+    m = mul4(mul4(sinv, winv), kinv);   // model/common.py:153: scale^-1 @ world^-1 @ camera^-1
+}
+
+__global__ __launch_bounds__(256) void ray_setup_fwd_kernel(RaySetupArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.R) return;
+    M4 kinv, winv, sinv, m;
+    pixel_to_world(a, kinv, winv, sinv, m);
+    const float px = a.pixels[2 * i], py = a.pixels[2 * i + 1];
+    const float dep = a.depth ? a.depth[i] : 1.f;
+    float ray[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ray[c] = m.m[4 * c] * px + m.m[4 * c + 1] * py + m.m[4 * c + 2];   // pixels_world - camera_world
+    const float n = sqrtf(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+    const float q0 = ray[0] * dep, q1 = ray[1] * dep, q2 = ray[2] * dep;
+    float dgt = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);                                              // |points_world - camera_world|
+    if (!a.normalise) dgt = dgt / n;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float d = a.normalise ? ray[c] / n : ray[c];
+        a.pts_o[3 * i + c] = m.m[4 * c + 3];
+        a.dir[3 * i + c] = d;
+        a.view[3 * i + c] = a.use_dir ? -d : 1.f;
+    }
+    a.ray_norm[i] = n;
+    a.d_gt[i] = dgt;
+    a.mask[i] = (isfinite(dgt) && dgt != 0.f) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void ray_setup_bwd_kernel(RaySetupArgs a) {
+    __shared__ float red[12][4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    if (i < a.R) {
+        M4 kinv, winv, sinv, m;
+        pixel_to_world(a, kinv, winv, sinv, m);
+        const float px = a.pixels[2 * i], py = a.pixels[2 * i + 1];
+        const float dep = a.depth ? a.depth[i] : 1.f;
+        float ray[3], gdir[3], gray[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ray[c] = m.m[4 * c] * px + m.m[4 * c + 1] * py + m.m[4 * c + 2];
+        const float n = sqrtf(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+        const float rn = 1.f / n;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float g = a.g_dir ? a.g_dir[3 * i + c] : 0.f;
+            if (a.use_dir && a.g_view) g -= a.g_view[3 * i + c];     // view = -dir
+            gdir[c] = g;
+        }
+        float gn = a.g_norm ? a.g_norm[i] : 0.f;                      // dL/d|ray|
+        float gdep = 0.f;
+        const float gd = a.g_dgt ? a.g_dgt[i] : 0.f;
+        const float sgn = dep > 0.f ? 1.f : (dep < 0.f ? -1.f : 0.f);
+        if (a.normalise) {
+            const float dot = (gdir[0] * ray[0] + gdir[1] * ray[1] + gdir[2] * ray[2]) * rn * rn;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gray[c] = (gdir[c] - ray[c] * dot) * rn;   // through ray / |ray|
+            if (gd != 0.f) { gn += gd * fabsf(dep); gdep = gd * n * sgn; }        // d_gt = |depth| |ray|
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gray[c] = gdir[c];
+            if (gd != 0.f) gdep = gd * sgn;                                        // d_gt = |depth| (the |ray| cancels)
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gray[c] += gn * ray[c] * rn;
+        if (a.g_depth) a.g_depth[i] = gdep;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            acc[4 * c + 0] = gray[c] * px;
+            acc[4 * c + 1] = gray[c] * py;
+            acc[4 * c + 2] = gray[c];
+            acc[4 * c + 3] = a.g_o ? a.g_o[3 * i + c] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0) red[k][wv] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) atomicAdd(a.acc + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// dL/dM (12 accumulated floats) -> dL/dK, dL/dW, dL/dS through M = S^-1 W^-1 K^-1
+__global__ void ray_setup_mat_bwd_kernel(RaySetupArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    M4 kinv, winv, sinv, m;
+    pixel_to_world(a, kinv, winv, sinv, m);
+    M4 dm;
+    for (int k = 0; k < 12; ++k) dm.m[k] = a.acc[k];
+    for (int k = 12; k < 16; ++k) dm.m[k] = 0.f;
+    const M4 sw = mul4(sinv, winv);
+    const M4 d_kinv = mul4(transpose4(sw), dm);             // M = (S^-1 W^-1) K^-1
+    const M4 d_sw = mul4(dm, transpose4(kinv));
+    const M4 d_sinv = mul4(d_sw, transpose4(winv));
+    const M4 d_winv = mul4(transpose4(sinv), d_sw);
+    const M4 gk = inv_backward(kinv, d_kinv), gw = inv_backward(winv, d_winv), gs = inv_backward(sinv, d_sinv);
+    for (int k = 0; k < 16; ++k) { a.gK[k] = gk.m[k]; a.gW[k] = gw.m[k]; a.gS[k] = gs.m[k]; }
+}
+
+// ------------------------------------------------------------------------------------------------ depth gather
+// F.interpolate(mode='nearest') source index: min(floor(dst * (float)in/out), in-1), float32 like ATen.
+__device__ __forceinline__ int nearest_src(int dst, int dst_size, int src_size) {
+    const float scale = (float)src_size / (float)dst_size;
+    const int s = (int)floorf((float)dst * scale);
+    return s < src_size - 1 ? s : src_size - 1;
+}
+__global__ void depth_gather_fwd_kernel(const float* img, const int64_t* ray_idx, float* out, int R, int h, int w, int hd, int wd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const int64_t q = ray_idx[i];
+    const int y = (int)(q / w), x = (int)(q - (int64_t)y * w);
+    out[i] = img[(int64_t)nearest_src(y, h, hd) * wd + nearest_src(x, w, wd)];
+}
+__global__ void depth_gather_bwd_kernel(const float* g, const int64_t* ray_idx, float* g_img, int R, int h, int w, int hd, int wd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const int64_t q = ray_idx[i];
+    const int y = (int)(q / w), x = (int)(q - (int64_t)y * w);
+    atomicAdd(g_img + (int64_t)nearest_src(y, h, hd) * wd + nearest_src(x, w, wd), g[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ loss heads
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wv] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sm[k];
+    return t;
+}
+
+// one workgroup; rgb: sum |diff| (or diff^2) / R_total; depth: sum_valid |pred - gt| / M_total   (losses.py:27-32,59-64)
+__global__ __launch_bounds__(1024) void render_loss_kernel(LossArgs a) {
+    __shared__ float sm[16];
+    float s_rgb = 0.f, s_l2 = 0.f, s_dep = 0.f, cnt = 0.f;
+    for (int i = threadIdx.x; i < a.R; i += blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d = a.rgb[3 * i + c] - a.rgb_gt[3 * i + c];
+            s_rgb += a.rgb_l2 ? d * d : fabsf(d);
+            s_l2 += d * d;
+        }
+        if (a.mask[i]) {
+            float gt = a.d_gt[i];
+            if (a.ndc) gt = 1.f - 1.f / gt;                                   // rendering.py:157-158
+            s_dep += fabsf(a.dist[i] - gt);
+            cnt += 1.f;
+        }
+    }
+    s_rgb = block_sum(s_rgb, sm);
+    s_l2 = block_sum(s_l2, sm);
+    s_dep = block_sum(s_dep, sm);
+    cnt = block_sum(cnt, sm);
+    const float m = a.m_total >= 0.f ? a.m_total : cnt;
+    const float inv_r = 1.f / a.r_total, inv_m = m > 0.f ? 1.f / m : 0.f;
+    if (threadIdx.x == 0) {
+        const float lrgb = s_rgb * inv_r, ldep = s_dep * inv_m;
+        a.out[0] = a.w_rgb * lrgb + a.w_depth * ldep;
+        a.out[1] = lrgb;
+        a.out[2] = ldep;
+        a.out[3] = s_l2 / (3.f * a.r_total);
+        a.out[4] = cnt;
+    }
+    const float sign_eps = 0.f;
+    for (int i = threadIdx.x; i < a.R; i += blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d = a.rgb[3 * i + c] - a.rgb_gt[3 * i + c];
+            const float g = a.rgb_l2 ? 2.f * d : (d > sign_eps ? 1.f : (d < -sign_eps ? -1.f : 0.f));
+            a.g_rgb[3 * i + c] = a.w_rgb * inv_r * g;
+        }
+        float gd = 0.f, gg = 0.f;
+        if (a.mask[i]) {
+            float gt = a.d_gt[i];
+            const float raw_gt = gt;
+            if (a.ndc) gt = 1.f - 1.f / gt;
+            const float d = a.dist[i] - gt;
+            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            gd = a.w_depth * inv_m * sg;
+            gg = a.detach_gt ? 0.f : -gd * (a.ndc ? 1.f / (raw_gt * raw_gt) : 1.f);
+        }
+        a.g_dist[i] = gd;
+        a.g_dgt[i] = gg;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+hipError_t launch_se3_exp_fwd(const float* r_all, const float* t_all, int idx, float* c2w, hipStream_t st) {
+    hipLaunchKernelGGL(se3_exp_fwd_kernel, dim3(1), dim3(64), 0, st, r_all, t_all, idx, c2w);
+    return hipGetLastError();
+}
+hipError_t launch_se3_exp_bwd(const float* r_all, int idx, int n_cams, const float* d_c2w, float* d_r, float* d_t, hipStream_t st) {
+    hipLaunchKernelGGL(se3_exp_bwd_kernel, dim3((3 * n_cams + 255) / 256), dim3(256), 0, st, r_all, idx, n_cams, d_c2w, d_r, d_t);
+    return hipGetLastError();
+}
+hipError_t launch_inv4(const float* a, float* y, int batch, hipStream_t st) {
+    hipLaunchKernelGGL(inv4_fwd_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, a, y, batch);
+    return hipGetLastError();
+}
+hipError_t launch_inv4_bwd(const float* y, const float* dy, float* da, int batch, hipStream_t st) {
+    hipLaunchKernelGGL(inv4_bwd_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, y, dy, da, batch);
+    return hipGetLastError();
+}
+hipError_t launch_ray_setup_fwd(const RaySetupArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(ray_setup_fwd_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_ray_setup_bwd(const RaySetupArgs& a, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(a.acc, 0, 12 * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ray_setup_bwd_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ray_setup_mat_bwd_kernel, dim3(1), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_depth_gather_fwd(const float* img, const int64_t* idx, float* out, int R, int h, int w, int hd, int wd, hipStream_t st) {
+    hipLaunchKernelGGL(depth_gather_fwd_kernel, dim3((R + 255) / 256), dim3(256), 0, st, img, idx, out, R, h, w, hd, wd);
+    return hipGetLastError();
+}
+hipError_t launch_depth_gather_bwd(const float* g, const int64_t* idx, float* g_img, int R, int h, int w, int hd, int wd, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(g_img, 0, (size_t)hd * wd * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(depth_gather_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, st, g, idx, g_img, R, h, w, hd, wd);
+    return hipGetLastError();
+}
+hipError_t launch_render_loss(const LossArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(render_loss_kernel, dim3(1), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace nnr

@@ -69,6 +69,42 @@ struct WgradArgs {
     int n_jobs;
 };
 
+struct RaySetupArgs {
+    const float* pixels;  // (R,2) in [-1,1]
+    const float* depth;   // (R) or null (== 1)
+    const float *K, *W, *S;  // 4x4 each: camera_mat, world_mat, scale_mat
+    float *pts_o, *dir, *view;  // (R,3)
+    float *ray_norm, *d_gt;      // (R)
+    uint8_t* mask;               // (R)
+    // backward
+    const float *g_o, *g_dir, *g_view, *g_norm, *g_dgt;  // upstream gradients (any may be null)
+    float* g_depth;              // (R) or null
+    float* acc;                  // 12 floats: dL/dM[:3,:4], zeroed by the launcher
+    float *gK, *gW, *gS;         // 16 each
+    int R;
+    int normalise, use_dir;
+};
+
+struct LossArgs {
+    const float *rgb, *rgb_gt, *dist, *d_gt;
+    const uint8_t* mask;
+    float* out;     // [loss, loss_rgb, loss_depth, l2_mean, n_valid]
+    float *g_rgb, *g_dist, *g_dgt;
+    int R;
+    float r_total, m_total;   // normalisers (m_total < 0: use this call's valid count)
+    float w_rgb, w_depth;
+    int rgb_l2, ndc, detach_gt;
+};
+
+hipError_t launch_se3_exp_fwd(const float* r_all, const float* t_all, int idx, float* c2w, hipStream_t st);
+hipError_t launch_se3_exp_bwd(const float* r_all, int idx, int n_cams, const float* d_c2w, float* d_r, float* d_t, hipStream_t st);
+hipError_t launch_inv4(const float* a, float* y, int batch, hipStream_t st);
+hipError_t launch_inv4_bwd(const float* y, const float* dy, float* da, int batch, hipStream_t st);
+hipError_t launch_ray_setup_fwd(const RaySetupArgs& a, hipStream_t st);
+hipError_t launch_ray_setup_bwd(const RaySetupArgs& a, hipStream_t st);
+hipError_t launch_depth_gather_fwd(const float* img, const int64_t* idx, float* out, int R, int h, int w, int hd, int wd, hipStream_t st);
+hipError_t launch_depth_gather_bwd(const float* g, const int64_t* idx, float* g_img, int R, int h, int w, int hd, int wd, hipStream_t st);
+hipError_t launch_render_loss(const LossArgs& a, hipStream_t st);
 hipError_t launch_pack(int D, const PackArgs& a, hipStream_t st);
 hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st);
 hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st);

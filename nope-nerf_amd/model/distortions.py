@@ -14,10 +14,10 @@ class Learn_Distortion(nn.Module):
         self.num_cams = num_cams
 
     def forward(self, cam_id):
-        dev = self.global_scales.device
+        cid = int(cam_id)
         scale = self.global_scales[cam_id]
-        if scale < 0.01:
-            scale = torch.tensor(0.01, device=dev)
-        if self.fix_scaleN and cam_id == self.num_cams - 1:
-            scale = torch.tensor(1, device=dev)
+        # value AND gradient of the reference's `if scale < 0.01: scale = tensor(0.01)` without the device->host sync
+        scale = torch.where(scale < 0.01, torch.full_like(scale, 0.01), scale)
+        if self.fix_scaleN and cid == self.num_cams - 1:
+            scale = torch.ones_like(scale).detach()
         return scale, self.global_shifts[cam_id]

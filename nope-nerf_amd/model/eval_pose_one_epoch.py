@@ -5,6 +5,7 @@ import logging
 
 import torch
 
+from nnr import camera
 from model.common import arange_pixels
 from model.losses import Loss_Eval
 
@@ -42,7 +43,8 @@ class Trainer_pose(object):
         img, depth_img, camera_mat, scale_mat, img_idx = self.process_data_dict(data)
         dev = self.device
         b, _, h, w = img.shape
-        world_mat = torch.inverse(self.pose_param_net(img_idx)).unsqueeze(0)
+        c2w = self.pose_param_net(img_idx)
+        world_mat = (camera.inverse4(c2w) if c2w.is_cuda else torch.inverse(c2w)).unsqueeze(0)
         if self.focal_net is not None:
             fxfy = self.focal_net(0)
             camera_mat = torch.zeros(4, 4, device=dev)

@@ -116,15 +116,13 @@ class Loss(nn.Module):
             diff = 0.15 * diff + 0.85 * compute_ssim_loss.to(diff.device)(rgb1, rgb2)
         return self.mean_on_mask(diff, valid_points)
 
-    def forward(self, rgb_pred, rgb_gt, depth_pred=None, depth_gt=None, t_list=None, X=None, Y=None, rgb_pc1=None,
-                rgb_pc1_proj=None, valid_points=None, d1_proj=None, d2=None, d2_proj=None, d1=None, weights={},
-                rgb_loss_type='l2', **kwargs):
-        z = _zero(rgb_gt)
+    def aux_terms(self, ref, t_list=None, X=None, Y=None, rgb_pc1=None, rgb_pc1_proj=None, valid_points=None, d1_proj=None,
+                  d2=None, d2_proj=None, d1=None, weights={}, **kwargs):
+        """The per-image terms (point cloud, surface reprojection, trajectory smoothness, depth consistency) and their
+        weighted sum; `ref` is any tensor on the target device."""
+        z = _zero(ref)
         on = lambda k: weights[k] != 0.0
-        rendering = on('rgb_weight') or on('depth_weight')
         parts = {
-            'loss_rgb': self.get_rgb_full_loss(rgb_pred, rgb_gt, rgb_loss_type) if on('rgb_weight') else z,
-            'loss_depth': self.get_depth_loss(depth_pred, depth_gt) if on('depth_weight') else z,
             'loss_pc': self.get_pc_loss(X, Y) if on('pc_weight') else z,
             'loss_rgb_s': self.get_rgb_s_loss(rgb_pc1, rgb_pc1_proj, valid_points) if on('rgb_s_weight') else z,
             'loss_depth_consistency': self.get_depth_consistency_loss(d1_proj, d2, d2_proj, d1)
@@ -134,11 +132,20 @@ class Loss(nn.Module):
             parts['loss_dist_1st'], parts['loss_dist_2nd'] = self.get_weight_dist_loss(t_list)
         else:
             parts['loss_dist_1st'], parts['loss_dist_2nd'] = z, z
-        loss = (weights['rgb_weight'] * parts['loss_rgb'] + weights['depth_weight'] * parts['loss_depth'] +
-                weights['weight_dist_1st_loss'] * parts['loss_dist_1st'] +
-                weights['weight_dist_2nd_loss'] * parts['loss_dist_2nd'] +
-                weights['pc_weight'] * parts['loss_pc'] + weights['rgb_s_weight'] * parts['loss_rgb_s'] +
-                weights['depth_consistency_weight'] * parts['loss_depth_consistency'])
+        total = (weights['weight_dist_1st_loss'] * parts['loss_dist_1st'] +
+                 weights['weight_dist_2nd_loss'] * parts['loss_dist_2nd'] +
+                 weights['pc_weight'] * parts['loss_pc'] + weights['rgb_s_weight'] * parts['loss_rgb_s'] +
+                 weights['depth_consistency_weight'] * parts['loss_depth_consistency'])
+        return total, parts
+
+    def forward(self, rgb_pred, rgb_gt, depth_pred=None, depth_gt=None, weights={}, rgb_loss_type='l2', **kwargs):
+        z = _zero(rgb_gt)
+        on = lambda k: weights[k] != 0.0
+        rendering = on('rgb_weight') or on('depth_weight')
+        aux, parts = self.aux_terms(rgb_gt, weights=weights, **kwargs)
+        parts['loss_rgb'] = self.get_rgb_full_loss(rgb_pred, rgb_gt, rgb_loss_type) if on('rgb_weight') else z
+        parts['loss_depth'] = self.get_depth_loss(depth_pred, depth_gt) if on('depth_weight') else z
+        loss = weights['rgb_weight'] * parts['loss_rgb'] + weights['depth_weight'] * parts['loss_depth'] + aux
         if torch.isnan(loss):
             raise FloatingPointError('NaN loss (the reference drops into breakpoint() here, losses.py:204-205)')
         out = {'loss': loss, 'l2_mean': F.mse_loss(rgb_pred, rgb_gt) if rendering else z}

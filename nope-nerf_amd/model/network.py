@@ -3,6 +3,8 @@ renderer (reference model/network.py:8-33)."""
 import torch
 import torch.nn as nn
 
+from nnr import camera
+
 
 def nearest_source_index(dst_idx, dst_size, src_size):
     """Source index F.interpolate(mode='nearest') reads for destination index `dst_idx` along one axis:
@@ -26,9 +28,12 @@ class nope_nerf(nn.Module):
             # The reference nearest-resizes the whole depth map to the image size every step and then gathers R
             # values (network.py:22-24).  Gather-then-nothing is the same thing: index the source pixel directly.
             h, w = img_size
-            hd, wd = depth_img.shape[-2:]
-            ys = nearest_source_index(torch.div(ray_idx, w, rounding_mode='floor'), h, hd)
-            xs = nearest_source_index(ray_idx % w, w, wd)
-            depth = depth_img[0, 0][ys, xs].view(1, -1, 1)
+            if depth_img.is_cuda:
+                depth = camera.depth_gather(depth_img, ray_idx, h, w)               # one launch (nnr_depth_gather_*)
+            else:
+                hd, wd = depth_img.shape[-2:]
+                ys = nearest_source_index(torch.div(ray_idx, w, rounding_mode='floor'), h, hd)
+                xs = nearest_source_index(ray_idx % w, w, wd)
+                depth = depth_img[0, 0][ys, xs].view(1, -1, 1)
         return self.renderer(p, depth, camera_mat, world_mat, scale_mat, rendering_technique, eval_=eval_mode, it=it,
                              add_noise=add_noise)

@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from model.common import make_c2w
+from nnr import camera
 
 
 class LearnPose(nn.Module):
@@ -18,7 +19,10 @@ class LearnPose(nn.Module):
 
     def forward(self, cam_id):
         i = int(cam_id)
-        pose = make_c2w(self.r[i], self.t[i])
+        if self.r.is_cuda:      # one HIP launch forward, one backward (nnr_se3_exp_*), instead of ~60 ATen kernels
+            pose = camera.se3_exp(self.r, self.t, i)
+        else:
+            pose = make_c2w(self.r[i], self.t[i])
         return pose if self.init_c2w is None else pose @ self.init_c2w[i]   # delta pose on top of the initial one
 
     def get_t(self):

@@ -14,9 +14,38 @@ import torch
 import torch.nn as nn
 
 import nnr
+from nnr import camera
 from .common import get_ndc_rays_fxfy, pixel_to_world_matrix
 
 epsilon = 1e-6   # the transmittance epsilon of the reference (rendering.py:9) -- applied inside the composite kernel
+
+
+class RenderOutput(dict):
+    """The renderer's output dictionary (reference rendering.py:159-166).  `depth_pred` / `depth_gt` -- the per-ray
+    values compacted by the validity mask -- are materialised on first access: boolean-mask indexing costs a dozen small
+    kernels and a device->host sync, and the trainer's fused loss works on the dense tensors + mask instead
+    (keys `dist_dense`, `d_gt_dense`, `mask`)."""
+
+    _LAZY = ('depth_pred', 'depth_gt')
+
+    def __missing__(self, key):
+        if key not in self._LAZY:
+            raise KeyError(key)
+        mask = dict.__getitem__(self, 'mask')
+        if key == 'depth_pred':
+            val = dict.__getitem__(self, 'dist_dense')[mask]
+        else:
+            val = dict.__getitem__(self, 'd_gt_dense')[mask]
+            if dict.__getitem__(self, 'ndc'):
+                val = 1 - 1 / val                                                   # rendering.py:157-158
+        self[key] = val
+        return val
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._LAZY
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
 
 
 class Renderer(nn.Module):
@@ -71,22 +100,28 @@ class Renderer(nn.Module):
         n_samples = cfg['num_points'] - cfg['outside_steps']
         device = pixels.device
 
-        # --- rays (reference :54-72).  inv(S) inv(W) inv(K) stays inside autograd: pose / focal gradients flow here ---
-        m = pixel_to_world_matrix(camera_mat, world_mat, scale_mat)[0]             # (4,4)
-        cam = m[:3, 3]                                                              # camera centre
-        pix_h = torch.cat([pixels[0], torch.ones(n_rays, 1, device=device)], dim=-1)   # (R,3) = (x', y', 1)
-        ray = pix_h @ m[:3, :3].t()                                                 # pixels_world - camera_world
-        ray_norm = ray.norm(2, -1)
-        d_gt = (ray * depth[0]).norm(2, -1)                                         # |points_world - camera_world|
-        if cfg['normalise_ray']:
-            ray = ray / ray_norm.unsqueeze(-1)
+        # --- rays (reference :54-87).  inv(S) inv(W) inv(K) stays inside autograd: pose / focal gradients flow here ---
+        if pixels.is_cuda:
+            # one HIP launch (nnr_ray_setup_fwd; backward: nnr_ray_setup_bwd) for the three inverses, the unprojection,
+            # norms, d_gt and the validity mask
+            origin, ray, view, ray_norm, d_gt, object_mask = camera.ray_setup(
+                pixels, depth, camera_mat, world_mat, scale_mat, bool(cfg['normalise_ray']), bool(cfg['use_ray_dir']))
         else:
-            d_gt = d_gt / ray_norm
-        object_mask = torch.isfinite(d_gt) & (d_gt != 0)                            # :73-87
+            m = pixel_to_world_matrix(camera_mat, world_mat, scale_mat)[0]             # (4,4)
+            cam = m[:3, 3]                                                              # camera centre
+            pix_h = torch.cat([pixels[0], torch.ones(n_rays, 1, device=device)], dim=-1)   # (R,3) = (x', y', 1)
+            ray = pix_h @ m[:3, :3].t()                                                 # pixels_world - camera_world
+            ray_norm = ray.norm(2, -1)
+            d_gt = (ray * depth[0]).norm(2, -1)                                         # |points_world - camera_world|
+            if cfg['normalise_ray']:
+                ray = ray / ray_norm.unsqueeze(-1)
+            else:
+                d_gt = d_gt / ray_norm
+            object_mask = torch.isfinite(d_gt) & (d_gt != 0)                            # :73-87
+            view = -ray if cfg['use_ray_dir'] else torch.ones_like(ray)                 # :104-105,194-195
+            origin = cam.unsqueeze(0).expand(n_rays, 3)
 
         # --- per-ray sampling frame ---
-        view = -ray if cfg['use_ray_dir'] else torch.ones_like(ray)                 # :104-105,194-195
-        origin = cam.unsqueeze(0).expand(n_rays, 3)
         jitter = None
         if cfg['sample_option'] == 'ndc':                                           # :168-180
             focal = torch.cat([camera_mat[:, 0, 0], camera_mat[:, 1, 1]])
@@ -113,17 +148,17 @@ class Renderer(nn.Module):
         if eval_ and cfg['normalise_ray']:                                          # distance -> depth for evaluation (:150-154)
             dist_pred = dist_pred / ray_norm
             d_gt = d_gt / ray_norm
-        depth_gt = d_gt[object_mask]
-        if cfg['sample_option'] == 'ndc':
-            depth_gt = 1 - 1 / depth_gt
-        return {
+        return RenderOutput({
             'rgb': rgb.reshape(batch_size, -1, 3),
             'z_vals': z_val,
             'normal': None,
-            'depth_pred': dist_pred[object_mask],
-            'depth_gt': depth_gt,
             'alpha': alpha,
-        }
+            # dense per-ray values + validity mask; 'depth_pred' / 'depth_gt' (masked) are derived lazily from these
+            'dist_dense': dist_pred,
+            'd_gt_dense': d_gt,
+            'mask': object_mask,
+            'ndc': cfg['sample_option'] == 'ndc',
+        })
 
     # ------------------------------------------------------------------------------------------------ not on the hot path
     def phong_renderer(self, *args, **kwargs):

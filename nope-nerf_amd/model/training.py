@@ -20,7 +20,7 @@ from torch.nn import functional as F
 
 from model.common import arange_pixels, get_tensor_values, project_to_cam, transform_to_world
 from model.losses import Loss
-from nnr import parallel
+from nnr import camera, parallel
 
 logger_py = logging.getLogger(__name__)
 
@@ -48,6 +48,7 @@ class Trainer(object):
             setattr(self, k, cfg[k])
         self.loss = Loss(cfg)
         self._warned_geo = False
+        self._nan_flag = None      # device-side isnan(loss) of the previous step, checked one step late (no sync in the step)
 
     # ------------------------------------------------------------------------------------------------ step
     def _groups(self):
@@ -112,7 +113,7 @@ class Trainer(object):
         kwargs = {'t_list': self.pose_param_net.get_t(), 'weights': weights, 'rgb_loss_type': rgb_loss_type}
 
         num_cams = self.pose_param_net.num_cams
-        world_mat = torch.inverse(self.pose_param_net(img_idx)).unsqueeze(0)
+        world_mat = self._inverse(self.pose_param_net(img_idx)).unsqueeze(0)
         scale_input = shift_input = None
         if self.distortion_net is not None:
             scale_input, shift_input = self.distortion_net(img_idx)
@@ -141,19 +142,18 @@ class Trainer(object):
             out = self.model(p, ray_loc, camera_mat, world_mat, scale_mat, self.rendering_technique, it=it,
                              eval_mode=eval_mode, depth_img=depth_input, img_size=(h, w))
             renderer.jitter_window = None
-            rendered_rgb, rendered_depth, gt_depth = out['rgb'], out['depth_pred'], out['depth_gt']
-            if self.detach_gt_depth:
-                gt_depth = gt_depth.detach()
+            rendered_rgb = out['rgb']
+            if not (rendered_rgb.is_cuda and self.loss.depth_loss_type == 'l1'):
+                rendered_depth, gt_depth = out['depth_pred'], out['depth_gt']     # masked views, only where the torch loss needs them
+                if self.detach_gt_depth:
+                    gt_depth = gt_depth.detach()
 
         if use_ref_imgs:
             self._reference_terms(kwargs, data, img, depth_input, camera_mat, world_mat, scale_input, img_idx, num_cams,
                                   h_depth, w_depth, weights, it, out_render_path)
 
-        if world > 1:
-            loss_dict = self._sharded_loss(rendered_rgb, rgb_gt, rendered_depth, gt_depth, n_total, ray_idx, depth_input,
-                                           (h, w), kwargs, world)
-        else:
-            loss_dict = self.loss(rendered_rgb, rgb_gt, rendered_depth, gt_depth, **kwargs)
+        loss_dict = self._total_loss(out if render_model else None, rendered_rgb, rgb_gt, rendered_depth, gt_depth, n_total,
+                                     ray_idx, depth_input, (h, w), kwargs, world)
         if self.optimizer_focal:
             loss_dict['focalx'] = fxfy[0] / camera_mat_gt[0, 0, 0]
             loss_dict['focaly'] = fxfy[1] / camera_mat_gt[0, 1, 1]
@@ -161,38 +161,59 @@ class Trainer(object):
         loss_dict['shift'] = shift_input
         return loss_dict
 
-    def _sharded_loss(self, rgb, rgb_gt, depth_pred, depth_gt, n_total, ray_idx, depth_input, img_size, kwargs, world):
-        """Local share of the loss such that SUM over ranks == the single-process loss: per-ray terms are divided by the
-        GLOBAL ray / valid-depth counts, per-image terms by world_size."""
-        from model.network import nearest_source_index
+    @staticmethod
+    def _inverse(m):
+        return camera.inverse4(m) if m.is_cuda else torch.inverse(m)
+
+    def _check_nan(self, loss):
+        """The reference stops on a NaN loss (losses.py:204-205).  Testing it synchronously would stall the launch queue
+        every step, so the flag of step i is read at step i+1 (it is long complete by then)."""
+        if self._nan_flag is not None and bool(self._nan_flag):
+            raise FloatingPointError('NaN loss in the previous training step')
+        self._nan_flag = torch.isnan(loss.detach())
+
+    def _total_loss(self, out, rgb, rgb_gt, depth_pred, depth_gt, n_total, ray_idx, depth_input, img_size, kwargs, world):
+        """rgb + depth heads (fused HIP kernel on the GPU) + per-image terms.  Under data parallelism each rank holds a
+        shard of the rays: per-ray terms are divided by the GLOBAL ray / valid-depth counts and per-image terms by
+        world_size, so that the SUM over ranks equals the single-process loss."""
         w = kwargs['weights']
-        h_img, w_img = img_size
-        hd, wd = depth_input.shape[-2:]
-        with torch.no_grad():   # global count of rays with a usable mono depth (finite, non-zero): no collective needed
-            ys = nearest_source_index(torch.div(ray_idx, w_img, rounding_mode='floor'), h_img, hd)
-            xs = nearest_source_index(ray_idx % w_img, w_img, wd)
-            d_all = depth_input[0, 0][ys, xs]
-            m_total = int((torch.isfinite(d_all) & (d_all != 0)).sum())
-        kw = dict(kwargs)
-        kw['weights'] = dict(w, rgb_weight=0.0, depth_weight=0.0)     # per-image terms only
-        out = self.loss(rgb, rgb_gt, depth_pred, depth_gt, **kw)
-        aux = out['loss'] / world
-        for k in ('loss_pc', 'loss_rgb_s', 'loss_dist_1st', 'loss_dist_2nd', 'loss_depth_consistency'):
-            out[k] = out[k] / world
+        m_total = -1.0
+        if world > 1:
+            from model.network import nearest_source_index
+            h_img, w_img = img_size
+            hd, wd = depth_input.shape[-2:]
+            with torch.no_grad():   # global count of rays with a usable mono depth (finite, non-zero): no collective needed
+                ys = nearest_source_index(torch.div(ray_idx, w_img, rounding_mode='floor'), h_img, hd)
+                xs = nearest_source_index(ray_idx % w_img, w_img, wd)
+                d_all = depth_input[0, 0][ys, xs]
+                m_total = float((torch.isfinite(d_all) & (d_all != 0)).sum())
+        fused = (out is not None and rgb.is_cuda and self.loss.depth_loss_type == 'l1' and 'dist_dense' in out)
+        if not fused and world == 1:
+            loss_dict = self.loss(rgb, rgb_gt, depth_pred, depth_gt, **kwargs)
+            return loss_dict
+        aux, parts = self.loss.aux_terms(rgb_gt, **kwargs)
+        loss_dict = {k: v / world for k, v in parts.items()}
         zero = torch.zeros((), device=rgb_gt.device)
-        lrgb = ldep = zero
-        if w['rgb_weight'] != 0.0:
-            diff = rgb - rgb_gt
-            lrgb = (diff.abs().sum() if kwargs['rgb_loss_type'] == 'l1' else (diff * diff).sum()) / float(n_total)
-        if w['depth_weight'] != 0.0:
+        if out is None:
+            lmain, lrgb, ldep, l2 = zero, zero, zero, zero
+        elif fused:
+            lmain, a4 = camera.render_loss(rgb, rgb_gt, out['dist_dense'], out['d_gt_dense'], out['mask'], r_total=n_total,
+                                           m_total=m_total, w_rgb=w['rgb_weight'], w_depth=w['depth_weight'],
+                                           rgb_l2=(kwargs['rgb_loss_type'] == 'l2'), ndc=out['ndc'],
+                                           detach_gt=self.detach_gt_depth)
+            lrgb, ldep, l2 = a4[0], a4[1], a4[2]
+        else:
             if self.loss.depth_loss_type != 'l1':
                 raise NotImplementedError("depth_loss_type 'invariant' takes a median over all rays of the step "
                                           "(losses.py:42-46); it needs an all-gather and is not sharded yet")
-            ldep = (depth_pred - depth_gt).abs().sum() / float(max(m_total, 1))
-        out['loss_rgb'], out['loss_depth'] = lrgb, ldep
-        out['l2_mean'] = ((rgb - rgb_gt) ** 2).sum() / float(3 * n_total)
-        out['loss'] = w['rgb_weight'] * lrgb + w['depth_weight'] * ldep + aux
-        return out
+            diff = rgb - rgb_gt
+            lrgb = (diff.abs().sum() if kwargs['rgb_loss_type'] == 'l1' else (diff * diff).sum()) / float(n_total)
+            ldep = (depth_pred - depth_gt).abs().sum() / float(max(m_total, 1.0)) if w['depth_weight'] != 0.0 else zero
+            l2 = (diff * diff).sum() / float(3 * n_total)
+            lmain = w['rgb_weight'] * lrgb + w['depth_weight'] * ldep
+        loss_dict.update(loss_rgb=lrgb, loss_depth=ldep, l2_mean=l2, loss=lmain + aux / world)
+        self._check_nan(loss_dict['loss'])
+        return loss_dict
 
     def _reference_terms(self, kwargs, data, img, depth_input, camera_mat, world_mat, scale_input, img_idx, num_cams,
                          h_depth, w_depth, weights, it, out_render_path):
@@ -210,14 +231,14 @@ class Trainer(object):
             c2w_ref, depth_ref = c2w_ref.detach(), depth_ref.detach()
             if scale_ref is not None:
                 scale_ref, shift_ref = scale_ref.detach(), shift_ref.detach()
-        ref_rt = torch.inverse(c2w_ref).unsqueeze(0)
+        ref_rt = self._inverse(c2w_ref).unsqueeze(0)
         if img_idx < (num_cams - 1):
             d1, d2, img1, img2 = depth_input, depth_ref, img, ref_img
-            rel = ref_rt @ torch.inverse(world_mat)
+            rel = ref_rt @ self._inverse(world_mat)
             scale2 = scale_ref
         else:
             d1, d2, img1, img2 = depth_ref, depth_input, ref_img, img
-            rel = world_mat @ torch.inverse(ref_rt)
+            rel = world_mat @ self._inverse(ref_rt)
             scale2 = scale_input
         r_rel, t_rel = rel[:, :3, :3], rel[:, :3, 3]
 
@@ -259,7 +280,7 @@ class Trainer(object):
     def render_visdata(self, data, resolution, it, out_render_path):
         img, dpt, camera_mat, scale_mat, img_idx = self.process_data_dict(data)
         h, w = resolution
-        world_mat = torch.inverse(self.pose_param_net(img_idx)).unsqueeze(0)
+        world_mat = self._inverse(self.pose_param_net(img_idx)).unsqueeze(0)
         if self.optimizer_focal:
             _, camera_mat = self._camera_from_focal(self.device)
         p_idx = torch.arange(h * w, device=self.device)

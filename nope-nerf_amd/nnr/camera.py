@@ -1,0 +1,172 @@
+"""autograd wrappers of the camera front end and the loss heads of libnnr.so (include/nnr.h, nnr_camera.hip):
+one HIP launch each for SE(3) exp, 4x4 inverses, ray generation, the nearest-resize depth gather and the rgb/depth loss
+heads -- the reference spends ~300 tiny ATen kernels (incl. four rocSOLVER LU inverses) per step on the same work."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t):
+    return t.detach().contiguous().float()
+
+
+class _Se3Exp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, r_all, t_all, idx):
+        r, t = _f32(r_all), _f32(t_all)
+        c2w = torch.empty(4, 4, dtype=torch.float32, device=r.device)
+        L.check(L.load().nnr_se3_exp_fwd(L.ptr(r), L.ptr(t), int(idx), L.ptr(c2w), _st()), "nnr_se3_exp_fwd")
+        ctx.save_for_backward(r)
+        ctx.idx = int(idx)
+        return c2w
+
+    @staticmethod
+    def backward(ctx, g):
+        (r,) = ctx.saved_tensors
+        g = _f32(g)
+        d_r, d_t = torch.empty_like(r), torch.empty_like(r)
+        L.check(L.load().nnr_se3_exp_bwd(L.ptr(r), ctx.idx, r.shape[0], L.ptr(g), L.ptr(d_r), L.ptr(d_t), _st()),
+                "nnr_se3_exp_bwd")
+        return d_r, d_t, None
+
+
+def se3_exp(r_all: torch.Tensor, t_all: torch.Tensor, idx: int) -> torch.Tensor:
+    """(n_cams,3) axis-angle and translation tables -> 4x4 camera-to-world of camera idx."""
+    return _Se3Exp.apply(r_all, t_all, idx)
+
+
+class _Inv4(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):
+        x = _f32(a).view(-1, 16)
+        y = torch.empty_like(x)
+        L.check(L.load().nnr_inv4_fwd(L.ptr(x), L.ptr(y), x.shape[0], _st()), "nnr_inv4_fwd")
+        ctx.save_for_backward(y)
+        return y.view(a.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        gg = _f32(g).view(-1, 16)
+        d = torch.empty_like(y)
+        L.check(L.load().nnr_inv4_bwd(L.ptr(y), L.ptr(gg), L.ptr(d), y.shape[0], _st()), "nnr_inv4_bwd")
+        return d.view(g.shape)
+
+
+def inverse4(a: torch.Tensor) -> torch.Tensor:
+    """Inverse of (...,4,4) matrices (cofactor formula), differentiable."""
+    return _Inv4.apply(a)
+
+
+class _RaySetup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pixels, depth, K, W, S, normalise, use_dir):
+        pix = _f32(pixels).view(-1, 2)
+        R, dev = pix.shape[0], pix.device
+        dep = _f32(depth).view(-1) if depth is not None else None
+        k, w, s = _f32(K).view(16), _f32(W).view(16), _f32(S).view(16)
+        f = dict(dtype=torch.float32, device=dev)
+        pts_o, dirs, view = torch.empty(R, 3, **f), torch.empty(R, 3, **f), torch.empty(R, 3, **f)
+        norm, d_gt = torch.empty(R, **f), torch.empty(R, **f)
+        mask = torch.empty(R, dtype=torch.bool, device=dev)
+        L.check(L.load().nnr_ray_setup_fwd(L.ptr(pix), L.ptr(dep), L.ptr(k), L.ptr(w), L.ptr(s), R, int(normalise),
+                                           int(use_dir), L.ptr(pts_o), L.ptr(dirs), L.ptr(view), L.ptr(norm), L.ptr(d_gt),
+                                           L.ptr(mask), _st()), "nnr_ray_setup_fwd")
+        ctx.save_for_backward(pix, dep, k, w, s)
+        ctx.flags = (int(normalise), int(use_dir))
+        ctx.shapes = (None if depth is None else depth.shape, K.shape, W.shape, S.shape)
+        ctx.mark_non_differentiable(mask)
+        return pts_o, dirs, view, norm, d_gt, mask
+
+    @staticmethod
+    def backward(ctx, g_o, g_dir, g_view, g_norm, g_dgt, _gm):
+        pix, dep, k, w, s = ctx.saved_tensors
+        R, dev = pix.shape[0], pix.device
+        opt = lambda g: _f32(g) if g is not None else None
+        g_o, g_dir, g_view, g_norm, g_dgt = (opt(g) for g in (g_o, g_dir, g_view, g_norm, g_dgt))
+        f = dict(dtype=torch.float32, device=dev)
+        d_depth = torch.empty(R, **f) if dep is not None else None
+        out = torch.empty(3 * 16 + 12, **f)
+        dK, dW, dS, scratch = out[0:16], out[16:32], out[32:48], out[48:60]
+        L.check(L.load().nnr_ray_setup_bwd(L.ptr(pix), L.ptr(dep), L.ptr(k), L.ptr(w), L.ptr(s), R, ctx.flags[0], ctx.flags[1],
+                                           L.ptr(g_o), L.ptr(g_dir), L.ptr(g_view), L.ptr(g_norm), L.ptr(g_dgt), L.ptr(d_depth),
+                                           L.ptr(dK), L.ptr(dW), L.ptr(dS), L.ptr(scratch), _st()), "nnr_ray_setup_bwd")
+        dshape, kshape, wshape, sshape = ctx.shapes
+        return (None, d_depth.view(dshape) if d_depth is not None else None, dK.view(kshape), dW.view(wshape),
+                dS.view(sshape), None, None)
+
+
+def ray_setup(pixels, depth, camera_mat, world_mat, scale_mat, normalise: bool, use_dir: bool):
+    """pixels (1,R,2), depth (1,R,1)|None, three (1,4,4) matrices -> pts_o, dir, view (R,3), ray_norm, d_gt (R), mask (R) bool."""
+    return _RaySetup.apply(pixels, depth, camera_mat, world_mat, scale_mat, normalise, use_dir)
+
+
+class _DepthGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth_img, ray_idx, h, w):
+        img = _f32(depth_img)
+        hd, wd = img.shape[-2:]
+        idx = ray_idx.detach().contiguous().long()
+        R = idx.shape[0]
+        out = torch.empty(1, R, 1, dtype=torch.float32, device=img.device)
+        L.check(L.load().nnr_depth_gather_fwd(L.ptr(img), L.ptr(idx), L.ptr(out), R, int(h), int(w), hd, wd, _st()),
+                "nnr_depth_gather_fwd")
+        ctx.save_for_backward(idx)
+        ctx.dims = (int(h), int(w), hd, wd, tuple(depth_img.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        h, w, hd, wd, shape = ctx.dims
+        g = _f32(g).view(-1)
+        g_img = torch.empty(shape, dtype=torch.float32, device=g.device)
+        L.check(L.load().nnr_depth_gather_bwd(L.ptr(g), L.ptr(idx), L.ptr(g_img), idx.shape[0], h, w, hd, wd, _st()),
+                "nnr_depth_gather_bwd")
+        return g_img, None, None, None
+
+
+def depth_gather(depth_img: torch.Tensor, ray_idx: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """(1,1,hd,wd) mono-depth map -> (1,R,1) values at the rays' pixels of the nearest-resized (h,w) map."""
+    assert depth_img.shape[0] == 1 and depth_img.shape[1] == 1
+    return _DepthGather.apply(depth_img, ray_idx, h, w)
+
+
+class _RenderLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, rgb_gt, dist, d_gt, mask, r_total, m_total, w_rgb, w_depth, rgb_l2, ndc, detach_gt):
+        a, b, c, d = _f32(rgb).view(-1, 3), _f32(rgb_gt).view(-1, 3), _f32(dist).view(-1), _f32(d_gt).view(-1)
+        m = mask.detach().contiguous()
+        R, dev = a.shape[0], a.device
+        f = dict(dtype=torch.float32, device=dev)
+        out = torch.empty(5, **f)
+        g_rgb, g_dist, g_dgt = torch.empty(R, 3, **f), torch.empty(R, **f), torch.empty(R, **f)
+        L.check(L.load().nnr_render_loss(L.ptr(a), L.ptr(b), L.ptr(c), L.ptr(d), L.ptr(m), R, float(r_total), float(m_total),
+                                         float(w_rgb), float(w_depth), int(rgb_l2), int(ndc), int(detach_gt), L.ptr(out),
+                                         L.ptr(g_rgb), L.ptr(g_dist), L.ptr(g_dgt), _st()), "nnr_render_loss")
+        ctx.save_for_backward(g_rgb, g_dist, g_dgt)
+        ctx.shapes = (rgb.shape, dist.shape, d_gt.shape)
+        aux = out[1:]
+        ctx.mark_non_differentiable(aux)
+        return out[0], aux
+
+    @staticmethod
+    def backward(ctx, g, _ga):
+        g_rgb, g_dist, g_dgt = ctx.saved_tensors
+        s0, s1, s2 = ctx.shapes
+        return ((g_rgb * g).view(s0), None, (g_dist * g).view(s1), (g_dgt * g).view(s2)) + (None,) * 8
+
+
+def render_loss(rgb, rgb_gt, dist, d_gt, mask, *, r_total, m_total=-1.0, w_rgb, w_depth, rgb_l2=False, ndc=False,
+                detach_gt=False):
+    """Weighted rgb + depth loss heads on dense per-ray tensors + validity mask.
+    Returns (loss, aux) with aux = [loss_rgb, loss_depth, l2_mean, n_valid]."""
+    return _RenderLoss.apply(rgb, rgb_gt, dist, d_gt, mask, r_total, m_total, w_rgb, w_depth, rgb_l2, ndc, detach_gt)

@@ -24,7 +24,9 @@ LAYER_NAMES = ("layers0.0", "layers0.2", "layers0.4", "layers0.6", "layers1.0", 
 
 EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_floats", "nnr_workspace_floats",
            "nnr_plan_bytes", "nnr_plan_build", "nnr_pack_weights", "nnr_render_fwd", "nnr_render_bwd", "nnr_ws_plane",
-           "nnr_mlp_fwd", "nnr_composite_fwd", "nnr_composite_bwd", "nnr_mlp_dgrad", "nnr_mlp_wgrad", "nnr_ray_reduce")
+           "nnr_mlp_fwd", "nnr_composite_fwd", "nnr_composite_bwd", "nnr_mlp_dgrad", "nnr_mlp_wgrad", "nnr_ray_reduce",
+           "nnr_se3_exp_fwd", "nnr_se3_exp_bwd", "nnr_inv4_fwd", "nnr_inv4_bwd", "nnr_ray_setup_fwd", "nnr_ray_setup_bwd",
+           "nnr_depth_gather_fwd", "nnr_depth_gather_bwd", "nnr_render_loss")
 
 
 class Cfg(C.Structure):
@@ -73,6 +75,16 @@ def load():
     lib.nnr_mlp_dgrad.argtypes = [cfgp, vp, vp, vp]
     lib.nnr_mlp_wgrad.argtypes = [cfgp, C.POINTER(Params), vp, vp, vp]
     lib.nnr_ray_reduce.argtypes = [cfgp] + [vp] * 5
+    i32, f32 = C.c_int32, C.c_float
+    lib.nnr_se3_exp_fwd.argtypes = [vp, vp, i32, vp, vp]
+    lib.nnr_se3_exp_bwd.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    lib.nnr_inv4_fwd.argtypes = [vp, vp, i32, vp]
+    lib.nnr_inv4_bwd.argtypes = [vp, vp, vp, i32, vp]
+    lib.nnr_ray_setup_fwd.argtypes = [vp] * 5 + [i32] * 3 + [vp] * 7
+    lib.nnr_ray_setup_bwd.argtypes = [vp] * 5 + [i32] * 3 + [vp] * 11
+    lib.nnr_depth_gather_fwd.argtypes = [vp, vp, vp] + [i32] * 5 + [vp]
+    lib.nnr_depth_gather_bwd.argtypes = [vp, vp, vp] + [i32] * 5 + [vp]
+    lib.nnr_render_loss.argtypes = [vp] * 5 + [i32] + [f32] * 4 + [i32] * 3 + [vp] * 5
     for n in EXPORTS:
         if not hasattr(lib, n):
             raise RuntimeError(f"libnnr.so does not export {n}")

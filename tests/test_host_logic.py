@@ -99,20 +99,25 @@ def test_distortion_semantics():
         d.global_scales[2] = 5.0
     s0, _ = d(0)
     s2, _ = d(2)
-    assert float(s0) == pytest.approx(0.01) and not s0.requires_grad        # clamped to a constant
-    assert float(s2) == 1.0                                                 # last camera pinned
-    assert d(1)[0].requires_grad
+    assert float(s0) == pytest.approx(0.01)                                  # clamped ...
+    s0.sum().backward()
+    assert float(d.global_scales.grad[0]) == 0.0                             # ... to a constant: no gradient reaches the parameter
+    assert float(s2) == 1.0 and not s2.requires_grad                         # last camera pinned
+    d.global_scales.grad = None
+    s1, _ = d(1)
+    s1.sum().backward()
+    assert float(d.global_scales.grad[1]) == 1.0
 
 
-def test_z_tables_match_reference_sampling():
-    import model as mdl
-    cfg = make_cfg()
-    r = mdl.Renderer(mdl.OfficialStaticNerf(cfg), cfg['rendering'], device='cpu')
-    u = torch.rand(1, 5, 64)
-    lo, hi = r._z_tables(64, 0.01, 10, True, 'cpu')
-    assert torch.equal(lo + (hi - lo) * u[0], orc.sample_z(5, 64, 0.01, 10, u)[0])
-    lo, hi = r._z_tables(64, 0.0, 1.0, False, 'cpu')
-    assert torch.equal(lo, orc.sample_z(1, 64, 0.0, 1.0, None)[0, 0]) and lo is hi or torch.equal(lo, hi)
+def test_render_output_is_lazy_but_complete():
+    from model.rendering import RenderOutput
+    out = RenderOutput({'rgb': torch.zeros(1, 4, 3), 'dist_dense': torch.tensor([1., 2., 3., 4.]),
+                        'd_gt_dense': torch.tensor([2., 0., 4., float('inf')]),
+                        'mask': torch.tensor([True, False, True, False]), 'ndc': True})
+    assert 'depth_pred' in out and 'depth_gt' in out and 'nope' not in out
+    assert torch.equal(out['depth_pred'], torch.tensor([1., 3.]))
+    assert torch.equal(out['depth_gt'], 1 - 1 / torch.tensor([2., 4.]))
+    assert out.get('depth_pred') is out['depth_pred'] and out.get('nope') is None
 
 
 @pytest.mark.parametrize("name", ["tanks_d128", "llff_ndc_d128", "uniform_distalpha_masked_d128", "white_nonorm_d128",
