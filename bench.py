@@ -110,7 +110,7 @@ def kernel_roofline(net, device, reps=5):
     mid = 0.5 * (z[1:] + z[:-1])
     lo, hi = torch.cat([z[:1], mid]).to(device), torch.cat([mid, z[-1:]]).to(device)
     jit = torch.rand(R, N, generator=g).to(device)
-    w, b = [p.detach() for p in net.weights()], [p.detach() for p in net.biases()]
+    w, b = net.weights(), net.biases()
     packed = ops._packed_for(cfg, w, b)
     ws = torch.empty(lib.nnr_workspace_floats(C.byref(cfg)), device=device)
     rgb, dst = torch.empty(R, 3, device=device), torch.empty(R, device=device)

@@ -159,6 +159,10 @@ int nnr_ray_setup_bwd(const float* pixels, const float* depth, const float* K, c
                       const float* g_ray_norm, const float* g_d_gt, float* d_depth, float* dK, float* dW, float* dS,
                       float* scratch, void* stream);
 
+/* pixels (R,2) = arange_pixels((h,w))[1][:, ray_idx] (model/common.py:13-40, model/training.py:260-261) without building
+ * the (h*w,2) grid every step. */
+int nnr_pixels_from_index(const int64_t* ray_idx, float* pixels, int32_t n_rays, int32_t h, int32_t w, void* stream);
+
 /* depth = nearest-resize(depth_img (hd,wd) -> (h,w)).flatten()[ray_idx]  (model/network.py:22-24) without materialising
  * the resized image; backward scatter-adds into a zero-filled (hd,wd) gradient image. */
 int nnr_depth_gather_fwd(const float* depth_img, const int64_t* ray_idx, float* out, int32_t n_rays, int32_t h, int32_t w,

@@ -417,4 +417,9 @@ int nnr_render_loss(const float* rgb, const float* rgb_gt, const float* dist, co
     NNR_LAUNCH(launch_render_loss(a, (hipStream_t)stream));
 }
 
+int nnr_pixels_from_index(const int64_t* ray_idx, float* pixels, int32_t n_rays, int32_t h, int32_t w, void* stream) {
+    if (!ray_idx || !pixels || n_rays <= 0 || h < 2 || w < 2) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_pixels_from_index(ray_idx, pixels, n_rays, h, w, (hipStream_t)stream));
+}
+
 }  // extern "C"

@@ -285,6 +285,21 @@ __global__ void depth_gather_bwd_kernel(const float* g, const int64_t* ray_idx, 
     atomicAdd(g_img + (int64_t)nearest_src(y, h, hd) * wd + nearest_src(x, w, wd), g[i]);
 }
 
+// scaled pixel coordinates of flat indices: x' = 2 x/(w-1) - 1, y' = 2 y/(h-1) - 1, same float op order as arange_pixels
+// (model/common.py:36-39)
+__global__ void pixels_from_index_kernel(const int64_t* idx, float* out, int R, int h, int w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const int64_t q = idx[i];
+    const int y = (int)(q / w), x = (int)(q - (int64_t)y * w);
+    out[2 * i] = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, (float)x), (float)(w - 1)), 1.0f);
+    out[2 * i + 1] = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, (float)y), (float)(h - 1)), 1.0f);
+}
+hipError_t launch_pixels_from_index(const int64_t* idx, float* out, int R, int h, int w, hipStream_t st) {
+    hipLaunchKernelGGL(pixels_from_index_kernel, dim3((R + 255) / 256), dim3(256), 0, st, idx, out, R, h, w);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ loss heads
 __device__ __forceinline__ float block_sum(float v, float* sm) {
 #pragma unroll

@@ -105,6 +105,7 @@ hipError_t launch_ray_setup_bwd(const RaySetupArgs& a, hipStream_t st);
 hipError_t launch_depth_gather_fwd(const float* img, const int64_t* idx, float* out, int R, int h, int w, int hd, int wd, hipStream_t st);
 hipError_t launch_depth_gather_bwd(const float* g, const int64_t* idx, float* g_img, int R, int h, int w, int hd, int wd, hipStream_t st);
 hipError_t launch_render_loss(const LossArgs& a, hipStream_t st);
+hipError_t launch_pixels_from_index(const int64_t* idx, float* out, int R, int h, int w, hipStream_t st);
 hipError_t launch_pack(int D, const PackArgs& a, hipStream_t st);
 hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st);
 hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st);

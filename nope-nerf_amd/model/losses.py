@@ -132,10 +132,13 @@ class Loss(nn.Module):
             parts['loss_dist_1st'], parts['loss_dist_2nd'] = self.get_weight_dist_loss(t_list)
         else:
             parts['loss_dist_1st'], parts['loss_dist_2nd'] = z, z
-        total = (weights['weight_dist_1st_loss'] * parts['loss_dist_1st'] +
-                 weights['weight_dist_2nd_loss'] * parts['loss_dist_2nd'] +
-                 weights['pc_weight'] * parts['loss_pc'] + weights['rgb_s_weight'] * parts['loss_rgb_s'] +
-                 weights['depth_consistency_weight'] * parts['loss_depth_consistency'])
+        total = None   # only the active terms enter the sum: no arithmetic on constant zeros (each would be a kernel launch)
+        for wk, pk in (('weight_dist_1st_loss', 'loss_dist_1st'), ('weight_dist_2nd_loss', 'loss_dist_2nd'),
+                       ('pc_weight', 'loss_pc'), ('rgb_s_weight', 'loss_rgb_s'),
+                       ('depth_consistency_weight', 'loss_depth_consistency')):
+            if on(wk):
+                term = weights[wk] * parts[pk]
+                total = term if total is None else total + term
         return total, parts
 
     def forward(self, rgb_pred, rgb_gt, depth_pred=None, depth_gt=None, weights={}, rgb_loss_type='l2', **kwargs):
@@ -145,7 +148,9 @@ class Loss(nn.Module):
         aux, parts = self.aux_terms(rgb_gt, weights=weights, **kwargs)
         parts['loss_rgb'] = self.get_rgb_full_loss(rgb_pred, rgb_gt, rgb_loss_type) if on('rgb_weight') else z
         parts['loss_depth'] = self.get_depth_loss(depth_pred, depth_gt) if on('depth_weight') else z
-        loss = weights['rgb_weight'] * parts['loss_rgb'] + weights['depth_weight'] * parts['loss_depth'] + aux
+        loss = weights['rgb_weight'] * parts['loss_rgb'] + weights['depth_weight'] * parts['loss_depth']
+        if aux is not None:
+            loss = loss + aux
         if torch.isnan(loss):
             raise FloatingPointError('NaN loss (the reference drops into breakpoint() here, losses.py:204-205)')
         out = {'loss': loss, 'l2_mean': F.mse_loss(rgb_pred, rgb_gt) if rendering else z}

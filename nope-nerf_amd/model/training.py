@@ -48,7 +48,8 @@ class Trainer(object):
             setattr(self, k, cfg[k])
         self.loss = Loss(cfg)
         self._warned_geo = False
-        self._nan_flag = None      # device-side isnan(loss) of the previous step, checked one step late (no sync in the step)
+        self._nan_flag = None      # (pinned host flag, event) of the previous step's isnan(loss), read one step late
+        self._nan_host = None
 
     # ------------------------------------------------------------------------------------------------ step
     def _groups(self):
@@ -131,9 +132,12 @@ class Trainer(object):
         lo, hi = parallel.shard_bounds(n_total, rank, world)
         ray_loc = ray_idx[lo:hi]
         rgb_gt = img.view(batch_size, 3, h * w).permute(0, 2, 1)[:, ray_loc]
-        xs = (ray_loc % w).float()
-        ys = torch.div(ray_loc, w, rounding_mode='floor').float()
-        p = torch.stack([2.0 * xs / (w - 1) - 1.0, 2.0 * ys / (h - 1) - 1.0], dim=-1).unsqueeze(0)   # == arange_pixels()[1][:, idx]
+        if ray_loc.is_cuda:
+            p = camera.pixels_from_index(ray_loc, h, w)                                # == arange_pixels()[1][:, idx], one launch
+        else:
+            xs = (ray_loc % w).float()
+            ys = torch.div(ray_loc, w, rounding_mode='floor').float()
+            p = torch.stack([2.0 * xs / (w - 1) - 1.0, 2.0 * ys / (h - 1) - 1.0], dim=-1).unsqueeze(0)
 
         rendered_rgb = rendered_depth = gt_depth = None
         if render_model:
@@ -166,11 +170,25 @@ class Trainer(object):
         return camera.inverse4(m) if m.is_cuda else torch.inverse(m)
 
     def _check_nan(self, loss):
-        """The reference stops on a NaN loss (losses.py:204-205).  Testing it synchronously would stall the launch queue
-        every step, so the flag of step i is read at step i+1 (it is long complete by then)."""
-        if self._nan_flag is not None and bool(self._nan_flag):
-            raise FloatingPointError('NaN loss in the previous training step')
-        self._nan_flag = torch.isnan(loss.detach())
+        """The reference stops on a NaN loss (losses.py:204-205).  Reading the flag synchronously (or even enqueueing its
+        device->host copy late) would drain the launch queue every step, so the copy of step i is enqueued -- into pinned
+        memory, with an event -- right behind its loss kernel and only looked at during step i+1."""
+        if self._nan_flag is not None:
+            host, ev = self._nan_flag
+            ev.synchronize()
+            if bool(host):
+                raise FloatingPointError('NaN loss in the previous training step')
+        if loss.is_cuda:
+            if self._nan_host is None:
+                self._nan_host = [torch.empty((), dtype=torch.bool).pin_memory() for _ in range(2)]
+            host = self._nan_host[0]
+            self._nan_host.reverse()
+            host.copy_(torch.isnan(loss.detach()), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._nan_flag = (host, ev)
+        elif bool(torch.isnan(loss)):
+            raise FloatingPointError('NaN loss')
 
     def _total_loss(self, out, rgb, rgb_gt, depth_pred, depth_gt, n_total, ray_idx, depth_input, img_size, kwargs, world):
         """rgb + depth heads (fused HIP kernel on the GPU) + per-image terms.  Under data parallelism each rank holds a
@@ -192,7 +210,10 @@ class Trainer(object):
             loss_dict = self.loss(rgb, rgb_gt, depth_pred, depth_gt, **kwargs)
             return loss_dict
         aux, parts = self.loss.aux_terms(rgb_gt, **kwargs)
-        loss_dict = {k: v / world for k, v in parts.items()}
+        if world > 1:
+            parts = {k: v / world for k, v in parts.items()}
+            aux = aux / world if aux is not None else None
+        loss_dict = dict(parts)
         zero = torch.zeros((), device=rgb_gt.device)
         if out is None:
             lmain, lrgb, ldep, l2 = zero, zero, zero, zero
@@ -211,7 +232,7 @@ class Trainer(object):
             ldep = (depth_pred - depth_gt).abs().sum() / float(max(m_total, 1.0)) if w['depth_weight'] != 0.0 else zero
             l2 = (diff * diff).sum() / float(3 * n_total)
             lmain = w['rgb_weight'] * lrgb + w['depth_weight'] * ldep
-        loss_dict.update(loss_rgb=lrgb, loss_depth=ldep, l2_mean=l2, loss=lmain + aux / world)
+        loss_dict.update(loss_rgb=lrgb, loss_depth=ldep, l2_mean=l2, loss=lmain if aux is None else lmain + aux)
         self._check_nan(loss_dict['loss'])
         return loss_dict
 

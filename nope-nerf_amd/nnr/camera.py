@@ -170,3 +170,11 @@ def render_loss(rgb, rgb_gt, dist, d_gt, mask, *, r_total, m_total=-1.0, w_rgb, 
     """Weighted rgb + depth loss heads on dense per-ray tensors + validity mask.
     Returns (loss, aux) with aux = [loss_rgb, loss_depth, l2_mean, n_valid]."""
     return _RenderLoss.apply(rgb, rgb_gt, dist, d_gt, mask, r_total, m_total, w_rgb, w_depth, rgb_l2, ndc, detach_gt)
+
+
+def pixels_from_index(ray_idx: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """Flat pixel indices (R,) -> scaled pixel coordinates (1,R,2) in [-1,1] (no gradient)."""
+    idx = ray_idx.detach().contiguous().long()
+    out = torch.empty(1, idx.shape[0], 2, dtype=torch.float32, device=idx.device)
+    L.check(L.load().nnr_pixels_from_index(L.ptr(idx), L.ptr(out), idx.shape[0], int(h), int(w), _st()), "nnr_pixels_from_index")
+    return out

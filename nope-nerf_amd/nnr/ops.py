@@ -8,6 +8,7 @@ PyTorch is used for device memory, the current stream and the autograd graph edg
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -25,34 +26,42 @@ def _require_gpu(t: torch.Tensor):
 # packed weights: re-packed only when a parameter tensor changed (optimizer.step bumps tensor._version)
 # ----------------------------------------------------------------------------------------------------------------------
 class _PackCache:
-    def __init__(self):
-        self.key = None
-        self.packed = None
+    """Valid only for the very same tensor objects (weak references -- a data_ptr or id() can be recycled by a new model
+    after the old one is freed) at the very same in-place versions."""
 
-    def get(self, cfg: L.Cfg, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> torch.Tensor:
-        key = (cfg.hidden,) + tuple((t.data_ptr(), t._version) for t in (*weights, *biases))
-        if key != self.key or self.packed is None:
-            lib = L.load()
-            n = lib.nnr_packed_floats(C.byref(cfg))
-            packed = torch.empty(n, dtype=torch.float32, device=weights[0].device)
-            ps = L.params_struct(weights, biases)
-            L.check(lib.nnr_pack_weights(C.byref(cfg), C.byref(ps), L.ptr(packed),
-                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_pack_weights")
-            self.key, self.packed = key, packed
-        return self.packed
+    def __init__(self, hidden, tensors, packed):
+        self.hidden = hidden
+        self.refs = [weakref.ref(t) for t in tensors]
+        self.versions = [t._version for t in tensors]
+        self.packed = packed
+
+    def matches(self, hidden, tensors):
+        return (self.hidden == hidden and len(self.refs) == len(tensors)
+                and all(r() is t for r, t in zip(self.refs, tensors))
+                and self.versions == [t._version for t in tensors])
 
 
-_pack_caches = {}   # (device, data_ptr of the first weight) -> cache; a handful of models at most
+_pack_caches = {}   # id(first weight) -> _PackCache; a handful of live models at most
 
 
 def _packed_for(cfg, weights, biases):
-    anchor = (str(weights[0].device), weights[0].data_ptr())
-    cache = _pack_caches.get(anchor)
-    if cache is None:
-        if len(_pack_caches) >= 8:
-            _pack_caches.pop(next(iter(_pack_caches)))
-        cache = _pack_caches[anchor] = _PackCache()
-    return cache.get(cfg, weights, biases)
+    """Packed (MFMA-fragment order) copy of the 24 parameter tensors; `weights`/`biases` must be the caller's long-lived
+    tensor objects (nn.Parameters), not temporaries."""
+    tensors = [*weights, *biases]
+    key = id(tensors[0])
+    hit = _pack_caches.get(key)
+    if hit is not None and hit.matches(cfg.hidden, tensors):
+        return hit.packed
+    lib = L.load()
+    n = lib.nnr_packed_floats(C.byref(cfg))
+    packed = torch.empty(n, dtype=torch.float32, device=tensors[0].device)
+    ps = L.params_struct([w.detach() for w in weights], [b.detach() for b in biases])
+    L.check(lib.nnr_pack_weights(C.byref(cfg), C.byref(ps), L.ptr(packed),
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_pack_weights")
+    for k in [k for k, v in _pack_caches.items() if any(r() is None for r in v.refs)]:
+        del _pack_caches[k]             # drop entries of models that no longer exist
+    _pack_caches[key] = _PackCache(cfg.hidden, tensors, packed)
+    return packed
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -136,9 +145,7 @@ class _RenderRays(torch.autograd.Function):
         pts_o, pts_d, view_d = (t.detach().contiguous().float() for t in (pts_o, pts_d, view_d))
         z_lo, z_hi = z_lo.detach().contiguous().float(), z_hi.detach().contiguous().float()
         jit = jitter.detach().contiguous().float().view(R, N) if jitter is not None else None
-        weights = [w.detach() for w in weights]
-        biases = [b.detach() for b in biases]
-        packed = _packed_for(cfg, weights, biases)
+        packed = _packed_for(cfg, *opts["params"])
         ws = _take_workspace(cfg, dev)
         rgb = torch.empty(R, 3, **f32)
         dist = torch.empty(R, **f32)
@@ -154,6 +161,7 @@ class _RenderRays(torch.autograd.Function):
         else:
             _give_workspace(cfg, dev, ws)
         ctx.mark_non_differentiable(alpha, zv)
+        ctx.set_materialize_grads(False)      # undefined upstream gradients arrive as None, not as zero-filled tensors
         return rgb, dist, alpha, zv
 
     @staticmethod
@@ -195,7 +203,8 @@ def render_rays(pts_o: torch.Tensor, pts_d: torch.Tensor, view_d: torch.Tensor, 
     """(R,3) sampling origin / direction / view direction, (N) z interval tables, optional (R,N) jitter, the 12
     nn.Linear weights and biases in state_dict order  ->  rgb (R,3), dist (R), alpha (R,N), z (R,N).
     Differentiable w.r.t. pts_o, pts_d, view_d, weights, biases."""
-    opts = dict(hidden=hidden, dist_alpha=dist_alpha, white_bg=white_bg, relu_sigma=relu_sigma)
+    opts = dict(hidden=hidden, dist_alpha=dist_alpha, white_bg=white_bg, relu_sigma=relu_sigma,
+                params=(list(weights), list(biases)))    # the caller's own tensor objects: identity keys the pack cache
     if not torch.is_grad_enabled():
         # forward-only (eval / visualisation inside torch.no_grad): no stash, small workspace
         return _RenderRays.apply(pts_o.detach(), pts_d.detach(), view_d.detach(), z_lo, z_hi, jitter, opts,
@@ -214,7 +223,7 @@ def mlp_points(pts: torch.Tensor, view: torch.Tensor, weights, biases, *, hidden
     view = view.detach().contiguous().float()
     zeros3 = torch.zeros_like(pts)
     z0 = torch.zeros(1, dtype=torch.float32, device=dev)
-    packed = _packed_for(cfg, [w.detach() for w in weights], [b.detach() for b in biases])
+    packed = _packed_for(cfg, list(weights), list(biases))
     ws = _take_workspace(cfg, dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     L.check(lib.nnr_mlp_fwd(C.byref(cfg), L.ptr(pts), L.ptr(zeros3), L.ptr(view), L.ptr(z0), L.ptr(z0), None,

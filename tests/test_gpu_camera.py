@@ -49,8 +49,8 @@ def test_inverse4_matches_torch():
     a2 = a.to(DEV).requires_grad_(True)
     out = camera.inverse4(a2)
     (out * G.to(DEV)).sum().backward()
-    close(out, ref, 1e-5)
-    close(a2.grad, a1.grad, 1e-5)
+    close(out, ref, 5e-5)        # cofactor formula vs LU: different rounding, same answer
+    close(a2.grad, a1.grad, 5e-5)
 
 
 def torch_ray_setup(pixels, depth, K, W, S, normalise, use_dir):
@@ -123,6 +123,15 @@ def test_depth_gather_matches_interpolate(dst, src):
     (out * up.to(DEV)).sum().backward()
     assert torch.equal(out.cpu(), ref.detach())
     close(b.grad, a.grad, 1e-6)
+
+
+def test_pixels_from_index_is_bit_exact():
+    from model.common import arange_pixels
+    from nnr import camera
+    h, w = 540, 960
+    idx = torch.randperm(h * w, generator=torch.Generator().manual_seed(9))[:4096]
+    ref = arange_pixels((h, w))[1][:, idx]
+    assert torch.equal(camera.pixels_from_index(idx.to(DEV), h, w).cpu(), ref)
 
 
 @pytest.mark.parametrize("l2,ndc,detach", [(False, False, False), (True, False, False), (False, True, False), (False, False, True)])
