@@ -15,38 +15,92 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// acc[mt] += A_part[32*mt.., :] * in   for one layer part.
+// ---- weight panels through LDS ---------------------------------------------------------------------------------------
+// The four waves of a workgroup consume the same packed-weight stream, one 32 KiB panel (32 fragments = 128 MFMAs per
+// wave = 8192 cycles) at a time.  Panels are DMA'd global -> LDS (global_load_lds_dwordx4: 1 KiB per wave-instruction,
+// lane-linear, no VGPR round trip) into a ring of three buffers, two panels ahead; MFMA issue then depends only on
+// ds_read_b128 (lgkmcnt), never on vmcnt -- which on CDNA4 also counts the stash *stores* interleaved into the stream and
+// would otherwise stall every k-group behind HBM write latency.  Per panel: one counted s_waitcnt + one s_barrier.
+constexpr int kNBuf = 3;
+constexpr int kPanelF4 = kPanelFrags * 64;  // float4 elements per panel
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+struct PanelPipe {
+    const f32x4* src;  // stream base in global memory, already offset by this lane and this wave's fragment slice
+    f32x4* lds;        // base of the three panel buffers in LDS
+    int wave, lane;
+    int n_panels;      // panels in the stream
+
+    // This wave copies fragments [8*wave, 8*wave+8) of panel p into buffer p % 3: 8 DMA instructions, always exactly 8 --
+    // the counted wait below relies on it.
+    __device__ __forceinline__ void issue(int p) const {
+        const f32x4* g = src + (int64_t)p * kPanelF4;
+        f32x4* l = lds + (p % kNBuf) * kPanelF4 + wave * (8 * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * 64), (lds_ptr_t)(l + i * 64), 16, 0, 0);
+    }
+    // Make panel p readable and recycle the buffer of panel p-1 for panel p+2.
+    //   vmcnt(8): everything older than the 8 youngest VMEM ops of this wave is complete.  The 8 DMA ops of panel p+1 were
+    //   issued after those of panel p, so panel p has landed (any stores issued since only make the wait more conservative).
+    //   The barrier then tells every wave that (a) all four slices of panel p are in LDS and (b) everybody is done reading
+    //   panel p-1, whose buffer the DMA of panel p+2 overwrites.
+    __device__ __forceinline__ void enter(int p) const {
+        // lgkmcnt(0): this wave's ds_reads of panel p-1 have returned before it reports "done reading" at the barrier
+        if (p + 1 < n_panels)
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (p + 2 < n_panels) issue(p + 2);
+    }
+    __device__ __forceinline__ void start() const {  // prologue: two panels in flight
+        issue(0);
+        if (n_panels > 1) issue(1);
+    }
+};
+
+// acc[mt] += A_part[32*mt.., :] * in   for one layer part whose packed panels start at stream panel p0.
 //   in    : 16*KT registers in fragment layout (this wave's 32 samples)
-//   frag  : packed A fragments of the part, [4*KT][MT][64] float4, already offset by +lane
 //   stash : optional (sample, feature) row-major destination of `in` (row of this lane's sample, + 4*half): the four
 //           registers consumed by k-group g are features 8g+4h..+3, i.e. one 16-byte store per k-group, issued *inside*
-//           the MFMA stream.  Stashing a layer's input here -- instead of its output in the epilogue -- spreads the
-//           10 KB/sample of training stash evenly over the kernel; in an epilogue burst every CU of the chip stores at
-//           once and each wave then sits in s_waitcnt vmcnt (stores count) until HBM has drained 32 MB.
-// Fragments are fetched straight from L2/L1 one k-group ahead (1 KiB coalesced per wave-load, 4 MFMAs each); all
-// waves of the chip stream the same 2.4 MB so the working set is L2 resident and the 4 waves of a CU share L1 lines.
+//           the MFMA stream.  Stashing a layer's input here -- instead of its output in an epilogue burst -- spreads the
+//           10 KB/sample of training stash evenly over the kernel.
 template <int KT, int MT, bool STASH = false, int NACC, int NIN>
-__device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const f32x4* __restrict__ frag,
+__device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
                                           float* stash = nullptr) {
     static_assert(MT <= NACC && 16 * KT <= NIN, "tile counts exceed the register arrays");
-    constexpr int G = 4 * KT;
-    f32x4 cur[MT], nxt[MT];
+    constexpr int G = 4 * KT, GP = part_gp(MT), NP = part_panels(KT, MT);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) cur[mt] = frag[mt * 64];
+    for (int q = 0; q < NP; ++q) {
+        const int p = p0 + q;
+        pipe.enter(p);
+        const f32x4* buf = pipe.lds + (p % kNBuf) * kPanelF4 + pipe.lane;
+        f32x4 cur[MT], nxt[MT];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (g + 1 < G) {
+        for (int mt = 0; mt < MT; ++mt) cur[mt] = buf[mt * 64];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) nxt[mt] = frag[((g + 1) * MT + mt) * 64];
+        for (int gl = 0; gl < GP; ++gl) {
+            const int g = q * GP + gl;
+            if (g < G) {
+                if (gl + 1 < GP && g + 1 < G) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) nxt[mt] = buf[((gl + 1) * MT + mt) * 64];
+                }
+                if constexpr (STASH)
+                    *reinterpret_cast<f32x4*>(stash + 8 * g) = f32x4{in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(cur[mt][i], in[4 * g + i], acc[mt]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) cur[mt] = nxt[mt];
+            }
         }
-        if constexpr (STASH) *reinterpret_cast<f32x4*>(stash + 8 * g) = f32x4{in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(cur[mt][i], in[4 * g + i], acc[mt]);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) cur[mt] = nxt[mt];
     }
 }
 

@@ -12,9 +12,11 @@
 // Four consecutive registers r = 4g..4g+3 hold features 8g+4h+{0,1,2,3}: four consecutive k.
 //
 // Packed weights ("A fragments"): for a layer part with A[Mp=32*MT][Kp=32*KT] the fragment (g, mt), g in [0,4*KT),
-// is 64 lanes x 4 floats = 1 KiB, lane l holding A[32*mt + (l&31)][8*g + 4*(l>>5) + i], i = 0..3, and fragments are
-// stored in consumption order  index = g*MT + mt.  A wave's 16-byte-per-lane load of one fragment is one contiguous
-// 1 KiB read and feeds 4 MFMAs.
+// is 64 lanes x 4 floats = 1 KiB, lane l holding A[32*mt + (l&31)][8*g + 4*(l>>5) + i], i = 0..3: one 16-byte-per-lane
+// read of a fragment feeds 4 MFMAs.  Fragments are grouped into PANELS of 32 KiB (32 fragment slots) in consumption
+// order -- the unit the MLP kernels DMA into LDS (global_load_lds_dwordx4, lane-linear, so the LDS image equals the global
+// image and a ds_read_b128 at +lane*16 is conflict-free).  A panel holds GP = 32/MT whole k-groups of one part (k-groups
+// never straddle panels; slots beyond GP*MT are zero padding), fragment (g, mt) living in panel g/GP, slot (g%GP)*MT + mt.
 #pragma once
 #include <stdint.h>
 
@@ -47,7 +49,10 @@ struct PartDesc {
     int ld;         // W row pitch (= in_features)
 };
 
-NNR_HD constexpr int part_floats(int KT, int MT) { return 4 * KT * MT * 256; }
+constexpr int kPanelFrags = 32;                 // fragment slots per panel
+constexpr int kPanelFloats = kPanelFrags * 256;  // 32 KiB
+NNR_HD constexpr int part_gp(int MT) { return kPanelFrags / MT; }  // k-groups per panel
+NNR_HD constexpr int part_panels(int KT, int MT) { return (4 * KT + part_gp(MT) - 1) / part_gp(MT); }
 
 template <int D>
 struct Layout {
@@ -89,18 +94,22 @@ struct Layout {
             default: return {0, 1, DT, 2, kPosReal, D, 0, kPosReal};
         }
     }
-    NNR_HD static constexpr int fwd_off(int p) {
+    // first panel of a part; the forward stream occupies panels [0, fwd_panels), the backward stream follows
+    NNR_HD static constexpr int fwd_panel0(int p) {
         int o = 0;
-        for (int i = 0; i < p; ++i) o += part_floats(fwd(i).KT, fwd(i).MT);
+        for (int i = 0; i < p; ++i) o += part_panels(fwd(i).KT, fwd(i).MT);
         return o;
     }
-    NNR_HD static constexpr int bwd_off(int p) {
-        int o = fwd_off(F_NPARTS);
-        for (int i = 0; i < p; ++i) o += part_floats(bwd(i).KT, bwd(i).MT);
+    static constexpr int fwd_panels = fwd_panel0(F_NPARTS);
+    NNR_HD static constexpr int bwd_panel0(int p) {  // relative to the start of the backward stream
+        int o = 0;
+        for (int i = 0; i < p; ++i) o += part_panels(bwd(i).KT, bwd(i).MT);
         return o;
     }
+    static constexpr int bwd_panels = bwd_panel0(B_NPARTS);
+    static constexpr int bwd_base = fwd_panels * kPanelFloats;  // float offset of the backward stream
     // biases, each padded to a multiple of 32 floats: hidden 1..8, sigma, feature, colour hidden, rgb
-    static constexpr int bias_base = bwd_off(B_NPARTS);
+    static constexpr int bias_base = (fwd_panels + bwd_panels) * kPanelFloats;
     NNR_HD static constexpr int bias_off(int layer) {  // layer in state_dict order
         int o = bias_base;
         for (int i = 0; i < layer; ++i) o += bias_pad(i);
@@ -109,6 +118,7 @@ struct Layout {
     NNR_HD static constexpr int bias_pad(int layer) { return layer == 8 || layer == 11 ? 32 : (layer == 10 ? (D / 2 + 31) / 32 * 32 : D); }
     NNR_HD static constexpr int bias_real(int layer) { return layer == 8 ? 1 : layer == 11 ? 3 : layer == 10 ? D / 2 : D; }
     static constexpr int packed_floats = bias_off(12);
+    static constexpr int bias_floats = packed_floats - bias_base;
 
     // ---- workspace planes (floats), S_pad = samples rounded up to a multiple of kBlockSamples ----
     static constexpr int x_width = kPosPad + 8 * D + (D + kDirPad) + D / 2;  // per-sample activation stash

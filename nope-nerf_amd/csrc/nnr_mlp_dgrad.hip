@@ -20,8 +20,12 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     const int64_t s = (int64_t)blockIdx.x * kBlockSamples + wave * kChunk + col;
     const bool live = s < a.S;  // padded samples carry zero gradients so they add nothing to the weight gradients
 
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed) + lane;
-    auto frag = [&](int part) { return wp + L::bwd_off(part) / 4; };
+    // weight panels of the transposed (backward) stream through the LDS ring -- see PanelPipe in nnr_device.h
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4];
+    const PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed + L::bwd_base) + wave * (8 * 64) + lane, smem, wave, lane,
+                         L::bwd_panels};
+    pipe.start();
+    auto p0 = [&](int part) { return L::bwd_panel0(part); };
     const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const uint32_t* mask_base = a.ws_mask + ((chunk * L::n_mask_layers) * 64 + lane) * L::mask_words;
 
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     {
         f32x16 acc[HT];
         zero_acc(acc);
-        gemm_part<1, HT>(acc, drgb, frag(B_RGB));
+        gemm_part<1, HT>(acc, drgb, pipe, p0(B_RGB));
         uint32_t mw[L::mask_words];
         const uint32_t* m = mask_base + (int64_t)8 * 64 * L::mask_words;
 #pragma unroll
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
         zero_acc(acc);
         // every gradient vector is stashed by the gemm that consumes it (one 16-byte store per k-group, inside the
         // MFMA stream) -- see gemm_part
-        gemm_part<HT, DT + 1, true>(acc, dg, frag(B_RGBH), a.ws_dg + s * (D / 2) + 4 * half);
+        gemm_part<HT, DT + 1, true>(acc, dg, pipe, p0(B_RGBH), a.ws_dg + s * (D / 2) + 4 * half);
 #pragma unroll
         for (int r = 0; r < 16 * DT; ++r) d[r] = acc[r >> 4][r & 15];
         // direction-encoding backward: d v = sum_f d gamma_4(v)_f/dv * grad_f, using the stored encoding for the
@@ -96,19 +100,19 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     for (int r = 0; r < 16; ++r) dsig[r] = 0.f;
     dsig[0] = half == 0 ? dout[3] : 0.f;
     zero_acc(acc);
-    gemm_part<DT, DT, true>(acc, d, frag(B_FEAT), a.ws_df + s * D + 4 * half);
-    gemm_part<1, DT>(acc, dsig, frag(B_SIG));
+    gemm_part<DT, DT, true>(acc, d, pipe, p0(B_FEAT), a.ws_df + s * D + 4 * half);
+    gemm_part<1, DT>(acc, dsig, pipe, p0(B_SIG));
     masked_layer(7);
     // hidden 8,7,6 -> d pre-activation of 7,6,5
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         zero_acc(acc);
-        gemm_part<DT, DT, true>(acc, d, wp + (L::bwd_off(B_L8) + l * part_floats(DT, DT)) / 4, dh(7 - l));
+        gemm_part<DT, DT, true>(acc, d, pipe, p0(B_L8) + l * part_panels(DT, DT), dh(7 - l));
         masked_layer(6 - l);
     }
     // hidden 5 (skip layer): rows [0,D) -> d h4, rows [D, D+64) -> d posenc (kept for the end)
     zero_acc(acc);
-    gemm_part<DT, DT + 2, true>(acc, d, frag(B_L5), dh(4));
+    gemm_part<DT, DT + 2, true>(acc, d, pipe, p0(B_L5), dh(4));
     float de[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) de[r] = acc[DT + (r >> 4)][r & 15];
@@ -117,14 +121,14 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         zero_acc(acc);
-        gemm_part<DT, DT, true>(acc, d, wp + (L::bwd_off(B_L4) + l * part_floats(DT, DT)) / 4, dh(3 - l));
+        gemm_part<DT, DT, true>(acc, d, pipe, p0(B_L4) + l * part_panels(DT, DT), dh(3 - l));
         masked_layer(2 - l);
     }
     // hidden 1: d posenc += W1^T d1
     {
         f32x16 acc2[2];
         zero_acc(acc2);
-        gemm_part<DT, 2, true>(acc2, d, frag(B_L1), dh(0));
+        gemm_part<DT, 2, true>(acc2, d, pipe, p0(B_L1), dh(0));
 #pragma unroll
         for (int r = 0; r < 32; ++r) de[r] += acc2[r >> 4][r & 15];
     }

@@ -1,7 +1,7 @@
 // nnr_mlp_fwd.hip -- fused NeRF MLP forward for gfx950: sampling + positional encoding + 12 layers, per-sample
 // (rgb, sigma_raw) out.  Restates, per sample: model/rendering.py:184-195 (z, points, view dir) and
 // model/official_nerf.py:60-96 (the MLP).  One wave = 32 samples; activations stay in VGPRs between layers as MFMA
-// B-operands (see nnr_layout.h); weights stream from L2 as pre-packed A fragments.
+// B-operands (see nnr_layout.h); weights arrive as pre-packed A fragments through a DMA-fed LDS ring shared by the 4 waves.
 //
 // Roofline: MFMA-bound.  593 408 MACs/sample at D=256 -> 9 472 v_mfma_f32_32x32x2_f32 per 32 samples (9 272 useful,
 // 2 % padding of the 63/27/1/3-wide edges) = 606 k cycles per wave against ~10 k cycles of everything else.
@@ -45,9 +45,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dirv[r] = enc_feature(frag_feature(r, half), kDirReal, vx, vy, vz);
 
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed) + lane;
-    auto frag = [&](int part) { return wp + L::fwd_off(part) / 4; };
-    const float* bias = a.packed;
+    // ---- weight panels (LDS ring, DMA two panels ahead) and the bias table, all in ONE __shared__ array ----
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + (L::bias_floats + 3) / 4];
+    float* const lbias = reinterpret_cast<float*>(smem + kNBuf * kPanelF4);
+    for (int i = threadIdx.x; i < L::bias_floats; i += 256) lbias[i] = a.packed[L::bias_base + i];
+    __syncthreads();   // before any DMA is in flight: this is the only full barrier of the kernel
+    const PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave * (8 * 64) + lane, smem, wave, lane, L::fwd_panels};
+    pipe.start();
+    auto p0 = [&](int part) { return L::fwd_panel0(part); };
+    const float* bias = lbias - L::bias_base;   // index with L::bias_off(layer)
 
     uint32_t* mask_base = nullptr;
     if (TRAIN) {
@@ -94,35 +100,35 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     auto xh = [&](int hidden_idx /*0..7*/) -> float* {
         return TRAIN ? a.ws_xh + ((int64_t)hidden_idx * a.S_pad + s) * D + 4 * half : nullptr;
     };
-    gemm_part<2, DT, TRAIN>(acc, e, frag(F_L1), xe);
+    gemm_part<2, DT, TRAIN>(acc, e, pipe, p0(F_L1), xe);
     relu_layer(0);
     // hidden 2..4
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         zero_acc(acc);
-        gemm_part<DT, DT, TRAIN>(acc, h, wp + (L::fwd_off(F_L2) + l * part_floats(DT, DT)) / 4, xh(l));
+        gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_L2) + l * part_panels(DT, DT), xh(l));
         relu_layer(1 + l);
     }
     // hidden 5: [h4 ; e] -> D   (skip connection, input order [h, posenc]: model/official_nerf.py:63)
     zero_acc(acc);
-    gemm_part<DT, DT, TRAIN>(acc, h, frag(F_L5H), xh(3));
-    gemm_part<2, DT>(acc, e, frag(F_L5E));
+    gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_L5H), xh(3));
+    gemm_part<2, DT>(acc, e, pipe, p0(F_L5E));
     relu_layer(4);
     // hidden 6..8
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         zero_acc(acc);
-        gemm_part<DT, DT, TRAIN>(acc, h, wp + (L::fwd_off(F_L6) + l * part_floats(DT, DT)) / 4, xh(4 + l));
+        gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_L6) + l * part_panels(DT, DT), xh(4 + l));
         relu_layer(5 + l);
     }
     // density head: D -> 1 (row 0 of a 32-row tile)
     f32x16 acc1[1];
     zero_acc(acc1);
-    gemm_part<DT, 1>(acc1, h, frag(F_SIG));
+    gemm_part<DT, 1>(acc1, h, pipe, p0(F_SIG));
     const float sigma_raw = acc1[0][0] + bias[L::bias_off(8)];
     // feature: D -> D, no activation
     zero_acc(acc);
-    gemm_part<DT, DT, TRAIN>(acc, h, frag(F_FEAT), xh(7));
+    gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_FEAT), xh(7));
     float* const xf = TRAIN ? a.ws_xf + s * (D + kDirPad) + 4 * half : nullptr;
     {
         const float* b = bias + L::bias_off(9) + 4 * half;
@@ -138,8 +144,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // colour hidden: [feat ; gamma_4(v)] -> D/2, ReLU   (input order [feat, dir_enc]: model/official_nerf.py:89)
     f32x16 accg[HT];
     zero_acc(accg);
-    gemm_part<DT, HT, TRAIN>(accg, h, frag(F_RGBH_F), xf);
-    gemm_part<1, HT, TRAIN>(accg, dirv, frag(F_RGBH_D), TRAIN ? xf + D : nullptr);
+    gemm_part<DT, HT, TRAIN>(accg, h, pipe, p0(F_RGBH_F), xf);
+    gemm_part<1, HT, TRAIN>(accg, dirv, pipe, p0(F_RGBH_D), TRAIN ? xf + D : nullptr);
     float g[16 * HT];
     {
         const float* b = bias + L::bias_off(10) + 4 * half;
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     }
     // rgb: D/2 -> 3, sigmoid (rows 0..2 of a 32-row tile live in registers 0..2 of half 0)
     zero_acc(acc1);
-    gemm_part<HT, 1, TRAIN>(acc1, g, frag(F_RGB), TRAIN ? a.ws_xg + s * (D / 2) + 4 * half : nullptr);
+    gemm_part<HT, 1, TRAIN>(acc1, g, pipe, p0(F_RGB), TRAIN ? a.ws_xg + s * (D / 2) + 4 * half : nullptr);
     if (half == 0 && s < a.S) {
         const float* b = bias + L::bias_off(11);
         f32x4 o;

@@ -1,6 +1,7 @@
 // nnr_pack.hip -- re-pack the 12 nn.Linear tensors of OfficialStaticNerf (model/official_nerf.py:20-37, (out,in)
 // row-major) into MFMA A-fragment order (nnr_layout.h), once forward-oriented (A = W) and once transposed (A = W^T, for
-// the input-gradient chain), plus zero-padded biases.  One launch, ~5 MB written; runs after every optimiser step.
+// the input-gradient chain), grouped into the 32 KiB panels the MLP kernels DMA into LDS, plus zero-padded biases.
+// One launch, ~5 MB written; runs after every optimiser step.
 #include "nnr_device.h"
 #include "nnr_kernels.h"
 
@@ -12,29 +13,31 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per packed float4
     const int64_t n_frag4 = L::bias_base / 4;
     if (gid < n_frag4) {
-        // locate the part
-        int64_t f = gid * 4;  // float offset
+        const int panel = (int)(gid / (kPanelFrags * 64));   // global panel index (forward stream, then backward stream)
+        const int slot = (int)((gid / 64) % kPanelFrags);
+        const int lane = (int)(gid & 63);
+        // locate the part that owns this panel
         PartDesc pd{};
-        int64_t base = 0;
+        int base = 0;
         bool found = false;
 #pragma unroll
         for (int p = 0; p < F_NPARTS; ++p) {
             const PartDesc d = L::fwd(p);
-            const int64_t sz = part_floats(d.KT, d.MT);
-            if (!found && f < base + sz) { pd = d; found = true; }
-            if (!found) base += sz;
+            const int np = part_panels(d.KT, d.MT);
+            if (!found && panel < base + np) { pd = d; found = true; }
+            if (!found) base += np;
         }
 #pragma unroll
         for (int p = 0; p < B_NPARTS; ++p) {
             const PartDesc d = L::bwd(p);
-            const int64_t sz = part_floats(d.KT, d.MT);
-            if (!found && f < base + sz) { pd = d; found = true; }
-            if (!found) base += sz;
+            const int np = part_panels(d.KT, d.MT);
+            if (!found && panel < base + np) { pd = d; found = true; }
+            if (!found) base += np;
         }
-        const int64_t local = (f - base) / 4;       // float4 index inside the part: (g*MT + mt)*64 + lane
-        const int lane = (int)(local & 63);
-        const int fi = (int)(local >> 6);
-        const int mt = fi % pd.MT, g = fi / pd.MT;
+        const int gp = part_gp(pd.MT);
+        const int g = (panel - base) * gp + slot / pd.MT;   // k-group
+        const int mt = slot % pd.MT;
+        const bool live = slot < gp * pd.MT && g < 4 * pd.KT;
         const int m = 32 * mt + (lane & 31);
         const int k0 = 8 * g + 4 * (lane >> 5);
         const float* W = a.w[pd.layer];
@@ -43,7 +46,8 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + i;
             float x = 0.f;
-            if (m < pd.m_real && k < pd.k_real) x = pd.transpose ? W[(int64_t)k * pd.ld + pd.off + m] : W[(int64_t)m * pd.ld + pd.off + k];
+            if (live && m < pd.m_real && k < pd.k_real)
+                x = pd.transpose ? W[(int64_t)k * pd.ld + pd.off + m] : W[(int64_t)m * pd.ld + pd.off + k];
             v[i] = x;
         }
         reinterpret_cast<f32x4*>(a.packed)[gid] = v;

@@ -41,16 +41,33 @@ def part_matrix(W, part):
     return A
 
 
+PANEL_FRAGS = 32
+
+
 def pack_part(A, KT, MT):
-    """[4*KT][MT][64 lanes][4] with lane l -> A[32*mt + (l&31)][8*g + 4*(l>>5) + i]."""
-    out = np.zeros((4 * KT, MT, 64, 4), dtype=np.float32)
+    """Panelised fragments of one part: [n_panels][32 slots][64 lanes][4]; k-group g lives in panel g//GP (GP = 32//MT),
+    slot (g % GP)*MT + mt; lane l holds A[32*mt + (l&31)][8*g + 4*(l>>5) + i].  Unused slots are zero."""
+    gp = PANEL_FRAGS // MT
+    n_panels = (4 * KT + gp - 1) // gp
+    out = np.zeros((n_panels, PANEL_FRAGS, 64, 4), dtype=np.float32)
     lane = np.arange(64)
     for g in range(4 * KT):
         for mt in range(MT):
             rows = 32 * mt + (lane & 31)
             for i in range(4):
-                out[g, mt, :, i] = A[rows, 8 * g + 4 * (lane >> 5) + i]
+                out[g // gp, (g % gp) * MT + mt, :, i] = A[rows, 8 * g + 4 * (lane >> 5) + i]
     return out.reshape(-1)
+
+
+def part_frags(packed_part, KT, MT):
+    """Inverse view of pack_part: [4*KT][MT][64][4]."""
+    gp = PANEL_FRAGS // MT
+    pan = packed_part.reshape(-1, PANEL_FRAGS, 64, 4)
+    out = np.zeros((4 * KT, MT, 64, 4), dtype=packed_part.dtype)
+    for g in range(4 * KT):
+        for mt in range(MT):
+            out[g, mt] = pan[g // gp, (g % gp) * MT + mt]
+    return out
 
 
 def pack_all(weights, biases, D):
@@ -106,7 +123,7 @@ def mfma32(a, b, c):
 
 def gemm_part_emulated(packed_part, in_regs, KT, MT):
     """Mirror of nnr_device.h::gemm_part: returns acc[MT][16][64]."""
-    frag = packed_part.reshape(4 * KT, MT, 64, 4)
+    frag = part_frags(packed_part, KT, MT)
     acc = np.zeros((MT, 16, 64), dtype=np.float64)
     for g in range(4 * KT):
         for i in range(4):
