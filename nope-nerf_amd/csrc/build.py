@@ -23,6 +23,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name, defines):
+    """Profiling-only library with compile-time ablations (e.g. -DNNR_ABLATE_NO_STASH); results are NOT valid.
+    Written to nnr/libnnr_<name>.so and selected with NNR_LIB=<path> (see nnr/lib.py)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.join(os.path.dirname(HERE), "nnr", "libnnr_%s.so" % name)
+    cmd = [hipcc] + [f for f in FLAGS if f not in ("-x", "hip")] + ["-D" + d for d in defines] + ["-shared", "-x", "hip"] + \
+          [os.path.join(HERE, s) for s in SOURCES] + ["-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return out
+
+
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -49,4 +62,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant nostash NNR_ABLATE_NO_STASH [...]
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

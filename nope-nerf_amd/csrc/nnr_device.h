@@ -36,6 +36,9 @@ struct PanelPipe {
     // This wave copies fragments [8*wave, 8*wave+8) of panel p into buffer p % 3: 8 DMA instructions, always exactly 8 --
     // the counted wait below relies on it.
     __device__ __forceinline__ void issue(int p) const {
+#ifdef NNR_ABLATE_NO_DMA
+        return;
+#endif
         const f32x4* g = src + (int64_t)p * kPanelF4;
         f32x4* l = lds + (p % kNBuf) * kPanelF4 + wave * (8 * 64);
 #pragma unroll
@@ -48,6 +51,10 @@ struct PanelPipe {
     //   The barrier then tells every wave that (a) all four slices of panel p are in LDS and (b) everybody is done reading
     //   panel p-1, whose buffer the DMA of panel p+2 overwrites.
     __device__ __forceinline__ void enter(int p) const {
+#ifdef NNR_ABLATE_NO_SYNC
+        if (p + 2 < n_panels) issue(p + 2);
+        return;
+#endif
         // lgkmcnt(0): this wave's ds_reads of panel p-1 have returned before it reports "done reading" at the barrier
         if (p + 1 < n_panels)
             asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -90,8 +97,10 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) nxt[mt] = buf[((gl + 1) * MT + mt) * 64];
                 }
+#ifndef NNR_ABLATE_NO_STASH
                 if constexpr (STASH)
                     *reinterpret_cast<f32x4*>(stash + 8 * g) = f32x4{in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]};
+#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll

@@ -11,6 +11,12 @@
 
 namespace nnr {
 
+#ifdef NNR_ABLATE_NO_MASK
+constexpr bool kAblateNoMask = true;   // profiling build only
+#else
+constexpr bool kAblateNoMask = false;
+#endif
+
 template <int D, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     using L = Layout<D>;
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
                     x = fmaxf(x, 0.f);
                     const int r = 16 * t + 4 * q + i;
                     h[r] = x;
-                    if (TRAIN) mw[r >> 5] |= (x > 0.f ? 1u : 0u) << (r & 31);
+                    if (TRAIN && !kAblateNoMask) mw[r >> 5] |= (x > 0.f ? 1u : 0u) << (r & 31);
                 }
             }
         }
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
                     float x = fmaxf(accg[t][4 * q + i] + bb[i], 0.f);
                     const int r = 16 * t + 4 * q + i;
                     g[r] = x;
-                    if (TRAIN) mw[r >> 5] |= (x > 0.f ? 1u : 0u) << (r & 31);
+                    if (TRAIN && !kAblateNoMask) mw[r >> 5] |= (x > 0.f ? 1u : 0u) << (r & 31);
                 }
             }
         if (TRAIN) {

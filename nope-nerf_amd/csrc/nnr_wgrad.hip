@@ -98,6 +98,9 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
     }
 
     // flush: D[row m'][col n] of sub-tile (i,j) -> dW[row0 + MI*m' + i][wcol0 + NI*n + j]
+#ifdef NNR_ABLATE_NO_FLUSH
+    return;
+#endif
     float* gw = a.gw[jb.layer];
 #pragma unroll
     for (int i = 0; i < MI; ++i)

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnnr.so")
+LIB_PATH = os.environ.get("NNR_LIB", os.path.join(_HERE, "libnnr.so"))   # NNR_LIB: profiling builds only (csrc/build.py --variant)
 
 NNR_F_DIST_ALPHA = 1
 NNR_F_WHITE_BG = 2

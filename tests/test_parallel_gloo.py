@@ -1,0 +1,108 @@
+"""CPU, world_size 2 over gloo: the ray-sharded data-parallel step (model.Trainer + nnr.parallel) reproduces the
+single-process step -- same loss, same gradients for MLP, pose and distortion -- with ONE flat all-reduce.
+The HIP render operator is swapped for the CPU oracle backend (tests/oracle_backend.py) so that the host logic under test
+(shard bounds, jitter window, global loss normalisation, flat-bucket all-reduce) runs without a GPU."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_util as gu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(case, n_rays):
+    import model as mdl
+    import model.rendering as rendering
+    import oracle_backend
+    from test_host_logic import make_cfg
+    rendering.nnr.render_rays = oracle_backend.render_rays
+    t = gu.tensors(case)
+    rc = gu.render_cfg(case)
+    cfg = make_cfg(int(case["cfg.hidden"]), **{k: rc[k] for k in ('num_points', 'dist_alpha', 'sample_option', 'depth_range',
+                                                                  'normalise_ray', 'white_background')})
+    tcfg = {'type': 'nope_nerf', 'n_training_points': n_rays, 'vis_geo': False, 'detach_gt_depth': False, 'pc_ratio': 4,
+            'match_method': 'dense', 'shift_first': False, 'detach_ref_img': True, 'scale_pcs': True, 'detach_rgbs_scale': False,
+            'vis_reprojection_every': 5000, 'nearest_limit': 0.01, 'annealing_epochs': 2000, 'rgb_weight': [1.0, 1.0],
+            'depth_weight': [0.04, 0.0], 'pc_weight': [0.0, 0.0], 'rgb_s_weight': [0.0, 0.0],
+            'depth_consistency_weight': [0.0, 0.0], 'weight_dist_2nd_loss': [0.5, 0.5], 'weight_dist_1st_loss': [0.1, 0.1],
+            'depth_loss_type': 'l1', 'with_ssim': False, 'with_auto_mask': False}
+    net = mdl.OfficialStaticNerf(cfg)
+    net.load_state_dict(case["weights"])
+    model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device='cpu'), cfg, device='cpu')
+    pose = mdl.LearnPose(gu.N_CAMS, True, True, cfg)
+    distn = mdl.Learn_Distortion(gu.N_CAMS, True, True, cfg)
+    with torch.no_grad():
+        pose.r.copy_(t["pose_r"]); pose.t.copy_(t["pose_t"])
+        distn.global_scales.copy_(t["scales"]); distn.global_shifts.copy_(t["shifts"])
+    sgd = lambda m: torch.optim.SGD(m.parameters(), lr=0.0)
+    tr = mdl.Trainer(model, sgd(model), tcfg, device='cpu', optimizer_pose=sgd(pose), pose_param_net=pose,
+                     optimizer_distortion=sgd(distn), distortion_net=distn)
+    data = {'img': t["img"], 'img.idx': int(case["cfg.cam"]), 'img.dpt': t["depth_img"][:, 0], 'img.camera_mat': t["K"],
+            'img.scale_mat': torch.eye(4)[None]}
+    return tr, net, pose, distn, data
+
+
+def _step(case, n_rays):
+    tr, net, pose, distn, data = _build(case, n_rays)
+    torch.manual_seed(123)                      # same permutation and jitter stream on every rank
+    ld = tr.train_step(data, it=0, epoch=0, scheduling_start=10000, render_path=None)
+    grads = {k: v.grad.clone() for k, v in net.named_parameters()}
+    grads.update(r=pose.r.grad.clone(), t=pose.t.grad.clone(), scale=distn.global_scales.grad.clone(),
+                 shift=distn.global_shifts.grad.clone())
+    return {k: float(ld[k]) for k in ('loss', 'loss_rgb', 'loss_depth', 'l2_mean', 'loss_dist_1st', 'loss_dist_2nd')}, grads
+
+
+def _worker(rank, world, port, name, n_rays, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        losses, grads = _step(gu.load_case(name), n_rays)
+        if rank == 0:
+            q.put((losses, {k: v.numpy() for k, v in grads.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,n_rays", [("tanks_d128", 31), ("uniform_distalpha_masked_d128", 48)])
+def test_two_rank_step_equals_single_process(name, n_rays):
+    ref_losses, ref_grads = _step(gu.load_case(name), n_rays)          # world size 1, this process
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, n_rays, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    losses, grads = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k, v in ref_losses.items():
+        assert abs(losses[k] - v) <= 2e-6 * max(1.0, abs(v)), (k, losses[k], v)
+    for k, g in ref_grads.items():
+        err = float((torch.from_numpy(grads[k]) - g).abs().max())
+        assert err <= 1e-5 * max(1.0, float(g.abs().max())), (k, err)
+
+
+def test_allreduce_handles_missing_grads():
+    """A parameter without a gradient on this rank still occupies its slot in the flat bucket."""
+    from nnr import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        a, b = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2))
+        a.grad = torch.full((3,), 2.0)
+        ld = {'loss': torch.tensor(1.5)}
+        parallel.allreduce_gradients([a, b], ld)
+        assert torch.equal(a.grad, torch.full((3,), 2.0)) and torch.equal(b.grad, torch.zeros(2)) and float(ld['loss']) == 1.5
+    finally:
+        dist.destroy_process_group()
