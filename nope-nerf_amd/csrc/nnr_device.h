@@ -70,46 +70,68 @@ struct PanelPipe {
     }
 };
 
+// One k-group of A fragments (MT x 16 bytes per lane) in registers.
+template <int MT>
+struct Frags { f32x4 v[MT]; };
+
+// Enter the first panel of a layer part and fetch its first k-group.  Called BEFORE the previous layer's epilogue so that
+// the barrier, the DMA issue and the LDS latency of these reads hide under the epilogue's VALU work.
+template <int MT>
+__device__ __forceinline__ Frags<MT> gemm_open(const PanelPipe& pipe, int p0) {
+    pipe.enter(p0);
+    const f32x4* buf = pipe.lds + (p0 % kNBuf) * kPanelF4 + pipe.lane;
+    Frags<MT> f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) f.v[mt] = buf[mt * 64];
+    return f;
+}
+
 // acc[mt] += A_part[32*mt.., :] * in   for one layer part whose packed panels start at stream panel p0.
 //   in    : 16*KT registers in fragment layout (this wave's 32 samples)
+//   cur   : the part's first k-group, from gemm_open
 //   stash : optional (sample, feature) row-major destination of `in` (row of this lane's sample, + 4*half): the four
 //           registers consumed by k-group g are features 8g+4h..+3, i.e. one 16-byte store per k-group, issued *inside*
 //           the MFMA stream.  Stashing a layer's input here -- instead of its output in an epilogue burst -- spreads the
 //           10 KB/sample of training stash evenly over the kernel.
+// Software pipeline, pinned with sched_barrier(0) (left alone, hipcc sinks every ds_read to just before its first use
+// and then waits lgkmcnt(0) with the matrix pipe idle): while the 4*MT MFMAs of k-group g run, the fragments of k-group
+// g+1 are already on their way from LDS -- across a panel boundary too (the panel switch, i.e. wait + barrier + DMA
+// issue, sits in front of those reads and is covered by the same MFMAs).
 template <int KT, int MT, bool STASH = false, int NACC, int NIN>
 __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
-                                          float* stash = nullptr) {
+                                          Frags<MT> cur, float* stash = nullptr) {
     static_assert(MT <= NACC && 16 * KT <= NIN, "tile counts exceed the register arrays");
-    constexpr int G = 4 * KT, GP = part_gp(MT), NP = part_panels(KT, MT);
+    constexpr int G = 4 * KT, GP = part_gp(MT);
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int p = p0 + q;
-        pipe.enter(p);
-        const f32x4* buf = pipe.lds + (p % kNBuf) * kPanelF4 + pipe.lane;
-        f32x4 cur[MT], nxt[MT];
+    for (int g = 0; g < G; ++g) {
+        // first half of this k-group's MFMAs ...
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) cur[mt] = buf[mt * 64];
+        for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int gl = 0; gl < GP; ++gl) {
-            const int g = q * GP + gl;
-            if (g < G) {
-                if (gl + 1 < GP && g + 1 < G) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) nxt[mt] = buf[((gl + 1) * MT + mt) * 64];
-                }
-#ifndef NNR_ABLATE_NO_STASH
-                if constexpr (STASH)
-                    *reinterpret_cast<f32x4*>(stash + 8 * g) = f32x4{in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]};
-#endif
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(cur[mt][i], in[4 * g + i], acc[mt]);
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) cur[mt] = nxt[mt];
-            }
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(cur.v[mt][i], in[4 * g + i], acc[mt]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // ... then, with 2*MT MFMAs in the pipe behind them and 2*MT more to come, the LDS reads of the next k-group
+        // (hipcc waits lgkmcnt(0) before the next group's first MFMA: placed here the reads have >= 2*MT*64 cycles to land)
+        Frags<MT> nxt;
+        if (g + 1 < G) {
+            const int pn = p0 + (g + 1) / GP;
+            if ((g + 1) % GP == 0) pipe.enter(pn);
+            const f32x4* buf = pipe.lds + (pn % kNBuf) * kPanelF4 + pipe.lane;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) nxt.v[mt] = buf[(((g + 1) % GP) * MT + mt) * 64];
+        }
+        if constexpr (STASH)
+            *reinterpret_cast<f32x4*>(stash + 8 * g) = f32x4{in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 2; i < 4; ++i) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(cur.v[mt][i], in[4 * g + i], acc[mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < G) cur = nxt;
     }
 }
 

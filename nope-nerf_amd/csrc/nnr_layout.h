@@ -38,7 +38,7 @@ constexpr int kPosPad = 64, kDirPad = 32;
 // ---- packed weight buffer -------------------------------------------------------------------------------------
 // Forward parts in stream order, backward (transposed) parts in stream order, then padded biases.
 enum FwdPart { F_L1 = 0, F_L2, F_L3, F_L4, F_L5H, F_L5E, F_L6, F_L7, F_L8, F_SIG, F_FEAT, F_RGBH_F, F_RGBH_D, F_RGB, F_NPARTS };
-enum BwdPart { B_RGB = 0, B_RGBH, B_FEAT, B_SIG, B_L8, B_L7, B_L6, B_L5, B_L4, B_L3, B_L2, B_L1, B_NPARTS };
+enum BwdPart { B_RGB = 0, B_RGBH_F, B_RGBH_D, B_FEAT, B_SIG, B_L8, B_L7, B_L6, B_L5E, B_L5H, B_L4, B_L3, B_L2, B_L1, B_NPARTS };
 
 struct PartDesc {
     int layer;      // index into nnr_params (state_dict order)
@@ -81,13 +81,15 @@ struct Layout {
     NNR_HD static constexpr PartDesc bwd(int p) {
         switch (p) {
             case B_RGB: return {11, 1, 1, HT, D / 2, 3, 0, D / 2};
-            case B_RGBH: return {10, 1, HT, DT + 1, D + kDirReal, D / 2, 0, D + kDirReal};
+            case B_RGBH_F: return {10, 1, HT, DT, D, D / 2, 0, D + kDirReal};
+            case B_RGBH_D: return {10, 1, HT, 1, kDirReal, D / 2, D, D + kDirReal};
             case B_FEAT: return {9, 1, DT, DT, D, D, 0, D};
             case B_SIG: return {8, 1, 1, DT, D, 1, 0, D};
             case B_L8: return {7, 1, DT, DT, D, D, 0, D};
             case B_L7: return {6, 1, DT, DT, D, D, 0, D};
             case B_L6: return {5, 1, DT, DT, D, D, 0, D};
-            case B_L5: return {4, 1, DT, DT + 2, D + kPosReal, D, 0, D + kPosReal};
+            case B_L5H: return {4, 1, DT, DT, D, D, 0, D + kPosReal};
+            case B_L5E: return {4, 1, DT, 2, kPosReal, D, D, D + kPosReal};
             case B_L4: return {3, 1, DT, DT, D, D, 0, D};
             case B_L3: return {2, 1, DT, DT, D, D, 0, D};
             case B_L2: return {1, 1, DT, DT, D, D, 0, D};

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     const bool live = s < a.S;  // padded samples carry zero gradients so they add nothing to the weight gradients
 
     // weight panels of the transposed (backward) stream through the LDS ring -- see PanelPipe in nnr_device.h
-    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4];
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kWavesPerBlock * 8 * 64];
+    f32x4* const de_lds = smem + kNBuf * kPanelF4 + wave * (8 * 64) + lane;   // parking spot of d(posenc) from the skip layer
     const PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed + L::bwd_base) + wave * (8 * 64) + lane, smem, wave, lane,
                          L::bwd_panels};
     pipe.start();
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     {
         f32x16 acc[HT];
         zero_acc(acc);
-        gemm_part<1, HT>(acc, drgb, pipe, p0(B_RGB));
+        gemm_part<1, HT>(acc, drgb, pipe, p0(B_RGB), gemm_open<HT>(pipe, p0(B_RGB)));
         uint32_t mw[L::mask_words];
         const uint32_t* m = mask_base + (int64_t)8 * 64 * L::mask_words;
 #pragma unroll
@@ -53,13 +54,18 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16 * HT; ++r) dg[r] = ((mw[r >> 5] >> (r & 31)) & 1u) ? acc[r >> 4][r & 15] : 0.f;
     }
+    Frags<DT> frh = gemm_open<DT>(pipe, p0(B_RGBH_F));   // opened before the mask epilogue above retires
     float d[16 * DT];  // current D-wide gradient (d feature, then d pre-activation of hidden 8..1)
     {
-        f32x16 acc[DT + 1];
+        f32x16 acc[DT];
         zero_acc(acc);
         // every gradient vector is stashed by the gemm that consumes it (one 16-byte store per k-group, inside the
-        // MFMA stream) -- see gemm_part
-        gemm_part<HT, DT + 1, true>(acc, dg, pipe, p0(B_RGBH), a.ws_dg + s * (D / 2) + 4 * half);
+        // MFMA stream) -- see gemm_part.  Wg^T is consumed as two parts: rows of the feature (D) and of the direction
+        // encoding (27 -> one 32-row tile).
+        gemm_part<HT, DT, true>(acc, dg, pipe, p0(B_RGBH_F), frh, a.ws_dg + s * (D / 2) + 4 * half);
+        f32x16 accd[1];
+        zero_acc(accd);
+        gemm_part<HT, 1>(accd, dg, pipe, p0(B_RGBH_D), gemm_open<1>(pipe, p0(B_RGBH_D)));
 #pragma unroll
         for (int r = 0; r < 16 * DT; ++r) d[r] = acc[r >> 4][r & 15];
         // direction-encoding backward: d v = sum_f d gamma_4(v)_f/dv * grad_f, using the stored encoding for the
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
             float sc;
             enc_feature_meta(f, kDirReal, c, sc, partner);
             const float pv = partner >= 0 ? enc[partner] : 1.f;
-            const float contrib = acc[DT][r] * sc * pv;
+            const float contrib = accd[0][r] * sc * pv;
             gv[0] += c == 0 ? contrib : 0.f;
             gv[1] += c == 1 ? contrib : 0.f;
             gv[2] += c == 2 ? contrib : 0.f;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     }
 
     // ---- trunk ----
-    f32x16 acc[DT + 2];
+    f32x16 acc[DT];
     auto masked_layer = [&](int hidden_idx /*0..7*/) {  // d <- acc .* relu'(h_idx)
         uint32_t mw[L::mask_words];
         const uint32_t* m = mask_base + (int64_t)hidden_idx * 64 * L::mask_words;
@@ -100,37 +106,53 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     for (int r = 0; r < 16; ++r) dsig[r] = 0.f;
     dsig[0] = half == 0 ? dout[3] : 0.f;
     zero_acc(acc);
-    gemm_part<DT, DT, true>(acc, d, pipe, p0(B_FEAT), a.ws_df + s * D + 4 * half);
-    gemm_part<1, DT>(acc, dsig, pipe, p0(B_SIG));
+    gemm_part<DT, DT, true>(acc, d, pipe, p0(B_FEAT), gemm_open<DT>(pipe, p0(B_FEAT)), a.ws_df + s * D + 4 * half);
+    gemm_part<1, DT>(acc, dsig, pipe, p0(B_SIG), gemm_open<DT>(pipe, p0(B_SIG)));
+    Frags<DT> fr = gemm_open<DT>(pipe, p0(B_L8));
     masked_layer(7);
     // hidden 8,7,6 -> d pre-activation of 7,6,5
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         zero_acc(acc);
-        gemm_part<DT, DT, true>(acc, d, pipe, p0(B_L8) + l * part_panels(DT, DT), dh(7 - l));
+        gemm_part<DT, DT, true>(acc, d, pipe, p0(B_L8) + l * part_panels(DT, DT), fr, dh(7 - l));
+        if (l < 2) fr = gemm_open<DT>(pipe, p0(B_L8) + (l + 1) * part_panels(DT, DT));
         masked_layer(6 - l);
     }
-    // hidden 5 (skip layer): rows [0,D) -> d h4, rows [D, D+64) -> d posenc (kept for the end)
-    zero_acc(acc);
-    gemm_part<DT, DT + 2, true>(acc, d, pipe, p0(B_L5), dh(4));
-    float de[32];
+    // hidden 5 (skip layer), two parts of W5^T: rows [D, D+63) -> d posenc (kept for the end), rows [0,D) -> d h4
+    {
+        f32x16 acce[2];
+        zero_acc(acce);
+        gemm_part<DT, 2>(acce, d, pipe, p0(B_L5E), gemm_open<2>(pipe, p0(B_L5E)));
+        // 32 registers that are not needed again until the very end: park them in LDS (same array as the panels)
 #pragma unroll
-    for (int r = 0; r < 32; ++r) de[r] = acc[DT + (r >> 4)][r & 15];
+        for (int q = 0; q < 8; ++q)
+            de_lds[q * 64] = f32x4{acce[q >> 2][4 * (q & 3)], acce[q >> 2][4 * (q & 3) + 1], acce[q >> 2][4 * (q & 3) + 2],
+                                   acce[q >> 2][4 * (q & 3) + 3]};
+    }
+    zero_acc(acc);
+    gemm_part<DT, DT, true>(acc, d, pipe, p0(B_L5H), gemm_open<DT>(pipe, p0(B_L5H)), dh(4));
+    fr = gemm_open<DT>(pipe, p0(B_L4));
     masked_layer(3);
     // hidden 4,3,2 -> d pre-activation of 3,2,1
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         zero_acc(acc);
-        gemm_part<DT, DT, true>(acc, d, pipe, p0(B_L4) + l * part_panels(DT, DT), dh(3 - l));
+        gemm_part<DT, DT, true>(acc, d, pipe, p0(B_L4) + l * part_panels(DT, DT), fr, dh(3 - l));
+        if (l < 2) fr = gemm_open<DT>(pipe, p0(B_L4) + (l + 1) * part_panels(DT, DT));
         masked_layer(2 - l);
     }
-    // hidden 1: d posenc += W1^T d1
+    // hidden 1: d posenc = W1^T d1 + (skip-layer part parked in LDS)
+    float de[32];
     {
         f32x16 acc2[2];
         zero_acc(acc2);
-        gemm_part<DT, 2, true>(acc2, d, pipe, p0(B_L1), dh(0));
+        gemm_part<DT, 2, true>(acc2, d, pipe, p0(B_L1), gemm_open<2>(pipe, p0(B_L1)), dh(0));
 #pragma unroll
-        for (int r = 0; r < 32; ++r) de[r] += acc2[r >> 4][r & 15];
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 v = de_lds[q * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) de[4 * q + i] = acc2[q >> 2][4 * (q & 3) + i] + v[i];
+        }
     }
     // positional-encoding backward -> d point
     {

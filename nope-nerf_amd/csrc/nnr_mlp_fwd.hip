@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
                     x = fmaxf(x, 0.f);
                     const int r = 16 * t + 4 * q + i;
                     h[r] = x;
-                    if (TRAIN && !kAblateNoMask) mw[r >> 5] |= (x > 0.f ? 1u : 0u) << (r & 31);
+                    if (TRAIN && !kAblateNoMask) mw[r >> 5] |= min(__float_as_uint(x), 1u) << (r & 31);   // x >= 0: bit = (x != 0), no VCC round trip
                 }
             }
         }
@@ -106,35 +106,42 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     auto xh = [&](int hidden_idx /*0..7*/) -> float* {
         return TRAIN ? a.ws_xh + ((int64_t)hidden_idx * a.S_pad + s) * D + 4 * half : nullptr;
     };
-    gemm_part<2, DT, TRAIN>(acc, e, pipe, p0(F_L1), xe);
+    // Every part is opened (panel switch + first fragment reads) before the epilogue that precedes it.
+    gemm_part<2, DT, TRAIN>(acc, e, pipe, p0(F_L1), gemm_open<DT>(pipe, p0(F_L1)), xe);
+    Frags<DT> fr = gemm_open<DT>(pipe, p0(F_L2));
     relu_layer(0);
     // hidden 2..4
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         zero_acc(acc);
-        gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_L2) + l * part_panels(DT, DT), xh(l));
+        gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_L2) + l * part_panels(DT, DT), fr, xh(l));
+        fr = gemm_open<DT>(pipe, p0(F_L2) + (l + 1) * part_panels(DT, DT));   // l == 2: that is the first panel of hidden 5
         relu_layer(1 + l);
     }
     // hidden 5: [h4 ; e] -> D   (skip connection, input order [h, posenc]: model/official_nerf.py:63)
     zero_acc(acc);
-    gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_L5H), xh(3));
-    gemm_part<2, DT>(acc, e, pipe, p0(F_L5E));
+    static_assert(L::fwd_panel0(F_L5H) == L::fwd_panel0(F_L2) + 3 * part_panels(DT, DT), "stream order");
+    gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_L5H), fr, xh(3));
+    gemm_part<2, DT>(acc, e, pipe, p0(F_L5E), gemm_open<DT>(pipe, p0(F_L5E)));
+    fr = gemm_open<DT>(pipe, p0(F_L6));
     relu_layer(4);
     // hidden 6..8
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         zero_acc(acc);
-        gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_L6) + l * part_panels(DT, DT), xh(4 + l));
+        gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_L6) + l * part_panels(DT, DT), fr, xh(4 + l));
+        if (l < 2) fr = gemm_open<DT>(pipe, p0(F_L6) + (l + 1) * part_panels(DT, DT));
         relu_layer(5 + l);
     }
     // density head: D -> 1 (row 0 of a 32-row tile)
     f32x16 acc1[1];
     zero_acc(acc1);
-    gemm_part<DT, 1>(acc1, h, pipe, p0(F_SIG));
+    gemm_part<DT, 1>(acc1, h, pipe, p0(F_SIG), gemm_open<1>(pipe, p0(F_SIG)));
     const float sigma_raw = acc1[0][0] + bias[L::bias_off(8)];
     // feature: D -> D, no activation
     zero_acc(acc);
-    gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_FEAT), xh(7));
+    gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_FEAT), gemm_open<DT>(pipe, p0(F_FEAT)), xh(7));
+    Frags<HT> frg = gemm_open<HT>(pipe, p0(F_RGBH_F));
     float* const xf = TRAIN ? a.ws_xf + s * (D + kDirPad) + 4 * half : nullptr;
     {
         const float* b = bias + L::bias_off(9) + 4 * half;
@@ -150,8 +157,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // colour hidden: [feat ; gamma_4(v)] -> D/2, ReLU   (input order [feat, dir_enc]: model/official_nerf.py:89)
     f32x16 accg[HT];
     zero_acc(accg);
-    gemm_part<DT, HT, TRAIN>(accg, h, pipe, p0(F_RGBH_F), xf);
-    gemm_part<1, HT, TRAIN>(accg, dirv, pipe, p0(F_RGBH_D), TRAIN ? xf + D : nullptr);
+    gemm_part<DT, HT, TRAIN>(accg, h, pipe, p0(F_RGBH_F), frg, xf);
+    gemm_part<1, HT, TRAIN>(accg, dirv, pipe, p0(F_RGBH_D), gemm_open<HT>(pipe, p0(F_RGBH_D)), TRAIN ? xf + D : nullptr);
+    Frags<1> fr1 = gemm_open<1>(pipe, p0(F_RGB));
     float g[16 * HT];
     {
         const float* b = bias + L::bias_off(10) + 4 * half;
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
                     float x = fmaxf(accg[t][4 * q + i] + bb[i], 0.f);
                     const int r = 16 * t + 4 * q + i;
                     g[r] = x;
-                    if (TRAIN && !kAblateNoMask) mw[r >> 5] |= (x > 0.f ? 1u : 0u) << (r & 31);
+                    if (TRAIN && !kAblateNoMask) mw[r >> 5] |= min(__float_as_uint(x), 1u) << (r & 31);   // x >= 0: bit = (x != 0), no VCC round trip
                 }
             }
         if (TRAIN) {
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     }
     // rgb: D/2 -> 3, sigmoid (rows 0..2 of a 32-row tile live in registers 0..2 of half 0)
     zero_acc(acc1);
-    gemm_part<HT, 1, TRAIN>(acc1, g, pipe, p0(F_RGB), TRAIN ? a.ws_xg + s * (D / 2) + 4 * half : nullptr);
+    gemm_part<HT, 1, TRAIN>(acc1, g, pipe, p0(F_RGB), fr1, TRAIN ? a.ws_xg + s * (D / 2) + 4 * half : nullptr);
     if (half == 0 && s < a.S) {
         const float* b = bias + L::bias_off(11);
         f32x4 o;

@@ -27,7 +27,11 @@ template <int W>
 __device__ __forceinline__ Vec<W> load_vec(const float* p) {
     Vec<W> r;
     if constexpr (W == 4) {
+#ifdef NNR_NT_WGRAD
+        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
         const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#endif
         r.v[0] = t[0]; r.v[1] = t[1]; r.v[2] = t[2]; r.v[3] = t[3];
     } else if constexpr (W == 2) {
         const f32x2 t = *reinterpret_cast<const f32x2*>(p);

@@ -1,0 +1,50 @@
+"""Full-image inference helper shared by Eval_Images / Extract_Images: renders an (h, w) frame through the forward-only
+fused kernel in chunks of `points_batch_size` rays (reference model/eval_images.py:66-87,
+model/extracting_images.py:50-74)."""
+import numpy as np
+import torch
+from PIL import Image
+
+from model.common import arange_pixels
+
+
+def camera_from_focal(fxfy, device):
+    k = torch.zeros(1, 4, 4, device=device)
+    k[0, 0, 0], k[0, 1, 1], k[0, 2, 2], k[0, 3, 3] = float(fxfy[0]), -float(fxfy[1]), -1.0, 1.0
+    return k
+
+
+def inverse_pose(c2w):
+    from nnr import camera
+    return (camera.inverse4(c2w) if c2w.is_cuda else torch.inverse(c2w)).unsqueeze(0)
+
+
+def render_full_image(renderer, resolution, camera_mat, world_mat, scale_mat, render_type, device, points_batch_size=100000, it=0):
+    """-> rgb (h,w,3) float tensor on `device`, depth (h,w) numpy.  The mono-depth input is all ones so that no ray is
+    masked (the reference builds the same constant through a grid_sample of zeros)."""
+    h, w = resolution
+    pixels = arange_pixels(resolution=(h, w), device=device)[1]
+    depth = torch.ones(1, h * w, 1, device=device)
+    rgb, dep = [], []
+    with torch.no_grad():
+        for pix_i, d_i in zip(torch.split(pixels, points_batch_size, dim=1), torch.split(depth, points_batch_size, dim=1)):
+            out = renderer(pix_i, d_i, camera_mat, world_mat, scale_mat, render_type, eval_=True, it=it, add_noise=False)
+            rgb.append(out['rgb'])
+            dep.append(out['depth_pred'])
+    return torch.cat(rgb, dim=1).view(h, w, 3), torch.cat(dep, dim=0).view(h, w).cpu().numpy()
+
+
+def depth_to_u8(depth):
+    return np.clip(255.0 / depth.max() * (depth - depth.min()), 0, 255).astype(np.uint8)
+
+
+def resize_nearest(arr, size_hw):
+    """cv2.resize(..., INTER_NEAREST) for a 2-D array: source index floor(dst * scale)."""
+    gh, gw = size_hw
+    ys = np.minimum((np.arange(gh) * (arr.shape[0] / gh)).astype(np.int64), arr.shape[0] - 1)
+    xs = np.minimum((np.arange(gw) * (arr.shape[1] / gw)).astype(np.int64), arr.shape[1] - 1)
+    return arr[ys][:, xs]
+
+
+def save_png(arr_u8, path):
+    Image.fromarray(arr_u8).save(path)

@@ -21,8 +21,9 @@ def fwd_parts(D):
 def bwd_parts(D):
     DT, HT = D // 32, D // 64
     return [
-        (11, 1, 1, HT, D // 2, 3, 0), (10, 1, HT, DT + 1, D + 27, D // 2, 0), (9, 1, DT, DT, D, D, 0), (8, 1, 1, DT, D, 1, 0),
-        (7, 1, DT, DT, D, D, 0), (6, 1, DT, DT, D, D, 0), (5, 1, DT, DT, D, D, 0), (4, 1, DT, DT + 2, D + 63, D, 0),
+        (11, 1, 1, HT, D // 2, 3, 0), (10, 1, HT, DT, D, D // 2, 0), (10, 1, HT, 1, 27, D // 2, D), (9, 1, DT, DT, D, D, 0),
+        (8, 1, 1, DT, D, 1, 0),
+        (7, 1, DT, DT, D, D, 0), (6, 1, DT, DT, D, D, 0), (5, 1, DT, DT, D, D, 0), (4, 1, DT, 2, 63, D, D), (4, 1, DT, DT, D, D, 0),
         (3, 1, DT, DT, D, D, 0), (2, 1, DT, DT, D, D, 0), (1, 1, DT, DT, D, D, 0), (0, 1, DT, 2, 63, D, 0)]
 
 

@@ -207,3 +207,31 @@ def test_full_size_against_oracle_sample():
         orgb, odist, _ = trace_util.traced_render(P, o[sel], d[sel], -d[sel], lo, hi, jit[sel], dist_alpha=False, white_bg=False)
     assert float((rgb[sel.cuda()].cpu() - orgb).abs().max()) <= TOL
     assert float((dist[sel.cuda()].cpu() - odist).abs().max()) <= TOL * 10      # distances reach 10
+
+
+def test_full_image_inference_matches_oracle(tmp_path):
+    """The evaluation / visualisation drivers (Extract_Images -> forward-only kernel in ray chunks) against the oracle."""
+    import model as mdl
+    from model.extracting_images import Extract_Images
+    from test_host_logic import make_cfg
+    case = gu.load_case("tanks_eval_d128")
+    t = gu.tensors(case)
+    dev = torch.device("cuda")
+    cfg = make_cfg(128, num_points=48)
+    cfg['extract_images'] = {'resolution': [21, 34]}
+    net = mdl.OfficialStaticNerf(cfg)
+    net.load_state_dict(case["weights"])
+    model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device=dev), cfg, device=dev)
+    c2w = orc.pose_c2w(t["pose_r"][1], t["pose_t"][1])
+    ex = Extract_Images(model.renderer, cfg, use_learnt_poses=True, use_learnt_focal=False, device=dev, render_type='nope_nerf')
+    ex.points_batch_size = 300          # several ragged chunks
+    data = {'img.camera_mat': t["K"], 'img.scale_mat': torch.eye(4)[None], 'img.idx': 0}
+    out = ex.generate_images(data, str(tmp_path), [c2w.to(dev)], None, 0, output_geo=False)
+    rc = dict(gu.render_cfg(case), num_points=48)
+    with torch.no_grad():
+        ref = orc.render(case["weights"], orc.pixel_grid(21, 34), torch.ones(1, 21 * 34, 1), t["K"],
+                         torch.inverse(c2w)[None], torch.eye(4)[None], rc, jitter=None, eval_=True)
+    img_ref = (ref["rgb"].view(21, 34, 3).numpy() * 255)
+    assert np.abs(out['img'].astype(np.float64) - img_ref).max() <= 1.0          # uint8 quantisation of a 1e-4 match
+    depth = np.load(str(tmp_path / "depth_out" / "0.npy"))
+    np.testing.assert_allclose(depth, ref["depth_pred"].view(21, 34).numpy(), rtol=0, atol=2e-4)

@@ -173,3 +173,10 @@ def test_shard_bounds_cover():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_resize_nearest_matches_interpolate():
+    from model.imaging import resize_nearest
+    a = np.random.default_rng(0).standard_normal((21, 34)).astype(np.float32)
+    ref = F.interpolate(torch.from_numpy(a)[None, None], (40, 57), mode='nearest')[0, 0].numpy()
+    np.testing.assert_array_equal(resize_nearest(a, (40, 57)), ref)

@@ -43,13 +43,15 @@ def test_transposed_parts_and_skip_layer():
     W, _ = rand_weights(D)
     rng = np.random.default_rng(2)
     d5 = rng.standard_normal((D, 32)).astype(np.float32)
-    part = lr.bwd_parts(D)[7]                                      # hidden 5 transposed: rows = [h4 (D) ; posenc (63)]
-    pk = lr.pack_part(lr.part_matrix(W[4], part), part[2], part[3])
-    acc = lr.gemm_part_emulated(pk, lr.to_regs(d5), part[2], part[3])
-    full = lr.from_regs(acc.reshape(-1, 64))
     ref = W[4].T @ d5
-    np.testing.assert_allclose(full[:D + 63], ref, rtol=1e-4, atol=1e-4)
-    assert np.all(full[D + 63:] == 0)
+    for idx, rows in ((9, slice(0, D)), (8, slice(D, D + 63))):  # hidden 5 transposed: rows [h4 (D)] and [posenc (63)]
+        part = lr.bwd_parts(D)[idx]
+        pk = lr.pack_part(lr.part_matrix(W[4], part), part[2], part[3])
+        acc = lr.gemm_part_emulated(pk, lr.to_regs(d5), part[2], part[3])
+        full = lr.from_regs(acc.reshape(-1, 64))
+        n = rows.stop - rows.start
+        np.testing.assert_allclose(full[:n], ref[rows], rtol=1e-4, atol=1e-4)
+        assert np.all(full[n:] == 0)
     part = lr.fwd_parts(D)[5]                                      # skip layer, posenc part: columns D.. of layers1.0
     A = lr.part_matrix(W[4], part)
     np.testing.assert_array_equal(A[:, :63], W[4][:, D:])
