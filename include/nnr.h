@@ -173,11 +173,13 @@ int nnr_depth_gather_bwd(const float* g_out, const int64_t* ray_idx, float* g_im
 /* Loss heads feeding the backward (model/losses.py:27-32,59-64,196-202): out[0] = w_rgb * L_rgb + w_depth * L_depth,
  * out[1] = L_rgb = sum|rgb - gt| (or squared if rgb_l2) / r_total, out[2] = L_depth = sum_valid |dist - d_gt| / m_total,
  * out[3] = mean squared rgb error, out[4] = number of valid depths in this call.  m_total < 0 means "this call's count";
- * data-parallel callers pass the global counts.  ndc applies depth_gt = 1 - 1/d_gt (rendering.py:157-158).  The
+ * data-parallel callers pass the global counts (m_total_dev, if not NULL, is a device scalar that overrides m_total so
+ * that no host sync is needed to obtain it).  ndc applies depth_gt = 1 - 1/d_gt (rendering.py:157-158).  The
  * gradients of out[0] w.r.t. rgb, dist, d_gt are written to g_rgb (R,3), g_dist (R), g_d_gt (R). */
 int nnr_render_loss(const float* rgb, const float* rgb_gt, const float* dist, const float* d_gt, const uint8_t* mask,
                     int32_t n_rays, float r_total, float m_total, float w_rgb, float w_depth, int32_t rgb_l2, int32_t ndc,
-                    int32_t detach_gt, float* out5, float* g_rgb, float* g_dist, float* g_d_gt, void* stream);
+                    int32_t detach_gt, const float* m_total_dev, float* out5, float* g_rgb, float* g_dist, float* g_d_gt,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,7 +59,7 @@ std::vector<Unit> wgrad_units(int D) {
     auto add = [&](int layer, int MI, int NI, int dpl, int dcol, int dvalid, int xpl, int xcol, int xvalid, int row0, int wcol0,
                    int rows_real, int cols_real, int ldw, int bias) {
         Unit x{};
-        x.j = WgradJob{layer, MI, NI, dpl, dcol, dvalid, xpl, xcol, xvalid, row0, wcol0, rows_real, cols_real, ldw, 0, 0, bias};
+        x.j = WgradJob{layer, MI, NI, dpl, dcol, dvalid, xpl, xcol, xvalid, row0, wcol0, rows_real, cols_real, ldw, 0, 0, bias, 0, 1, 0};
         x.group = group;
         u.push_back(x);
     };
@@ -132,8 +132,11 @@ std::vector<WgradJob> build_plan_for(const nnr_cfg* c, int target_waves) {
             for (size_t t = i; t < e; ++t) {
                 WgradJob j = units[t].j;
                 j.k0 = (int32_t)(g0 * kGranule);
-                j.k1 = (int32_t)(g1 * kGranule);
-                if (j.k1 > j.k0) jobs.push_back(j);
+                j.k1 = (int32_t)(g1 * kGranule);   // q <= granules, so no range is empty and job indices are regular
+                j.split = (int32_t)s;
+                j.n_splits = (int32_t)q;
+                j.split_stride = (int32_t)(e - i);
+                jobs.push_back(j);
             }
         }
         i = e;
@@ -180,7 +183,9 @@ size_t nnr_packed_floats(const nnr_cfg* cfg) {
 
 size_t nnr_workspace_floats(const nnr_cfg* cfg) {
     if (check_cfg(cfg) != NNR_OK) return 0;
-    return (size_t)ws_layout(cfg).total();
+    const WsLayout w = ws_layout(cfg);
+    // training: the planes, then one partial slot per weight-gradient job
+    return (size_t)w.total() + (w.train ? build_plan(cfg).size() * (size_t)kSlotFloats : 0);
 }
 
 int64_t nnr_ws_plane(const nnr_cfg* cfg, int pl, int32_t* pitch_out) {
@@ -323,6 +328,7 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const nnr_param_grads* g, const void* plan
         a.plane_pitch[p] = pitch;
     }
     a.n_jobs = (int)(nnr_plan_bytes(cfg) / sizeof(WgradJob));
+    a.slots = ws + w.total();
     hipError_t e = launch_wgrad(a, (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
@@ -407,13 +413,15 @@ int nnr_depth_gather_bwd(const float* g_out, const int64_t* ray_idx, float* g_im
 }
 int nnr_render_loss(const float* rgb, const float* rgb_gt, const float* dist, const float* d_gt, const uint8_t* mask,
                     int32_t n_rays, float r_total, float m_total, float w_rgb, float w_depth, int32_t rgb_l2, int32_t ndc,
-                    int32_t detach_gt, float* out5, float* g_rgb, float* g_dist, float* g_d_gt, void* stream) {
+                    int32_t detach_gt, const float* m_total_dev, float* out5, float* g_rgb, float* g_dist, float* g_d_gt,
+                    void* stream) {
     if (!rgb || !rgb_gt || !dist || !d_gt || !mask || !out5 || !g_rgb || !g_dist || !g_d_gt || n_rays <= 0 || r_total <= 0.f)
         return NNR_E_BADCFG;
     LossArgs a{};
     a.rgb = rgb; a.rgb_gt = rgb_gt; a.dist = dist; a.d_gt = d_gt; a.mask = mask; a.out = out5;
     a.g_rgb = g_rgb; a.g_dist = g_dist; a.g_dgt = g_d_gt; a.R = n_rays; a.r_total = r_total; a.m_total = m_total;
     a.w_rgb = w_rgb; a.w_depth = w_depth; a.rgb_l2 = rgb_l2; a.ndc = ndc; a.detach_gt = detach_gt;
+    a.m_total_dev = m_total_dev;
     NNR_LAUNCH(launch_render_loss(a, (hipStream_t)stream));
 }
 

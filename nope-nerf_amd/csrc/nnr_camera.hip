@@ -335,7 +335,8 @@ __global__ __launch_bounds__(1024) void render_loss_kernel(LossArgs a) {
     s_l2 = block_sum(s_l2, sm);
     s_dep = block_sum(s_dep, sm);
     cnt = block_sum(cnt, sm);
-    const float m = a.m_total >= 0.f ? a.m_total : cnt;
+    const float mt = a.m_total_dev ? *a.m_total_dev : a.m_total;
+    const float m = mt >= 0.f ? mt : cnt;
     const float inv_r = 1.f / a.r_total, inv_m = m > 0.f ? 1.f / m : 0.f;
     if (threadIdx.x == 0) {
         const float lrgb = s_rgb * inv_r, ldep = s_dep * inv_m;

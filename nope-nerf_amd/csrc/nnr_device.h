@@ -15,6 +15,18 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- profiling builds only (-DNNR_TIMELINE): shader-clock stamps of one mid-grid wave, read back with nnr_timeline_* ----
+#ifdef NNR_TIMELINE
+#define NNR_TL_DECL(name) __device__ unsigned long long name[32];
+#define NNR_STAMP(name, i)                                                                      \
+    do {                                                                                        \
+        if ((blockIdx.x == 700 || (gridDim.x < 700 && blockIdx.x == 700 / 8)) && threadIdx.x == 0) name[i] = __builtin_amdgcn_s_memtime();     \
+    } while (0)
+#else
+#define NNR_TL_DECL(name)
+#define NNR_STAMP(name, i)
+#endif
+
 // ---- weight panels through LDS ---------------------------------------------------------------------------------------
 // The four waves of a workgroup consume the same packed-weight stream, one 32 KiB panel (32 fragments = 128 MFMAs per
 // wave = 8192 cycles) at a time.  Panels are DMA'd global -> LDS (global_load_lds_dwordx4: 1 KiB per wave-instruction,
@@ -28,45 +40,67 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 struct PanelPipe {
-    const f32x4* src;  // stream base in global memory, already offset by this lane and this wave's fragment slice
+    const f32x4* src;  // stream base in global memory offset by this wave's fragment slice (wave-uniform: SGPRs)
     f32x4* lds;        // base of the three panel buffers in LDS
-    int wave, lane;
+    int wave, lane;    // wave is wave-uniform (readfirstlane'd by the caller)
     int n_panels;      // panels in the stream
 
-    // This wave copies fragments [8*wave, 8*wave+8) of panel p into buffer p % 3: 8 DMA instructions, always exactly 8 --
-    // the counted wait below relies on it.
-    __device__ __forceinline__ void issue(int p) const {
+    // This wave copies fragments [8*wave, 8*wave+8) of panel p into buffer p % 3 as 8 DMA "pieces" of 1 KiB, always
+    // exactly 8 per panel -- the counted wait below relies on it.  With a uniform base the address is
+    // SGPR base + lane*16 and the LDS destination (M0) is scalar: no VALU work per piece.
+    __device__ __forceinline__ void piece(int p, int i) const {
 #ifdef NNR_ABLATE_NO_DMA
         return;
 #endif
-        const f32x4* g = src + (int64_t)p * kPanelF4;
-        f32x4* l = lds + (p % kNBuf) * kPanelF4 + wave * (8 * 64);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * 64), (lds_ptr_t)(l + i * 64), 16, 0, 0);
+        // One address pair per PANEL (global: VGPRs, LDS: M0), both pointing at piece 4; the piece is selected by the
+        // instruction's signed 13-bit immediate, which offsets the global and the LDS address alike -- so a piece costs
+        // one VMEM issue and no address arithmetic.
+        const f32x4* g = src + (int64_t)p * kPanelF4 + 4 * 64 + lane;
+        f32x4* l = lds + (p % kNBuf) * kPanelF4 + wave * (8 * 64) + 4 * 64;
+        switch (i) {   // the offset operand must be a literal
+            case 0: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -4096, 0); break;
+            case 1: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -3072, 0); break;
+            case 2: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -2048, 0); break;
+            case 3: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -1024, 0); break;
+            case 4: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0); break;
+            case 5: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 1024, 0); break;
+            case 6: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 2048, 0); break;
+            default: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 3072, 0); break;
+        }
     }
-    // Make panel p readable and recycle the buffer of panel p-1 for panel p+2.
-    //   vmcnt(8): everything older than the 8 youngest VMEM ops of this wave is complete.  The 8 DMA ops of panel p+1 were
+    // pieces [first, first+count) of panel p (nothing past the end of the stream; p is wave-uniform)
+    __device__ __forceinline__ void pieces(int p, int first, int count) const {
+        if (p < n_panels) {
+#pragma unroll
+            for (int i = first; i < first + count && i < 8; ++i) piece(p, i);
+        }
+    }
+    // Make panel p readable and release the buffer of panel p-1 (which the pieces of panel p+2 overwrite; the caller
+    // issues them AFTER this call, spread over the k-groups of panel p -- see gemm_part).
+    //   vmcnt(8): everything older than the 8 youngest VMEM ops of this wave is complete.  The 8 pieces of panel p+1 were
     //   issued after those of panel p, so panel p has landed (any stores issued since only make the wait more conservative).
     //   The barrier then tells every wave that (a) all four slices of panel p are in LDS and (b) everybody is done reading
-    //   panel p-1, whose buffer the DMA of panel p+2 overwrites.
+    //   panel p-1.
+    // EXTRA: VMEM ops (stash stores) this wave certainly issued, in addition to the 8 pieces of panel p+1, after the last
+    // piece of panel p -- they may stay in flight too (a store's completion is the L2's write acknowledgement; waiting for
+    // recent ones here stalls the matrix pipe behind HBM write latency).
+    template <int EXTRA = 0>
     __device__ __forceinline__ void enter(int p) const {
 #ifdef NNR_ABLATE_NO_SYNC
-        if (p + 2 < n_panels) issue(p + 2);
         return;
 #endif
+        static_assert(8 + EXTRA < 64, "vmcnt is a 6-bit field");
         // lgkmcnt(0): this wave's ds_reads of panel p-1 have returned before it reports "done reading" at the barrier
         if (p + 1 < n_panels)
-            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + EXTRA) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (p + 2 < n_panels) issue(p + 2);
     }
     __device__ __forceinline__ void start() const {  // prologue: two panels in flight
-        issue(0);
-        if (n_panels > 1) issue(1);
+        pieces(0, 0, 8);
+        pieces(1, 0, 8);
     }
 };
 
@@ -74,11 +108,20 @@ struct PanelPipe {
 template <int MT>
 struct Frags { f32x4 v[MT]; };
 
-// Enter the first panel of a layer part and fetch its first k-group.  Called BEFORE the previous layer's epilogue so that
-// the barrier, the DMA issue and the LDS latency of these reads hide under the epilogue's VALU work.
-template <int MT>
+// k-groups of a part that live in its panel number pi, and DMA pieces issued per k-group slot of that panel
+template <int KT, int MT>
+__device__ __forceinline__ constexpr int panel_groups(int pi) {
+    return (4 * KT - pi * part_gp(MT)) < part_gp(MT) ? (4 * KT - pi * part_gp(MT)) : part_gp(MT);
+}
+template <int KT, int MT>
+__device__ __forceinline__ constexpr int panel_ppk(int pi) { return (8 + panel_groups<KT, MT>(pi) - 1) / panel_groups<KT, MT>(pi); }
+
+// Enter the first panel of a layer part (KT x MT tiles), start the DMA of the panel two ahead and fetch the part's first
+// k-group.
+template <int KT, int MT>
 __device__ __forceinline__ Frags<MT> gemm_open(const PanelPipe& pipe, int p0) {
     pipe.enter(p0);
+    pipe.pieces(p0 + 2, 0, panel_ppk<KT, MT>(0));
     const f32x4* buf = pipe.lds + (p0 % kNBuf) * kPanelF4 + pipe.lane;
     Frags<MT> f;
 #pragma unroll
@@ -88,51 +131,130 @@ __device__ __forceinline__ Frags<MT> gemm_open(const PanelPipe& pipe, int p0) {
 
 // acc[mt] += A_part[32*mt.., :] * in   for one layer part whose packed panels start at stream panel p0.
 //   in    : 16*KT registers in fragment layout (this wave's 32 samples)
-//   cur   : the part's first k-group, from gemm_open
 //   stash : optional (sample, feature) row-major destination of `in` (row of this lane's sample, + 4*half): the four
 //           registers consumed by k-group g are features 8g+4h..+3, i.e. one 16-byte store per k-group, issued *inside*
 //           the MFMA stream.  Stashing a layer's input here -- instead of its output in an epilogue burst -- spreads the
 //           10 KB/sample of training stash evenly over the kernel.
+//   side  : optional VALU work hidden under this part's MFMAs: NSIDE units side(0..NSIDE-1), PPG per k-group, starting
+//           at k-group SHIFT.  The MLP kernels use it to finish the PREVIOUS pass's accumulators (bias is already in
+//           them; ReLU + sign bit, or the ReLU' select) one register pair per unit.  Two patterns:
+//             SHIFT = 0: the units write registers of `in` that this part reads later (pair u -> registers >= 2u of the
+//                        upper half, first needed at k-group >= 2*KT) -- "finish the other half while starting";
+//             SHIFT = 1: the units OVERWRITE `in` behind the read pointer (k-group g rewrites registers 4(g-1)..4g-1,
+//                        last read by k-group g-1) -- the new half-A vector replaces the old input in place.
+//           Units that do not fit ((G - SHIFT) * PPG < NSIDE) run after the last k-group.
 // Software pipeline, pinned with sched_barrier(0) (left alone, hipcc sinks every ds_read to just before its first use
-// and then waits lgkmcnt(0) with the matrix pipe idle): while the 4*MT MFMAs of k-group g run, the fragments of k-group
-// g+1 are already on their way from LDS -- across a panel boundary too (the panel switch, i.e. wait + barrier + DMA
-// issue, sits in front of those reads and is covered by the same MFMAs).
-template <int KT, int MT, bool STASH = false, int NACC, int NIN>
+// and then waits lgkmcnt(0) with the matrix pipe idle, and lumps the VALU / VMEM work where it stalls MFMA issue).
+// A k-group is 4*MT MFMAs; with one wave per SIMD the wave has ~16 issue slots per 64-cycle fp32 MFMA, but a VMEM
+// instruction that touches 32 lines or a handful of VALU ops each take most of one such gap -- so the non-MFMA work of a
+// k-group is cut into MT + 4 "fillers" placed in DIFFERENT gaps, evenly spread: the MT LDS reads of the next k-group
+// (across a panel boundary too: the panel switch -- wait + barrier -- sits in front of the first read), the stash store,
+// the first half of the side units, the DMA piece(s), the second half of the side units.
+// Pin the accumulators at a program point.  The MFMA builtin is a pure function to LLVM, so nothing ties it to the
+// side-effecting skeleton (sched_barrier, stores, DMA) around it: IR passes may -- and for some passes do -- sink all MFMAs of
+// a part below that skeleton, leaving the reads of a whole panel live at once (hundreds of spills).  An empty volatile
+// asm that "modifies" the accumulators (in AGPRs) orders the MFMA chain against the other side effects at no run-time cost.
+template <int MT, int NACC>
+__device__ __forceinline__ void pin_acc(f32x16 (&acc)[NACC]) {
+    if constexpr (MT == 1) asm volatile("" : "+a"(acc[0]));
+    else if constexpr (MT == 2) asm volatile("" : "+a"(acc[0]), "+a"(acc[1]));
+    else if constexpr (MT == 4) asm volatile("" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
+    else static_assert(MT == 1 || MT == 2 || MT == 4, "unsupported tile count");
+}
+
+struct NoSide {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+template <int KT, int MT, bool STASH, int NSIDE_, int PPG, int SHIFT, class Side, int NACC, int NIN>
 __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
-                                          Frags<MT> cur, float* stash = nullptr) {
+                                          float* stash, const Side& side) {
+#ifdef NNR_ABLATE_NO_SIDE
+    constexpr int NSIDE = 0;   // profiling build only
+#else
+    constexpr int NSIDE = NSIDE_;
+#endif
     static_assert(MT <= NACC && 16 * KT <= NIN, "tile counts exceed the register arrays");
     constexpr int G = 4 * KT, GP = part_gp(MT);
+    constexpr int NM = 4 * MT;   // MFMAs (= gaps) per k-group
+    constexpr int NF = MT + 4;   // fillers per k-group; filler f sits in the gap after MFMA number f * NM / NF
+    Frags<MT> cur = gemm_open<KT, MT>(pipe, p0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        // first half of this k-group's MFMAs ...
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(cur.v[mt][i], in[4 * g + i], acc[mt]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ... then, with 2*MT MFMAs in the pipe behind them and 2*MT more to come, the LDS reads of the next k-group
-        // (hipcc waits lgkmcnt(0) before the next group's first MFMA: placed here the reads have >= 2*MT*64 cycles to land)
+        const int u0 = (g - SHIFT) * PPG;                 // first side unit of this k-group
+        const int um = u0 + (PPG + 1) / 2, u1 = u0 + PPG;  // split between two gaps
         Frags<MT> nxt;
-        if (g + 1 < G) {
-            const int pn = p0 + (g + 1) / GP;
-            if ((g + 1) % GP == 0) pipe.enter(pn);
-            const f32x4* buf = pipe.lds + (pn % kNBuf) * kPanelF4 + pipe.lane;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) nxt.v[mt] = buf[(((g + 1) % GP) * MT + mt) * 64];
+        for (int j = 0; j < NM; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
+            acc[j % MT] = mfma32(cur.v[j % MT][j / MT], in[4 * g + j / MT], acc[j % MT]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                if (f * NM / NF != j) continue;
+                if (f < MT) {   // LDS read of fragment f of the next k-group
+                    if (g + 1 < G) {
+                        const int pn = p0 + (g + 1) / GP;
+                        // panel switch inside the part: the stores of this panel's earlier k-groups are younger than
+                        // the pieces waited for
+#ifdef NNR_ABLATE_VMCNT8
+                        if (f == 0 && (g + 1) % GP == 0) pipe.template enter<0>(pn);
+#else
+                        if (f == 0 && (g + 1) % GP == 0) pipe.template enter<STASH ? GP - 1 : 0>(pn);
+#endif
+                        const f32x4* buf = pipe.lds + (pn % kNBuf) * kPanelF4 + pipe.lane;
+                        nxt.v[f] = buf[(((g + 1) % GP) * MT + f) * 64];
+                    }
+                } else if (f == MT) {
+#ifndef NNR_ABLATE_NO_STASH
+                    if constexpr (STASH)
+                        *reinterpret_cast<f32x4*>(stash + 8 * g) = f32x4{in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]};
+#endif
+                } else if (f == MT + 1) {
+                    if constexpr (NSIDE > 0) {
+#pragma unroll
+                        for (int u = u0; u < um; ++u)
+                            if (u >= 0 && u < NSIDE) side(u);
+                    }
+                } else if (f == MT + 2) {
+                    // DMA pieces of the panel two ahead, spread over the k-groups of the current panel: slot 0 right
+                    // after the panel switch (which happens in the LAST k-group of the previous panel, or in
+                    // gemm_open), slots 1.. in the following k-groups
+                    const int pi = g / GP, gi = g % GP;
+                    const int n_in = (G - pi * GP) < GP ? (G - pi * GP) : GP;
+                    if (gi == n_in - 1) {
+                        if (g + 1 < G) {   // this k-group entered panel pi+1 above
+                            const int n_nx = (G - (pi + 1) * GP) < GP ? (G - (pi + 1) * GP) : GP;
+                            pipe.pieces(p0 + pi + 3, 0, (8 + n_nx - 1) / n_nx);
+                        }
+                    } else {
+                        const int ppk = (8 + n_in - 1) / n_in;
+                        pipe.pieces(p0 + pi + 2, (gi + 1) * ppk, ppk);
+                    }
+                } else {
+                    if constexpr (NSIDE > 0) {
+#pragma unroll
+                        for (int u = um; u < u1; ++u)
+                            if (u >= 0 && u < NSIDE) side(u);
+                    }
+                }
+            }
         }
-        if constexpr (STASH)
-            *reinterpret_cast<f32x4*>(stash + 8 * g) = f32x4{in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]};
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 2; i < 4; ++i) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(cur.v[mt][i], in[4 * g + i], acc[mt]);
-        }
+        pin_acc<MT>(acc);
         __builtin_amdgcn_sched_barrier(0);
         if (g + 1 < G) cur = nxt;
     }
+    if constexpr (NSIDE > 0) {
+#pragma unroll
+        for (int u = (G - SHIFT) * PPG; u < NSIDE; ++u)
+            if (u >= 0) side(u);
+    }
+}
+
+template <int KT, int MT, bool STASH = false, int NACC, int NIN>
+__device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
+                                          float* stash = nullptr) {
+    gemm_part<KT, MT, STASH, 0, 1, 0>(acc, in, pipe, p0, stash, NoSide{});
 }
 
 template <int N>
@@ -176,6 +298,15 @@ __device__ __forceinline__ void enc_feature_meta(int f, int n_real, int& coord, 
     coord = is_cos ? rem - 3 : rem;
     scale = is_cos ? -ldexpf(1.f, lvl) : ldexpf(1.f, lvl);
     partner = is_cos ? f - 3 : f + 3;
+}
+
+// ReLU as ONE instruction.  fmaxf(x, 0) (and every builtin hipcc folds to it) costs two: the MFMA result is canonicalised
+// first.  Every VALU instruction inside the MFMA stream delays the matrix pipe by about its own issue time, so the
+// instruction is spelled out.  (v_max_f32 returns the non-NaN operand, like fmaxf.)
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 __device__ __forceinline__ float softplus_ref(float x) {  // F.softplus, beta=1, threshold=20

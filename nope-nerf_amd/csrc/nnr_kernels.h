@@ -64,6 +64,7 @@ struct WgradArgs {
     float* gb[12];
     const WgradJob* jobs;
     const float* ws;           // workspace base
+    float* slots;              // n_jobs partial slots of kSlotFloats (see nnr_layout.h)
     int64_t plane_off[48];     // offset (floats) of each plane id, -1 if absent
     int32_t plane_pitch[48];
     int n_jobs;
@@ -92,6 +93,7 @@ struct LossArgs {
     float *g_rgb, *g_dist, *g_dgt;
     int R;
     float r_total, m_total;   // normalisers (m_total < 0: use this call's valid count)
+    const float* m_total_dev; // optional device scalar overriding m_total
     float w_rgb, w_depth;
     int rgb_l2, ndc, detach_gt;
 };

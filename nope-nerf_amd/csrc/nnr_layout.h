@@ -36,16 +36,29 @@ constexpr int kPosReal = 63, kDirReal = 27;     // (2L+1)*3
 constexpr int kPosPad = 64, kDirPad = 32;
 
 // ---- packed weight buffer -------------------------------------------------------------------------------------
-// Forward parts in stream order, backward (transposed) parts in stream order, then padded biases.
-enum FwdPart { F_L1 = 0, F_L2, F_L3, F_L4, F_L5H, F_L5E, F_L6, F_L7, F_L8, F_SIG, F_FEAT, F_RGBH_F, F_RGBH_D, F_RGB, F_NPARTS };
-enum BwdPart { B_RGB = 0, B_RGBH_F, B_RGBH_D, B_FEAT, B_SIG, B_L8, B_L7, B_L6, B_L5E, B_L5H, B_L4, B_L3, B_L2, B_L1, B_NPARTS };
+// Forward parts in stream order, backward (transposed) parts in stream order, padded biases, head tables.
+//
+// Every D-wide layer is consumed as TWO passes over its input, one per half of the output tiles ("A" = output features
+// [0,D/2), "B" = [D/2,D)): while pass B's MFMAs run, the wave finishes pass A's epilogue (bias is already in the
+// accumulator; ReLU, sign bits, move to the activation registers), and pass B's epilogue runs under the first half of the
+// NEXT layer's pass A -- whose first D/2 k-values only need the A half.  With one wave per SIMD this is the only way to
+// keep the matrix pipe busy during epilogues.  The 1-row density head and the 3-row rgb head are not MFMA work at all
+// (a 32-row tile would be 97 % padding): they are per-lane dot products against the head tables below.
+enum FwdPart {
+    F_L1A = 0, F_L1B, F_L2A, F_L2B, F_L3A, F_L3B, F_L4A, F_L4B, F_L5HA, F_L5EA, F_L5HB, F_L5EB,
+    F_L6A, F_L6B, F_L7A, F_L7B, F_L8A, F_L8B, F_FEATA, F_FEATB, F_RGBH_F, F_RGBH_D, F_NPARTS
+};
+enum BwdPart {
+    B_RGBH_FA = 0, B_RGBH_FB, B_RGBH_D, B_FEATA, B_FEATB, B_L8A, B_L8B, B_L7A, B_L7B, B_L6A, B_L6B,
+    B_L5E, B_L5HA, B_L5HB, B_L4A, B_L4B, B_L3A, B_L3B, B_L2A, B_L2B, B_L1, B_NPARTS
+};
 
 struct PartDesc {
     int layer;      // index into nnr_params (state_dict order)
-    int transpose;  // 0: A[m][k] = W[m][koff+k]   1: A[m][k] = W[k][moff+m]
+    int transpose;  // 0: A[m][k] = W[moff+m][koff+k]   1: A[m][k] = W[koff+k][moff+m]
     int KT, MT;     // tiles of 32 along k and m
     int m_real, k_real;  // valid rows / cols of A (rest is zero padding)
-    int off;        // column offset into W's in-dimension (koff or moff)
+    int moff, koff; // offsets of the part inside W
     int ld;         // W row pitch (= in_features)
 };
 
@@ -57,44 +70,32 @@ NNR_HD constexpr int part_panels(int KT, int MT) { return (4 * KT + part_gp(MT) 
 template <int D>
 struct Layout {
     static constexpr int DT = D / 32;
-    static constexpr int HT = D / 64;  // colour-hidden tiles (D/2 wide)
+    static constexpr int HT = D / 64;  // tiles of half a layer's outputs == tiles of the colour-hidden layer (D/2 wide)
     static_assert(D == 128 || D == 256, "hidden width must be 128 or 256");
+    static constexpr int P = kPosReal, Q = kDirReal, Dh = D / 2;
 
     NNR_HD static constexpr PartDesc fwd(int p) {
-        switch (p) {
-            case F_L1: return {0, 0, 2, DT, D, kPosReal, 0, kPosReal};
-            case F_L2: return {1, 0, DT, DT, D, D, 0, D};
-            case F_L3: return {2, 0, DT, DT, D, D, 0, D};
-            case F_L4: return {3, 0, DT, DT, D, D, 0, D};
-            case F_L5H: return {4, 0, DT, DT, D, D, 0, D + kPosReal};
-            case F_L5E: return {4, 0, 2, DT, D, kPosReal, D, D + kPosReal};
-            case F_L6: return {5, 0, DT, DT, D, D, 0, D};
-            case F_L7: return {6, 0, DT, DT, D, D, 0, D};
-            case F_L8: return {7, 0, DT, DT, D, D, 0, D};
-            case F_SIG: return {8, 0, DT, 1, 1, D, 0, D};
-            case F_FEAT: return {9, 0, DT, DT, D, D, 0, D};
-            case F_RGBH_F: return {10, 0, DT, HT, D / 2, D, 0, D + kDirReal};
-            case F_RGBH_D: return {10, 0, 1, HT, D / 2, kDirReal, D, D + kDirReal};
-            default: return {11, 0, HT, 1, 3, D / 2, 0, D / 2};
+        if (p < F_L2A) return {0, 0, 2, HT, Dh, P, (p & 1) * Dh, 0, P};
+        if (p < F_L5HA) return {1 + (p - F_L2A) / 2, 0, DT, HT, Dh, D, (p & 1) * Dh, 0, D};
+        if (p < F_L6A) {
+            const int q = p - F_L5HA, half = q >> 1;
+            if (q & 1) return {4, 0, 2, HT, Dh, P, half * Dh, D, D + P};
+            return {4, 0, DT, HT, Dh, D, half * Dh, 0, D + P};
         }
+        if (p < F_FEATA) return {5 + (p - F_L6A) / 2, 0, DT, HT, Dh, D, (p & 1) * Dh, 0, D};
+        if (p < F_RGBH_F) return {9, 0, DT, HT, Dh, D, (p & 1) * Dh, 0, D};
+        if (p == F_RGBH_F) return {10, 0, DT, HT, Dh, D, 0, 0, D + Q};
+        return {10, 0, 1, HT, Dh, Q, 0, D, D + Q};
     }
     NNR_HD static constexpr PartDesc bwd(int p) {
-        switch (p) {
-            case B_RGB: return {11, 1, 1, HT, D / 2, 3, 0, D / 2};
-            case B_RGBH_F: return {10, 1, HT, DT, D, D / 2, 0, D + kDirReal};
-            case B_RGBH_D: return {10, 1, HT, 1, kDirReal, D / 2, D, D + kDirReal};
-            case B_FEAT: return {9, 1, DT, DT, D, D, 0, D};
-            case B_SIG: return {8, 1, 1, DT, D, 1, 0, D};
-            case B_L8: return {7, 1, DT, DT, D, D, 0, D};
-            case B_L7: return {6, 1, DT, DT, D, D, 0, D};
-            case B_L6: return {5, 1, DT, DT, D, D, 0, D};
-            case B_L5H: return {4, 1, DT, DT, D, D, 0, D + kPosReal};
-            case B_L5E: return {4, 1, DT, 2, kPosReal, D, D, D + kPosReal};
-            case B_L4: return {3, 1, DT, DT, D, D, 0, D};
-            case B_L3: return {2, 1, DT, DT, D, D, 0, D};
-            case B_L2: return {1, 1, DT, DT, D, D, 0, D};
-            default: return {0, 1, DT, 2, kPosReal, D, 0, kPosReal};
-        }
+        if (p < B_RGBH_D) return {10, 1, HT, HT, Dh, Dh, p * Dh, 0, D + Q};
+        if (p == B_RGBH_D) return {10, 1, HT, 1, Q, Dh, D, 0, D + Q};
+        if (p < B_L8A) return {9, 1, DT, HT, Dh, D, (p - B_FEATA) * Dh, 0, D};
+        if (p < B_L5E) return {7 - (p - B_L8A) / 2, 1, DT, HT, Dh, D, ((p - B_L8A) & 1) * Dh, 0, D};
+        if (p == B_L5E) return {4, 1, DT, 2, P, D, D, 0, D + P};
+        if (p < B_L4A) return {4, 1, DT, HT, Dh, D, (p - B_L5HA) * Dh, 0, D + P};
+        if (p < B_L1) return {3 - (p - B_L4A) / 2, 1, DT, HT, Dh, D, ((p - B_L4A) & 1) * Dh, 0, D};
+        return {0, 1, DT, 2, P, D, 0, 0, P};
     }
     // first panel of a part; the forward stream occupies panels [0, fwd_panels), the backward stream follows
     NNR_HD static constexpr int fwd_panel0(int p) {
@@ -119,8 +120,14 @@ struct Layout {
     }
     NNR_HD static constexpr int bias_pad(int layer) { return layer == 8 || layer == 11 ? 32 : (layer == 10 ? (D / 2 + 31) / 32 * 32 : D); }
     NNR_HD static constexpr int bias_real(int layer) { return layer == 8 ? 1 : layer == 11 ? 3 : layer == 10 ? D / 2 : D; }
-    static constexpr int packed_floats = bias_off(12);
-    static constexpr int bias_floats = packed_floats - bias_base;
+    // head tables in REGISTER order (index [half][r], feature = frag_feature(r, half)): density row, then the 3 rgb rows
+    static constexpr int bias_floats = bias_off(12) - bias_base;
+    static constexpr int head_base = bias_off(12);
+    static constexpr int wsig_off = head_base;                  // [2][16*DT]
+    static constexpr int wrgb_off = wsig_off + 2 * 16 * DT;     // [3][2][16*HT]
+    static constexpr int head_floats = 2 * 16 * DT + 3 * 2 * 16 * HT;
+    static constexpr int packed_floats = head_base + head_floats;
+    static constexpr int table_floats = bias_floats + head_floats;  // what the MLP kernels copy into LDS
 
     // ---- workspace planes (floats), S_pad = samples rounded up to a multiple of kBlockSamples ----
     static constexpr int x_width = kPosPad + 8 * D + (D + kDirPad) + D / 2;  // per-sample activation stash
@@ -175,7 +182,9 @@ struct WsLayout {
 // ---- weight-gradient plan: one entry per wave job ---------------------------------------------------------------
 // dW[layer][row0 + MI*m + i][wcol0 + NI*n + j] += sum_{s in [k0,k1)} Dlt[s][dcol0 + MI*m + i] * X[s][xcol0 + NI*n + j]
 // (m, n in [0,32), i < MI, j < NI): a wave tile of 32*MI rows x 32*NI cols with interleaved sub-tiles, so one
-// MI-wide and one NI-wide vector load per lane feed MI*NI MFMAs.
+// MI-wide and one NI-wide vector load per lane feed MI*NI MFMAs.  The sample axis is split over `n_splits` jobs per tile;
+// each job writes its partial tile to its own slot of the workspace (plain, coalesced stores) and a second small kernel
+// adds the slots of a tile into dW -- ~27 float atomics per weight at the end of every wave cost 7 % of the kernel.
 struct WgradJob {
     int32_t layer;           // parameter index (state_dict order), -1 = idle wave
     int32_t MI, NI;          // 1, 2 or 4
@@ -183,8 +192,13 @@ struct WgradJob {
     int32_t x_plane, x_col0, x_valid;  // activation operand
     int32_t row0, wcol0;     // destination offsets in W (rows = out features, cols = in features)
     int32_t rows_real, cols_real, ldw;  // bounds and pitch of W
-    int32_t k0, k1;          // sample range (multiples of 8)
-    int32_t bias;            // 1: this job also reduces d(bias)[row] = sum_s Dlt[s][row]
+    int32_t k0, k1;          // sample range (multiples of 16)
+    int32_t bias;            // 1: this tile also reduces d(bias)[row] = sum_s Dlt[s][row]
+    int32_t split, n_splits, split_stride;  // this job is split `split` of its tile; split s lives at job index (this - split*stride) + s*stride
 };
+// partial slot of job i: floats [i*kSlotFloats, (i+1)*kSlotFloats) of the slot region = tile (32*MI rows x 32*NI cols,
+// row-major, pitch 32*NI) followed by the two half-wave bias partials [2][32*MI]
+constexpr int kSlotTile = 128 * 128;
+constexpr int kSlotFloats = kSlotTile + 2 * 128;
 
 }  // namespace nnr

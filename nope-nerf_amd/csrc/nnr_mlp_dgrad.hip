@@ -9,23 +9,83 @@
 
 namespace nnr {
 
+// Compile-time description of one encoding feature (same block order as enc_feature in nnr_device.h).
+struct EncMeta { int coord; float scale; int partner; };
+__device__ __forceinline__ constexpr EncMeta enc_meta(int f, int n_real) {
+    if (f >= n_real) return {0, 0.f, 0};
+    if (f < 3) return {f, 1.f, -1};
+    const int t = f - 3, lvl = t / 6, rem = t - 6 * lvl;
+    const bool is_cos = rem >= 3;
+    const float a = (float)(1 << lvl);
+    return {is_cos ? rem - 3 : rem, is_cos ? -a : a, is_cos ? f - 3 : f + 3};
+}
+
+// Chain rule through gamma_L for the NR registers of one lane: returns d/d(x,y,z) of sum_r g[r] * gamma(.)_{f(r,half)}.
+// `pv[r]` = scale * partner value (cos for a sin feature, -sin for a cos feature, 1 for the identity block), prepared by
+// enc_partners.  The coordinate of register r is compile-time for half 0 and rotates by one for half 1 (f -> f+4, blocks of 3).
+template <int NR>
+__device__ __forceinline__ void enc_partners(float (&pv)[NR], const float* enc, int n_real, int half) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const EncMeta m0 = enc_meta(frag_feature(r, 0), n_real), m1 = enc_meta(frag_feature(r, 1), n_real);
+        const int partner = half ? m1.partner : m0.partner;
+        const float sc = half ? m1.scale : m0.scale;
+        pv[r] = sc * (partner >= 0 ? enc[partner] : 1.f);
+    }
+}
+template <int NR, class G>
+__device__ __forceinline__ f32x4 enc_backward(const G& g, const float (&pv)[NR], int half) {
+    float g3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int f0 = frag_feature(r, 0);
+        const int c0 = f0 < 3 ? f0 : (f0 - 3) % 3;
+        g3[c0] = fmaf(g(r), pv[r], g3[c0]);
+    }
+    float o[3] = {half ? g3[2] : g3[0], half ? g3[0] : g3[1], half ? g3[1] : g3[2]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
+    return f32x4{o[0], o[1], o[2], 0.f};
+}
+
+NNR_TL_DECL(tl_dgrad)
+
 template <int D>
 __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
+    NNR_STAMP(tl_dgrad, 0);
     using L = Layout<D>;
     constexpr int DT = L::DT, HT = L::HT;
+    constexpr int HR = 16 * HT;              // registers of half a layer's outputs
+    constexpr int NP = HR / 2;               // register pairs per half (the unit of hidden epilogue work)
+    constexpr int HW = (HR + 31) / 32;       // mask words per half
+    constexpr int PP = part_panels(DT, HT);  // panels of one D x D/2 pass
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int half = lane >> 5;
     const int col = lane & 31;
     const int64_t s = (int64_t)blockIdx.x * kBlockSamples + wave * kChunk + col;
+#ifdef NNR_ABLATE_STASH_L2
+    const int64_t ss = s & 127;   // profiling build only: every stash store hits the same 128 rows (L2-resident)
+#else
+    const int64_t ss = s;         // row of the stash planes
+#endif
     const bool live = s < a.S;  // padded samples carry zero gradients so they add nothing to the weight gradients
 
-    // weight panels of the transposed (backward) stream through the LDS ring -- see PanelPipe in nnr_device.h
-    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kWavesPerBlock * 8 * 64];
-    f32x4* const de_lds = smem + kNBuf * kPanelF4 + wave * (8 * 64) + lane;   // parking spot of d(posenc) from the skip layer
-    const PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed + L::bwd_base) + wave * (8 * 64) + lane, smem, wave, lane,
+    // LDS: the panel ring of the transposed (backward) weight stream, a parking area for d(posenc) of the skip layer and
+    // the head tables (density row, rgb rows, register order) -- one array, see PanelPipe in nnr_device.h
+    constexpr int kPark = kWavesPerBlock * 8 * 64;
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kPark + (L::head_floats + 3) / 4];
+    f32x4* const de_lds = smem + kNBuf * kPanelF4 + wave * (8 * 64) + lane;
+    float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4 + kPark);
+    for (int i = threadIdx.x; i < L::head_floats; i += 256) ltab[i] = a.packed[L::head_base + i];
+    __syncthreads();   // before any DMA is in flight: the only full barrier of the kernel
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed + L::bwd_base) + wave_u * (8 * 64), smem, wave_u, lane,
                          L::bwd_panels};
     pipe.start();
+    NNR_STAMP(tl_dgrad, 1);
+    const float* const wsig = ltab + half * (16 * DT);   // density row, this half's registers
+    const float* const wrgb = ltab + 2 * 16 * DT;        // rgb rows: [(2c + half) * HR + r]
     auto p0 = [&](int part) { return L::bwd_panel0(part); };
     const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const uint32_t* mask_base = a.ws_mask + ((chunk * L::n_mask_layers) * 64 + lane) * L::mask_words;
@@ -34,147 +94,146 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     if (live) dout = *reinterpret_cast<const f32x4*>(a.ws_dout4 + 4 * s);
     else if (half == 0) *reinterpret_cast<f32x4*>(a.ws_dout4 + 4 * s) = dout;   // padded rows feed the weight-gradient kernel: zero them
 
-    // ---- colour branch ----
-    // d rgb_pre (3, padded to one 32-row tile): rows 0..2 = registers 0..2 of half 0
-    float drgb[16];
+    float d[16 * DT];    // current D-wide gradient (d feature, then d pre-activation of hidden 8..1), rewritten in place
+    f32x16 accA[HT], accB[HT];   // halves A ([0,D/2)) and B ([D/2,D)) of the gradient being computed
+    uint32_t mwA[HW], mwB[HW];   // ReLU sign bits of the layer whose gradient sits in accA / accB
+    auto load_mask = [&](uint32_t(&mw)[HW], int layer_idx, int hb) __attribute__((always_inline)) {
+        const uint32_t* m = mask_base + (int64_t)layer_idx * 64 * L::mask_words + hb * HW;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) drgb[r] = 0.f;
-    drgb[0] = half == 0 ? dout[0] : 0.f;
-    drgb[1] = half == 0 ? dout[1] : 0.f;
-    drgb[2] = half == 0 ? dout[2] : 0.f;
-    float dg[16 * HT];
-    {
-        f32x16 acc[HT];
-        zero_acc(acc);
-        gemm_part<1, HT>(acc, drgb, pipe, p0(B_RGB), gemm_open<HT>(pipe, p0(B_RGB)));
-        uint32_t mw[L::mask_words];
-        const uint32_t* m = mask_base + (int64_t)8 * 64 * L::mask_words;
-#pragma unroll
-        for (int w = 0; w < L::mask_words; ++w) mw[w] = m[w];
-#pragma unroll
-        for (int r = 0; r < 16 * HT; ++r) dg[r] = ((mw[r >> 5] >> (r & 31)) & 1u) ? acc[r >> 4][r & 15] : 0.f;
+        for (int w = 0; w < HW; ++w) mw[w] = m[w];
+    };
+// one epilogue unit u (registers 2u, 2u+1 of the half): d[off + 2u + i] = relu'(.) ? acc : 0, or a plain move
+#define NNR_SEL_PAIR(ACC, OFF, MW)                                                                           \
+    [&](int u) __attribute__((always_inline)) {                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+            const int r = 2 * u + i;                                                                         \
+            d[(OFF) + r] = ((MW[r >> 5] >> (r & 31)) & 1u) ? ACC[r >> 4][r & 15] : 0.f;                      \
+        }                                                                                                    \
     }
-    Frags<DT> frh = gemm_open<DT>(pipe, p0(B_RGBH_F));   // opened before the mask epilogue above retires
-    float d[16 * DT];  // current D-wide gradient (d feature, then d pre-activation of hidden 8..1)
+#define NNR_MOVE_PAIR(ACC, OFF)                                                                              \
+    [&](int u) __attribute__((always_inline)) {                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) d[(OFF) + 2 * u + i] = ACC[(2 * u + i) >> 4][(2 * u + i) & 15]; \
+    }
+
+    // ---- colour branch ----
+    // d g = relu'(g) .* (Wc^T d rgb_pre): three FMAs per value against the rgb rows in LDS (a 3-deep GEMM is not MFMA work)
+    float dg[HR];
+    load_mask(mwA, 8, 0);
+#pragma unroll
+    for (int q = 0; q < HR / 4; ++q) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrgb + (0 + half) * HR + 4 * q);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(wrgb + (2 + half) * HR + 4 * q);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(wrgb + (4 + half) * HR + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = fmaf(w2[i], dout[2], fmaf(w1[i], dout[1], w0[i] * dout[0]));
+            dg[4 * q + i] = ((mwA[(4 * q + i) >> 5] >> ((4 * q + i) & 31)) & 1u) ? v : 0.f;
+        }
+    }
+    // [d feat ; d gamma(v)] = Wg^T d g.  Every gradient vector is stashed by the first pass that consumes it (one 16-byte
+    // store per k-group inside the MFMA stream, see gemm_part); the epilogue of each half-output pass runs as side work of
+    // the following pass.
+    zero_acc(accA);
+    gemm_part<HT, HT, true>(accA, dg, pipe, p0(B_RGBH_FA), a.ws_dg + ss * (D / 2) + 4 * half);
+    zero_acc(accB);
+    gemm_part<HT, HT, false, NP, 2, 0>(accB, dg, pipe, p0(B_RGBH_FB), nullptr, NNR_MOVE_PAIR(accA, 0));
     {
-        f32x16 acc[DT];
-        zero_acc(acc);
-        // every gradient vector is stashed by the gemm that consumes it (one 16-byte store per k-group, inside the
-        // MFMA stream) -- see gemm_part.  Wg^T is consumed as two parts: rows of the feature (D) and of the direction
-        // encoding (27 -> one 32-row tile).
-        gemm_part<HT, DT, true>(acc, dg, pipe, p0(B_RGBH_F), frh, a.ws_dg + s * (D / 2) + 4 * half);
+        float pvd[16];   // stored direction encoding (sin<->cos partners): the loads land under this short pass
+        enc_partners(pvd, a.ws_xf + (live ? s : 0) * (D + kDirPad) + D, kDirReal, half);
         f32x16 accd[1];
         zero_acc(accd);
-        gemm_part<HT, 1>(accd, dg, pipe, p0(B_RGBH_D), gemm_open<1>(pipe, p0(B_RGBH_D)));
-#pragma unroll
-        for (int r = 0; r < 16 * DT; ++r) d[r] = acc[r >> 4][r & 15];
-        // direction-encoding backward: d v = sum_f d gamma_4(v)_f/dv * grad_f, using the stored encoding for the
-        // sin<->cos partner values (model/official_nerf.py:112-118)
-        const float* enc = a.ws_xf + (live ? s : 0) * (D + kDirPad) + D;
-        float gv[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = frag_feature(r, half);
-            int c, partner;
-            float sc;
-            enc_feature_meta(f, kDirReal, c, sc, partner);
-            const float pv = partner >= 0 ? enc[partner] : 1.f;
-            const float contrib = accd[0][r] * sc * pv;
-            gv[0] += c == 0 ? contrib : 0.f;
-            gv[1] += c == 1 ? contrib : 0.f;
-            gv[2] += c == 2 ? contrib : 0.f;
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gv[c] += __shfl_xor(gv[c], 32, 64);
-        if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dview + 4 * s) = f32x4{gv[0], gv[1], gv[2], 0.f};
+        gemm_part<HT, 1>(accd, dg, pipe, p0(B_RGBH_D));
+        const f32x4 gv = enc_backward<16>([&](int r) { return accd[0][r]; }, pvd, half);
+        if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dview + 4 * s) = gv;
     }
 
     // ---- trunk ----
-    f32x16 acc[DT];
-    auto masked_layer = [&](int hidden_idx /*0..7*/) {  // d <- acc .* relu'(h_idx)
-        uint32_t mw[L::mask_words];
-        const uint32_t* m = mask_base + (int64_t)hidden_idx * 64 * L::mask_words;
+    NNR_STAMP(tl_dgrad, 2);
+    auto dh = [&](int hidden_idx /*0..7*/) -> float* { return a.ws_dh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half; };
+    // d h8 = relu'(h8) .* (Wf^T d feat + w_sigma^T d sigma_raw): the rank-1 density term is the accumulator's initial value
+    auto init_sigma = [&](f32x16(&acc)[HT], int hb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int w = 0; w < L::mask_words; ++w) mw[w] = m[w];
+        for (int t = 0; t < HT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16 * DT; ++r) d[r] = ((mw[r >> 5] >> (r & 31)) & 1u) ? acc[r >> 4][r & 15] : 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wsig + hb * HR + 16 * t + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][4 * q + i] = w4[i] * dout[3];
+            }
     };
-    auto dh = [&](int hidden_idx /*0..7*/) -> float* { return a.ws_dh + ((int64_t)hidden_idx * a.S_pad + s) * D + 4 * half; };
-    // d h8 = Wf^T d feat + w_sigma^T d sigma_raw
-    float dsig[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dsig[r] = 0.f;
-    dsig[0] = half == 0 ? dout[3] : 0.f;
-    zero_acc(acc);
-    gemm_part<DT, DT, true>(acc, d, pipe, p0(B_FEAT), gemm_open<DT>(pipe, p0(B_FEAT)), a.ws_df + s * D + 4 * half);
-    gemm_part<1, DT>(acc, dsig, pipe, p0(B_SIG), gemm_open<DT>(pipe, p0(B_SIG)));
-    Frags<DT> fr = gemm_open<DT>(pipe, p0(B_L8));
-    masked_layer(7);
+    load_mask(mwA, 7, 0);
+    init_sigma(accA, 0);
+    gemm_part<DT, HT, true, NP, 2, 0>(accA, d, pipe, p0(B_FEATA), a.ws_df + ss * D + 4 * half, NNR_MOVE_PAIR(accB, HR));
+    load_mask(mwB, 7, 1);
+    init_sigma(accB, 1);
+    gemm_part<DT, HT, false, NP, 2, 1>(accB, d, pipe, p0(B_FEATB), nullptr, NNR_SEL_PAIR(accA, 0, mwA));
+    NNR_STAMP(tl_dgrad, 3);
+    // Invariant from here on: d[0, HR) holds half A of the newest gradient, accB its half B still to be masked (mwB).
+
+    // one transposed D x D layer at panel pa: consumes the gradient in d (stashing it to `stash`), produces the gradient of
+    // the layer below, masked by the sign bits of hidden layer `mask_idx`
+    auto bwd_layer = [&](int pa, float* stash, int mask_idx) __attribute__((always_inline)) {
+        zero_acc(accA);
+        load_mask(mwA, mask_idx, 0);
+        // pass A: the first half of the k-groups only reads d[0,HR); the previous gradient's half B is finished meanwhile
+        gemm_part<DT, HT, true, NP, 2, 0>(accA, d, pipe, pa, stash, NNR_SEL_PAIR(accB, HR, mwB));
+        load_mask(mwB, mask_idx, 1);
+        zero_acc(accB);
+        // pass B: half A of the new gradient replaces d[0,HR) in place, one k-group behind the reads
+        gemm_part<DT, HT, false, NP, 2, 1>(accB, d, pipe, pa + PP, nullptr, NNR_SEL_PAIR(accA, 0, mwA));
+    };
     // hidden 8,7,6 -> d pre-activation of 7,6,5
 #pragma unroll 1
-    for (int l = 0; l < 3; ++l) {
-        zero_acc(acc);
-        gemm_part<DT, DT, true>(acc, d, pipe, p0(B_L8) + l * part_panels(DT, DT), fr, dh(7 - l));
-        if (l < 2) fr = gemm_open<DT>(pipe, p0(B_L8) + (l + 1) * part_panels(DT, DT));
-        masked_layer(6 - l);
-    }
-    // hidden 5 (skip layer), two parts of W5^T: rows [D, D+63) -> d posenc (kept for the end), rows [0,D) -> d h4
+    for (int l = 0; l < 3; ++l) bwd_layer(p0(B_L8A) + 2 * PP * l, dh(7 - l), 6 - l);
+    NNR_STAMP(tl_dgrad, 4);
+    // hidden 5 (skip layer), three passes over W5^T: rows [D, D+63) -> d posenc (parked in LDS until the end), rows [0,D) -> d h4
     {
         f32x16 acce[2];
         zero_acc(acce);
-        gemm_part<DT, 2>(acce, d, pipe, p0(B_L5E), gemm_open<2>(pipe, p0(B_L5E)));
-        // 32 registers that are not needed again until the very end: park them in LDS (same array as the panels)
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
+        load_mask(mwA, 3, 0);
+        gemm_part<DT, 2, true, NP, 2, 0>(acce, d, pipe, p0(B_L5E), dh(4), NNR_SEL_PAIR(accB, HR, mwB));
+        load_mask(mwB, 3, 1);
+        zero_acc(accA);
+        auto park = [&](int q) __attribute__((always_inline)) {
             de_lds[q * 64] = f32x4{acce[q >> 2][4 * (q & 3)], acce[q >> 2][4 * (q & 3) + 1], acce[q >> 2][4 * (q & 3) + 2],
                                    acce[q >> 2][4 * (q & 3) + 3]};
+        };
+        gemm_part<DT, HT, false, 8, 1, 0>(accA, d, pipe, p0(B_L5HA), nullptr, park);
     }
-    zero_acc(acc);
-    gemm_part<DT, DT, true>(acc, d, pipe, p0(B_L5H), gemm_open<DT>(pipe, p0(B_L5H)), dh(4));
-    fr = gemm_open<DT>(pipe, p0(B_L4));
-    masked_layer(3);
+    zero_acc(accB);
+    gemm_part<DT, HT, false, NP, 2, 1>(accB, d, pipe, p0(B_L5HB), nullptr, NNR_SEL_PAIR(accA, 0, mwA));
+    NNR_STAMP(tl_dgrad, 5);
     // hidden 4,3,2 -> d pre-activation of 3,2,1
 #pragma unroll 1
-    for (int l = 0; l < 3; ++l) {
-        zero_acc(acc);
-        gemm_part<DT, DT, true>(acc, d, pipe, p0(B_L4) + l * part_panels(DT, DT), fr, dh(3 - l));
-        if (l < 2) fr = gemm_open<DT>(pipe, p0(B_L4) + (l + 1) * part_panels(DT, DT));
-        masked_layer(2 - l);
-    }
-    // hidden 1: d posenc = W1^T d1 + (skip-layer part parked in LDS)
-    float de[32];
+    for (int l = 0; l < 3; ++l) bwd_layer(p0(B_L4A) + 2 * PP * l, dh(3 - l), 2 - l);
+    NNR_STAMP(tl_dgrad, 6);
+    // hidden 1: d posenc = W1^T d1 + (skip-layer part parked in LDS), then the chain rule through gamma_10 -> d point
     {
+        float pve[32];   // stored position encoding (sin<->cos partners): the loads land under the last pass
+        enc_partners(pve, a.ws_xe + (live ? s : 0) * kPosPad, kPosReal, half);
         f32x16 acc2[2];
         zero_acc(acc2);
-        gemm_part<DT, 2, true>(acc2, d, pipe, p0(B_L1), gemm_open<2>(pipe, p0(B_L1)), dh(0));
+        gemm_part<DT, 2, true, NP, 2, 0>(acc2, d, pipe, p0(B_L1), dh(0), NNR_SEL_PAIR(accB, HR, mwB));
+        float de[32];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const f32x4 v = de_lds[q * 64];
 #pragma unroll
             for (int i = 0; i < 4; ++i) de[4 * q + i] = acc2[q >> 2][4 * (q & 3) + i] + v[i];
         }
+        const f32x4 gp = enc_backward<32>([&](int r) { return de[r]; }, pve, half);
+        if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dpts + 4 * s) = gp;
     }
-    // positional-encoding backward -> d point
-    {
-        const float* enc = a.ws_xe + (live ? s : 0) * kPosPad;
-        float gp[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const int f = frag_feature(r, half);
-            int c, partner;
-            float sc;
-            enc_feature_meta(f, kPosReal, c, sc, partner);
-            const float pv = partner >= 0 ? enc[partner] : 1.f;
-            const float contrib = de[r] * sc * pv;
-            gp[0] += c == 0 ? contrib : 0.f;
-            gp[1] += c == 1 ? contrib : 0.f;
-            gp[2] += c == 2 ? contrib : 0.f;
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gp[c] += __shfl_xor(gp[c], 32, 64);
-        if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dpts + 4 * s) = f32x4{gp[0], gp[1], gp[2], 0.f};
-    }
+    NNR_STAMP(tl_dgrad, 7);
+#undef NNR_SEL_PAIR
+#undef NNR_MOVE_PAIR
 }
+
+#ifdef NNR_TIMELINE
+extern "C" int nnr_timeline_dgrad(unsigned long long* host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_dgrad), 32 * sizeof(unsigned long long));
+}
+#endif
 
 template <int D>
 static hipError_t launch(const MlpDgradArgs& a, hipStream_t st) {

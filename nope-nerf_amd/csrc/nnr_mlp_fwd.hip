@@ -5,6 +5,7 @@
 //
 // Roofline: MFMA-bound.  593 408 MACs/sample at D=256 -> 9 472 v_mfma_f32_32x32x2_f32 per 32 samples (9 272 useful,
 // 2 % padding of the 63/27/1/3-wide edges) = 606 k cycles per wave against ~10 k cycles of everything else.
+// Every D-wide layer runs as two half-output passes so that epilogues execute under MFMAs (nnr_layout.h).
 // HBM per sample: 4 B jitter in, 20 B out (+ the 10 KB activation stash when training, written once, never re-read here).
 #include "nnr_device.h"
 #include "nnr_kernels.h"
@@ -17,8 +18,11 @@ constexpr bool kAblateNoMask = true;   // profiling build only
 constexpr bool kAblateNoMask = false;
 #endif
 
+NNR_TL_DECL(tl_fwd)
+
 template <int D, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
+    NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 0);
     using L = Layout<D>;
     constexpr int DT = L::DT, HT = L::HT;
     const int lane = threadIdx.x & 63;
@@ -27,6 +31,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     const int col = lane & 31;
     const int64_t s = (int64_t)blockIdx.x * kBlockSamples + wave * kChunk + col;  // this lane's sample
     const int64_t sc = s < a.S ? s : a.S - 1;                                      // clamp: padded samples recompute the last one
+#ifdef NNR_ABLATE_STASH_L2
+    const int64_t ss = s & 127;   // profiling build only: every stash store hits the same 128 rows (L2-resident)
+#else
+    const int64_t ss = s;         // row of the stash planes
+#endif
     const int ray = (int)(sc / a.N);
     const int j = (int)(sc - (int64_t)ray * a.N);
 
@@ -50,154 +59,221 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     float dirv[16];  // gamma_4(v): 27 -> 32
 #pragma unroll
     for (int r = 0; r < 16; ++r) dirv[r] = enc_feature(frag_feature(r, half), kDirReal, vx, vy, vz);
+    NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 1);
 
-    // ---- weight panels (LDS ring, DMA two panels ahead) and the bias table, all in ONE __shared__ array ----
-    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + (L::bias_floats + 3) / 4];
-    float* const lbias = reinterpret_cast<float*>(smem + kNBuf * kPanelF4);
-    for (int i = threadIdx.x; i < L::bias_floats; i += 256) lbias[i] = a.packed[L::bias_base + i];
+    // ---- weight panels (LDS ring, DMA two panels ahead) and the bias / head tables, all in ONE __shared__ array ----
+    constexpr int kPark = kWavesPerBlock * 12 * 64;   // per wave 12 float4 slots per lane: posenc (8) + direnc (4)
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kPark + (L::table_floats + 3) / 4];
+    f32x4* const park = smem + kNBuf * kPanelF4 + wave * (12 * 64) + lane;
+    float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4 + kPark);
+    for (int i = threadIdx.x; i < L::table_floats; i += 256) ltab[i] = a.packed[L::bias_base + i];
     __syncthreads();   // before any DMA is in flight: this is the only full barrier of the kernel
-    const PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave * (8 * 64) + lane, smem, wave, lane, L::fwd_panels};
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave_u * (8 * 64), smem, wave_u, lane, L::fwd_panels};
     pipe.start();
-    auto p0 = [&](int part) { return L::fwd_panel0(part); };
-    const float* bias = lbias - L::bias_base;   // index with L::bias_off(layer)
+    NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 2);
+    // the direction encoding is needed once, at the very end: park it in LDS instead of holding 16 registers for 70 panels
+#pragma unroll
+    for (int q = 0; q < 4; ++q) park[(8 + q) * 64] = f32x4{dirv[4 * q], dirv[4 * q + 1], dirv[4 * q + 2], dirv[4 * q + 3]};
+    const float* bias = ltab - L::bias_base;   // index with L::bias_off(layer), L::wsig_off, L::wrgb_off
 
     uint32_t* mask_base = nullptr;
     if (TRAIN) {
-        // masks: [chunk][layer][lane][mask_words]
+        // masks: [chunk][layer][lane][mask_words]; half A of a layer owns the low words, half B the high words
         int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave;
         mask_base = a.ws_mask + ((chunk * L::n_mask_layers) * 64 + lane) * L::mask_words;
     }
+    constexpr int HR = 16 * HT;              // registers of half a layer's outputs
+    constexpr int NP = HR / 2;               // register pairs per half (the unit of hidden epilogue work)
+    constexpr int HW = (HR + 31) / 32;       // mask words per half
+    constexpr int PP = part_panels(DT, HT);  // panels of one D x D/2 pass
 
-    float h[16 * DT];
-    f32x16 acc[DT];
+    float h[16 * DT];    // current layer input (activations of the previous layer), rewritten in place
+    f32x16 accA[HT], accB[HT];   // halves A ([0,D/2)) and B ([D/2,D)) of the layer being computed
+    uint32_t mwA[HW], mwB[HW];
 
-    // epilogue of a D-wide ReLU layer: h = relu(acc + b); keep the sign bits (the activations themselves are stashed
-    // by the *next* layer's gemm, interleaved with its MFMAs)
-    auto relu_layer = [&](int layer_idx /*0..7*/) {
-        const float* b = bias + L::bias_off(layer_idx) + 4 * half;
-        uint32_t mw[L::mask_words];
-#pragma unroll
-        for (int w = 0; w < L::mask_words; ++w) mw[w] = 0;
-#pragma unroll
-        for (int t = 0; t < DT; ++t) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 bb = *reinterpret_cast<const f32x4*>(b + 32 * t + 8 * q);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float x = acc[t][4 * q + i] + bb[i];
-                    x = fmaxf(x, 0.f);
-                    const int r = 16 * t + 4 * q + i;
-                    h[r] = x;
-                    if (TRAIN && !kAblateNoMask) mw[r >> 5] |= min(__float_as_uint(x), 1u) << (r & 31);   // x >= 0: bit = (x != 0), no VCC round trip
-                }
-            }
-        }
-        if (TRAIN) {
-            uint32_t* m = mask_base + (int64_t)layer_idx * 64 * L::mask_words;
-#pragma unroll
-            for (int w = 0; w < L::mask_words; ++w) m[w] = mw[w];
-        }
-    };
-
-    // hidden 1: 63 -> D
-    zero_acc(acc);
-    float* const xe = TRAIN ? a.ws_xe + s * kPosPad + 4 * half : nullptr;
-    auto xh = [&](int hidden_idx /*0..7*/) -> float* {
-        return TRAIN ? a.ws_xh + ((int64_t)hidden_idx * a.S_pad + s) * D + 4 * half : nullptr;
-    };
-    // Every part is opened (panel switch + first fragment reads) before the epilogue that precedes it.
-    gemm_part<2, DT, TRAIN>(acc, e, pipe, p0(F_L1), gemm_open<DT>(pipe, p0(F_L1)), xe);
-    Frags<DT> fr = gemm_open<DT>(pipe, p0(F_L2));
-    relu_layer(0);
-    // hidden 2..4
-#pragma unroll 1
-    for (int l = 0; l < 3; ++l) {
-        zero_acc(acc);
-        gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_L2) + l * part_panels(DT, DT), fr, xh(l));
-        fr = gemm_open<DT>(pipe, p0(F_L2) + (l + 1) * part_panels(DT, DT));   // l == 2: that is the first panel of hidden 5
-        relu_layer(1 + l);
-    }
-    // hidden 5: [h4 ; e] -> D   (skip connection, input order [h, posenc]: model/official_nerf.py:63)
-    zero_acc(acc);
-    static_assert(L::fwd_panel0(F_L5H) == L::fwd_panel0(F_L2) + 3 * part_panels(DT, DT), "stream order");
-    gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_L5H), fr, xh(3));
-    gemm_part<2, DT>(acc, e, pipe, p0(F_L5E), gemm_open<DT>(pipe, p0(F_L5E)));
-    fr = gemm_open<DT>(pipe, p0(F_L6));
-    relu_layer(4);
-    // hidden 6..8
-#pragma unroll 1
-    for (int l = 0; l < 3; ++l) {
-        zero_acc(acc);
-        gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_L6) + l * part_panels(DT, DT), fr, xh(4 + l));
-        if (l < 2) fr = gemm_open<DT>(pipe, p0(F_L6) + (l + 1) * part_panels(DT, DT));
-        relu_layer(5 + l);
-    }
-    // density head: D -> 1 (row 0 of a 32-row tile)
-    f32x16 acc1[1];
-    zero_acc(acc1);
-    gemm_part<DT, 1>(acc1, h, pipe, p0(F_SIG), gemm_open<1>(pipe, p0(F_SIG)));
-    const float sigma_raw = acc1[0][0] + bias[L::bias_off(8)];
-    // feature: D -> D, no activation
-    zero_acc(acc);
-    gemm_part<DT, DT, TRAIN>(acc, h, pipe, p0(F_FEAT), gemm_open<DT>(pipe, p0(F_FEAT)), xh(7));
-    Frags<HT> frg = gemm_open<HT>(pipe, p0(F_RGBH_F));
-    float* const xf = TRAIN ? a.ws_xf + s * (D + kDirPad) + 4 * half : nullptr;
-    {
-        const float* b = bias + L::bias_off(9) + 4 * half;
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 bb = *reinterpret_cast<const f32x4*>(b + 32 * t + 8 * q);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) h[16 * t + 4 * q + i] = acc[t][4 * q + i] + bb[i];
-            }
-    }
-    // colour hidden: [feat ; gamma_4(v)] -> D/2, ReLU   (input order [feat, dir_enc]: model/official_nerf.py:89)
-    f32x16 accg[HT];
-    zero_acc(accg);
-    gemm_part<DT, HT, TRAIN>(accg, h, pipe, p0(F_RGBH_F), frg, xf);
-    gemm_part<1, HT, TRAIN>(accg, dirv, pipe, p0(F_RGBH_D), gemm_open<HT>(pipe, p0(F_RGBH_D)), TRAIN ? xf + D : nullptr);
-    Frags<1> fr1 = gemm_open<1>(pipe, p0(F_RGB));
-    float g[16 * HT];
-    {
-        const float* b = bias + L::bias_off(10) + 4 * half;
-        uint32_t mw[L::mask_words];
-#pragma unroll
-        for (int w = 0; w < L::mask_words; ++w) mw[w] = 0;
+    // accumulators start at the bias, so an epilogue is only ReLU (+ sign bit) or a move
+    auto init_acc = [&](f32x16(&acc)[HT], int bias_offset) __attribute__((always_inline)) {
+        const float* b = bias + bias_offset + 4 * half;
 #pragma unroll
         for (int t = 0; t < HT; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f32x4 bb = *reinterpret_cast<const f32x4*>(b + 32 * t + 8 * q);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 32 * t + 8 * q);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float x = fmaxf(accg[t][4 * q + i] + bb[i], 0.f);
-                    const int r = 16 * t + 4 * q + i;
-                    g[r] = x;
-                    if (TRAIN && !kAblateNoMask) mw[r >> 5] |= min(__float_as_uint(x), 1u) << (r & 31);   // x >= 0: bit = (x != 0), no VCC round trip
-                }
+                for (int i = 0; i < 4; ++i) acc[t][4 * q + i] = bb[i];
             }
-        if (TRAIN) {
-            uint32_t* m = mask_base + (int64_t)8 * 64 * L::mask_words;
+    };
+    auto clear_mask = [&](uint32_t(&mw)[HW]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int w = 0; w < L::mask_words; ++w) m[w] = mw[w];
+        for (int w = 0; w < HW; ++w) mw[w] = 0;
+    };
+    auto store_mask = [&](const uint32_t(&mw)[HW], int layer_idx, int hb) __attribute__((always_inline)) {
+        if (TRAIN) {
+            uint32_t* m = mask_base + (int64_t)layer_idx * 64 * L::mask_words + hb * HW;
+#pragma unroll
+            for (int w = 0; w < HW; ++w) m[w] = mw[w];
         }
+    };
+// one epilogue unit u (registers 2u, 2u+1 of the half): h[off + 2u + i] = relu(acc) (+ sign bit) or plain move
+#define NNR_RELU_PAIR(ACC, OFF, MW)                                                                          \
+    [&](int u) __attribute__((always_inline)) {                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+            const int r = 2 * u + i;                                                                         \
+            const float x = ACC[r >> 4][r & 15];                                                             \
+            h[(OFF) + r] = relu1(x);                                                                         \
+            if (TRAIN && !kAblateNoMask) MW[r >> 5] |= x > 0.f ? (1u << (r & 31)) : 0u;                      \
+        }                                                                                                    \
     }
-    // rgb: D/2 -> 3, sigmoid (rows 0..2 of a 32-row tile live in registers 0..2 of half 0)
-    zero_acc(acc1);
-    gemm_part<HT, 1, TRAIN>(acc1, g, pipe, p0(F_RGB), fr1, TRAIN ? a.ws_xg + s * (D / 2) + 4 * half : nullptr);
+#define NNR_MOVE_PAIR(ACC, OFF)                                                                              \
+    [&](int u) __attribute__((always_inline)) {                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) h[(OFF) + 2 * u + i] = ACC[(2 * u + i) >> 4][(2 * u + i) & 15]; \
+    }
+    auto p0 = [&](int part) { return L::fwd_panel0(part); };
+    float* const xe = TRAIN ? a.ws_xe + ss * kPosPad + 4 * half : nullptr;
+    auto xh = [&](int hidden_idx /*0..7*/) -> float* {
+        return TRAIN ? a.ws_xh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half : nullptr;
+    };
+
+    // ---- hidden 1: 63 -> D, input = posenc.  Pass A, then pass B with A's epilogue hidden under it. ----
+    init_acc(accA, L::bias_off(0));
+    gemm_part<2, HT, TRAIN>(accA, e, pipe, p0(F_L1A), xe);
+    init_acc(accB, L::bias_off(0) + L::Dh);
+    clear_mask(mwA);
+    gemm_part<2, HT, false, NP, NP / 8, 0>(accB, e, pipe, p0(F_L1B), nullptr, NNR_RELU_PAIR(accA, 0, mwA));
+    store_mask(mwA, 0, 0);
+    // posenc is needed again only by the skip layer: park it in LDS meanwhile
+#pragma unroll
+    for (int q = 0; q < 8; ++q) park[q * 64] = f32x4{e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]};
+    NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 3);
+    // Invariant from here on: h[0, HR) holds half A of the newest layer, accB holds its half B still to be finished.
+
+    // one D -> D ReLU layer (state_dict index `li`, previous layer index li-1), packed at panel pa
+    auto dense_layer = [&](int li, int pa, float* stash) __attribute__((always_inline)) {
+        init_acc(accA, L::bias_off(li));
+        clear_mask(mwB);
+        // pass A: the first half of the k-groups only needs h[0,HR); the previous layer's half B is finished meanwhile
+        gemm_part<DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, pa, stash, NNR_RELU_PAIR(accB, HR, mwB));
+        store_mask(mwB, li - 1, 1);
+        init_acc(accB, L::bias_off(li) + L::Dh);
+        clear_mask(mwA);
+        // pass B: half A of the new layer replaces h[0,HR) in place, one k-group behind the reads
+        gemm_part<DT, HT, false, NP, 2, 1>(accB, h, pipe, pa + PP, nullptr, NNR_RELU_PAIR(accA, 0, mwA));
+        store_mask(mwA, li, 0);
+    };
+    // hidden 2..4
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) dense_layer(1 + l, p0(F_L2A) + 2 * PP * l, xh(l));
+    NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 4);
+    // hidden 5: [h4 ; e] -> D   (skip connection, input order [h, posenc]: model/official_nerf.py:63)
+    init_acc(accA, L::bias_off(4));
+    clear_mask(mwB);
+    gemm_part<DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, p0(F_L5HA), xh(3), NNR_RELU_PAIR(accB, HR, mwB));
+    store_mask(mwB, 3, 1);
+    float e5[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4 v = park[q * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e5[4 * q + i] = v[i];
+    }
+    gemm_part<2, HT>(accA, e5, pipe, p0(F_L5EA));
+    init_acc(accB, L::bias_off(4) + L::Dh);
+    clear_mask(mwA);
+    gemm_part<DT, HT, false, NP, 2, 1>(accB, h, pipe, p0(F_L5HB), nullptr, NNR_RELU_PAIR(accA, 0, mwA));
+    gemm_part<2, HT>(accB, e5, pipe, p0(F_L5EB));
+    store_mask(mwA, 4, 0);
+    NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 5);
+    // hidden 6..8
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) dense_layer(5 + l, p0(F_L6A) + 2 * PP * l, xh(4 + l));
+    NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 6);
+
+    // feature: D -> D, no activation.  Pass A finishes hidden 8.  Under pass B the density head -- a per-lane dot product
+    // of h8 with the density row (a 1-row GEMM is not MFMA work) -- consumes each register pair of h8 just before
+    // feature half A overwrites it.
+    init_acc(accA, L::bias_off(9));
+    clear_mask(mwB);
+    gemm_part<DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, p0(F_FEATA), xh(7), NNR_RELU_PAIR(accB, HR, mwB));
+    store_mask(mwB, 7, 1);
+    init_acc(accB, L::bias_off(9) + L::Dh);
+    float sg0 = 0.f, sg1 = 0.f;
+    {
+        const float* wsg = bias + L::wsig_off + half * (16 * DT);
+        auto sigma_then_move = [&](int u) __attribute__((always_inline)) {
+            const f32x2 w2 = *reinterpret_cast<const f32x2*>(wsg + 2 * u);
+            sg0 = fmaf(w2[0], h[2 * u], sg0);
+            sg1 = fmaf(w2[1], h[2 * u + 1], sg1);
+            if (u < NP) {
+                h[2 * u] = accA[(2 * u) >> 4][(2 * u) & 15];
+                h[2 * u + 1] = accA[(2 * u + 1) >> 4][(2 * u + 1) & 15];
+            }
+        };
+        gemm_part<DT, HT, false, 2 * NP, 2, 1>(accB, h, pipe, p0(F_FEATB), nullptr, sigma_then_move);
+    }
+    const float sg = sg0 + sg1;
+    const float sigma_raw = sg + __shfl_xor(sg, 32, 64) + bias[L::bias_off(8)];
+    NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 7);
+
+    // colour hidden: [feat ; gamma_4(v)] -> D/2, ReLU   (input order [feat, dir_enc]: model/official_nerf.py:89)
+    float* const xf = TRAIN ? a.ws_xf + ss * (D + kDirPad) + 4 * half : nullptr;
+    init_acc(accA, L::bias_off(10));
+    gemm_part<DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, p0(F_RGBH_F), xf, NNR_MOVE_PAIR(accB, HR));
+    float dir2[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = park[(8 + q) * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dir2[4 * q + i] = v[i];
+    }
+    gemm_part<1, HT, TRAIN>(accA, dir2, pipe, p0(F_RGBH_D), TRAIN ? xf + D : nullptr);
+    NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 8);
+    clear_mask(mwA);
+#pragma unroll
+    for (int u = 0; u < NP; ++u) NNR_RELU_PAIR(accA, 0, mwA)(u);   // g = h[0, HR)
+    store_mask(mwA, 8, 0);
+    if (TRAIN) {
+        float* xg = a.ws_xg + ss * (D / 2) + 4 * half;
+#pragma unroll
+        for (int q = 0; q < HR / 4; ++q)
+            *reinterpret_cast<f32x4*>(xg + 8 * q) = f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
+    }
+    // rgb head: 3 per-lane dot products over the lane's half of g, halves combined by one shuffle, then sigmoid
+    float rgbv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* wc = bias + L::wrgb_off + (2 * c + half) * HR;
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < HR / 4; ++q) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wc + 4 * q);
+            acc0 = fmaf(w4[0], h[4 * q], acc0);
+            acc1 = fmaf(w4[1], h[4 * q + 1], acc1);
+            acc0 = fmaf(w4[2], h[4 * q + 2], acc0);
+            acc1 = fmaf(w4[3], h[4 * q + 3], acc1);
+        }
+        const float part = acc0 + acc1;
+        rgbv[c] = part + __shfl_xor(part, 32, 64);
+    }
     if (half == 0 && s < a.S) {
         const float* b = bias + L::bias_off(11);
         f32x4 o;
-        o[0] = sigmoid_ref(acc1[0][0] + b[0]);
-        o[1] = sigmoid_ref(acc1[0][1] + b[1]);
-        o[2] = sigmoid_ref(acc1[0][2] + b[2]);
+        o[0] = sigmoid_ref(rgbv[0] + b[0]);
+        o[1] = sigmoid_ref(rgbv[1] + b[1]);
+        o[2] = sigmoid_ref(rgbv[2] + b[2]);
         o[3] = sigma_raw;
         *reinterpret_cast<f32x4*>(a.ws_out4 + 4 * s) = o;
     }
+    NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 9);
+#undef NNR_RELU_PAIR
+#undef NNR_MOVE_PAIR
 }
+
+#ifdef NNR_TIMELINE
+extern "C" int nnr_timeline_fwd(unsigned long long* host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_fwd), 32 * sizeof(unsigned long long));
+}
+#endif
 
 template <int D>
 static hipError_t launch(const MlpFwdArgs& a, bool train, hipStream_t st) {

@@ -47,21 +47,35 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
             const int k = k0 + i;
             float x = 0.f;
             if (live && m < pd.m_real && k < pd.k_real)
-                x = pd.transpose ? W[(int64_t)k * pd.ld + pd.off + m] : W[(int64_t)m * pd.ld + pd.off + k];
+                x = pd.transpose ? W[(int64_t)(pd.koff + k) * pd.ld + pd.moff + m] : W[(int64_t)(pd.moff + m) * pd.ld + pd.koff + k];
             v[i] = x;
         }
         reinterpret_cast<f32x4*>(a.packed)[gid] = v;
     } else {
-        const int64_t bi = (gid - n_frag4);  // one thread per bias float here (tail threads)
-        int64_t o = 0;
+        const int64_t bi = (gid - n_frag4);  // one thread per float of the bias / head-table tail
+        if (bi < L::bias_floats) {
+            int64_t o = 0;
 #pragma unroll
-        for (int l = 0; l < 12; ++l) {
-            const int pad = L::bias_pad(l);
-            if (bi >= o && bi < o + pad) {
-                const int j = (int)(bi - o);
-                a.packed[L::bias_base + bi] = j < L::bias_real(l) ? a.b[l][j] : 0.f;
+            for (int l = 0; l < 12; ++l) {
+                const int pad = L::bias_pad(l);
+                if (bi >= o && bi < o + pad) {
+                    const int j = (int)(bi - o);
+                    a.packed[L::bias_base + bi] = j < L::bias_real(l) ? a.b[l][j] : 0.f;
+                }
+                o += pad;
             }
-            o += pad;
+        } else if (bi < L::table_floats) {
+            // head tables in register order: value for (half h, register r) belongs to feature 32t + (rho&3) + 8(rho>>2) + 4h
+            const int t = (int)(bi - L::bias_floats);
+            const int nsig = 2 * 16 * L::DT, nrow = 2 * 16 * L::HT;
+            int row, rem, nreg;
+            const float* W;
+            int ld;
+            if (t < nsig) { row = 0; rem = t; nreg = 16 * L::DT; W = a.w[8]; ld = D; }
+            else { row = (t - nsig) / nrow; rem = (t - nsig) % nrow; nreg = 16 * L::HT; W = a.w[11]; ld = D / 2; }
+            const int h = rem / nreg, r = rem % nreg;
+            const int f = 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h;
+            a.packed[L::head_base + t] = W[(int64_t)row * ld + f];
         }
     }
 }
@@ -69,7 +83,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
 template <int D>
 static hipError_t launch(const PackArgs& a, hipStream_t st) {
     using L = Layout<D>;
-    const int64_t threads = L::bias_base / 4 + (L::packed_floats - L::bias_base);
+    const int64_t threads = L::bias_base / 4 + L::table_floats;
     dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     hipLaunchKernelGGL((pack_kernel<D>), grid, block, 0, st, a);
     return hipGetLastError();

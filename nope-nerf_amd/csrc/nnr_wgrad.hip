@@ -4,16 +4,17 @@
 //
 // Shape of the problem: outputs are tiny (2.4 MB), the reduction dimension is every sample of the step.  So this is a
 // split-K kernel: a *wave job* owns a (32*MI) x (32*NI) tile of one dW and a contiguous range of samples, keeps the
-// tile in MI*NI MFMA accumulators (256 registers for 4x4) for the whole range and flushes once with float atomics.
+// tile in MI*NI MFMA accumulators (256 registers for 4x4) for the whole range and writes it once to its own partial
+// slot; wgrad_reduce_kernel then adds the slots of each tile into dW.
 // Both operands are read straight from the (sample, feature) row-major stashes: with interleaved sub-tiles
 // (row = MI*m + i) one MI-wide and one NI-wide vector load per lane feed MI*NI MFMAs; the four jobs of a 256x256 layer
 // that share a sample range sit in one workgroup so their re-reads hit L1/L2.  The job table comes from the host plan.
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
-
 #include "nnr_device.h"
 #include "nnr_kernels.h"
 
 namespace nnr {
+
+NNR_TL_DECL(tl_wgrad)
 
 template <int W>
 struct Vec { float v[W]; };
@@ -27,11 +28,7 @@ template <int W>
 __device__ __forceinline__ Vec<W> load_vec(const float* p) {
     Vec<W> r;
     if constexpr (W == 4) {
-#ifdef NNR_NT_WGRAD
-        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-#else
         const f32x4 t = *reinterpret_cast<const f32x4*>(p);
-#endif
         r.v[0] = t[0]; r.v[1] = t[1]; r.v[2] = t[2]; r.v[3] = t[3];
     } else if constexpr (W == 2) {
         const f32x2 t = *reinterpret_cast<const f32x2*>(p);
@@ -44,8 +41,8 @@ __device__ __forceinline__ Vec<W> load_vec(const float* p) {
 
 constexpr int kU = 4;  // k-steps (pairs of samples) per pipeline stage
 
-template <int MI, int NI>
-__device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a, int lane) {
+template <int MI, int NI, bool BIAS>
+__device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a, int lane, int ji) {
     const int half = lane >> 5, m = lane & 31;
     const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
     const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
@@ -83,10 +80,11 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = mfma32(d[u].v[i], x[u].v[j], acc[i][j]);
-                bsum[i] += d[u].v[i];
+                if constexpr (BIAS) bsum[i] += d[u].v[i];
             }
         }
     };
+    NNR_STAMP(tl_wgrad, 0);
     load_stage(dA, xA, jb.k0);
     for (int64_t k = jb.k0; k < jb.k1; k += 4 * kU) {
         // sched_barrier(0): nothing moves across.  Without it the scheduler sinks each load down to its first use
@@ -101,33 +99,40 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // flush: D[row m'][col n] of sub-tile (i,j) -> dW[row0 + MI*m' + i][wcol0 + NI*n + j]
+    NNR_STAMP(tl_wgrad, 1);
+#ifdef NNR_TIMELINE
+    if (blockIdx.x == 700 / 8 && threadIdx.x == 0) { tl_wgrad[4] = (unsigned long long)(jb.k1 - jb.k0); tl_wgrad[5] = MI * 8 + NI; }
+#endif
+    // flush: D[row m'][col n] of sub-tile (i,j) -> slot[(MI*m' + i) * 32*NI + NI*n + j].  One NI-wide store per (i, r):
+    // 32 lanes cover a whole tile row (32*NI contiguous floats).  Rows / columns outside the valid range hold garbage
+    // (see load_vec); the reduction never reads them.
 #ifdef NNR_ABLATE_NO_FLUSH
     return;
 #endif
-    float* gw = a.gw[jb.layer];
+    float* slot = a.slots + (int64_t)ji * kSlotFloats;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int colw = jb.wcol0 + NI * m + j;
-            const bool cok = (NI * m + j < jb.x_valid) && colw < jb.cols_real;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int mr = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int row = jb.row0 + MI * mr + i;
-                if (cok && MI * mr + i < jb.d_valid && row < jb.rows_real) unsafeAtomicAdd(gw + (int64_t)row * jb.ldw + colw, acc[i][j][r]);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* dst = slot + (MI * mr + i) * (32 * NI) + NI * m;
+            if constexpr (NI == 4) *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+            else if constexpr (NI == 2) *reinterpret_cast<f32x2*>(dst) = f32x2{acc[i][0][r], acc[i][1][r]};
+            else *dst = acc[i][0][r];
         }
-    if (jb.bias) {
-        float* gb = a.gb[jb.layer];
+    if constexpr (BIAS) {   // this half-wave's share of sum_s Dlt[s][row0 + MI*m + i]
+        float* dst = slot + kSlotTile + half * (32 * MI) + MI * m;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int row = jb.row0 + MI * m + i;
-            if (dok && row < jb.rows_real) unsafeAtomicAdd(gb + row, bsum[i]);
-        }
+        for (int i = 0; i < MI; ++i) dst[i] = bsum[i];
     }
+    NNR_STAMP(tl_wgrad, 2);
 }
+
+#ifdef NNR_TIMELINE
+extern "C" int nnr_timeline_wgrad(unsigned long long* host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_wgrad), 32 * sizeof(unsigned long long));
+}
+#endif
 
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63;
@@ -135,21 +140,59 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     if (ji >= a.n_jobs) return;
     const WgradJob jb = a.jobs[ji];
     if (jb.layer < 0) return;
-    const int key = __builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI);
+    // bias reduction (MI VALU adds per k-step inside the MFMA stream) only in the jobs that own it
+    const int key = __builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI + (jb.bias ? 64 : 0));
+#define NNR_WGRAD_CASE(MI_, NI_)                                                \
+    case MI_ * 8 + NI_: wgrad_job<MI_, NI_, false>(jb, a, lane, ji); break;      \
+    case MI_ * 8 + NI_ + 64: wgrad_job<MI_, NI_, true>(jb, a, lane, ji); break;
     switch (key) {
-        case 4 * 8 + 4: wgrad_job<4, 4>(jb, a, lane); break;
-        case 4 * 8 + 2: wgrad_job<4, 2>(jb, a, lane); break;
-        case 4 * 8 + 1: wgrad_job<4, 1>(jb, a, lane); break;
-        case 2 * 8 + 4: wgrad_job<2, 4>(jb, a, lane); break;
-        case 2 * 8 + 1: wgrad_job<2, 1>(jb, a, lane); break;
-        case 1 * 8 + 4: wgrad_job<1, 4>(jb, a, lane); break;
-        case 1 * 8 + 2: wgrad_job<1, 2>(jb, a, lane); break;
+        NNR_WGRAD_CASE(4, 4)
+        NNR_WGRAD_CASE(4, 2)
+        NNR_WGRAD_CASE(4, 1)
+        NNR_WGRAD_CASE(2, 4)
+        NNR_WGRAD_CASE(2, 1)
+        NNR_WGRAD_CASE(1, 4)
+        NNR_WGRAD_CASE(1, 2)
         default: break;
+    }
+#undef NNR_WGRAD_CASE
+}
+
+// dW[tile] += sum over the tile's splits of their partial slots; d(bias) likewise.  Every weight belongs to exactly one
+// tile, so plain read-modify-write.  Blocks of jobs that are not split 0 of their tile exit at once.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
+    const int ji = blockIdx.x >> 4;   // 16 blocks x 256 threads x one float4 = a 128 x 128 tile
+    const WgradJob jb = a.jobs[ji];
+    if (jb.layer < 0 || jb.split != 0) return;
+    const int t = (blockIdx.x & 15) * 256 + threadIdx.x;
+    const int pitch = 32 * jb.NI, f4_per_row = 8 * jb.NI;
+    const int row = t / f4_per_row, c0 = 4 * (t - row * f4_per_row);
+    if (row < 32 * jb.MI && row < jb.d_valid && jb.row0 + row < jb.rows_real) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        const float* src = a.slots + (int64_t)ji * kSlotFloats + row * pitch + c0;
+        for (int s = 0; s < jb.n_splits; ++s) sum += *reinterpret_cast<const f32x4*>(src + (int64_t)s * jb.split_stride * kSlotFloats);
+        float* dst = a.gw[jb.layer] + (int64_t)(jb.row0 + row) * jb.ldw + jb.wcol0 + c0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c0 + e < jb.x_valid && jb.wcol0 + c0 + e < jb.cols_real) dst[e] += sum[e];
+    }
+    if (jb.bias && (blockIdx.x & 15) == 0 && threadIdx.x < 32 * jb.MI) {
+        const int r = threadIdx.x;
+        if (r < jb.d_valid && jb.row0 + r < jb.rows_real) {
+            float sum = 0.f;
+            const float* src = a.slots + (int64_t)ji * kSlotFloats + kSlotTile + r;
+            for (int s = 0; s < jb.n_splits; ++s) {
+                const float* p = src + (int64_t)s * jb.split_stride * kSlotFloats;
+                sum += p[0] + p[32 * jb.MI];
+            }
+            a.gb[jb.layer][jb.row0 + r] += sum;
+        }
     }
 }
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(wgrad_kernel, dim3((a.n_jobs + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_jobs * 16), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

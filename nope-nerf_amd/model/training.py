@@ -204,7 +204,7 @@ class Trainer(object):
                 ys = nearest_source_index(torch.div(ray_idx, w_img, rounding_mode='floor'), h_img, hd)
                 xs = nearest_source_index(ray_idx % w_img, w_img, wd)
                 d_all = depth_input[0, 0][ys, xs]
-                m_total = float((torch.isfinite(d_all) & (d_all != 0)).sum())
+                m_total = (torch.isfinite(d_all) & (d_all != 0)).sum().float()   # stays on the device: no sync
         fused = (out is not None and rgb.is_cuda and self.loss.depth_loss_type == 'l1' and 'dist_dense' in out)
         if not fused and world == 1:
             loss_dict = self.loss(rgb, rgb_gt, depth_pred, depth_gt, **kwargs)
@@ -229,7 +229,8 @@ class Trainer(object):
                                           "(losses.py:42-46); it needs an all-gather and is not sharded yet")
             diff = rgb - rgb_gt
             lrgb = (diff.abs().sum() if kwargs['rgb_loss_type'] == 'l1' else (diff * diff).sum()) / float(n_total)
-            ldep = (depth_pred - depth_gt).abs().sum() / float(max(m_total, 1.0)) if w['depth_weight'] != 0.0 else zero
+            ldep = (depth_pred - depth_gt).abs().sum() / torch.clamp(torch.as_tensor(m_total, device=rgb.device), min=1.0) \
+                if w['depth_weight'] != 0.0 else zero
             l2 = (diff * diff).sum() / float(3 * n_total)
             lmain = w['rgb_weight'] * lrgb + w['depth_weight'] * ldep
         loss_dict.update(loss_rgb=lrgb, loss_depth=ldep, l2_mean=l2, loss=lmain if aux is None else lmain + aux)

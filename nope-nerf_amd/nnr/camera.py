@@ -149,8 +149,12 @@ class _RenderLoss(torch.autograd.Function):
         f = dict(dtype=torch.float32, device=dev)
         out = torch.empty(5, **f)
         g_rgb, g_dist, g_dgt = torch.empty(R, 3, **f), torch.empty(R, **f), torch.empty(R, **f)
+        m_dev = None
+        if torch.is_tensor(m_total):                      # device scalar (data-parallel global count): no host sync
+            m_dev = m_total.detach().float().reshape(1).contiguous()
+            m_total = -1.0
         L.check(L.load().nnr_render_loss(L.ptr(a), L.ptr(b), L.ptr(c), L.ptr(d), L.ptr(m), R, float(r_total), float(m_total),
-                                         float(w_rgb), float(w_depth), int(rgb_l2), int(ndc), int(detach_gt), L.ptr(out),
+                                         float(w_rgb), float(w_depth), int(rgb_l2), int(ndc), int(detach_gt), L.ptr(m_dev), L.ptr(out),
                                          L.ptr(g_rgb), L.ptr(g_dist), L.ptr(g_dgt), _st()), "nnr_render_loss")
         ctx.save_for_backward(g_rgb, g_dist, g_dgt)
         ctx.shapes = (rgb.shape, dist.shape, d_gt.shape)

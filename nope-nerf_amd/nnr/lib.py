@@ -39,7 +39,8 @@ class Params(C.Structure):
 
 class WgradJob(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("layer", "MI", "NI", "d_plane", "d_col0", "d_valid", "x_plane", "x_col0",
-                                         "x_valid", "row0", "wcol0", "rows_real", "cols_real", "ldw", "k0", "k1", "bias")]
+                                         "x_valid", "row0", "wcol0", "rows_real", "cols_real", "ldw", "k0", "k1", "bias",
+                                         "split", "n_splits", "split_stride")]
 
 
 _lib = None
@@ -85,7 +86,7 @@ def load():
     lib.nnr_depth_gather_fwd.argtypes = [vp, vp, vp] + [i32] * 5 + [vp]
     lib.nnr_depth_gather_bwd.argtypes = [vp, vp, vp] + [i32] * 5 + [vp]
     lib.nnr_pixels_from_index.argtypes = [vp, vp, i32, i32, i32, vp]
-    lib.nnr_render_loss.argtypes = [vp] * 5 + [i32] + [f32] * 4 + [i32] * 3 + [vp] * 5
+    lib.nnr_render_loss.argtypes = [vp] * 5 + [i32] + [f32] * 4 + [i32] * 3 + [vp] * 6
     for n in EXPORTS:
         if not hasattr(lib, n):
             raise RuntimeError(f"libnnr.so does not export {n}")

@@ -43,15 +43,17 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], loss_dict: Optiona
     pieces += [loss_dict[k].detach().reshape(1).float() for k in keys]
     flat = torch.cat(pieces)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    off = 0
+    views, off = [], 0
     for p in params:
         n = p.numel()
-        g = flat[off:off + n].view_as(p)
-        if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
+        views.append(flat[off:off + n].view_as(p))
         off += n
+    have = [i for i, p in enumerate(params) if p.grad is not None]
+    if have:
+        torch._foreach_copy_([params[i].grad for i in have], [views[i] for i in have])   # one multi-tensor launch
+    for i, p in enumerate(params):
+        if p.grad is None:
+            p.grad = views[i].clone()
     for k in keys:
         # keep the autograd-free logged value; 'loss' itself is no longer needed for backward at this point
         loss_dict[k] = flat[off].clone()

@@ -10,21 +10,31 @@ LAYERS = ("layers0.0", "layers0.2", "layers0.4", "layers0.6", "layers1.0", "laye
 
 
 def fwd_parts(D):
-    DT, HT = D // 32, D // 64
-    return [  # (layer, transpose, KT, MT, m_real, k_real, off)
-        (0, 0, 2, DT, D, 63, 0), (1, 0, DT, DT, D, D, 0), (2, 0, DT, DT, D, D, 0), (3, 0, DT, DT, D, D, 0),
-        (4, 0, DT, DT, D, D, 0), (4, 0, 2, DT, D, 63, D), (5, 0, DT, DT, D, D, 0), (6, 0, DT, DT, D, D, 0),
-        (7, 0, DT, DT, D, D, 0), (8, 0, DT, 1, 1, D, 0), (9, 0, DT, DT, D, D, 0), (10, 0, DT, HT, D // 2, D, 0),
-        (10, 0, 1, HT, D // 2, 27, D), (11, 0, HT, 1, 3, D // 2, 0)]
+    """(layer, transpose, KT, MT, m_real, k_real, moff, koff) in stream order -- mirrors Layout<D>::fwd."""
+    DT, HT, Dh = D // 32, D // 64, D // 2
+    parts = [(0, 0, 2, HT, Dh, 63, h * Dh, 0) for h in (0, 1)]
+    for l in (1, 2, 3):
+        parts += [(l, 0, DT, HT, Dh, D, h * Dh, 0) for h in (0, 1)]
+    for h in (0, 1):
+        parts += [(4, 0, DT, HT, Dh, D, h * Dh, 0), (4, 0, 2, HT, Dh, 63, h * Dh, D)]
+    for l in (5, 6, 7):
+        parts += [(l, 0, DT, HT, Dh, D, h * Dh, 0) for h in (0, 1)]
+    parts += [(9, 0, DT, HT, Dh, D, h * Dh, 0) for h in (0, 1)]
+    parts += [(10, 0, DT, HT, Dh, D, 0, 0), (10, 0, 1, HT, Dh, 27, 0, D)]
+    return parts
 
 
 def bwd_parts(D):
-    DT, HT = D // 32, D // 64
-    return [
-        (11, 1, 1, HT, D // 2, 3, 0), (10, 1, HT, DT, D, D // 2, 0), (10, 1, HT, 1, 27, D // 2, D), (9, 1, DT, DT, D, D, 0),
-        (8, 1, 1, DT, D, 1, 0),
-        (7, 1, DT, DT, D, D, 0), (6, 1, DT, DT, D, D, 0), (5, 1, DT, DT, D, D, 0), (4, 1, DT, 2, 63, D, D), (4, 1, DT, DT, D, D, 0),
-        (3, 1, DT, DT, D, D, 0), (2, 1, DT, DT, D, D, 0), (1, 1, DT, DT, D, D, 0), (0, 1, DT, 2, 63, D, 0)]
+    DT, HT, Dh = D // 32, D // 64, D // 2
+    parts = [(10, 1, HT, HT, Dh, Dh, h * Dh, 0) for h in (0, 1)] + [(10, 1, HT, 1, 27, Dh, D, 0)]
+    parts += [(9, 1, DT, HT, Dh, D, h * Dh, 0) for h in (0, 1)]
+    for l in (7, 6, 5):
+        parts += [(l, 1, DT, HT, Dh, D, h * Dh, 0) for h in (0, 1)]
+    parts += [(4, 1, DT, 2, 63, D, D, 0)] + [(4, 1, DT, HT, Dh, D, h * Dh, 0) for h in (0, 1)]
+    for l in (3, 2, 1):
+        parts += [(l, 1, DT, HT, Dh, D, h * Dh, 0) for h in (0, 1)]
+    parts += [(0, 1, DT, 2, 63, D, 0, 0)]
+    return parts
 
 
 def bias_pads(D):
@@ -33,12 +43,12 @@ def bias_pads(D):
 
 def part_matrix(W, part):
     """Dense zero-padded A[32*MT][32*KT] of a part."""
-    layer, tr, KT, MT, m_real, k_real, off = part
+    layer, tr, KT, MT, m_real, k_real, moff, koff = part
     A = np.zeros((32 * MT, 32 * KT), dtype=np.float32)
     if tr:
-        A[:m_real, :k_real] = W[:k_real, off:off + m_real].T
+        A[:m_real, :k_real] = W[koff:koff + k_real, moff:moff + m_real].T
     else:
-        A[:m_real, :k_real] = W[:m_real, off:off + k_real]
+        A[:m_real, :k_real] = W[moff:moff + m_real, koff:koff + k_real]
     return A
 
 
@@ -71,6 +81,17 @@ def part_frags(packed_part, KT, MT):
     return out
 
 
+def head_tables(weights, D):
+    """Density and rgb rows in register order [half][r] (feature = frag_feature(r, half))."""
+    DT, HT = D // 32, D // 64
+    out = []
+    for W, rows, nreg in ((weights[8], 1, 16 * DT), (weights[11], 3, 16 * HT)):
+        for row in range(rows):
+            for h in (0, 1):
+                out.append(np.array([W[row, frag_feature(r, h)] for r in range(nreg)], dtype=np.float32))
+    return np.concatenate(out)
+
+
 def pack_all(weights, biases, D):
     """weights/biases: lists of 12 numpy arrays in state_dict order -> the packed buffer nnr_pack_weights produces."""
     chunks = []
@@ -80,6 +101,7 @@ def pack_all(weights, biases, D):
         v = np.zeros(pad, dtype=np.float32)
         v[:b.size] = b
         chunks.append(v)
+    chunks.append(head_tables(weights, D))
     return np.concatenate(chunks)
 
 

@@ -20,22 +20,30 @@ def rand_weights(D, seed=0):
     return [rng.standard_normal(s).astype(np.float32) for s in shapes], [rng.standard_normal(s[0]).astype(np.float32) for s in shapes]
 
 
+def _layer(W_l, parts, idxs, x_regs):
+    """Emulate the passes `idxs` of one layer on input registers; returns the dense (rows, 32) result."""
+    outs = []
+    for i in idxs:
+        part = parts[i]
+        pk = lr.pack_part(lr.part_matrix(W_l, part), part[2], part[3])
+        acc = lr.gemm_part_emulated(pk, x_regs, part[2], part[3])
+        outs.append(lr.from_regs(acc.reshape(-1, 64))[:part[4]])
+    return np.concatenate(outs)
+
+
 def test_chained_layers_in_register_layout():
-    """Two chained layers computed with emulated MFMAs on packed fragments == plain matmuls; the output registers of
-    one layer are directly the B operands of the next (no transpose)."""
+    """Two chained layers, each as its two half-output passes, computed with emulated MFMAs on packed fragments == plain
+    matmuls; the output registers of one layer are directly the B operands of the next (no transpose)."""
     D = 128
     W, _ = rand_weights(D)
     rng = np.random.default_rng(1)
     e = np.zeros((64, 32), dtype=np.float32)
     e[:63] = rng.standard_normal((63, 32))
     parts = lr.fwd_parts(D)
-    p1 = lr.pack_part(lr.part_matrix(W[0], parts[0]), parts[0][2], parts[0][3])
-    acc = lr.gemm_part_emulated(p1, lr.to_regs(e), parts[0][2], parts[0][3])
-    h1 = np.maximum(acc.reshape(-1, 64), 0)                       # registers of hidden 1 (16*DT, 64)
-    np.testing.assert_allclose(lr.from_regs(h1), np.maximum(W[0] @ e[:63], 0), rtol=1e-5, atol=1e-5)
-    p2 = lr.pack_part(lr.part_matrix(W[1], parts[1]), parts[1][2], parts[1][3])
-    acc2 = lr.gemm_part_emulated(p2, h1, parts[1][2], parts[1][3])
-    np.testing.assert_allclose(lr.from_regs(acc2.reshape(-1, 64)), W[1] @ np.maximum(W[0] @ e[:63], 0), rtol=1e-4, atol=1e-4)
+    h1 = np.maximum(_layer(W[0], parts, (0, 1), lr.to_regs(e)), 0)
+    np.testing.assert_allclose(h1, np.maximum(W[0] @ e[:63], 0), rtol=1e-5, atol=1e-5)
+    h2 = _layer(W[1], parts, (2, 3), lr.to_regs(h1))
+    np.testing.assert_allclose(h2, W[1] @ np.maximum(W[0] @ e[:63], 0), rtol=1e-4, atol=1e-4)
 
 
 def test_transposed_parts_and_skip_layer():
@@ -43,19 +51,32 @@ def test_transposed_parts_and_skip_layer():
     W, _ = rand_weights(D)
     rng = np.random.default_rng(2)
     d5 = rng.standard_normal((D, 32)).astype(np.float32)
+    bp = lr.bwd_parts(D)
+    idx = [i for i, p in enumerate(bp) if p[0] == 4]              # hidden 5 transposed: posenc rows, then the two h4 halves
+    assert [bp[i][6] for i in idx] == [D, 0, D // 2]
     ref = W[4].T @ d5
-    for idx, rows in ((9, slice(0, D)), (8, slice(D, D + 63))):  # hidden 5 transposed: rows [h4 (D)] and [posenc (63)]
-        part = lr.bwd_parts(D)[idx]
-        pk = lr.pack_part(lr.part_matrix(W[4], part), part[2], part[3])
-        acc = lr.gemm_part_emulated(pk, lr.to_regs(d5), part[2], part[3])
-        full = lr.from_regs(acc.reshape(-1, 64))
-        n = rows.stop - rows.start
-        np.testing.assert_allclose(full[:n], ref[rows], rtol=1e-4, atol=1e-4)
-        assert np.all(full[n:] == 0)
-    part = lr.fwd_parts(D)[5]                                      # skip layer, posenc part: columns D.. of layers1.0
-    A = lr.part_matrix(W[4], part)
-    np.testing.assert_array_equal(A[:, :63], W[4][:, D:])
+    np.testing.assert_allclose(_layer(W[4], bp, idx[1:], lr.to_regs(d5)), ref[:D], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(_layer(W[4], bp, idx[:1], lr.to_regs(d5)), ref[D:], rtol=1e-4, atol=1e-4)
+    fp = lr.fwd_parts(D)
+    e_parts = [p for p in fp if p[0] == 4 and p[7] == D]          # skip layer, posenc columns D.. of layers1.0
+    assert len(e_parts) == 2
+    A = lr.part_matrix(W[4], e_parts[1])
+    np.testing.assert_array_equal(A[:D // 2, :63], W[4][D // 2:, D:])
     assert np.all(A[:, 63] == 0)
+
+
+def test_head_tables_are_register_ordered_rows():
+    D = 256
+    W, _ = rand_weights(D)
+    t = lr.head_tables(W, D)
+    h8 = np.random.default_rng(3).standard_normal((D, 32)).astype(np.float32)
+    regs = lr.to_regs(h8)                                         # (128, 64): lane = 32*half + sample
+    wsig = t[:2 * 128].reshape(2, 128)
+    dot = np.zeros(64)
+    for lane in range(64):
+        dot[lane] = np.dot(wsig[lane >> 5], regs[:, lane])
+    np.testing.assert_allclose(dot[:32] + dot[32:], (W[8] @ h8)[0], rtol=1e-4, atol=1e-4)
+    assert t.size == 2 * 128 + 3 * 2 * 64
 
 
 def test_library_exports_every_declared_symbol():
@@ -81,7 +102,8 @@ def test_sizes_and_error_codes(D):
     x_width = 64 + 8 * D + (D + 32) + D // 2
     d_width = 8 * D + D + D // 2
     expect = S_pad * (4 + 1 + 4 + 4 + 4 + x_width + d_width + 9 * 2 * (D // 64))
-    assert lib.nnr_workspace_floats(C.byref(cfg)) == expect
+    n_jobs = lib.nnr_plan_bytes(C.byref(cfg)) // C.sizeof(L.WgradJob)
+    assert lib.nnr_workspace_floats(C.byref(cfg)) == expect + n_jobs * (128 * 128 + 256)   # + one partial slot per job
     assert lib.nnr_workspace_floats(C.byref(L.make_cfg(16, 64, D))) == S_pad * 5
     assert lib.nnr_workspace_floats(C.byref(L.make_cfg(16, 64, 192))) == 0        # unsupported width
     assert lib.nnr_pack_weights(C.byref(L.make_cfg(16, 64, 192)), None, None, None) == -2
@@ -116,4 +138,12 @@ def test_wgrad_plan_covers_every_weight_once(D, R, N):
     for l in range(12):
         assert np.all(cover[l] == S_pad), (l, np.unique(cover[l]))
         assert np.all(bias_cover[l] == S_pad), l
-    assert len(plan_jobs(cfg)) % 4 == 0
+    allj = plan_jobs(cfg)
+    assert len(allj) % 4 == 0
+    for idx, j in enumerate(allj):           # the splits of a tile sit at a regular stride, split 0 first
+        if j.layer < 0:
+            continue
+        lead = idx - j.split * j.split_stride
+        for s in range(j.n_splits):
+            o = allj[lead + s * j.split_stride]
+            assert (o.layer, o.row0, o.wcol0, o.split, o.n_splits) == (j.layer, j.row0, j.wcol0, s, j.n_splits)

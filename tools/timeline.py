@@ -1,0 +1,40 @@
+"""Profiling helper: run the fused-MLP kernels with a -DNNR_TIMELINE library (NNR_LIB) and print the per-stage shader-clock
+deltas of one mid-grid wave (forward: train then inference)."""
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "nope-nerf_amd"))
+import torch
+
+import bench
+
+if __name__ == "__main__":
+    dev = torch.device("cuda", 0)
+    import model as mdl
+    from nnr import lib as nnrlib
+    cfg = bench.full_cfg(bench.R_PER_GPU)
+    torch.manual_seed(42)
+    net = mdl.OfficialStaticNerf(cfg).to(dev)
+    out = bench.kernel_roofline(net, dev, reps=2)
+    print(json.dumps(out["kernels"]))
+    handle = ctypes.CDLL(nnrlib.LIB_PATH)
+    for name in ("nnr_timeline_fwd", "nnr_timeline_dgrad", "nnr_timeline_wgrad"):
+        if not hasattr(handle, name):
+            continue
+        buf = (ctypes.c_ulonglong * 32)()
+        torch.cuda.synchronize()
+        rc = getattr(handle, name)(buf)
+        for base, tag in ((0, "train"), (16, "infer")):
+            v = [int(x) for x in buf[base:base + 16]]
+            if not any(v):
+                continue
+            if name.endswith("wgrad"):
+                print(name, "loop", v[1] - v[0], "flush", v[2] - v[1], "samples", v[4], "MI*8+NI", v[5],
+                      "cycles/16 samples (ideal %d)" % (64 * 4 * (v[5] // 8) * (v[5] % 8)), (v[1] - v[0]) / max(v[4], 1) * 16)
+                continue
+            n = max(i for i, x in enumerate(v) if x) + 1
+            print(name, tag, "rc", rc, "total", v[n - 1] - v[0], "deltas", [v[i + 1] - v[i] for i in range(n - 1)])
