@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -59,7 +60,7 @@ std::vector<Unit> wgrad_units(int D) {
     auto add = [&](int layer, int MI, int NI, int dpl, int dcol, int dvalid, int xpl, int xcol, int xvalid, int row0, int wcol0,
                    int rows_real, int cols_real, int ldw, int bias) {
         Unit x{};
-        x.j = WgradJob{layer, MI, NI, dpl, dcol, dvalid, xpl, xcol, xvalid, row0, wcol0, rows_real, cols_real, ldw, 0, 0, bias, 0, 1, 0};
+        x.j = WgradJob{layer, MI, NI, dpl, dcol, dvalid, xpl, xcol, xvalid, row0, wcol0, rows_real, cols_real, ldw, 0, 0, bias, 0, -1, 0};
         x.group = group;
         u.push_back(x);
     };
@@ -67,7 +68,8 @@ std::vector<Unit> wgrad_units(int D) {
     auto dxd = [&](int layer, int dpl, int xpl, int ldw, int cols_real) {
         for (int a = 0; a < nb; ++a)
             for (int b = 0; b < nb; ++b)
-                add(layer, 4, 4, dpl, 128 * a, D - 128 * a, xpl, 128 * b, D - 128 * b, 128 * a, 128 * b, D, cols_real, ldw, b == 0);
+                add(layer, 4, 4, dpl, 128 * a, D - 128 * a, xpl, 128 * b, D - 128 * b, 128 * a, 128 * b, D, cols_real, ldw,
+                    nb == 2 ? 2 + b : 1);   // the two tiles of a row block share d(bias): even / odd sample pairs
         ++group;
     };
     // posenc-input parts: hidden 1 (param 0) and the e-part of hidden 5 (param 4, columns D..D+62)
@@ -101,61 +103,113 @@ std::vector<Unit> wgrad_units(int D) {
     return u;
 }
 
-constexpr int kTargetWaves = 1024;  // 256 CUs x 4 SIMDs, one 256-accumulator wave each
-constexpr int kMaxBlocks = 248;     // every workgroup must be resident at once (1 per CU): a 257th would run as a second round
-constexpr int kGranule = 16;        // samples per loop iteration of the wgrad kernel (two stages of kU = 4 sample pairs)
+constexpr int kMaxBlocks = 256;   // one 4-wave workgroup per CU: the kernel needs the whole register file, and every
+                                  // workgroup must be resident at once (a 257th would run as a second round)
+constexpr int kGranule = 16;      // samples per loop iteration of the wgrad kernel (two stages of kU = 4 sample pairs)
+constexpr int kMinGranulesPerBlock = 64;  // small problems use fewer workgroups (each job costs a 64 KB slot + a flush)
 
-std::vector<WgradJob> build_plan_for(const nnr_cfg* c, int target_waves) {
+struct Plan {
+    std::vector<WgradJob> jobs;        // grouped by wave: wave w runs jobs [wave_first[w], wave_first[w+1])
+    std::vector<int32_t> wave_first;   // n_waves + 1 entries, n_waves a multiple of 4
+};
+
+// Balanced static schedule.  Work is measured in cost-granules (MI*NI MFMAs-per-sample-pair x 16 samples).  The D x D
+// layers (4 tiles of 4x4 that share their two operand column halves) are scheduled per WORKGROUP: the 8 layers form one
+// tape of (layer, granule) positions that is cut into equal spans, a span crossing a layer boundary becoming two segments
+// whose four tiles go to the four waves -- same sample range in one CU, so the operand re-reads hit L1/L2.  Everything else
+// (posenc parts, density, colour, rgb: 14 % of the work) is scheduled per WAVE on a second tape weighted by tile cost.
+// Each job flushes to its own slot; the splits of a tile are chained (next_split) for the reduction kernel.
+Plan build_plan(const nnr_cfg* c) {
     const WsLayout w = ws_layout(c);
-    std::vector<Unit> units = wgrad_units(c->hidden);
-    int64_t cost = 0;
-    for (auto& u : units) cost += u.j.MI * u.j.NI;
+    const std::vector<Unit> units = wgrad_units(c->hidden);
     const int64_t granules = w.S_pad / kGranule;
-    std::vector<WgradJob> jobs;
-    auto pad4 = [&]() {
-        while (jobs.size() % 4 != 0) {
-            WgradJob idle{};
-            idle.layer = -1;
-            jobs.push_back(idle);
-        }
-    };
-    size_t i = 0;
-    while (i < units.size()) {
+    std::vector<std::vector<int>> groups;   // class A: groups of four 4x4 tiles
+    std::vector<int> small;                  // class B: unit indices
+    for (size_t i = 0; i < units.size();) {
         size_t e = i;
         while (e < units.size() && units[e].group == units[i].group) ++e;
-        // every unit of a group has the same cost by construction except the colour-hidden tail; split by the first
-        int64_t q = std::max<int64_t>(1, (units[i].j.MI * units[i].j.NI * (int64_t)target_waves + cost / 2) / cost);
-        q = std::min(q, granules);
-        if ((e - i) == 4) pad4();  // a 4-tile group starts on a workgroup boundary: its same-range tiles share L1/L2
-        for (int64_t s = 0; s < q; ++s) {
-            const int64_t g0 = granules * s / q, g1 = granules * (s + 1) / q;
-            for (size_t t = i; t < e; ++t) {
-                WgradJob j = units[t].j;
-                j.k0 = (int32_t)(g0 * kGranule);
-                j.k1 = (int32_t)(g1 * kGranule);   // q <= granules, so no range is empty and job indices are regular
-                j.split = (int32_t)s;
-                j.n_splits = (int32_t)q;
-                j.split_stride = (int32_t)(e - i);
-                jobs.push_back(j);
-            }
-        }
+        bool dxd = (e - i) == 4;
+        for (size_t t = i; t < e; ++t) dxd = dxd && units[t].j.MI == 4 && units[t].j.NI == 4;
+        if (dxd) groups.push_back({(int)i, (int)i + 1, (int)i + 2, (int)i + 3});
+        else
+            for (size_t t = i; t < e; ++t) small.push_back((int)t);
         i = e;
     }
-    pad4();
-    return jobs;
+    // Measured cycles per cost-granule relative to a 4x4 tile (tools/timeline.py, MI355X): narrow tiles issue the same
+    // loads for fewer MFMAs.  Weights in 1/1000.
+    auto weight = [](const WgradJob& j) -> int64_t {
+        const int mn = j.MI * j.NI;
+        int w = mn == 16 ? 1000 : mn == 8 ? 1035 : mn == 4 ? 1145 : 1250;
+        if (j.bias == 1) w += mn == 16 ? 20 : mn == 8 ? 42 : 20;
+        return (int64_t)mn * w;
+    };
+    int64_t cost_a = 0, cost_b = 0;
+    for (auto& g : groups) cost_a += 4 * weight(units[g[0]].j);   // bias halves: all four tiles of a group weigh the same
+    for (int u : small) cost_b += weight(units[u].j);
+    static const int max_blocks = [] {   // NNR_WGRAD_MAX_BLOCKS: tuning knob for experiments
+        const char* e = std::getenv("NNR_WGRAD_MAX_BLOCKS");
+        return e ? std::max(2, std::atoi(e)) : kMaxBlocks;
+    }();
+    const int n_blocks = (int)std::max<int64_t>(2, std::min<int64_t>(max_blocks, granules * (int64_t)groups.size() / kMinGranulesPerBlock));
+    int nb_b = (int)((cost_b * n_blocks + (cost_a + cost_b) / 2) / (cost_a + cost_b));
+    nb_b = std::max(1, std::min(n_blocks - 1, nb_b));
+    const int nb_a = n_blocks - nb_b;
+
+    std::vector<std::vector<WgradJob>> per_wave((size_t)n_blocks * 4);
+    auto emit = [&](int wave, int unit, int64_t g0, int64_t g1) {
+        if (g1 <= g0) return;
+        WgradJob j = units[unit].j;
+        j.k0 = (int32_t)(g0 * kGranule);
+        j.k1 = (int32_t)(g1 * kGranule);
+        j.split = unit;   // temporarily: the tile id, replaced by the split index below
+        per_wave[wave].push_back(j);
+    };
+    // class A
+    const int64_t tape_a = granules * (int64_t)groups.size();
+    for (int b = 0; b < nb_a; ++b) {
+        const int64_t a0 = tape_a * b / nb_a, a1 = tape_a * (b + 1) / nb_a;
+        for (int64_t g = a0 / granules; g <= (a1 - 1) / granules && a1 > a0; ++g) {
+            const int64_t lo = std::max(a0, g * granules) - g * granules, hi = std::min(a1, (g + 1) * granules) - g * granules;
+            for (int t = 0; t < 4; ++t) emit(4 * b + t, groups[g][t], lo, hi);
+        }
+    }
+    // class B: tile u occupies [off_u, off_u + cost_u * granules) of the tape; a cut inside a tile is rounded to a granule
+    const int nw_b = nb_b * 4;
+    const int64_t tape_b = cost_b * granules;
+    std::vector<int64_t> cuts((size_t)nw_b + 1);
+    for (int v = 0; v <= nw_b; ++v) cuts[v] = tape_b * v / nw_b;
+    int64_t off = 0;
+    for (int u : small) {
+        const int64_t cu = weight(units[u].j), end = off + cu * granules;
+        auto to_granule = [&](int64_t x) { return std::min(granules, std::max<int64_t>(0, (x - off + cu / 2) / cu)); };
+        for (int v = 0; v < nw_b; ++v) {
+            if (cuts[v + 1] <= off || cuts[v] >= end) continue;
+            const int64_t g0 = cuts[v] <= off ? 0 : to_granule(cuts[v]);
+            const int64_t g1 = cuts[v + 1] >= end ? granules : to_granule(cuts[v + 1]);
+            emit(4 * nb_a + v, u, g0, g1);
+        }
+        off = end;
+    }
+    // flatten by wave, then chain the splits of every tile in sample order
+    Plan p;
+    p.wave_first.push_back(0);
+    for (auto& v : per_wave) {
+        for (auto& j : v) p.jobs.push_back(j);
+        p.wave_first.push_back((int32_t)p.jobs.size());
+    }
+    std::vector<std::vector<int>> by_tile(units.size());
+    for (size_t i = 0; i < p.jobs.size(); ++i) by_tile[p.jobs[i].split].push_back((int)i);
+    for (auto& v : by_tile) {
+        std::sort(v.begin(), v.end(), [&](int x, int y) { return p.jobs[x].k0 < p.jobs[y].k0; });
+        for (size_t s = 0; s < v.size(); ++s) {
+            p.jobs[v[s]].split = (int32_t)s;
+            p.jobs[v[s]].next_split = s + 1 < v.size() ? v[s + 1] : -1;
+        }
+    }
+    return p;
 }
 
-// The split factor is chosen so that ALL workgroups are co-resident (one 4-wave workgroup per CU: the kernel needs the
-// whole register file).  With even one workgroup too many the tail runs as a second round and the kernel takes twice
-// as long -- measured: 1057 waves on 1024 slots ran at 42 % MFMA utilisation.
-std::vector<WgradJob> build_plan(const nnr_cfg* c) {
-    int target = kTargetWaves;
-    for (;;) {
-        std::vector<WgradJob> jobs = build_plan_for(c, target);
-        if ((int)(jobs.size() / 4) <= kMaxBlocks || target <= 64) return jobs;
-        target -= 16;
-    }
-}
+size_t plan_bytes(const Plan& p) { return p.jobs.size() * sizeof(WgradJob) + p.wave_first.size() * sizeof(int32_t); }
 
 }  // namespace
 
@@ -185,7 +239,7 @@ size_t nnr_workspace_floats(const nnr_cfg* cfg) {
     if (check_cfg(cfg) != NNR_OK) return 0;
     const WsLayout w = ws_layout(cfg);
     // training: the planes, then one partial slot per weight-gradient job
-    return (size_t)w.total() + (w.train ? build_plan(cfg).size() * (size_t)kSlotFloats : 0);
+    return (size_t)w.total() + (w.train ? build_plan(cfg).jobs.size() * (size_t)kSlotFloats : 0);
 }
 
 int64_t nnr_ws_plane(const nnr_cfg* cfg, int pl, int32_t* pitch_out) {
@@ -198,15 +252,26 @@ int64_t nnr_ws_plane(const nnr_cfg* cfg, int pl, int32_t* pitch_out) {
 
 size_t nnr_plan_bytes(const nnr_cfg* cfg) {
     if (check_cfg(cfg) != NNR_OK) return 0;
-    return build_plan(cfg).size() * sizeof(WgradJob);
+    return plan_bytes(build_plan(cfg));
+}
+
+int nnr_plan_counts(const nnr_cfg* cfg, int32_t* n_jobs, int32_t* n_waves) {
+    int rc = check_cfg(cfg);
+    if (rc != NNR_OK) return rc;
+    const Plan p = build_plan(cfg);
+    if (n_jobs) *n_jobs = (int32_t)p.jobs.size();
+    if (n_waves) *n_waves = (int32_t)p.wave_first.size() - 1;
+    return NNR_OK;
 }
 
 int nnr_plan_build(const nnr_cfg* cfg, void* plan_host) {
     int rc = check_cfg(cfg);
     if (rc != NNR_OK) return rc;
     if (!plan_host) return NNR_E_BADCFG;
-    const std::vector<WgradJob> jobs = build_plan(cfg);
-    std::memcpy(plan_host, jobs.data(), jobs.size() * sizeof(WgradJob));
+    const Plan p = build_plan(cfg);   // layout: WgradJob[n_jobs], then int32 wave_first[n_waves + 1]
+    std::memcpy(plan_host, p.jobs.data(), p.jobs.size() * sizeof(WgradJob));
+    std::memcpy(static_cast<char*>(plan_host) + p.jobs.size() * sizeof(WgradJob), p.wave_first.data(),
+                p.wave_first.size() * sizeof(int32_t));
     return NNR_OK;
 }
 
@@ -327,7 +392,12 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const nnr_param_grads* g, const void* plan
         a.plane_off[p] = w.plane(p, &pitch);
         a.plane_pitch[p] = pitch;
     }
-    a.n_jobs = (int)(nnr_plan_bytes(cfg) / sizeof(WgradJob));
+    {
+        const Plan p = build_plan(cfg);   // host-only arithmetic, microseconds
+        a.n_jobs = (int)p.jobs.size();
+        a.n_waves = (int)p.wave_first.size() - 1;
+    }
+    a.wave_first = reinterpret_cast<const int32_t*>(a.jobs + a.n_jobs);
     a.slots = ws + w.total();
     hipError_t e = launch_wgrad(a, (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);

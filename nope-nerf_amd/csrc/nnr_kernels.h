@@ -67,7 +67,8 @@ struct WgradArgs {
     float* slots;              // n_jobs partial slots of kSlotFloats (see nnr_layout.h)
     int64_t plane_off[48];     // offset (floats) of each plane id, -1 if absent
     int32_t plane_pitch[48];
-    int n_jobs;
+    const int32_t* wave_first; // wave w runs jobs [wave_first[w], wave_first[w+1])
+    int n_jobs, n_waves;
 };
 
 struct RaySetupArgs {

@@ -182,7 +182,7 @@ struct WsLayout {
 // ---- weight-gradient plan: one entry per wave job ---------------------------------------------------------------
 // dW[layer][row0 + MI*m + i][wcol0 + NI*n + j] += sum_{s in [k0,k1)} Dlt[s][dcol0 + MI*m + i] * X[s][xcol0 + NI*n + j]
 // (m, n in [0,32), i < MI, j < NI): a wave tile of 32*MI rows x 32*NI cols with interleaved sub-tiles, so one
-// MI-wide and one NI-wide vector load per lane feed MI*NI MFMAs.  The sample axis is split over `n_splits` jobs per tile;
+// MI-wide and one NI-wide vector load per lane feed MI*NI MFMAs.  The sample axis is split over several jobs per tile;
 // each job writes its partial tile to its own slot of the workspace (plain, coalesced stores) and a second small kernel
 // adds the slots of a tile into dW -- ~27 float atomics per weight at the end of every wave cost 7 % of the kernel.
 struct WgradJob {
@@ -193,8 +193,10 @@ struct WgradJob {
     int32_t row0, wcol0;     // destination offsets in W (rows = out features, cols = in features)
     int32_t rows_real, cols_real, ldw;  // bounds and pitch of W
     int32_t k0, k1;          // sample range (multiples of 16)
-    int32_t bias;            // 1: this tile also reduces d(bias)[row] = sum_s Dlt[s][row]
-    int32_t split, n_splits, split_stride;  // this job is split `split` of its tile; split s lives at job index (this - split*stride) + s*stride
+    int32_t bias;            // this tile also reduces d(bias)[row] = sum_s Dlt[s][row]: 1 = every sample pair, 2 / 3 = the
+                             // even / odd pairs (two tiles of a row block share the work), 0 = not at all
+    int32_t split, next_split;  // this job is split `split` (in sample order) of its tile; job index of the next one, -1 = last
+    int32_t reserved;
 };
 // partial slot of job i: floats [i*kSlotFloats, (i+1)*kSlotFloats) of the slot region = tile (32*MI rows x 32*NI cols,
 // row-major, pitch 32*NI) followed by the two half-wave bias partials [2][32*MI]

@@ -15,6 +15,12 @@
 namespace nnr {
 
 NNR_TL_DECL(tl_wgrad)
+#ifdef NNR_TIMELINE
+__device__ unsigned long long tl_wgrad_all[4096];   // [wave slot][start, end]
+extern "C" int nnr_timeline_wgrad_all(unsigned long long* host4096) {
+    return (int)hipMemcpyFromSymbol(host4096, HIP_SYMBOL(tl_wgrad_all), 4096 * sizeof(unsigned long long));
+}
+#endif
 
 template <int W>
 struct Vec { float v[W]; };
@@ -41,7 +47,7 @@ __device__ __forceinline__ Vec<W> load_vec(const float* p) {
 
 constexpr int kU = 4;  // k-steps (pairs of samples) per pipeline stage
 
-template <int MI, int NI, bool BIAS>
+template <int MI, int NI, int BIAS>   // BIAS: WgradJob::bias
 __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a, int lane, int ji) {
     const int half = lane >> 5, m = lane & 31;
     const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
@@ -80,7 +86,7 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = mfma32(d[u].v[i], x[u].v[j], acc[i][j]);
-                if constexpr (BIAS) bsum[i] += d[u].v[i];
+                if (BIAS == 1 || (BIAS == 2 && u % 2 == 0) || (BIAS == 3 && u % 2 == 1)) bsum[i] += d[u].v[i];   // u is unrolled: folds
             }
         }
     };
@@ -120,7 +126,7 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
             else if constexpr (NI == 2) *reinterpret_cast<f32x2*>(dst) = f32x2{acc[i][0][r], acc[i][1][r]};
             else *dst = acc[i][0][r];
         }
-    if constexpr (BIAS) {   // this half-wave's share of sum_s Dlt[s][row0 + MI*m + i]
+    if constexpr (BIAS != 0) {   // this half-wave's share of sum_s Dlt[s][row0 + MI*m + i]
         float* dst = slot + kSlotTile + half * (32 * MI) + MI * m;
 #pragma unroll
         for (int i = 0; i < MI; ++i) dst[i] = bsum[i];
@@ -136,41 +142,50 @@ extern "C" int nnr_timeline_wgrad(unsigned long long* host32) {
 
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63;
-    const int ji = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (ji >= a.n_jobs) return;
-    const WgradJob jb = a.jobs[ji];
-    if (jb.layer < 0) return;
-    // bias reduction (MI VALU adds per k-step inside the MFMA stream) only in the jobs that own it
-    const int key = __builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI + (jb.bias ? 64 : 0));
+    const int wslot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int j0 = a.wave_first[wslot], j1 = a.wave_first[wslot + 1];
+#ifdef NNR_TIMELINE
+    if (lane == 0 && wslot < 2048) tl_wgrad_all[2 * wslot] = __builtin_amdgcn_s_memtime();
+#endif
+    for (int ji = j0; ji < j1; ++ji) {   // 1 job per wave, 2 where the wave's span of the schedule crosses a tile boundary
+        const WgradJob jb = a.jobs[ji];
+        // bias reduction (MI VALU adds per k-step inside the MFMA stream) only in the jobs that own it
+        const int key = __builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI + 64 * jb.bias);
 #define NNR_WGRAD_CASE(MI_, NI_)                                                \
-    case MI_ * 8 + NI_: wgrad_job<MI_, NI_, false>(jb, a, lane, ji); break;      \
-    case MI_ * 8 + NI_ + 64: wgrad_job<MI_, NI_, true>(jb, a, lane, ji); break;
-    switch (key) {
-        NNR_WGRAD_CASE(4, 4)
-        NNR_WGRAD_CASE(4, 2)
-        NNR_WGRAD_CASE(4, 1)
-        NNR_WGRAD_CASE(2, 4)
-        NNR_WGRAD_CASE(2, 1)
-        NNR_WGRAD_CASE(1, 4)
-        NNR_WGRAD_CASE(1, 2)
-        default: break;
-    }
+    case MI_ * 8 + NI_: wgrad_job<MI_, NI_, 0>(jb, a, lane, ji); break;          \
+    case MI_ * 8 + NI_ + 64: wgrad_job<MI_, NI_, 1>(jb, a, lane, ji); break;
+        switch (key) {
+            case 4 * 8 + 4 + 128: wgrad_job<4, 4, 2>(jb, a, lane, ji); break;
+            case 4 * 8 + 4 + 192: wgrad_job<4, 4, 3>(jb, a, lane, ji); break;
+            NNR_WGRAD_CASE(4, 4)
+            NNR_WGRAD_CASE(4, 2)
+            NNR_WGRAD_CASE(4, 1)
+            NNR_WGRAD_CASE(2, 4)
+            NNR_WGRAD_CASE(2, 1)
+            NNR_WGRAD_CASE(1, 4)
+            NNR_WGRAD_CASE(1, 2)
+            default: break;
+        }
 #undef NNR_WGRAD_CASE
+    }
+#ifdef NNR_TIMELINE
+    if (lane == 0 && wslot < 2048) tl_wgrad_all[2 * wslot + 1] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // dW[tile] += sum over the tile's splits of their partial slots; d(bias) likewise.  Every weight belongs to exactly one
-// tile, so plain read-modify-write.  Blocks of jobs that are not split 0 of their tile exit at once.
+// tile, so plain read-modify-write.  Blocks of jobs that are not split 0 of their tile exit at once; split 0 walks the chain.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
     const int ji = blockIdx.x >> 4;   // 16 blocks x 256 threads x one float4 = a 128 x 128 tile
     const WgradJob jb = a.jobs[ji];
-    if (jb.layer < 0 || jb.split != 0) return;
+    if (jb.split != 0) return;
     const int t = (blockIdx.x & 15) * 256 + threadIdx.x;
     const int pitch = 32 * jb.NI, f4_per_row = 8 * jb.NI;
     const int row = t / f4_per_row, c0 = 4 * (t - row * f4_per_row);
     if (row < 32 * jb.MI && row < jb.d_valid && jb.row0 + row < jb.rows_real) {
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         const float* src = a.slots + (int64_t)ji * kSlotFloats + row * pitch + c0;
-        for (int s = 0; s < jb.n_splits; ++s) sum += *reinterpret_cast<const f32x4*>(src + (int64_t)s * jb.split_stride * kSlotFloats);
+        for (int j = ji; j >= 0; j = a.jobs[j].next_split) sum += *reinterpret_cast<const f32x4*>(src + (int64_t)(j - ji) * kSlotFloats);
         float* dst = a.gw[jb.layer] + (int64_t)(jb.row0 + row) * jb.ldw + jb.wcol0 + c0;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -181,17 +196,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
         if (r < jb.d_valid && jb.row0 + r < jb.rows_real) {
             float sum = 0.f;
             const float* src = a.slots + (int64_t)ji * kSlotFloats + kSlotTile + r;
-            for (int s = 0; s < jb.n_splits; ++s) {
-                const float* p = src + (int64_t)s * jb.split_stride * kSlotFloats;
+            for (int j = ji; j >= 0; j = a.jobs[j].next_split) {
+                const float* p = src + (int64_t)(j - ji) * kSlotFloats;
                 sum += p[0] + p[32 * jb.MI];
             }
-            a.gb[jb.layer][jb.row0 + r] += sum;
+            atomicAdd(a.gb[jb.layer] + jb.row0 + r, sum);   // two tiles of a row block may each hold a share
         }
     }
 }
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(wgrad_kernel, dim3((a.n_jobs + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(a.n_waves / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_jobs * 16), dim3(256), 0, st, a);
     return hipGetLastError();
 }

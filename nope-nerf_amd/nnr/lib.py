@@ -23,7 +23,7 @@ LAYER_NAMES = ("layers0.0", "layers0.2", "layers0.4", "layers0.6", "layers1.0", 
                "layers1.6", "fc_density", "fc_feature", "rgb_layers.0", "fc_rgb")
 
 EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_floats", "nnr_workspace_floats",
-           "nnr_plan_bytes", "nnr_plan_build", "nnr_pack_weights", "nnr_render_fwd", "nnr_render_bwd", "nnr_ws_plane",
+           "nnr_plan_bytes", "nnr_plan_counts", "nnr_plan_build", "nnr_pack_weights", "nnr_render_fwd", "nnr_render_bwd", "nnr_ws_plane",
            "nnr_mlp_fwd", "nnr_composite_fwd", "nnr_composite_bwd", "nnr_mlp_dgrad", "nnr_mlp_wgrad", "nnr_ray_reduce",
            "nnr_se3_exp_fwd", "nnr_se3_exp_bwd", "nnr_inv4_fwd", "nnr_inv4_bwd", "nnr_ray_setup_fwd", "nnr_ray_setup_bwd",
            "nnr_depth_gather_fwd", "nnr_depth_gather_bwd", "nnr_render_loss", "nnr_pixels_from_index")
@@ -40,7 +40,7 @@ class Params(C.Structure):
 class WgradJob(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("layer", "MI", "NI", "d_plane", "d_col0", "d_valid", "x_plane", "x_col0",
                                          "x_valid", "row0", "wcol0", "rows_real", "cols_real", "ldw", "k0", "k1", "bias",
-                                         "split", "n_splits", "split_stride")]
+                                         "split", "next_split", "reserved")]
 
 
 _lib = None
@@ -65,6 +65,7 @@ def load():
         getattr(lib, n).restype = C.c_size_t
         getattr(lib, n).argtypes = [cfgp]
     lib.nnr_plan_build.argtypes = [cfgp, vp]
+    lib.nnr_plan_counts.argtypes = [cfgp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.nnr_pack_weights.argtypes = [cfgp, C.POINTER(Params), vp, vp]
     lib.nnr_render_fwd.argtypes = [cfgp] + [vp] * 13
     lib.nnr_render_bwd.argtypes = [cfgp, vp, vp, vp, C.POINTER(Params), vp, vp, vp, vp, vp, vp]

@@ -105,14 +105,21 @@ def _plan_for(cfg: L.Cfg, device) -> torch.Tensor:
     return plan
 
 
-def plan_jobs(cfg: L.Cfg):
-    """Host copy of the weight-gradient plan as a list of WgradJob (for tests / DESIGN inspection)."""
+def plan_jobs(cfg: L.Cfg, with_waves: bool = False):
+    """Host copy of the weight-gradient plan as a list of WgradJob (for tests / DESIGN inspection); with_waves also
+    returns the wave_first table (wave w runs jobs [wave_first[w], wave_first[w+1]))."""
     lib = L.load()
+    nj, nw = C.c_int32(0), C.c_int32(0)
+    L.check(lib.nnr_plan_counts(C.byref(cfg), C.byref(nj), C.byref(nw)), "nnr_plan_counts")
     nbytes = lib.nnr_plan_bytes(C.byref(cfg))
-    n = nbytes // C.sizeof(L.WgradJob)
-    buf = (L.WgradJob * n)()
-    L.check(lib.nnr_plan_build(C.byref(cfg), C.cast(buf, C.c_void_p)), "nnr_plan_build")
-    return list(buf)
+    assert nbytes == nj.value * C.sizeof(L.WgradJob) + 4 * (nw.value + 1)
+    raw = (C.c_uint8 * nbytes)()
+    L.check(lib.nnr_plan_build(C.byref(cfg), C.cast(raw, C.c_void_p)), "nnr_plan_build")
+    jobs = list((L.WgradJob * nj.value).from_buffer_copy(raw, 0))
+    if not with_waves:
+        return jobs
+    first = list((C.c_int32 * (nw.value + 1)).from_buffer_copy(raw, nj.value * C.sizeof(L.WgradJob)))
+    return jobs, first
 
 
 def workspace_plane(cfg: L.Cfg, ws: torch.Tensor, plane: int, n_rows: Optional[int] = None) -> torch.Tensor:

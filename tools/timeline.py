@@ -38,3 +38,29 @@ if __name__ == "__main__":
                 continue
             n = max(i for i, x in enumerate(v) if x) + 1
             print(name, tag, "rc", rc, "total", v[n - 1] - v[0], "deltas", [v[i + 1] - v[i] for i in range(n - 1)])
+    if hasattr(handle, "nnr_timeline_wgrad_all"):
+        import numpy as np
+        buf = (ctypes.c_ulonglong * 4096)()
+        handle.nnr_timeline_wgrad_all(buf)
+        v = np.array(buf, dtype=np.int64).reshape(-1, 2)
+        v = v[v[:, 0] > 0]
+        t0 = v[:, 0].min()
+        dur = v[:, 1] - v[:, 0]
+        print("wgrad waves", len(v), "start spread", int(v[:, 0].max() - t0), "end max", int(v[:, 1].max() - t0),
+              "dur min/mean/max", int(dur.min()), int(dur.mean()), int(dur.max()))
+        nb = len(v) // 4
+        per_blk = dur[:nb * 4].reshape(nb, 4).max(axis=1)
+        order = np.argsort(per_blk)
+        print("slowest blocks", [(int(b), int(per_blk[b])) for b in order[-6:]], "fastest", [(int(b), int(per_blk[b])) for b in order[:4]])
+        from nnr import ops
+        from nnr import lib as L2
+        jobs, first = ops.plan_jobs(L2.make_cfg(bench.R_PER_GPU, bench.N_SAMPLES, bench.HIDDEN, train=True), with_waves=True)
+        import collections
+        bytype = collections.defaultdict(list)
+        for wv in range(len(first) - 1):
+            js = jobs[first[wv]:first[wv + 1]]
+            key = tuple(sorted({(j.MI, j.NI, j.bias) for j in js}))
+            cost = sum(j.MI * j.NI * (j.k1 - j.k0) // 16 for j in js)
+            bytype[key].append(dur[wv] / max(cost, 1))
+        for k, x in sorted(bytype.items()):
+            print("class B/A wave types", k, "n", len(x), "cycles per cost-granule min/mean/max %.1f %.1f %.1f" % (min(x), sum(x) / len(x), max(x)))
