@@ -94,6 +94,22 @@ def build_trainer(device, world):
     return trainer, net
 
 
+def _hbm_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01/hbm_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE, separate runs of tools/profile_kernels.py at this very shape).  Counters cannot be
+    collected from inside this process; None if the summary is not there."""
+    path = os.path.join(ROOT, 'profiles', 'r01', 'hbm_traffic.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)['kernels']
+    key = {'mlp_fwd': 'mlp_fwd_kernel<256, true>', 'mlp_dgrad': 'mlp_dgrad_kernel<256>', 'mlp_wgrad': 'wgrad_kernel('}[kernel]
+    for name, v in table.items():
+        if key in name:
+            return int(v['fetch_bytes'] + v['write_bytes'])
+    return None
+
+
 def kernel_roofline(net, device, reps=5):
     """Time the three fused-MLP kernels of one 1024x192 step individually with HIP events on the launch stream."""
     from nnr import lib as L
@@ -152,7 +168,7 @@ def kernel_roofline(net, device, reps=5):
     mlp_ms = times['mlp_fwd'] + times['mlp_dgrad'] + times['mlp_wgrad']
     return {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+        'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': _hbm_traffic(dom),
         'flop_per_launch': flops, 'kernels': per,
         'fused_mlp_all_three': {'ms': round(mlp_ms, 4), 'tflops': round(3 * flops / (mlp_ms * 1e-3) / 1e12, 2),
                                 'frac': round(3 * flops / (mlp_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
