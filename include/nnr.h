@@ -166,6 +166,17 @@ int nnr_ray_setup_bwd(const float* pixels, const float* depth, const float* K, c
  * the (h*w,2) grid every step. */
 int nnr_pixels_from_index(const int64_t* ray_idx, float* pixels, int32_t n_rays, int32_t h, int32_t w, void* stream);
 
+/* Point-cloud loss.  nnr_pc_nearest: for every row of src (n_src,3) the index of the nearest row of dst
+ * (n_dst,3) and the distance to it: Loss.comp_closest_pts_idx_with_split + the norm of comp_point_point_error
+ * (model/losses.py:125-148) without the (3, S, D) difference tensor.  Same fp32 distance as torch.linalg.norm, first
+ * index on ties.  scratch: n_src * 8 bytes, 8-byte aligned.
+ * nnr_pc_error_bwd: gradient of mean_s dist[s] times the device scalar g_loss[0]: g_src (n_src,3) is overwritten,
+ * g_dst (n_dst,3) is ACCUMULATED into (zero-fill first); either may be null. */
+int nnr_pc_nearest(const float* src, const float* dst, int32_t n_src, int32_t n_dst, int64_t* idx, float* dist, void* scratch,
+                   void* stream);
+int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_loss, int32_t n_src,
+                     float* g_src, float* g_dst, void* stream);
+
 /* depth = nearest-resize(depth_img (hd,wd) -> (h,w)).flatten()[ray_idx]  (model/network.py:22-24) without materialising
  * the resized image; backward scatter-adds into a zero-filled (hd,wd) gradient image. */
 int nnr_depth_gather_fwd(const float* depth_img, const int64_t* ray_idx, float* out, int32_t n_rays, int32_t h, int32_t w,

@@ -500,4 +500,17 @@ int nnr_pixels_from_index(const int64_t* ray_idx, float* pixels, int32_t n_rays,
     NNR_LAUNCH(launch_pixels_from_index(ray_idx, pixels, n_rays, h, w, (hipStream_t)stream));
 }
 
+int nnr_pc_nearest(const float* src, const float* dst, int32_t n_src, int32_t n_dst, int64_t* idx, float* dist, void* scratch,
+                   void* stream) {
+    if (!src || !dst || !idx || !dist || !scratch || n_src <= 0 || n_dst <= 0) return NNR_E_BADCFG;
+    if (((uintptr_t)scratch & 7) != 0) return NNR_E_ALIGN;
+    NNR_LAUNCH(launch_pc_nearest(src, dst, n_src, n_dst, idx, dist, static_cast<unsigned long long*>(scratch), (hipStream_t)stream));
+}
+
+int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_loss, int32_t n_src,
+                     float* g_src, float* g_dst, void* stream) {
+    if (!src || !dst || !idx || !dist || !g_loss || n_src <= 0 || (!g_src && !g_dst)) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_pc_error_bwd(src, dst, idx, dist, g_loss, n_src, g_src, g_dst, (hipStream_t)stream));
+}
+
 }  // extern "C"

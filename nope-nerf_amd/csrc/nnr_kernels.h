@@ -109,6 +109,10 @@ hipError_t launch_depth_gather_fwd(const float* img, const int64_t* idx, float* 
 hipError_t launch_depth_gather_bwd(const float* g, const int64_t* idx, float* g_img, int R, int h, int w, int hd, int wd, hipStream_t st);
 hipError_t launch_render_loss(const LossArgs& a, hipStream_t st);
 hipError_t launch_pixels_from_index(const int64_t* idx, float* out, int R, int h, int w, hipStream_t st);
+hipError_t launch_pc_nearest(const float* src, const float* dst, int S, int D, int64_t* idx, float* dist, unsigned long long* keys,
+                             hipStream_t st);
+hipError_t launch_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_loss, int S,
+                               float* g_src, float* g_dst, hipStream_t st);
 hipError_t launch_pack(int D, const PackArgs& a, hipStream_t st);
 hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st);
 hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st);

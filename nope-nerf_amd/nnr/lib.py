@@ -26,7 +26,8 @@ EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_
            "nnr_plan_bytes", "nnr_plan_counts", "nnr_plan_build", "nnr_pack_weights", "nnr_render_fwd", "nnr_render_bwd", "nnr_ws_plane",
            "nnr_mlp_fwd", "nnr_composite_fwd", "nnr_composite_bwd", "nnr_mlp_dgrad", "nnr_mlp_wgrad", "nnr_ray_reduce",
            "nnr_se3_exp_fwd", "nnr_se3_exp_bwd", "nnr_inv4_fwd", "nnr_inv4_bwd", "nnr_ray_setup_fwd", "nnr_ray_setup_bwd",
-           "nnr_depth_gather_fwd", "nnr_depth_gather_bwd", "nnr_render_loss", "nnr_pixels_from_index")
+           "nnr_depth_gather_fwd", "nnr_depth_gather_bwd", "nnr_render_loss", "nnr_pixels_from_index", "nnr_pc_nearest",
+           "nnr_pc_error_bwd")
 
 
 class Cfg(C.Structure):
@@ -87,6 +88,8 @@ def load():
     lib.nnr_depth_gather_fwd.argtypes = [vp, vp, vp] + [i32] * 5 + [vp]
     lib.nnr_depth_gather_bwd.argtypes = [vp, vp, vp] + [i32] * 5 + [vp]
     lib.nnr_pixels_from_index.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.nnr_pc_nearest.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.nnr_pc_error_bwd.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
     lib.nnr_render_loss.argtypes = [vp] * 5 + [i32] + [f32] * 4 + [i32] * 3 + [vp] * 6
     for n in EXPORTS:
         if not hasattr(lib, n):

@@ -306,6 +306,31 @@ def loss_heads(out: dict, rgb_gt: torch.Tensor, rgb_weight=1.0, depth_weight=0.0
     return rgb_weight * lrgb + depth_weight * ldep, lrgb, ldep
 
 
+# ----------------------------------------------------------------------------------------
+# point-cloud loss between a frame and its reference frame  (model/losses.py:114-148)
+# ----------------------------------------------------------------------------------------
+
+def closest_idx(pts_src: torch.Tensor, pts_des: torch.Tensor, split: int = 500000) -> torch.Tensor:
+    """Loss.comp_closest_pts_idx_with_split -- model/losses.py:125-142: (3,S),(3,D) -> (S,) argmin over the dense distance matrix."""
+    out = []
+    for sec in torch.split(pts_src, split, dim=1):
+        diff = sec[:, :, None] - pts_des[:, None, :]
+        out.append(torch.argmin(torch.linalg.norm(diff, dim=0), dim=1))
+    return torch.cat(out)
+
+
+def point_point_error(xt: torch.Tensor, yt: torch.Tensor) -> torch.Tensor:
+    """Loss.comp_point_point_error -- model/losses.py:143-148."""
+    idx = closest_idx(xt, yt)
+    return torch.mean(torch.linalg.norm(xt - yt[:, idx], dim=0))
+
+
+def pc_loss(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """Loss.get_pc_loss, match_method 'dense' -- model/losses.py:114-121: x (1,S,3), y (1,D,3), symmetric sum."""
+    xt, yt = x[0].permute(1, 0), y[0].permute(1, 0)
+    return point_point_error(xt, yt) + point_point_error(yt, xt)
+
+
 def train_step_scope(params, pose_r, pose_t, scales, shifts, cam: int, camera_mat, depth_img, img, img_size,
                      ray_idx, jitter, cfg: dict, *, rgb_weight=1.0, depth_weight=0.04, rgb_type="l1",
                      shift_first=False):
