@@ -39,7 +39,7 @@ FLOP_PER_SAMPLE_PASS = 2 * 593408            # forward == dgrad == wgrad, BASELI
 PEAK_FP32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
 
 
-def full_cfg(rays_total):
+def full_cfg(rays_total, aux=False):
     cfg = {
         'model': {'hidden_dim': HIDDEN, 'pos_enc_levels': 10, 'dir_enc_levels': 4, 'occ_activation': 'softplus'},
         'rendering': {'type': 'nope_nerf', 'n_max_network_queries': 64000, 'white_background': False, 'radius': 4.0,
@@ -56,6 +56,9 @@ def full_cfg(rays_total):
             'depth_loss_type': 'l1', 'with_ssim': False, 'with_auto_mask': False,
         },
     }
+    if aux:   # configs/default.yaml:99-100 -- the first training phase: point-cloud + surface-reprojection losses on
+        cfg['training']['pc_weight'] = [1.0, 0.0]
+        cfg['training']['rgb_s_weight'] = [1.0, 0.0]
     return cfg
 
 
@@ -69,12 +72,16 @@ def synthetic_batch(device, seed=42):
         'img.dpt': (1 + 2 * torch.rand(1, IMG_H, IMG_W, generator=g)).to(device),
         'img.camera_mat': K.to(device),
         'img.scale_mat': torch.eye(4).unsqueeze(0).to(device),
+        # the neighbouring frame the per-image losses compare against (dataloading: ref_imgs / ref_dpts / ref_idxs)
+        'img.ref_imgs': torch.rand(1, 3, IMG_H, IMG_W, generator=g).to(device),
+        'img.ref_dpts': (1 + 2 * torch.rand(1, IMG_H, IMG_W, generator=g)).to(device),
+        'img.ref_idxs': 4,
     }
 
 
-def build_trainer(device, world):
+def build_trainer(device, world, aux=False):
     import model as mdl
-    cfg = full_cfg(R_PER_GPU * world)
+    cfg = full_cfg(R_PER_GPU * world, aux)
     torch.manual_seed(42)
     net = mdl.OfficialStaticNerf(cfg)
     model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device=device), cfg, device=device)
@@ -215,6 +222,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--aux', action='store_true',
+                    help='also run the per-image point-cloud / reprojection losses of the first training phase (not the headline metric)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -229,7 +238,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1"
 
-    trainer, net = build_trainer(device, world)
+    trainer, net = build_trainer(device, world, args.aux)
     data = synthetic_batch(device)
 
     def step(i):
@@ -263,7 +272,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: 1024 rays/GPU x 192 samples (64 coarse + 128 fine pinned as one '
                                    '192-sample stratified pass), 8-layer-256 MLP, pose + distortion learnable, fp32; '
-                                   'full Trainer.train_step incl. 3 Adam steps; aux per-image losses off',
+                                   'full Trainer.train_step incl. 3 Adam steps; aux per-image losses ' + ('ON (pc + rgb_s)' if args.aux else 'off'),
                        'rays_per_gpu': R_PER_GPU, 'n_samples': N_SAMPLES, 'hidden': HIDDEN, 'image': [IMG_H, IMG_W],
                        'parallelism': f'dp{world} (ray-sharded, one flat all-reduce)'},
             'final_loss': round(loss_val, 6),

@@ -5,7 +5,7 @@
 // Roofline: VALU-bound (no reuse to speak of for a matrix unit: the per-pair work is 3 subtractions, a 3-term sum of
 // squares and a compare; the dot-product form |x|^2 + |y|^2 - 2xy would put it on MFMA but changes the rounding and with
 // it the argmin).  8 VALU instructions per (source, destination) pair per lane, S*D pairs: 2.1 G lane-instructions per
-// direction = 53 us at 64 lanes/clk/CU x 256 CUs x 2.4 GHz.  HBM traffic is the two clouds (390 KB) and 20 B per source point.
+// direction = 53 us at 64 lanes/clk/CU x 256 CUs x 2.4 GHz (half that with packed fp32).  HBM traffic is the two clouds (390 KB) and 20 B per source point.
 //
 // Parity: the reference takes argmin over sqrt(dx^2 + dy^2 + dz^2) as torch evaluates it -- the sum of squares as the fma
 // chain fma(dz,dz, fma(dy,dy, dx*dx)) (checked bit-for-bit against torch.linalg.norm on the host) -- and returns the FIRST
@@ -15,7 +15,9 @@
 
 namespace nnr {
 
-constexpr int kPcBlock = 256;   // source points per workgroup (one per lane)
+constexpr int kPcBlock = 256;   // lanes per workgroup
+constexpr int kPcPer = 4;       // source points per lane: one LDS read feeds four pairs, held as two float2 so that the
+                                // subtract / square / fma chain issues as packed fp32 (v_pk_*: two pairs per instruction)
 constexpr int kPcTile = 1024;   // destination points staged in LDS at a time (16 KB as float4)
 
 // keys[s] = min over this block's destination range of (sqrt(d2) bits << 32 | index): distances are >= 0, so their bit
@@ -23,12 +25,25 @@ constexpr int kPcTile = 1024;   // destination points staged in LDS at a time (1
 __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __restrict__ src, const float* __restrict__ dst, int S,
                                                               int D, int d_per_block, unsigned long long* __restrict__ keys) {
     __shared__ f32x4 tile[kPcTile];
-    const int s = blockIdx.x * kPcBlock + threadIdx.x;
-    const int sc = s < S ? s : S - 1;
-    const float x = src[3 * sc], y = src[3 * sc + 1], z = src[3 * sc + 2];
+    const int s0 = (blockIdx.x * kPcBlock + threadIdx.x) * kPcPer;
+    f32x2 x[2], y[2], z[2];
+#pragma unroll
+    for (int u = 0; u < kPcPer; ++u) {
+        const int sc = s0 + u < S ? s0 + u : S - 1;
+        x[u >> 1][u & 1] = src[3 * sc];
+        y[u >> 1][u & 1] = src[3 * sc + 1];
+        z[u >> 1][u & 1] = src[3 * sc + 2];
+    }
     const int d0 = blockIdx.y * d_per_block, d1 = min(D, d0 + d_per_block);
-    float best_d2 = __builtin_inff(), best_s = __builtin_inff();
-    int best_i = 0x7fffffff;
+    f32x2 best_d2[2];
+    float best_s[kPcPer];
+    int best_i[kPcPer];
+#pragma unroll
+    for (int u = 0; u < kPcPer; ++u) {
+        best_d2[u >> 1][u & 1] = __builtin_inff();
+        best_s[u] = __builtin_inff();
+        best_i[u] = 0x7fffffff;
+    }
     for (int t0 = d0; t0 < d1; t0 += kPcTile) {
         const int n = min(kPcTile, d1 - t0);
         __syncthreads();
@@ -37,20 +52,34 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __res
             tile[i] = f32x4{p[0], p[1], p[2], 0.f};
         }
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 2
         for (int i = 0; i < n; ++i) {
             const f32x4 q = tile[i];   // same address in every lane: an LDS broadcast
-            const float dx = x - q[0], dy = y - q[1], dz = z - q[2];
-            const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
-            if (d2 < best_d2) {        // rare after the first few points: the sqrt stays out of the steady-state loop
-                const float sq = __fsqrt_rn(d2);
-                if (sq < best_s) { best_s = sq; best_i = t0 + i; }   // equal sqrt: the earlier index stays
-                best_d2 = d2;
+            f32x2 d2[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const f32x2 dx = x[v] - q[0], dy = y[v] - q[1], dz = z[v] - q[2];
+                // torch.linalg.norm's sum of squares: fma(dz,dz, fma(dy,dy, dx*dx)), every step rounded to fp32
+                d2[v] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+            }
+            // rare after the first few points: the sqrt and the bookkeeping stay out of the steady-state loop
+            if ((d2[0][0] < best_d2[0][0]) | (d2[0][1] < best_d2[0][1]) | (d2[1][0] < best_d2[1][0]) | (d2[1][1] < best_d2[1][1])) {
+#pragma unroll
+                for (int u = 0; u < kPcPer; ++u) {
+                    const float v = d2[u >> 1][u & 1];
+                    if (v < best_d2[u >> 1][u & 1]) {
+                        const float sq = __fsqrt_rn(v);
+                        if (sq < best_s[u]) { best_s[u] = sq; best_i[u] = t0 + i; }   // equal sqrt: the earlier index stays
+                        best_d2[u >> 1][u & 1] = v;
+                    }
+                }
             }
         }
     }
-    if (s < S && best_i != 0x7fffffff)
-        atomicMin(keys + s, ((unsigned long long)__float_as_uint(best_s) << 32) | (unsigned int)best_i);
+#pragma unroll
+    for (int u = 0; u < kPcPer; ++u)
+        if (s0 + u < S && best_i[u] != 0x7fffffff)
+            atomicMin(keys + s0 + u, ((unsigned long long)__float_as_uint(best_s[u]) << 32) | (unsigned int)best_i[u]);
 }
 
 __global__ void pc_fill_keys_kernel(unsigned long long* keys, int S) {
@@ -87,11 +116,11 @@ __global__ void pc_error_bwd_kernel(const float* __restrict__ src, const float* 
 hipError_t launch_pc_nearest(const float* src, const float* dst, int S, int D, int64_t* idx, float* dist, unsigned long long* keys,
                              hipStream_t st) {
     // enough workgroups to fill the chip: split the destination range until there are ~4 per CU
-    const int bx = (S + kPcBlock - 1) / kPcBlock;
+    const int bx = (S + kPcBlock * kPcPer - 1) / (kPcBlock * kPcPer);
     int split = (1024 + bx - 1) / bx;
-    const int max_split = (D + kPcTile - 1) / kPcTile;
+    const int max_split = (D + 255) / 256;   // at least 256 destination points per workgroup
     split = split < 1 ? 1 : (split > max_split ? max_split : split);
-    const int d_per_block = ((D + split - 1) / split + kPcTile - 1) / kPcTile * kPcTile;
+    const int d_per_block = ((D + split - 1) / split + 255) / 256 * 256;
     const int by = (D + d_per_block - 1) / d_per_block;
     hipLaunchKernelGGL(pc_fill_keys_kernel, dim3((S + 255) / 256), dim3(256), 0, st, keys, S);
     hipLaunchKernelGGL(pc_nearest_kernel, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);

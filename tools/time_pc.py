@@ -12,10 +12,18 @@ def bench(fn, n=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
 
 if __name__ == "__main__":
-    S = 96 * 168
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 96 * 168
     g = torch.Generator().manual_seed(0)
-    x = (torch.rand(1, S, 3, generator=g) * 4).cuda().requires_grad_(True)
-    y = (torch.rand(1, S, 3, generator=g) * 4).cuda().requires_grad_(True)
+    if len(sys.argv) > 2:   # "grid": two back-projected depth maps (pixel grid x random depth), like the trainer's clouds
+        w = int(round((S * 16 / 9) ** 0.5)); h = S // w; S = h * w
+        ys, xs = torch.meshgrid(torch.linspace(-1, 1, h), torch.linspace(-1, 1, w), indexing='ij')
+        def cloud():
+            d = 1 + 2 * torch.rand(h, w, generator=g)
+            return torch.stack([xs * d * 0.7, ys * d * 0.4, -d], -1).view(1, S, 3)
+        x, y = cloud().cuda().requires_grad_(True), cloud().cuda().requires_grad_(True)
+    else:
+        x = (torch.rand(1, S, 3, generator=g) * 4).cuda().requires_grad_(True)
+        y = (torch.rand(1, S, 3, generator=g) * 4).cuda().requires_grad_(True)
     lm = Loss({'depth_loss_type': 'l1', 'match_method': 'dense', 'with_ssim': False})
     def hip():
         l = lm.get_pc_loss(x, y); l.backward()
