@@ -331,6 +331,79 @@ def pc_loss(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return point_point_error(xt, yt) + point_point_error(yt, xt)
 
 
+def mean_on_mask(diff: torch.Tensor, valid: torch.Tensor) -> torch.Tensor:
+    """Loss.mean_on_mask -- model/losses.py:77-85."""
+    mask = valid.expand_as(diff)
+    if mask.sum() > 0:
+        return diff[mask].sum() / mask.sum()
+    return torch.tensor(0.0)
+
+
+def project_to_cam(points: torch.Tensor, camera_mat: torch.Tensor):
+    """model/common.py:436-457: K [p;1], perspective divide, |x|,|y| <= 1 mask."""
+    ph = torch.cat([points, torch.ones_like(points[..., :1])], dim=-1).permute(0, 2, 1)
+    q = (camera_mat @ ph)[:, :3].permute(0, 2, 1)
+    xy = q[..., :2] / q[..., 2:]
+    return xy, (xy.abs().max(dim=-1)[0] <= 1).unsqueeze(-1).bool()
+
+
+def aux_scope(pose_r, pose_t, scales, shifts, cam: int, ref: int, camera_mat, depth_img, depth_ref_img, img, ref_img, *,
+              pc_weight=1.0, rgb_s_weight=1.0, pc_ratio=4, nearest_limit=0.01, shift_first=False, detach_ref_img=True,
+              scale_pcs=True, detach_rgbs_scale=False):
+    """The per-image terms between a frame and its reference frame -- model/training.py:280-365 (inputs) and
+    model/losses.py:114-157 (point-cloud and surface-reprojection losses; with_ssim off).  depth images (1,1,hd,wd) are the
+    raw mono depths; returns (weighted sum, loss_pc, loss_rgb_s)."""
+    num_cams = pose_r.shape[0]
+    world_mat = torch.inverse(pose_c2w(pose_r[cam], pose_t[cam])).unsqueeze(0)         # :238
+    sc, sh = distortion(scales, shifts, cam, num_cams)
+    depth_input = (depth_img + sh) * sc if shift_first else depth_img * sc + sh         # :240-245
+    c2w_ref = pose_c2w(pose_r[ref], pose_t[ref])                                        # :281
+    sc_r, sh_r = distortion(scales, shifts, ref, num_cams)
+    depth_ref = sc_r * (depth_ref_img + sh_r) if shift_first else sc_r * depth_ref_img + sh_r
+    if detach_ref_img:                                                                  # :288-292
+        c2w_ref, depth_ref = c2w_ref.detach(), depth_ref.detach()
+        sc_r = sc_r.detach()
+    ref_rt = torch.inverse(c2w_ref).unsqueeze(0)
+    if cam < num_cams - 1:                                                              # :296-313
+        d1, d2, img1, img2 = depth_input, depth_ref, img, ref_img
+        rel = ref_rt @ torch.inverse(world_mat)
+        scale2 = sc_r
+    else:
+        d1, d2, img1, img2 = depth_ref, depth_input, ref_img, img
+        rel = world_mat @ torch.inverse(ref_rt)
+        scale2 = sc
+    r_rel, t_rel = rel[:, :3, :3], rel[:, :3, 3]
+    res = (int(depth_img.shape[-2] / pc_ratio), int(depth_img.shape[-1] / pc_ratio))    # :315-316
+    p_pc = pixel_grid(*res)
+    d1 = F.interpolate(d1, res, mode="nearest")
+    d2 = F.interpolate(d2, res, mode="nearest")
+    d1[d1 < nearest_limit] = nearest_limit                                              # :320-321 (in place: no gradient there)
+    d2[d2 < nearest_limit] = nearest_limit
+    eye = torch.eye(4).unsqueeze(0)
+    pc1 = unproject(p_pc, d1.view(1, -1, 1), camera_mat, eye, eye)                      # :322-323
+    pc2 = unproject(p_pc, d2.view(1, -1, 1), camera_mat, eye, eye)
+    loss_rgb_s = torch.tensor(0.0)
+    if rgb_s_weight != 0.0:                                                             # :325-341
+        i1 = F.interpolate(img1, res, mode="bilinear")
+        i2 = F.interpolate(img2, res, mode="bilinear")
+        sample = lambda im, p: F.grid_sample(im, p.unsqueeze(1), mode="bilinear", align_corners=True).squeeze(2).permute(0, 2, 1)
+        rgb_pc1 = sample(i1, p_pc)
+        src = pc1.detach().clone() if detach_rgbs_scale else pc1
+        rot = src @ r_rel.transpose(1, 2) + t_rel
+        behind = (-rot[:, :, 2:] < nearest_limit).expand_as(rot)
+        rot[behind] = nearest_limit
+        p_re, valid = project_to_cam(rot, camera_mat)
+        rgb_proj = sample(i2, p_re)
+        shape = (1, res[0], res[1])
+        diff = (rgb_pc1.view(*shape, 3) - rgb_proj.view(*shape, 3)).abs().clamp(0, 1)   # losses.py:150-157, with_ssim False
+        loss_rgb_s = mean_on_mask(diff, valid.view(*shape, 1))
+    pc1 = pc1 @ r_rel.transpose(1, 2) + t_rel                                           # :353-358
+    if scale_pcs:
+        pc1, pc2 = pc1 / scale2, pc2 / scale2
+    loss_pc = pc_loss(pc1, pc2) if pc_weight != 0.0 else torch.tensor(0.0)
+    return pc_weight * loss_pc + rgb_s_weight * loss_rgb_s, loss_pc, loss_rgb_s
+
+
 def train_step_scope(params, pose_r, pose_t, scales, shifts, cam: int, camera_mat, depth_img, img, img_size,
                      ray_idx, jitter, cfg: dict, *, rgb_weight=1.0, depth_weight=0.04, rgb_type="l1",
                      shift_first=False):

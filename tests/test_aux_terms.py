@@ -1,0 +1,98 @@
+"""Per-image losses of the first training phase (point cloud + surface reprojection).
+CPU: the oracle (train_step_scope + aux_scope) against the golden vectors minted from the reference Trainer.train_step with
+pc_weight = rgb_s_weight = 1 (oracle/gen_golden_aux.py).  GPU (-m gpu): the product Trainer.train_step -- render kernels,
+per-image terms, every fused op in the loop -- against the same golden: loss parts to 1e-5, pose / distortion gradients to
+1e-4 of their scale."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "aux_terms.npz"))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+H, W, R, N, N_CAMS = 48, 64, 64, 32, 6
+
+
+def _inp(name):
+    return {k: torch.from_numpy(GOLD[f"{name}.in.{k}"]) for k in
+            ("K", "img", "ref_img", "dpt", "ref_dpt", "pose_r", "pose_t", "scales", "shifts")}
+
+
+@pytest.mark.parametrize("name", ["mid", "last"])
+def test_oracle_aux_scope_matches_reference_golden(name):
+    import nerf_oracle as orc
+    inp = _inp(name)
+    cam, ref = int(GOLD[f"{name}.cam"]), int(GOLD[f"{name}.ref"])
+    leaves = {k: inp[k].clone().requires_grad_(True) for k in ("pose_r", "pose_t", "scales", "shifts")}
+    aux, l_pc, l_rgbs = orc.aux_scope(leaves["pose_r"], leaves["pose_t"], leaves["scales"], leaves["shifts"], cam, ref, inp["K"],
+                                      inp["dpt"].unsqueeze(1), inp["ref_dpt"].unsqueeze(1), inp["img"], inp["ref_img"])
+    aux.backward()
+    np.testing.assert_allclose(l_pc.item(), float(GOLD[f"{name}.out.loss_pc"]), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(l_rgbs.item(), float(GOLD[f"{name}.out.loss_rgb_s"]), rtol=0, atol=1e-6)
+    for k in leaves:
+        g = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(inp[k])
+        np.testing.assert_allclose(g.numpy(), GOLD[f"{name}.gaux.{k}"], rtol=0, atol=2e-6, err_msg=k)
+
+
+def _trainer(inp, dev):
+    import model as mdl
+    import golden_util as gu
+    cfg = gu.trainer_cfg(128, R, N) if hasattr(gu, "trainer_cfg") else None
+    if cfg is None:
+        cfg = {
+            'model': {'hidden_dim': 128, 'pos_enc_levels': 10, 'dir_enc_levels': 4, 'occ_activation': 'softplus'},
+            'rendering': {'type': 'nope_nerf', 'n_max_network_queries': 64000, 'white_background': False, 'radius': 4.0,
+                          'num_points': N, 'depth_range': [0.01, 10], 'dist_alpha': False, 'use_ray_dir': True,
+                          'normalise_ray': True, 'normal_loss': False, 'sample_option': 'uniform', 'outside_steps': 0},
+            'depth': {'type': 'None'}, 'distortion': {'fix_scaleN': True},
+            'training': {
+                'type': 'nope_nerf', 'n_training_points': R, 'vis_geo': False, 'detach_gt_depth': False, 'pc_ratio': 4,
+                'match_method': 'dense', 'shift_first': False, 'detach_ref_img': True, 'scale_pcs': True,
+                'detach_rgbs_scale': False, 'vis_reprojection_every': 10 ** 9, 'nearest_limit': 0.01, 'annealing_epochs': 2000,
+                'rgb_weight': [1.0, 1.0], 'depth_weight': [0.04, 0.0], 'pc_weight': [1.0, 0.0], 'rgb_s_weight': [1.0, 0.0],
+                'depth_consistency_weight': [0.0, 0.0], 'weight_dist_2nd_loss': [0.0, 0.0], 'weight_dist_1st_loss': [0.0, 0.0],
+                'depth_loss_type': 'l1', 'with_ssim': False, 'with_auto_mask': False},
+        }
+    net = mdl.OfficialStaticNerf(cfg)
+    wts = np.load(os.path.join(HERE, "golden", "weights_d128.npz"))
+    net.load_state_dict({k: torch.from_numpy(wts[k]) for k in wts.files})
+    model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device=dev), cfg, device=dev)
+    pose = mdl.LearnPose(N_CAMS, True, True, cfg).to(dev)
+    dist = mdl.Learn_Distortion(N_CAMS, True, True, cfg).to(dev)
+    with torch.no_grad():
+        pose.r.copy_(inp["pose_r"]); pose.t.copy_(inp["pose_t"])
+        dist.global_scales.copy_(inp["scales"]); dist.global_shifts.copy_(inp["shifts"])
+    sgd = lambda m: torch.optim.SGD(m.parameters(), lr=0.0)
+    tr = mdl.Trainer(model, sgd(model), cfg['training'], device=dev, optimizer_pose=sgd(pose), pose_param_net=pose,
+                     optimizer_distortion=sgd(dist), distortion_net=dist)
+    return tr, pose, dist
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mid", "last"])
+def test_trainer_step_with_per_image_losses_matches_reference_golden(name, monkeypatch):
+    dev = torch.device("cuda")
+    inp = _inp(name)
+    cam, ref = int(GOLD[f"{name}.cam"]), int(GOLD[f"{name}.ref"])
+    tr, pose, dist = _trainer(inp, dev)
+    # replay the reference's draws (its generator is the CPU one): pixel permutation and jitter
+    ray_idx = torch.from_numpy(GOLD[f"{name}.ray_idx"])
+    jitter = torch.from_numpy(GOLD[f"{name}.jitter"])
+    monkeypatch.setattr(torch, "randperm", lambda n, device=None, **kw: torch.cat([ray_idx, torch.zeros(n - R, dtype=torch.int64)]).to(device))
+    real_rand = torch.rand
+    monkeypatch.setattr(torch, "rand", lambda *s, device=None, **kw: jitter.to(device) if tuple(s) == (1, R, N) else real_rand(*s, device=device, **kw))
+    data = {"img": inp["img"].to(dev), "img.idx": cam, "img.dpt": inp["dpt"].to(dev), "img.camera_mat": inp["K"].to(dev),
+            "img.scale_mat": torch.eye(4).unsqueeze(0).to(dev), "img.ref_imgs": inp["ref_img"].to(dev),
+            "img.ref_dpts": inp["ref_dpt"].to(dev), "img.ref_idxs": ref}
+    ld = tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
+    for k in ("loss", "loss_pc", "loss_rgb_s", "loss_rgb", "loss_depth"):
+        np.testing.assert_allclose(float(ld[k]), float(GOLD[f"{name}.out.{k}"]), rtol=0, atol=1e-5, err_msg=k)
+    got = {"pose_r": pose.r.grad, "pose_t": pose.t.grad, "scales": dist.global_scales.grad, "shifts": dist.global_shifts.grad}
+    for k, g in got.items():
+        ref_g = GOLD[f"{name}.g.{k}"]
+        g = g.cpu().numpy() if g is not None else np.zeros_like(ref_g)
+        scale = max(1.0, float(np.abs(ref_g).max()))
+        assert float(np.abs(g - ref_g).max()) / scale <= 1e-4, (k, float(np.abs(g - ref_g).max()), scale)
