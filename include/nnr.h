@@ -177,6 +177,31 @@ int nnr_pc_nearest(const float* src, const float* dst, int32_t n_src, int32_t n_
 int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_loss, int32_t n_src,
                      float* g_src, float* g_dst, void* stream);
 
+/* Per-image losses between a frame ("1") and its neighbour ("2"), fused (SURVEY 8 f1 + f2): the inputs of reference
+ * model/training.py:315-358 and the point-cloud / surface re-projection losses of model/losses.py:114-157 (with_ssim off)
+ * and their backward.  d1_img/d2_img (hd,wd): the scaled+shifted depth maps; img1r/img2r (3,hr,wr): the images resized
+ * (bilinear) to the sampling grid hr = hd/pc_ratio, wr = wd/pc_ratio; K, Kinv, rel: 4x4 row-major camera matrix, its
+ * inverse and the relative transform Rt_rel_12; scale2: device scalar.  out[4] = {loss_pc, loss_rgb_s, n_valid, 0}.
+ * The backward takes g_out[2] = dL/d{loss_pc, loss_rgb_s} (device) and ACCUMULATES into g_d1_img / g_d2_img (hd,wd;
+ * zero-fill first; either may be null) and OVERWRITES g_rel_scale[16] = {dL/d rel rows 0..2 (12 floats), dL/d scale2, 0..}.
+ * Both calls use the same workspace (nnr_aux_workspace_floats) and the same inputs. */
+#define NNR_AUX_RGBS 1u         /* rgb_s_weight != 0 */
+#define NNR_AUX_PC 2u           /* pc_weight != 0 */
+#define NNR_AUX_SCALE_PCS 4u    /* training.scale_pcs */
+#define NNR_AUX_DETACH_RGBS 8u  /* training.detach_rgbs_scale */
+typedef struct nnr_aux_cfg {
+    int32_t hd, wd, hr, wr;
+    float nearest_limit;
+    uint32_t flags;
+} nnr_aux_cfg;
+size_t nnr_aux_workspace_floats(const nnr_aux_cfg* cfg);
+int nnr_aux_terms_fwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* d2_img, const float* img1r, const float* img2r,
+                      const float* K, const float* Kinv, const float* rel, const float* scale2, float* out, float* workspace,
+                      void* stream);
+int nnr_aux_terms_bwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* d2_img, const float* img1r, const float* img2r,
+                      const float* K, const float* Kinv, const float* rel, const float* scale2, const float* g_out,
+                      float* g_d1_img, float* g_d2_img, float* g_rel_scale, float* workspace, void* stream);
+
 /* depth = nearest-resize(depth_img (hd,wd) -> (h,w)).flatten()[ray_idx]  (model/network.py:22-24) without materialising
  * the resized image; backward scatter-adds into a zero-filled (hd,wd) gradient image. */
 int nnr_depth_gather_fwd(const float* depth_img, const int64_t* ray_idx, float* out, int32_t n_rays, int32_t h, int32_t w,

@@ -513,4 +513,62 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
     NNR_LAUNCH(launch_pc_error_bwd(src, dst, idx, dist, g_loss, n_src, g_src, g_dst, (hipStream_t)stream));
 }
 
+namespace {
+// workspace of the per-image losses, in floats; 8-byte items first so that they stay aligned
+size_t aux_fill(const nnr_aux_cfg* c, float* ws, nnr::AuxArgs& a) {   // returns the workspace size in floats, 0 = bad cfg
+    if (!c || c->hd <= 0 || c->wd <= 0 || c->hr < 2 || c->wr < 2 || c->hr > c->hd || c->wr > c->wd) return 0;
+    const int64_t S = (int64_t)c->hr * c->wr;
+    a.hd = c->hd; a.wd = c->wd; a.hr = c->hr; a.wr = c->wr; a.S = (int)S;
+    a.nl = c->nearest_limit;
+    a.flags = c->flags;
+    float* p = ws;
+    auto take = [&](int64_t n) { float* r = p; p += n; return r; };
+    a.keys = reinterpret_cast<unsigned long long*>(take(4 * S));
+    a.idx_xy = reinterpret_cast<int64_t*>(take(2 * S));
+    a.idx_yx = reinterpret_cast<int64_t*>(take(2 * S));
+    a.X = take(3 * S); a.Y = take(3 * S); a.gX = take(3 * S); a.gY = take(3 * S);
+    a.gxy = take(2 * S);
+    a.dist_xy = take(S); a.dist_yx = take(S);
+    a.pflags = reinterpret_cast<uint32_t*>(take(S));
+    a.acc = take(8);
+    a.g_acc = take(16);
+    return (size_t)(p - ws);
+}
+}  // namespace
+
+size_t nnr_aux_workspace_floats(const nnr_aux_cfg* cfg) {
+    nnr::AuxArgs a{};
+    static float origin;   // only differences of pointers derived from it are used
+    return aux_fill(cfg, &origin, a);
+}
+
+int nnr_aux_terms_fwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* d2_img, const float* img1r, const float* img2r,
+                      const float* K, const float* Kinv, const float* rel, const float* scale2, float* out, float* ws, void* stream) {
+    nnr::AuxArgs a{};
+    if (!ws || !aux_fill(cfg, ws, a)) return NNR_E_BADCFG;
+    if (!d1_img || !d2_img || !K || !Kinv || !rel || !out) return NNR_E_BADCFG;
+    if ((cfg->flags & NNR_AUX_RGBS) && (!img1r || !img2r)) return NNR_E_BADCFG;
+    if ((cfg->flags & NNR_AUX_SCALE_PCS) && !scale2) return NNR_E_BADCFG;
+    if (((uintptr_t)ws & 7) != 0) return NNR_E_ALIGN;
+    a.d1_img = d1_img; a.d2_img = d2_img; a.img1r = img1r; a.img2r = img2r; a.K = K; a.Kinv = Kinv; a.rel = rel; a.scale2 = scale2;
+    a.out = out;
+    NNR_LAUNCH(launch_aux_fwd(a, (hipStream_t)stream));
+}
+
+int nnr_aux_terms_bwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* d2_img, const float* img1r, const float* img2r,
+                      const float* K, const float* Kinv, const float* rel, const float* scale2, const float* g_out, float* g_d1_img,
+                      float* g_d2_img, float* g_rel_scale, float* ws, void* stream) {
+    nnr::AuxArgs a{};
+    if (!ws || !aux_fill(cfg, ws, a)) return NNR_E_BADCFG;
+    if (!d1_img || !d2_img || !K || !Kinv || !rel || !g_out || !g_rel_scale) return NNR_E_BADCFG;
+    if ((cfg->flags & NNR_AUX_SCALE_PCS) && !scale2) return NNR_E_BADCFG;
+    if (((uintptr_t)ws & 7) != 0) return NNR_E_ALIGN;
+    a.d1_img = d1_img; a.d2_img = d2_img; a.img1r = img1r; a.img2r = img2r; a.K = K; a.Kinv = Kinv; a.rel = rel; a.scale2 = scale2;
+    a.g_out = g_out; a.g_d1_img = g_d1_img; a.g_d2_img = g_d2_img;
+    hipError_t e = launch_aux_bwd(a, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e);
+    e = hipMemcpyAsync(g_rel_scale, a.g_acc, 16 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    return e == hipSuccess ? NNR_OK : hip_fail(e);
+}
+
 }  // extern "C"

@@ -1,0 +1,295 @@
+// nnr_aux.hip -- the per-image losses between a frame and its reference frame, fused (SURVEY 8 f1 + f2).
+// Replaces, per training step while pc_weight / rgb_s_weight > 0 (the whole first training phase), the ~290 small torch
+// launches of reference model/training.py:315-358 (nearest-resized depths, back-projection of both depth maps, relative
+// transform, re-projection, two bilinear grid_samples) and model/losses.py:114-157 (point-cloud loss, surface
+// re-projection loss, with_ssim off) and their autograd, by one per-point forward kernel, the nearest-neighbour kernels
+// of nnr_pointcloud.hip and one per-point backward kernel.  O(points) work (32 400 at 540x960, pc_ratio 4): latency /
+// launch-count bound, not bandwidth or FLOP bound; the only heavy part is the nearest-neighbour search.
+//
+// Per point i of the (hr, wr) sampling grid, x' = 2x/(wr-1)-1, y' = 2y/(hr-1)-1 (arange_pixels, model/common.py:13-40):
+//   d1 = max(nearest-resize(d1_img)[i], nl), d2 likewise               (training.py:318-321; no gradient where clamped)
+//   pc1 = Kinv [x' d1, y' d1, d1, 1],  pc2 likewise                     (transform_to_world, common.py:112-160)
+//   rot = R pc1 + t                                                     (training.py:330,353)
+//   X = rot / scale2, Y = pc2 / scale2                                  (:355-357)  -> point-cloud loss (losses.py:114-148)
+//   rot' = (nl,nl,nl) where -rot.z < nl;  xy = (K [rot';1]).xy / .z;  valid = max|xy| <= 1     (:331-333, common.py:436-457)
+//   rgb_s = mean over valid points and 3 channels of clamp(|img1r(x',y') - img2r(xy)|, 0, 1)     (losses.py:150-157)
+#include "../../include/nnr.h"
+#include "nnr_device.h"
+#include "nnr_kernels.h"
+
+namespace nnr {
+
+__device__ __forceinline__ int aux_nearest_src(int dst, int dst_size, int src_size) {   // F.interpolate(mode='nearest')
+    const float scale = (float)src_size / (float)dst_size;
+    const int s = (int)floorf((float)dst * scale);
+    return s < src_size - 1 ? s : src_size - 1;
+}
+
+// grid_sample(mode='bilinear', padding_mode='zeros', align_corners=True) of a (3, h, w) image at (gx, gy) in [-1,1]; also the
+// derivative of every channel with respect to (gx, gy)
+struct Bilinear {
+    float v[3], dx[3], dy[3];
+};
+__device__ __forceinline__ Bilinear sample_bilinear(const float* img, int h, int w, float gx, float gy) {
+    const float ix = (gx + 1.f) * 0.5f * (float)(w - 1), iy = (gy + 1.f) * 0.5f * (float)(h - 1);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float ax = ix - fx0, ay = iy - fy0;
+    const bool okx0 = x0 >= 0 && x0 < w, okx1 = x1 >= 0 && x1 < w, oky0 = y0 >= 0 && y0 < h, oky1 = y1 >= 0 && y1 < h;
+    Bilinear r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* p = img + (int64_t)c * h * w;
+        const float v00 = okx0 && oky0 ? p[y0 * w + x0] : 0.f, v01 = okx1 && oky0 ? p[y0 * w + x1] : 0.f;
+        const float v10 = okx0 && oky1 ? p[y1 * w + x0] : 0.f, v11 = okx1 && oky1 ? p[y1 * w + x1] : 0.f;
+        r.v[c] = (v00 * (1.f - ax) + v01 * ax) * (1.f - ay) + (v10 * (1.f - ax) + v11 * ax) * ay;
+        r.dx[c] = ((v01 - v00) * (1.f - ay) + (v11 - v10) * ay) * 0.5f * (float)(w - 1);
+        r.dy[c] = ((v10 - v00) * (1.f - ax) + (v11 - v01) * ax) * 0.5f * (float)(h - 1);
+    }
+    return r;
+}
+
+enum : uint32_t { kClamp1 = 1, kClamp2 = 2, kBehind = 4, kValid = 8 };
+
+struct AuxGeom {   // shared by the forward and the backward kernel
+    float xp, yp;
+    int src1;       // flat index of the source pixel in the (hd, wd) depth images
+    float d1, d2;
+    uint32_t flags;
+    float pc1[3], pc2[3], rot[3];
+};
+
+__device__ __forceinline__ AuxGeom aux_geometry(const AuxArgs& a, int i) {
+    AuxGeom g;
+    const int y = i / a.wr, x = i - y * a.wr;
+    g.xp = 2.f * (float)x / (float)(a.wr - 1) - 1.f;
+    g.yp = 2.f * (float)y / (float)(a.hr - 1) - 1.f;
+    g.src1 = aux_nearest_src(y, a.hr, a.hd) * a.wd + aux_nearest_src(x, a.wr, a.wd);
+    g.d1 = a.d1_img[g.src1];
+    g.d2 = a.d2_img[g.src1];
+    g.flags = 0;
+    if (g.d1 < a.nl) { g.d1 = a.nl; g.flags |= kClamp1; }
+    if (g.d2 < a.nl) { g.d2 = a.nl; g.flags |= kClamp2; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float* k = a.Kinv + 4 * r;
+        g.pc1[r] = k[0] * (g.xp * g.d1) + k[1] * (g.yp * g.d1) + k[2] * g.d1 + k[3];
+        g.pc2[r] = k[0] * (g.xp * g.d2) + k[1] * (g.yp * g.d2) + k[2] * g.d2 + k[3];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) g.rot[r] = a.rel[4 * r] * g.pc1[0] + a.rel[4 * r + 1] * g.pc1[1] + a.rel[4 * r + 2] * g.pc1[2] + a.rel[4 * r + 3];
+    if (-g.rot[2] < a.nl) g.flags |= kBehind;
+    return g;
+}
+
+// projection of the (possibly replaced) rotated point: q = K[:3,:] [p;1], xy = q.xy / q.z
+__device__ __forceinline__ void aux_project(const AuxArgs& a, const AuxGeom& g, float (&q)[3], float (&xy)[2]) {
+    float p[3] = {g.rot[0], g.rot[1], g.rot[2]};
+    if (g.flags & kBehind) p[0] = p[1] = p[2] = a.nl;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) q[r] = a.K[4 * r] * p[0] + a.K[4 * r + 1] * p[1] + a.K[4 * r + 2] * p[2] + a.K[4 * r + 3];
+    xy[0] = q[0] / q[2];
+    xy[1] = q[1] / q[2];
+}
+
+__device__ __forceinline__ float block_sum(float v, float* scratch) {   // sum over a 256-thread block, result in thread 0
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    __syncthreads();
+    return r;
+}
+
+// forward: X, Y for the nearest-neighbour search; the re-projection loss sum / count; d(point loss)/d(xy) for the backward
+__global__ __launch_bounds__(256) void aux_points_fwd_kernel(AuxArgs a) {
+    __shared__ float scratch[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float lsum = 0.f, lcnt = 0.f;
+    if (i < a.S) {
+        const AuxGeom g = aux_geometry(a, i);
+        const float s2 = (a.flags & NNR_AUX_SCALE_PCS) ? a.scale2[0] : 1.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            a.X[3 * i + r] = g.rot[r] / s2;
+            a.Y[3 * i + r] = g.pc2[r] / s2;
+        }
+        float gxy0 = 0.f, gxy1 = 0.f;
+        uint32_t fl = g.flags;
+        if (a.flags & NNR_AUX_RGBS) {
+            float q[3], xy[2];
+            aux_project(a, g, q, xy);
+            if (fmaxf(fabsf(xy[0]), fabsf(xy[1])) <= 1.f) {
+                fl |= kValid;
+                const Bilinear s1 = sample_bilinear(a.img1r, a.hr, a.wr, g.xp, g.yp);
+                const Bilinear s2b = sample_bilinear(a.img2r, a.hr, a.wr, xy[0], xy[1]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float u = s1.v[c] - s2b.v[c], au = fabsf(u);
+                    lsum += fminf(au, 1.f);
+                    // d clamp(|u|,0,1)/d rgb2 = -sign(u) inside (0,1), 0 at the clamps (torch: clamp passes the gradient at the
+                    // bounds, abs gives 0 at 0)
+                    const float gu = (au > 0.f && au <= 1.f) ? (u > 0.f ? -1.f : 1.f) : 0.f;
+                    gxy0 += gu * s2b.dx[c];
+                    gxy1 += gu * s2b.dy[c];
+                }
+                lcnt = 1.f;
+            }
+            a.gxy[2 * i] = gxy0;
+            a.gxy[2 * i + 1] = gxy1;
+        }
+        a.pflags[i] = fl;
+    }
+    const float bs = block_sum(lsum, scratch), bc = block_sum(lcnt, scratch);
+    if (threadIdx.x == 0 && (a.flags & NNR_AUX_RGBS)) {
+        atomicAdd(a.acc + 0, bs);
+        atomicAdd(a.acc + 1, bc);
+    }
+}
+
+// keys for both directions in one launch
+__global__ void aux_fill_keys_kernel(unsigned long long* keys, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = ~0ull;
+}
+
+// decode (distance bits << 32 | index) and sum the distances of one direction into acc[slot]
+__global__ __launch_bounds__(256) void aux_decode_kernel(const unsigned long long* keys, int S, int64_t* idx, float* dist, float* acc_slot) {
+    __shared__ float scratch[4];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    float d = 0.f;
+    if (s < S) {
+        const unsigned long long k = keys[s];
+        idx[s] = (int64_t)(unsigned int)(k & 0xffffffffu);
+        d = __uint_as_float((unsigned int)(k >> 32));
+        dist[s] = d;
+    }
+    const float bs = block_sum(d, scratch);
+    if (threadIdx.x == 0) atomicAdd(acc_slot, bs);
+}
+
+// out = [loss_pc, loss_rgb_s, n_valid, 0]
+__global__ void aux_finish_kernel(AuxArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    a.out[0] = (a.flags & NNR_AUX_PC) ? (a.acc[2] + a.acc[3]) / (float)a.S : 0.f;
+    a.out[1] = (a.flags & NNR_AUX_RGBS) && a.acc[1] > 0.f ? a.acc[0] / (3.f * a.acc[1]) : 0.f;
+    a.out[2] = a.acc[1];
+    a.out[3] = 0.f;
+}
+
+// d mean_s dist[s] * coef, ACCUMULATED: g_src[s] += w (src_s - dst_j), g_dst[j] -= the same (atomics: shared destinations)
+__global__ void aux_pc_bwd_kernel(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_out, int S,
+                                  float* g_src, float* g_dst) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int64_t j = idx[s];
+    const float dd = dist[s];
+    const float w = dd > 0.f ? g_out[0] / ((float)S * dd) : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = w * (src[3 * s + c] - dst[3 * j + c]);
+        atomicAdd(g_src + 3 * s + c, v);
+        atomicAdd(g_dst + 3 * j + c, -v);
+    }
+}
+
+// backward per point: chain gX, gY (point-cloud loss) and the saved d(point loss)/d(xy) (re-projection loss) back to the
+// two depth images, the relative transform and scale2
+__global__ __launch_bounds__(256) void aux_points_bwd_kernel(AuxArgs a) {
+    __shared__ float scratch[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float acc[13];   // dL/d rel[r][0..3] for r = 0..2, dL/d scale2
+#pragma unroll
+    for (int k = 0; k < 13; ++k) acc[k] = 0.f;
+    if (i < a.S) {
+        const AuxGeom g = aux_geometry(a, i);
+        const uint32_t fl = a.pflags[i];
+        const bool scale = (a.flags & NNR_AUX_SCALE_PCS) != 0;
+        const float s2 = scale ? a.scale2[0] : 1.f;
+        float g_rot[3] = {0.f, 0.f, 0.f}, g_rot_s[3] = {0.f, 0.f, 0.f}, g_pc2[3] = {0.f, 0.f, 0.f};
+        if (a.flags & NNR_AUX_PC) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float gx = a.gX[3 * i + r], gy = a.gY[3 * i + r];
+                g_rot[r] = gx / s2;
+                g_pc2[r] = gy / s2;
+                if (scale) acc[12] -= (gx * a.X[3 * i + r] + gy * a.Y[3 * i + r]) / s2;
+            }
+        }
+        if ((a.flags & NNR_AUX_RGBS) && (fl & kValid) && !(fl & kBehind) && a.acc[1] > 0.f) {
+            float q[3], xy[2];
+            aux_project(a, g, q, xy);
+            const float coef = a.g_out[1] / (3.f * a.acc[1]);
+            const float gx = a.gxy[2 * i] * coef, gy = a.gxy[2 * i + 1] * coef;
+            const float gq[3] = {gx / q[2], gy / q[2], -(gx * q[0] + gy * q[1]) / (q[2] * q[2])};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g_rot_s[c] = a.K[c] * gq[0] + a.K[4 + c] * gq[1] + a.K[8 + c] * gq[2];
+        }
+        float g_pc1[3] = {0.f, 0.f, 0.f};
+        const bool detach = (a.flags & NNR_AUX_DETACH_RGBS) != 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float gt = g_rot[r] + g_rot_s[r];
+            acc[4 * r + 0] = gt * g.pc1[0];
+            acc[4 * r + 1] = gt * g.pc1[1];
+            acc[4 * r + 2] = gt * g.pc1[2];
+            acc[4 * r + 3] = gt;
+            const float gp = g_rot[r] + (detach ? 0.f : g_rot_s[r]);   // detach_rgbs_scale: the re-projection sees a detached cloud
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g_pc1[c] += a.rel[4 * r + c] * gp;
+        }
+        // pc = Kinv[:, :3] (x' d, y' d, d) + Kinv[:, 3]  ->  d pc / d d = Kinv[:, :3] (x', y', 1)
+        float gd1 = 0.f, gd2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float* k = a.Kinv + 4 * r;
+            const float dir = k[0] * g.xp + k[1] * g.yp + k[2];
+            gd1 += g_pc1[r] * dir;
+            gd2 += g_pc2[r] * dir;
+        }
+        if (a.g_d1_img && !(fl & kClamp1) && gd1 != 0.f) atomicAdd(a.g_d1_img + g.src1, gd1);
+        if (a.g_d2_img && !(fl & kClamp2) && gd2 != 0.f) atomicAdd(a.g_d2_img + g.src1, gd2);
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const float bs = block_sum(acc[k], scratch);
+        if (threadIdx.x == 0 && bs != 0.f) atomicAdd(a.g_acc + k, bs);
+    }
+}
+
+hipError_t launch_aux_fwd(const AuxArgs& a, hipStream_t st) {
+    const int S = a.S, nb = (S + 255) / 256;
+    hipError_t e = hipMemsetAsync(a.acc, 0, 8 * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(aux_points_fwd_kernel, dim3(nb), dim3(256), 0, st, a);
+    if (a.flags & NNR_AUX_PC) {
+        hipLaunchKernelGGL(aux_fill_keys_kernel, dim3((2 * S + 255) / 256), dim3(256), 0, st, a.keys, 2 * S);
+        e = launch_pc_nearest_keys(a.X, a.Y, S, S, a.keys, st);
+        if (e != hipSuccess) return e;
+        e = launch_pc_nearest_keys(a.Y, a.X, S, S, a.keys + S, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(aux_decode_kernel, dim3(nb), dim3(256), 0, st, a.keys, S, a.idx_xy, a.dist_xy, a.acc + 2);
+        hipLaunchKernelGGL(aux_decode_kernel, dim3(nb), dim3(256), 0, st, a.keys + S, S, a.idx_yx, a.dist_yx, a.acc + 3);
+    }
+    hipLaunchKernelGGL(aux_finish_kernel, dim3(1), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_aux_bwd(const AuxArgs& a, hipStream_t st) {
+    const int S = a.S, nb = (S + 255) / 256;
+    hipError_t e = hipMemsetAsync(a.g_acc, 0, 16 * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    if (a.flags & NNR_AUX_PC) {
+        e = hipMemsetAsync(a.gX, 0, (size_t)6 * S * sizeof(float), st);   // gX and gY are adjacent
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(aux_pc_bwd_kernel, dim3(nb), dim3(256), 0, st, a.X, a.Y, a.idx_xy, a.dist_xy, a.g_out, S, a.gX, a.gY);
+        hipLaunchKernelGGL(aux_pc_bwd_kernel, dim3(nb), dim3(256), 0, st, a.Y, a.X, a.idx_yx, a.dist_yx, a.g_out, S, a.gY, a.gX);
+    }
+    hipLaunchKernelGGL(aux_points_bwd_kernel, dim3(nb), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace nnr

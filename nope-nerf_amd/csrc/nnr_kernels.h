@@ -109,6 +109,31 @@ hipError_t launch_depth_gather_fwd(const float* img, const int64_t* idx, float* 
 hipError_t launch_depth_gather_bwd(const float* g, const int64_t* idx, float* g_img, int R, int h, int w, int hd, int wd, hipStream_t st);
 hipError_t launch_render_loss(const LossArgs& a, hipStream_t st);
 hipError_t launch_pixels_from_index(const int64_t* idx, float* out, int R, int h, int w, hipStream_t st);
+// per-image losses (nnr_aux.hip); flags = NNR_AUX_* of nnr.h
+struct AuxArgs {
+    const float *d1_img, *d2_img;   // (hd, wd) scaled / shifted depth maps of frame 1 and 2
+    const float *img1r, *img2r;     // (3, hr, wr) images resized to the sampling grid
+    const float *K, *Kinv, *rel;    // 4x4 row-major
+    const float* scale2;            // device scalar (read only with NNR_AUX_SCALE_PCS)
+    int hd, wd, hr, wr, S;
+    float nl;
+    uint32_t flags;
+    // workspace
+    float *X, *Y, *gxy, *gX, *gY;   // (S,3) (S,3) (S,2) (S,3) (S,3); gX and gY adjacent
+    uint32_t* pflags;               // (S)
+    unsigned long long* keys;       // (2S)
+    int64_t *idx_xy, *idx_yx;
+    float *dist_xy, *dist_yx;
+    float* acc;                     // 8: rgb_s sum, valid count, sum dist xy, sum dist yx
+    float* out;                     // 4: loss_pc, loss_rgb_s, n_valid, 0
+    // backward
+    const float* g_out;             // 2: dL/d loss_pc, dL/d loss_rgb_s
+    float *g_d1_img, *g_d2_img;     // (hd, wd), accumulated into; may be null
+    float* g_acc;                   // 16: dL/d rel rows 0..2 (12), dL/d scale2 (1)
+};
+hipError_t launch_aux_fwd(const AuxArgs& a, hipStream_t st);
+hipError_t launch_aux_bwd(const AuxArgs& a, hipStream_t st);
+hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int D, unsigned long long* keys, hipStream_t st);
 hipError_t launch_pc_nearest(const float* src, const float* dst, int S, int D, int64_t* idx, float* dist, unsigned long long* keys,
                              hipStream_t st);
 hipError_t launch_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_loss, int S,

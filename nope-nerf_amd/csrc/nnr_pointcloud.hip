@@ -113,8 +113,8 @@ __global__ void pc_error_bwd_kernel(const float* __restrict__ src, const float* 
     }
 }
 
-hipError_t launch_pc_nearest(const float* src, const float* dst, int S, int D, int64_t* idx, float* dist, unsigned long long* keys,
-                             hipStream_t st) {
+// keys must hold ~0 (or earlier candidates): the search only lowers them
+hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int D, unsigned long long* keys, hipStream_t st) {
     // enough workgroups to fill the chip: split the destination range until there are ~4 per CU
     const int bx = (S + kPcBlock * kPcPer - 1) / (kPcBlock * kPcPer);
     int split = (1024 + bx - 1) / bx;
@@ -122,8 +122,15 @@ hipError_t launch_pc_nearest(const float* src, const float* dst, int S, int D, i
     split = split < 1 ? 1 : (split > max_split ? max_split : split);
     const int d_per_block = ((D + split - 1) / split + 255) / 256 * 256;
     const int by = (D + d_per_block - 1) / d_per_block;
-    hipLaunchKernelGGL(pc_fill_keys_kernel, dim3((S + 255) / 256), dim3(256), 0, st, keys, S);
     hipLaunchKernelGGL(pc_nearest_kernel, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
+    return hipGetLastError();
+}
+
+hipError_t launch_pc_nearest(const float* src, const float* dst, int S, int D, int64_t* idx, float* dist, unsigned long long* keys,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(pc_fill_keys_kernel, dim3((S + 255) / 256), dim3(256), 0, st, keys, S);
+    hipError_t e = launch_pc_nearest_keys(src, dst, S, D, keys, st);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(pc_decode_kernel, dim3((S + 255) / 256), dim3(256), 0, st, keys, S, idx, dist);
     return hipGetLastError();
 }

@@ -121,14 +121,20 @@ class Loss(nn.Module):
         return self.mean_on_mask(diff, valid_points)
 
     def aux_terms(self, ref, t_list=None, X=None, Y=None, rgb_pc1=None, rgb_pc1_proj=None, valid_points=None, d1_proj=None,
-                  d2=None, d2_proj=None, d1=None, weights={}, **kwargs):
+                  d2=None, d2_proj=None, d1=None, weights={}, fused_aux=None, **kwargs):
         """The per-image terms (point cloud, surface reprojection, trajectory smoothness, depth consistency) and their
-        weighted sum; `ref` is any tensor on the target device."""
+        weighted sum; `ref` is any tensor on the target device.  `fused_aux` = (loss_pc, loss_rgb_s) already computed by the
+        fused HIP path (nnr/aux.py) from the same inputs."""
         z = _zero(ref)
         on = lambda k: weights[k] != 0.0
+        if fused_aux is not None:
+            l_pc, l_rgbs = fused_aux
+        else:
+            l_pc = self.get_pc_loss(X, Y) if on('pc_weight') else z
+            l_rgbs = self.get_rgb_s_loss(rgb_pc1, rgb_pc1_proj, valid_points) if on('rgb_s_weight') else z
         parts = {
-            'loss_pc': self.get_pc_loss(X, Y) if on('pc_weight') else z,
-            'loss_rgb_s': self.get_rgb_s_loss(rgb_pc1, rgb_pc1_proj, valid_points) if on('rgb_s_weight') else z,
+            'loss_pc': l_pc if on('pc_weight') else z,
+            'loss_rgb_s': l_rgbs if on('rgb_s_weight') else z,
             'loss_depth_consistency': self.get_depth_consistency_loss(d1_proj, d2, d2_proj, d1)
             if on('depth_consistency_weight') else z,
         }

@@ -265,6 +265,18 @@ class Trainer(object):
         r_rel, t_rel = rel[:, :3, :3], rel[:, :3, 3]
 
         res = (int(h_depth / self.pc_ratio), int(w_depth / self.pc_ratio))
+        dump = (weights['rgb_s_weight'] != 0.0 and (it % self.vis_reprojection_every) == 0 and out_render_path is not None)
+        if d1.is_cuda and not self.optimizer_focal and not self.loss.cfg['with_ssim'] and img.shape[0] == 1 and not dump:
+            # one fused forward / backward pair (nnr/aux.py) instead of ~290 small launches; same inputs, same losses
+            from nnr import aux as nnr_aux
+            rgb_s = weights['rgb_s_weight'] != 0.0
+            i1 = F.interpolate(img1, res, mode='bilinear') if rgb_s else None
+            i2 = F.interpolate(img2, res, mode='bilinear') if rgb_s else None
+            l_pc, l_rgbs, _ = nnr_aux.aux_terms(d1, d2, rel, scale2, i1, i2, camera_mat, self._inverse(camera_mat), res, nl,
+                                                rgb_s=rgb_s, pc=weights['pc_weight'] != 0.0, scale_pcs=bool(self.scale_pcs),
+                                                detach_rgbs_scale=self.detach_rgbs_scale)
+            kwargs.update(fused_aux=(l_pc, l_rgbs), sample_resolution=res)
+            return
         pixel_locations, p_pc = arange_pixels(resolution=res, device=device)
         d1 = F.interpolate(d1, res, mode='nearest')
         d2 = F.interpolate(d2, res, mode='nearest')
@@ -289,7 +301,7 @@ class Trainer(object):
             kwargs['rgb_pc1'] = rgb_pc1.view(*shape, 3)
             kwargs['rgb_pc1_proj'] = rgb_proj.view(*shape, 3)
             kwargs['valid_points'] = valid.view(*shape, 1)
-            if (it % self.vis_reprojection_every) == 0 and out_render_path is not None:
+            if dump:
                 for tag, t in (('img1', kwargs['rgb_pc1']), ('img2', kwargs['rgb_pc1_proj'])):
                     _save_png((t[0] * 255).detach().cpu().numpy().astype(np.uint8),
                               os.path.join(out_render_path, '%d_%04d_%s.png' % (it, img_idx, tag)))

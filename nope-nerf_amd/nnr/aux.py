@@ -1,0 +1,79 @@
+"""The per-image losses between a frame and its neighbour as two fused HIP calls (SURVEY 8 f1 + f2): point-cloud loss and
+surface re-projection loss of reference model/training.py:315-358 + model/losses.py:114-157, forward and backward.
+CUDA tensors only; model/training.py keeps the torch expression for everything this does not cover (CPU, with_ssim,
+a learnable focal length)."""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _AuxTerms(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d1_img, d2_img, rel, scale2, img1r, img2r, K, Kinv, hr, wr, nl, flags):
+        lib = L.load()
+        dev = d1_img.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        d1, d2 = d1_img.detach().contiguous().float(), d2_img.detach().contiguous().float()
+        hd, wd = d1.shape[-2:]
+        cfg = L.AuxCfg(int(hd), int(wd), int(hr), int(wr), float(nl), int(flags))
+        n_ws = lib.nnr_aux_workspace_floats(C.byref(cfg))
+        if n_ws == 0:
+            raise RuntimeError("nnr_aux: bad configuration %r" % ((hd, wd, hr, wr),))
+        ws = torch.empty(n_ws + 2, **f32)
+        ws = ws[(ws.data_ptr() % 8) // 4:]                         # 8-byte alignment for the 64-bit items
+        rel_c, K_c, Kinv_c = (t.detach().reshape(16).contiguous().float() for t in (rel, K, Kinv))
+        s2 = scale2.detach().reshape(1).contiguous().float() if scale2 is not None else None
+        i1 = img1r.detach().contiguous().float() if img1r is not None else None
+        i2 = img2r.detach().contiguous().float() if img2r is not None else None
+        out = torch.empty(4, **f32)
+        p = lambda t: L.ptr(t) if t is not None else None
+        L.check(lib.nnr_aux_terms_fwd(C.byref(cfg), p(d1), p(d2), p(i1), p(i2), p(K_c), p(Kinv_c), p(rel_c), p(s2), p(out), p(ws),
+                                      _st()), "nnr_aux_terms_fwd")
+        ctx.cfg, ctx.ws = cfg, ws
+        ctx.tensors = (d1, d2, i1, i2, K_c, Kinv_c, rel_c, s2)
+        ctx.shapes = (d1_img.shape, d2_img.shape, rel.shape, None if scale2 is None else scale2.shape)
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_pc, g_rgbs, _g_count):
+        lib = L.load()
+        d1, d2, i1, i2, K_c, Kinv_c, rel_c, s2 = ctx.tensors
+        need_d1, need_d2, need_rel, need_s2 = ctx.needs_input_grad[:4]
+        f32 = dict(dtype=torch.float32, device=d1.device)
+        g_out = torch.zeros(2, **f32)
+        if g_pc is not None:
+            g_out[0] = g_pc
+        if g_rgbs is not None:
+            g_out[1] = g_rgbs
+        g_d1 = torch.zeros_like(d1) if need_d1 else None
+        g_d2 = torch.zeros_like(d2) if need_d2 else None
+        g_rs = torch.empty(16, **f32)
+        p = lambda t: L.ptr(t) if t is not None else None
+        L.check(lib.nnr_aux_terms_bwd(C.byref(ctx.cfg), p(d1), p(d2), p(i1), p(i2), p(K_c), p(Kinv_c), p(rel_c), p(s2), p(g_out),
+                                      p(g_d1), p(g_d2), p(g_rs), p(ctx.ws), _st()), "nnr_aux_terms_bwd")
+        sh1, sh2, shr, shs = ctx.shapes
+        g_rel = None
+        if need_rel:
+            g_rel = torch.cat([g_rs[:12], torch.zeros(4, **f32)]).view(shr)
+        g_s2 = g_rs[12].view(shs) if (need_s2 and shs is not None) else None
+        return (g_d1.view(sh1) if need_d1 else None, g_d2.view(sh2) if need_d2 else None, g_rel, g_s2,
+                None, None, None, None, None, None, None, None)
+
+
+def aux_terms(d1_img, d2_img, rel, scale2, img1r, img2r, K, Kinv, res, nearest_limit, *, rgb_s=True, pc=True, scale_pcs=True,
+              detach_rgbs_scale=False):
+    """(loss_pc, loss_rgb_s, n_valid) for one frame pair.  d1_img/d2_img: (..., hd, wd) depth maps (scaled + shifted), rel:
+    (..., 4, 4) relative transform, scale2: scalar tensor, img1r/img2r: (..., 3, hr, wr), K/Kinv: (..., 4, 4)."""
+    if not d1_img.is_cuda:
+        raise RuntimeError("nnr.aux needs CUDA tensors (no CPU fallback)")
+    flags = (L.AUX_RGBS if rgb_s else 0) | (L.AUX_PC if pc else 0) | (L.AUX_SCALE_PCS if scale_pcs else 0) | \
+            (L.AUX_DETACH_RGBS if detach_rgbs_scale else 0)
+    return _AuxTerms.apply(d1_img, d2_img, rel, scale2 if scale_pcs else None, img1r, img2r, K, Kinv, int(res[0]), int(res[1]),
+                           float(nearest_limit), flags)

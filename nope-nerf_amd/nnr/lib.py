@@ -27,7 +27,7 @@ EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_
            "nnr_mlp_fwd", "nnr_composite_fwd", "nnr_composite_bwd", "nnr_mlp_dgrad", "nnr_mlp_wgrad", "nnr_ray_reduce",
            "nnr_se3_exp_fwd", "nnr_se3_exp_bwd", "nnr_inv4_fwd", "nnr_inv4_bwd", "nnr_ray_setup_fwd", "nnr_ray_setup_bwd",
            "nnr_depth_gather_fwd", "nnr_depth_gather_bwd", "nnr_render_loss", "nnr_pixels_from_index", "nnr_pc_nearest",
-           "nnr_pc_error_bwd")
+           "nnr_pc_error_bwd", "nnr_aux_workspace_floats", "nnr_aux_terms_fwd", "nnr_aux_terms_bwd")
 
 
 class Cfg(C.Structure):
@@ -36,6 +36,14 @@ class Cfg(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("weight", C.c_void_p * N_LAYERS), ("bias", C.c_void_p * N_LAYERS)]
+
+
+class AuxCfg(C.Structure):
+    _fields_ = [("hd", C.c_int32), ("wd", C.c_int32), ("hr", C.c_int32), ("wr", C.c_int32), ("nearest_limit", C.c_float),
+                ("flags", C.c_uint32)]
+
+
+AUX_RGBS, AUX_PC, AUX_SCALE_PCS, AUX_DETACH_RGBS = 1, 2, 4, 8
 
 
 class WgradJob(C.Structure):
@@ -89,6 +97,11 @@ def load():
     lib.nnr_depth_gather_bwd.argtypes = [vp, vp, vp] + [i32] * 5 + [vp]
     lib.nnr_pixels_from_index.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.nnr_pc_nearest.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
+    auxp = C.POINTER(AuxCfg)
+    lib.nnr_aux_workspace_floats.restype = C.c_size_t
+    lib.nnr_aux_workspace_floats.argtypes = [auxp]
+    lib.nnr_aux_terms_fwd.argtypes = [auxp] + [vp] * 11
+    lib.nnr_aux_terms_bwd.argtypes = [auxp] + [vp] * 14
     lib.nnr_pc_error_bwd.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
     lib.nnr_render_loss.argtypes = [vp] * 5 + [i32] + [f32] * 4 + [i32] * 3 + [vp] * 6
     for n in EXPORTS:

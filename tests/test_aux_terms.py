@@ -37,11 +37,9 @@ def test_oracle_aux_scope_matches_reference_golden(name):
         np.testing.assert_allclose(g.numpy(), GOLD[f"{name}.gaux.{k}"], rtol=0, atol=2e-6, err_msg=k)
 
 
-def _trainer(inp, dev):
+def _trainer(inp, dev, **training_overrides):
     import model as mdl
-    import golden_util as gu
-    cfg = gu.trainer_cfg(128, R, N) if hasattr(gu, "trainer_cfg") else None
-    if cfg is None:
+    if True:
         cfg = {
             'model': {'hidden_dim': 128, 'pos_enc_levels': 10, 'dir_enc_levels': 4, 'occ_activation': 'softplus'},
             'rendering': {'type': 'nope_nerf', 'n_max_network_queries': 64000, 'white_background': False, 'radius': 4.0,
@@ -56,6 +54,7 @@ def _trainer(inp, dev):
                 'depth_consistency_weight': [0.0, 0.0], 'weight_dist_2nd_loss': [0.0, 0.0], 'weight_dist_1st_loss': [0.0, 0.0],
                 'depth_loss_type': 'l1', 'with_ssim': False, 'with_auto_mask': False},
         }
+    cfg['training'].update(training_overrides)
     net = mdl.OfficialStaticNerf(cfg)
     wts = np.load(os.path.join(HERE, "golden", "weights_d128.npz"))
     net.load_state_dict({k: torch.from_numpy(wts[k]) for k in wts.files})
@@ -96,3 +95,57 @@ def test_trainer_step_with_per_image_losses_matches_reference_golden(name, monke
         g = g.cpu().numpy() if g is not None else np.zeros_like(ref_g)
         scale = max(1.0, float(np.abs(ref_g).max()))
         assert float(np.abs(g - ref_g).max()) / scale <= 1e-4, (k, float(np.abs(g - ref_g).max()), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,flags", [
+    ("mid", dict(scale_pcs=False)), ("mid", dict(detach_rgbs_scale=True)), ("mid", dict(pc_weight=[0.0, 0.0])),
+    ("mid", dict(rgb_s_weight=[0.0, 0.0])), ("last", dict(detach_rgbs_scale=True, scale_pcs=False)), ("mid", dict(shift_first=True)),
+])
+def test_fused_per_image_terms_match_oracle_for_every_flag(name, flags):
+    """Only the per-image terms (render weights 0), every configuration switch of reference training.py:325-357, against
+    the oracle restatement (itself pinned to the reference for the default switches)."""
+    import nerf_oracle as orc
+    dev = torch.device("cuda")
+    inp = _inp(name)
+    cam, ref = int(GOLD[f"{name}.cam"]), int(GOLD[f"{name}.ref"])
+    over = dict(rgb_weight=[0.0, 0.0], depth_weight=[0.0, 0.0])
+    over.update(flags)
+    tr, pose, dist = _trainer(inp, dev, **over)
+    data = {"img": inp["img"].to(dev), "img.idx": cam, "img.dpt": inp["dpt"].to(dev), "img.camera_mat": inp["K"].to(dev),
+            "img.scale_mat": torch.eye(4).unsqueeze(0).to(dev), "img.ref_imgs": inp["ref_img"].to(dev),
+            "img.ref_dpts": inp["ref_dpt"].to(dev), "img.ref_idxs": ref}
+    ld = tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
+    leaves = {k: inp[k].clone().requires_grad_(True) for k in ("pose_r", "pose_t", "scales", "shifts")}
+    kw = dict(pc_weight=over.get("pc_weight", [1.0])[0], rgb_s_weight=over.get("rgb_s_weight", [1.0])[0],
+              scale_pcs=over.get("scale_pcs", True), detach_rgbs_scale=over.get("detach_rgbs_scale", False),
+              shift_first=over.get("shift_first", False))
+    aux, l_pc, l_rgbs = orc.aux_scope(leaves["pose_r"], leaves["pose_t"], leaves["scales"], leaves["shifts"], cam, ref, inp["K"],
+                                      inp["dpt"].unsqueeze(1), inp["ref_dpt"].unsqueeze(1), inp["img"], inp["ref_img"], **kw)
+    aux.backward()
+    np.testing.assert_allclose(float(ld["loss_pc"]), float(l_pc), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(float(ld["loss_rgb_s"]), float(l_rgbs), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(float(ld["loss"]), float(aux), rtol=0, atol=1e-5)
+    got = {"pose_r": pose.r.grad, "pose_t": pose.t.grad, "scales": dist.global_scales.grad, "shifts": dist.global_shifts.grad}
+    for k, g in got.items():
+        ref_g = leaves[k].grad.numpy() if leaves[k].grad is not None else np.zeros_like(inp[k].numpy())
+        g = g.cpu().numpy() if g is not None else np.zeros_like(ref_g)
+        scale = max(1.0, float(np.abs(ref_g).max()))
+        assert float(np.abs(g - ref_g).max()) / scale <= 1e-4, (k, flags, float(np.abs(g - ref_g).max()), scale)
+
+
+@pytest.mark.gpu
+def test_fused_path_is_the_one_that_runs(monkeypatch):
+    """The trainer must reach libnnr.so for the per-image terms on the GPU (no silent torch fallback)."""
+    from nnr import aux as nnr_aux
+    calls = []
+    real = nnr_aux.aux_terms
+    monkeypatch.setattr(nnr_aux, "aux_terms", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    dev = torch.device("cuda")
+    inp = _inp("mid")
+    tr, _, _ = _trainer(inp, dev)
+    data = {"img": inp["img"].to(dev), "img.idx": 2, "img.dpt": inp["dpt"].to(dev), "img.camera_mat": inp["K"].to(dev),
+            "img.scale_mat": torch.eye(4).unsqueeze(0).to(dev), "img.ref_imgs": inp["ref_img"].to(dev),
+            "img.ref_dpts": inp["ref_dpt"].to(dev), "img.ref_idxs": 3}
+    tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
+    assert calls == [1]
