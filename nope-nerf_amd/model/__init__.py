@@ -1,12 +1,15 @@
-"""`import model as mdl` -- the reference's public surface (reference model/__init__.py:1-10), backed by the
-MI355X-native render path in `nnr` (libnnr.so)."""
-from model.checkpoints import CheckpointIO
-from model.network import nope_nerf
-from model.training import Trainer
-from model.rendering import Renderer
-from model.config import get_model
-from model.official_nerf import OfficialStaticNerf
-from model.poses import LearnPose
-from model.intrinsics import LearnFocal
-from model.eval_pose_one_epoch import Trainer_pose
-from model.distortions import Learn_Distortion
+"""`import model as mdl` -- the reference's public surface (same ten names as reference model/__init__.py), backed by the
+MI355X-native render path in `nnr` (libnnr.so).  The names are resolved from one table so that the surface is stated once
+and checked at import time."""
+import importlib
+
+_EXPORTS = {
+    'CheckpointIO': 'checkpoints', 'nope_nerf': 'network', 'Trainer': 'training', 'Renderer': 'rendering',
+    'get_model': 'config', 'OfficialStaticNerf': 'official_nerf', 'LearnPose': 'poses', 'LearnFocal': 'intrinsics',
+    'Trainer_pose': 'eval_pose_one_epoch', 'Learn_Distortion': 'distortions',
+}
+__all__ = sorted(_EXPORTS)
+
+for _name, _module in _EXPORTS.items():
+    globals()[_name] = getattr(importlib.import_module('model.' + _module), _name)
+del _name, _module
