@@ -150,7 +150,7 @@ def kernel_roofline(net, device, reps=5):
         'composite_fwd': lambda: lib.nnr_composite_fwd(C.byref(cfg), L.ptr(rgb), L.ptr(dst), None, None, L.ptr(ws), st),
         'composite_bwd': lambda: lib.nnr_composite_bwd(C.byref(cfg), L.ptr(d_rgb), L.ptr(d_dst), L.ptr(ws), st),
         'mlp_dgrad': lambda: lib.nnr_mlp_dgrad(C.byref(cfg), L.ptr(packed), L.ptr(ws), st),
-        'mlp_wgrad': lambda: lib.nnr_mlp_wgrad(C.byref(cfg), C.byref(gs), L.ptr(plan), L.ptr(ws), st),
+        'mlp_wgrad': lambda: lib.nnr_mlp_wgrad(C.byref(cfg), L.ptr(packed), C.byref(gs), L.ptr(plan), L.ptr(ws), st),
     }
     cfg_inf = L.make_cfg(R, N, D)      # forward-only variant (eval / visualisation): no stash
     ws_inf = torch.empty(lib.nnr_workspace_floats(C.byref(cfg_inf)), device=device)

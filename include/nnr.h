@@ -127,7 +127,7 @@ int nnr_composite_fwd(const nnr_cfg* cfg, float* rgb, float* dist, float* opt_al
                       float* workspace, void* stream);
 int nnr_composite_bwd(const nnr_cfg* cfg, const float* d_rgb, const float* d_dist, float* workspace, void* stream);
 int nnr_mlp_dgrad(const nnr_cfg* cfg, const float* packed, float* workspace, void* stream);
-int nnr_mlp_wgrad(const nnr_cfg* cfg, const nnr_param_grads* grads_host, const void* plan, float* workspace,
+int nnr_mlp_wgrad(const nnr_cfg* cfg, const float* packed, const nnr_param_grads* grads_host, const void* plan, float* workspace,
                   void* stream);
 int nnr_ray_reduce(const nnr_cfg* cfg, float* d_pts_o, float* d_pts_d, float* d_view, float* workspace, void* stream);
 

@@ -87,15 +87,16 @@ std::vector<Unit> wgrad_units(int D) {
     dxd(5, P_DH1 + 5, P_XH1 + 4, D, D);
     dxd(6, P_DH1 + 6, P_XH1 + 5, D, D);
     dxd(7, P_DH1 + 7, P_XH1 + 6, D, D);
-    dxd(9, P_DF, P_XH1 + 7, D, D);
     // density head (param 8): 1 x D, gradient operand = column 3 of the per-sample output gradients
     for (int b = 0; b < nb; ++b) add(8, 1, 4, P_DOUT4, 3, 1, P_XH1 + 7, 128 * b, D - 128 * b, 0, 128 * b, 1, D, D, b == 0);
     ++group;
-    // colour hidden (param 10): D/2 x (D + 27)
+    // colour hidden: the merged matrix W' = Wg[:, :D] Wf (D/2 x D, pseudo-parameter kMergedLayer) against hidden 8, and the
+    // direction-encoding columns of param 10 (D/2 x 27 at column D).  dWf, dWg[:, :D], dbf follow from dW', db' in the
+    // un-merge step after the reduction (nnr_wgrad.hip).
     const int mi_g = D == 256 ? 4 : 2;
     for (int b = 0; b < nb; ++b)
-        add(10, mi_g, 4, P_DG, 0, D / 2, P_XF, 128 * b, D - 128 * b, 0, 128 * b, D / 2, D + kDirReal, D + kDirReal, b == 0);
-    add(10, mi_g, 1, P_DG, 0, D / 2, P_XF, D, kDirPad, 0, D, D / 2, D + kDirReal, D + kDirReal, 0);
+        add(kMergedLayer, mi_g, 4, P_DG, 0, D / 2, P_XH1 + 7, 128 * b, D - 128 * b, 0, 128 * b, D / 2, D, D, b == 0);
+    add(10, mi_g, 1, P_DG, 0, D / 2, P_XF, 0, kDirPad, 0, D, D / 2, D + kDirReal, D + kDirReal, 0);
     ++group;
     // rgb (param 11): 3 x D/2, gradient operand = columns 0..2 of the per-sample output gradients
     add(11, 1, D == 256 ? 4 : 2, P_DOUT4, 0, 3, P_XG, 0, D / 2, 0, 0, 3, D / 2, D / 2, 1);
@@ -238,8 +239,9 @@ size_t nnr_packed_floats(const nnr_cfg* cfg) {
 size_t nnr_workspace_floats(const nnr_cfg* cfg) {
     if (check_cfg(cfg) != NNR_OK) return 0;
     const WsLayout w = ws_layout(cfg);
-    // training: the planes, then one partial slot per weight-gradient job
-    return (size_t)w.total() + (w.train ? build_plan(cfg).jobs.size() * (size_t)kSlotFloats : 0);
+    // training: the planes, one partial slot per weight-gradient job, then dW' (D/2 x D) and db' (D/2)
+    const size_t merged = (size_t)(cfg->hidden / 2) * cfg->hidden + cfg->hidden / 2;
+    return (size_t)w.total() + (w.train ? build_plan(cfg).jobs.size() * (size_t)kSlotFloats + merged : 0);
 }
 
 int64_t nnr_ws_plane(const nnr_cfg* cfg, int pl, int32_t* pitch_out) {
@@ -365,7 +367,6 @@ int nnr_mlp_dgrad(const nnr_cfg* cfg, const float* packed, float* ws, void* stre
     a.ws_xf = ws + plane(w, P_XF);
     a.ws_mask = reinterpret_cast<const uint32_t*>(ws + plane(w, P_MASK));
     a.ws_dh = ws + plane(w, P_DH1);
-    a.ws_df = ws + plane(w, P_DF);
     a.ws_dg = ws + plane(w, P_DG);
     a.ws_dpts = ws + plane(w, P_DPTS);
     a.ws_dview = ws + plane(w, P_DVIEW);
@@ -374,10 +375,10 @@ int nnr_mlp_dgrad(const nnr_cfg* cfg, const float* packed, float* ws, void* stre
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
-int nnr_mlp_wgrad(const nnr_cfg* cfg, const nnr_param_grads* g, const void* plan, float* ws, void* stream) {
+int nnr_mlp_wgrad(const nnr_cfg* cfg, const float* packed, const nnr_param_grads* g, const void* plan, float* ws, void* stream) {
     int rc = check_cfg(cfg);
     if (rc != NNR_OK) return rc;
-    if (!(cfg->flags & NNR_F_TRAIN) || !g || !plan || !ws) return NNR_E_BADCFG;
+    if (!(cfg->flags & NNR_F_TRAIN) || !packed || !g || !plan || !ws) return NNR_E_BADCFG;
     const WsLayout w = ws_layout(cfg);
     WgradArgs a{};
     for (int i = 0; i < 12; ++i) {
@@ -399,6 +400,10 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const nnr_param_grads* g, const void* plan
     }
     a.wave_first = reinterpret_cast<const int32_t*>(a.jobs + a.n_jobs);
     a.slots = ws + w.total();
+    a.gw[kMergedLayer] = a.slots + (size_t)a.n_jobs * kSlotFloats;
+    a.gb[kMergedLayer] = a.gw[kMergedLayer] + (size_t)(cfg->hidden / 2) * cfg->hidden;
+    a.packed = packed;
+    a.D = cfg->hidden;
     hipError_t e = launch_wgrad(a, (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
@@ -425,7 +430,7 @@ int nnr_render_bwd(const nnr_cfg* cfg, const float* packed, const float* d_rgb, 
     if (rc != NNR_OK) return rc;
     rc = nnr_mlp_dgrad(cfg, packed, ws, stream);
     if (rc != NNR_OK) return rc;
-    rc = nnr_mlp_wgrad(cfg, grads, plan, ws, stream);
+    rc = nnr_mlp_wgrad(cfg, packed, grads, plan, ws, stream);
     if (rc != NNR_OK) return rc;
     return nnr_ray_reduce(cfg, d_pts_o, d_pts_d, d_view, ws, stream);
 }

@@ -16,7 +16,7 @@ struct MlpFwdArgs {
     float* ws_z;      // (S_pad)
     float* ws_xe;     // (S_pad,64)
     float* ws_xh;     // 8 x (S_pad,D)
-    float* ws_xf;     // (S_pad,D+32)
+    float* ws_xf;     // (S_pad,32): direction encoding
     float* ws_xg;     // (S_pad,D/2)
     uint32_t* ws_mask;
     int64_t S, S_pad;
@@ -27,10 +27,9 @@ struct MlpDgradArgs {
     const float* packed;
     float* ws_dout4;        // (S_pad,4): d rgb_pre[3], d sigma_raw (rows >= S are zero-filled here)
     const float* ws_xe;     // posenc stash (for d gamma/dp)
-    const float* ws_xf;     // [feature|direnc] stash (direnc part used)
+    const float* ws_xf;     // direction-encoding stash
     const uint32_t* ws_mask;
     float* ws_dh;    // 8 x (S_pad,D)
-    float* ws_df;    // (S_pad,D)
     float* ws_dg;    // (S_pad,D/2)
     float* ws_dpts;  // (S_pad,4)
     float* ws_dview; // (S_pad,4)
@@ -54,14 +53,16 @@ struct RayReduceArgs {
 };
 
 struct PackArgs {
-    const float* w[12];
-    const float* b[12];
+    const float* w[13];   // 12 nn.Linear weights + [12] = the merged matrix W' inside `packed` (filled by the launcher)
+    const float* b[13];
     float* packed;
 };
 
 struct WgradArgs {
-    float* gw[12];
-    float* gb[12];
+    float* gw[13];             // [12] = dW' scratch (D/2 x D) in the workspace
+    float* gb[13];             // [12] = db' scratch
+    const float* packed;       // for the un-merge step: copies of Wf, Wg[:, :D], bf (nnr_layout.h merge area)
+    int D;
     const WgradJob* jobs;
     const float* ws;           // workspace base
     float* slots;              // n_jobs partial slots of kSlotFloats (see nnr_layout.h)

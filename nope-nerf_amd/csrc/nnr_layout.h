@@ -44,12 +44,20 @@ constexpr int kPosPad = 64, kDirPad = 32;
 // NEXT layer's pass A -- whose first D/2 k-values only need the A half.  With one wave per SIMD this is the only way to
 // keep the matrix pipe busy during epilogues.  The 1-row density head and the 3-row rgb head are not MFMA work at all
 // (a 32-row tile would be 97 % padding): they are per-lane dot products against the head tables below.
+//
+// The feature layer (model/official_nerf.py:33,87: D -> D, NO activation) feeds only the colour-hidden layer, so the two
+// are one linear map: g = relu(Wg [Wf h8 + bf ; dir] + bg) = relu((Wg[:, :D] Wf) h8 + Wg[:, D:] dir + (Wg[:, :D] bf + bg)).
+// The pack kernel forms the MERGED matrix W' = Wg[:, :D] Wf (D/2 x D) and bias b' once per optimiser step; the MLP kernels
+// never evaluate the feature layer (-10.8 % of the MACs of all three passes, -2 KB/sample of stash), and the weight-gradient
+// kernel produces dW', db', from which dWf = Wg1^T dW', dWg1 = dW' Wf^T + db' bf^T, dbf = Wg1^T db', dbg = db' follow by
+// two small products per step (exact chain rule; fp32 rounding differs from evaluating the layers one by one at the 1e-7 level).
+constexpr int kMergedLayer = 12;   // pseudo-parameter index of W' / b' (after the 12 nn.Linear tensors)
 enum FwdPart {
     F_L1A = 0, F_L1B, F_L2A, F_L2B, F_L3A, F_L3B, F_L4A, F_L4B, F_L5HA, F_L5EA, F_L5HB, F_L5EB,
-    F_L6A, F_L6B, F_L7A, F_L7B, F_L8A, F_L8B, F_FEATA, F_FEATB, F_RGBH_F, F_RGBH_D, F_NPARTS
+    F_L6A, F_L6B, F_L7A, F_L7B, F_L8A, F_L8B, F_RGBH_F, F_RGBH_D, F_NPARTS
 };
 enum BwdPart {
-    B_RGBH_FA = 0, B_RGBH_FB, B_RGBH_D, B_FEATA, B_FEATB, B_L8A, B_L8B, B_L7A, B_L7B, B_L6A, B_L6B,
+    B_RGBH_FA = 0, B_RGBH_FB, B_RGBH_D, B_L8A, B_L8B, B_L7A, B_L7B, B_L6A, B_L6B,
     B_L5E, B_L5HA, B_L5HB, B_L4A, B_L4B, B_L3A, B_L3B, B_L2A, B_L2B, B_L1, B_NPARTS
 };
 
@@ -82,15 +90,13 @@ struct Layout {
             if (q & 1) return {4, 0, 2, HT, Dh, P, half * Dh, D, D + P};
             return {4, 0, DT, HT, Dh, D, half * Dh, 0, D + P};
         }
-        if (p < F_FEATA) return {5 + (p - F_L6A) / 2, 0, DT, HT, Dh, D, (p & 1) * Dh, 0, D};
-        if (p < F_RGBH_F) return {9, 0, DT, HT, Dh, D, (p & 1) * Dh, 0, D};
-        if (p == F_RGBH_F) return {10, 0, DT, HT, Dh, D, 0, 0, D + Q};
+        if (p < F_RGBH_F) return {5 + (p - F_L6A) / 2, 0, DT, HT, Dh, D, (p & 1) * Dh, 0, D};
+        if (p == F_RGBH_F) return {kMergedLayer, 0, DT, HT, Dh, D, 0, 0, D};   // W' (D/2 x D), input h8
         return {10, 0, 1, HT, Dh, Q, 0, D, D + Q};
     }
     NNR_HD static constexpr PartDesc bwd(int p) {
-        if (p < B_RGBH_D) return {10, 1, HT, HT, Dh, Dh, p * Dh, 0, D + Q};
+        if (p < B_RGBH_D) return {kMergedLayer, 1, HT, HT, Dh, Dh, p * Dh, 0, D};   // W'^T: d h8 halves from d g
         if (p == B_RGBH_D) return {10, 1, HT, 1, Q, Dh, D, 0, D + Q};
-        if (p < B_L8A) return {9, 1, DT, HT, Dh, D, (p - B_FEATA) * Dh, 0, D};
         if (p < B_L5E) return {7 - (p - B_L8A) / 2, 1, DT, HT, Dh, D, ((p - B_L8A) & 1) * Dh, 0, D};
         if (p == B_L5E) return {4, 1, DT, 2, P, D, D, 0, D + P};
         if (p < B_L4A) return {4, 1, DT, HT, Dh, D, (p - B_L5HA) * Dh, 0, D + P};
@@ -126,12 +132,19 @@ struct Layout {
     static constexpr int wsig_off = head_base;                  // [2][16*DT]
     static constexpr int wrgb_off = wsig_off + 2 * 16 * DT;     // [3][2][16*HT]
     static constexpr int head_floats = 2 * 16 * DT + 3 * 2 * 16 * HT;
-    static constexpr int packed_floats = head_base + head_floats;
     static constexpr int table_floats = bias_floats + head_floats;  // what the MLP kernels copy into LDS
+    // merge area (row-major): W' [Dh][D], b' [Dh], then copies of Wf [D][D], Wg[:, :D] [Dh][D] and bf [D] for the
+    // un-merge step of the weight-gradient pass.  The bias slot of layer 10 above holds b' (not bg).
+    static constexpr int merged_w_off = head_base + head_floats;
+    static constexpr int merged_b_off = merged_w_off + Dh * D;
+    static constexpr int copy_wf_off = merged_b_off + Dh;
+    static constexpr int copy_wg_off = copy_wf_off + D * D;
+    static constexpr int copy_bf_off = copy_wg_off + Dh * D;
+    static constexpr int packed_floats = copy_bf_off + D;
 
     // ---- workspace planes (floats), S_pad = samples rounded up to a multiple of kBlockSamples ----
-    static constexpr int x_width = kPosPad + 8 * D + (D + kDirPad) + D / 2;  // per-sample activation stash
-    static constexpr int d_width = 8 * D + D + D / 2;                       // per-sample gradient stash
+    static constexpr int x_width = kPosPad + 8 * D + kDirPad + D / 2;  // per-sample activation stash
+    static constexpr int d_width = 8 * D + D / 2;                      // per-sample gradient stash
     static constexpr int mask_words = DT / 2;                                // uint32 per lane per masked layer
     static constexpr int n_mask_layers = 9;                                  // hidden 1..8 + colour hidden
 };
@@ -139,9 +152,9 @@ struct Layout {
 // workspace plane ids (nnr_ws_plane)
 enum Plane {
     P_OUT4 = 0, P_Z = 1, P_DOUT4 = 2, P_DPTS = 3, P_DVIEW = 4,
-    P_XE = 10, P_XH1 = 11, /* .. P_XH8 = 18 */ P_XF = 19, P_XG = 20,
+    P_XE = 10, P_XH1 = 11, /* .. P_XH8 = 18 */ P_XF = 19 /* direction encoding only */, P_XG = 20,
     P_MASK = 25,
-    P_DH1 = 31, /* .. P_DH8 = 38 */ P_DF = 39, P_DG = 40,
+    P_DH1 = 31, /* .. P_DH8 = 38 */ P_DG = 40,
 };
 
 struct WsLayout {
@@ -161,12 +174,12 @@ struct WsLayout {
         if (step(P_DOUT4, 4) || step(P_DPTS, 4) || step(P_DVIEW, 4) || step(P_XE, kPosPad)) { *pitch = w; return o; }
         for (int l = 0; l < 8; ++l)
             if (step(P_XH1 + l, D)) { *pitch = w; return o; }
-        if (step(P_XF, D + kDirPad) || step(P_XG, D / 2)) { *pitch = w; return o; }
+        if (step(P_XF, kDirPad) || step(P_XG, D / 2)) { *pitch = w; return o; }
         // masks: [S_pad/32 chunks][9 layers][64 lanes][D/64 words]  == S_pad * 9 * 2 * (D/64) / ... words per sample: 9*2*(D/64)
         if (step(P_MASK, 9 * 2 * (D / 64))) { *pitch = w; return o; }
         for (int l = 0; l < 8; ++l)
             if (step(P_DH1 + l, D)) { *pitch = w; return o; }
-        if (step(P_DF, D) || step(P_DG, D / 2)) { *pitch = w; return o; }
+        if (step(P_DG, D / 2)) { *pitch = w; return o; }
         if (p == -1) { *pitch = 0; return o; }  // total
         return -1;
     }
@@ -186,7 +199,7 @@ struct WsLayout {
 // each job writes its partial tile to its own slot of the workspace (plain, coalesced stores) and a second small kernel
 // adds the slots of a tile into dW -- ~27 float atomics per weight at the end of every wave cost 7 % of the kernel.
 struct WgradJob {
-    int32_t layer;           // parameter index (state_dict order), -1 = idle wave
+    int32_t layer;           // parameter index (state_dict order); kMergedLayer = the merged feature/colour matrix W'
     int32_t MI, NI;          // 1, 2 or 4
     int32_t d_plane, d_col0, d_valid;  // gradient operand: workspace plane id, first column, valid columns from d_col0
     int32_t x_plane, x_col0, x_valid;  // activation operand

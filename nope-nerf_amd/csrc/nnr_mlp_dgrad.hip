@@ -130,27 +130,10 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
             dg[4 * q + i] = ((mwA[(4 * q + i) >> 5] >> ((4 * q + i) & 31)) & 1u) ? v : 0.f;
         }
     }
-    // [d feat ; d gamma(v)] = Wg^T d g.  Every gradient vector is stashed by the first pass that consumes it (one 16-byte
-    // store per k-group inside the MFMA stream, see gemm_part); the epilogue of each half-output pass runs as side work of
-    // the following pass.
-    zero_acc(accA);
-    gemm_part<HT, HT, true>(accA, dg, pipe, p0(B_RGBH_FA), a.ws_dg + ss * (D / 2) + 4 * half);
-    zero_acc(accB);
-    gemm_part<HT, HT, false, NP, 2, 0>(accB, dg, pipe, p0(B_RGBH_FB), nullptr, NNR_MOVE_PAIR(accA, 0));
-    {
-        float pvd[16];   // stored direction encoding (sin<->cos partners): the loads land under this short pass
-        enc_partners(pvd, a.ws_xf + (live ? s : 0) * (D + kDirPad) + D, kDirReal, half);
-        f32x16 accd[1];
-        zero_acc(accd);
-        gemm_part<HT, 1>(accd, dg, pipe, p0(B_RGBH_D));
-        const f32x4 gv = enc_backward<16>([&](int r) { return accd[0][r]; }, pvd, half);
-        if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dview + 4 * s) = gv;
-    }
-
-    // ---- trunk ----
-    NNR_STAMP(tl_dgrad, 2);
-    auto dh = [&](int hidden_idx /*0..7*/) -> float* { return a.ws_dh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half; };
-    // d h8 = relu'(h8) .* (Wf^T d feat + w_sigma^T d sigma_raw): the rank-1 density term is the accumulator's initial value
+    // [d h8 ; d gamma(v)] from d g.  The feature layer is folded into the colour-hidden layer (nnr_layout.h): d h8 =
+    // relu'(h8) .* (W'^T d g + w_sigma^T d sigma_raw), the rank-1 density term being the accumulator's initial value.
+    // Every gradient vector is stashed by the first pass that consumes it (one 16-byte store per k-group inside the MFMA
+    // stream, see gemm_part); the epilogue of each half-output pass runs as side work of the following pass.
     auto init_sigma = [&](f32x16(&acc)[HT], int hb) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < HT; ++t)
@@ -163,11 +146,24 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     };
     load_mask(mwA, 7, 0);
     init_sigma(accA, 0);
-    gemm_part<DT, HT, true, NP, 2, 0>(accA, d, pipe, p0(B_FEATA), a.ws_df + ss * D + 4 * half, NNR_MOVE_PAIR(accB, HR));
+    gemm_part<HT, HT, true>(accA, dg, pipe, p0(B_RGBH_FA), a.ws_dg + ss * (D / 2) + 4 * half);
     load_mask(mwB, 7, 1);
     init_sigma(accB, 1);
-    gemm_part<DT, HT, false, NP, 2, 1>(accB, d, pipe, p0(B_FEATB), nullptr, NNR_SEL_PAIR(accA, 0, mwA));
+    gemm_part<HT, HT, false, NP, 2, 0>(accB, dg, pipe, p0(B_RGBH_FB), nullptr, NNR_SEL_PAIR(accA, 0, mwA));
+    {
+        float pvd[16];   // stored direction encoding (sin<->cos partners): the loads land under this short pass
+        enc_partners(pvd, a.ws_xf + (live ? s : 0) * kDirPad, kDirReal, half);
+        f32x16 accd[1];
+        zero_acc(accd);
+        gemm_part<HT, 1>(accd, dg, pipe, p0(B_RGBH_D));
+        const f32x4 gv = enc_backward<16>([&](int r) { return accd[0][r]; }, pvd, half);
+        if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dview + 4 * s) = gv;
+    }
+    NNR_STAMP(tl_dgrad, 2);
     NNR_STAMP(tl_dgrad, 3);
+
+    // ---- trunk ----
+    auto dh = [&](int hidden_idx /*0..7*/) -> float* { return a.ws_dh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half; };
     // Invariant from here on: d[0, HR) holds half A of the newest gradient, accB its half B still to be masked (mwB).
 
     // one transposed D x D layer at panel pa: consumes the gradient in d (stashing it to `stash`), produces the gradient of

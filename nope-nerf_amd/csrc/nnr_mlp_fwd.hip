@@ -189,36 +189,34 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     for (int l = 0; l < 3; ++l) dense_layer(5 + l, p0(F_L6A) + 2 * PP * l, xh(4 + l));
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 6);
 
-    // feature: D -> D, no activation.  Pass A finishes hidden 8.  Under pass B the density head -- a per-lane dot product
-    // of h8 with the density row (a 1-row GEMM is not MFMA work) -- consumes each register pair of h8 just before
-    // feature half A overwrites it.
-    init_acc(accA, L::bias_off(9));
+    // colour hidden: g = relu(W' h8 + Wg[:, D:] gamma_4(v) + b'), W' = Wg[:, :D] Wf -- the feature layer (no activation,
+    // model/official_nerf.py:87-89) is folded into this one by the pack kernel, see nnr_layout.h.  One pass (D/2 outputs).
+    // Its side work first finishes hidden 8 (half B), then evaluates the density head -- a per-lane dot product of h8 with
+    // the density row (a 1-row GEMM is not MFMA work).
+    float* const xf = TRAIN ? a.ws_xf + ss * kDirPad + 4 * half : nullptr;
+    init_acc(accA, L::bias_off(10));
     clear_mask(mwB);
-    gemm_part<DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, p0(F_FEATA), xh(7), NNR_RELU_PAIR(accB, HR, mwB));
-    store_mask(mwB, 7, 1);
-    init_acc(accB, L::bias_off(9) + L::Dh);
     float sg0 = 0.f, sg1 = 0.f;
     {
         const float* wsg = bias + L::wsig_off + half * (16 * DT);
-        auto sigma_then_move = [&](int u) __attribute__((always_inline)) {
-            const f32x2 w2 = *reinterpret_cast<const f32x2*>(wsg + 2 * u);
-            sg0 = fmaf(w2[0], h[2 * u], sg0);
-            sg1 = fmaf(w2[1], h[2 * u + 1], sg1);
+        auto finish_then_sigma = [&](int u) __attribute__((always_inline)) {
             if (u < NP) {
-                h[2 * u] = accA[(2 * u) >> 4][(2 * u) & 15];
-                h[2 * u + 1] = accA[(2 * u + 1) >> 4][(2 * u + 1) & 15];
+                NNR_RELU_PAIR(accB, HR, mwB)(u);
+            } else {   // pair u - NP of all 16*DT registers of h8; every register is final by now (see PPG below)
+                const int v = u - NP;
+                const f32x2 w2 = *reinterpret_cast<const f32x2*>(wsg + 2 * v);
+                sg0 = fmaf(w2[0], h[2 * v], sg0);
+                sg1 = fmaf(w2[1], h[2 * v + 1], sg1);
             }
         };
-        gemm_part<DT, HT, false, 2 * NP, 2, 1>(accB, h, pipe, p0(F_FEATB), nullptr, sigma_then_move);
+        // 4 units per k-group: the NP finishing units occupy k-groups [0, NP/4) -- long before k-group 2*DT first reads
+        // h[HR..] -- and the 2*NP density units k-groups [NP/4, 3*NP/4) <= 4*DT
+        gemm_part<DT, HT, TRAIN, 3 * NP, 4, 0>(accA, h, pipe, p0(F_RGBH_F), xh(7), finish_then_sigma);
     }
+    store_mask(mwB, 7, 1);
     const float sg = sg0 + sg1;
     const float sigma_raw = sg + __shfl_xor(sg, 32, 64) + bias[L::bias_off(8)];
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 7);
-
-    // colour hidden: [feat ; gamma_4(v)] -> D/2, ReLU   (input order [feat, dir_enc]: model/official_nerf.py:89)
-    float* const xf = TRAIN ? a.ws_xf + ss * (D + kDirPad) + 4 * half : nullptr;
-    init_acc(accA, L::bias_off(10));
-    gemm_part<DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, p0(F_RGBH_F), xf, NNR_MOVE_PAIR(accB, HR));
     float dir2[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -226,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dir2[4 * q + i] = v[i];
     }
-    gemm_part<1, HT, TRAIN>(accA, dir2, pipe, p0(F_RGBH_D), TRAIN ? xf + D : nullptr);
+    gemm_part<1, HT, TRAIN>(accA, dir2, pipe, p0(F_RGBH_D), xf);
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 8);
     clear_mask(mwA);
 #pragma unroll

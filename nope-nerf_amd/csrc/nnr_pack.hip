@@ -7,6 +7,31 @@
 
 namespace nnr {
 
+// W' = Wg[:, :D] Wf and b' = Wg[:, :D] bf + bg (nnr_layout.h), plus the copies the un-merge step of the weight-gradient pass
+// reads.  One thread per element of W'; products accumulated in index order with fma.
+template <int D>
+__global__ __launch_bounds__(256) void merge_kernel(PackArgs a) {
+    using L = Layout<D>;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* Wf = a.w[9];
+    const float* Wg = a.w[10];
+    constexpr int ldg = D + kDirReal;
+    if (gid < L::Dh * D) {
+        const int m = gid / D, k = gid - m * D;
+        float acc = 0.f;
+        for (int j = 0; j < D; ++j) acc = fmaf(Wg[m * ldg + j], Wf[j * D + k], acc);
+        a.packed[L::merged_w_off + gid] = acc;
+        a.packed[L::copy_wg_off + gid] = Wg[m * ldg + k];
+    }
+    if (gid < L::Dh) {
+        float acc = a.b[10][gid];
+        for (int j = 0; j < D; ++j) acc = fmaf(Wg[gid * ldg + j], a.b[9][j], acc);
+        a.packed[L::merged_b_off + gid] = acc;
+    }
+    if (gid < D) a.packed[L::copy_bf_off + gid] = a.b[9][gid];
+    for (int i = gid; i < D * D; i += gridDim.x * blockDim.x) a.packed[L::copy_wf_off + i] = Wf[i];
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     using L = Layout<D>;
@@ -60,7 +85,8 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
                 const int pad = L::bias_pad(l);
                 if (bi >= o && bi < o + pad) {
                     const int j = (int)(bi - o);
-                    a.packed[L::bias_base + bi] = j < L::bias_real(l) ? a.b[l][j] : 0.f;
+                    // the colour-hidden slot holds the merged bias b'
+                    a.packed[L::bias_base + bi] = j < L::bias_real(l) ? (l == 10 ? a.b[kMergedLayer][j] : a.b[l][j]) : 0.f;
                 }
                 o += pad;
             }
@@ -81,8 +107,12 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
 }
 
 template <int D>
-static hipError_t launch(const PackArgs& a, hipStream_t st) {
+static hipError_t launch(const PackArgs& a0, hipStream_t st) {
     using L = Layout<D>;
+    PackArgs a = a0;
+    a.w[kMergedLayer] = a.packed + L::merged_w_off;
+    a.b[kMergedLayer] = a.packed + L::merged_b_off;
+    hipLaunchKernelGGL((merge_kernel<D>), dim3((L::Dh * D + 255) / 256), dim3(256), 0, st, a);
     const int64_t threads = L::bias_base / 4 + L::table_floats;
     dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     hipLaunchKernelGGL((pack_kernel<D>), grid, block, 0, st, a);

@@ -205,9 +205,49 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
     }
 }
 
+// Un-merge (nnr_layout.h): from dW' (D/2 x D) and db' of the merged matrix W' = Wg1 Wf, b' = Wg1 bf + bg, with Wg1 = Wg[:, :D]:
+//   dWf += Wg1^T dW'      dWg[:, :D] += dW' Wf^T + db' bf^T      dbf += Wg1^T db'      dbg += db'
+// Two (D x D/2 x D) products per step, 0.03 % of the MFMA work of the pass: plain VALU dot products, one output per thread.
+template <int D>
+__global__ __launch_bounds__(256) void wgrad_unmerge_kernel(WgradArgs a) {
+    using L = Layout<D>;
+    constexpr int Dh = L::Dh, ldg = D + kDirReal;
+    const float* Wf = a.packed + L::copy_wf_off;    // [D][D]
+    const float* Wg1 = a.packed + L::copy_wg_off;   // [Dh][D]
+    const float* bf = a.packed + L::copy_bf_off;
+    const float* dWm = a.gw[kMergedLayer];          // [Dh][D]
+    const float* dbm = a.gb[kMergedLayer];
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid < D * D) {                               // dWf[j][k] += sum_m Wg1[m][j] dW'[m][k]
+        const int j = gid / D, k = gid - j * D;
+        float acc = 0.f;
+        for (int m = 0; m < Dh; ++m) acc = fmaf(Wg1[m * D + j], dWm[m * D + k], acc);
+        a.gw[9][gid] += acc;
+    } else if (gid < D * D + Dh * D) {               // dWg[m][j] += sum_k dW'[m][k] Wf[j][k] + db'[m] bf[j]
+        const int t = gid - D * D, m = t / D, j = t - m * D;
+        float acc = dbm[m] * bf[j];
+        for (int k = 0; k < D; ++k) acc = fmaf(dWm[m * D + k], Wf[j * D + k], acc);
+        a.gw[10][m * ldg + j] += acc;
+    } else if (gid < D * D + Dh * D + D) {           // dbf[j] += sum_m Wg1[m][j] db'[m]
+        const int j = gid - D * D - Dh * D;
+        float acc = 0.f;
+        for (int m = 0; m < Dh; ++m) acc = fmaf(Wg1[m * D + j], dbm[m], acc);
+        a.gb[9][j] += acc;
+    } else if (gid < D * D + Dh * D + D + Dh) {      // dbg += db'
+        const int m = gid - D * D - Dh * D - D;
+        a.gb[10][m] += dbm[m];
+    }
+}
+
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
+    const size_t merged = ((size_t)(a.D / 2) * a.D + a.D / 2) * sizeof(float);
+    hipError_t e = hipMemsetAsync(a.gw[kMergedLayer], 0, merged, st);   // dW', db' are accumulated into like any gradient
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(wgrad_kernel, dim3(a.n_waves / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_jobs * 16), dim3(256), 0, st, a);
+    const int threads = a.D * a.D + (a.D / 2) * a.D + a.D + a.D / 2;
+    if (a.D == 256) hipLaunchKernelGGL((wgrad_unmerge_kernel<256>), dim3((threads + 255) / 256), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_unmerge_kernel<128>), dim3((threads + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

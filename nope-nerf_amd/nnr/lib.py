@@ -84,7 +84,7 @@ def load():
     lib.nnr_composite_fwd.argtypes = [cfgp] + [vp] * 6
     lib.nnr_composite_bwd.argtypes = [cfgp] + [vp] * 4
     lib.nnr_mlp_dgrad.argtypes = [cfgp, vp, vp, vp]
-    lib.nnr_mlp_wgrad.argtypes = [cfgp, C.POINTER(Params), vp, vp, vp]
+    lib.nnr_mlp_wgrad.argtypes = [cfgp, vp, C.POINTER(Params), vp, vp, vp]
     lib.nnr_ray_reduce.argtypes = [cfgp] + [vp] * 5
     i32, f32 = C.c_int32, C.c_float
     lib.nnr_se3_exp_fwd.argtypes = [vp, vp, i32, vp, vp]

@@ -193,7 +193,7 @@ class _RenderRays(torch.autograd.Function):
             flat = torch.zeros(int(offs[-1]), **f32)
             views = [flat[offs[i]: offs[i] + sizes[i]].view(ctx.shapes[i]) for i in range(2 * L.N_LAYERS)]
             gs = L.params_struct(views[:L.N_LAYERS], views[L.N_LAYERS:])
-            L.check(lib.nnr_mlp_wgrad(C.byref(cfg), C.byref(gs), L.ptr(_plan_for(cfg, dev)), L.ptr(ws), st), "nnr_mlp_wgrad")
+            L.check(lib.nnr_mlp_wgrad(C.byref(cfg), L.ptr(ctx.packed), C.byref(gs), L.ptr(_plan_for(cfg, dev)), L.ptr(ws), st), "nnr_mlp_wgrad")
             grads = [v if ctx.needs_input_grad[7 + i] else None for i, v in enumerate(views)]
         d_o = d_d = d_v = None
         if need_rays:

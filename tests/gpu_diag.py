@@ -90,9 +90,7 @@ def run(D, R, N, dist_alpha, white_bg, seed=0):
         report(f"hidden {i + 1} activations", plane(11 + i), t[f"h{i + 1}"])
     out4 = plane(0)
     report("sigma_raw", out4[:, 3], t["raw"].reshape(-1))
-    xf = plane(19)
-    report("feature", xf[:, :D], t["f"])
-    report("direnc stash", xf[:, D:D + 27], t["dir"])
+    report("direnc stash", plane(19)[:, :27], t["dir"])   # the feature vector is never formed (merged into the colour layer)
     report("colour hidden", plane(20), t["g"])
     report("rgb (per sample)", out4[:, :3], t["rgb"])
     report("alpha", alpha, t["alpha"])
@@ -112,7 +110,7 @@ def run(D, R, N, dist_alpha, white_bg, seed=0):
     host = np.zeros(nbytes, dtype=np.uint8)
     L.check(lib.nnr_plan_build(C.byref(cfg), host.ctypes.data_as(C.c_void_p)), "plan")
     plan = torch.from_numpy(host).to(dev)
-    L.check(lib.nnr_mlp_wgrad(C.byref(cfg), C.byref(gs), L.ptr(plan), L.ptr(ws), st), "wgrad")
+    L.check(lib.nnr_mlp_wgrad(C.byref(cfg), L.ptr(packed), C.byref(gs), L.ptr(plan), L.ptr(ws), st), "wgrad")
     d_o, d_d, d_v = (torch.empty(R, 3, device=dev) for _ in range(3))
     L.check(lib.nnr_ray_reduce(C.byref(cfg), L.ptr(d_o), L.ptr(d_d), L.ptr(d_v), L.ptr(ws), st), "ray_reduce")
     torch.cuda.synchronize()
@@ -120,7 +118,6 @@ def run(D, R, N, dist_alpha, white_bg, seed=0):
     report("d rgb_pre", dout[:, :3], t["rgbpre"].grad)
     report("d sigma_raw", dout[:, 3], t["raw"].grad.reshape(-1))
     report("d colour hidden pre", plane(40), t["gpre"].grad)
-    report("d feature", plane(39), t["f"].grad)
     for i in range(7, -1, -1):
         report(f"d hidden {i + 1} pre", plane(31 + i), t[f"pre{i + 1}"].grad)
     report("d point", plane(3)[:, :3], t["pts"].grad)

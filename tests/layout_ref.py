@@ -9,6 +9,17 @@ LAYERS = ("layers0.0", "layers0.2", "layers0.4", "layers0.6", "layers1.0", "laye
           "fc_density", "fc_feature", "rgb_layers.0", "fc_rgb")
 
 
+MERGED = 12   # pseudo-layer: the feature layer folded into the colour-hidden layer (nnr_layout.h)
+
+
+def merged(weights, biases, D):
+    """W' = Wg[:, :D] Wf and b' = Wg[:, :D] bf + bg; float64 accumulation rounded once (the device uses an fp32 fma chain:
+    equal to ~1e-7, compared with a tolerance)."""
+    wg1 = weights[10][:, :D].astype(np.float64)
+    return ((wg1 @ weights[9].astype(np.float64)).astype(np.float32),
+            (wg1 @ biases[9].astype(np.float64) + biases[10].astype(np.float64)).astype(np.float32))
+
+
 def fwd_parts(D):
     """(layer, transpose, KT, MT, m_real, k_real, moff, koff) in stream order -- mirrors Layout<D>::fwd."""
     DT, HT, Dh = D // 32, D // 64, D // 2
@@ -19,15 +30,13 @@ def fwd_parts(D):
         parts += [(4, 0, DT, HT, Dh, D, h * Dh, 0), (4, 0, 2, HT, Dh, 63, h * Dh, D)]
     for l in (5, 6, 7):
         parts += [(l, 0, DT, HT, Dh, D, h * Dh, 0) for h in (0, 1)]
-    parts += [(9, 0, DT, HT, Dh, D, h * Dh, 0) for h in (0, 1)]
-    parts += [(10, 0, DT, HT, Dh, D, 0, 0), (10, 0, 1, HT, Dh, 27, 0, D)]
+    parts += [(MERGED, 0, DT, HT, Dh, D, 0, 0), (10, 0, 1, HT, Dh, 27, 0, D)]   # W' = Wg[:, :D] Wf, then the direction columns
     return parts
 
 
 def bwd_parts(D):
     DT, HT, Dh = D // 32, D // 64, D // 2
-    parts = [(10, 1, HT, HT, Dh, Dh, h * Dh, 0) for h in (0, 1)] + [(10, 1, HT, 1, 27, Dh, D, 0)]
-    parts += [(9, 1, DT, HT, Dh, D, h * Dh, 0) for h in (0, 1)]
+    parts = [(MERGED, 1, HT, HT, Dh, Dh, h * Dh, 0) for h in (0, 1)] + [(10, 1, HT, 1, 27, Dh, D, 0)]
     for l in (7, 6, 5):
         parts += [(l, 1, DT, HT, Dh, D, h * Dh, 0) for h in (0, 1)]
     parts += [(4, 1, DT, 2, 63, D, D, 0)] + [(4, 1, DT, HT, Dh, D, h * Dh, 0) for h in (0, 1)]
@@ -92,17 +101,30 @@ def head_tables(weights, D):
     return np.concatenate(out)
 
 
-def pack_all(weights, biases, D):
-    """weights/biases: lists of 12 numpy arrays in state_dict order -> the packed buffer nnr_pack_weights produces."""
-    chunks = []
-    for part in fwd_parts(D) + bwd_parts(D):
-        chunks.append(pack_part(part_matrix(weights[part[0]], part), part[2], part[3]))
-    for b, pad in zip(biases, bias_pads(D)):
-        v = np.zeros(pad, dtype=np.float32)
-        v[:b.size] = b
+def pack_all(weights, biases, D, with_exact_mask=False):
+    """weights/biases: lists of 12 numpy arrays in state_dict order -> the packed buffer nnr_pack_weights produces.
+    with_exact_mask: also a bool array, False where the value derives from the merged matrix (compare with a tolerance)."""
+    wm, bm = merged(weights, biases, D)
+    w13 = list(weights) + [wm]
+    chunks, exact = [], []
+    def put(v, is_exact):
         chunks.append(v)
-    chunks.append(head_tables(weights, D))
-    return np.concatenate(chunks)
+        exact.append(np.full(v.size, is_exact))
+    for part in fwd_parts(D) + bwd_parts(D):
+        put(pack_part(part_matrix(w13[part[0]], part), part[2], part[3]), part[0] != MERGED)
+    for l, (b, pad) in enumerate(zip(biases, bias_pads(D))):
+        v = np.zeros(pad, dtype=np.float32)
+        src = bm if l == 10 else b          # the colour-hidden slot holds the merged bias
+        v[:src.size] = src
+        put(v, l != 10)
+    put(head_tables(weights, D), True)
+    put(wm.reshape(-1), False)
+    put(bm, False)
+    put(weights[9].reshape(-1), True)       # copies for the un-merge step
+    put(np.ascontiguousarray(weights[10][:, :D]).reshape(-1), True)
+    put(biases[9], True)
+    out = np.concatenate(chunks)
+    return (out, np.concatenate(exact)) if with_exact_mask else out
 
 
 # ---- register layout + MFMA emulation -------------------------------------------------------------------------------

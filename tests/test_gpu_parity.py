@@ -92,8 +92,10 @@ def test_pack_kernel_is_bit_exact(D):
     ps = L.params_struct(wd, bd)
     L.check(lib.nnr_pack_weights(C.byref(cfg), C.byref(ps), L.ptr(packed),
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "pack")
-    ref = lr.pack_all([x.numpy() for x in w], [x.numpy() for x in b], D)
-    assert np.array_equal(packed.cpu().numpy(), ref)
+    ref, exact = lr.pack_all([x.numpy() for x in w], [x.numpy() for x in b], D, with_exact_mask=True)
+    got = packed.cpu().numpy()
+    assert np.array_equal(got[exact], ref[exact])                       # pure re-ordering: bit-exact
+    np.testing.assert_allclose(got[~exact], ref[~exact], rtol=0, atol=2e-6)   # merged feature/colour matrix: an fp32 fma chain
     assert _loaded_native()
 
 

@@ -99,13 +99,14 @@ def test_sizes_and_error_codes(D):
     cfg = L.make_cfg(16, 64, D, train=True)
     assert lib.nnr_packed_floats(C.byref(cfg)) == lr.pack_all(W, B, D).size
     S_pad = 16 * 64
-    x_width = 64 + 8 * D + (D + 32) + D // 2
-    d_width = 8 * D + D + D // 2
+    x_width = 64 + 8 * D + 32 + D // 2      # posenc, h1..h8, direction encoding, colour hidden (no feature vector: merged)
+    d_width = 8 * D + D // 2
     expect = S_pad * (4 + 1 + 4 + 4 + 4 + x_width + d_width + 9 * 2 * (D // 64))
     nj = C.c_int32(0)
     assert lib.nnr_plan_counts(C.byref(cfg), C.byref(nj), None) == 0
     n_jobs = nj.value
-    assert lib.nnr_workspace_floats(C.byref(cfg)) == expect + n_jobs * (128 * 128 + 256)   # + one partial slot per job
+    merged = (D // 2) * D + D // 2                # dW', db' of the merged feature/colour matrix
+    assert lib.nnr_workspace_floats(C.byref(cfg)) == expect + n_jobs * (128 * 128 + 256) + merged   # + one partial slot per job
     assert lib.nnr_workspace_floats(C.byref(L.make_cfg(16, 64, D))) == S_pad * 5
     assert lib.nnr_workspace_floats(C.byref(L.make_cfg(16, 64, 192))) == 0        # unsupported width
     assert lib.nnr_pack_weights(C.byref(L.make_cfg(16, 64, 192)), None, None, None) == -2
@@ -121,7 +122,10 @@ def test_wgrad_plan_covers_every_weight_once(D, R, N):
     cfg = L.make_cfg(R, N, D, train=True)
     jobs = plan_jobs(cfg)
     S_pad = (R * N + 127) // 128 * 128
-    shapes = [(D, 63), (D, D), (D, D), (D, D), (D, D + 63), (D, D), (D, D), (D, D), (1, D), (D, D), (D // 2, D + 27), (3, D // 2)]
+    # index 12 = the merged feature/colour matrix W' (D/2 x D); the feature layer (9) and the first D columns of the
+    # colour-hidden layer (10) get their gradients from it in the un-merge step, so no job covers them
+    shapes = [(D, 63), (D, D), (D, D), (D, D), (D, D + 63), (D, D), (D, D), (D, D), (1, D), (D, D), (D // 2, D + 27), (3, D // 2),
+              (D // 2, D)]
     cover = [np.zeros(s, dtype=np.int64) for s in shapes]
     bias_cover = [np.zeros(s[0], dtype=np.int64) for s in shapes]
     m = np.arange(32)
@@ -137,9 +141,14 @@ def test_wgrad_plan_covers_every_weight_once(D, R, N):
         cover[j.layer][np.ix_(rows, cols)] += j.k1 - j.k0
         if j.bias:   # 1: every sample pair; 2 / 3: the even / odd pairs (shared between the two tiles of a row block)
             bias_cover[j.layer][rows] += (j.k1 - j.k0) * (2 if j.bias == 1 else 1)
-    for l in range(12):
-        assert np.all(cover[l] == S_pad), (l, np.unique(cover[l]))
-        assert np.all(bias_cover[l] == 2 * S_pad), l
+    for l in range(13):
+        if l == 9:
+            assert not cover[l].any() and not bias_cover[l].any()
+        elif l == 10:
+            assert not cover[l][:, :D].any() and np.all(cover[l][:, D:] == S_pad) and not bias_cover[l].any()
+        else:
+            assert np.all(cover[l] == S_pad), (l, np.unique(cover[l]))
+            assert np.all(bias_cover[l] == 2 * S_pad), l
     allj, first = plan_jobs(cfg, with_waves=True)
     assert (len(first) - 1) % 4 == 0 and (len(first) - 1) // 4 <= 256 and first[0] == 0 and first[-1] == len(allj)
     assert all(a <= b for a, b in zip(first, first[1:]))
