@@ -39,7 +39,7 @@ FLOP_PER_SAMPLE_PASS = 2 * 593408            # forward == dgrad == wgrad, BASELI
 PEAK_FP32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
 
 
-def full_cfg(rays_total, aux=False):
+def full_cfg(rays_total, aux=False, bf16=False):
     cfg = {
         'model': {'hidden_dim': HIDDEN, 'pos_enc_levels': 10, 'dir_enc_levels': 4, 'occ_activation': 'softplus'},
         'rendering': {'type': 'nope_nerf', 'n_max_network_queries': 64000, 'white_background': False, 'radius': 4.0,
@@ -56,6 +56,8 @@ def full_cfg(rays_total, aux=False):
             'depth_loss_type': 'l1', 'with_ssim': False, 'with_auto_mask': False,
         },
     }
+    if bf16:  # BASELINE configs[2] arithmetic: bf16 MFMA products, fp32 accumulation (not the headline metric)
+        cfg['rendering']['mfma_dtype'] = 'bf16'
     if aux:   # configs/default.yaml:99-100 -- the first training phase: point-cloud + surface-reprojection losses on
         cfg['training']['pc_weight'] = [1.0, 0.0]
         cfg['training']['rgb_s_weight'] = [1.0, 0.0]
@@ -79,9 +81,9 @@ def synthetic_batch(device, seed=42):
     }
 
 
-def build_trainer(device, world, aux=False):
+def build_trainer(device, world, aux=False, bf16=False):
     import model as mdl
-    cfg = full_cfg(R_PER_GPU * world, aux)
+    cfg = full_cfg(R_PER_GPU * world, aux, bf16)
     torch.manual_seed(42)
     net = mdl.OfficialStaticNerf(cfg)
     model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device=device), cfg, device=device)
@@ -224,6 +226,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--aux', action='store_true',
                     help='also run the per-image point-cloud / reprojection losses of the first training phase (not the headline metric)')
+    ap.add_argument('--bf16', action='store_true',
+                    help='bf16-MFMA mode of the MLP forward / input-gradient kernels (BASELINE configs[2] arithmetic; not the headline metric)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -238,7 +242,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1"
 
-    trainer, net = build_trainer(device, world, args.aux)
+    trainer, net = build_trainer(device, world, args.aux, args.bf16)
     data = synthetic_batch(device)
 
     def step(i):
@@ -269,7 +273,7 @@ def main():
         out = {
             'metric': 'training rays/sec', 'value': round(rays / (ms * 1e-3), 1), 'unit': 'rays/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 products / f32 accumulate' if args.bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: 1024 rays/GPU x 192 samples (64 coarse + 128 fine pinned as one '
                                    '192-sample stratified pass), 8-layer-256 MLP, pose + distortion learnable, fp32; '
                                    'full Trainer.train_step incl. 3 Adam steps; aux per-image losses ' + ('ON (pc + rgb_s)' if args.aux else 'off'),

@@ -41,6 +41,9 @@ extern "C" {
 #define NNR_F_WHITE_BG 2u   /* rendering.white_background (model/rendering.py:145-147) */
 #define NNR_F_RELU_SIGMA 4u /* model.occ_activation != 'softplus' (model/official_nerf.py:77-80) */
 #define NNR_F_TRAIN 8u      /* keep what the backward needs (activation stash, ReLU masks) */
+#define NNR_F_BF16 16u      /* bf16 MFMA with fp32 accumulation in the MLP forward and input-gradient kernels (BASELINE configs[2]);
+                             * everything else -- bias, activations between layers, stash, weight gradients -- stays fp32.  The
+                             * packed-weight buffer has its own size and layout in this mode. */
 
 /* Problem description.  POD, passed by pointer, read on the host only. */
 typedef struct nnr_cfg {

@@ -45,7 +45,11 @@ int64_t plane(const WsLayout& w, int id) {
     return w.plane(id, &pitch);
 }
 
-size_t packed_floats(int D) { return D == 256 ? (size_t)Layout<256>::packed_floats : (size_t)Layout<128>::packed_floats; }
+size_t packed_floats(int D, bool bf16) {
+    if (bf16) return D == 256 ? (size_t)Layout<256, true>::packed_floats : (size_t)Layout<128, true>::packed_floats;
+    return D == 256 ? (size_t)Layout<256>::packed_floats : (size_t)Layout<128>::packed_floats;
+}
+bool is_bf16(const nnr_cfg* c) { return (c->flags & NNR_F_BF16) != 0; }
 
 // ---- weight-gradient plan -------------------------------------------------------------------------------------------
 struct Unit {  // a wave tile before the split over samples
@@ -233,7 +237,7 @@ int nnr_last_hip_error(void) { return g_last_hip; }
 
 size_t nnr_packed_floats(const nnr_cfg* cfg) {
     if (check_cfg(cfg) != NNR_OK) return 0;
-    return packed_floats(cfg->hidden);
+    return packed_floats(cfg->hidden, is_bf16(cfg));
 }
 
 size_t nnr_workspace_floats(const nnr_cfg* cfg) {
@@ -289,7 +293,7 @@ int nnr_pack_weights(const nnr_cfg* cfg, const nnr_params* p, float* packed, voi
         a.b[i] = p->bias[i];
     }
     a.packed = packed;
-    hipError_t e = launch_pack(cfg->hidden, a, (hipStream_t)stream);
+    hipError_t e = launch_pack(cfg->hidden, a, is_bf16(cfg), (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
@@ -313,7 +317,7 @@ int nnr_mlp_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, cons
         a.ws_mask = reinterpret_cast<uint32_t*>(ws + plane(w, P_MASK));
     }
     a.S = w.S; a.S_pad = w.S_pad; a.N = cfg->n_samples;
-    hipError_t e = launch_mlp_fwd(cfg->hidden, a, w.train, (hipStream_t)stream);
+    hipError_t e = launch_mlp_fwd(cfg->hidden, a, w.train, is_bf16(cfg), (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
@@ -371,7 +375,7 @@ int nnr_mlp_dgrad(const nnr_cfg* cfg, const float* packed, float* ws, void* stre
     a.ws_dpts = ws + plane(w, P_DPTS);
     a.ws_dview = ws + plane(w, P_DVIEW);
     a.S = w.S; a.S_pad = w.S_pad;
-    hipError_t e = launch_mlp_dgrad(cfg->hidden, a, (hipStream_t)stream);
+    hipError_t e = launch_mlp_dgrad(cfg->hidden, a, is_bf16(cfg), (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
@@ -404,6 +408,7 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const float* packed, const nnr_param_grads
     a.gb[kMergedLayer] = a.gw[kMergedLayer] + (size_t)(cfg->hidden / 2) * cfg->hidden;
     a.packed = packed;
     a.D = cfg->hidden;
+    a.bf16 = is_bf16(cfg) ? 1 : 0;
     hipError_t e = launch_wgrad(a, (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }

@@ -257,6 +257,116 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
     gemm_part<KT, MT, STASH, 0, 1, 0>(acc, in, pipe, p0, stash, NoSide{});
 }
 
+// ---- bf16-MFMA variant (NNR_F_BF16) ---------------------------------------------------------------------------------
+// Same contract as gemm_part, but a fragment row covers a DOUBLE k-group: 8 consecutive activation registers, converted
+// to bf16 (round to nearest even, v_cvt_pk_bf16_f32), against one 16-byte fragment of 8 bf16 weights through
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Everything outside the product stays fp32: accumulators, bias, side work,
+// stash, masks.  Per row: MT MFMAs of 32 cycles against the same non-MFMA work as two fp32 k-groups, so this variant is
+// bound by issue / HBM, not by the matrix pipe.  PPG counts units per fp32 k-group; a row runs twice as many.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NIN>
+__device__ __forceinline__ bf16x8 pack_row(const float (&in)[NIN], int b) {
+    bf16x8 q;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = (__bf16)in[8 * b + i];
+    return q;
+}
+
+template <int KT, int MT, bool STASH, int NSIDE_, int PPG_, int SHIFT, class Side, int NACC, int NIN>
+__device__ __forceinline__ void gemm_part_bf16(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
+                                               float* stash, const Side& side) {
+#ifdef NNR_ABLATE_NO_SIDE
+    constexpr int NSIDE = 0;   // profiling build only
+#else
+    constexpr int NSIDE = NSIDE_;
+#endif
+    static_assert(MT <= NACC && 16 * KT <= NIN, "tile counts exceed the register arrays");
+    constexpr int G = 2 * KT, GP = part_gp(MT), PPG = 2 * PPG_;
+    auto rows_in = [](int pi) { return (G - pi * GP) < GP ? (G - pi * GP) : GP; };
+    pipe.enter(p0);
+    pipe.pieces(p0 + 2, 0, (8 + rows_in(0) - 1) / rows_in(0));
+    Frags<MT> cur;
+    {
+        const f32x4* buf = pipe.lds + (p0 % kNBuf) * kPanelF4 + pipe.lane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) cur.v[mt] = buf[mt * 64];
+    }
+    bf16x8 bq = pack_row(in, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int u0 = (g - SHIFT) * PPG, um = u0 + (PPG + 1) / 2, u1 = u0 + PPG;
+        Frags<MT> nxt;
+        bf16x8 nq;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.v[j]), bq, acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                if (f * MT / 4 != j) continue;
+                if (f == 0) {          // fragment reads of the next row (panel switch in front of them)
+                    if (g + 1 < G) {
+                        const int pn = p0 + (g + 1) / GP;
+                        if ((g + 1) % GP == 0) pipe.template enter<STASH ? 2 * (GP - 1) : 0>(pn);
+                        const f32x4* buf = pipe.lds + (pn % kNBuf) * kPanelF4 + pipe.lane;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) nxt.v[mt] = buf[(((g + 1) % GP) * MT + mt) * 64];
+                    }
+                } else if (f == 1) {   // next row's B operand; this row's stash (two quads = two 16-byte stores)
+                    if (g + 1 < G) nq = pack_row(in, g + 1);
+                    if constexpr (STASH) {
+                        *reinterpret_cast<f32x4*>(stash + 16 * g) = f32x4{in[8 * g], in[8 * g + 1], in[8 * g + 2], in[8 * g + 3]};
+                        *reinterpret_cast<f32x4*>(stash + 16 * g + 8) = f32x4{in[8 * g + 4], in[8 * g + 5], in[8 * g + 6], in[8 * g + 7]};
+                    }
+                } else if (f == 2) {
+                    if constexpr (NSIDE > 0) {
+#pragma unroll
+                        for (int u = u0; u < um; ++u)
+                            if (u >= 0 && u < NSIDE) side(u);
+                    }
+                } else {
+                    const int pi = g / GP, gi = g % GP;
+                    const int n_in = rows_in(pi);
+                    if (gi == n_in - 1) {
+                        if (g + 1 < G) pipe.pieces(p0 + pi + 3, 0, (8 + rows_in(pi + 1) - 1) / rows_in(pi + 1));
+                    } else {
+                        const int ppk = (8 + n_in - 1) / n_in;
+                        pipe.pieces(p0 + pi + 2, (gi + 1) * ppk, ppk);
+                    }
+                    if constexpr (NSIDE > 0) {
+#pragma unroll
+                        for (int u = um; u < u1; ++u)
+                            if (u >= 0 && u < NSIDE) side(u);
+                    }
+                }
+            }
+        }
+        pin_acc<MT>(acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < G) { cur = nxt; bq = nq; }
+    }
+    if constexpr (NSIDE > 0) {
+#pragma unroll
+        for (int u = (G - SHIFT) * PPG; u < NSIDE; ++u)
+            if (u >= 0) side(u);
+    }
+}
+
+// fp32 or bf16 product, chosen at compile time by the kernel's BF16 template parameter
+template <bool BF16, int KT, int MT, bool STASH, int NSIDE, int PPG, int SHIFT, class Side, int NACC, int NIN>
+__device__ __forceinline__ void gemm_sel(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0, float* stash,
+                                         const Side& side) {
+    if constexpr (BF16) gemm_part_bf16<KT, MT, STASH, NSIDE, PPG, SHIFT>(acc, in, pipe, p0, stash, side);
+    else gemm_part<KT, MT, STASH, NSIDE, PPG, SHIFT>(acc, in, pipe, p0, stash, side);
+}
+template <bool BF16, int KT, int MT, bool STASH = false, int NACC, int NIN>
+__device__ __forceinline__ void gemm_sel(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
+                                         float* stash = nullptr) {
+    gemm_sel<BF16, KT, MT, STASH, 0, 1, 0>(acc, in, pipe, p0, stash, NoSide{});
+}
+
 template <int N>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N]) {
 #pragma unroll

@@ -62,7 +62,7 @@ struct WgradArgs {
     float* gw[13];             // [12] = dW' scratch (D/2 x D) in the workspace
     float* gb[13];             // [12] = db' scratch
     const float* packed;       // for the un-merge step: copies of Wf, Wg[:, :D], bf (nnr_layout.h merge area)
-    int D;
+    int D, bf16;               // bf16: `packed` is the bf16-mode buffer (same merge area, different offsets)
     const WgradJob* jobs;
     const float* ws;           // workspace base
     float* slots;              // n_jobs partial slots of kSlotFloats (see nnr_layout.h)
@@ -139,9 +139,9 @@ hipError_t launch_pc_nearest(const float* src, const float* dst, int S, int D, i
                              hipStream_t st);
 hipError_t launch_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_loss, int S,
                                float* g_src, float* g_dst, hipStream_t st);
-hipError_t launch_pack(int D, const PackArgs& a, hipStream_t st);
-hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st);
-hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st);
+hipError_t launch_pack(int D, const PackArgs& a, bool bf16, hipStream_t st);
+hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, bool bf16, hipStream_t st);
+hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, bool bf16, hipStream_t st);
 hipError_t launch_composite_fwd(const CompositeArgs& a, hipStream_t st);
 hipError_t launch_composite_bwd(const CompositeArgs& a, hipStream_t st);
 hipError_t launch_ray_reduce(const RayReduceArgs& a, hipStream_t st);

@@ -72,10 +72,17 @@ struct PartDesc {
 
 constexpr int kPanelFrags = 32;                 // fragment slots per panel
 constexpr int kPanelFloats = kPanelFrags * 256;  // 32 KiB
-NNR_HD constexpr int part_gp(int MT) { return kPanelFrags / MT; }  // k-groups per panel
-NNR_HD constexpr int part_panels(int KT, int MT) { return (4 * KT + part_gp(MT) - 1) / part_gp(MT); }
+NNR_HD constexpr int part_gp(int MT) { return kPanelFrags / MT; }  // fragment rows (k-groups) per panel
+// fragment rows of a part: fp32 -- one per k-group of 8 (4*KT); bf16 -- one per DOUBLE k-group of 16 (2*KT), see below
+NNR_HD constexpr int part_rows(int KT, bool bf16) { return bf16 ? 2 * KT : 4 * KT; }
+NNR_HD constexpr int part_panels(int KT, int MT, bool bf16 = false) { return (part_rows(KT, bf16) + part_gp(MT) - 1) / part_gp(MT); }
 
-template <int D>
+// BF16 = true: the packed weights of the bf16-MFMA mode (NNR_F_BF16).  A fragment is still 64 lanes x 16 bytes, but holds
+// 8 bf16 per lane: lane l of fragment (b, mt) has A[32*mt + (l&31)][16b + 4h + i] (i = 0..3), then [16b + 8 + 4h + i] with
+// h = l>>5 -- the two k-groups 2b, 2b+1 of the fp32 layout, which is exactly the order in which 8 consecutive activation
+// registers of a lane hold them, so one v_mfma_f32_32x32x16_bf16 consumes 8 registers (packed to bf16) against one fragment
+// (the k labelling inside an MFMA is arbitrary as long as A and B agree).  Biases, head tables and the merge area stay fp32.
+template <int D, bool BF16 = false>
 struct Layout {
     static constexpr int DT = D / 32;
     static constexpr int HT = D / 64;  // tiles of half a layer's outputs == tiles of the colour-hidden layer (D/2 wide)
@@ -106,13 +113,13 @@ struct Layout {
     // first panel of a part; the forward stream occupies panels [0, fwd_panels), the backward stream follows
     NNR_HD static constexpr int fwd_panel0(int p) {
         int o = 0;
-        for (int i = 0; i < p; ++i) o += part_panels(fwd(i).KT, fwd(i).MT);
+        for (int i = 0; i < p; ++i) o += part_panels(fwd(i).KT, fwd(i).MT, BF16);
         return o;
     }
     static constexpr int fwd_panels = fwd_panel0(F_NPARTS);
     NNR_HD static constexpr int bwd_panel0(int p) {  // relative to the start of the backward stream
         int o = 0;
-        for (int i = 0; i < p; ++i) o += part_panels(bwd(i).KT, bwd(i).MT);
+        for (int i = 0; i < p; ++i) o += part_panels(bwd(i).KT, bwd(i).MT, BF16);
         return o;
     }
     static constexpr int bwd_panels = bwd_panel0(B_NPARTS);

@@ -20,10 +20,10 @@ constexpr bool kAblateNoMask = false;
 
 NNR_TL_DECL(tl_fwd)
 
-template <int D, bool TRAIN>
+template <int D, bool TRAIN, bool BF16>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 0);
-    using L = Layout<D>;
+    using L = Layout<D, BF16>;
     constexpr int DT = L::DT, HT = L::HT;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     constexpr int HR = 16 * HT;              // registers of half a layer's outputs
     constexpr int NP = HR / 2;               // register pairs per half (the unit of hidden epilogue work)
     constexpr int HW = (HR + 31) / 32;       // mask words per half
-    constexpr int PP = part_panels(DT, HT);  // panels of one D x D/2 pass
+    constexpr int PP = part_panels(DT, HT, BF16);  // panels of one D x D/2 pass
 
     float h[16 * DT];    // current layer input (activations of the previous layer), rewritten in place
     f32x16 accA[HT], accB[HT];   // halves A ([0,D/2)) and B ([D/2,D)) of the layer being computed
@@ -137,10 +137,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 
     // ---- hidden 1: 63 -> D, input = posenc.  Pass A, then pass B with A's epilogue hidden under it. ----
     init_acc(accA, L::bias_off(0));
-    gemm_part<2, HT, TRAIN>(accA, e, pipe, p0(F_L1A), xe);
+    gemm_sel<BF16, 2, HT, TRAIN>(accA, e, pipe, p0(F_L1A), xe);
     init_acc(accB, L::bias_off(0) + L::Dh);
     clear_mask(mwA);
-    gemm_part<2, HT, false, NP, NP / 8, 0>(accB, e, pipe, p0(F_L1B), nullptr, NNR_RELU_PAIR(accA, 0, mwA));
+    gemm_sel<BF16, 2, HT, false, NP, NP / 8, 0>(accB, e, pipe, p0(F_L1B), nullptr, NNR_RELU_PAIR(accA, 0, mwA));
     store_mask(mwA, 0, 0);
     // posenc is needed again only by the skip layer: park it in LDS meanwhile
 #pragma unroll
@@ -153,12 +153,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         init_acc(accA, L::bias_off(li));
         clear_mask(mwB);
         // pass A: the first half of the k-groups only needs h[0,HR); the previous layer's half B is finished meanwhile
-        gemm_part<DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, pa, stash, NNR_RELU_PAIR(accB, HR, mwB));
+        gemm_sel<BF16, DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, pa, stash, NNR_RELU_PAIR(accB, HR, mwB));
         store_mask(mwB, li - 1, 1);
         init_acc(accB, L::bias_off(li) + L::Dh);
         clear_mask(mwA);
         // pass B: half A of the new layer replaces h[0,HR) in place, one k-group behind the reads
-        gemm_part<DT, HT, false, NP, 2, 1>(accB, h, pipe, pa + PP, nullptr, NNR_RELU_PAIR(accA, 0, mwA));
+        gemm_sel<BF16, DT, HT, false, NP, 2, 1>(accB, h, pipe, pa + PP, nullptr, NNR_RELU_PAIR(accA, 0, mwA));
         store_mask(mwA, li, 0);
     };
     // hidden 2..4
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // hidden 5: [h4 ; e] -> D   (skip connection, input order [h, posenc]: model/official_nerf.py:63)
     init_acc(accA, L::bias_off(4));
     clear_mask(mwB);
-    gemm_part<DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, p0(F_L5HA), xh(3), NNR_RELU_PAIR(accB, HR, mwB));
+    gemm_sel<BF16, DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, p0(F_L5HA), xh(3), NNR_RELU_PAIR(accB, HR, mwB));
     store_mask(mwB, 3, 1);
     float e5[32];
 #pragma unroll
@@ -177,11 +177,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) e5[4 * q + i] = v[i];
     }
-    gemm_part<2, HT>(accA, e5, pipe, p0(F_L5EA));
+    gemm_sel<BF16, 2, HT>(accA, e5, pipe, p0(F_L5EA));
     init_acc(accB, L::bias_off(4) + L::Dh);
     clear_mask(mwA);
-    gemm_part<DT, HT, false, NP, 2, 1>(accB, h, pipe, p0(F_L5HB), nullptr, NNR_RELU_PAIR(accA, 0, mwA));
-    gemm_part<2, HT>(accB, e5, pipe, p0(F_L5EB));
+    gemm_sel<BF16, DT, HT, false, NP, 2, 1>(accB, h, pipe, p0(F_L5HB), nullptr, NNR_RELU_PAIR(accA, 0, mwA));
+    gemm_sel<BF16, 2, HT>(accB, e5, pipe, p0(F_L5EB));
     store_mask(mwA, 4, 0);
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 5);
     // hidden 6..8
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         };
         // 4 units per k-group: the NP finishing units occupy k-groups [0, NP/4) -- long before k-group 2*DT first reads
         // h[HR..] -- and the 2*NP density units k-groups [NP/4, 3*NP/4) <= 4*DT
-        gemm_part<DT, HT, TRAIN, 3 * NP, 4, 0>(accA, h, pipe, p0(F_RGBH_F), xh(7), finish_then_sigma);
+        gemm_sel<BF16, DT, HT, TRAIN, 3 * NP, 4, 0>(accA, h, pipe, p0(F_RGBH_F), xh(7), finish_then_sigma);
     }
     store_mask(mwB, 7, 1);
     const float sg = sg0 + sg1;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dir2[4 * q + i] = v[i];
     }
-    gemm_part<1, HT, TRAIN>(accA, dir2, pipe, p0(F_RGBH_D), xf);
+    gemm_sel<BF16, 1, HT, TRAIN>(accA, dir2, pipe, p0(F_RGBH_D), xf);
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 8);
     clear_mask(mwA);
 #pragma unroll
@@ -274,17 +274,17 @@ extern "C" int nnr_timeline_fwd(unsigned long long* host32) {
 #endif
 
 template <int D>
-static hipError_t launch(const MlpFwdArgs& a, bool train, hipStream_t st) {
+static hipError_t launch(const MlpFwdArgs& a, bool train, bool bf16, hipStream_t st) {
     dim3 grid((unsigned)(a.S_pad / kBlockSamples)), block(256);
-    if (train)
-        hipLaunchKernelGGL((mlp_fwd_kernel<D, true>), grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL((mlp_fwd_kernel<D, false>), grid, block, 0, st, a);
+    if (train && bf16) hipLaunchKernelGGL((mlp_fwd_kernel<D, true, true>), grid, block, 0, st, a);
+    else if (train) hipLaunchKernelGGL((mlp_fwd_kernel<D, true, false>), grid, block, 0, st, a);
+    else if (bf16) hipLaunchKernelGGL((mlp_fwd_kernel<D, false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<D, false, false>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st) {
-    return D == 256 ? launch<256>(a, train, st) : launch<128>(a, train, st);
+hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, bool bf16, hipStream_t st) {
+    return D == 256 ? launch<256>(a, train, bf16, st) : launch<128>(a, train, bf16, st);
 }
 
 }  // namespace nnr

@@ -9,9 +9,9 @@ namespace nnr {
 
 // W' = Wg[:, :D] Wf and b' = Wg[:, :D] bf + bg (nnr_layout.h), plus the copies the un-merge step of the weight-gradient pass
 // reads.  One thread per element of W'; products accumulated in index order with fma.
-template <int D>
+template <int D, bool BF16>
 __global__ __launch_bounds__(256) void merge_kernel(PackArgs a) {
-    using L = Layout<D>;
+    using L = Layout<D, BF16>;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const float* Wf = a.w[9];
     const float* Wg = a.w[10];
@@ -32,9 +32,9 @@ __global__ __launch_bounds__(256) void merge_kernel(PackArgs a) {
     for (int i = gid; i < D * D; i += gridDim.x * blockDim.x) a.packed[L::copy_wf_off + i] = Wf[i];
 }
 
-template <int D>
+template <int D, bool BF16>
 __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
-    using L = Layout<D>;
+    using L = Layout<D, BF16>;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per packed float4
     const int64_t n_frag4 = L::bias_base / 4;
     if (gid < n_frag4) {
@@ -48,34 +48,39 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
 #pragma unroll
         for (int p = 0; p < F_NPARTS; ++p) {
             const PartDesc d = L::fwd(p);
-            const int np = part_panels(d.KT, d.MT);
+            const int np = part_panels(d.KT, d.MT, BF16);
             if (!found && panel < base + np) { pd = d; found = true; }
             if (!found) base += np;
         }
 #pragma unroll
         for (int p = 0; p < B_NPARTS; ++p) {
             const PartDesc d = L::bwd(p);
-            const int np = part_panels(d.KT, d.MT);
+            const int np = part_panels(d.KT, d.MT, BF16);
             if (!found && panel < base + np) { pd = d; found = true; }
             if (!found) base += np;
         }
         const int gp = part_gp(pd.MT);
-        const int g = (panel - base) * gp + slot / pd.MT;   // k-group
+        const int g = (panel - base) * gp + slot / pd.MT;   // fragment row: k-group (fp32) or double k-group (bf16)
         const int mt = slot % pd.MT;
-        const bool live = slot < gp * pd.MT && g < 4 * pd.KT;
+        const bool live = slot < gp * pd.MT && g < part_rows(pd.KT, BF16);
         const int m = 32 * mt + (lane & 31);
-        const int k0 = 8 * g + 4 * (lane >> 5);
         const float* W = a.w[pd.layer];
-        f32x4 v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + i;
-            float x = 0.f;
+        auto elem = [&](int k) -> float {
             if (live && m < pd.m_real && k < pd.k_real)
-                x = pd.transpose ? W[(int64_t)(pd.koff + k) * pd.ld + pd.moff + m] : W[(int64_t)(pd.moff + m) * pd.ld + pd.koff + k];
-            v[i] = x;
+                return pd.transpose ? W[(int64_t)(pd.koff + k) * pd.ld + pd.moff + m] : W[(int64_t)(pd.moff + m) * pd.ld + pd.koff + k];
+            return 0.f;
+        };
+        if constexpr (BF16) {   // 8 bf16: k = 16g + 4h + i, then 16g + 8 + 4h + i (nnr_layout.h)
+            bf16x8 q;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = (__bf16)elem(16 * g + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3));
+            reinterpret_cast<bf16x8*>(a.packed)[gid] = q;
+        } else {
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = elem(8 * g + 4 * (lane >> 5) + i);
+            reinterpret_cast<f32x4*>(a.packed)[gid] = v;
         }
-        reinterpret_cast<f32x4*>(a.packed)[gid] = v;
     } else {
         const int64_t bi = (gid - n_frag4);  // one thread per float of the bias / head-table tail
         if (bi < L::bias_floats) {
@@ -106,19 +111,22 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     }
 }
 
-template <int D>
+template <int D, bool BF16>
 static hipError_t launch(const PackArgs& a0, hipStream_t st) {
-    using L = Layout<D>;
+    using L = Layout<D, BF16>;
     PackArgs a = a0;
     a.w[kMergedLayer] = a.packed + L::merged_w_off;
     a.b[kMergedLayer] = a.packed + L::merged_b_off;
-    hipLaunchKernelGGL((merge_kernel<D>), dim3((L::Dh * D + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((merge_kernel<D, BF16>), dim3((L::Dh * D + 255) / 256), dim3(256), 0, st, a);
     const int64_t threads = L::bias_base / 4 + L::table_floats;
     dim3 grid((unsigned)((threads + 255) / 256)), block(256);
-    hipLaunchKernelGGL((pack_kernel<D>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((pack_kernel<D, BF16>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_pack(int D, const PackArgs& a, hipStream_t st) { return D == 256 ? launch<256>(a, st) : launch<128>(a, st); }
+hipError_t launch_pack(int D, const PackArgs& a, bool bf16, hipStream_t st) {
+    if (bf16) return D == 256 ? launch<256, true>(a, st) : launch<128, true>(a, st);
+    return D == 256 ? launch<256, false>(a, st) : launch<128, false>(a, st);
+}
 
 }  // namespace nnr

@@ -208,9 +208,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
 // Un-merge (nnr_layout.h): from dW' (D/2 x D) and db' of the merged matrix W' = Wg1 Wf, b' = Wg1 bf + bg, with Wg1 = Wg[:, :D]:
 //   dWf += Wg1^T dW'      dWg[:, :D] += dW' Wf^T + db' bf^T      dbf += Wg1^T db'      dbg += db'
 // Two (D x D/2 x D) products per step, 0.03 % of the MFMA work of the pass: plain VALU dot products, one output per thread.
-template <int D>
+template <int D, bool BF16>
 __global__ __launch_bounds__(256) void wgrad_unmerge_kernel(WgradArgs a) {
-    using L = Layout<D>;
+    using L = Layout<D, BF16>;
     constexpr int Dh = L::Dh, ldg = D + kDirReal;
     const float* Wf = a.packed + L::copy_wf_off;    // [D][D]
     const float* Wg1 = a.packed + L::copy_wg_off;   // [Dh][D]
@@ -246,8 +246,11 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(wgrad_kernel, dim3(a.n_waves / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_jobs * 16), dim3(256), 0, st, a);
     const int threads = a.D * a.D + (a.D / 2) * a.D + a.D + a.D / 2;
-    if (a.D == 256) hipLaunchKernelGGL((wgrad_unmerge_kernel<256>), dim3((threads + 255) / 256), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_unmerge_kernel<128>), dim3((threads + 255) / 256), dim3(256), 0, st, a);
+    const dim3 grid((threads + 255) / 256), block(256);
+    if (a.D == 256 && a.bf16) hipLaunchKernelGGL((wgrad_unmerge_kernel<256, true>), grid, block, 0, st, a);
+    else if (a.D == 256) hipLaunchKernelGGL((wgrad_unmerge_kernel<256, false>), grid, block, 0, st, a);
+    else if (a.bf16) hipLaunchKernelGGL((wgrad_unmerge_kernel<128, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wgrad_unmerge_kernel<128, false>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 

@@ -143,7 +143,8 @@ class Renderer(nn.Module):
         rgb, dist_pred, alpha, z_val = nnr.render_rays(
             pts_o, pts_d, view, z_lo, z_hi, jitter, net.weights(), net.biases(), hidden=net.hidden_dim,
             dist_alpha=bool(cfg['dist_alpha']), white_bg=bool(self.white_background),
-            relu_sigma=(net.occ_activation != 'softplus'))
+            relu_sigma=(net.occ_activation != 'softplus'),
+            bf16=(str(cfg.get('mfma_dtype', 'fp32')).lower() == 'bf16'))   # rendering.mfma_dtype: fp32 (default) | bf16
 
         if eval_ and cfg['normalise_ray']:                                          # distance -> depth for evaluation (:150-154)
             dist_pred = dist_pred / ray_norm

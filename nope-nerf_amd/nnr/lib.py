@@ -16,6 +16,7 @@ NNR_F_DIST_ALPHA = 1
 NNR_F_WHITE_BG = 2
 NNR_F_RELU_SIGMA = 4
 NNR_F_TRAIN = 8
+NNR_F_BF16 = 16
 N_LAYERS = 12
 
 #: state_dict order of the 12 nn.Linear layers (reference model/official_nerf.py:20-37)
@@ -123,9 +124,9 @@ def check(rc: int, what: str):
 
 
 def make_cfg(n_rays: int, n_samples: int, hidden: int, *, dist_alpha=False, white_bg=False, relu_sigma=False,
-             train=False) -> Cfg:
+             train=False, bf16=False) -> Cfg:
     flags = (NNR_F_DIST_ALPHA if dist_alpha else 0) | (NNR_F_WHITE_BG if white_bg else 0) | \
-            (NNR_F_RELU_SIGMA if relu_sigma else 0) | (NNR_F_TRAIN if train else 0)
+            (NNR_F_RELU_SIGMA if relu_sigma else 0) | (NNR_F_TRAIN if train else 0) | (NNR_F_BF16 if bf16 else 0)
     return Cfg(int(n_rays), int(n_samples), int(hidden), flags)
 
 

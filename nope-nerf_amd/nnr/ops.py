@@ -30,7 +30,7 @@ class _PackCache:
     after the old one is freed) at the very same in-place versions."""
 
     def __init__(self, hidden, tensors, packed):
-        self.hidden = hidden
+        self.hidden = hidden   # (width, bf16 mode): the two modes have different packed layouts
         self.refs = [weakref.ref(t) for t in tensors]
         self.versions = [t._version for t in tensors]
         self.packed = packed
@@ -48,9 +48,10 @@ def _packed_for(cfg, weights, biases):
     """Packed (MFMA-fragment order) copy of the 24 parameter tensors; `weights`/`biases` must be the caller's long-lived
     tensor objects (nn.Parameters), not temporaries."""
     tensors = [*weights, *biases]
-    key = id(tensors[0])
+    mode = (cfg.hidden, bool(cfg.flags & L.NNR_F_BF16))
+    key = (id(tensors[0]), mode[1])
     hit = _pack_caches.get(key)
-    if hit is not None and hit.matches(cfg.hidden, tensors):
+    if hit is not None and hit.matches(mode, tensors):
         return hit.packed
     lib = L.load()
     n = lib.nnr_packed_floats(C.byref(cfg))
@@ -60,7 +61,7 @@ def _packed_for(cfg, weights, biases):
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_pack_weights")
     for k in [k for k, v in _pack_caches.items() if any(r() is None for r in v.refs)]:
         del _pack_caches[k]             # drop entries of models that no longer exist
-    _pack_caches[key] = _PackCache(cfg.hidden, tensors, packed)
+    _pack_caches[key] = _PackCache(mode, tensors, packed)
     return packed
 
 
@@ -146,7 +147,7 @@ class _RenderRays(torch.autograd.Function):
         R, N = pts_o.shape[0], z_lo.shape[0]
         need_grad = any(ctx.needs_input_grad)
         cfg = L.make_cfg(R, N, opts["hidden"], dist_alpha=opts["dist_alpha"], white_bg=opts["white_bg"],
-                         relu_sigma=opts["relu_sigma"], train=need_grad)
+                         relu_sigma=opts["relu_sigma"], train=need_grad, bf16=opts.get("bf16", False))
         lib = L.load()
         f32 = dict(dtype=torch.float32, device=dev)
         pts_o, pts_d, view_d = (t.detach().contiguous().float() for t in (pts_o, pts_d, view_d))
@@ -206,11 +207,12 @@ class _RenderRays(torch.autograd.Function):
 
 def render_rays(pts_o: torch.Tensor, pts_d: torch.Tensor, view_d: torch.Tensor, z_lo: torch.Tensor, z_hi: torch.Tensor,
                 jitter: Optional[torch.Tensor], weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], *,
-                hidden: int, dist_alpha: bool, white_bg: bool, relu_sigma: bool):
+                hidden: int, dist_alpha: bool, white_bg: bool, relu_sigma: bool, bf16: bool = False):
     """(R,3) sampling origin / direction / view direction, (N) z interval tables, optional (R,N) jitter, the 12
     nn.Linear weights and biases in state_dict order  ->  rgb (R,3), dist (R), alpha (R,N), z (R,N).
-    Differentiable w.r.t. pts_o, pts_d, view_d, weights, biases."""
-    opts = dict(hidden=hidden, dist_alpha=dist_alpha, white_bg=white_bg, relu_sigma=relu_sigma,
+    Differentiable w.r.t. pts_o, pts_d, view_d, weights, biases.  bf16: bf16-MFMA products (fp32 accumulation) in the MLP
+    forward and input-gradient kernels (NNR_F_BF16); weight gradients stay fp32."""
+    opts = dict(hidden=hidden, dist_alpha=dist_alpha, white_bg=white_bg, relu_sigma=relu_sigma, bf16=bool(bf16),
                 params=(list(weights), list(biases)))    # the caller's own tensor objects: identity keys the pack cache
     if not torch.is_grad_enabled():
         # forward-only (eval / visualisation inside torch.no_grad): no stash, small workspace

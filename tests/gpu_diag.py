@@ -33,7 +33,9 @@ def report(name, got, ref):
     err = (got - ref).abs().max().item() if got.numel() else 0.0
     scale = max(1.0, ref.abs().max().item()) if ref.numel() else 1.0
     bad = not np.isfinite(err) or err / scale > TOL
-    print(f"  {name:28s} max|err| {err:10.3e}  scale {scale:9.3e}  {'FAIL' if bad else 'ok'}")
+    mx = ref.abs().max().item() if ref.numel() else 0.0
+    rms = ((got - ref).pow(2).mean().sqrt() / max(ref.pow(2).mean().sqrt().item(), 1e-30)).item() if ref.numel() else 0.0
+    print(f"  {name:28s} max|err| {err:10.3e}  scale {scale:9.3e}  max|ref| {mx:9.3e}  rel-rms {rms:8.2e}  {'FAIL' if bad else 'ok'}")
     return not bad
 
 
@@ -58,7 +60,7 @@ def run(D, R, N, dist_alpha, white_bg, seed=0):
     d_dist = torch.randn(R, generator=g) / R * 0.04
 
     lib = L.load()
-    cfg = L.make_cfg(R, N, D, dist_alpha=dist_alpha, white_bg=white_bg, train=True)
+    cfg = L.make_cfg(R, N, D, dist_alpha=dist_alpha, white_bg=white_bg, train=True, bf16=bool(int(os.environ.get('NNR_DIAG_BF16', '0'))))
     cu = lambda t: t.to(dev).contiguous()
     w_d, b_d = [cu(w) for w in weights], [cu(b) for b in biases]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

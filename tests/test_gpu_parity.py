@@ -41,9 +41,11 @@ def build(case, device):
     return net, model, pose, dist, t
 
 
-def run_hip(case, eval_=False):
+def run_hip(case, eval_=False, mfma_dtype=None):
     dev = torch.device("cuda")
     net, model, pose, dist, t = build(case, dev)
+    if mfma_dtype is not None:
+        model.renderer.cfg['mfma_dtype'] = mfma_dtype
     from model.common import arange_pixels
     from model.losses import Loss
     h, w, cam = int(case["cfg.h"]), int(case["cfg.w"]), int(case["cfg.cam"])
@@ -237,3 +239,38 @@ def test_full_image_inference_matches_oracle(tmp_path):
     assert np.abs(out['img'].astype(np.float64) - img_ref).max() <= 1.0          # uint8 quantisation of a 1e-4 match
     depth = np.load(str(tmp_path / "depth_out" / "0.npy"))
     np.testing.assert_allclose(depth, ref["depth_pred"].view(21, 34).numpy(), rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("name", ["tanks_d128", "tanks_d256_n192", "llff_ndc_d128"])
+def test_bf16_mfma_mode_against_fp32_golden(name, capsys):
+    """BASELINE configs[2] arithmetic: bf16 MFMA products with fp32 accumulation in the MLP forward and input-gradient
+    kernels (rendering.mfma_dtype: bf16), everything else fp32.  Compared with the fp32 reference golden; the measured errors are
+    printed.  Outputs: 2e-3 absolute (measured ~1e-4).  Gradients: relative L2 error of every tensor <= 0.2 (measured 0.04-0.1):
+    activations agree to 0.3 %, but a ReLU whose pre-activation is below the bf16 noise flips, and each flipped unit
+    contributes its whole gradient to an element-wise difference -- ~1 % of the units, i.e. ~10 % in L2, while the element-wise
+    maximum can reach 25 % of the tensor's largest entry.  That is the nature of reduced-precision training, not a defect of
+    the kernels (tests/gpu_diag.py with NNR_DIAG_BF16=1 shows the per-layer numbers)."""
+    case = gu.load_case(name)
+    out, grads = run_hip(case, mfma_dtype='bf16')
+    errs = {}
+    for k in ("rgb", "depth_pred"):
+        got = out[k].detach().cpu().numpy()
+        errs[k] = float(np.abs(got - case["out." + k]).max())
+        assert errs[k] <= 2e-3, (k, errs[k])
+    np.testing.assert_allclose(out["z_vals"].cpu().numpy(), case["out.z_vals"], rtol=0, atol=1e-6)   # sampling is not affected
+    worst_l2, worst_max = ("", 0.0), ("", 0.0)
+    for k, (kind, ref, norm) in gu.golden_grads(case).items():
+        g = grads[k].detach().cpu().numpy().reshape(-1).astype(np.float64)
+        if kind != "full":
+            g = g[::g.size // gu.SUBSAMPLE]
+        r = ref.reshape(-1).astype(np.float64)
+        if np.abs(r).max() == 0:
+            continue
+        l2 = float(np.linalg.norm(g - r) / np.linalg.norm(r))
+        mx = float(np.abs(g - r).max() / np.abs(r).max())
+        worst_l2 = max(worst_l2, (k, l2), key=lambda t: t[1])
+        worst_max = max(worst_max, (k, mx), key=lambda t: t[1])
+        assert l2 <= 0.2, (k, l2)
+    with capsys.disabled():
+        print("\nbf16 mode vs fp32 golden [%s]: rgb %.2e depth %.2e; gradients: worst relative L2 %.3f (%s), worst element / max %.3f (%s)"
+              % (name, errs["rgb"], errs["depth_pred"], worst_l2[1], worst_l2[0], worst_max[1], worst_max[0]))
