@@ -140,6 +140,84 @@ extern "C" int nnr_timeline_wgrad(unsigned long long* host32) {
 }
 #endif
 
+// bf16-MFMA variant (NNR_F_BF16): the same tile / job structure, but one v_mfma_f32_32x32x16_bf16 contracts 16 samples:
+// lane (m, half) supplies the 8 samples k + 8*half + 0..7 of its MI rows / NI columns, converted to bf16 on the fly from
+// the fp32 stashes (fp32 accumulation, fp32 bias sums).  16 MFMAs of 32 cycles per 16 samples against the same bytes as the
+// fp32 kernel: this variant is HBM-bound (17.7 KB per sample), not MFMA-bound.
+template <int MI, int NI, int BIAS>
+__device__ __forceinline__ void wgrad_job_bf16(const WgradJob& jb, const WgradArgs& a, int lane, int ji) {
+    const int half = lane >> 5, m = lane & 31;
+    const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
+    const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
+    const float* dptr = a.ws + a.plane_off[jb.d_plane] + jb.d_col0 + (dok ? MI * m : 0) + (int64_t)(8 * half) * dp;
+    const float* xptr = a.ws + a.plane_off[jb.x_plane] + jb.x_col0 + (xok ? NI * m : 0) + (int64_t)(8 * half) * xp;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
+
+    // One raw stage (8 samples x (MI + NI) floats per lane, 16 KB per wave) is in flight while the previous one, already
+    // converted to bf16 (half the registers), feeds the MFMAs.  (Two raw stages in flight would cover the loaded HBM latency
+    // better, but hipcc spills ~1000 registers on that version; as it stands the kernel is latency-bound at ~2.6 TB/s.)
+    // Sample ranges are multiples of 16 (kGranule) = one MFMA per sub-tile.
+    Vec<MI> d[8];
+    Vec<NI> x[8];
+    auto load_stage = [&](int64_t kk) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            d[u] = load_vec<MI>(dptr + (kk + u) * dp);
+            x[u] = load_vec<NI>(xptr + (kk + u) * xp);
+        }
+    };
+    load_stage(jb.k0);
+    for (int64_t k = jb.k0; k < jb.k1; k += 16) {
+        bf16x8 av[MI], bv[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                av[i][u] = (__bf16)d[u].v[i];
+                if (BIAS == 1 || (BIAS == 2 && u % 2 == 0) || (BIAS == 3 && u % 2 == 1)) bsum[i] += d[u].v[i];
+            }
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bv[j][u] = (__bf16)x[u].v[j];
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(k + 16 < jb.k1 ? k + 16 : k);   // no branch around loads: a redundant re-read at the tail
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float* slot = a.slots + (int64_t)ji * kSlotFloats;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* dst = slot + (MI * mr + i) * (32 * NI) + NI * m;
+            if constexpr (NI == 4) *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+            else if constexpr (NI == 2) *reinterpret_cast<f32x2*>(dst) = f32x2{acc[i][0][r], acc[i][1][r]};
+            else *dst = acc[i][0][r];
+        }
+    if constexpr (BIAS != 0) {
+        float* dst = slot + kSlotTile + half * (32 * MI) + MI * m;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) dst[i] = bsum[i];
+    }
+}
+
+template <bool BF16>
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wslot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -151,12 +229,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
         const WgradJob jb = a.jobs[ji];
         // bias reduction (MI VALU adds per k-step inside the MFMA stream) only in the jobs that own it
         const int key = __builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI + 64 * jb.bias);
-#define NNR_WGRAD_CASE(MI_, NI_)                                                \
-    case MI_ * 8 + NI_: wgrad_job<MI_, NI_, 0>(jb, a, lane, ji); break;          \
-    case MI_ * 8 + NI_ + 64: wgrad_job<MI_, NI_, 1>(jb, a, lane, ji); break;
+#define NNR_WGRAD_RUN(MI_, NI_, B_)                                                      \
+    do {                                                                                 \
+        if constexpr (BF16) wgrad_job_bf16<MI_, NI_, B_>(jb, a, lane, ji);               \
+        else wgrad_job<MI_, NI_, B_>(jb, a, lane, ji);                                   \
+    } while (0)
+#define NNR_WGRAD_CASE(MI_, NI_)                                 \
+    case MI_ * 8 + NI_: NNR_WGRAD_RUN(MI_, NI_, 0); break;        \
+    case MI_ * 8 + NI_ + 64: NNR_WGRAD_RUN(MI_, NI_, 1); break;
         switch (key) {
-            case 4 * 8 + 4 + 128: wgrad_job<4, 4, 2>(jb, a, lane, ji); break;
-            case 4 * 8 + 4 + 192: wgrad_job<4, 4, 3>(jb, a, lane, ji); break;
+            case 4 * 8 + 4 + 128: NNR_WGRAD_RUN(4, 4, 2); break;
+            case 4 * 8 + 4 + 192: NNR_WGRAD_RUN(4, 4, 3); break;
             NNR_WGRAD_CASE(4, 4)
             NNR_WGRAD_CASE(4, 2)
             NNR_WGRAD_CASE(4, 1)
@@ -167,6 +250,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
             default: break;
         }
 #undef NNR_WGRAD_CASE
+#undef NNR_WGRAD_RUN
     }
 #ifdef NNR_TIMELINE
     if (lane == 0 && wslot < 2048) tl_wgrad_all[2 * wslot + 1] = __builtin_amdgcn_s_memtime();
@@ -243,7 +327,8 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const size_t merged = ((size_t)(a.D / 2) * a.D + a.D / 2) * sizeof(float);
     hipError_t e = hipMemsetAsync(a.gw[kMergedLayer], 0, merged, st);   // dW', db' are accumulated into like any gradient
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(a.n_waves / 4), dim3(256), 0, st, a);
+    if (a.bf16) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_jobs * 16), dim3(256), 0, st, a);
     const int threads = a.D * a.D + (a.D / 2) * a.D + a.D + a.D / 2;
     const dim3 grid((threads + 255) / 256), block(256);

@@ -41,6 +41,11 @@ if __name__ == "__main__":
                                                   L.ptr(packed), L.ptr(ws), st)}
             if train:
                 fns["dgrad"] = lambda: lib.nnr_mlp_dgrad(C.byref(cfg), L.ptr(packed), L.ptr(ws), st)
+                gw = [torch.zeros_like(x) for x in net.weights()]
+                gb = [torch.zeros_like(x) for x in net.biases()]
+                gs = L.params_struct(gw, gb)
+                plan = ops._plan_for(cfg, dev)
+                fns["wgrad"] = lambda: lib.nnr_mlp_wgrad(C.byref(cfg), L.ptr(packed), C.byref(gs), L.ptr(plan), L.ptr(ws), st)
             for name, fn in fns.items():
                 L.check(fn(), name)
                 torch.cuda.synchronize()
