@@ -34,6 +34,28 @@ def _save_png(arr_u8, path):
     Image.fromarray(arr_u8).save(path)
 
 
+def _use_fused_adam(opt):
+    """the reference steps up to four torch.optim.Adam instances per iteration; torch's default
+    ('foreach') implementation is ~7 launches per optimiser (21 of the ~90 small launches of a step, 0.18 ms).  The same
+    class has a single-kernel implementation (fused=True, the same update rule and the same state_dict layout), which is
+    selected here for plain Adam on GPU parameters.  Anything else (other optimisers, CPU parameters, amsgrad / capturable /
+    differentiable variants) is left alone."""
+    if type(opt) is not torch.optim.Adam:
+        return False
+    params = [p for g in opt.param_groups for p in g['params']]
+    if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+        return False
+    if any(g.get('amsgrad') or g.get('capturable') or g.get('differentiable') or g.get('maximize') for g in opt.param_groups):
+        return False
+    for g in opt.param_groups:
+        g['fused'], g['foreach'] = True, False
+    for p in params:   # state restored before this point keeps its step counter on the host: the fused kernel wants it beside p
+        st = opt.state.get(p)
+        if st and 'step' in st:
+            st['step'] = torch.as_tensor(float(st['step']), dtype=torch.float32, device=p.device)
+    return True
+
+
 class Trainer(object):
     def __init__(self, model, optimizer, cfg, device=None, optimizer_pose=None, pose_param_net=None,
                  optimizer_focal=None, focal_net=None, optimizer_distortion=None, distortion_net=None, **kwargs):
@@ -50,6 +72,9 @@ class Trainer(object):
         self._warned_geo = False
         self._nan_flag = None      # (pinned host flag, event) of the previous step's isnan(loss), read one step late
         self._nan_host = None
+        if cfg.get('fuse_optimizers', True):   # training.fuse_optimizers: False keeps torch's default multi-kernel Adam
+            for opt in (optimizer, optimizer_pose, optimizer_focal, optimizer_distortion):
+                _use_fused_adam(opt)
 
     # ------------------------------------------------------------------------------------------------ step
     def _groups(self):
