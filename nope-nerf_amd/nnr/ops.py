@@ -25,18 +25,41 @@ def _require_gpu(t: torch.Tensor):
 # ----------------------------------------------------------------------------------------------------------------------
 # packed weights: re-packed only when a parameter tensor changed (optimizer.step bumps tensor._version)
 # ----------------------------------------------------------------------------------------------------------------------
+_param_epoch = 0   # bumped after every torch optimizer step, see _after_any_optimizer_step
+
+
+def _after_any_optimizer_step(optimizer, args, kwargs):
+    """Global optimizer post-step hook.  tensor._version is NOT a reliable change detector: torch's fused optimizers
+    (Adam(fused=True) -- which model.Trainer selects) update parameters in place without bumping it, and a stale packed
+    copy means the render kernels silently keep using old weights.  Any optimizer step therefore invalidates every pack."""
+    global _param_epoch
+    _param_epoch += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_register_step_hook(_after_any_optimizer_step)
+
+
+def invalidate_packed_weights():
+    """For code that changes parameters behind torch's back (custom kernels writing through .data_ptr())."""
+    global _param_epoch
+    _param_epoch += 1
+
+
 class _PackCache:
     """Valid only for the very same tensor objects (weak references -- a data_ptr or id() can be recycled by a new model
-    after the old one is freed) at the very same in-place versions."""
+    after the old one is freed) at the very same in-place versions, with no optimizer step since."""
 
     def __init__(self, hidden, tensors, packed):
         self.hidden = hidden   # (width, bf16 mode): the two modes have different packed layouts
         self.refs = [weakref.ref(t) for t in tensors]
         self.versions = [t._version for t in tensors]
+        self.epoch = _param_epoch
         self.packed = packed
 
     def matches(self, hidden, tensors):
-        return (self.hidden == hidden and len(self.refs) == len(tensors)
+        return (self.hidden == hidden and self.epoch == _param_epoch and len(self.refs) == len(tensors)
                 and all(r() is t for r, t in zip(self.refs, tensors))
                 and self.versions == [t._version for t in tensors])
 

@@ -43,3 +43,31 @@ def test_fused_adam_matches_default_adam_and_keeps_the_state_layout():
         torch.testing.assert_close(c, a, rtol=0, atol=1e-6)
     sa, sb = opt_ref.state_dict()['state'][0], opt_f.state_dict()['state'][0]
     assert set(sa) == set(sb) == {'step', 'exp_avg', 'exp_avg_sq'} and float(sa['step']) == float(sb['step']) == 4.0
+
+
+@pytest.mark.gpu
+def test_packed_weights_follow_a_fused_optimizer_step():
+    """torch's fused Adam updates parameters without bumping tensor._version; the packed copy the kernels read must still
+    be refreshed (nnr/ops.py: global optimizer post-step hook).  A stale pack would freeze training silently."""
+    import model as mdl
+    from nnr import ops
+    from model.training import _use_fused_adam
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    net = mdl.OfficialStaticNerf({'model': {'hidden_dim': 128, 'pos_enc_levels': 10, 'dir_enc_levels': 4,
+                                            'occ_activation': 'softplus'}, 'rendering': {'white_background': False, 'dist_alpha': False}}).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    assert _use_fused_adam(opt)
+    pts, view = torch.randn(256, 3, device=dev), torch.nn.functional.normalize(torch.randn(256, 3, device=dev), dim=-1)
+    with torch.no_grad():
+        before, _ = ops.mlp_points(pts, view, net.weights(), net.biases(), hidden=128)
+        again, _ = ops.mlp_points(pts, view, net.weights(), net.biases(), hidden=128)      # cache hit: identical
+    assert torch.equal(before, again)
+    versions = [p._version for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = torch.randn_like(p)
+    opt.step()
+    assert versions == [p._version for p in net.parameters()]                 # the premise: no version bump
+    with torch.no_grad():
+        after, _ = ops.mlp_points(pts, view, net.weights(), net.biases(), hidden=128)
+    assert float((after - before).abs().max()) > 1e-4                         # the new weights are the ones evaluated
