@@ -1,12 +1,14 @@
-// nnr_mlp_fwd.hip -- fused NeRF MLP forward for gfx950: sampling + positional encoding + 12 layers, per-sample
+// nnr_mlp_fwd.hip -- fused NeRF MLP forward for gfx950: sampling + positional encoding + the MLP, per-sample
 // (rgb, sigma_raw) out.  Restates, per sample: model/rendering.py:184-195 (z, points, view dir) and
 // model/official_nerf.py:60-96 (the MLP).  One wave = 32 samples; activations stay in VGPRs between layers as MFMA
 // B-operands (see nnr_layout.h); weights arrive as pre-packed A fragments through a DMA-fed LDS ring shared by the 4 waves.
 //
-// Roofline: MFMA-bound.  593 408 MACs/sample at D=256 -> 9 472 v_mfma_f32_32x32x2_f32 per 32 samples (9 272 useful,
-// 2 % padding of the 63/27/1/3-wide edges) = 606 k cycles per wave against ~10 k cycles of everything else.
-// Every D-wide layer runs as two half-output passes so that epilogues execute under MFMAs (nnr_layout.h).
-// HBM per sample: 4 B jitter in, 20 B out (+ the 10 KB activation stash when training, written once, never re-read here).
+// Roofline: MFMA-bound.  Algorithmic work 593 408 MACs/sample at D=256; executed 528 000: the feature layer is folded into
+// the colour-hidden layer (nnr_layout.h), leaving 8 448 v_mfma_f32_32x32x2_f32 per 32 samples (1.5 % padding of the
+// 63 / 27-wide edges) = 541 k cycles per wave against ~40-90 k cycles of everything else.
+// Every D-wide layer runs as two half-output passes so that epilogues execute inside the MFMA stream (nnr_device.h).
+// HBM per sample: 4 B jitter in, 20 B out (+ the 9.4 KB activation stash when training, written once, never re-read here).
+// BF16 = true: the same kernel with bf16 MFMA products (gemm_part_bf16); then issue / the stash write is the bound.
 #include "nnr_device.h"
 #include "nnr_kernels.h"
 

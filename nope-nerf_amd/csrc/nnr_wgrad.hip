@@ -8,7 +8,9 @@
 // slot; wgrad_reduce_kernel then adds the slots of each tile into dW.
 // Both operands are read straight from the (sample, feature) row-major stashes: with interleaved sub-tiles
 // (row = MI*m + i) one MI-wide and one NI-wide vector load per lane feed MI*NI MFMAs; the four jobs of a 256x256 layer
-// that share a sample range sit in one workgroup so their re-reads hit L1/L2.  The job table comes from the host plan.
+// that share a sample range sit in one workgroup so their re-reads hit L1/L2.  The job table comes from the host plan
+// (nnr_api.cpp: build_plan -- a balanced static schedule, one wave program per SIMD of the chip).  The feature layer and the
+// first D columns of the colour-hidden layer get their gradients from the merged matrix W' (wgrad_unmerge_kernel).
 #include "nnr_device.h"
 #include "nnr_kernels.h"
 
