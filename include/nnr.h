@@ -41,9 +41,9 @@ extern "C" {
 #define NNR_F_WHITE_BG 2u   /* rendering.white_background (model/rendering.py:145-147) */
 #define NNR_F_RELU_SIGMA 4u /* model.occ_activation != 'softplus' (model/official_nerf.py:77-80) */
 #define NNR_F_TRAIN 8u      /* keep what the backward needs (activation stash, ReLU masks) */
-#define NNR_F_BF16 16u      /* bf16 MFMA with fp32 accumulation in the MLP forward and input-gradient kernels (BASELINE configs[2]);
-                             * everything else -- bias, activations between layers, stash, weight gradients -- stays fp32.  The
-                             * packed-weight buffer has its own size and layout in this mode. */
+#define NNR_F_BF16 16u      /* bf16 MFMA products with fp32 accumulation in the three MLP kernels (BASELINE configs[2]); bias,
+                             * activations between layers, stash and every gradient buffer stay fp32.  The packed-weight
+                             * buffer has its own size and layout in this mode (nnr_packed_floats). */
 
 /* Problem description.  POD, passed by pointer, read on the host only. */
 typedef struct nnr_cfg {
@@ -117,8 +117,10 @@ int nnr_render_bwd(const nnr_cfg* cfg, const float* packed, const float* d_rgb, 
  * Offset (in floats) and row pitch of a workspace plane; returns <0 for an unknown plane.
  * Planes: 0 sample outputs (S,4: rgb, sigma_raw)   1 z (S)   2 d(sample outputs) (S,4)
  *         3 d(point) (S,4)  4 d(view) (S,4)   10 posenc (S,64)   11..18 hidden activations 1..8 (S,D)
- *         19 [feature|direnc] (S,D+32)   20 colour hidden (S,D/2)
- *         31..38 d(pre-activation) of hidden 1..8 (S,D)   39 d(feature) (S,D)   40 d(colour hidden) (S,D/2) */
+ *         19 direction encoding (S,32)   20 colour hidden (S,D/2)   25 ReLU sign bits
+ *         31..38 d(pre-activation) of hidden 1..8 (S,D)   40 d(colour hidden) (S,D/2)
+ * (the feature vector of model/official_nerf.py:87 and its gradient are never formed: that layer is folded into the
+ * colour-hidden layer, see nnr_layout.h) */
 int64_t nnr_ws_plane(const nnr_cfg* cfg, int plane, int32_t* pitch_out);
 
 /* Individual stages, exported for profiling and bench.py's per-kernel roofline timing.  Same arguments
