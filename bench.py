@@ -265,7 +265,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_val = float(ld['loss'])
+    loss_val = float(ld['loss'].detach())
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
