@@ -54,16 +54,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     const float vx = rv[0], vy = rv[1], vz = rv[2];
     if (half == 0 && s < a.S) a.ws_z[s] = z;
 
-    // ---- encodings, straight into fragment layout ----
-    float e[32];  // gamma_10(p): 63 -> 64
-#pragma unroll
-    for (int r = 0; r < 32; ++r) e[r] = enc_feature(frag_feature(r, half), kPosReal, px, py, pz);
-    float dirv[16];  // gamma_4(v): 27 -> 32
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dirv[r] = enc_feature(frag_feature(r, half), kDirReal, vx, vy, vz);
-    NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 1);
-
-    // ---- weight panels (LDS ring, DMA two panels ahead) and the bias / head tables, all in ONE __shared__ array ----
+    // ---- weight panels (LDS ring, DMA two panels ahead) and the bias / head tables, all in ONE __shared__ array.
+    // Started BEFORE the encodings: the table copy overlaps the latency of the sampling loads above, and the first two
+    // panels arrive while the ~90 sincosf evaluations below run. ----
     constexpr int kPark = kWavesPerBlock * 12 * 64;   // per wave 12 float4 slots per lane: posenc (8) + direnc (4)
     __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kPark + (L::table_floats + 3) / 4];
     f32x4* const park = smem + kNBuf * kPanelF4 + wave * (12 * 64) + lane;
@@ -73,7 +66,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave_u * (8 * 64), smem, wave_u, lane, L::fwd_panels};
     pipe.start();
+    // ---- encodings, straight into fragment layout ----
+    float e[32];  // gamma_10(p): 63 -> 64
+#pragma unroll
+    for (int r = 0; r < 32; ++r) e[r] = enc_feature(frag_feature(r, half), kPosReal, px, py, pz);
+    float dirv[16];  // gamma_4(v): 27 -> 32
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dirv[r] = enc_feature(frag_feature(r, half), kDirReal, vx, vy, vz);
+    NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 1);
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 2);
+
     // the direction encoding is needed once, at the very end: park it in LDS instead of holding 16 registers for 70 panels
 #pragma unroll
     for (int q = 0; q < 4; ++q) park[(8 + q) * 64] = f32x4{dirv[4 * q], dirv[4 * q + 1], dirv[4 * q + 2], dirv[4 * q + 3]};

@@ -60,7 +60,9 @@ def run(D, R, N, dist_alpha, white_bg, seed=0):
     d_dist = torch.randn(R, generator=g) / R * 0.04
 
     lib = L.load()
-    cfg = L.make_cfg(R, N, D, dist_alpha=dist_alpha, white_bg=white_bg, train=True, bf16=bool(int(os.environ.get('NNR_DIAG_BF16', '0'))))
+    relu_sigma = bool(int(os.environ.get('NNR_DIAG_RELU', '0')))
+    cfg = L.make_cfg(R, N, D, dist_alpha=dist_alpha, white_bg=white_bg, relu_sigma=relu_sigma, train=True,
+                     bf16=bool(int(os.environ.get('NNR_DIAG_BF16', '0'))))
     cu = lambda t: t.to(dev).contiguous()
     w_d, b_d = [cu(w) for w in weights], [cu(b) for b in biases]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -82,7 +84,8 @@ def run(D, R, N, dist_alpha, white_bg, seed=0):
     # oracle with trace
     P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     po, pd, pv = (t.clone().requires_grad_(True) for t in (pts_o, pts_d, view))
-    orgb, odist, t = trace_util.traced_render(P, po, pd, pv, z_lo, z_hi, jitter, dist_alpha=dist_alpha, white_bg=white_bg)
+    orgb, odist, t = trace_util.traced_render(P, po, pd, pv, z_lo, z_hi, jitter, dist_alpha=dist_alpha, white_bg=white_bg,
+                                              relu_sigma=bool(int(os.environ.get('NNR_DIAG_RELU', '0'))))
     plane = lambda i: ops.workspace_plane(cfg, ws, i)
     S = R * N
     report("z", plane(1)[:, 0], t["z"].reshape(-1))

@@ -213,6 +213,53 @@ def test_full_size_against_oracle_sample():
     assert float((dist[sel.cuda()].cpu() - odist).abs().max()) <= TOL * 10      # distances reach 10
 
 
+@pytest.mark.parametrize("D,R,N,dist_alpha,white_bg,relu_sigma,jittered", [
+    (128, 1, 2, False, False, False, True),      # the smallest render: one ray, two samples (126 of the 128 padded samples are filler)
+    (128, 7, 17, True, False, False, True),      # ragged sizes, dist_alpha
+    (256, 33, 65, False, True, True, True),      # white background, ReLU density
+    (256, 5, 130, True, True, False, False),     # no jitter (eval sampling), long rays
+    (128, 129, 3, False, False, True, True),     # more rays than a wave, samples not a multiple of anything
+])
+def test_ragged_shapes_and_every_flag_against_live_oracle(D, R, N, dist_alpha, white_bg, relu_sigma, jittered):
+    """Forward and full backward on sizes that are not multiples of the 32-sample wave / 128-sample workgroup / 16-sample
+    weight-gradient granule, with every rendering switch, against the oracle evaluated on this host."""
+    import nnr
+    from nnr import lib as L
+    dev = torch.device("cuda")
+    params, o, d, lo, hi, jit = _synthetic(D, R, N, seed=11 + R, dist_alpha=dist_alpha)
+    if not jittered:
+        jit = None
+    g = torch.Generator().manual_seed(5)
+    d_rgb, d_dist = torch.randn(R, 3, generator=g) / R, torch.randn(R, generator=g) / R
+    w = [params[n + ".weight"].to(dev).requires_grad_(True) for n in L.LAYER_NAMES]
+    b = [params[n + ".bias"].to(dev).requires_grad_(True) for n in L.LAYER_NAMES]
+    oo, dd, vv = o.to(dev).requires_grad_(True), d.to(dev).requires_grad_(True), (-d).to(dev).requires_grad_(True)
+    rgb, dist, alpha, z = nnr.render_rays(oo, dd, vv, lo.to(dev), hi.to(dev), jit.to(dev) if jit is not None else None, w, b,
+                                          hidden=D, dist_alpha=dist_alpha, white_bg=white_bg, relu_sigma=relu_sigma)
+    (rgb * d_rgb.to(dev)).sum().add((dist * d_dist.to(dev)).sum()).backward()
+    # The oracle in fp64 is the reference; the oracle in fp32 tells how well-conditioned each quantity is in fp32 at all
+    # (with a ReLU density and 2^9-fold position frequencies d(point) of some rays is only good to 1e-3 in ANY fp32 evaluation).
+    def oracle(dt):
+        P = {k: v.clone().to(dt).requires_grad_(True) for k, v in params.items()}
+        po, pd, pv = (t.clone().to(dt).requires_grad_(True) for t in (o, d, -d))
+        orgb, odist, _ = trace_util.traced_render(P, po, pd, pv, lo.to(dt), hi.to(dt), None if jit is None else jit.to(dt),
+                                                  dist_alpha=dist_alpha, white_bg=white_bg, relu_sigma=relu_sigma)
+        ((orgb * d_rgb.to(dt)).sum() + (odist * d_dist.to(dt)).sum()).backward()
+        out = {"rgb": orgb, "dist": odist, "d pts_o": po.grad, "d pts_d": pd.grad, "d view": pv.grad}
+        for n in L.LAYER_NAMES:
+            out["dW " + n], out["db " + n] = P[n + ".weight"].grad, P[n + ".bias"].grad
+        return {k: v.detach().double() for k, v in out.items()}
+    ref, ref32 = oracle(torch.float64), oracle(torch.float32)
+    got = {"rgb": rgb, "dist": dist, "d pts_o": oo.grad, "d pts_d": dd.grad, "d view": vv.grad}
+    for i, n in enumerate(L.LAYER_NAMES):
+        got["dW " + n], got["db " + n] = w[i].grad, b[i].grad
+    for k, r in ref.items():
+        scale = max(1.0, float(r.abs().max()))
+        tol = max(TOL * scale, 4.0 * float((ref32[k] - r).abs().max()))
+        err = float((got[k].detach().cpu().double() - r).abs().max())
+        assert err <= tol, (k, D, R, N, err, tol)
+
+
 def test_full_image_inference_matches_oracle(tmp_path):
     """The evaluation / visualisation drivers (Extract_Images -> forward-only kernel in ray chunks) against the oracle."""
     import model as mdl
