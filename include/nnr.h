@@ -207,6 +207,15 @@ int nnr_aux_terms_bwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* 
                       const float* K, const float* Kinv, const float* rel, const float* scale2, const float* g_out,
                       float* g_d1_img, float* g_d2_img, float* g_rel_scale, float* workspace, void* stream);
 
+/* out[0..r) = torch.randperm(n, device=cuda)[:r] (the pixel pick of model/training.py:257) from the n int64 keys torch's
+ * randperm would have drawn (keys = empty(n, int64).random_(INT64_MIN, INT64_MAX)), the number of key bits it sorts by, and
+ * the generator's (seed, philox offset) at the point where torch re-shuffles duplicate keys -- without sorting all n keys.
+ * scratch: 8 + 8*4096 bytes, 8-byte aligned; scratch word [1] becomes 1 if the candidate buffer under/overflowed (probability
+ * < 1e-20 by construction).  NNR_E_UNSUPPORTED where the packing does not fit (bits + ceil(log2 n) > 64, r > 1504, n < 8r):
+ * callers fall back to torch.randperm. */
+int nnr_randperm_prefix(const int64_t* keys, int64_t n, int32_t bits, int32_t r, uint64_t seed, uint64_t offset, int64_t* out,
+                        void* scratch, void* stream);
+
 /* depth = nearest-resize(depth_img (hd,wd) -> (h,w)).flatten()[ray_idx]  (model/network.py:22-24) without materialising
  * the resized image; backward scatter-adds into a zero-filled (hd,wd) gradient image. */
 int nnr_depth_gather_fwd(const float* depth_img, const int64_t* ray_idx, float* out, int32_t n_rays, int32_t h, int32_t w,

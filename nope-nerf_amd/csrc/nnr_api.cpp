@@ -523,6 +523,16 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
     NNR_LAUNCH(launch_pc_error_bwd(src, dst, idx, dist, g_loss, n_src, g_src, g_dst, (hipStream_t)stream));
 }
 
+int nnr_randperm_prefix(const int64_t* keys, int64_t n, int32_t bits, int32_t r, uint64_t seed, uint64_t offset, int64_t* out,
+                        void* scratch, void* stream) {
+    int idx_bits = 1;
+    while ((1ll << idx_bits) < n) ++idx_bits;
+    if (!keys || !out || !scratch || n <= 0 || r <= 0 || r > n || bits < 1 || bits > 64) return NNR_E_BADCFG;
+    if (bits + idx_bits > 64 || 2 * (int64_t)r + 64 > 2048 + 1024 || n < 8 * (int64_t)r) return NNR_E_UNSUPPORTED;
+    if (((uintptr_t)scratch & 7) != 0) return NNR_E_ALIGN;
+    NNR_LAUNCH(launch_randperm_prefix(keys, n, bits, r, seed, offset, out, static_cast<unsigned int*>(scratch), (hipStream_t)stream));
+}
+
 namespace {
 // workspace of the per-image losses, in floats; 8-byte items first so that they stay aligned
 size_t aux_fill(const nnr_aux_cfg* c, float* ws, nnr::AuxArgs& a) {   // returns the workspace size in floats, 0 = bad cfg

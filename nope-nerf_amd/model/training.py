@@ -20,7 +20,7 @@ from torch.nn import functional as F
 
 from model.common import arange_pixels, get_tensor_values, project_to_cam, transform_to_world
 from model.losses import Loss
-from nnr import camera, parallel
+from nnr import camera, parallel, sampling
 
 logger_py = logging.getLogger(__name__)
 
@@ -152,7 +152,7 @@ class Trainer(object):
 
         # pixel pick: the permutation is drawn exactly as the reference does (training.py:257), so indices are bit-identical
         n_points = self.n_training_points
-        ray_idx = torch.randperm(h * w, device=device)[:n_points]
+        ray_idx = sampling.randperm_prefix(h * w, n_points, device)   # == torch.randperm(h * w, device=device)[:n_points]
         n_total = ray_idx.shape[0]
         lo, hi = parallel.shard_bounds(n_total, rank, world)
         ray_loc = ray_idx[lo:hi]

