@@ -112,7 +112,7 @@ def _hbm_traffic(kernel):
         return None
     with open(path) as f:
         table = json.load(f)['kernels']
-    key = {'mlp_fwd': 'mlp_fwd_kernel<256, true>', 'mlp_dgrad': 'mlp_dgrad_kernel<256>', 'mlp_wgrad': 'wgrad_kernel('}[kernel]
+    key = {'mlp_fwd': 'mlp_fwd_kernel<256, true, false>', 'mlp_dgrad': 'mlp_dgrad_kernel<256, false>', 'mlp_wgrad': 'wgrad_kernel<false>'}[kernel]
     for name, v in table.items():
         if key in name:
             return int(v['fetch_bytes'] + v['write_bytes'])
