@@ -180,3 +180,16 @@ def test_resize_nearest_matches_interpolate():
     a = np.random.default_rng(0).standard_normal((21, 34)).astype(np.float32)
     ref = F.interpolate(torch.from_numpy(a)[None, None], (40, 57), mode='nearest')[0, 0].numpy()
     np.testing.assert_array_equal(resize_nearest(a, (40, 57)), ref)
+
+
+def test_bench_traffic_lookup_finds_the_committed_pmc_summary():
+    """bench.py reports roofline.traffic from profiles/r01/hbm_traffic.json; the kernel-name keys must keep matching."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k in ("mlp_fwd", "mlp_dgrad", "mlp_wgrad"):
+        t = bench._hbm_traffic(k)
+        assert t is not None and 1e9 < t < 1e10, (k, t)
