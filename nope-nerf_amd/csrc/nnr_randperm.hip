@@ -7,7 +7,7 @@
 // Fisher-Yates driven by Philox (seed, subsequence = island start position, offset = the generator's offset before the
 // call).  The first r positions of that permutation are the indices of the r smallest masked keys in (key, index) order,
 // with the islands that START among them shuffled the same way.  So: keep the candidates below a threshold chosen for
-// ~2r + 64 expected hits (10 sigma above r, 40 sigma below the buffer), sort those in LDS, replay the island shuffles.
+// ~1.5r + 96 expected hits (15 sigma above r, 60 sigma below the buffer), sort those in LDS, replay the island shuffles.
 // The host side draws the keys with the same torch call and advances the generator exactly as torch would
 // (nope-nerf_amd/nnr/sampling.py, which also self-checks against torch.randperm on first use).
 #include <hiprand/hiprand_kernel.h>
@@ -24,11 +24,17 @@ constexpr int kRpCap = 4096;   // candidate capacity (power of two: bitonic sort
 __global__ void randperm_select_kernel(const int64_t* __restrict__ keys, int64_t n, unsigned long long mask, unsigned long long limit,
                                        int idx_bits, unsigned int* __restrict__ scratch) {
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(scratch + 2);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned long long k = (unsigned long long)keys[i] & mask;
+    // two consecutive keys per thread, the grid covers n once
+    const int64_t i0 = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    if (i0 >= n) return;
+    const long long kk[2] = {keys[i0], i0 + 1 < n ? keys[i0 + 1] : 0ll};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (i0 + u >= n) break;
+        const unsigned long long k = (unsigned long long)kk[u] & mask;
         if (k < limit) {
             const unsigned int p = atomicAdd(scratch, 1u);
-            if (p < kRpCap) cand[p] = (k << idx_bits) | (unsigned long long)i;
+            if (p < kRpCap) cand[p] = (k << idx_bits) | (unsigned long long)(i0 + u);
         }
     }
 }
@@ -41,12 +47,13 @@ __global__ __launch_bounds__(1024) void randperm_finish_kernel(unsigned int* __r
     const unsigned int count = scratch[0];
     const int m = count < (unsigned)kRpCap ? (int)count : kRpCap;
     if (threadIdx.x == 0) scratch[1] = (count < (unsigned)r || count > (unsigned)kRpCap) ? 1u : 0u;
-    for (int i = threadIdx.x; i < kRpCap; i += 1024) s[i] = i < m ? cand[i] : ~0ull;
+    const int sort_n = m <= kRpCap / 2 ? kRpCap / 2 : kRpCap;   // the usual count (~1.5r + 96 <= 2048) sorts in half the steps
+    for (int i = threadIdx.x; i < sort_n; i += 1024) s[i] = i < m ? cand[i] : ~0ull;
     __syncthreads();
     // bitonic sort, ascending by (masked key, index): the order a stable sort by key leaves
-    for (int k = 2; k <= kRpCap; k <<= 1)
+    for (int k = 2; k <= sort_n; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < kRpCap / 2; t += 1024) {
+            for (int t = threadIdx.x; t < sort_n / 2; t += 1024) {
                 const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
                 const bool up = (lo & k) == 0;
                 const unsigned long long a = s[lo], b = s[hi];
@@ -83,12 +90,12 @@ hipError_t launch_randperm_prefix(const int64_t* keys, int64_t n, int bits, int 
     int idx_bits = 1;
     while ((1ll << idx_bits) < n) ++idx_bits;
     const unsigned long long mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
-    // expected candidates 2r + 64: limit = 2^bits * (2r + 64) / n
-    const long double frac = (long double)(2 * r + 64) / (long double)n;
+    // expected candidates 1.5r + 96: limit = 2^bits * (1.5r + 96) / n
+    const long double frac = (long double)(r + r / 2 + 96) / (long double)n;
     const unsigned long long limit = (unsigned long long)((long double)(bits >= 64 ? 18446744073709551615.0L : (long double)(1ull << bits)) * frac);
     hipError_t e = hipMemsetAsync(scratch, 0, 2 * sizeof(unsigned int), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(randperm_select_kernel, dim3(512), dim3(256), 0, st, keys, n, mask, limit, idx_bits, scratch);
+    hipLaunchKernelGGL(randperm_select_kernel, dim3((unsigned)((n / 2 + 256) / 256)), dim3(256), 0, st, keys, n, mask, limit, idx_bits, scratch);
     hipLaunchKernelGGL(randperm_finish_kernel, dim3(1), dim3(1024), 0, st, scratch, r, idx_bits, seed, offset, out);
     return hipGetLastError();
 }
