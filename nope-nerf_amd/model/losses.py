@@ -39,8 +39,16 @@ class SSIM(nn.Module):
 compute_ssim_loss = SSIM()
 
 
+_ZEROS = {}
+
+
 def _zero(ref):
-    return torch.zeros((), dtype=torch.float32, device=ref.device)
+    """The constant 0 that inactive loss terms report, one tensor per device (a fresh torch.zeros(()) is a kernel launch, and
+    a step reports five to eight of them).  Read-only by convention: callers log it or add it, never write into it."""
+    z = _ZEROS.get(ref.device)
+    if z is None:
+        z = _ZEROS[ref.device] = torch.zeros((), dtype=torch.float32, device=ref.device)
+    return z
 
 
 class Loss(nn.Module):

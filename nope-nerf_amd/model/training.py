@@ -19,7 +19,7 @@ from PIL import Image
 from torch.nn import functional as F
 
 from model.common import arange_pixels, get_tensor_values, project_to_cam, transform_to_world
-from model.losses import Loss
+from model.losses import Loss, _zero
 from nnr import camera, parallel, sampling
 
 logger_py = logging.getLogger(__name__)
@@ -239,7 +239,7 @@ class Trainer(object):
             parts = {k: v / world for k, v in parts.items()}
             aux = aux / world if aux is not None else None
         loss_dict = dict(parts)
-        zero = torch.zeros((), device=rgb_gt.device)
+        zero = _zero(rgb_gt)
         if out is None:
             lmain, lrgb, ldep, l2 = zero, zero, zero, zero
         elif fused:

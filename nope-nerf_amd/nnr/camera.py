@@ -148,7 +148,8 @@ class _RenderLoss(torch.autograd.Function):
         R, dev = a.shape[0], a.device
         f = dict(dtype=torch.float32, device=dev)
         out = torch.empty(5, **f)
-        g_rgb, g_dist, g_dgt = torch.empty(R, 3, **f), torch.empty(R, **f), torch.empty(R, **f)
+        flat = torch.empty(5 * R, **f)                       # the three gradient tensors in one allocation: scaled by one launch
+        g_rgb, g_dist, g_dgt = flat[:3 * R].view(R, 3), flat[3 * R:4 * R], flat[4 * R:]
         m_dev = None
         if torch.is_tensor(m_total):                      # device scalar (data-parallel global count): no host sync
             m_dev = m_total.detach().float().reshape(1).contiguous()
@@ -156,17 +157,18 @@ class _RenderLoss(torch.autograd.Function):
         L.check(L.load().nnr_render_loss(L.ptr(a), L.ptr(b), L.ptr(c), L.ptr(d), L.ptr(m), R, float(r_total), float(m_total),
                                          float(w_rgb), float(w_depth), int(rgb_l2), int(ndc), int(detach_gt), L.ptr(m_dev), L.ptr(out),
                                          L.ptr(g_rgb), L.ptr(g_dist), L.ptr(g_dgt), _st()), "nnr_render_loss")
-        ctx.save_for_backward(g_rgb, g_dist, g_dgt)
-        ctx.shapes = (rgb.shape, dist.shape, d_gt.shape)
+        ctx.save_for_backward(flat)
+        ctx.shapes = (rgb.shape, dist.shape, d_gt.shape, R)
         aux = out[1:]
         ctx.mark_non_differentiable(aux)
         return out[0], aux
 
     @staticmethod
     def backward(ctx, g, _ga):
-        g_rgb, g_dist, g_dgt = ctx.saved_tensors
-        s0, s1, s2 = ctx.shapes
-        return ((g_rgb * g).view(s0), None, (g_dist * g).view(s1), (g_dgt * g).view(s2)) + (None,) * 8
+        (flat,) = ctx.saved_tensors
+        s0, s1, s2, R = ctx.shapes
+        scaled = flat * g                                    # one launch for all three
+        return (scaled[:3 * R].view(s0), None, scaled[3 * R:4 * R].view(s1), scaled[4 * R:].view(s2)) + (None,) * 8
 
 
 def render_loss(rgb, rgb_gt, dist, d_gt, mask, *, r_total, m_total=-1.0, w_rgb, w_depth, rgb_l2=False, ndc=False,
