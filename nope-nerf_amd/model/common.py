@@ -8,8 +8,8 @@ Hot-path items and the reference lines 
   get_ndc_rays_fxfy        model/common.py:632-675
   vec2skew / Exp / make_c2w / convert3x4_4x4                   model/common.py:277-330
 Everything here is a handful of O(R) or O(1) torch ops per step; the per-sample work lives in the HIP kernels.
-The render-path-generation and metric helpers of the reference's common.py (spirals, b-splines, depth metrics)
-are host-side tooling outside the hot path and are not provided.
+The novel-view path generators vis/render.py imports from here (spiral, slerp / B-spline interpolation of the learned poses,
+common.py:333-404,511-615) live in model/trajectories.py and are re-exported below.
 """
 import logging
 import os
@@ -17,6 +17,10 @@ import shutil
 
 import numpy as np
 import torch
+
+from model.trajectories import (create_spheric_poses, generate_spiral_nerf, get_poses_at_times, interp_poses,  # noqa: F401
+                                interp_poses_bspline, interp_t, normalize, poses_avg, render_path_spiral, scipy_bspline,
+                                viewmatrix)
 
 logger_py = logging.getLogger(__name__)
 

@@ -2,22 +2,26 @@
 model/distortions.py:4-26: scale is floored at the *constant* 0.01 (no gradient below it) and the last camera's
 scale is pinned to 1 when distortion.fix_scaleN is set."""
 import torch
-import torch.nn as nn
+from torch import nn
+
+_SCALE_FLOOR = 0.01
 
 
 class Learn_Distortion(nn.Module):
+    """state_dict keys: global_scales, global_shifts -- both (num_cams, 1)."""
+
     def __init__(self, num_cams, learn_scale, learn_shift, cfg):
         super().__init__()
-        self.global_scales = nn.Parameter(torch.ones(num_cams, 1), requires_grad=learn_scale)
-        self.global_shifts = nn.Parameter(torch.zeros(num_cams, 1), requires_grad=learn_shift)
-        self.fix_scaleN = cfg['distortion']['fix_scaleN']
         self.num_cams = num_cams
+        self.fix_scaleN = cfg['distortion']['fix_scaleN']
+        self.global_shifts = nn.Parameter(torch.zeros(num_cams, 1), requires_grad=learn_shift)
+        self.global_scales = nn.Parameter(torch.ones(num_cams, 1), requires_grad=learn_scale)
 
     def forward(self, cam_id):
-        cid = int(cam_id)
-        scale = self.global_scales[cam_id]
-        # value AND gradient of the reference's `if scale < 0.01: scale = tensor(0.01)` without the device->host sync
-        scale = torch.where(scale < 0.01, torch.full_like(scale, 0.01), scale)
-        if self.fix_scaleN and cid == self.num_cams - 1:
-            scale = torch.ones_like(scale).detach()
-        return scale, self.global_shifts[cam_id]
+        """-> (scale, shift) of one camera, (1,) each."""
+        shift = self.global_shifts[cam_id]
+        if self.fix_scaleN and int(cam_id) == self.num_cams - 1:
+            return torch.ones_like(shift), shift                      # the gauge: the last view's depth scale is 1
+        raw = self.global_scales[cam_id]
+        # value AND gradient of the reference's `if scale < 0.01: scale = tensor(0.01)` without its device->host sync
+        return torch.where(raw < _SCALE_FLOOR, torch.full_like(raw, _SCALE_FLOOR), raw), shift

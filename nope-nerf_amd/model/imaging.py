@@ -9,8 +9,10 @@ from model.common import arange_pixels
 
 
 def camera_from_focal(fxfy, device):
+    """(1,4,4) K = diag(fx, -fy, -1, 1) from a (frozen) learned focal pair; device-side copies, no host sync."""
     k = torch.zeros(1, 4, 4, device=device)
-    k[0, 0, 0], k[0, 1, 1], k[0, 2, 2], k[0, 3, 3] = float(fxfy[0]), -float(fxfy[1]), -1.0, 1.0
+    fxfy = fxfy.detach().to(device)
+    k[0, 0, 0], k[0, 1, 1], k[0, 2, 2], k[0, 3, 3] = fxfy[0], -fxfy[1], -1.0, 1.0
     return k
 
 

@@ -236,7 +236,8 @@ class Trainer(object):
             return loss_dict
         aux, parts = self.loss.aux_terms(rgb_gt, **kwargs)
         if world > 1:
-            parts = {k: v / world for k, v in parts.items()}
+            zero = _zero(rgb_gt)
+            parts = {k: (v if v is zero else v / world) for k, v in parts.items()}   # inactive terms stay the cached 0
             aux = aux / world if aux is not None else None
         loss_dict = dict(parts)
         zero = _zero(rgb_gt)

@@ -55,6 +55,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], loss_dict: Optiona
         if p.grad is None:
             p.grad = views[i].clone()
     for k in keys:
-        # keep the autograd-free logged value; 'loss' itself is no longer needed for backward at this point
-        loss_dict[k] = flat[off].clone()
+        # the autograd-free logged value ('loss' is no longer needed for backward at this point); a view of the private
+        # bucket, not a copy -- each copy would be one more launch per step
+        loss_dict[k] = flat[off]
         off += 1
