@@ -155,9 +155,14 @@ Plan build_plan(const nnr_cfg* c) {
         const char* e = std::getenv("NNR_WGRAD_MAX_BLOCKS");
         return e ? std::max(2, std::atoi(e)) : kMaxBlocks;
     }();
-    const int n_blocks = (int)std::max<int64_t>(2, std::min<int64_t>(max_blocks, granules * (int64_t)groups.size() / kMinGranulesPerBlock));
+    // Workgroups: one per kMinGranulesPerBlock granules of a D x D-at-256 group's worth of work (four 4x4 tiles), counted over
+    // BOTH classes -- at D = 128 every unit is class B (a D x D layer is a single tile there), and sizing the launch by the
+    // class-A groups alone left that whole configuration on one workgroup.
+    const int64_t group_cost = 4 * 16 * 1000;
+    const int64_t group_equiv = std::max<int64_t>(1, (cost_a + cost_b + group_cost / 2) / group_cost);
+    const int n_blocks = (int)std::max<int64_t>(2, std::min<int64_t>(max_blocks, granules * group_equiv / kMinGranulesPerBlock));
     int nb_b = (int)((cost_b * n_blocks + (cost_a + cost_b) / 2) / (cost_a + cost_b));
-    nb_b = std::max(1, std::min(n_blocks - 1, nb_b));
+    nb_b = groups.empty() ? n_blocks : std::max(1, std::min(n_blocks - 1, nb_b));
     const int nb_a = n_blocks - nb_b;
 
     std::vector<std::vector<WgradJob>> per_wave((size_t)n_blocks * 4);

@@ -20,7 +20,8 @@ def umeyama_sim3(model, data):
     if np.linalg.det(U) * np.linalg.det(Vt.T) < 0:
         S[2, 2] = -1
     R = U @ S @ Vt
-    s = np.trace(np.diag(sv) @ S) / var_d
+    with np.errstate(divide='ignore', invalid='ignore'):      # coincident centres (identity initialisation): s is nan, as in the reference
+        s = np.trace(np.diag(sv) @ S) / var_d
     return s, R, mu_m - s * R @ mu_d
 
 

@@ -193,3 +193,19 @@ def test_bench_traffic_lookup_finds_the_committed_pmc_summary():
     for k in ("mlp_fwd", "mlp_dgrad", "mlp_wgrad"):
         t = bench._hbm_traffic(k)
         assert t is not None and 1e9 < t < 1e10, (k, t)
+
+
+def test_scene_training_loop_on_the_cpu_stand_in(monkeypatch, tmp_path):
+    """tools/train_scene.py end to end (scene writer -> dataloading -> Trainer -> pose metrics) with the oracle-backed operator."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import scene_writer
+    import train_scene
+    from model import rendering
+    monkeypatch.setattr(rendering.nnr, "render_rays", oracle_backend.render_rays)
+    scene_writer.write_scene(str(tmp_path), scene="toy", frames=5, size=(24, 32), seed=4)
+    res = train_scene.run(str(tmp_path), "toy", epochs=2, log_every=1, device="cpu", n_rays=16, n_samples=8, hidden=128,
+                          sample_rate=10 ** 6)
+    assert res["steps"] == 10 and res["views"] == 5 and len(res["curve"]) == 3
+    assert res["curve"][0]["psnr"] is None and res["curve"][-1]["psnr"] > 0 and res["curve"][-1]["ate"] > 0
