@@ -111,7 +111,8 @@ std::vector<Unit> wgrad_units(int D) {
 constexpr int kMaxBlocks = 256;   // one 4-wave workgroup per CU: the kernel needs the whole register file, and every
                                   // workgroup must be resident at once (a 257th would run as a second round)
 constexpr int kGranule = 16;      // samples per loop iteration of the wgrad kernel (two stages of kU = 4 sample pairs)
-constexpr int kMinGranulesPerBlock = 64;  // small problems use fewer workgroups (each job costs a 64 KB slot + a flush)
+constexpr int kMinGranulesPerBlock = 16;  // small problems use fewer workgroups: a job costs a 64 KB slot + its flush (~2 us),
+                                          // a granule of a 4x4 tile ~3.4 us of MFMA, so 16 granules keep the flush under 4 %
 
 struct Plan {
     std::vector<WgradJob> jobs;        // grouped by wave: wave w runs jobs [wave_first[w], wave_first[w+1])
