@@ -529,12 +529,17 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
     NNR_LAUNCH(launch_pc_error_bwd(src, dst, idx, dist, g_loss, n_src, g_src, g_dst, (hipStream_t)stream));
 }
 
+size_t nnr_randperm_scratch_bytes(int32_t r) {
+    const unsigned int cap = r > 0 ? nnr::randperm_capacity(r) : 0;
+    return cap ? 8 + 8 * (size_t)cap : 0;
+}
+
 int nnr_randperm_prefix(const int64_t* keys, int64_t n, int32_t bits, int32_t r, uint64_t seed, uint64_t offset, int64_t* out,
                         void* scratch, void* stream) {
     int idx_bits = 1;
     while ((1ll << idx_bits) < n) ++idx_bits;
     if (!keys || !out || !scratch || n <= 0 || r <= 0 || r > n || bits < 1 || bits > 64) return NNR_E_BADCFG;
-    if (bits + idx_bits > 64 || 2 * (int64_t)r + 64 > 2048 + 1024 || n < 8 * (int64_t)r) return NNR_E_UNSUPPORTED;
+    if (bits + idx_bits > 64 || nnr::randperm_capacity(r) == 0 || n < 8 * (int64_t)r) return NNR_E_UNSUPPORTED;
     if (((uintptr_t)scratch & 7) != 0) return NNR_E_ALIGN;
     NNR_LAUNCH(launch_randperm_prefix(keys, n, bits, r, seed, offset, out, static_cast<unsigned int*>(scratch), (hipStream_t)stream));
 }

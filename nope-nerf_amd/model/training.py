@@ -222,13 +222,16 @@ class Trainer(object):
         w = kwargs['weights']
         m_total = -1.0
         if world > 1:
-            from model.network import nearest_source_index
             h_img, w_img = img_size
-            hd, wd = depth_input.shape[-2:]
             with torch.no_grad():   # global count of rays with a usable mono depth (finite, non-zero): no collective needed
-                ys = nearest_source_index(torch.div(ray_idx, w_img, rounding_mode='floor'), h_img, hd)
-                xs = nearest_source_index(ray_idx % w_img, w_img, wd)
-                d_all = depth_input[0, 0][ys, xs]
+                if depth_input.is_cuda:
+                    d_all = camera.depth_gather(depth_input, ray_idx, h_img, w_img)          # one launch
+                else:
+                    from model.network import nearest_source_index
+                    hd, wd = depth_input.shape[-2:]
+                    ys = nearest_source_index(torch.div(ray_idx, w_img, rounding_mode='floor'), h_img, hd)
+                    xs = nearest_source_index(ray_idx % w_img, w_img, wd)
+                    d_all = depth_input[0, 0][ys, xs]
                 m_total = (torch.isfinite(d_all) & (d_all != 0)).sum().float()   # stays on the device: no sync
         fused = (out is not None and rgb.is_cuda and self.loss.depth_loss_type == 'l1' and 'dist_dense' in out)
         if not fused and world == 1:

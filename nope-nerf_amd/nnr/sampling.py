@@ -16,7 +16,6 @@ from . import lib as L
 
 _CHECKS = 3          # first calls (per process) verified against torch.randperm
 _state = {"checked": 0, "enabled": True}
-_SCRATCH_WORDS = 2 + 2 * 4096
 
 
 def _key_bits(n: int) -> int:
@@ -26,13 +25,22 @@ def _key_bits(n: int) -> int:
     return min(64, int(math.ceil(math.log2(nd - (6 * nd * nd + 1) / log_threshold_12))))
 
 
+def _capacity(r: int) -> int:
+    """Candidate-buffer size of the kernel for a pick of r (mirror of randperm_capacity in nnr_randperm.hip; equality with
+    nnr_randperm_scratch_bytes is asserted in tests/test_host_logic.py): the threshold is set for r + 20 sqrt(r) + 64 expected
+    candidates and the buffer leaves 40 sigma above that.  0 = too many for the in-LDS sort."""
+    expect = r + 20.0 * math.sqrt(r) + 64.0
+    hi = expect + 40.0 * math.sqrt(expect)
+    return 4096 if hi <= 4096 else 16384 if hi <= 16384 else 0
+
+
 def _fast(n: int, r: int, device) -> torch.Tensor:
     gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
     keys = torch.empty(n, dtype=torch.int64, device=device).random_(-2 ** 63, 2 ** 63 - 1)   # the call randperm makes (bits > 32)
     seed, offset = gen.initial_seed(), gen.get_offset()
     gen.set_offset(offset + (n + 3) // 4 * 4)        # philox_cuda_state(n) of randperm_handle_duplicate_keys
     out = torch.empty(r, dtype=torch.int64, device=device)
-    scratch = torch.empty(_SCRATCH_WORDS, dtype=torch.int32, device=device)
+    scratch = torch.empty(2 + 2 * _capacity(r), dtype=torch.int32, device=device)
     L.check(L.load().nnr_randperm_prefix(L.ptr(keys), n, _key_bits(n), r, seed, offset, L.ptr(out), L.ptr(scratch),
                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_randperm_prefix")
     return out
@@ -40,7 +48,7 @@ def _fast(n: int, r: int, device) -> torch.Tensor:
 
 def supported(n: int, r: int) -> bool:
     bits = _key_bits(n)
-    return bits > 32 and bits + max(1, (n - 1).bit_length()) <= 64 and 2 * r + 64 <= 3072 and n >= 8 * r
+    return bits > 32 and bits + max(1, (n - 1).bit_length()) <= 64 and _capacity(r) > 0 and n >= 8 * r
 
 
 def randperm_prefix(n: int, r: int, device) -> torch.Tensor:

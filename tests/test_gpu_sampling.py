@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 
 
-@pytest.mark.parametrize("n,r", [(540 * 960, 1024), (756 * 1008, 1024), (480 * 640 + 7, 333), (46_400, 64), (1_000_003, 1500)])
+@pytest.mark.parametrize("n,r", [(540 * 960, 1024), (756 * 1008, 1024), (480 * 640 + 7, 333), (46_400, 64), (1_000_003, 1500),
+                                 (540 * 960, 2048), (540 * 960, 4096), (540 * 960, 8192), (756 * 1008, 9943)])
 def test_matches_torch_randperm_and_leaves_the_same_generator_state(n, r):
     from nnr import sampling
     assert sampling.supported(n, r)
@@ -32,11 +33,12 @@ def test_matches_torch_randperm_and_leaves_the_same_generator_state(n, r):
 def test_unsupported_sizes_fall_back_to_torch():
     from nnr import sampling
     assert not sampling.supported(1000, 10)                    # 32-bit key branch of torch's randperm
-    assert not sampling.supported(540 * 960, 4096)             # more rays than the candidate buffer is sized for
-    torch.manual_seed(5)
-    a = sampling.randperm_prefix(1000, 10, DEV)
-    torch.manual_seed(5)
-    assert torch.equal(a, torch.randperm(1000, device=DEV)[:10])
+    assert not sampling.supported(540 * 960, 20000)            # more rays than the larger candidate buffer is sized for
+    for n, r in ((1000, 10), (540 * 960, 20000)):
+        torch.manual_seed(5)
+        a = sampling.randperm_prefix(n, r, DEV)
+        torch.manual_seed(5)
+        assert torch.equal(a, torch.randperm(n, device=DEV)[:r])
 
 
 def test_self_check_disables_the_fast_path_on_mismatch(monkeypatch):

@@ -209,3 +209,16 @@ def test_scene_training_loop_on_the_cpu_stand_in(monkeypatch, tmp_path):
                           sample_rate=10 ** 6)
     assert res["steps"] == 10 and res["views"] == 5 and len(res["curve"]) == 3
     assert res["curve"][0]["psnr"] is None and res["curve"][-1]["psnr"] > 0 and res["curve"][-1]["ate"] > 0
+
+
+def test_pixel_pick_capacity_rule_matches_the_library():
+    """nnr/sampling.py decides in Python whether the fast pixel pick applies; the C side must agree for every r."""
+    import ctypes as C
+    from nnr import lib as L
+    from nnr import sampling
+    lib = L.load()
+    for r in list(range(1, 3000, 7)) + [1401, 1402, 8192, 9943, 9944, 12288, 32768]:
+        cap = sampling._capacity(r)
+        assert lib.nnr_randperm_scratch_bytes(r) == (8 + 8 * cap if cap else 0), r
+    assert sampling._capacity(1024) == 4096 and sampling._capacity(8192) == 16384 and sampling._capacity(9944) == 0
+    assert sampling.supported(540 * 960, 8192) and not sampling.supported(540 * 960, 70000)
