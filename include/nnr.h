@@ -210,10 +210,11 @@ int nnr_aux_terms_bwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* 
 /* out[0..r) = torch.randperm(n, device=cuda)[:r] (the pixel pick of model/training.py:257) from the n int64 keys torch's
  * randperm would have drawn (keys = empty(n, int64).random_(INT64_MIN, INT64_MAX)), the number of key bits it sorts by, and
  * the generator's (seed, philox offset) at the point where torch re-shuffles duplicate keys -- without sorting all n keys.
- * scratch: nnr_randperm_scratch_bytes(r) bytes (8 + 8 * 4096 up to r = 1401, 8 + 8 * 16384 up to r = 9943), 8-byte aligned;
- * scratch word [1] becomes 1 if the candidate buffer under/overflowed (probability < 1e-50 by construction: the threshold
- * leaves >= 16 sigma below and >= 40 sigma above the expected count).  NNR_E_UNSUPPORTED where the packing or the LDS sort
- * does not fit (bits + ceil(log2 n) > 64, scratch_bytes(r) == 0, n < 8r): callers fall back to torch.randperm. */
+ * scratch: nnr_randperm_scratch_bytes(r) bytes = 8 + 20 * capacity (capacity 4096 up to r = 1401, 16384 up to r = 9943, 65536
+ * up to r = 51463), 8-byte aligned; scratch word [1] becomes 1 if the candidate buffer under/overflowed (probability < 1e-50 by
+ * construction: the threshold leaves >= 16 sigma below and >= 40 sigma above the expected count).  NNR_E_UNSUPPORTED where the
+ * packing does not fit or r is beyond the largest buffer (bits + ceil(log2 n) > 64, scratch_bytes(r) == 0, n < 8r): callers fall
+ * back to torch.randperm. */
 size_t nnr_randperm_scratch_bytes(int32_t r);
 int nnr_randperm_prefix(const int64_t* keys, int64_t n, int32_t bits, int32_t r, uint64_t seed, uint64_t offset, int64_t* out,
                         void* scratch, void* stream);

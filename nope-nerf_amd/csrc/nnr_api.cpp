@@ -531,7 +531,7 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
 
 size_t nnr_randperm_scratch_bytes(int32_t r) {
     const unsigned int cap = r > 0 ? nnr::randperm_capacity(r) : 0;
-    return cap ? 8 + 8 * (size_t)cap : 0;
+    return cap ? 8 + 20 * (size_t)cap : 0;   // header, u32 ranks, u64 candidates, u64 candidates in order
 }
 
 int nnr_randperm_prefix(const int64_t* keys, int64_t n, int32_t bits, int32_t r, uint64_t seed, uint64_t offset, int64_t* out,

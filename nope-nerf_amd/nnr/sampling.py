@@ -28,10 +28,10 @@ def _key_bits(n: int) -> int:
 def _capacity(r: int) -> int:
     """Candidate-buffer size of the kernel for a pick of r (mirror of randperm_capacity in nnr_randperm.hip; equality with
     nnr_randperm_scratch_bytes is asserted in tests/test_host_logic.py): the threshold is set for r + 20 sqrt(r) + 64 expected
-    candidates and the buffer leaves 40 sigma above that.  0 = too many for the in-LDS sort."""
+    candidates and the buffer leaves 40 sigma above that.  0 = beyond the largest buffer."""
     expect = r + 20.0 * math.sqrt(r) + 64.0
     hi = expect + 40.0 * math.sqrt(expect)
-    return 4096 if hi <= 4096 else 16384 if hi <= 16384 else 0
+    return next((c for c in (4096, 16384, 65536) if hi <= c), 0)
 
 
 def _fast(n: int, r: int, device) -> torch.Tensor:
@@ -40,7 +40,7 @@ def _fast(n: int, r: int, device) -> torch.Tensor:
     seed, offset = gen.initial_seed(), gen.get_offset()
     gen.set_offset(offset + (n + 3) // 4 * 4)        # philox_cuda_state(n) of randperm_handle_duplicate_keys
     out = torch.empty(r, dtype=torch.int64, device=device)
-    scratch = torch.empty(2 + 2 * _capacity(r), dtype=torch.int32, device=device)
+    scratch = torch.empty(2 + 5 * _capacity(r), dtype=torch.int32, device=device)     # header, ranks, candidates, ordered
     L.check(L.load().nnr_randperm_prefix(L.ptr(keys), n, _key_bits(n), r, seed, offset, L.ptr(out), L.ptr(scratch),
                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_randperm_prefix")
     return out

@@ -13,7 +13,8 @@ DEV = torch.device("cuda", 0)
 
 
 @pytest.mark.parametrize("n,r", [(540 * 960, 1024), (756 * 1008, 1024), (480 * 640 + 7, 333), (46_400, 64), (1_000_003, 1500),
-                                 (540 * 960, 2048), (540 * 960, 4096), (540 * 960, 8192), (756 * 1008, 9943)])
+                                 (540 * 960, 2048), (540 * 960, 4096), (540 * 960, 8192), (756 * 1008, 9943),
+                                 (756 * 1008, 9944), (540 * 960, 32768)])
 def test_matches_torch_randperm_and_leaves_the_same_generator_state(n, r):
     from nnr import sampling
     assert sampling.supported(n, r)
@@ -33,8 +34,8 @@ def test_matches_torch_randperm_and_leaves_the_same_generator_state(n, r):
 def test_unsupported_sizes_fall_back_to_torch():
     from nnr import sampling
     assert not sampling.supported(1000, 10)                    # 32-bit key branch of torch's randperm
-    assert not sampling.supported(540 * 960, 20000)            # more rays than the larger candidate buffer is sized for
-    for n, r in ((1000, 10), (540 * 960, 20000)):
+    assert not sampling.supported(540 * 960, 60000)            # more rays than the largest candidate buffer is sized for
+    for n, r in ((1000, 10), (540 * 960, 60000)):
         torch.manual_seed(5)
         a = sampling.randperm_prefix(n, r, DEV)
         torch.manual_seed(5)
@@ -71,7 +72,7 @@ def test_duplicate_keys_are_reshuffled_like_torch():
         keys[grp] = (keys[grp[0]] & ~mask) | (7 * gi + 1)          # group gi shares the masked key 7*gi+1 (ascending with gi)
     seed, offset = 123456789, 4096
     out = torch.empty(r, dtype=torch.int64, device=DEV)
-    scratch = torch.empty(2 + 2 * 4096, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(L.load().nnr_randperm_scratch_bytes(r) // 4, dtype=torch.int32, device=DEV)
     kd = keys.to(DEV)
     L.check(L.load().nnr_randperm_prefix(L.ptr(kd), n, bits, r, seed, offset, L.ptr(out), L.ptr(scratch),
                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_randperm_prefix")

@@ -217,8 +217,9 @@ def test_pixel_pick_capacity_rule_matches_the_library():
     from nnr import lib as L
     from nnr import sampling
     lib = L.load()
-    for r in list(range(1, 3000, 7)) + [1401, 1402, 8192, 9943, 9944, 12288, 32768]:
+    for r in list(range(1, 3000, 7)) + [1401, 1402, 8192, 9943, 9944, 12288, 32768, 51463, 51464, 10 ** 6]:
         cap = sampling._capacity(r)
-        assert lib.nnr_randperm_scratch_bytes(r) == (8 + 8 * cap if cap else 0), r
-    assert sampling._capacity(1024) == 4096 and sampling._capacity(8192) == 16384 and sampling._capacity(9944) == 0
-    assert sampling.supported(540 * 960, 8192) and not sampling.supported(540 * 960, 70000)
+        assert lib.nnr_randperm_scratch_bytes(r) == (8 + 20 * cap if cap else 0), r
+    assert [sampling._capacity(r) for r in (1024, 1401, 1402, 8192, 9943, 9944, 32768, 51463, 51464)] == \
+        [4096, 4096, 16384, 16384, 16384, 65536, 65536, 65536, 0]
+    assert sampling.supported(540 * 960, 8192) and sampling.supported(540 * 960, 32768) and not sampling.supported(540 * 960, 70000)

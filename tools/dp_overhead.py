@@ -34,12 +34,13 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--skip-single", action="store_true", help="only the virtual-rank run (for a kernel trace of it)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     data = bench.synthetic_batch(dev)
     trainer, _ = bench.build_trainer(dev, 1)
-    single = timed(trainer, data, a.steps)
+    single = float('nan') if a.skip_single else timed(trainer, data, a.steps)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
