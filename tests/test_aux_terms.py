@@ -37,7 +37,7 @@ def test_oracle_aux_scope_matches_reference_golden(name):
         np.testing.assert_allclose(g.numpy(), GOLD[f"{name}.gaux.{k}"], rtol=0, atol=2e-6, err_msg=k)
 
 
-def _trainer(inp, dev, **training_overrides):
+def _trainer(inp, dev, adam=False, **training_overrides):
     import model as mdl
     if True:
         cfg = {
@@ -64,9 +64,10 @@ def _trainer(inp, dev, **training_overrides):
     with torch.no_grad():
         pose.r.copy_(inp["pose_r"]); pose.t.copy_(inp["pose_t"])
         dist.global_scales.copy_(inp["scales"]); dist.global_shifts.copy_(inp["shifts"])
-    sgd = lambda m: torch.optim.SGD(m.parameters(), lr=0.0)
-    tr = mdl.Trainer(model, sgd(model), cfg['training'], device=dev, optimizer_pose=sgd(pose), pose_param_net=pose,
-                     optimizer_distortion=sgd(dist), distortion_net=dist)
+    # lr-0 SGD for the single-step gradient checks; the reference's three Adam instances (configs/default.yaml:79-82) otherwise
+    opt = (lambda m, lr: torch.optim.Adam(m.parameters(), lr=lr)) if adam else (lambda m, lr: torch.optim.SGD(m.parameters(), lr=0.0))
+    tr = mdl.Trainer(model, opt(model, 1e-3), cfg['training'], device=dev, optimizer_pose=opt(pose, 5e-4), pose_param_net=pose,
+                     optimizer_distortion=opt(dist, 5e-4), distortion_net=dist)
     return tr, pose, dist
 
 
