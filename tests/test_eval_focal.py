@@ -1,0 +1,98 @@
+"""The two callers of the render path beyond the plain training step, against goldens from the reference classes
+(oracle/gen_golden_eval.py -> tests/golden/eval_focal.npz): the test-time pose-optimisation step (Trainer_pose, reference
+model/eval_pose_one_epoch.py) and a training step with a learnable focal length (LearnFocal, reference model/intrinsics.py +
+model/training.py:247-252,372-374).  CPU: oracle-backed operator (host logic); gpu: the HIP kernels."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in ("nope-nerf_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+
+GOLD = np.load(os.path.join(HERE, "golden", "eval_focal.npz"))
+R, N = 64, 32
+
+
+def _devices():
+    return [pytest.param("cpu"), pytest.param("cuda", marks=pytest.mark.gpu)]
+
+
+def _backend(dev, monkeypatch):
+    if dev == "cpu":
+        import oracle_backend
+        from model import rendering
+        monkeypatch.setattr(rendering.nnr, "render_rays", oracle_backend.render_rays)
+    return torch.device(dev)
+
+
+def _close(got, want, tol=1e-4):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    scale = max(1.0, float(np.abs(want).max()))
+    return float(np.abs(got - want).max()) / scale <= tol
+
+
+def _replay_perm(monkeypatch, ray_idx):
+    monkeypatch.setattr(torch, "randperm", lambda n, device=None, **kw: torch.cat([ray_idx, torch.zeros(n - R, dtype=torch.int64)]).to(device))
+
+
+@pytest.mark.parametrize("dev", _devices())
+def test_pose_optimisation_step_matches_the_reference(dev, monkeypatch):
+    import model as mdl
+    from test_aux_terms import _trainer
+    dev = _backend(dev, monkeypatch)
+    inp = {k: torch.from_numpy(GOLD["init." + k]) for k in ("pose_r", "pose_t", "scales", "shifts")}
+    tr, _, _ = _trainer(inp, dev)                                         # only for its seed-42 D=128 network + renderer
+    cfg = {"pose": {}}
+    pose = mdl.LearnPose(3, True, True, cfg, init_c2w=torch.from_numpy(GOLD["pose_opt.c2w0"]).to(dev)).to(dev)
+    with torch.no_grad():
+        pose.r.copy_(inp["pose_r"][:3]); pose.t.copy_(inp["pose_t"][:3])
+    tp = mdl.Trainer_pose(tr.model, {"n_points": R, "type": "nope_nerf"}, device=dev,
+                          optimizer_pose=torch.optim.SGD(pose.parameters(), lr=0.0), pose_param_net=pose)
+    _replay_perm(monkeypatch, torch.from_numpy(GOLD["pose_opt.ray_idx"]))
+    frame = int(GOLD["pose_opt.frame"])
+    data = {"img": torch.from_numpy(GOLD["imgs"][frame:frame + 1]), "img.idx": torch.tensor([int(GOLD["pose_opt.view"])]),
+            "img.camera_mat": torch.from_numpy(GOLD["K"]), "img.scale_mat": torch.eye(4).unsqueeze(0)}
+    ld = tp.train_step(data)
+    assert abs(float(ld["loss"].detach()) - float(GOLD["pose_opt.loss"])) <= 1e-6
+    assert _close(pose.r.grad, GOLD["pose_opt.g.r"], 1e-4 * float(np.abs(GOLD["pose_opt.g.r"]).max()))
+    assert _close(pose.t.grad, GOLD["pose_opt.g.t"], 1e-4 * float(np.abs(GOLD["pose_opt.g.t"]).max()))
+    assert not tr.model.training and pose.training                          # frozen field in eval mode, poses in train mode
+
+
+@pytest.mark.parametrize("dev", _devices())
+def test_training_step_with_learnable_focal_matches_the_reference(dev, monkeypatch):
+    import model as mdl
+    from test_aux_terms import _trainer
+    dev = _backend(dev, monkeypatch)
+    inp = {k: torch.from_numpy(GOLD["init." + k]) for k in ("pose_r", "pose_t", "scales", "shifts")}
+    tr0, pose, dist = _trainer(inp, dev)
+    focal = mdl.LearnFocal(True, False, order=2, init_focal=[float(GOLD["focal.init"][0]), float(GOLD["focal.init"][1])]).to(dev)
+    sgd = lambda m: torch.optim.SGD(m.parameters(), lr=0.0)
+    cfg = {k: getattr(tr0, k) for k in ('detach_gt_depth', 'pc_ratio', 'match_method', 'shift_first', 'detach_ref_img', 'scale_pcs',
+                                        'detach_rgbs_scale', 'vis_reprojection_every', 'nearest_limit', 'annealing_epochs', 'rgb_weight',
+                                        'depth_weight', 'pc_weight', 'rgb_s_weight', 'depth_consistency_weight', 'weight_dist_2nd_loss',
+                                        'weight_dist_1st_loss')}
+    cfg.update(type='nope_nerf', n_training_points=R, vis_geo=False, depth_loss_type='l1', with_ssim=False, with_auto_mask=False)
+    tr = mdl.Trainer(tr0.model, sgd(tr0.model), cfg, device=dev, optimizer_pose=sgd(pose), pose_param_net=pose,
+                     optimizer_focal=sgd(focal), focal_net=focal, optimizer_distortion=sgd(dist), distortion_net=dist)
+    _replay_perm(monkeypatch, torch.from_numpy(GOLD["focal.ray_idx"]))
+    jitter, real_rand = torch.from_numpy(GOLD["focal.jitter"]), torch.rand
+    monkeypatch.setattr(torch, "rand", lambda *s, device=None, **kw: jitter.to(device) if tuple(s) == (1, R, N) else real_rand(*s, device=device, **kw))
+    cam, nb = int(GOLD["focal.cam"]), int(GOLD["focal.nb"])
+    imgs, dpts = torch.from_numpy(GOLD["imgs"]).to(dev), torch.from_numpy(GOLD["dpts"]).to(dev)
+    data = {"img": imgs[cam:cam + 1], "img.idx": cam, "img.dpt": dpts[cam:cam + 1], "img.camera_mat": torch.from_numpy(GOLD["K"]).to(dev),
+            "img.scale_mat": torch.eye(4).unsqueeze(0).to(dev), "img.ref_imgs": imgs[nb:nb + 1], "img.ref_dpts": dpts[nb:nb + 1],
+            "img.ref_idxs": nb}
+    ld = tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
+    for k in ("loss", "loss_rgb", "loss_depth", "loss_pc", "loss_rgb_s", "l2_mean", "focalx", "focaly"):
+        assert abs(float(ld[k].detach()) - float(GOLD["focal.out." + k])) <= 1e-5, (k, float(ld[k]), float(GOLD["focal.out." + k]))
+    for k, t in (("fx", focal.fx), ("fy", focal.fy), ("pose_r", pose.r), ("pose_t", pose.t), ("scales", dist.global_scales),
+                 ("shifts", dist.global_shifts)):
+        want = GOLD["focal.g." + k]
+        got = t.grad if t.grad is not None else torch.zeros_like(t)
+        assert _close(got, want, 1e-4), (k, got, want)
