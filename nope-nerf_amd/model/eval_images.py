@@ -1,7 +1,7 @@
 """Eval_Images -- full-image rendering + PSNR / SSIM / LPIPS for evaluation/eval.py; constructor, `eval_images`
 signature and the returned dictionary follow reference model/eval_images.py:16-137.  The render loop runs the
-forward-only fused HIP kernel; SSIM comes from the reference checkout's third_party.pytorch_ssim when importable
-(falls back to the trainer's 3x3 SSIM), LPIPS is whatever callable the caller passes."""
+forward-only fused HIP kernel; SSIM is the Gaussian-window metric of third_party/pytorch_ssim restated in model/imaging.py
+(pinned to the reference function's values), LPIPS is whatever callable the caller passes."""
 import logging
 import os
 
@@ -13,15 +13,6 @@ from model import imaging
 from model.common import mse2psnr
 
 logger_py = logging.getLogger(__name__)
-
-
-def _ssim(a, b):
-    try:
-        from third_party import pytorch_ssim
-        return pytorch_ssim.ssim(a, b).item()
-    except ImportError:
-        from model.losses import compute_ssim_loss
-        return float(1 - 2 * compute_ssim_loss.to(a.device)(a, b).mean())
 
 
 class Eval_Images(object):
@@ -57,7 +48,7 @@ class Eval_Images(object):
         mse = F.mse_loss(img_out, img_gt).item()
         psnr = mse2psnr(mse)
         chw = lambda t: t.permute(2, 0, 1).unsqueeze(0).contiguous()
-        ssim = _ssim(chw(img_out), chw(img_gt))
+        ssim = imaging.ssim_gaussian(chw(img_out), chw(img_gt)).item()
         lpips_loss = lpips_vgg_fn(chw(img_out), chw(img_gt), normalize=True).item()
         tqdm.write('{0:4d} img: PSNR: {1:.2f}, SSIM: {2:.2f},  LPIPS {3:.2f}'.format(img_idx, psnr, ssim, lpips_loss))
 

@@ -50,3 +50,24 @@ def resize_nearest(arr, size_hw):
 
 def save_png(arr_u8, path):
     Image.fromarray(arr_u8).save(path)
+
+
+def ssim_gaussian(a, b, window_size=11, sigma=1.5):
+    """Mean SSIM of two (B,C,H,W) images in [0,1] (Wang et al. 2004: Gaussian window, zero-padded 'same' filtering, K1 = 0.01,
+    K2 = 0.03, dynamic range 1, mean over pixels and channels) -- the metric evaluation/eval.py reports through
+    third_party/pytorch_ssim.ssim; the window is applied as two 1-D passes."""
+    x = torch.arange(window_size, dtype=torch.float32, device=a.device) - window_size // 2
+    g = torch.exp(-x * x / (2.0 * sigma * sigma))
+    g = g / g.sum()
+    c = a.shape[1]
+    kh, kw = g.view(1, 1, -1, 1).expand(c, 1, -1, 1), g.view(1, 1, 1, -1).expand(c, 1, 1, -1)
+    pad = window_size // 2
+
+    def blur(t):
+        t = torch.nn.functional.conv2d(t, kh, padding=(pad, 0), groups=c)
+        return torch.nn.functional.conv2d(t, kw, padding=(0, pad), groups=c)
+
+    mu_a, mu_b = blur(a), blur(b)
+    var_a, var_b, cov = blur(a * a) - mu_a * mu_a, blur(b * b) - mu_b * mu_b, blur(a * b) - mu_a * mu_b
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu_a * mu_b + c1) * (2 * cov + c2)) / ((mu_a * mu_a + mu_b * mu_b + c1) * (var_a + var_b + c2))).mean()

@@ -223,3 +223,14 @@ def test_pixel_pick_capacity_rule_matches_the_library():
     assert [sampling._capacity(r) for r in (1024, 1401, 1402, 8192, 9943, 9944, 32768, 51463, 51464)] == \
         [4096, 4096, 16384, 16384, 16384, 65536, 65536, 65536, 0]
     assert sampling.supported(540 * 960, 8192) and sampling.supported(540 * 960, 32768) and not sampling.supported(540 * 960, 70000)
+
+
+def test_ssim_metric_matches_the_reference_function():
+    """model.imaging.ssim_gaussian == third_party/pytorch_ssim.ssim of the reference checkout (oracle/gen_golden_ssim.py)."""
+    import os
+    from model import imaging
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ssim.npz"))
+    for i in range(3):
+        a, b = torch.from_numpy(gold[f"a{i}"]), torch.from_numpy(gold[f"b{i}"])
+        assert abs(float(imaging.ssim_gaussian(a, b)) - float(gold[f"v{i}"])) <= 2e-6
+        assert abs(float(imaging.ssim_gaussian(a, a)) - 1.0) <= 1e-6
