@@ -86,3 +86,14 @@ class OfficialStaticNerf(nn.Module):
     def gradient(self, p, it):
         raise NotImplementedError("second-order d(sigma)/dp (normal loss, phong renderer; reference "
                                   "official_nerf.py:46-58) is not part of the HIP hot path")
+
+
+def encode_position(input, levels, inc_input):
+    """gamma_L of the last axis, (..., C) -> (..., C (2L [+ 1])): [x,] sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x),
+    every block C wide (reference model/official_nerf.py:99-119).  The render kernels compute this in registers; the function is
+    kept for callers that import it."""
+    freqs = 2.0 ** torch.arange(levels, dtype=input.dtype, device=input.device)
+    scaled = input.unsqueeze(-2) * freqs.view(-1, 1)                                    # (..., L, C)
+    waves = torch.stack([torch.sin(scaled), torch.cos(scaled)], dim=-2)                 # (..., L, 2, C)
+    waves = waves.reshape(*input.shape[:-1], 2 * levels * input.shape[-1])
+    return torch.cat([input, waves], dim=-1) if inc_input else waves

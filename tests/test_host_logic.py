@@ -234,3 +234,11 @@ def test_ssim_metric_matches_the_reference_function():
         a, b = torch.from_numpy(gold[f"a{i}"]), torch.from_numpy(gold[f"b{i}"])
         assert abs(float(imaging.ssim_gaussian(a, b)) - float(gold[f"v{i}"])) <= 2e-6
         assert abs(float(imaging.ssim_gaussian(a, a)) - 1.0) <= 1e-6
+
+
+def test_encode_position_matches_the_oracle_encoding():
+    from model.official_nerf import encode_position
+    x = torch.randn(6, 4, 3, generator=torch.Generator().manual_seed(0))
+    for levels in (10, 4):
+        assert torch.equal(encode_position(x, levels, True), orc.posenc(x, levels))
+    assert encode_position(x, 3, False).shape == (6, 4, 18)
