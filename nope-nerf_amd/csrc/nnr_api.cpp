@@ -37,6 +37,7 @@ WsLayout ws_layout(const nnr_cfg* c) {
     w.S_pad = (w.S + kBlockSamples - 1) / kBlockSamples * kBlockSamples;
     w.D = c->hidden;
     w.train = (c->flags & NNR_F_TRAIN) != 0;
+    w.bf16 = w.train && (c->flags & NNR_F_BF16) != 0;
     return w;
 }
 
@@ -276,10 +277,22 @@ int nnr_plan_counts(const nnr_cfg* cfg, int32_t* n_jobs, int32_t* n_waves) {
     return NNR_OK;
 }
 
+// The bf16 weight-gradient jobs decide at compile time, from the tile shape alone, which operand planes are stored as bf16
+// (nnr_wgrad.hip): verify that rule against the planes the units actually name.
+static bool bf16_operand_rule_holds(int D) {
+    auto is_bf16_plane = [](int p) { return (p >= P_XH1 && p < P_XH1 + 8) || p == P_XG || (p >= P_DH1 && p < P_DH1 + 8) || p == P_DG; };
+    for (const Unit& u : wgrad_units(D)) {
+        const bool d_rule = u.j.MI != 1, x_rule = u.j.NI == 4 || u.j.MI == 1;
+        if (is_bf16_plane(u.j.d_plane) != d_rule || is_bf16_plane(u.j.x_plane) != x_rule) return false;
+    }
+    return true;
+}
+
 int nnr_plan_build(const nnr_cfg* cfg, void* plan_host) {
     int rc = check_cfg(cfg);
     if (rc != NNR_OK) return rc;
     if (!plan_host) return NNR_E_BADCFG;
+    if (is_bf16(cfg) && !bf16_operand_rule_holds(cfg->hidden)) return NNR_E_UNSUPPORTED;
     const Plan p = build_plan(cfg);   // layout: WgradJob[n_jobs], then int32 wave_first[n_waves + 1]
     std::memcpy(plan_host, p.jobs.data(), p.jobs.size() * sizeof(WgradJob));
     std::memcpy(static_cast<char*>(plan_host) + p.jobs.size() * sizeof(WgradJob), p.wave_first.data(),

@@ -9,6 +9,8 @@ namespace nnr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // D(32x32) += A(32x2) * B(2x32), exact fp32 (v_mfma_f32_32x32x2_f32): lane l supplies A[l&31][l>>5] and B[l>>5][l&31].
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -273,7 +275,11 @@ __device__ __forceinline__ bf16x8 pack_row(const float (&in)[NIN], int b) {
     return q;
 }
 
-template <int KT, int MT, bool STASH, int NSIDE_, int PPG_, int SHIFT, class Side, int NACC, int NIN>
+// STASH: 0 = none; 1 = the input rows go to a bf16 plane (hidden activations, pre-activation gradients: exactly the 8 bf16 values
+// the MFMA of that row consumes, as two 8-byte stores into the natural feature order -- `stash` is then a bf16 element
+// pointer in disguise, see stash_bf16()); 2 = to an fp32 plane as in the fp32 kernels (the encodings, which the backward of the
+// encodings reads back at full precision).
+template <int KT, int MT, int STASH, int NSIDE_, int PPG_, int SHIFT, class Side, int NACC, int NIN>
 __device__ __forceinline__ void gemm_part_bf16(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
                                                float* stash, const Side& side) {
 #ifdef NNR_ABLATE_NO_SIDE
@@ -309,16 +315,21 @@ __device__ __forceinline__ void gemm_part_bf16(f32x16 (&acc)[NACC], const float 
                 if (f == 0) {          // fragment reads of the next row (panel switch in front of them)
                     if (g + 1 < G) {
                         const int pn = p0 + (g + 1) / GP;
-                        if ((g + 1) % GP == 0) pipe.template enter<STASH ? 2 * (GP - 1) : 0>(pn);
+                        if ((g + 1) % GP == 0) pipe.template enter<STASH != 0 ? 2 * (GP - 1) : 0>(pn);
                         const f32x4* buf = pipe.lds + (pn % kNBuf) * kPanelF4 + pipe.lane;
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) nxt.v[mt] = buf[(((g + 1) % GP) * MT + mt) * 64];
                     }
                 } else if (f == 1) {   // next row's B operand; this row's stash (two quads = two 16-byte stores)
                     if (g + 1 < G) nq = pack_row(in, g + 1);
-                    if constexpr (STASH) {
+                    if constexpr (STASH == 2) {
                         *reinterpret_cast<f32x4*>(stash + 16 * g) = f32x4{in[8 * g], in[8 * g + 1], in[8 * g + 2], in[8 * g + 3]};
                         *reinterpret_cast<f32x4*>(stash + 16 * g + 8) = f32x4{in[8 * g + 4], in[8 * g + 5], in[8 * g + 6], in[8 * g + 7]};
+                    } else if constexpr (STASH == 1) {   // bq = features 16g + 4h + {0..3}, 16g + 8 + 4h + {0..3} of this lane's sample
+                        const f32x4 raw = __builtin_bit_cast(f32x4, bq);
+                        __bf16* sb = reinterpret_cast<__bf16*>(stash);
+                        *reinterpret_cast<f32x2*>(sb + 16 * g) = f32x2{raw[0], raw[1]};
+                        *reinterpret_cast<f32x2*>(sb + 16 * g + 8) = f32x2{raw[2], raw[3]};
                     }
                 } else if (f == 2) {
                     if constexpr (NSIDE > 0) {
@@ -355,13 +366,20 @@ __device__ __forceinline__ void gemm_part_bf16(f32x16 (&acc)[NACC], const float 
 }
 
 // fp32 or bf16 product, chosen at compile time by the kernel's BF16 template parameter
-template <bool BF16, int KT, int MT, bool STASH, int NSIDE, int PPG, int SHIFT, class Side, int NACC, int NIN>
+// STASH: 0 none, 1 the plane of the kernel's mode (bf16 plane in the bf16 kernels), 2 an fp32 plane in either mode
+template <bool BF16, int KT, int MT, int STASH, int NSIDE, int PPG, int SHIFT, class Side, int NACC, int NIN>
 __device__ __forceinline__ void gemm_sel(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0, float* stash,
                                          const Side& side) {
     if constexpr (BF16) gemm_part_bf16<KT, MT, STASH, NSIDE, PPG, SHIFT>(acc, in, pipe, p0, stash, side);
-    else gemm_part<KT, MT, STASH, NSIDE, PPG, SHIFT>(acc, in, pipe, p0, stash, side);
+    else gemm_part<KT, MT, (STASH != 0), NSIDE, PPG, SHIFT>(acc, in, pipe, p0, stash, side);
 }
-template <bool BF16, int KT, int MT, bool STASH = false, int NACC, int NIN>
+// row pointer into a stash plane: element (row, col) of a plane whose rows hold `width` elements, fp32 or (BF16) bf16
+template <bool BF16>
+__device__ __forceinline__ float* stash_row(float* plane, int64_t row, int width, int col) {
+    if constexpr (BF16) return reinterpret_cast<float*>(reinterpret_cast<__bf16*>(plane) + row * width + col);
+    else return plane + row * width + col;
+}
+template <bool BF16, int KT, int MT, int STASH = 0, int NACC, int NIN>
 __device__ __forceinline__ void gemm_sel(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
                                          float* stash = nullptr) {
     gemm_sel<BF16, KT, MT, STASH, 0, 1, 0>(acc, in, pipe, p0, stash, NoSide{});

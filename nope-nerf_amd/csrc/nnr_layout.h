@@ -168,9 +168,13 @@ struct WsLayout {
     int64_t S, S_pad;
     int D;
     bool train;
+    bool bf16 = false;   // NNR_F_BF16 training: the operands of the weight-gradient products that the MFMAs consume as bf16 anyway
+                         // -- hidden activations (P_XH1.., P_XG) and pre-activation gradients (P_DH1.., P_DG) -- are STORED as
+                         // bf16 (pitch below = floats per row = elements / 2); encodings, masks and the 4-wide planes stay fp32
     NNR_HD int64_t plane(int p, int* pitch) const {
         int64_t o = 0;
         int w = 0;
+        const int wD = bf16 ? D / 2 : D, wDh = bf16 ? D / 4 : D / 2;
         auto step = [&](int id, int width) -> bool {
             if (id == p) { w = width; return true; }
             o += S_pad * (int64_t)width;
@@ -180,13 +184,13 @@ struct WsLayout {
         if (!train) return -1;
         if (step(P_DOUT4, 4) || step(P_DPTS, 4) || step(P_DVIEW, 4) || step(P_XE, kPosPad)) { *pitch = w; return o; }
         for (int l = 0; l < 8; ++l)
-            if (step(P_XH1 + l, D)) { *pitch = w; return o; }
-        if (step(P_XF, kDirPad) || step(P_XG, D / 2)) { *pitch = w; return o; }
+            if (step(P_XH1 + l, wD)) { *pitch = w; return o; }
+        if (step(P_XF, kDirPad) || step(P_XG, wDh)) { *pitch = w; return o; }
         // masks: [S_pad/32 chunks][9 layers][64 lanes][D/64 words]  == S_pad * 9 * 2 * (D/64) / ... words per sample: 9*2*(D/64)
         if (step(P_MASK, 9 * 2 * (D / 64))) { *pitch = w; return o; }
         for (int l = 0; l < 8; ++l)
-            if (step(P_DH1 + l, D)) { *pitch = w; return o; }
-        if (step(P_DG, D / 2)) { *pitch = w; return o; }
+            if (step(P_DH1 + l, wD)) { *pitch = w; return o; }
+        if (step(P_DG, wDh)) { *pitch = w; return o; }
         if (p == -1) { *pitch = 0; return o; }  // total
         return -1;
     }

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     };
     load_mask(mwA, 7, 0);
     init_sigma(accA, 0);
-    gemm_sel<BF16, HT, HT, true>(accA, dg, pipe, p0(B_RGBH_FA), a.ws_dg + ss * (D / 2) + 4 * half);
+    gemm_sel<BF16, HT, HT, 1>(accA, dg, pipe, p0(B_RGBH_FA), stash_row<BF16>(a.ws_dg, ss, D / 2, 4 * half));
     load_mask(mwB, 7, 1);
     init_sigma(accB, 1);
     gemm_sel<BF16, HT, HT, false, NP, 2, 0>(accB, dg, pipe, p0(B_RGBH_FB), nullptr, NNR_SEL_PAIR(accA, 0, mwA));
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     NNR_STAMP(tl_dgrad, 3);
 
     // ---- trunk ----
-    auto dh = [&](int hidden_idx /*0..7*/) -> float* { return a.ws_dh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half; };
+    auto dh = [&](int hidden_idx /*0..7*/) -> float* { return stash_row<BF16>(a.ws_dh, (int64_t)hidden_idx * a.S_pad + ss, D, 4 * half); };
     // Invariant from here on: d[0, HR) holds half A of the newest gradient, accB its half B still to be masked (mwB).
 
     // one transposed D x D layer at panel pa: consumes the gradient in d (stashing it to `stash`), produces the gradient of

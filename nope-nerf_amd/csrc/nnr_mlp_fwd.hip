@@ -136,12 +136,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     auto p0 = [&](int part) { return L::fwd_panel0(part); };
     float* const xe = TRAIN ? a.ws_xe + ss * kPosPad + 4 * half : nullptr;
     auto xh = [&](int hidden_idx /*0..7*/) -> float* {
-        return TRAIN ? a.ws_xh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half : nullptr;
+        return TRAIN ? stash_row<BF16>(a.ws_xh, (int64_t)hidden_idx * a.S_pad + ss, D, 4 * half) : nullptr;
     };
 
     // ---- hidden 1: 63 -> D, input = posenc.  Pass A, then pass B with A's epilogue hidden under it. ----
     init_acc(accA, L::bias_off(0));
-    gemm_sel<BF16, 2, HT, TRAIN>(accA, e, pipe, p0(F_L1A), xe);
+    gemm_sel<BF16, 2, HT, TRAIN ? 2 : 0>(accA, e, pipe, p0(F_L1A), xe);            // the encodings stay fp32 in either mode
     init_acc(accB, L::bias_off(0) + L::Dh);
     clear_mask(mwA);
     gemm_sel<BF16, 2, HT, false, NP, NP / 8, 0>(accB, e, pipe, p0(F_L1B), nullptr, NNR_RELU_PAIR(accA, 0, mwA));
@@ -228,17 +228,24 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dir2[4 * q + i] = v[i];
     }
-    gemm_sel<BF16, 1, HT, TRAIN>(accA, dir2, pipe, p0(F_RGBH_D), xf);
+    gemm_sel<BF16, 1, HT, TRAIN ? 2 : 0>(accA, dir2, pipe, p0(F_RGBH_D), xf);
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 8);
     clear_mask(mwA);
 #pragma unroll
     for (int u = 0; u < NP; ++u) NNR_RELU_PAIR(accA, 0, mwA)(u);   // g = h[0, HR)
     store_mask(mwA, 8, 0);
     if (TRAIN) {
-        float* xg = a.ws_xg + ss * (D / 2) + 4 * half;
+        float* xg = stash_row<BF16>(a.ws_xg, ss, D / 2, 4 * half);
 #pragma unroll
-        for (int q = 0; q < HR / 4; ++q)
-            *reinterpret_cast<f32x4*>(xg + 8 * q) = f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
+        for (int q = 0; q < HR / 4; ++q) {
+            if constexpr (BF16) {   // a bf16 plane: features 8q + 4h + {0..3} of this sample, 8 bytes
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                const bf16x4 v = {(__bf16)h[4 * q], (__bf16)h[4 * q + 1], (__bf16)h[4 * q + 2], (__bf16)h[4 * q + 3]};
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(xg) + 8 * q) = v;
+            } else {
+                *reinterpret_cast<f32x4*>(xg + 8 * q) = f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
+            }
+        }
     }
     // rgb head: 3 per-lane dot products over the lane's half of g, halves combined by one shuffle, then sigmoid
     float rgbv[3];

@@ -143,16 +143,71 @@ extern "C" int nnr_timeline_wgrad(unsigned long long* host32) {
 #endif
 
 // bf16-MFMA variant (NNR_F_BF16): the same tile / job structure, but one v_mfma_f32_32x32x16_bf16 contracts 16 samples:
-// lane (m, half) supplies the 8 samples k + 8*half + 0..7 of its MI rows / NI columns, converted to bf16 on the fly from
-// the fp32 stashes (fp32 accumulation, fp32 bias sums).  16 MFMAs of 32 cycles per 16 samples against the same bytes as the
-// fp32 kernel: this variant is HBM-bound (17.7 KB per sample), not MFMA-bound.
+// lane (m, half) supplies the 8 samples k + 8*half + 0..7 of its MI rows / NI columns (fp32 accumulation, fp32 bias sums).
+// In this mode the forward and the input-gradient kernels store the hidden activations and the pre-activation gradients as the
+// very bf16 values their own MFMAs consumed (WsLayout::bf16), so most operands arrive as bf16 -- half the bytes of the fp32
+// planes and half the registers per stage in flight -- and only need their 16-bit halves regrouped (v_perm_b32) from
+// [sample][feature] to the MFMA's [feature][8 samples].  The encodings (P_XE, P_XF) and the 4-wide output gradients (P_DOUT4)
+// stay fp32 and are converted here.  Which operand is which follows from the tile shape (checked on the host by
+// nnr_plan_build): the gradient operand is bf16 unless MI == 1 (heads: P_DOUT4); the activation operand is bf16 when NI == 4
+// or MI == 1 (hidden activations), fp32 otherwise (NI 2 / 1 against the encodings).
+// HBM-bound (about 9 KB per sample); two stages (2 x 16 samples) are in flight per wave.
+template <int W, bool B16>
+struct RawRow {   // W consecutive features of one sample, as loaded
+    static constexpr int NW = B16 ? W / 2 : W;
+    uint32_t w[NW];
+};
+
+template <int W, bool B16>
+__device__ __forceinline__ RawRow<W, B16> load_raw(const char* p) {
+    RawRow<W, B16> r;
+    constexpr int NW = RawRow<W, B16>::NW;
+    if constexpr (NW == 4) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+        r.w[0] = t[0]; r.w[1] = t[1]; r.w[2] = t[2]; r.w[3] = t[3];
+    } else if constexpr (NW == 2) {
+        const u32x2 t = *reinterpret_cast<const u32x2*>(p);
+        r.w[0] = t[0]; r.w[1] = t[1];
+    } else {
+        r.w[0] = *reinterpret_cast<const uint32_t*>(p);
+    }
+    return r;
+}
+
+// feature i of 8 consecutive samples -> one MFMA operand row (8 bf16)
+template <int W, bool B16>
+__device__ __forceinline__ bf16x8 gather_feature(const RawRow<W, B16> (&rows)[8], int i) {
+    u32x4 out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (B16) {   // halves i of words rows[2j], rows[2j+1]:  low <- sample 2j, high <- sample 2j + 1
+            const uint32_t lo = rows[2 * j].w[i >> 1], hi = rows[2 * j + 1].w[i >> 1];
+            out[j] = __builtin_amdgcn_perm(hi, lo, (i & 1) ? 0x07060302u : 0x05040100u);
+        } else {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const bf16x2 v = {(__bf16)__builtin_bit_cast(float, rows[2 * j].w[i]), (__bf16)__builtin_bit_cast(float, rows[2 * j + 1].w[i])};
+            out[j] = __builtin_bit_cast(uint32_t, v);
+        }
+    }
+    return __builtin_bit_cast(bf16x8, out);
+}
+
+template <int W, bool B16>
+__device__ __forceinline__ float raw_value(const RawRow<W, B16>& row, int i) {
+    if constexpr (B16) return __builtin_bit_cast(float, (i & 1) ? (row.w[i >> 1] & 0xffff0000u) : (row.w[i >> 1] << 16));
+    else return __builtin_bit_cast(float, row.w[i]);
+}
+
 template <int MI, int NI, int BIAS>
 __device__ __forceinline__ void wgrad_job_bf16(const WgradJob& jb, const WgradArgs& a, int lane, int ji) {
+    constexpr bool DB = MI != 1, XB = NI == 4 || MI == 1;        // operand planes stored as bf16 (see above)
     const int half = lane >> 5, m = lane & 31;
-    const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
+    const int64_t dstride = 4ll * a.plane_pitch[jb.d_plane], xstride = 4ll * a.plane_pitch[jb.x_plane];   // bytes per sample row
     const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
-    const float* dptr = a.ws + a.plane_off[jb.d_plane] + jb.d_col0 + (dok ? MI * m : 0) + (int64_t)(8 * half) * dp;
-    const float* xptr = a.ws + a.plane_off[jb.x_plane] + jb.x_col0 + (xok ? NI * m : 0) + (int64_t)(8 * half) * xp;
+    const char* dptr = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane]) + (DB ? 2 : 4) * (jb.d_col0 + (dok ? MI * m : 0)) +
+                       (8 * half) * dstride;
+    const char* xptr = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane]) + (XB ? 2 : 4) * (jb.x_col0 + (xok ? NI * m : 0)) +
+                       (8 * half) * xstride;
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -165,42 +220,56 @@ __device__ __forceinline__ void wgrad_job_bf16(const WgradJob& jb, const WgradAr
 #pragma unroll
     for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
 
-    // One raw stage (8 samples x (MI + NI) floats per lane, 16 KB per wave) is in flight while the previous one, already
-    // converted to bf16 (half the registers), feeds the MFMAs.  (Two raw stages in flight would cover the loaded HBM latency
-    // better, but hipcc spills ~1000 registers on that version; as it stands the kernel is latency-bound at ~2.6 TB/s.)
-    // Sample ranges are multiples of 16 (kGranule) = one MFMA per sub-tile.
-    Vec<MI> d[8];
-    Vec<NI> x[8];
-    auto load_stage = [&](int64_t kk) {
+    struct Stage {
+        RawRow<MI, DB> d[8];
+        RawRow<NI, XB> x[8];
+    };
+    auto load_stage = [&](Stage& st, int64_t kk) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            d[u] = load_vec<MI>(dptr + (kk + u) * dp);
-            x[u] = load_vec<NI>(xptr + (kk + u) * xp);
+            st.d[u] = load_raw<MI, DB>(dptr + (kk + u) * dstride);
+            st.x[u] = load_raw<NI, XB>(xptr + (kk + u) * xstride);
         }
     };
-    load_stage(jb.k0);
-    for (int64_t k = jb.k0; k < jb.k1; k += 16) {
+    // consume one stage: regroup / convert, refill the stage's registers with the samples two stages ahead, multiply
+    auto step = [&](Stage& st, int64_t next_k) __attribute__((always_inline)) {
         bf16x8 av[MI], bv[NI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) {
+            av[i] = gather_feature<MI, DB>(st.d, i);
+            if constexpr (BIAS != 0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                av[i][u] = (__bf16)d[u].v[i];
-                if (BIAS == 1 || (BIAS == 2 && u % 2 == 0) || (BIAS == 3 && u % 2 == 1)) bsum[i] += d[u].v[i];
+                for (int u = 0; u < 8; ++u)
+                    if (BIAS == 1 || (BIAS == 2 && u % 2 == 0) || (BIAS == 3 && u % 2 == 1)) bsum[i] += raw_value<MI, DB>(st.d[u], i);
             }
+        }
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) bv[j][u] = (__bf16)x[u].v[j];
+        for (int j = 0; j < NI; ++j) bv[j] = gather_feature<NI, XB>(st.x, j);
         __builtin_amdgcn_sched_barrier(0);
-        load_stage(k + 16 < jb.k1 ? k + 16 : k);   // no branch around loads: a redundant re-read at the tail
+        load_stage(st, next_k);   // no branch around loads: past the end it re-reads the last stage
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    // Sample ranges are multiples of 16 (kGranule) = one MFMA per sub-tile and stage.  Three stages of 16 samples rotate; the
+    // loop body is unconditional (a branch inside it made hipcc spill 600 registers), the 0-2 left-over stages follow.
+    Stage sa, sb, sc;
+    const int64_t last = jb.k1 - 16;
+    auto at = [&](int64_t kk) { return kk <= last ? kk : last; };
+    load_stage(sa, jb.k0);
+    load_stage(sb, at(jb.k0 + 16));
+    load_stage(sc, at(jb.k0 + 32));
+    int64_t k = jb.k0;
+    for (; k + 48 <= jb.k1; k += 48) {
+        step(sa, at(k + 48));
+        step(sb, at(k + 64));
+        step(sc, at(k + 80));
     }
+    if (k < jb.k1) step(sa, last);
+    if (k + 16 < jb.k1) step(sb, last);
     float* slot = a.slots + (int64_t)ji * kSlotFloats;
 #pragma unroll
     for (int i = 0; i < MI; ++i)

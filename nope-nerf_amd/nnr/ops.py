@@ -147,15 +147,18 @@ def plan_jobs(cfg: L.Cfg, with_waves: bool = False):
 
 
 def workspace_plane(cfg: L.Cfg, ws: torch.Tensor, plane: int, n_rows: Optional[int] = None) -> torch.Tensor:
-    """View of one workspace plane as (rows, pitch) -- used by the parity tests to localise a mismatch."""
+    """One workspace plane as (rows, width) -- used by the parity tests to localise a mismatch.  A view for the fp32 planes; the
+    planes a bf16 training workspace stores as bf16 (hidden activations 11..18, 20 and their gradients 31..38, 40: WsLayout in
+    nnr_layout.h) come back converted to fp32."""
     pitch = C.c_int32(0)
     off = L.load().nnr_ws_plane(C.byref(cfg), plane, C.byref(pitch))
     if off < 0:
         raise KeyError(plane)
     S = cfg.n_rays * cfg.n_samples
-    s_pad = (S + 127) // 128 * 128
-    v = ws[off: off + s_pad * pitch.value].view(s_pad, pitch.value)
-    return v[: (n_rows if n_rows is not None else S)]
+    rows = n_rows if n_rows is not None else S
+    v = ws[off: off + rows * pitch.value].view(rows, pitch.value)
+    stored_bf16 = (cfg.flags & L.NNR_F_BF16) and (cfg.flags & L.NNR_F_TRAIN) and (11 <= plane <= 18 or plane == 20 or 31 <= plane <= 38 or plane == 40)
+    return v.view(torch.bfloat16).float() if stored_bf16 else v
 
 
 # ----------------------------------------------------------------------------------------------------------------------
