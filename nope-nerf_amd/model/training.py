@@ -82,11 +82,13 @@ class Trainer(object):
                 (self.distortion_net, self.optimizer_distortion)]
 
     def train_step(self, data, it=None, epoch=None, scheduling_start=None, render_path=None):
-        self.model.train()
+        if not self.model.training:        # Module.train() walks every sub-module: skip the walk when nothing changes
+            self.model.train()
         self.optimizer.zero_grad()
         for net, opt in self._groups():
             if net:
-                net.train()
+                if not net.training:
+                    net.train()
                 opt.zero_grad()
         loss_dict = self.compute_loss(data, it=it, epoch=epoch, scheduling_start=scheduling_start,
                                       out_render_path=render_path)

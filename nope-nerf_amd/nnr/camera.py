@@ -11,7 +11,7 @@ from . import lib as L
 
 
 def _st():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return L.stream()
 
 
 def _f32(t):

@@ -148,3 +148,13 @@ def params_struct(weights, biases) -> Params:
         p.weight[i] = weights[i].data_ptr()
         p.bias[i] = biases[i].data_ptr()
     return p
+
+
+def stream():
+    """The current torch stream of the current device as the `void* stream` argument of the C ABI.  torch._C's raw accessor is
+    a tenth of the cost of torch.cuda.current_stream().cuda_stream (a dozen lookups per training step)."""
+    import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return C.c_void_p(raw(torch.cuda.current_device()))
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -81,7 +81,7 @@ def _packed_for(cfg, weights, biases):
     packed = torch.empty(n, dtype=torch.float32, device=tensors[0].device)
     ps = L.params_struct([w.detach() for w in weights], [b.detach() for b in biases])
     L.check(lib.nnr_pack_weights(C.byref(cfg), C.byref(ps), L.ptr(packed),
-                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_pack_weights")
+                                 L.stream()), "nnr_pack_weights")
     for k in [k for k, v in _pack_caches.items() if any(r() is None for r in v.refs)]:
         del _pack_caches[k]             # drop entries of models that no longer exist
     _pack_caches[key] = _PackCache(mode, tensors, packed)
@@ -185,7 +185,7 @@ class _RenderRays(torch.autograd.Function):
         dist = torch.empty(R, **f32)
         alpha = torch.empty(R, N, **f32)
         zv = torch.empty(R, N, **f32)
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        st = L.stream()
         L.check(lib.nnr_render_fwd(C.byref(cfg), L.ptr(pts_o), L.ptr(pts_d), L.ptr(view_d), L.ptr(z_lo), L.ptr(z_hi),
                                    L.ptr(jit), L.ptr(packed), L.ptr(rgb), L.ptr(dist), L.ptr(alpha), L.ptr(zv), L.ptr(ws), st),
                 "nnr_render_fwd")
@@ -208,7 +208,7 @@ class _RenderRays(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         d_rgb = (d_rgb if d_rgb is not None else torch.zeros(R, 3, **f32)).contiguous().float()
         d_dist = (d_dist if d_dist is not None else torch.zeros(R, **f32)).contiguous().float()
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        st = L.stream()
         need_w = any(ctx.needs_input_grad[7:])
         need_rays = any(ctx.needs_input_grad[:3])
         L.check(lib.nnr_composite_bwd(C.byref(cfg), L.ptr(d_rgb), L.ptr(d_dist), L.ptr(ws), st), "nnr_composite_bwd")
@@ -260,7 +260,7 @@ def mlp_points(pts: torch.Tensor, view: torch.Tensor, weights, biases, *, hidden
     z0 = torch.zeros(1, dtype=torch.float32, device=dev)
     packed = _packed_for(cfg, list(weights), list(biases))
     ws = _take_workspace(cfg, dev)
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = L.stream()
     L.check(lib.nnr_mlp_fwd(C.byref(cfg), L.ptr(pts), L.ptr(zeros3), L.ptr(view), L.ptr(z0), L.ptr(z0), None,
                             L.ptr(packed), L.ptr(ws), st), "nnr_mlp_fwd")
     out = workspace_plane(cfg, ws, 0).clone()

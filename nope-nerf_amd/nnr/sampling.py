@@ -42,7 +42,7 @@ def _fast(n: int, r: int, device) -> torch.Tensor:
     out = torch.empty(r, dtype=torch.int64, device=device)
     scratch = torch.empty(2 + 5 * _capacity(r), dtype=torch.int32, device=device)     # header, ranks, candidates, ordered
     L.check(L.load().nnr_randperm_prefix(L.ptr(keys), n, _key_bits(n), r, seed, offset, L.ptr(out), L.ptr(scratch),
-                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_randperm_prefix")
+                                         L.stream()), "nnr_randperm_prefix")
     return out
 
 

@@ -151,7 +151,7 @@ def _synthetic(D, R, N, seed=0, dist_alpha=False):
     return params, o, d, torch.cat([z[:1], mid]), torch.cat([mid, z[-1:]]), torch.rand(R, N, generator=g)
 
 
-def _hip_render(params, o, d, lo, hi, jit, D, d_rgb=None, d_dist=None, dist_alpha=False):
+def _hip_render(params, o, d, lo, hi, jit, D, d_rgb=None, d_dist=None, dist_alpha=False, bf16=False):
     import nnr
     dev = torch.device("cuda")
     from nnr import lib as L
@@ -160,7 +160,7 @@ def _hip_render(params, o, d, lo, hi, jit, D, d_rgb=None, d_dist=None, dist_alph
     oo, dd = o.to(dev).requires_grad_(True), d.to(dev).requires_grad_(True)
     vv = (-d).to(dev).requires_grad_(True)
     rgb, dist, alpha, z = nnr.render_rays(oo, dd, vv, lo.to(dev), hi.to(dev), jit.to(dev) if jit is not None else None, w, b,
-                                          hidden=D, dist_alpha=dist_alpha, white_bg=False, relu_sigma=False)
+                                          hidden=D, dist_alpha=dist_alpha, white_bg=False, relu_sigma=False, bf16=bf16)
     grads = None
     if d_rgb is not None:
         (rgb * d_rgb.to(dev)).sum().add((dist * d_dist.to(dev)).sum()).backward()
@@ -168,11 +168,23 @@ def _hip_render(params, o, d, lo, hi, jit, D, d_rgb=None, d_dist=None, dist_alph
     return rgb.detach(), dist.detach(), alpha, grads
 
 
-def test_full_size_properties():
-    """BASELINE.json config 2 (1024 rays x 192 samples, D=256): size-independent properties of the path --
-    determinism, ray-permutation equivariance, alpha/weight bounds, linearity of the backward in the upstream
-    gradient, and shard additivity (sum of half-batch gradients == full-batch gradient: the data-parallel identity)."""
-    D, R, N = 256, 1024, 192
+@pytest.mark.parametrize("R,N,bf16", [(1024, 192, False), (4096, 128, True)])
+def test_full_size_properties(R, N, bf16):
+    """BASELINE.json config 2 (1024 rays x 192 samples, D=256, fp32) and config 3 (4096 x 128, bf16 products): size-independent
+    properties of the path -- determinism, ray-permutation equivariance, alpha/weight bounds, linearity of the backward in the
+    upstream gradient (exact in bf16 too: a factor 2 commutes with the rounding), and shard additivity (sum of half-batch
+    gradients == full-batch gradient: the data-parallel identity)."""
+    D = 256
+    import functools
+    global _hip_render
+    plain, _hip_render = _hip_render, functools.partial(_hip_render, bf16=bf16)
+    try:
+        _full_size_properties(D, R, N)
+    finally:
+        _hip_render = plain
+
+
+def _full_size_properties(D, R, N):
     params, o, d, lo, hi, jit = _synthetic(D, R, N)
     g = torch.Generator().manual_seed(5)
     d_rgb, d_dist = torch.randn(R, 3, generator=g) / R, torch.randn(R, generator=g) / R
