@@ -37,6 +37,8 @@ R_PER_GPU, N_SAMPLES, HIDDEN = 1024, 192, 256
 IMG_H, IMG_W, N_CAMS = 540, 960, 16
 FLOP_PER_SAMPLE_PASS = 2 * 593408            # forward == dgrad == wgrad, BASELINE.md section 2
 PEAK_FP32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0               # dense bf16 MFMA (not the 2:1-sparsity headline figure)
+PEAK_HBM_GBS = 8000.0                        # HBM3E
 
 
 def full_cfg(rays_total, aux=False, bf16=False):
@@ -119,13 +121,14 @@ def _hbm_traffic(kernel):
     return None
 
 
-def kernel_roofline(net, device, reps=5):
-    """Time the three fused-MLP kernels of one 1024x192 step individually with HIP events on the launch stream."""
+def kernel_roofline(net, device, reps=5, bf16=False):
+    """Time the three fused-MLP kernels of one 1024x192 step individually with HIP events on the launch stream.
+    bf16=True (bench.py --bf16, not the headline): the bf16-product kernels, whose bound is HBM, not the matrix pipe."""
     from nnr import lib as L
     from nnr import ops
     lib = L.load()
     R, N, D = R_PER_GPU, N_SAMPLES, HIDDEN
-    cfg = L.make_cfg(R, N, D, train=True)
+    cfg = L.make_cfg(R, N, D, train=True, bf16=bf16)
     g = torch.Generator().manual_seed(1)
     d = torch.randn(R, 3, generator=g)
     d = (d / d.norm(dim=-1, keepdim=True)).to(device)
@@ -154,7 +157,7 @@ def kernel_roofline(net, device, reps=5):
         'mlp_dgrad': lambda: lib.nnr_mlp_dgrad(C.byref(cfg), L.ptr(packed), L.ptr(ws), st),
         'mlp_wgrad': lambda: lib.nnr_mlp_wgrad(C.byref(cfg), L.ptr(packed), C.byref(gs), L.ptr(plan), L.ptr(ws), st),
     }
-    cfg_inf = L.make_cfg(R, N, D)      # forward-only variant (eval / visualisation): no stash
+    cfg_inf = L.make_cfg(R, N, D, bf16=bf16)      # forward-only variant (eval / visualisation): no stash
     ws_inf = torch.empty(lib.nnr_workspace_floats(C.byref(cfg_inf)), device=device)
     stages['mlp_fwd_infer'] = lambda: lib.nnr_mlp_fwd(C.byref(cfg_inf), L.ptr(o), L.ptr(d), L.ptr(view), L.ptr(lo), L.ptr(hi),
                                                       L.ptr(jit), L.ptr(packed), L.ptr(ws_inf), st)
@@ -175,6 +178,23 @@ def kernel_roofline(net, device, reps=5):
     dom = max(('mlp_fwd', 'mlp_dgrad', 'mlp_wgrad'), key=lambda k: times[k])
     achieved = flops / (times[dom] * 1e-3) / 1e12
     mlp_ms = times['mlp_fwd'] + times['mlp_dgrad'] + times['mlp_wgrad']
+    if bf16:
+        # Algorithmic HBM bytes per sample of the bf16-mode kernels: hidden activations and their
+        # gradients are bf16 planes (8 x D + D/2 elements each), encodings (64 + 32) and the 4-wide planes fp32, masks 1 bit
+        # per activation.  fwd writes the stash; dgrad reads masks + dout4 + encodings and writes the gradient planes;
+        # wgrad reads activations + gradients + encodings + dout4 once.
+        act = (8 * D + D // 2) * 2
+        enc, masks, four = (64 + 32) * 4, 9 * 2 * (D // 64) * 4, 16
+        byts = {'mlp_fwd': act + enc + masks + four + 4, 'mlp_dgrad': act + masks + four + enc + 2 * four,
+                'mlp_wgrad': 2 * act + enc + four}
+        gbs = {k: byts[k] * R * N / (times[k] * 1e-3) / 1e9 for k in byts}
+        dom = max(byts, key=lambda k: times[k])
+        for k in byts:
+            per[k]['gbytes_per_s'] = round(gbs[k], 1)
+        return {'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs[dom], 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': round(gbs[dom] / PEAK_HBM_GBS, 4), 'traffic': None, 'bytes_per_launch': byts[dom] * R * N, 'kernels': per,
+                'fused_mlp_all_three': {'ms': round(mlp_ms, 4), 'tflops': round(3 * flops / (mlp_ms * 1e-3) / 1e12, 2),
+                                        'frac_of_bf16_mfma_peak': round(3 * flops / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}}
     return {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': _hbm_traffic(dom),
@@ -281,7 +301,7 @@ def main():
                        'parallelism': f'dp{world} (ray-sharded, one flat all-reduce)'},
             'final_loss': round(loss_val, 6),
         }
-        out['roofline'] = kernel_roofline(net, device)
+        out['roofline'] = kernel_roofline(net, device, bf16=args.bf16)
         out['cpu_baseline'] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
