@@ -107,7 +107,12 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     [&](int u) __attribute__((always_inline)) {                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
             const int r = 2 * u + i;                                                                         \
-            d[(OFF) + r] = ((MW[r >> 5] >> (r & 31)) & 1u) ? ACC[r >> 4][r & 15] : 0.f;                      \
+            if constexpr (BF16) {   /* issue-bound kernel: sign-extended bit field + and (2 instructions, not 3) */ \
+                const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe((int)MW[r >> 5], r & 31, 1);           \
+                d[(OFF) + r] = __uint_as_float(__float_as_uint(ACC[r >> 4][r & 15]) & keep);                 \
+            } else {                                                                                         \
+                d[(OFF) + r] = ((MW[r >> 5] >> (r & 31)) & 1u) ? ACC[r >> 4][r & 15] : 0.f;                  \
+            }                                                                                                \
         }                                                                                                    \
     }
 #define NNR_MOVE_PAIR(ACC, OFF)                                                                              \

@@ -116,17 +116,25 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         if (TRAIN) {
             uint32_t* m = mask_base + (int64_t)layer_idx * 64 * L::mask_words + hb * HW;
 #pragma unroll
-            for (int w = 0; w < HW; ++w) m[w] = mw[w];
+            for (int w = 0; w < HW; ++w) m[w] = BF16 ? ~__builtin_bitreverse32(mw[w]) : mw[w];
         }
     };
-// one epilogue unit u (registers 2u, 2u+1 of the half): h[off + 2u + i] = relu(acc) (+ sign bit) or plain move
+// one epilogue unit u (registers 2u, 2u+1 of the half): h[off + 2u + i] = relu(acc) (+ sign bit) or plain move.
+// Mask bit r = (x > 0).  The bf16 kernels are bound by instruction issue, not by the matrix pipe, so there the three
+// instructions per value (compare, select, or) become one: the SIGN bits are shifted into the word in register order
+// (v_alignbit_b32), and store_mask reverses and inverts the finished word.  The two differ only for x == +0.0 exactly
+// (sign clear, not > 0), which an fp32 sum of bf16 products does not produce outside all-zero rows -- and those have no
+// gradient to pass on either way.
 #define NNR_RELU_PAIR(ACC, OFF, MW)                                                                          \
     [&](int u) __attribute__((always_inline)) {                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
             const int r = 2 * u + i;                                                                         \
             const float x = ACC[r >> 4][r & 15];                                                             \
             h[(OFF) + r] = relu1(x);                                                                         \
-            if (TRAIN && !kAblateNoMask) MW[r >> 5] |= x > 0.f ? (1u << (r & 31)) : 0u;                      \
+            if (TRAIN && !kAblateNoMask) {                                                                   \
+                if constexpr (BF16) MW[r >> 5] = __builtin_amdgcn_alignbit(MW[r >> 5], __float_as_uint(x), 31); \
+                else MW[r >> 5] |= x > 0.f ? (1u << (r & 31)) : 0u;                                          \
+            }                                                                                                \
         }                                                                                                    \
     }
 #define NNR_MOVE_PAIR(ACC, OFF)                                                                              \
