@@ -207,7 +207,12 @@ def test_scene_training_loop_on_the_cpu_stand_in(monkeypatch, tmp_path):
     scene_writer.write_scene(str(tmp_path), scene="toy", frames=5, size=(24, 32), seed=4)
     res = train_scene.run(str(tmp_path), "toy", epochs=2, log_every=1, device="cpu", n_rays=16, n_samples=8, hidden=128,
                           sample_rate=10 ** 6)
-    assert res["steps"] == 10 and res["views"] == 5 and len(res["curve"]) == 3
+    assert res["steps"] == 10 and res["views"] == 5 and len(res["curve"]) == 3 and res["novel_views"] is None
+    # with held-out views: test-time pose optimisation + full-frame scoring of frames 1 and 4 (sample_rate 3)
+    res = train_scene.run(str(tmp_path), "toy", epochs=1, log_every=1, device="cpu", n_rays=16, n_samples=8, hidden=128,
+                          sample_rate=3, resident=False, eval_epochs=5)
+    nv = res["novel_views"]
+    assert res["views"] == 3 and nv["views"] == 2 and nv["psnr"] > 0 and 0 < nv["ssim"] <= 1 and nv["pose_opt_mse_last"] > 0
     assert res["curve"][0]["psnr"] is None and res["curve"][-1]["psnr"] > 0 and res["curve"][-1]["ate"] > 0
 
 

@@ -79,8 +79,50 @@ def pose_errors(pose_net, gt_poses, n_views):
     return {"ate": float(compute_ATE(gt, aligned)), "rpe_trans_x100": float(rpe_t * 100), "rpe_rot_deg": float(np.degrees(rpe_r))}
 
 
-def run(path, scene, style="tanks", epochs=100, seed=42, log_every=10, device=None, **cfg_kw):
-    """-> dict with the per-epoch PSNR / pose-error curve and the loop throughput."""
+def novel_view_eval(cfg, nope, pose, train_field, device, epochs, out_dir, n_points=1024):
+    """What reference evaluation/eval.py:54-186 does for the held-out views: initialise their poses from the learned training
+    trajectory (init_method 'pre': the training pose just before each held-out frame), optimise them against the frozen field
+    (Trainer_pose, Adam 1e-3 halved five times), then render every held-out frame in full and score it.  LPIPS needs a VGG
+    checkpoint and is reported as 0."""
+    import dataloading as dl
+    import model as mdl
+    from model.eval_images import Eval_Images
+    loader, fields = dl.get_dataloader(cfg, mode="eval", shuffle=False)
+    f = fields["img"]
+    if f.N_imgs == 0:
+        return None
+    with torch.no_grad():
+        learned = torch.stack([pose(i) for i in range(train_field.N_imgs)])
+    sr = train_field.sample_rate
+    init = learned[int(sr / 2) - 1::sr - 1][:f.N_imgs].clone()
+    eval_pose = mdl.LearnPose(f.N_imgs, True, True, cfg, init_c2w=init).to(device)
+    opt = torch.optim.Adam(eval_pose.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=list(range(0, epochs, max(1, epochs // 5))), gamma=0.5)
+    tp = mdl.Trainer_pose(nope, {"n_points": n_points, "type": "nope_nerf"}, device=device, optimizer_pose=opt, pose_param_net=eval_pose)
+    first = last = None
+    for e in range(epochs):
+        l2 = torch.stack([tp.train_step(batch)["loss"].detach() for batch in loader]).mean()
+        sched.step()
+        if e in (0, epochs - 1):
+            v = float(l2)
+            first, last = (v, last) if e == 0 else (first, v)
+    eval_pose.eval()
+    with torch.no_grad():
+        c2ws = torch.stack([eval_pose(i) for i in range(f.N_imgs)])
+    cfg = dict(cfg, extract_images={"resolution": [f.H, f.W]})
+    gen = Eval_Images(nope.renderer, cfg, use_learnt_poses=True, use_learnt_focal=False, device=device, render_type="nope_nerf",
+                      c2ws=c2ws, img_list=f.img_list)
+    zero = lambda a, b, normalize=True: torch.zeros(())
+    t0 = time.perf_counter()
+    rows = [gen.eval_images(batch, out_dir, None, zero, logger=None) for batch in loader]
+    dt = time.perf_counter() - t0
+    return {"views": f.N_imgs, "pose_opt_epochs": epochs, "pose_opt_mse_first": first, "pose_opt_mse_last": last,
+            "psnr": float(np.mean([r["psnr"] for r in rows])), "ssim": float(np.mean([r["ssim"] for r in rows])),
+            "seconds_per_frame": dt / max(1, len(rows))}
+
+
+def run(path, scene, style="tanks", epochs=100, seed=42, log_every=10, device=None, eval_epochs=0, eval_dir=None, **cfg_kw):
+    """-> dict with the per-epoch PSNR / pose-error curve and the loop throughput (+ novel-view scores with eval_epochs > 0)."""
     import dataloading as dl
     from model.common import mse2psnr
     device = torch.device(device or "cuda")
@@ -111,7 +153,12 @@ def run(path, scene, style="tanks", epochs=100, seed=42, log_every=10, device=No
             curve.append(dict(epoch=epoch, psnr=float(mse2psnr(mse)), **pose_errors(pose, gt, n_views)))
             print(json.dumps(curve[-1]), flush=True)
     n_rays = cfg["training"]["n_training_points"]
-    return {"scene": scene, "style": style, "views": n_views, "image": [field.H, field.W], "rays_per_step": n_rays,
+    novel = None
+    if eval_epochs > 0:
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            novel = novel_view_eval(cfg, trainer.model, pose, field, device, eval_epochs, eval_dir or tmp, n_points=min(1024, n_rays))
+    return {"novel_views": novel, "scene": scene, "style": style, "views": n_views, "image": [field.H, field.W], "rays_per_step": n_rays,
             "samples_per_ray": cfg["rendering"]["num_points"], "hidden": cfg["model"]["hidden_dim"], "epochs": epochs,
             "steps": it + 1, "loader": "resident" if cfg["dataloading"]["resident"] else "host(workers=%d)" % cfg["dataloading"]["n_workers"],
             "aux_losses": cfg["training"]["pc_weight"][0] != 0.0,
@@ -133,9 +180,11 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="DataLoader worker processes of the host loader (reference default: 1)")
     ap.add_argument("--no-aux", action="store_true")
     ap.add_argument("--log-every", type=int, default=10)
+    ap.add_argument("--eval-epochs", type=int, default=0, help="test-time pose optimisation epochs before scoring the held-out views")
+    ap.add_argument("--eval-dir", default=None, help="where the rendered held-out frames go (default: a temporary directory)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    res = run(a.path, a.scene, style=a.style, epochs=a.epochs, log_every=a.log_every, n_rays=a.rays, n_samples=a.samples,
+    res = run(a.path, a.scene, style=a.style, epochs=a.epochs, log_every=a.log_every, eval_epochs=a.eval_epochs, eval_dir=a.eval_dir, n_rays=a.rays, n_samples=a.samples,
               hidden=a.hidden, resident=not a.host_loader, aux=not a.no_aux, resize_factor=a.factor, workers=a.workers)
     print(json.dumps({k: v for k, v in res.items() if k != "curve"}))
     if a.out:
