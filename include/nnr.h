@@ -222,6 +222,15 @@ size_t nnr_randperm_scratch_bytes(int32_t r);
 int nnr_randperm_prefix(const int64_t* keys, int64_t n, int32_t bits, int32_t r, uint64_t seed, uint64_t offset, int64_t* out,
                         void* scratch, void* stream);
 
+/* World rays -> NDC rays of a forward-facing scene: get_ndc_rays_fxfy (model/common.py:632-675) as Renderer.sample_ndc calls it
+ * (model/rendering.py:168-180; near_plane = 1).  rays_o, rays_d, o_ndc, d_ndc: (n_rays, 3); camera_mat: the 4x4 K = diag(2f/w,
+ * -2f/h, -1, 1) on the device (entries [0] and [5] are read).  The backward returns the gradients with respect to the world rays;
+ * the intrinsics are constants here (with a learnable focal the caller keeps the torch expression). */
+int nnr_ndc_rays_fwd(const float* rays_o, const float* rays_d, const float* camera_mat, float near_plane, float* o_ndc, float* d_ndc,
+                     int32_t n_rays, void* stream);
+int nnr_ndc_rays_bwd(const float* rays_o, const float* rays_d, const float* camera_mat, float near_plane, const float* g_o_ndc,
+                     const float* g_d_ndc, float* g_rays_o, float* g_rays_d, int32_t n_rays, void* stream);
+
 /* depth = nearest-resize(depth_img (hd,wd) -> (h,w)).flatten()[ray_idx]  (model/network.py:22-24) without materialising
  * the resized image; backward scatter-adds into a zero-filled (hd,wd) gradient image. */
 int nnr_depth_gather_fwd(const float* depth_img, const int64_t* ray_idx, float* out, int32_t n_rays, int32_t h, int32_t w,

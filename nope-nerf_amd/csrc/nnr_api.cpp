@@ -500,6 +500,17 @@ int nnr_ray_setup_bwd(const float* pixels, const float* depth, const float* K, c
     a.R = n_rays; a.normalise = normalise; a.use_dir = use_dir;
     NNR_LAUNCH(launch_ray_setup_bwd(a, (hipStream_t)stream));
 }
+int nnr_ndc_rays_fwd(const float* rays_o, const float* rays_d, const float* camera_mat, float near_plane, float* o_ndc, float* d_ndc,
+                     int32_t n_rays, void* stream) {
+    if (!rays_o || !rays_d || !camera_mat || !o_ndc || !d_ndc || n_rays <= 0) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_ndc_rays_fwd(rays_o, rays_d, camera_mat, near_plane, o_ndc, d_ndc, n_rays, (hipStream_t)stream));
+}
+int nnr_ndc_rays_bwd(const float* rays_o, const float* rays_d, const float* camera_mat, float near_plane, const float* g_o_ndc,
+                     const float* g_d_ndc, float* g_rays_o, float* g_rays_d, int32_t n_rays, void* stream) {
+    if (!rays_o || !rays_d || !camera_mat || !g_o_ndc || !g_d_ndc || !g_rays_o || !g_rays_d || n_rays <= 0) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_ndc_rays_bwd(rays_o, rays_d, camera_mat, near_plane, g_o_ndc, g_d_ndc, g_rays_o, g_rays_d, n_rays, (hipStream_t)stream));
+}
+
 int nnr_depth_gather_fwd(const float* depth_img, const int64_t* ray_idx, float* out, int32_t n_rays, int32_t h, int32_t w,
                          int32_t hd, int32_t wd, void* stream) {
     if (!depth_img || !ray_idx || !out || n_rays <= 0 || h <= 0 || w <= 0 || hd <= 0 || wd <= 0) return NNR_E_BADCFG;

@@ -407,6 +407,63 @@ hipError_t launch_depth_gather_bwd(const float* g, const int64_t* idx, float* g_
     hipLaunchKernelGGL(depth_gather_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, st, g, idx, g_img, R, h, w, hd, wd);
     return hipGetLastError();
 }
+// ---- NDC rays for forward-facing scenes (model/common.py:632-675, called from Renderer.sample_ndc, rendering.py:168-180) ----
+// Per ray: shift the origin to the near plane, project origin and direction with (gx, gy) = (-1/(1/K00), -1/(1/K11)) -- the
+// reference writes the focal that way, the double reciprocal is kept.  ~25 torch ops forward and twice that backward become
+// one launch each.  Unfused mul/add/div in the forward, in the reference's operation order.
+__global__ void ndc_rays_fwd_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ K, float near_,
+                                    float* __restrict__ o_ndc, float* __restrict__ d_ndc, int R) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const float gx = __fdiv_rn(-1.f, __fdiv_rn(1.f, K[0])), gy = __fdiv_rn(-1.f, __fdiv_rn(1.f, K[5]));
+    const float ox = o[3 * i], oy = o[3 * i + 1], oz = o[3 * i + 2], dx = d[3 * i], dy = d[3 * i + 1], dz = d[3 * i + 2];
+    const float t = __fdiv_rn(-__fadd_rn(near_, oz), dz);
+    const float px = __fadd_rn(ox, __fmul_rn(t, dx)), py = __fadd_rn(oy, __fmul_rn(t, dy)), pz = __fadd_rn(oz, __fmul_rn(t, dz));
+    const float u = __fdiv_rn(px, pz), v = __fdiv_rn(py, pz);
+    const float onz = __fadd_rn(1.f, __fdiv_rn(__fmul_rn(2.f, near_), pz));
+    o_ndc[3 * i] = __fmul_rn(gx, u);
+    o_ndc[3 * i + 1] = __fmul_rn(gy, v);
+    o_ndc[3 * i + 2] = onz;
+    d_ndc[3 * i] = __fmul_rn(gx, __fsub_rn(__fdiv_rn(dx, dz), u));
+    d_ndc[3 * i + 1] = __fmul_rn(gy, __fsub_rn(__fdiv_rn(dy, dz), v));
+    d_ndc[3 * i + 2] = __fsub_rn(1.f, onz);
+}
+// gradients with respect to the world rays (the intrinsics are treated as constants: a learnable focal takes the torch path)
+__global__ void ndc_rays_bwd_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ K, float near_,
+                                    const float* __restrict__ g_o_ndc, const float* __restrict__ g_d_ndc, float* __restrict__ g_o,
+                                    float* __restrict__ g_d, int R) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const float gx = -1.f / (1.f / K[0]), gy = -1.f / (1.f / K[5]);
+    const float ox = o[3 * i], oy = o[3 * i + 1], oz = o[3 * i + 2], dx = d[3 * i], dy = d[3 * i + 1], dz = d[3 * i + 2];
+    const float a = near_ + oz, t = -a / dz;
+    const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+    const float gox = g_o_ndc[3 * i], goy = g_o_ndc[3 * i + 1], goz = g_o_ndc[3 * i + 2];
+    const float gdx = g_d_ndc[3 * i], gdy = g_d_ndc[3 * i + 1], gdz = g_d_ndc[3 * i + 2];
+    const float g_u = gx * (gox - gdx), g_v = gy * (goy - gdy);            // u = px/pz, v = py/pz enter o_ndc.xy and -d_ndc.xy
+    const float g_rx = gx * gdx, g_ry = gy * gdy;                          // rx = dx/dz, ry = dy/dz
+    const float ipz = 1.f / pz, idz = 1.f / dz;
+    const float g_px = g_u * ipz, g_py = g_v * ipz;
+    const float g_pz = -(g_u * px + g_v * py) * ipz * ipz - (goz - gdz) * 2.f * near_ * ipz * ipz;   // o_ndc.z = 1 + 2 near / pz = 1 - d_ndc.z
+    const float g_t = g_px * dx + g_py * dy + g_pz * dz;                   // p = o + t d
+    const float g_a = -g_t * idz;                                          // t = -a / dz
+    g_o[3 * i] = g_px;
+    g_o[3 * i + 1] = g_py;
+    g_o[3 * i + 2] = g_pz + g_a;                                           // a = near + oz
+    g_d[3 * i] = t * g_px + g_rx * idz;
+    g_d[3 * i + 1] = t * g_py + g_ry * idz;
+    g_d[3 * i + 2] = t * g_pz + g_t * a * idz * idz - (g_rx * dx + g_ry * dy) * idz * idz;
+}
+hipError_t launch_ndc_rays_fwd(const float* o, const float* d, const float* K, float near_, float* o_ndc, float* d_ndc, int R, hipStream_t st) {
+    hipLaunchKernelGGL(ndc_rays_fwd_kernel, dim3((R + 255) / 256), dim3(256), 0, st, o, d, K, near_, o_ndc, d_ndc, R);
+    return hipGetLastError();
+}
+hipError_t launch_ndc_rays_bwd(const float* o, const float* d, const float* K, float near_, const float* g_o_ndc, const float* g_d_ndc,
+                               float* g_o, float* g_d, int R, hipStream_t st) {
+    hipLaunchKernelGGL(ndc_rays_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, st, o, d, K, near_, g_o_ndc, g_d_ndc, g_o, g_d, R);
+    return hipGetLastError();
+}
+
 hipError_t launch_render_loss(const LossArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(render_loss_kernel, dim3(1), dim3(1024), 0, st, a);
     return hipGetLastError();

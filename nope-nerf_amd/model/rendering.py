@@ -124,8 +124,11 @@ class Renderer(nn.Module):
         # --- per-ray sampling frame ---
         jitter = None
         if cfg['sample_option'] == 'ndc':                                           # :168-180
-            focal = torch.cat([camera_mat[:, 0, 0], camera_mat[:, 1, 1]])
-            pts_o, pts_d = get_ndc_rays_fxfy(focal, 1.0, rays_o=origin, rays_d=ray)
+            if pixels.is_cuda and not camera_mat.requires_grad:       # one launch each way instead of ~25 + ~50 torch ops
+                pts_o, pts_d = camera.ndc_rays(origin, ray, camera_mat, 1.0)
+            else:                                                    # CPU stand-in; a focal that is being learned
+                focal = torch.cat([camera_mat[:, 0, 0], camera_mat[:, 1, 1]])
+                pts_o, pts_d = get_ndc_rays_fxfy(focal, 1.0, rays_o=origin, rays_d=ray)
             z_lo, z_hi = self._z_tables(n_samples, 0., 1., False, device)
         elif cfg['sample_option'] == 'uniform':                                     # :182-197
             pts_o, pts_d = origin, ray

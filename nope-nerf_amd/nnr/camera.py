@@ -184,3 +184,33 @@ def pixels_from_index(ray_idx: torch.Tensor, h: int, w: int) -> torch.Tensor:
     out = torch.empty(1, idx.shape[0], 2, dtype=torch.float32, device=idx.device)
     L.check(L.load().nnr_pixels_from_index(L.ptr(idx), L.ptr(out), idx.shape[0], int(h), int(w), _st()), "nnr_pixels_from_index")
     return out
+
+
+class _NdcRays(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, origin, ray, camera_mat, near):
+        o, d, K = _f32(origin), _f32(ray), _f32(camera_mat)
+        R = d.shape[0]
+        o = o.expand(R, 3).contiguous()
+        out_o, out_d = torch.empty(R, 3, dtype=torch.float32, device=d.device), torch.empty(R, 3, dtype=torch.float32, device=d.device)
+        L.check(L.load().nnr_ndc_rays_fwd(L.ptr(o), L.ptr(d), L.ptr(K), float(near), L.ptr(out_o), L.ptr(out_d), R, _st()), "nnr_ndc_rays_fwd")
+        ctx.save_for_backward(o, d, K)
+        ctx.near, ctx.o_shape = float(near), tuple(origin.shape)
+        return out_o, out_d
+
+    @staticmethod
+    def backward(ctx, g_o_ndc, g_d_ndc):
+        o, d, K = ctx.saved_tensors
+        R = d.shape[0]
+        g_o, g_d = torch.empty_like(o), torch.empty_like(d)
+        L.check(L.load().nnr_ndc_rays_bwd(L.ptr(o), L.ptr(d), L.ptr(K), ctx.near, L.ptr(_f32(g_o_ndc)), L.ptr(_f32(g_d_ndc)), L.ptr(g_o),
+                                          L.ptr(g_d), R, _st()), "nnr_ndc_rays_bwd")
+        if ctx.o_shape != tuple(g_o.shape):      # the origin was one point broadcast over the rays
+            g_o = g_o.sum(0).reshape(ctx.o_shape) if len(ctx.o_shape) == 1 else g_o.sum(0, keepdim=True).expand(ctx.o_shape)
+        return g_o, g_d, None, None
+
+
+def ndc_rays(origin: torch.Tensor, ray: torch.Tensor, camera_mat: torch.Tensor, near: float = 1.0):
+    """get_ndc_rays_fxfy (reference model/common.py:632-675) for (R,3) world rays in one launch each way; camera_mat (1,4,4) or
+    (4,4) is a constant of the graph (the caller keeps the torch expression when the focal is being learned)."""
+    return _NdcRays.apply(origin, ray, camera_mat.reshape(-1, 4, 4)[0], near)

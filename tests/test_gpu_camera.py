@@ -207,3 +207,34 @@ def test_trainer_train_step_matches_reference_golden(name, monkeypatch):
     got.update(pose_r=pose.r.grad, pose_t=pose.t.grad, scales=dist.global_scales.grad, shifts=dist.global_shifts.grad)
     for k, (kind, ref, norm) in gu.golden_grads(case).items():
         gu.compare_grad(k, got[k], kind, ref, norm, 1e-4)
+
+
+def test_ndc_rays_match_the_torch_expression():
+    """nnr_ndc_rays_fwd/bwd vs get_ndc_rays_fxfy (reference model/common.py:632-675) under torch autograd."""
+    from model.common import get_ndc_rays_fxfy
+    from nnr import camera
+    g = torch.Generator().manual_seed(4)
+    R = 777
+    o = (0.2 * torch.randn(R, 3, generator=g)).to(DEV)
+    d = torch.randn(R, 3, generator=g)
+    d[:, 2] = -(0.5 + d[:, 2].abs())                      # forward-facing: looking down -z
+    d = (d / d.norm(dim=-1, keepdim=True)).to(DEV)
+    K = torch.diag(torch.tensor([1.8, -2.4, -1.0, 1.0])).unsqueeze(0).to(DEV)
+    go, gd = torch.randn(R, 3, generator=g).to(DEV), torch.randn(R, 3, generator=g).to(DEV)
+    o1, d1 = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    ro, rd = get_ndc_rays_fxfy(torch.cat([K[:, 0, 0], K[:, 1, 1]]), 1.0, rays_o=o1, rays_d=d1)
+    ((ro * go).sum() + (rd * gd).sum()).backward()
+    o2, d2 = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    ho, hd = camera.ndc_rays(o2, d2, K, 1.0)
+    ((ho * go).sum() + (hd * gd).sum()).backward()
+    for a, b in ((ho, ro), (hd, rd)):      # same operations in the same order; ATen's device division may round differently
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+    for a, b in ((o2.grad, o1.grad), (d2.grad, d1.grad)):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+    # a single origin broadcast over the rays (what the camera centre is): its gradient is the sum over rays
+    c1, c2 = o[0].clone().requires_grad_(True), o[0].clone().requires_grad_(True)
+    ro, rd = get_ndc_rays_fxfy(torch.cat([K[:, 0, 0], K[:, 1, 1]]), 1.0, rays_o=c1.expand(R, 3), rays_d=d)
+    ((ro * go).sum() + (rd * gd).sum()).backward()
+    ho, hd = camera.ndc_rays(c2, d, K, 1.0)
+    ((ho * go).sum() + (hd * gd).sum()).backward()
+    assert float((c2.grad - c1.grad).abs().max()) <= 1e-4 * max(1.0, float(c1.grad.abs().max()))
