@@ -255,13 +255,28 @@ class Trainer(object):
                                            detach_gt=self.detach_gt_depth)
             lrgb, ldep, l2 = a4[0], a4[1], a4[2]
         else:
-            if self.loss.depth_loss_type != 'l1':
-                raise NotImplementedError("depth_loss_type 'invariant' takes a median over all rays of the step "
-                                          "(losses.py:42-46); it needs an all-gather and is not sharded yet")
+            invariant = None
+            if self.loss.depth_loss_type != 'l1' and w['depth_weight'] != 0.0:
+                # 'invariant' normalises by the median / mean deviation over ALL valid rays of the step (losses.py:42-46): gather the
+                # dense per-ray values, keep this rank's slice live, evaluate the loss on the full vectors.  Its gradient with
+                # respect to the local rays is then exact and the SUM over ranks is the single-process gradient; the reported value
+                # is divided by the world size so that the summed log equals the loss (value / W, gradient x 1).
+                pred_d, gt_d, valid = out['dist_dense'], out['d_gt_dense'], out['mask']
+                if out['ndc']:
+                    gt_d = 1 - 1 / gt_d
+                if self.detach_gt_depth:
+                    gt_d = gt_d.detach()
+                pred_all, gt_all = parallel.gather_rays(pred_d, n_total), parallel.gather_rays(gt_d, n_total)
+                valid_all = parallel.gather_rays(valid.to(pred_d.dtype), n_total) > 0.5
+                full = self.loss.depth_loss_dpt(pred_all[valid_all], gt_all[valid_all])
+                invariant = full.detach() / world + (full - full.detach())
             diff = rgb - rgb_gt
             lrgb = (diff.abs().sum() if kwargs['rgb_loss_type'] == 'l1' else (diff * diff).sum()) / float(n_total)
-            ldep = (depth_pred - depth_gt).abs().sum() / torch.clamp(torch.as_tensor(m_total, device=rgb.device), min=1.0) \
-                if w['depth_weight'] != 0.0 else zero
+            if invariant is not None:
+                ldep = invariant
+            else:
+                ldep = (depth_pred - depth_gt).abs().sum() / torch.clamp(torch.as_tensor(m_total, device=rgb.device), min=1.0) \
+                    if w['depth_weight'] != 0.0 else zero
             l2 = (diff * diff).sum() / float(3 * n_total)
             lmain = w['rgb_weight'] * lrgb + w['depth_weight'] * ldep
         loss_dict.update(loss_rgb=lrgb, loss_depth=ldep, l2_mean=l2, loss=lmain if aux is None else lmain + aux)

@@ -26,6 +26,25 @@ def shard_bounds(n: int, rank_: int, world: int):
     return lo, lo + base + (1 if rank_ < rem else 0)
 
 
+def gather_rays(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """Every rank's shard of a per-ray tensor, concatenated in ray order: (n_total, ...).  This rank's slice is the live tensor
+    (autograd flows into it), the others are constants -- the gradient of a loss over ALL rays with respect to the local rays,
+    which is what the SUM all-reduce of the parameter gradients needs.  One all-gather of ceil(n_total / W) rows per rank."""
+    world, me = world_size(), rank()
+    if world == 1:
+        return local
+    per = -(-n_total // world)
+    buf = local.detach().new_zeros((per,) + tuple(local.shape[1:]))
+    buf[:local.shape[0]] = local.detach()
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    pieces = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        pieces.append(local if r == me else outs[r][:hi - lo])
+    return torch.cat(pieces)
+
+
 _LOGGED = ('loss', 'loss_rgb', 'loss_depth', 'l2_mean', 'loss_dist_1st', 'loss_dist_2nd', 'loss_pc', 'loss_rgb_s',
            'loss_depth_consistency')
 

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(case, n_rays):
+def _build(case, n_rays, depth_loss_type='l1'):
     import model as mdl
     import model.rendering as rendering
     import oracle_backend
@@ -34,7 +34,7 @@ def _build(case, n_rays):
             'vis_reprojection_every': 5000, 'nearest_limit': 0.01, 'annealing_epochs': 2000, 'rgb_weight': [1.0, 1.0],
             'depth_weight': [0.04, 0.0], 'pc_weight': [0.0, 0.0], 'rgb_s_weight': [0.0, 0.0],
             'depth_consistency_weight': [0.0, 0.0], 'weight_dist_2nd_loss': [0.5, 0.5], 'weight_dist_1st_loss': [0.1, 0.1],
-            'depth_loss_type': 'l1', 'with_ssim': False, 'with_auto_mask': False}
+            'depth_loss_type': depth_loss_type, 'with_ssim': False, 'with_auto_mask': False}
     net = mdl.OfficialStaticNerf(cfg)
     net.load_state_dict(case["weights"])
     model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device='cpu'), cfg, device='cpu')
@@ -51,8 +51,8 @@ def _build(case, n_rays):
     return tr, net, pose, distn, data
 
 
-def _step(case, n_rays):
-    tr, net, pose, distn, data = _build(case, n_rays)
+def _step(case, n_rays, depth_loss_type='l1'):
+    tr, net, pose, distn, data = _build(case, n_rays, depth_loss_type)
     torch.manual_seed(123)                      # same permutation and jitter stream on every rank
     ld = tr.train_step(data, it=0, epoch=0, scheduling_start=10000, render_path=None)
     grads = {k: v.grad.clone() for k, v in net.named_parameters()}
@@ -61,25 +61,28 @@ def _step(case, n_rays):
     return {k: float(ld[k]) for k in ('loss', 'loss_rgb', 'loss_depth', 'l2_mean', 'loss_dist_1st', 'loss_dist_2nd')}, grads
 
 
-def _worker(rank, world, port, name, n_rays, q):
+def _worker(rank, world, port, name, n_rays, q, depth_loss_type='l1'):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     try:
-        losses, grads = _step(gu.load_case(name), n_rays)
+        losses, grads = _step(gu.load_case(name), n_rays, depth_loss_type)
         if rank == 0:
             q.put((losses, {k: v.numpy() for k, v in grads.items()}))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,n_rays", [("tanks_d128", 31), ("uniform_distalpha_masked_d128", 48)])
-def test_two_rank_step_equals_single_process(name, n_rays):
-    ref_losses, ref_grads = _step(gu.load_case(name), n_rays)          # world size 1, this process
+@pytest.mark.parametrize("name,n_rays,depth_loss_type", [("tanks_d128", 31, "l1"), ("uniform_distalpha_masked_d128", 48, "l1"),
+                                                         ("uniform_distalpha_masked_d128", 47, "invariant")])
+def test_two_rank_step_equals_single_process(name, n_rays, depth_loss_type):
+    """'invariant' normalises the depths by the median / mean deviation over all valid rays of the step: the ranks all-gather
+    the per-ray values (nnr.parallel.gather_rays) and differentiate the full loss with respect to their own rays."""
+    ref_losses, ref_grads = _step(gu.load_case(name), n_rays, depth_loss_type)          # world size 1, this process
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, n_rays, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, n_rays, q, depth_loss_type)) for r in range(2)]
     for p in procs:
         p.start()
     losses, grads = q.get(timeout=300)
