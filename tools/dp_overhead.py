@@ -34,6 +34,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--rank", type=int, default=0, help="which rank of the virtual job this process plays")
     ap.add_argument("--skip-single", action="store_true", help="only the virtual-rank run (for a kernel trace of it)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -46,9 +47,9 @@ if __name__ == "__main__":
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     from nnr import parallel
     parallel.world_size = lambda: a.world
-    parallel.rank = lambda: 0
+    parallel.rank = lambda: a.rank
     trainer, _ = bench.build_trainer(dev, a.world)
     virtual = timed(trainer, data, a.steps)
-    print(json.dumps({"world": a.world, "single_ms": round(single, 4), "virtual_rank0_ms": round(virtual, 4),
+    print(json.dumps({"world": a.world, "single_ms": round(single, 4), "virtual_rank": a.rank, "virtual_rank_ms": round(virtual, 4),
                       "overhead_ms": round(virtual - single, 4), "overhead_frac": round(virtual / single - 1, 4)}))
     dist.destroy_process_group()
