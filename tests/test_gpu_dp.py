@@ -57,17 +57,19 @@ def _step(case, n_rays, monkeypatch, rank=0, world=1):
     return {k: float(ld[k]) for k in ('loss', 'loss_rgb', 'loss_depth', 'l2_mean', 'loss_dist_1st')}, grads
 
 
-@pytest.mark.parametrize("name,n_rays", [("tanks_d128", 61), ("uniform_distalpha_masked_d128", 96)])
-def test_two_virtual_ranks_sum_to_single_process(name, n_rays, monkeypatch):
+@pytest.mark.parametrize("name,n_rays,world", [("tanks_d128", 61, 2), ("uniform_distalpha_masked_d128", 96, 2),
+                                               ("tanks_d128", 61, 8), ("llff_ndc_d128", 50, 4)])
+def test_virtual_ranks_sum_to_single_process(name, n_rays, world, monkeypatch):
+    """W virtual ranks (uneven shards: 61 rays over 8 ranks = 8,8,8,8,8,7,7,7), one after the other on the one GPU."""
     case = gu.load_case(name)
     ref_l, ref_g = _step(case, n_rays, monkeypatch)
-    l0, g0 = _step(case, n_rays, monkeypatch, 0, 2)
-    l1, g1 = _step(case, n_rays, monkeypatch, 1, 2)
+    parts = [_step(case, n_rays, monkeypatch, r, world) for r in range(world)]
     for k, v in ref_l.items():
-        assert abs(l0[k] + l1[k] - v) <= 1e-5 * max(1.0, abs(v)), (k, l0[k], l1[k], v)
-    for a, b, r in zip(g0, g1, ref_g):
+        total = sum(p[0][k] for p in parts)
+        assert abs(total - v) <= 1e-5 * max(1.0, abs(v)), (k, total, v)
+    for i, r in enumerate(ref_g):
         scale = max(1.0, float(r.abs().max()))
-        assert float((a + b - r).abs().max()) / scale <= 2e-5
+        assert float((sum(p[1][i] for p in parts) - r).abs().max()) / scale <= 2e-5
 
 
 def test_rccl_flat_allreduce_world1():
