@@ -33,14 +33,34 @@ def frames(seed):
     return torch.stack(imgs).clamp(0, 1), torch.stack(dpts)
 
 
+NDC_STEPS = [(2, 3), (4, 5), (5, 4)]
+NDC_RENDERING = dict(sample_option="ndc", dist_alpha=True, depth_range=[0.0, 1.0])       # configs/LLFF/fern.yaml
+NDC_TENSORS = ("layers0.0.weight", "layers1.0.weight", "fc_density.weight", "rgb_layers.0.weight", "fc_rgb.weight", "layers1.6.bias")
+
+
 def main():
     ref = gg.import_reference()
     torch.set_num_threads(8)
+    blob = run(ref, STEPS, {}, 31, 32)
+    ndc = run(ref, NDC_STEPS, NDC_RENDERING, 31, 32)          # same frames and initial parameters, stored once
+    base = np.load(os.path.join(gg.OUT, "weights_d128.npz"))
+    # the LLFF-style sequence rides along under "ndc.": draws, losses, small parameters, the moves of a few network tensors
+    for k, v in ndc.items():
+        if k.startswith("final.net.") or k.startswith("after1.") or k.startswith("init.") or k in ("imgs", "dpts", "K"):
+            continue
+        blob["ndc." + k] = v
+    for k in NDC_TENSORS:
+        blob["ndc.final.delta_f16." + k] = (ndc["final.net." + k] - base[k]).astype(np.float16)
+    finish(blob, base)
+
+
+def run(ref, STEPS, rendering, seed_inputs, seed_frames):
     cfg = copy.deepcopy(gg.base_cfg(128))
     cfg["training"].update(n_training_points=ga.R, pc_weight=[1.0, 0.0], rgb_s_weight=[1.0, 0.0], vis_reprojection_every=10 ** 9)
     cfg["rendering"]["num_points"] = ga.N
-    inp = ga.inputs(31)
-    imgs, dpts = frames(32)
+    cfg["rendering"].update(rendering)
+    inp = ga.inputs(seed_inputs)
+    imgs, dpts = frames(seed_frames)
     dev = torch.device("cpu")
     torch.manual_seed(42)
     net = ref.OfficialStaticNerf(cfg)
@@ -54,11 +74,13 @@ def main():
                      optimizer_distortion=adam(dist, 5e-4), distortion_net=dist)
     base = np.load(os.path.join(gg.OUT, "weights_d128.npz"))
     assert all(np.array_equal(base[k], v.numpy()) for k, v in net.state_dict().items())    # the seed-42 D=128 network
+    drawn_reset = True
     blob = {"imgs": imgs.numpy(), "dpts": dpts.numpy(), "K": inp["K"].numpy(), "steps": np.array(STEPS)}
     for k in ("pose_r", "pose_t", "scales", "shifts"):
         blob["init." + k] = inp[k].numpy()
     real_randperm, real_rand = torch.randperm, torch.rand
     drawn = {}
+    del drawn_reset
 
     def randperm(n, *a, **k):
         drawn["perm"] = real_randperm(n, *a, **k)
@@ -85,7 +107,8 @@ def main():
                     "img.ref_idxs": nb}
             ld = tr.train_step(data, it=s + 1, epoch=0, scheduling_start=10000, render_path=None)   # it = 0 would dump the re-projection PNGs
             blob[f"s{s}.ray_idx"] = drawn["perm"][:ga.R].numpy().copy()
-            blob[f"s{s}.jitter"] = drawn["jitter"].numpy().copy()
+            if "jitter" in drawn:                                    # NDC sampling draws none (rendering.py:168-180)
+                blob[f"s{s}.jitter"] = drawn["jitter"].numpy().copy()
             for k in LOGGED:
                 blob[f"s{s}.{k}"] = np.float64(float(ld[k]))
             print(f"step {s} cam {cam} nb {nb}: " + "  ".join(f"{k} {float(ld[k]):.6f}" for k in LOGGED))
@@ -94,6 +117,10 @@ def main():
     finally:
         torch.randperm, torch.rand = real_randperm, real_rand
     snapshot("final")
+    return blob
+
+
+def finish(blob, base):
     # the first-step and whole-run updates of the network, for scale
     d1 = np.concatenate([(blob[f"after1.net.{k}"] - base[k]).ravel() for k in base.files])
     print("after step 1: |update| max %.3e (lr = 1e-3: Adam's first step moves every touched entry by lr)" % np.abs(d1).max())

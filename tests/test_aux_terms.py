@@ -37,7 +37,7 @@ def test_oracle_aux_scope_matches_reference_golden(name):
         np.testing.assert_allclose(g.numpy(), GOLD[f"{name}.gaux.{k}"], rtol=0, atol=2e-6, err_msg=k)
 
 
-def _trainer(inp, dev, adam=False, **training_overrides):
+def _trainer(inp, dev, adam=False, rendering_overrides=None, **training_overrides):
     import model as mdl
     if True:
         cfg = {
@@ -55,6 +55,7 @@ def _trainer(inp, dev, adam=False, **training_overrides):
                 'depth_loss_type': 'l1', 'with_ssim': False, 'with_auto_mask': False},
         }
     cfg['training'].update(training_overrides)
+    cfg['rendering'].update(rendering_overrides or {})
     net = mdl.OfficialStaticNerf(cfg)
     wts = np.load(os.path.join(HERE, "golden", "weights_d128.npz"))
     net.load_state_dict({k: torch.from_numpy(wts[k]) for k in wts.files})
