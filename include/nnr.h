@@ -222,6 +222,16 @@ size_t nnr_randperm_scratch_bytes(int32_t r);
 int nnr_randperm_prefix(const int64_t* keys, int64_t n, int32_t bits, int32_t r, uint64_t seed, uint64_t offset, int64_t* out,
                         void* scratch, void* stream);
 
+/* The depth gather below with the per-image affine distortion of model/distortions.py:19-26 applied to the n_rays gathered values
+ * instead of to the whole map (model/training.py:240-245 then model/network.py:22-24: the same numbers): out = raw * scale + shift,
+ * or (raw + shift) * scale with shift_first.  scale, shift: one-element device tensors.  The backward writes g_scale_shift[0] =
+ * d loss / d scale and [1] = d loss / d shift (the raw map is data and has no gradient). */
+int nnr_depth_gather_affine_fwd(const float* depth_img, const int64_t* ray_idx, const float* scale, const float* shift, int32_t shift_first,
+                                float* out, int32_t n_rays, int32_t h, int32_t w, int32_t hd, int32_t wd, void* stream);
+int nnr_depth_gather_affine_bwd(const float* g_out, const float* depth_img, const int64_t* ray_idx, const float* scale, const float* shift,
+                                int32_t shift_first, float* g_scale_shift, int32_t n_rays, int32_t h, int32_t w, int32_t hd, int32_t wd,
+                                void* stream);
+
 /* World rays -> NDC rays of a forward-facing scene: get_ndc_rays_fxfy (model/common.py:632-675) as Renderer.sample_ndc calls it
  * (model/rendering.py:168-180; near_plane = 1).  rays_o, rays_d, o_ndc, d_ndc: (n_rays, 3); camera_mat: the 4x4 K = diag(2f/w,
  * -2f/h, -1, 1) on the device (entries [0] and [5] are read).  The backward returns the gradients with respect to the world rays;

@@ -500,6 +500,20 @@ int nnr_ray_setup_bwd(const float* pixels, const float* depth, const float* K, c
     a.R = n_rays; a.normalise = normalise; a.use_dir = use_dir;
     NNR_LAUNCH(launch_ray_setup_bwd(a, (hipStream_t)stream));
 }
+int nnr_depth_gather_affine_fwd(const float* depth_img, const int64_t* ray_idx, const float* scale, const float* shift, int32_t shift_first,
+                                float* out, int32_t n_rays, int32_t h, int32_t w, int32_t hd, int32_t wd, void* stream) {
+    if (!depth_img || !ray_idx || !scale || !shift || !out || n_rays <= 0 || h <= 0 || w <= 0 || hd <= 0 || wd <= 0) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_depth_gather_affine_fwd(depth_img, ray_idx, scale, shift, shift_first, out, n_rays, h, w, hd, wd, (hipStream_t)stream));
+}
+int nnr_depth_gather_affine_bwd(const float* g_out, const float* depth_img, const int64_t* ray_idx, const float* scale, const float* shift,
+                                int32_t shift_first, float* g_scale_shift, int32_t n_rays, int32_t h, int32_t w, int32_t hd, int32_t wd,
+                                void* stream) {
+    if (!g_out || !depth_img || !ray_idx || !scale || !shift || !g_scale_shift || n_rays <= 0 || h <= 0 || w <= 0 || hd <= 0 || wd <= 0)
+        return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_depth_gather_affine_bwd(g_out, depth_img, ray_idx, scale, shift, shift_first, g_scale_shift, n_rays, h, w, hd, wd,
+                                              (hipStream_t)stream));
+}
+
 int nnr_ndc_rays_fwd(const float* rays_o, const float* rays_d, const float* camera_mat, float near_plane, float* o_ndc, float* d_ndc,
                      int32_t n_rays, void* stream) {
     if (!rays_o || !rays_d || !camera_mat || !o_ndc || !d_ndc || n_rays <= 0) return NNR_E_BADCFG;

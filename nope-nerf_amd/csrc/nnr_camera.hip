@@ -285,6 +285,46 @@ __global__ void depth_gather_bwd_kernel(const float* g, const int64_t* ray_idx, 
     atomicAdd(g_img + (int64_t)nearest_src(y, h, hd) * wd + nearest_src(x, w, wd), g[i]);
 }
 
+// The same gather with the per-image affine depth distortion applied to the R gathered values instead of the whole map
+// (model/training.py:240-245 distorts the full image, model/network.py:22-24 then picks R of its pixels: the same numbers).
+// out = raw * scale + shift, or (raw + shift) * scale with shift_first; scale / shift are one-element device tensors.
+__global__ void depth_gather_affine_fwd_kernel(const float* img, const int64_t* ray_idx, const float* scale, const float* shift,
+                                               int shift_first, float* out, int R, int h, int w, int hd, int wd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const int64_t q = ray_idx[i];
+    const int y = (int)(q / w), x = (int)(q - (int64_t)y * w);
+    const float raw = img[(int64_t)nearest_src(y, h, hd) * wd + nearest_src(x, w, wd)];
+    out[i] = shift_first ? __fmul_rn(__fadd_rn(raw, shift[0]), scale[0]) : __fadd_rn(__fmul_rn(raw, scale[0]), shift[0]);
+}
+// g_ss[0] += d loss / d scale, g_ss[1] += d loss / d shift (block-reduced, one atomic pair per workgroup); the raw map has no gradient
+__global__ __launch_bounds__(256) void depth_gather_affine_bwd_kernel(const float* g, const float* img, const int64_t* ray_idx,
+                                                                      const float* scale, const float* shift, int shift_first,
+                                                                      float* g_ss, int R, int h, int w, int hd, int wd) {
+    __shared__ float red[2][4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float gs = 0.f, gh = 0.f;
+    if (i < R) {
+        const int64_t q = ray_idx[i];
+        const int y = (int)(q / w), x = (int)(q - (int64_t)y * w);
+        const float raw = img[(int64_t)nearest_src(y, h, hd) * wd + nearest_src(x, w, wd)];
+        const float gi = g[i];
+        // a non-finite raw depth (masked ray) carries a zero upstream gradient; keep 0 * inf out of the sums
+        if (gi != 0.f) {
+            gs = shift_first ? gi * (raw + shift[0]) : gi * raw;
+            gh = shift_first ? gi * scale[0] : gi;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        gs += __shfl_xor(gs, o, 64);
+        gh += __shfl_xor(gh, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = gs; red[1][threadIdx.x >> 6] = gh; }
+    __syncthreads();
+    if (threadIdx.x < 2) atomicAdd(g_ss + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
 // scaled pixel coordinates of flat indices: x' = 2 x/(w-1) - 1, y' = 2 y/(h-1) - 1, same float op order as arange_pixels
 // (model/common.py:36-39)
 __global__ void pixels_from_index_kernel(const int64_t* idx, float* out, int R, int h, int w) {
@@ -464,6 +504,20 @@ hipError_t launch_ndc_rays_bwd(const float* o, const float* d, const float* K, f
     return hipGetLastError();
 }
 
+hipError_t launch_depth_gather_affine_fwd(const float* img, const int64_t* idx, const float* scale, const float* shift, int shift_first,
+                                          float* out, int R, int h, int w, int hd, int wd, hipStream_t st) {
+    hipLaunchKernelGGL(depth_gather_affine_fwd_kernel, dim3((R + 255) / 256), dim3(256), 0, st, img, idx, scale, shift, shift_first, out, R, h,
+                       w, hd, wd);
+    return hipGetLastError();
+}
+hipError_t launch_depth_gather_affine_bwd(const float* g, const float* img, const int64_t* idx, const float* scale, const float* shift,
+                                          int shift_first, float* g_ss, int R, int h, int w, int hd, int wd, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(g_ss, 0, 2 * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(depth_gather_affine_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, st, g, img, idx, scale, shift, shift_first, g_ss,
+                       R, h, w, hd, wd);
+    return hipGetLastError();
+}
 hipError_t launch_render_loss(const LossArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(render_loss_kernel, dim3(1), dim3(1024), 0, st, a);
     return hipGetLastError();

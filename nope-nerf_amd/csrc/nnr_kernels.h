@@ -107,6 +107,10 @@ hipError_t launch_inv4_bwd(const float* y, const float* dy, float* da, int batch
 hipError_t launch_ray_setup_fwd(const RaySetupArgs& a, hipStream_t st);
 hipError_t launch_ray_setup_bwd(const RaySetupArgs& a, hipStream_t st);
 hipError_t launch_depth_gather_fwd(const float* img, const int64_t* idx, float* out, int R, int h, int w, int hd, int wd, hipStream_t st);
+hipError_t launch_depth_gather_affine_fwd(const float* img, const int64_t* idx, const float* scale, const float* shift, int shift_first,
+                                          float* out, int R, int h, int w, int hd, int wd, hipStream_t st);
+hipError_t launch_depth_gather_affine_bwd(const float* g, const float* img, const int64_t* idx, const float* scale, const float* shift,
+                                          int shift_first, float* g_ss, int R, int h, int w, int hd, int wd, hipStream_t st);
 hipError_t launch_ndc_rays_fwd(const float* o, const float* d, const float* K, float near_, float* o_ndc, float* d_ndc, int R, hipStream_t st);
 hipError_t launch_ndc_rays_bwd(const float* o, const float* d, const float* K, float near_, const float* g_o_ndc, const float* g_d_ndc,
                                float* g_o, float* g_d, int R, hipStream_t st);

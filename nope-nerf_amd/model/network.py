@@ -22,18 +22,25 @@ class nope_nerf(nn.Module):
         self.device = device
 
     def forward(self, p, ray_idx, camera_mat, world_mat, scale_mat, rendering_technique, it=0, eval_mode=False,
-                depth_img=None, add_noise=True, img_size=None):
+                depth_img=None, add_noise=True, img_size=None, depth_affine=None):
+        """`depth_affine` = (scale, shift, shift_first) is an extension for the trainer: `depth_img` is then the RAW mono-depth
+        map and the frame's distortion is applied to the gathered values only (the same numbers as distorting the map first)."""
         depth = None
         if rendering_technique == 'nope_nerf':
             # The reference nearest-resizes the whole depth map to the image size every step and then gathers R
             # values (network.py:22-24).  Gather-then-nothing is the same thing: index the source pixel directly.
             h, w = img_size
-            if depth_img.is_cuda:
+            if depth_img.is_cuda and depth_affine is not None:
+                depth = camera.depth_gather_affine(depth_img, ray_idx, depth_affine[0], depth_affine[1], h, w, depth_affine[2])
+            elif depth_img.is_cuda:
                 depth = camera.depth_gather(depth_img, ray_idx, h, w)               # one launch (nnr_depth_gather_*)
             else:
                 hd, wd = depth_img.shape[-2:]
                 ys = nearest_source_index(torch.div(ray_idx, w, rounding_mode='floor'), h, hd)
                 xs = nearest_source_index(ray_idx % w, w, wd)
                 depth = depth_img[0, 0][ys, xs].view(1, -1, 1)
+                if depth_affine is not None:
+                    sc, sh, first = depth_affine
+                    depth = (depth + sh) * sc if first else depth * sc + sh
         return self.renderer(p, depth, camera_mat, world_mat, scale_mat, rendering_technique, eval_=eval_mode, it=it,
                              add_noise=add_noise)

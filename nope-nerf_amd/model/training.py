@@ -143,10 +143,15 @@ class Trainer(object):
         num_cams = self.pose_param_net.num_cams
         world_mat = self._inverse(self.pose_param_net(img_idx)).unsqueeze(0)
         scale_input = shift_input = None
+        depth_affine = None
         if self.distortion_net is not None:
             scale_input, shift_input = self.distortion_net(img_idx)
-            depth_input = (depth_input + shift_input) * scale_input if self.shift_first \
-                else depth_input * scale_input + shift_input
+            if not use_ref_imgs:
+                # only the R picked pixels of the distorted map are ever used: distort those (model/network.py), not 518 400
+                depth_affine = (scale_input, shift_input, bool(self.shift_first))
+            else:   # the per-image losses read the whole distorted map
+                depth_input = (depth_input + shift_input) * scale_input if self.shift_first \
+                    else depth_input * scale_input + shift_input
         if self.optimizer_focal:
             fxfy, camera_mat = self._camera_from_focal(device)
         else:
@@ -171,7 +176,7 @@ class Trainer(object):
             renderer = self.model.renderer
             renderer.jitter_window = (lo, n_total) if world > 1 else None
             out = self.model(p, ray_loc, camera_mat, world_mat, scale_mat, self.rendering_technique, it=it,
-                             eval_mode=eval_mode, depth_img=depth_input, img_size=(h, w))
+                             eval_mode=eval_mode, depth_img=depth_input, img_size=(h, w), depth_affine=depth_affine)
             renderer.jitter_window = None
             rendered_rgb = out['rgb']
             if not (rendered_rgb.is_cuda and self.loss.depth_loss_type == 'l1'):
@@ -184,7 +189,7 @@ class Trainer(object):
                                   h_depth, w_depth, weights, it, out_render_path)
 
         loss_dict = self._total_loss(out if render_model else None, rendered_rgb, rgb_gt, rendered_depth, gt_depth, n_total,
-                                     ray_idx, depth_input, (h, w), kwargs, world)
+                                     ray_idx, depth_input, (h, w), kwargs, world, depth_affine)
         if self.optimizer_focal:
             loss_dict['focalx'] = fxfy[0] / camera_mat_gt[0, 0, 0]
             loss_dict['focaly'] = fxfy[1] / camera_mat_gt[0, 1, 1]
@@ -217,7 +222,8 @@ class Trainer(object):
         elif bool(torch.isnan(loss)):
             raise FloatingPointError('NaN loss')
 
-    def _total_loss(self, out, rgb, rgb_gt, depth_pred, depth_gt, n_total, ray_idx, depth_input, img_size, kwargs, world):
+    def _total_loss(self, out, rgb, rgb_gt, depth_pred, depth_gt, n_total, ray_idx, depth_input, img_size, kwargs, world,
+                    depth_affine=None):
         """rgb + depth heads (fused HIP kernel on the GPU) + per-image terms.  Under data parallelism each rank holds a
         shard of the rays: per-ray terms are divided by the GLOBAL ray / valid-depth counts and per-image terms by
         world_size, so that the SUM over ranks equals the single-process loss."""
@@ -226,7 +232,10 @@ class Trainer(object):
         if world > 1:
             h_img, w_img = img_size
             with torch.no_grad():   # global count of rays with a usable mono depth (finite, non-zero): no collective needed
-                if depth_input.is_cuda:
+                if depth_input.is_cuda and depth_affine is not None:
+                    d_all = camera.depth_gather_affine(depth_input, ray_idx, depth_affine[0], depth_affine[1], h_img, w_img,
+                                                       depth_affine[2])
+                elif depth_input.is_cuda:
                     d_all = camera.depth_gather(depth_input, ray_idx, h_img, w_img)          # one launch
                 else:
                     from model.network import nearest_source_index
@@ -234,6 +243,8 @@ class Trainer(object):
                     ys = nearest_source_index(torch.div(ray_idx, w_img, rounding_mode='floor'), h_img, hd)
                     xs = nearest_source_index(ray_idx % w_img, w_img, wd)
                     d_all = depth_input[0, 0][ys, xs]
+                    if depth_affine is not None:
+                        d_all = (d_all + depth_affine[1]) * depth_affine[0] if depth_affine[2] else d_all * depth_affine[0] + depth_affine[1]
                 m_total = (torch.isfinite(d_all) & (d_all != 0)).sum().float()   # stays on the device: no sync
         fused = (out is not None and rgb.is_cuda and self.loss.depth_loss_type == 'l1' and 'dist_dense' in out)
         if not fused and world == 1:

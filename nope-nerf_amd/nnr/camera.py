@@ -214,3 +214,34 @@ def ndc_rays(origin: torch.Tensor, ray: torch.Tensor, camera_mat: torch.Tensor, 
     """get_ndc_rays_fxfy (reference model/common.py:632-675) for (R,3) world rays in one launch each way; camera_mat (1,4,4) or
     (4,4) is a constant of the graph (the caller keeps the torch expression when the focal is being learned)."""
     return _NdcRays.apply(origin, ray, camera_mat.reshape(-1, 4, 4)[0], near)
+
+
+class _DepthGatherAffine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth_img, ray_idx, scale, shift, h, w, shift_first):
+        img, sc, sh = _f32(depth_img), _f32(scale).reshape(1), _f32(shift).reshape(1)
+        hd, wd = img.shape[-2:]
+        idx = ray_idx.detach().contiguous().long()
+        R = idx.shape[0]
+        out = torch.empty(1, R, 1, dtype=torch.float32, device=img.device)
+        L.check(L.load().nnr_depth_gather_affine_fwd(L.ptr(img), L.ptr(idx), L.ptr(sc), L.ptr(sh), int(bool(shift_first)), L.ptr(out), R,
+                                                    int(h), int(w), hd, wd, _st()), "nnr_depth_gather_affine_fwd")
+        ctx.save_for_backward(img, idx, sc, sh)
+        ctx.meta = (int(h), int(w), hd, wd, int(bool(shift_first)), tuple(scale.shape), tuple(shift.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        img, idx, sc, sh = ctx.saved_tensors
+        h, w, hd, wd, shift_first, s_shape, h_shape = ctx.meta
+        g_ss = torch.empty(2, dtype=torch.float32, device=img.device)
+        L.check(L.load().nnr_depth_gather_affine_bwd(L.ptr(_f32(g).view(-1)), L.ptr(img), L.ptr(idx), L.ptr(sc), L.ptr(sh), shift_first,
+                                                    L.ptr(g_ss), idx.shape[0], h, w, hd, wd, _st()), "nnr_depth_gather_affine_bwd")
+        return None, None, g_ss[0].reshape(s_shape), g_ss[1].reshape(h_shape), None, None, None
+
+
+def depth_gather_affine(depth_img, ray_idx, scale, shift, h: int, w: int, shift_first: bool = False) -> torch.Tensor:
+    """depth_gather of the distorted map (depth * scale + shift, or (depth + shift) * scale) without distorting the map:
+    (1,1,hd,wd) RAW mono depth + the frame's (1,) scale / shift -> (1,R,1); gradients reach scale and shift only."""
+    assert depth_img.shape[0] == 1 and depth_img.shape[1] == 1
+    return _DepthGatherAffine.apply(depth_img, ray_idx, scale, shift, h, w, shift_first)

@@ -238,3 +238,24 @@ def test_ndc_rays_match_the_torch_expression():
     ho, hd = camera.ndc_rays(c2, d, K, 1.0)
     ((ho * go).sum() + (hd * gd).sum()).backward()
     assert float((c2.grad - c1.grad).abs().max()) <= 1e-4 * max(1.0, float(c1.grad.abs().max()))
+
+
+@pytest.mark.parametrize("shift_first", [False, True])
+def test_depth_gather_affine_matches_distort_then_gather(shift_first):
+    """nnr_depth_gather_affine_* == distorting the whole map (training.py:240-245) and gathering (network.py:22-24)."""
+    from nnr import camera
+    g = torch.Generator().manual_seed(8)
+    h, w, hd, wd, R = 54, 96, 40, 72, 500
+    raw = (1 + 2 * torch.rand(1, 1, hd, wd, generator=g)).to(DEV)
+    idx = torch.randperm(h * w, generator=g)[:R].to(DEV)
+    up = torch.randn(1, R, 1, generator=g).to(DEV)
+    s1, t1 = torch.tensor([1.07], device=DEV, requires_grad=True), torch.tensor([-0.03], device=DEV, requires_grad=True)
+    full = (raw + t1) * s1 if shift_first else raw * s1 + t1
+    ref = camera.depth_gather(full, idx, h, w)
+    (ref * up).sum().backward()
+    s2, t2 = s1.detach().clone().requires_grad_(True), t1.detach().clone().requires_grad_(True)
+    got = camera.depth_gather_affine(raw, idx, s2, t2, h, w, shift_first)
+    (got * up).sum().backward()
+    assert torch.equal(got, ref)
+    for a, b in ((s2.grad, s1.grad), (t2.grad, t1.grad)):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
