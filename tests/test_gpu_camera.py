@@ -256,6 +256,6 @@ def test_depth_gather_affine_matches_distort_then_gather(shift_first):
     s2, t2 = s1.detach().clone().requires_grad_(True), t1.detach().clone().requires_grad_(True)
     got = camera.depth_gather_affine(raw, idx, s2, t2, h, w, shift_first)
     (got * up).sum().backward()
-    assert torch.equal(got, ref)
+    assert float((got - ref).abs().max()) <= 2.5e-7 * float(ref.abs().max())      # one ulp: ATen's device arithmetic may contract
     for a, b in ((s2.grad, s1.grad), (t2.grad, t1.grad)):
         assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
