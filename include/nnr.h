@@ -45,8 +45,9 @@ extern "C" {
                              * activations between layers and every reduction stay fp32.  The packed-weight buffer has its
                              * own size and layout in this mode (nnr_packed_floats), and so has a TRAINING workspace
                              * (nnr_workspace_floats): the hidden-activation planes 11..18, 20 and their gradient planes
-                             * 31..38, 40 hold bf16 elements -- the values the MFMAs consumed -- so nnr_ws_plane reports a
-                             * pitch of half the feature count for them; all other planes stay fp32. */
+                             * 31..38, 40 hold bf16 elements -- the values the MFMAs consumed, the two middle quads of every 16
+                             * features swapped -- so nnr_ws_plane reports a pitch of half the feature
+                             * count for them; all other planes stay fp32. */
 
 /* Problem description.  POD, passed by pointer, read on the host only. */
 typedef struct nnr_cfg {

@@ -170,7 +170,8 @@ struct WsLayout {
     bool train;
     bool bf16 = false;   // NNR_F_BF16 training: the operands of the weight-gradient products that the MFMAs consume as bf16 anyway
                          // -- hidden activations (P_XH1.., P_XG) and pre-activation gradients (P_DH1.., P_DG) -- are STORED as
-                         // bf16 (pitch below = floats per row = elements / 2); encodings, masks and the 4-wide planes stay fp32
+                         // bf16, the two middle quads of every 16 features swapped (stash_row in nnr_device.h; pitch below =
+                         // floats per row = elements / 2); encodings, masks and the 4-wide planes stay fp32
     NNR_HD int64_t plane(int p, int* pitch) const {
         int64_t o = 0;
         int w = 0;

@@ -244,15 +244,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     store_mask(mwA, 8, 0);
     if (TRAIN) {
         float* xg = stash_row<BF16>(a.ws_xg, ss, D / 2, 4 * half);
+        if constexpr (BF16) {   // bf16 plane (quads 1 and 2 of every 16 swapped): group g = registers 8g .. 8g+7 of this lane, 16 bytes
 #pragma unroll
-        for (int q = 0; q < HR / 4; ++q) {
-            if constexpr (BF16) {   // a bf16 plane: features 8q + 4h + {0..3} of this sample, 8 bytes
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                const bf16x4 v = {(__bf16)h[4 * q], (__bf16)h[4 * q + 1], (__bf16)h[4 * q + 2], (__bf16)h[4 * q + 3]};
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(xg) + 8 * q) = v;
-            } else {
+            for (int gq = 0; gq < HR / 8; ++gq)
+                *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(xg) + 16 * gq) = __builtin_bit_cast(f32x4, pack_row(h, gq));
+        } else {
+#pragma unroll
+            for (int q = 0; q < HR / 4; ++q)
                 *reinterpret_cast<f32x4*>(xg + 8 * q) = f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
-            }
         }
     }
     // rgb head: 3 per-lane dot products over the lane's half of g, halves combined by one shuffle, then sigmoid

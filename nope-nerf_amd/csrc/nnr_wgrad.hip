@@ -202,12 +202,26 @@ template <int MI, int NI, int BIAS>
 __device__ __forceinline__ void wgrad_job_bf16(const WgradJob& jb, const WgradArgs& a, int lane, int ji) {
     constexpr bool DB = MI != 1, XB = NI == 4 || MI == 1;        // operand planes stored as bf16 (see above)
     const int half = lane >> 5, m = lane & 31;
-    const int64_t dstride = 4ll * a.plane_pitch[jb.d_plane], xstride = 4ll * a.plane_pitch[jb.x_plane];   // bytes per sample row
     const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
-    const char* dptr = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane]) + (DB ? 2 : 4) * (jb.d_col0 + (dok ? MI * m : 0)) +
-                       (8 * half) * dstride;
-    const char* xptr = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane]) + (XB ? 2 : 4) * (jb.x_col0 + (xok ? NI * m : 0)) +
-                       (8 * half) * xstride;
+    // Address of the lane's W features of sample kk + 8 * half + u.  All planes are row-major; inside every 16-feature group of a
+    // bf16 plane the two middle quads are swapped (stash_row in nnr_device.h), so the lane's quad q sits where quad
+    // ((q & 1) << 1 | q >> 1) would.
+    struct Operand {
+        const char* base;
+        int64_t stride;     // bytes per sample row
+        __device__ __forceinline__ const char* at(int64_t kk, int u) const { return base + (kk + u) * stride; }
+    };
+    auto operand = [&](int plane, int col0, int W, bool ok, bool b16) {
+        const char* p = reinterpret_cast<const char*>(a.ws + a.plane_off[plane]);
+        int f0 = col0 + (ok ? W * m : 0);
+        const int64_t stride = 4ll * a.plane_pitch[plane];
+        if (b16) {
+            const int q = (f0 >> 2) & 3;
+            f0 += 4 * ((((q & 1) << 1) | (q >> 1)) - q);
+        }
+        return Operand{p + (b16 ? 2 : 4) * f0 + (8 * half) * stride, stride};
+    };
+    const Operand dop = operand(jb.d_plane, jb.d_col0, MI, dok, DB), xop = operand(jb.x_plane, jb.x_col0, NI, xok, XB);
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -227,8 +241,8 @@ __device__ __forceinline__ void wgrad_job_bf16(const WgradJob& jb, const WgradAr
     auto load_stage = [&](Stage& st, int64_t kk) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            st.d[u] = load_raw<MI, DB>(dptr + (kk + u) * dstride);
-            st.x[u] = load_raw<NI, XB>(xptr + (kk + u) * xstride);
+            st.d[u] = load_raw<MI, DB>(dop.at(kk, u));
+            st.x[u] = load_raw<NI, XB>(xop.at(kk, u));
         }
     };
     // consume one stage: regroup / convert, refill the stage's registers with the samples two stages ahead, multiply

@@ -148,17 +148,21 @@ def plan_jobs(cfg: L.Cfg, with_waves: bool = False):
 
 def workspace_plane(cfg: L.Cfg, ws: torch.Tensor, plane: int, n_rows: Optional[int] = None) -> torch.Tensor:
     """One workspace plane as (rows, width) -- used by the parity tests to localise a mismatch.  A view for the fp32 planes; the
-    planes a bf16 training workspace stores as bf16 (hidden activations 11..18, 20 and their gradients 31..38, 40: WsLayout in
-    nnr_layout.h) come back converted to fp32."""
+    planes a bf16 training workspace stores as bf16 (hidden activations 11..18, 20 and their gradients 31..38, 40:
+    WsLayout in nnr_layout.h) come back re-ordered and converted to fp32."""
     pitch = C.c_int32(0)
     off = L.load().nnr_ws_plane(C.byref(cfg), plane, C.byref(pitch))
     if off < 0:
         raise KeyError(plane)
     S = cfg.n_rays * cfg.n_samples
     rows = n_rows if n_rows is not None else S
-    v = ws[off: off + rows * pitch.value].view(rows, pitch.value)
     stored_bf16 = (cfg.flags & L.NNR_F_BF16) and (cfg.flags & L.NNR_F_TRAIN) and (11 <= plane <= 18 or plane == 20 or 31 <= plane <= 38 or plane == 40)
-    return v.view(torch.bfloat16).float() if stored_bf16 else v
+    if not stored_bf16:
+        return ws[off: off + rows * pitch.value].view(rows, pitch.value)
+    # bf16 plane: row-major with the two middle quads of every 16 features swapped (stash_row in nnr_device.h)
+    width = 2 * pitch.value
+    t = ws[off: off + rows * pitch.value].view(torch.bfloat16).view(rows, width // 16, 2, 2, 4)     # [row][group][half][half-group][4]
+    return t.permute(0, 1, 3, 2, 4).reshape(rows, width).float()
 
 
 # ----------------------------------------------------------------------------------------------------------------------
