@@ -19,12 +19,14 @@ __global__ __launch_bounds__(256) void merge_kernel(PackArgs a) {
     if (gid < L::Dh * D) {
         const int m = gid / D, k = gid - m * D;
         float acc = 0.f;
+#pragma unroll 16   // same fma chain, but 16 pairs of loads in flight: the loop is latency-bound (one wave per SIMD at best)
         for (int j = 0; j < D; ++j) acc = fmaf(Wg[m * ldg + j], Wf[j * D + k], acc);
         a.packed[L::merged_w_off + gid] = acc;
         a.packed[L::copy_wg_off + gid] = Wg[m * ldg + k];
     }
     if (gid < L::Dh) {
         float acc = a.b[10][gid];
+#pragma unroll 16
         for (int j = 0; j < D; ++j) acc = fmaf(Wg[gid * ldg + j], a.b[9][j], acc);
         a.packed[L::merged_b_off + gid] = acc;
     }

@@ -390,11 +390,13 @@ __global__ __launch_bounds__(256) void wgrad_unmerge_kernel(WgradArgs a) {
     if (gid < D * D) {                               // dWf[j][k] += sum_m Wg1[m][j] dW'[m][k]
         const int j = gid / D, k = gid - j * D;
         float acc = 0.f;
+#pragma unroll 16   // latency-bound dot products: keep 16 pairs of loads in flight (same fma chain)
         for (int m = 0; m < Dh; ++m) acc = fmaf(Wg1[m * D + j], dWm[m * D + k], acc);
         a.gw[9][gid] += acc;
     } else if (gid < D * D + Dh * D) {               // dWg[m][j] += sum_k dW'[m][k] Wf[j][k] + db'[m] bf[j]
         const int t = gid - D * D, m = t / D, j = t - m * D;
         float acc = dbm[m] * bf[j];
+#pragma unroll 16
         for (int k = 0; k < D; ++k) acc = fmaf(dWm[m * D + k], Wf[j * D + k], acc);
         a.gw[10][m * ldg + j] += acc;
     } else if (gid < D * D + Dh * D + D) {           // dbf[j] += sum_m Wg1[m][j] db'[m]
