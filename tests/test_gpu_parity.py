@@ -333,3 +333,31 @@ def test_bf16_mfma_mode_against_fp32_golden(name, capsys):
     with capsys.disabled():
         print("\nbf16 mode vs fp32 golden [%s]: rgb %.2e depth %.2e; gradients: worst relative L2 %.3f (%s), worst element / max %.3f (%s)"
               % (name, errs["rgb"], errs["depth_pred"], worst_l2[1], worst_l2[0], worst_max[1], worst_max[0]))
+
+
+def test_config4_eight_shards_of_4096_rays_equal_one_32768_ray_pass():
+    """BASELINE.json config 4 (8 ranks x 4096 rays of one image, Ballroom settings: uniform sampling, no dist_alpha, D=256, N=128):
+    the gradients of the eight shards sum to the gradients of a single 32 768-ray pass -- the data-parallel identity at the
+    full size (4.2 M samples, a 38 GB workspace) -- and a handful of its rays agree with the oracle."""
+    D, R, N, W = 256, 32768, 128, 8
+    params, o, d, lo, hi, jit = _synthetic(D, R, N, seed=11)
+    g = torch.Generator().manual_seed(6)
+    d_rgb, d_dist = torch.randn(R, 3, generator=g) / R, torch.randn(R, generator=g) / R
+    rgb, dist, _, full = _hip_render(params, o, d, lo, hi, jit, D, d_rgb, d_dist)
+    sums = None
+    per = R // W
+    for k in range(W):
+        sl = slice(k * per, (k + 1) * per)
+        r_k, dist_k, _, g_k = _hip_render(params, o[sl], d[sl], lo, hi, jit[sl], D, d_rgb[sl], d_dist[sl])
+        assert torch.equal(r_k, rgb[sl.start:sl.stop]) and torch.equal(dist_k, dist[sl.start:sl.stop])      # rays are independent
+        w_k = [x.clone() for x in g_k[3:]]
+        sums = w_k if sums is None else [a + b for a, b in zip(sums, w_k)]
+        assert torch.allclose(g_k[0], full[0][sl], atol=1e-6) and torch.allclose(g_k[1], full[1][sl], atol=1e-5)
+    for a, b in zip(sums, full[3:]):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) / scale <= 2e-5
+    sel = torch.arange(0, R, 4096)
+    with torch.no_grad():
+        orgb, odist, _ = trace_util.traced_render(dict(params), o[sel], d[sel], -d[sel], lo, hi, jit[sel], dist_alpha=False, white_bg=False)
+    assert float((rgb[sel.cuda()].cpu() - orgb).abs().max()) <= TOL
+    assert float((dist[sel.cuda()].cpu() - odist).abs().max()) <= TOL * 10
