@@ -3,7 +3,6 @@ hard-codes .cuda()).  The two heads that feed the fused backward are `get_rgb_fu
 divided by the number of rays, losses.py:27-32) and `get_depth_loss` (L1 sum / number of valid rays, :59-64); the rest
 are per-image auxiliary terms that stay in stock torch.
 """
-import numpy as np
 import torch
 from torch import nn
 from torch.nn import functional as F

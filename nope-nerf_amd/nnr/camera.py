@@ -3,7 +3,6 @@ one HIP launch each for SE(3) exp, 4x4 inverses, ray generation, the nearest-res
 heads -- the reference spends ~300 tiny ATen kernels (incl. four rocSOLVER LU inverses) per step on the same work."""
 from __future__ import annotations
 
-import ctypes as C
 
 import torch
 

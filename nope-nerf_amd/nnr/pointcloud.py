@@ -1,7 +1,6 @@
 """Point-cloud nearest neighbour + point-to-point error on the GPU: the HIP replacement of
 Loss.comp_closest_pts_idx_with_split / comp_point_point_error (reference model/losses.py:125-148).  CUDA tensors only:
 there is no CPU fallback here -- model/losses.py keeps the torch expression for CPU tensors."""
-import ctypes as C
 
 import torch
 

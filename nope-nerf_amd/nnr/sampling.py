@@ -7,7 +7,6 @@ returned indices AND the generator state afterwards are the ones torch.randperm 
 torch internals, so it is verified against torch.randperm itself on the first calls in every process (one host sync
 each); on any mismatch -- e.g. a torch release that changes its algorithm -- the module permanently falls back to
 torch.randperm."""
-import ctypes as C
 import math
 
 import torch

@@ -2,7 +2,6 @@
 model.Trainer (ray generation, masks, sharding, loss scaling, all-reduce) can be exercised without a GPU.
 Never imported by the product: tests monkeypatch `model.rendering.nnr.render_rays` with it."""
 import torch
-import torch.nn.functional as F
 
 import nerf_oracle as orc
 from nnr import LAYER_NAMES

@@ -1,6 +1,5 @@
 """GPU tests (-m gpu) of the camera front end / loss-head kernels (nnr_camera.hip) against plain PyTorch fp32 autograd
 of the same formulas, and of the whole Trainer.train_step (every fused op in the loop) against the reference golden."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

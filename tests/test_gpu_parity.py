@@ -3,7 +3,6 @@ against (a) the golden vectors minted from the real reference and (b) the CPU or
 Tolerance: 1e-4 max-abs for rgb / depth / gradients (gradients normalised by the golden tensor's max-abs when that
 exceeds 1) -- the fp32 bar of BASELINE.json; indices, masks and z-samples must agree to 1e-6."""
 import ctypes as C
-import os
 
 import numpy as np
 import pytest

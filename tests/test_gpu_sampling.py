@@ -4,7 +4,6 @@ smallest supported n; many generator states; and the duplicate-key path, which r
 kernel keys with forced duplicates together with what torch's own island re-shuffle makes of them."""
 import ctypes as C
 
-import numpy as np
 import pytest
 import torch
 
