@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
         for (int e = 0; e < 4; ++e)
             if (c0 + e < jb.x_valid && jb.wcol0 + c0 + e < jb.cols_real) dst[e] += sum[e];
     }
-    if (jb.bias && (blockIdx.x & 15) == 0 && threadIdx.x < 32 * jb.MI) {
+    if (jb.bias && (blockIdx.x & 15) == 0 && (int)threadIdx.x < 32 * jb.MI) {
         const int r = threadIdx.x;
         if (r < jb.d_valid && jb.row0 + r < jb.rows_real) {
             float sum = 0.f;
