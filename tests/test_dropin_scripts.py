@@ -70,3 +70,12 @@ def test_reference_train_and_eval_poses_run_on_our_packages(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     frames = os.listdir(os.path.join(out_dir, "extraction", "extracted_images", "bspline"))
     assert "video_out" in frames and len(frames) >= 3, frames
+    # the other two path options of vis/render.py: slerp + linear interpolation, and the NeRF-style spiral ("sprial" upstream)
+    for option in ("interp", "sprial"):
+        cfg["extract_images"]["traj_option"] = option
+        other = str(tmp_path / ("toy_%s.yaml" % option))
+        with open(other, "w") as fh:
+            yaml.safe_dump(cfg, fh)
+        r = _run(os.path.join("vis", "render.py"), other, {})
+        assert r.returncode == 0, option + r.stdout[-2000:] + r.stderr[-3000:]
+        assert "video_out" in os.listdir(os.path.join(out_dir, "extraction", "extracted_images", option))
