@@ -11,6 +11,7 @@ import pytest
 import yaml
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nope-nerf_amd"))
 REF = os.environ.get("NNR_REFERENCE", "/root/reference")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
@@ -79,3 +80,78 @@ def test_reference_train_and_eval_poses_run_on_our_packages(tmp_path):
         r = _run(os.path.join("vis", "render.py"), other, {})
         assert r.returncode == 0, option + r.stdout[-2000:] + r.stderr[-3000:]
         assert "video_out" in os.listdir(os.path.join(out_dir, "extraction", "extracted_images", option))
+
+
+def _base_cfg(data, out_dir):
+    return {
+        "model": {"hidden_dim": 128},
+        "dataloading": {"path": data, "scene": ["toy"], "n_workers": 0, "resize_factor": None, "sample_rate": 3, "spherify": False},
+        "rendering": {"num_points": 8},
+        "pose": {"learn_pose": True},
+        "training": {"out_dir": out_dir, "n_training_points": 16, "scheduling_start": 1, "scheduling_epoch": 1, "annealing_epochs": 1,
+                     "print_every": 4, "checkpoint_every": 4, "visualize_every": 1000, "vis_resolution": [6, 8], "pc_ratio": 2,
+                     "auto_scheduler": False},
+        "extract_images": {"resolution": [24, 32], "N_novel_imgs": 5},
+        "eval_pose": {"opt_pose_epoch": 5, "n_points": 16},
+    }
+
+
+@pytest.mark.parametrize("name,over", [
+    # the PSNR-plateau scheduler of the Tanks configs, network re-initialisation at the switch, per-view distortion logging
+    ("auto_reset", {"training": {"auto_scheduler": True, "scheduling_mode": "reset", "length_smooth": 1, "patient": 1,
+                                 "log_scale_shift_per_view": True}}),
+    # learnable focal length from the ground-truth focal, poses initialised from the (COLMAP-format) ground truth, SSIM term on
+    ("focal_gtpose_ssim", {"pose": {"learn_focal": True, "init_pose": True, "init_pose_type": "gt", "init_focal_type": "gt"},
+                           "training": {"with_ssim": True}}),
+    # LLFF-style rendering: NDC sampling, distance-based alpha, down-sized frames
+    ("llff", {"rendering": {"sample_option": "ndc", "dist_alpha": True, "depth_range": [0.0, 1.0]}, "dataloading": {"resize_factor": 2},
+              "extract_images": {"resolution": [12, 16]}}),
+])
+def test_reference_train_script_variants(tmp_path, name, over):
+    """Other branches of the reference's train.py / eval_poses.py against our packages (CPU stand-in)."""
+    import scene_writer
+    from dataloading.configloading import update_recursive
+    data = str(tmp_path / "data")
+    scene_writer.write_scene(data, scene="toy", frames=6, size=(24, 32), factor=2, seed=2)
+    out_dir = str(tmp_path / "out")
+    cfg = _base_cfg(data, out_dir)
+    update_recursive(cfg, over)
+    cfg_path = str(tmp_path / (name + ".yaml"))
+    with open(cfg_path, "w") as fh:
+        yaml.safe_dump(cfg, fh)
+    scalars = str(tmp_path / "scalars.json")
+    r = _run("train.py", cfg_path, {"DROPIN_SCALARS": scalars})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    tags = {t for t, _, _ in json.load(open(scalars))}
+    assert "train/psnr" in tags and "eval/ate_trans" in tags
+    if name == "focal_gtpose_ssim":
+        assert "train/focalx" in tags and "train/lr_focal" in tags and os.path.isfile(os.path.join(out_dir, "model_focal.pt"))
+    if name == "auto_reset":
+        assert any(t.startswith("train/scaleview") for t in tags)
+    r = _run(os.path.join("evaluation", "eval_poses.py"), cfg_path, {})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_reference_eval_script_pose_initialisations(tmp_path):
+    """evaluation/eval.py with every way it initialises the held-out poses (scale / ATE alignment of the ground-truth poses to the
+    learned trajectory, none) and with type_to_eval: train (no test-time optimisation)."""
+    import scene_writer
+    data = str(tmp_path / "data")
+    scene_writer.write_scene(data, scene="toy", frames=7, size=(24, 32), seed=3)
+    out_dir = str(tmp_path / "out")
+    cfg = _base_cfg(data, out_dir)
+    cfg_path = str(tmp_path / "base.yaml")
+    with open(cfg_path, "w") as fh:
+        yaml.safe_dump(cfg, fh)
+    r = _run("train.py", cfg_path, {})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for tag, eval_pose in (("scale", {"init_method": "scale"}), ("ate", {"init_method": "ate"}), ("none", {"init_method": "none"}),
+                           ("train", {"type_to_eval": "train"})):
+        cfg["eval_pose"] = dict(cfg["eval_pose"], **eval_pose)
+        path = str(tmp_path / (tag + ".yaml"))
+        with open(path, "w") as fh:
+            yaml.safe_dump(cfg, fh)
+        r = _run(os.path.join("evaluation", "eval.py"), path, {})
+        assert r.returncode == 0, tag + r.stdout[-2000:] + r.stderr[-3000:]
+        assert "Mean MSE" in r.stdout, tag
+        cfg["eval_pose"].pop("type_to_eval", None)
