@@ -94,11 +94,44 @@ def run(ref, name, cam, ref_idx, seed, blob):
     return weights
 
 
+def run_ssim(ref, name, cam, ref_idx, seed, blob):
+    """The same step with training.with_ssim: True (model/losses.py:150-157,222-252: 0.15 |diff| + 0.85 SSIM dissimilarity in the
+    surface re-projection term).  Same inputs and draws as case `name`; only the reference's outputs are recorded -- the SSIM
+    branch is plain torch on both sides and is not part of the oracle restatement."""
+    cfg = copy.deepcopy(gg.base_cfg(128))
+    cfg["training"].update(n_training_points=R, pc_weight=[1.0, 0.0], rgb_s_weight=[1.0, 0.0], vis_reprojection_every=10 ** 9,
+                           with_ssim=True)
+    cfg["rendering"]["num_points"] = N
+    inp = inputs(seed)
+    dev = torch.device("cpu")
+    torch.manual_seed(42)
+    net = ref.OfficialStaticNerf(cfg)
+    model = ref.get_model(ref.Renderer(net, cfg["rendering"], device=dev), cfg, device=dev)
+    pose, dist = ref.LearnPose(N_CAMS, True, True, cfg), ref.Learn_Distortion(N_CAMS, True, True, cfg)
+    with torch.no_grad():
+        pose.r.copy_(inp["pose_r"]); pose.t.copy_(inp["pose_t"])
+        dist.global_scales.copy_(inp["scales"]); dist.global_shifts.copy_(inp["shifts"])
+    sgd = lambda m: torch.optim.SGD(m.parameters(), lr=0.0)
+    tr = ref.Trainer(model, sgd(model), cfg["training"], device=dev, optimizer_pose=sgd(pose), pose_param_net=pose,
+                     optimizer_distortion=sgd(dist), distortion_net=dist)
+    data = {"img": inp["img"], "img.idx": cam, "img.dpt": inp["dpt"], "img.camera_mat": inp["K"],
+            "img.scale_mat": torch.eye(4).unsqueeze(0), "img.ref_imgs": inp["ref_img"], "img.ref_dpts": inp["ref_dpt"],
+            "img.ref_idxs": ref_idx}
+    torch.manual_seed(7)
+    ld = tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
+    for k in ("loss", "loss_pc", "loss_rgb_s", "loss_rgb", "loss_depth"):
+        blob[f"{name}_ssim.out.{k}"] = ld[k].detach().numpy()
+    for k, t in (("pose_r", pose.r), ("pose_t", pose.t), ("scales", dist.global_scales), ("shifts", dist.global_shifts)):
+        blob[f"{name}_ssim.g.{k}"] = (t.grad if t.grad is not None else torch.zeros_like(t)).numpy()
+    print(f"aux case {name} with SSIM: loss_rgb_s {float(ld['loss_rgb_s']):.6f} (plain: {float(blob[name + '.out.loss_rgb_s']):.6f})")
+
+
 def main():
     ref = gg.import_reference()
     torch.set_num_threads(8)
     blob = {}
     w = run(ref, "mid", 2, 3, 21, blob)          # ordinary frame: frame 1 = current, frame 2 = reference
+    run_ssim(ref, "mid", 2, 3, 21, blob)
     run(ref, "last", N_CAMS - 1, N_CAMS - 2, 22, blob)   # last camera: roles swapped, scale fixed to 1 (distortions.py:24-25)
     np.savez_compressed(os.path.join(gg.OUT, "aux_terms.npz"), **blob)
     base = np.load(os.path.join(gg.OUT, "weights_d128.npz"))   # same seed-42 D=128 network as the render cases

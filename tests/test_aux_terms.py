@@ -151,3 +151,37 @@ def test_fused_path_is_the_one_that_runs(monkeypatch):
             "img.ref_dpts": inp["ref_dpt"].to(dev), "img.ref_idxs": 3}
     tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
     assert calls == [1]
+
+
+def _ssim_step(dev, monkeypatch):
+    inp = _inp("mid")
+    cam, ref = int(GOLD["mid.cam"]), int(GOLD["mid.ref"])
+    tr, pose, dist = _trainer(inp, dev, with_ssim=True)
+    ray_idx, jitter = torch.from_numpy(GOLD["mid.ray_idx"]), torch.from_numpy(GOLD["mid.jitter"])
+    monkeypatch.setattr(torch, "randperm", lambda n, device=None, **kw: torch.cat([ray_idx, torch.zeros(n - R, dtype=torch.int64)]).to(device))
+    real_rand = torch.rand
+    monkeypatch.setattr(torch, "rand", lambda *s, device=None, **kw: jitter.to(device) if tuple(s) == (1, R, N) else real_rand(*s, device=device, **kw))
+    data = {"img": inp["img"].to(dev), "img.idx": cam, "img.dpt": inp["dpt"].to(dev), "img.camera_mat": inp["K"].to(dev),
+            "img.scale_mat": torch.eye(4).unsqueeze(0).to(dev), "img.ref_imgs": inp["ref_img"].to(dev),
+            "img.ref_dpts": inp["ref_dpt"].to(dev), "img.ref_idxs": ref}
+    ld = tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
+    for k in ("loss", "loss_pc", "loss_rgb_s", "loss_rgb", "loss_depth"):
+        np.testing.assert_allclose(float(ld[k].detach()), float(GOLD[f"mid_ssim.out.{k}"]), rtol=0, atol=1e-5, err_msg=k)
+    got = {"pose_r": pose.r.grad, "pose_t": pose.t.grad, "scales": dist.global_scales.grad, "shifts": dist.global_shifts.grad}
+    for k, g in got.items():
+        ref_g = GOLD[f"mid_ssim.g.{k}"]
+        g = g.cpu().numpy() if g is not None else np.zeros_like(ref_g)
+        assert float(np.abs(g - ref_g).max()) / max(1.0, float(np.abs(ref_g).max())) <= 1e-4, k
+
+
+def test_step_with_ssim_term_matches_reference_on_the_cpu_stand_in(monkeypatch):
+    """training.with_ssim: True (the surface re-projection term mixes in the 3x3 SSIM dissimilarity, losses.py:150-157,222-252)."""
+    import oracle_backend
+    from model import rendering
+    monkeypatch.setattr(rendering.nnr, "render_rays", oracle_backend.render_rays)
+    _ssim_step(torch.device("cpu"), monkeypatch)
+
+
+@pytest.mark.gpu
+def test_step_with_ssim_term_matches_reference_on_the_hip_kernels(monkeypatch):
+    _ssim_step(torch.device("cuda"), monkeypatch)
