@@ -379,11 +379,13 @@ __global__ __launch_bounds__(1024) void render_loss_kernel(LossArgs a) {
     const float m = mt >= 0.f ? mt : cnt;
     const float inv_r = 1.f / a.r_total, inv_m = m > 0.f ? 1.f / m : 0.f;
     if (threadIdx.x == 0) {
-        const float lrgb = s_rgb * inv_r, ldep = s_dep * inv_m;
-        a.out[0] = a.w_rgb * lrgb + a.w_depth * ldep;
+        // a term whose weight is 0 is not evaluated by the reference and reported as 0 (model/losses.py:164-171,190-193);
+        // l2_mean only if one of the two render terms is on
+        const float lrgb = a.w_rgb != 0.f ? s_rgb * inv_r : 0.f, ldep = a.w_depth != 0.f ? s_dep * inv_m : 0.f;
+        a.out[0] = (a.w_rgb != 0.f ? a.w_rgb * lrgb : 0.f) + (a.w_depth != 0.f ? a.w_depth * ldep : 0.f);
         a.out[1] = lrgb;
         a.out[2] = ldep;
-        a.out[3] = s_l2 / (3.f * a.r_total);
+        a.out[3] = (a.w_rgb != 0.f || a.w_depth != 0.f) ? s_l2 / (3.f * a.r_total) : 0.f;
         a.out[4] = cnt;
     }
     const float sign_eps = 0.f;

@@ -282,13 +282,14 @@ class Trainer(object):
                 full = self.loss.depth_loss_dpt(pred_all[valid_all], gt_all[valid_all])
                 invariant = full.detach() / world + (full - full.detach())
             diff = rgb - rgb_gt
-            lrgb = (diff.abs().sum() if kwargs['rgb_loss_type'] == 'l1' else (diff * diff).sum()) / float(n_total)
+            lrgb = (diff.abs().sum() if kwargs['rgb_loss_type'] == 'l1' else (diff * diff).sum()) / float(n_total) \
+                if w['rgb_weight'] != 0.0 else zero          # a term with weight 0 is reported as 0 (losses.py:164-171)
             if invariant is not None:
                 ldep = invariant
             else:
                 ldep = (depth_pred - depth_gt).abs().sum() / torch.clamp(torch.as_tensor(m_total, device=rgb.device), min=1.0) \
                     if w['depth_weight'] != 0.0 else zero
-            l2 = (diff * diff).sum() / float(3 * n_total)
+            l2 = (diff * diff).sum() / float(3 * n_total) if (w['rgb_weight'] != 0.0 or w['depth_weight'] != 0.0) else zero
             lmain = w['rgb_weight'] * lrgb + w['depth_weight'] * ldep
         loss_dict.update(loss_rgb=lrgb, loss_depth=ldep, l2_mean=l2, loss=lmain if aux is None else lmain + aux)
         self._check_nan(loss_dict['loss'])
