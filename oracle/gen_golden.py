@@ -76,6 +76,9 @@ CASES = {
                               rend=dict(white_background=True, normalise_ray=False), jitter=True),
     "zero_pose_d128": dict(hidden=128, R=32, N=64, h=60, w=80, hd=30, wd=40, rend={}, jitter=True, zero_pose=True),
     "tanks_d256_n192": dict(hidden=256, R=16, N=192, h=60, w=80, hd=30, wd=40, rend={}, jitter=True),
+    # the two remaining renderer switches: view direction replaced by ones (rendering.py:104-105), relu density (official_nerf.py:77-80)
+    "noraydir_relu_d128": dict(hidden=128, R=32, N=48, h=60, w=80, hd=30, wd=40, rend=dict(use_ray_dir=False), jitter=True,
+                               model=dict(occ_activation="relu")),
 }
 N_CAMS = 4
 SUBSAMPLE = 2048  # grads of the D=256 case are stored on a fixed stride to keep the fixture small
@@ -237,15 +240,20 @@ def trainer_crosscheck(ref, cfg):
     print("trainer cross-check: oracle train_step_scope == reference Trainer.train_step (aux losses off)")
 
 
-def main():
+def main(only=()):
+    """`python oracle/gen_golden.py [case ...]`: all cases + the trainer cross-check, or just the named cases (the fixtures of
+    the others stay byte-identical in git)."""
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
     torch.set_num_threads(8)
     worst = 0.0
     written = {}
     for name, c in CASES.items():
+        if only and name not in only:
+            continue
         cfg = base_cfg(c["hidden"])
         cfg["rendering"].update(c["rend"])
+        cfg["model"].update(c.get("model", {}))
         cfg["rendering"]["num_points"] = c["N"]
         inp = make_inputs(c)
         res, grads, weights = run_reference(ref, c, inp, cfg)
@@ -262,6 +270,7 @@ def main():
                 "cfg.ndc": int(cfg["rendering"]["sample_option"] == "ndc"),
                 "cfg.white": int(cfg["rendering"]["white_background"]),
                 "cfg.normalise_ray": int(cfg["rendering"]["normalise_ray"]),
+                "cfg.use_ray_dir": int(cfg["rendering"]["use_ray_dir"]), "cfg.occ_activation": cfg["model"]["occ_activation"],
                 "cfg.near": cfg["rendering"]["depth_range"][0], "cfg.far": cfg["rendering"]["depth_range"][1]}
         for k in ("K", "pose_r", "pose_t", "scales", "shifts", "depth_img", "img", "ray_idx"):
             blob["in." + k] = inp[k].numpy()
@@ -274,8 +283,13 @@ def main():
         blob["cfg.weights_file"] = wfile
         wpath = os.path.join(OUT, wfile)
         if wfile not in written:
-            np.savez_compressed(wpath, **{k: v.numpy() for k, v in weights.items()})
-            written[wfile] = {k: v.clone() for k, v in weights.items()}
+            if only and os.path.exists(wpath):   # partial regeneration: the shared weights file must already be the same network
+                old = np.load(wpath)
+                assert all(np.array_equal(old[k], v.numpy()) for k, v in weights.items() if k in old.files and "bias" not in k)
+                written[wfile] = {k: torch.from_numpy(old[k]) for k in old.files}
+            else:
+                np.savez_compressed(wpath, **{k: v.numpy() for k, v in weights.items()})
+                written[wfile] = {k: v.clone() for k, v in weights.items()}
         for k, v in weights.items():   # tensors that differ (white_background bias) ride along in the case file
             if not torch.equal(v, written[wfile][k]):
                 blob["w." + k] = v.numpy()
@@ -289,9 +303,10 @@ def main():
                 blob["g." + k] = g
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **blob)
         print(f"{name}: oracle == reference (max abs dev so far {worst:.2e}); wrote {name}.npz")
-    trainer_crosscheck(ref, base_cfg(128))
+    if not only:
+        trainer_crosscheck(ref, base_cfg(128))
     print("done; worst deviation oracle vs reference:", worst)
 
 
 if __name__ == "__main__":
-    main()
+    main(tuple(sys.argv[1:]))

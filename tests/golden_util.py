@@ -9,7 +9,7 @@ import nerf_oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GRAD_CASES = ["tanks_d128", "llff_ndc_d128", "uniform_distalpha_masked_d128", "white_nonorm_d128", "zero_pose_d128",
-              "tanks_d256_n192"]
+              "tanks_d256_n192", "noraydir_relu_d128"]
 EVAL_CASES = ["tanks_eval_d128", "masked_inf_eval_d128"]
 N_CAMS = 4
 SUBSAMPLE = 2048
@@ -33,8 +33,9 @@ def render_cfg(case):
         "sample_option": "ndc" if int(case["cfg.ndc"]) else "uniform",
         "depth_range": [float(case["cfg.near"]), float(case["cfg.far"])],
         "normalise_ray": bool(case["cfg.normalise_ray"]), "white_background": bool(case["cfg.white"]),
-        "use_ray_dir": True, "normal_loss": False, "outside_steps": 0, "n_max_network_queries": 64000,
-        "occ_activation": "softplus",
+        "use_ray_dir": bool(int(case["cfg.use_ray_dir"])) if "cfg.use_ray_dir" in case else True,
+        "normal_loss": False, "outside_steps": 0, "n_max_network_queries": 64000,
+        "occ_activation": str(case["cfg.occ_activation"]) if "cfg.occ_activation" in case else "softplus",
     }
 
 

@@ -21,7 +21,8 @@ def _trainer(case, n_rays):
     t = gu.tensors(case)
     rc = gu.render_cfg(case)
     cfg = make_cfg(int(case["cfg.hidden"]), **{k: rc[k] for k in ('num_points', 'dist_alpha', 'sample_option', 'depth_range',
-                                                                  'normalise_ray', 'white_background')})
+                                                                  'normalise_ray', 'white_background', 'use_ray_dir')})
+    cfg['model']['occ_activation'] = rc['occ_activation']
     tcfg = {'type': 'nope_nerf', 'n_training_points': n_rays, 'vis_geo': False, 'detach_gt_depth': False, 'pc_ratio': 4,
             'match_method': 'dense', 'shift_first': False, 'detach_ref_img': True, 'scale_pcs': True, 'detach_rgbs_scale': False,
             'vis_reprojection_every': 5000, 'nearest_limit': 0.01, 'annealing_epochs': 2000, 'rgb_weight': [1.0, 1.0],

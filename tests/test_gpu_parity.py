@@ -27,7 +27,8 @@ def build(case, device):
     from test_host_logic import make_cfg
     rc = gu.render_cfg(case)
     cfg = make_cfg(int(case["cfg.hidden"]), **{k: rc[k] for k in ('num_points', 'dist_alpha', 'sample_option', 'depth_range',
-                                                                  'normalise_ray', 'white_background')})
+                                                                  'normalise_ray', 'white_background', 'use_ray_dir')})
+    cfg['model']['occ_activation'] = rc['occ_activation']
     net = mdl.OfficialStaticNerf(cfg)
     net.load_state_dict(case["weights"])
     model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device=device), cfg, device=device)

@@ -121,7 +121,7 @@ def test_render_output_is_lazy_but_complete():
 
 
 @pytest.mark.parametrize("name", ["tanks_d128", "llff_ndc_d128", "uniform_distalpha_masked_d128", "white_nonorm_d128",
-                                  "zero_pose_d128"])
+                                  "zero_pose_d128", "noraydir_relu_d128"])
 def test_renderer_host_glue_against_reference_golden(name, monkeypatch):
     """model.Renderer / nope_nerf / LearnPose / Learn_Distortion with the kernels swapped for the CPU oracle must
     reproduce the reference's outputs and gradients: pins the O(R) host arithmetic (ray generation through the matrix
@@ -133,7 +133,8 @@ def test_renderer_host_glue_against_reference_golden(name, monkeypatch):
     t = gu.tensors(case)
     rc = gu.render_cfg(case)
     cfg = make_cfg(int(case["cfg.hidden"]), **{k: rc[k] for k in ('num_points', 'dist_alpha', 'sample_option', 'depth_range',
-                                                                  'normalise_ray', 'white_background')})
+                                                                  'normalise_ray', 'white_background', 'use_ray_dir')})
+    cfg['model']['occ_activation'] = rc['occ_activation']
     net = mdl.OfficialStaticNerf(cfg)
     net.load_state_dict(case["weights"])
     model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device='cpu'), cfg, device='cpu')
