@@ -155,3 +155,69 @@ def test_reference_eval_script_pose_initialisations(tmp_path):
         assert r.returncode == 0, tag + r.stdout[-2000:] + r.stderr[-3000:]
         assert "Mean MSE" in r.stdout, tag
         cfg["eval_pose"].pop("type_to_eval", None)
+
+
+def test_checkpoints_cross_load_between_reference_and_ours(tmp_path):
+    """A checkpoint written by the REFERENCE CheckpointIO (model + Adam state, poses, distortions) loads into our classes with
+    identical tensors, and one written by ours loads back into the reference's -- the migration path for existing runs."""
+    ref_dir, our_dir = str(tmp_path / "ref"), str(tmp_path / "ours")
+    os.makedirs(ref_dir), os.makedirs(our_dir)
+    writer = f'''
+import sys, torch
+sys.path.insert(0, {os.path.join(ROOT, "oracle")!r})
+import gen_golden as gg
+ref = gg.import_reference()
+cfg = gg.base_cfg(128)
+torch.manual_seed(5)
+net = ref.OfficialStaticNerf(cfg)
+model = ref.get_model(ref.Renderer(net, cfg["rendering"], device=torch.device("cpu")), cfg, device=torch.device("cpu"))
+pose, dist = ref.LearnPose(4, True, True, cfg), ref.Learn_Distortion(4, True, True, cfg)
+with torch.no_grad():
+    pose.r.normal_(); pose.t.normal_(); dist.global_scales.uniform_(0.5, 1.5); dist.global_shifts.normal_()
+opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+sum(p.sum() for p in model.parameters()).backward(); opt.step()
+mode = sys.argv[1]
+if mode == "save":
+    ref.CheckpointIO({ref_dir!r}, model=model, optimizer=opt).save("model.pt", epoch_it=7, it=123, loss_val_best=1.5)
+    ref.CheckpointIO({ref_dir!r}, model=pose).save("model_pose.pt", epoch_it=7, it=123)
+    ref.CheckpointIO({ref_dir!r}, model=dist).save("model_distortion.pt", epoch_it=7, it=123)
+    torch.save({{k: v for k, v in model.state_dict().items()}}, {os.path.join(ref_dir, "expect.pt")!r})
+else:
+    d = ref.CheckpointIO({our_dir!r}, model=model, optimizer=opt).load("model.pt")
+    want = torch.load({os.path.join(our_dir, "expect.pt")!r})
+    assert d["it"] == 321 and d["epoch_it"] == 9, d
+    assert all(torch.equal(v, want[k]) for k, v in model.state_dict().items())
+    ref.CheckpointIO({our_dir!r}, model=pose).load("model_pose.pt")
+    assert torch.equal(pose.r, want["__pose_r"])
+    print("reference loaded ours")
+'''
+    env = dict(os.environ, PYTHONPATH="")
+    r = subprocess.run([sys.executable, "-c", writer, "save"], cwd=REF, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import torch
+    import model as mdl
+    from test_host_logic import make_cfg
+    cfg = make_cfg(128)
+    net = mdl.OfficialStaticNerf(cfg)
+    model = mdl.get_model(mdl.Renderer(net, cfg["rendering"], device="cpu"), cfg, device="cpu")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    pose, dist = mdl.LearnPose(4, True, True, cfg), mdl.Learn_Distortion(4, True, True, cfg)
+    d = mdl.CheckpointIO(ref_dir, model=model, optimizer=opt).load("model.pt")
+    assert d["it"] == 123 and d["epoch_it"] == 7 and d["loss_val_best"] == 1.5
+    want = torch.load(os.path.join(ref_dir, "expect.pt"))
+    assert all(torch.equal(v, want[k]) for k, v in model.state_dict().items())
+    assert len(opt.state) == len(list(model.parameters()))                       # Adam moments came along
+    mdl.CheckpointIO(ref_dir, model=pose).load("model_pose.pt")
+    mdl.CheckpointIO(ref_dir, model=dist).load("model_distortion.pt")
+    assert float(pose.r.detach().abs().sum()) > 0 and float((dist.global_scales.detach() - 1).abs().sum()) > 0
+    # and back: ours -> reference
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.25)
+    mdl.CheckpointIO(our_dir, model=model, optimizer=opt).save("model.pt", epoch_it=9, it=321)
+    mdl.CheckpointIO(our_dir, model=pose).save("model_pose.pt", epoch_it=9, it=321)
+    expect = {k: v.clone() for k, v in model.state_dict().items()}
+    expect["__pose_r"] = pose.r.detach().clone()
+    torch.save(expect, os.path.join(our_dir, "expect.pt"))
+    r = subprocess.run([sys.executable, "-c", writer, "load"], cwd=REF, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "reference loaded ours" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
