@@ -81,6 +81,21 @@ def main():
         blob["extract.img"], blob["extract.depth"] = np.asarray(out3["img"]), np.asarray(out3["depth"])
         blob["extract.depth_npy"] = np.load(os.path.join(tmp, "x", "depth_out", "0.npy"))
         assert out3["geo"] is None
+        # Trainer.render_visdata (model/training.py:100-163): the periodic visualisation render of a training view
+        tcfg = dict(cfg["training"], vis_geo=False)
+        model = ref.get_model(renderer, cfg, device=dev)
+        pose = ref.LearnPose(3, True, True, cfg, init_c2w=c2ws)
+        sgd = lambda m: torch.optim.SGD(m.parameters(), lr=0.0)
+        tr = ref.Trainer(model, sgd(model), tcfg, device=dev, optimizer_pose=sgd(pose), pose_param_net=pose)
+        vis = os.path.join(tmp, "vis")
+        os.makedirs(vis)
+        dpt = 1 + 2 * torch.rand(1, 9, 12, generator=g)
+        blob["vis.dpt"] = dpt.numpy()
+        vdata = {"img": img, "img.dpt": dpt, "img.idx": 2, "img.camera_mat": K, "img.scale_mat": torch.eye(4).unsqueeze(0)}
+        ret = tr.render_visdata(vdata, (6, 8), 100, vis)
+        blob["vis.ret"] = np.asarray(ret)
+        blob["vis.png.img"] = np.asarray(Image.open(os.path.join(vis, "0002_img.png")))
+        blob["vis.png.depth"] = np.asarray(Image.open(os.path.join(vis, "0002_depth.png")))
     print({k: float(blob["eval." + k]) for k in ("mse", "psnr", "ssim")}, "valid depths", blob["eval.depth_gt"].shape)
     out_path = os.path.join(gg.OUT, "eval_images.npz")
     np.savez_compressed(out_path, **blob)

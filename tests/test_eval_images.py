@@ -78,3 +78,27 @@ def test_extract_images_matches_the_reference(dev, monkeypatch, tmp_path):
     out = ex.generate_images(cam, str(tmp_path), torch.from_numpy(GOLD["c2ws"]).to(d), None, 0, False)
     assert out["geo"] is None and _u8_close(out["img"], GOLD["extract.img"]) and _u8_close(out["depth"], GOLD["extract.depth"])
     np.testing.assert_allclose(np.load(os.path.join(str(tmp_path), "depth_out", "0.npy")), GOLD["extract.depth_npy"], rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("dev", _devices())
+def test_render_visdata_matches_the_reference(dev, monkeypatch, tmp_path):
+    """Trainer.render_visdata (reference model/training.py:100-163): returned frame and the two PNGs."""
+    import model as mdl
+    renderer, cfg = _renderer(dev, monkeypatch)
+    d = torch.device(dev)
+    model = mdl.get_model(renderer, cfg, device=d)
+    pose = mdl.LearnPose(3, True, True, cfg, init_c2w=torch.from_numpy(GOLD["c2ws"])).to(d)
+    tcfg = {'type': 'nope_nerf', 'n_training_points': 16, 'vis_geo': False, 'detach_gt_depth': False, 'pc_ratio': 4, 'match_method': 'dense',
+            'shift_first': False, 'detach_ref_img': True, 'scale_pcs': True, 'detach_rgbs_scale': False, 'vis_reprojection_every': 5000,
+            'nearest_limit': 0.01, 'annealing_epochs': 2000, 'rgb_weight': [1.0, 1.0], 'depth_weight': [0.04, 0.0], 'pc_weight': [0.0, 0.0],
+            'rgb_s_weight': [0.0, 0.0], 'depth_consistency_weight': [0.0, 0.0], 'weight_dist_2nd_loss': [0.0, 0.0],
+            'weight_dist_1st_loss': [0.0, 0.0], 'depth_loss_type': 'l1', 'with_ssim': False, 'with_auto_mask': False}
+    sgd = lambda m: torch.optim.SGD(m.parameters(), lr=0.0)
+    tr = mdl.Trainer(model, sgd(model), tcfg, device=d, optimizer_pose=sgd(pose), pose_param_net=pose)
+    data = {"img": torch.from_numpy(GOLD["img"]), "img.dpt": torch.from_numpy(GOLD["vis.dpt"]), "img.idx": 2,
+            "img.camera_mat": torch.from_numpy(GOLD["K"]), "img.scale_mat": torch.eye(4).unsqueeze(0)}
+    ret = tr.render_visdata(data, (6, 8), 100, str(tmp_path))
+    assert ret.dtype == np.uint8 and ret.shape == GOLD["vis.ret"].shape and _u8_close(ret, GOLD["vis.ret"])
+    for name, key in (("0002_img.png", "vis.png.img"), ("0002_depth.png", "vis.png.depth")):
+        png = np.asarray(Image.open(os.path.join(str(tmp_path), name)))
+        assert png.shape == GOLD[key].shape and _u8_close(png, GOLD[key]), name
