@@ -145,7 +145,7 @@ def run(path, scene, style="tanks", epochs=100, seed=42, log_every=10, device=No
             it += 1
             losses = trainer.train_step(batch, it, epoch, 10 ** 6, None)
             l2.append(losses["l2_mean"])
-        mse = float(torch.stack(l2).mean())                      # the epoch's only device->host sync
+        mse = float(torch.stack(l2).detach().mean())             # the epoch's only device->host sync
         if epoch > 0:                                            # epoch 0 pays the lazy initialisations
             t_loop += time.perf_counter() - t0
             steps_timed += len(l2)
