@@ -125,6 +125,7 @@ def run(path, scene, style="tanks", epochs=100, seed=42, log_every=10, device=No
     """-> dict with the per-epoch PSNR / pose-error curve and the loop throughput (+ novel-view scores with eval_epochs > 0)."""
     import dataloading as dl
     from model.common import mse2psnr
+    from nnr import parallel
     device = torch.device(device or "cuda")
     sync = torch.cuda.synchronize if device.type == "cuda" else (lambda: None)
     np.random.seed(seed)
@@ -151,7 +152,8 @@ def run(path, scene, style="tanks", epochs=100, seed=42, log_every=10, device=No
             steps_timed += len(l2)
         if epoch % log_every == 0 or epoch == epochs - 1:
             curve.append(dict(epoch=epoch, psnr=float(mse2psnr(mse)), **pose_errors(pose, gt, n_views)))
-            print(json.dumps(curve[-1]), flush=True)
+            if parallel.rank() == 0:
+                print(json.dumps(curve[-1]), flush=True)
     n_rays = cfg["training"]["n_training_points"]
     novel = None
     if eval_epochs > 0:
