@@ -248,3 +248,24 @@ def test_encode_position_matches_the_oracle_encoding():
     for levels in (10, 4):
         assert torch.equal(encode_position(x, levels, True), orc.posenc(x, levels))
     assert encode_position(x, 3, False).shape == (6, 4, 18)
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The bench.py line committed with the round's profiles carries every field the driver / judge read (task contract):
+    metric block, `roofline` of the dominant kernel with PMC traffic, `cpu_baseline` of the oracle port."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.loads(open(os.path.join(root, "profiles", "r01", "h_round_end_bench.json.txt")).read())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["metric"] == "training rays/sec" and line["unit"] == "rays/s" and line["n_gpus"] == 1 and line["higher_is_better"] is True
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "f32" and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - 1024 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3
+    assert isinstance(r["traffic"], int) and r["traffic"] > 1e9            # HBM bytes per launch from the PMC passes
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "rays/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
