@@ -20,6 +20,10 @@ from . import lib as L
 def _require_gpu(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError("nnr: the render path runs only on an AMD GPU (HIP); got a CPU tensor and there is no CPU fallback")
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        # the kernels are launched on the current device's current stream (one process per GPU: torch.cuda.set_device(local_rank))
+        raise RuntimeError("nnr: tensors live on cuda:%d but the current device is cuda:%d; call torch.cuda.set_device first"
+                           % (t.device.index, torch.cuda.current_device()))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
