@@ -269,3 +269,24 @@ def test_committed_bench_line_follows_the_contract():
     assert isinstance(r["traffic"], int) and r["traffic"] > 1e9            # HBM bytes per launch from the PMC passes
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "rays/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_ctypes_signatures_have_the_arity_of_the_header():
+    """Every prototype of include/nnr.h against the argtypes the binding declares: a count mismatch would corrupt the call."""
+    import os
+    import re
+    from nnr import lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "nnr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = dict(re.findall(r"\b(?:int|size_t|int64_t|const char\*)\s+(nnr_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S))
+    assert set(protos) == set(L.EXPORTS), set(protos) ^ set(L.EXPORTS)
+    lib = L.load()
+    checked = 0
+    for name, params in protos.items():
+        n = 0 if params.strip() in ("", "void") else params.count(",") + 1
+        argtypes = getattr(lib, name).argtypes
+        if argtypes is not None:
+            assert len(argtypes) == n, (name, len(argtypes), n)
+            checked += 1
+    assert checked >= 30
