@@ -2,27 +2,37 @@
 """bench.py -- training rays/s of the NoPe-NeRF render hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1 starts itself: without WORLD_SIZE in the environment the script re-executes under `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU, RCCL); launched by torchrun it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
 
 One *step* = one `model.Trainer.train_step` over one synthetic image batch resident in HBM: pose / distortion forward,
 random pixel pick, ray generation, stratified sampling, fused MLP forward, compositing, rgb-L1 + depth-L1 loss heads,
 full backward to the MLP / pose / distortion gradients, (N>1: one flat RCCL all-reduce), and the three Adam steps.
 The per-image auxiliary losses (point-cloud NN, surface reprojection) are SURVEY.md section 8(f) "next" rows and are
-switched off (their weights anneal to 0 in the reference too).
+switched off in the headline (their weights anneal to 0 in the reference too); `--aux` turns them on.
 
-Workload = BASELINE.json configs[1]: 1024 rays x (64+128) samples per GPU, 8-layer-256 MLP, pose + distortion learnable,
-fp32.  The reference has no coarse/fine resampling (SURVEY.md header), so "64 coarse + 128 fine" is pinned as 192
-stratified samples per ray in a single pass.  Weak scaling: every rank renders its own 1024-ray shard of a
-(1024*N)-ray step.
+Headline workload = BASELINE.json configs[1]: 1024 rays x (64+128) samples per GPU, 8-layer-256 MLP, pose + distortion
+learnable, fp32.  The reference has no coarse/fine resampling (SURVEY.md header), so "64 coarse + 128 fine" is pinned as 192
+stratified samples per ray in a single pass.  Weak scaling: every rank renders its own shard of a (rays_per_gpu * N)-ray step.
 
-The JSON line carries `roofline` (dominant fused-MLP kernel timed with HIP events on the launch stream; algorithmic
-FLOPs = 1 186 816 per sample per pass) and `cpu_baseline` (the CPU oracle -- a port of the
-reference's PyTorch path -- timed on this host's cores on a bounded sample of the same workload).
+The ONE JSON line carries
+  * `roofline`      -- the dominant fused-MLP kernel timed with HIP events on the launch stream; algorithmic FLOPs =
+                       1 186 816 per sample per pass (BASELINE.md section 2);
+  * `cpu_baseline`  -- the CPU oracle (a port of the reference's PyTorch path) timed on this host's cores on a bounded
+                       sample of the same workload (2 warm-ups + 5 timed steps);
+  * `configs`       -- (N = 1 only) the other BASELINE.json configurations measured in the same run: `bf16_4096x128`
+                       (configs[2]: bf16 MFMA products, fp32 accumulate), `fp32_1024x128` (the reference's stock default
+                       N = 128) and `cpu_32x64_d128` (configs[0]: the reference's own CPU-runnable case, full step with the
+                       per-image losses on, timed on the host through the oracle).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,19 +43,20 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-R_PER_GPU, N_SAMPLES, HIDDEN = 1024, 192, 256
+R_PER_GPU, N_SAMPLES, HIDDEN = 1024, 192, 256     # BASELINE configs[1]
 IMG_H, IMG_W, N_CAMS = 540, 960, 16
-FLOP_PER_SAMPLE_PASS = 2 * 593408            # forward == dgrad == wgrad, BASELINE.md section 2
+MACS_PER_SAMPLE = {256: 593408, 128: 157440}   # sum of in x out over the 12 nn.Linear
+FLOP_PER_SAMPLE_PASS = 2 * MACS_PER_SAMPLE[256]   # forward == dgrad == wgrad
 PEAK_FP32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0               # dense bf16 MFMA (not the 2:1-sparsity headline figure)
 PEAK_HBM_GBS = 8000.0                        # HBM3E
 
 
-def full_cfg(rays_total, aux=False, bf16=False):
+def full_cfg(rays_total, aux=False, bf16=False, n_samples=None, hidden=None):
     cfg = {
-        'model': {'hidden_dim': HIDDEN, 'pos_enc_levels': 10, 'dir_enc_levels': 4, 'occ_activation': 'softplus'},
+        'model': {'hidden_dim': hidden or HIDDEN, 'pos_enc_levels': 10, 'dir_enc_levels': 4, 'occ_activation': 'softplus'},
         'rendering': {'type': 'nope_nerf', 'n_max_network_queries': 64000, 'white_background': False, 'radius': 4.0,
-                      'num_points': N_SAMPLES, 'depth_range': [0.01, 10], 'dist_alpha': False, 'use_ray_dir': True,
+                      'num_points': n_samples or N_SAMPLES, 'depth_range': [0.01, 10], 'dist_alpha': False, 'use_ray_dir': True,
                       'normalise_ray': True, 'normal_loss': False, 'sample_option': 'uniform', 'outside_steps': 0},
         'depth': {'type': 'None'},
         'distortion': {'fix_scaleN': True},
@@ -58,7 +69,7 @@ def full_cfg(rays_total, aux=False, bf16=False):
             'depth_loss_type': 'l1', 'with_ssim': False, 'with_auto_mask': False,
         },
     }
-    if bf16:  # BASELINE configs[2] arithmetic: bf16 MFMA products, fp32 accumulation (not the headline metric)
+    if bf16:  # BASELINE configs[2] arithmetic: bf16 MFMA products, fp32 accumulation
         cfg['rendering']['mfma_dtype'] = 'bf16'
     if aux:   # configs/default.yaml:99-100 -- the first training phase: point-cloud + surface-reprojection losses on
         cfg['training']['pc_weight'] = [1.0, 0.0]
@@ -66,26 +77,27 @@ def full_cfg(rays_total, aux=False, bf16=False):
     return cfg
 
 
-def synthetic_batch(device, seed=42):
+def synthetic_batch(device, seed=42, depth_hw=None):
     g = torch.Generator().manual_seed(seed)
     f = 0.7 * IMG_W
     K = torch.diag(torch.tensor([2 * f / IMG_W, -2 * f / IMG_H, -1.0, 1.0])).unsqueeze(0)
+    dh, dw = depth_hw or (IMG_H, IMG_W)
     return {
         'img': torch.rand(1, 3, IMG_H, IMG_W, generator=g).to(device),
         'img.idx': 3,
-        'img.dpt': (1 + 2 * torch.rand(1, IMG_H, IMG_W, generator=g)).to(device),
+        'img.dpt': (1 + 2 * torch.rand(1, dh, dw, generator=g)).to(device),
         'img.camera_mat': K.to(device),
         'img.scale_mat': torch.eye(4).unsqueeze(0).to(device),
         # the neighbouring frame the per-image losses compare against (dataloading: ref_imgs / ref_dpts / ref_idxs)
         'img.ref_imgs': torch.rand(1, 3, IMG_H, IMG_W, generator=g).to(device),
-        'img.ref_dpts': (1 + 2 * torch.rand(1, IMG_H, IMG_W, generator=g)).to(device),
+        'img.ref_dpts': (1 + 2 * torch.rand(1, dh, dw, generator=g)).to(device),
         'img.ref_idxs': 4,
     }
 
 
-def build_trainer(device, world, aux=False, bf16=False):
+def build_trainer(device, world, aux=False, bf16=False, rays_per_gpu=None, n_samples=None, hidden=None):
     import model as mdl
-    cfg = full_cfg(R_PER_GPU * world, aux, bf16)
+    cfg = full_cfg((rays_per_gpu or R_PER_GPU) * world, aux, bf16, n_samples, hidden)
     torch.manual_seed(42)
     net = mdl.OfficialStaticNerf(cfg)
     model = mdl.get_model(mdl.Renderer(net, cfg['rendering'], device=device), cfg, device=device)
@@ -105,29 +117,42 @@ def build_trainer(device, world, aux=False, bf16=False):
     return trainer, net
 
 
-def _hbm_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01/hbm_traffic.json: rocprofv3 --pmc
-    FETCH_SIZE and --pmc WRITE_SIZE, separate runs of tools/profile_kernels.py at this very shape).  Counters cannot be
-    collected from inside this process; None if the summary is not there."""
-    path = os.path.join(ROOT, 'profiles', 'r01', 'hbm_traffic.json')
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        table = json.load(f)['kernels']
-    key = {'mlp_fwd': 'mlp_fwd_kernel<256, true, false>', 'mlp_dgrad': 'mlp_dgrad_kernel<256, false>', 'mlp_wgrad': 'wgrad_kernel<false>'}[kernel]
-    for name, v in table.items():
-        if key in name:
-            return int(v['fetch_bytes'] + v['write_bytes'])
-    return None
+_TRAFFIC_FILES = ('profiles/r02/hbm_traffic.json', 'profiles/r01/hbm_traffic.json')
+_KERNEL_KEYS = {
+    False: {'mlp_fwd': 'mlp_fwd_kernel<256, true, false>', 'mlp_dgrad': 'mlp_dgrad_kernel<256, false>', 'mlp_wgrad': 'wgrad_kernel<false>'},
+    True: {'mlp_fwd': 'mlp_fwd_kernel<256, true, true>', 'mlp_dgrad': 'mlp_dgrad_kernel<256, true>', 'mlp_wgrad': 'wgrad'},
+}
 
 
-def kernel_roofline(net, device, reps=5, bf16=False):
-    """Time the three fused-MLP kernels of one 1024x192 step individually with HIP events on the launch stream.
-    bf16=True (bench.py --bf16, not the headline): the bf16-product kernels, whose bound is HBM, not the matrix pipe."""
+def _hbm_traffic(kernel, bf16=False, shape=None):
+    """(HBM bytes per launch of `kernel`, where the number comes from).  PMC counters cannot be collected from inside this process:
+    the figure is read from the committed summary of separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of
+    tools/profile_kernels.py at the very shape named in the file (FETCH_SIZE doubled per MI355X_MICROARCH.md).  (None, None) if no
+    summary holds this kernel at this shape."""
+    for rel in _TRAFFIC_FILES:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            table = json.load(f)
+        if shape is not None and tuple(table.get('shape', (1024, 192))) != tuple(shape):
+            continue
+        if bool(table.get('bf16', False)) != bool(bf16):
+            continue
+        key = _KERNEL_KEYS[bool(bf16)][kernel]
+        for name, v in table['kernels'].items():
+            if key in name:
+                return int(v['fetch_bytes'] + v['write_bytes']), rel + ' (offline PMC passes, not measured in this run)'
+    return None, None
+
+
+def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None):
+    """Time the three fused-MLP kernels of one step individually with HIP events on the launch stream.
+    bf16=True: the bf16-product kernels, whose bound is HBM, not the matrix pipe."""
     from nnr import lib as L
     from nnr import ops
     lib = L.load()
-    R, N, D = R_PER_GPU, N_SAMPLES, HIDDEN
+    R, N, D = rays or R_PER_GPU, n_samples or N_SAMPLES, net.hidden_dim
     cfg = L.make_cfg(R, N, D, train=True, bf16=bf16)
     g = torch.Generator().manual_seed(1)
     d = torch.randn(R, 3, generator=g)
@@ -159,8 +184,9 @@ def kernel_roofline(net, device, reps=5, bf16=False):
     }
     cfg_inf = L.make_cfg(R, N, D, bf16=bf16)      # forward-only variant (eval / visualisation): no stash
     ws_inf = torch.empty(lib.nnr_workspace_floats(C.byref(cfg_inf)), device=device)
+    packed_inf = ops._packed_for(cfg_inf, w, b)
     stages['mlp_fwd_infer'] = lambda: lib.nnr_mlp_fwd(C.byref(cfg_inf), L.ptr(o), L.ptr(d), L.ptr(view), L.ptr(lo), L.ptr(hi),
-                                                      L.ptr(jit), L.ptr(packed), L.ptr(ws_inf), st)
+                                                      L.ptr(jit), L.ptr(packed_inf), L.ptr(ws_inf), st)
     times = {}
     for name, fn in stages.items():
         L.check(fn(), name)            # warm-up + makes the workspace valid for the next stage
@@ -172,45 +198,67 @@ def kernel_roofline(net, device, reps=5, bf16=False):
         e1.record()
         torch.cuda.synchronize()
         times[name] = e0.elapsed_time(e1) / reps   # ms per launch
-    flops = FLOP_PER_SAMPLE_PASS * R * N
+    flops = 2 * MACS_PER_SAMPLE[D] * R * N
     per = {k: {'ms': round(v, 4), 'tflops': round(flops / (v * 1e-3) / 1e12, 2) if k.startswith('mlp_') else None}
            for k, v in times.items()}
     dom = max(('mlp_fwd', 'mlp_dgrad', 'mlp_wgrad'), key=lambda k: times[k])
     achieved = flops / (times[dom] * 1e-3) / 1e12
     mlp_ms = times['mlp_fwd'] + times['mlp_dgrad'] + times['mlp_wgrad']
+    three = {'ms': round(mlp_ms, 4), 'tflops': round(3 * flops / (mlp_ms * 1e-3) / 1e12, 2)}
     if bf16:
-        # Algorithmic HBM bytes per sample of the bf16-mode kernels (DESIGN.md section 7): hidden activations and their
+        # Algorithmic HBM bytes per sample of the bf16-mode kernels (DESIGN.md section 4): hidden activations and their
         # gradients are bf16 planes (8 x D + D/2 elements each), encodings (64 + 32) and the 4-wide planes fp32, masks 1 bit
         # per activation.  fwd writes the stash; dgrad reads masks + dout4 + encodings and writes the gradient planes;
         # wgrad reads activations + gradients + encodings + dout4 once.
-        act = (8 * D + D // 2) * 2
-        enc, masks, four = (64 + 32) * 4, 9 * 2 * (D // 64) * 4, 16
-        byts = {'mlp_fwd': act + enc + masks + four + 4, 'mlp_dgrad': act + masks + four + enc + 2 * four,
-                'mlp_wgrad': 2 * act + enc + four}
+        byts = bf16_bytes_per_sample(D)
         gbs = {k: byts[k] * R * N / (times[k] * 1e-3) / 1e9 for k in byts}
         dom = max(byts, key=lambda k: times[k])
         for k in byts:
             per[k]['gbytes_per_s'] = round(gbs[k], 1)
+        traffic, src = _hbm_traffic(dom, True, (R, N))
+        three['frac_of_bf16_mfma_peak'] = round(three['tflops'] / PEAK_BF16_MFMA_TFLOPS, 4)
+        three['gbytes_per_s'] = round(sum(byts.values()) * R * N / (mlp_ms * 1e-3) / 1e9, 1)
+        three['frac_of_hbm_peak'] = round(three['gbytes_per_s'] / PEAK_HBM_GBS, 4)
         return {'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs[dom], 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                'frac': round(gbs[dom] / PEAK_HBM_GBS, 4), 'traffic': None, 'bytes_per_launch': byts[dom] * R * N, 'kernels': per,
-                'fused_mlp_all_three': {'ms': round(mlp_ms, 4), 'tflops': round(3 * flops / (mlp_ms * 1e-3) / 1e12, 2),
-                                        'frac_of_bf16_mfma_peak': round(3 * flops / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}}
+                'frac': round(gbs[dom] / PEAK_HBM_GBS, 4), 'traffic': traffic, 'traffic_source': src,
+                'bytes_per_launch': byts[dom] * R * N, 'kernels': per, 'fused_mlp_all_three': three}
+    traffic, src = _hbm_traffic(dom, False, (R, N))
+    three['frac'] = round(three['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4)
     return {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': _hbm_traffic(dom),
-        'flop_per_launch': flops, 'kernels': per,
-        'fused_mlp_all_three': {'ms': round(mlp_ms, 4), 'tflops': round(3 * flops / (mlp_ms * 1e-3) / 1e12, 2),
-                                'frac': round(3 * flops / (mlp_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+        'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': src,
+        'flop_per_launch': flops, 'kernels': per, 'fused_mlp_all_three': three,
     }
 
 
-def cpu_baseline(sample_rays=192, steps=3):
-    """The CPU oracle (oracle/nerf_oracle.py, a port of the reference's PyTorch path) on this host's cores, on a bounded
-    sample of the same workload: `sample_rays` rays x 192 samples, D=256, forward + loss heads + backward."""
+def bf16_bytes_per_sample(D):
+    act = (8 * D + D // 2) * 2
+    enc, masks, four = (64 + 32) * 4, 9 * 2 * (D // 64) * 4, 16
+    return {'mlp_fwd': act + enc + masks + four + 4, 'mlp_dgrad': act + masks + four + enc + 2 * four, 'mlp_wgrad': 2 * act + enc + four}
+
+
+def _host_cpu():
+    model = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return os.cpu_count() or 1, model
+
+
+def cpu_baseline(sample_rays=192, warmup=2, steps=5):
+    """The CPU oracle (oracle/nerf_oracle.py, a port of the reference's PyTorch path: the reference itself cannot travel to the GPU
+    box) on this host's cores, on a bounded sample of the headline workload: `sample_rays` rays x 192 samples, D=256, forward +
+    loss heads + backward; median of `steps` timed steps after `warmup` untimed ones."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as orc
-    cores = min(os.cpu_count() or 1, 32)   # the GEMMs here are (12k x 256) x (256 x 256): more threads only add sync cost
-    torch.set_num_threads(cores)
+    host_cores, cpu_model = _host_cpu()
+    threads = min(host_cores, 32)   # the GEMMs here are (37k x 256) x (256 x 256): more threads only add sync cost
+    torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
     params = {k: v.requires_grad_(True) for k, v in orc.init_params(HIDDEN, 1).items()}
     pose_r = (0.01 * torch.randn(N_CAMS, 3, generator=g)).requires_grad_(True)
@@ -224,7 +272,7 @@ def cpu_baseline(sample_rays=192, steps=3):
     rcfg = full_cfg(sample_rays)['rendering']
     rcfg['occ_activation'] = 'softplus'
     ts = []
-    for i in range(steps + 1):
+    for i in range(warmup + steps):
         ray_idx = torch.randperm(IMG_H * IMG_W, generator=g)[:sample_rays]
         jitter = torch.rand(1, sample_rays, N_SAMPLES, generator=g)
         t0 = time.perf_counter()
@@ -232,10 +280,127 @@ def cpu_baseline(sample_rays=192, steps=3):
                                        jitter, rcfg)
         loss.backward()
         ts.append(time.perf_counter() - t0)
-    med = float(np.median(ts[1:]))
-    return {'value': round(sample_rays / med, 2), 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{sample_rays} rays x {N_SAMPLES} samples, D={HIDDEN}, fwd+loss+bwd, median of {steps} steps after 1 warm-up, '
-                      f'torch {torch.__version__} CPU, {cores} threads'}
+    med = float(np.median(ts[warmup:]))
+    return {'value': round(sample_rays / med, 2), 'unit': 'rays/s', 'cores': threads, 'host_cores': host_cores, 'threads': threads,
+            'cpu': cpu_model, 'kind': 'port',
+            'sample': f'{sample_rays} rays x {N_SAMPLES} samples, D={HIDDEN}, fwd+loss+bwd, median of {steps} steps after {warmup} '
+                      f'warm-ups, torch {torch.__version__} CPU, {threads} threads on a {host_cores}-core host'}
+
+
+def cpu_config0(warmup=2, steps=5):
+    """BASELINE configs[0] -- the reference's own CPU-runnable case: configs/Tanks/Ignatius.yaml settings, 32 rays x 64 samples,
+    hidden_dim 128 (the reference architecture at D=128; `model.num_layers` is unused there), FULL training step
+    with the first-phase per-image losses on (point cloud + surface re-projection, on 216x384 mono-depth maps -> a 54x96 sampling
+    grid), forward + backward, on the host cores through the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nerf_oracle as orc
+    host_cores, cpu_model = _host_cpu()
+    threads = min(host_cores, 32)
+    torch.set_num_threads(threads)
+    R, N, D, dh, dw = 32, 64, 128, 216, 384
+    g = torch.Generator().manual_seed(0)
+    params = {k: v.requires_grad_(True) for k, v in orc.init_params(D, 1).items()}
+    pose_r = (0.01 * torch.randn(N_CAMS, 3, generator=g)).requires_grad_(True)
+    pose_t = (0.01 * torch.randn(N_CAMS, 3, generator=g)).requires_grad_(True)
+    scales = (1 + 0.05 * torch.randn(N_CAMS, 1, generator=g)).requires_grad_(True)
+    shifts = (0.05 * torch.randn(N_CAMS, 1, generator=g)).requires_grad_(True)
+    f = 0.7 * IMG_W
+    K = torch.diag(torch.tensor([2 * f / IMG_W, -2 * f / IMG_H, -1.0, 1.0])).unsqueeze(0)
+    depth, depth_ref = (1 + 2 * torch.rand(1, 1, dh, dw, generator=g) for _ in range(2))
+    img, img_ref = (torch.rand(1, 3, IMG_H, IMG_W, generator=g) for _ in range(2))
+    rcfg = full_cfg(R, n_samples=N, hidden=D)['rendering']
+    rcfg['occ_activation'] = 'softplus'
+    ts = []
+    for i in range(warmup + steps):
+        ray_idx = torch.randperm(IMG_H * IMG_W, generator=g)[:R]
+        jitter = torch.rand(1, R, N, generator=g)
+        t0 = time.perf_counter()
+        loss, _ = orc.train_step_scope(params, pose_r, pose_t, scales, shifts, 3, K, depth, img, (IMG_H, IMG_W), ray_idx, jitter, rcfg)
+        aux, _, _ = orc.aux_scope(pose_r, pose_t, scales, shifts, 3, 4, K, depth, depth_ref, img, img_ref)
+        (loss + aux).backward()
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts[warmup:]))
+    return {'workload': 'BASELINE configs[0]: Tanks/Ignatius settings, 32 rays x 64 samples, D=128, full step incl. per-image losses '
+                        '(54x96 grid), CPU', 'ms_per_step': round(med * 1e3, 3), 'value': round(R / med, 1), 'unit': 'rays/s',
+            'kind': 'port', 'threads': threads, 'host_cores': host_cores, 'cpu': cpu_model,
+            'sample': f'median of {steps} steps after {warmup} warm-ups'}
+
+
+def _timed_steps(trainer, data, warmup, steps, world):
+    def step(i):
+        return trainer.train_step(data, it=i, epoch=0, scheduling_start=10000, render_path=None)
+    ld = None
+    for i in range(warmup):
+        ld = step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ld = step(warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=data['img'].device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    trainer.flush_nan_check()
+    return elapsed, float(ld['loss'].detach())
+
+
+def extra_config(device, name, rays, n_samples, bf16, steps=10, warmup=3):
+    """One more BASELINE configuration measured in the same run on one GPU: full Trainer.train_step + the kernels' roofline."""
+    trainer, net = build_trainer(device, 1, False, bf16, rays, n_samples)
+    data = synthetic_batch(device)
+    elapsed, loss = _timed_steps(trainer, data, warmup, steps, 1)
+    ms = elapsed / steps * 1e3
+    roof = kernel_roofline(net, device, reps=3, bf16=bf16, rays=rays, n_samples=n_samples)
+    out = {'workload': name, 'rays_per_gpu': rays, 'n_samples': n_samples, 'hidden': HIDDEN,
+           'dtype': 'bf16 products / f32 accumulate' if bf16 else 'f32', 'steps': steps, 'warmup': warmup,
+           'ms_per_step': round(ms, 4), 'value': round(rays / (ms * 1e-3), 1), 'unit': 'rays/s', 'final_loss': round(loss, 6),
+           'roofline': {k: roof[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source')},
+           'kernels_ms': {k: v['ms'] for k, v in roof['kernels'].items()}, 'fused_mlp_all_three': roof['fused_mlp_all_three']}
+    del trainer, net, data
+    torch.cuda.empty_cache()
+    return out
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one per GPU)."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
+def allreduce_probe(device, n_floats, reps=20):
+    """The step's one collective on its own: SUM all-reduce of a flat fp32 bucket of the gradient size, microseconds per call
+    (max over ranks), and the number of ranks that actually took part (the sum of ones)."""
+    buf = torch.ones(n_floats, device=device)
+    dist.all_reduce(buf)
+    ranks_seen = int(round(float(buf[0].item())))
+    buf.fill_(1.0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / reps * 1e6
+    t = torch.tensor([us], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return ranks_seen, float(t.item())
 
 
 def main():
@@ -243,66 +408,97 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--rays-per-gpu', type=int, default=R_PER_GPU, help='rays each rank renders per step (BASELINE configs[3]: 4096)')
+    ap.add_argument('--samples', type=int, default=N_SAMPLES, help='samples per ray (headline 192 = 64 + 128; stock default 128)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the extra `configs` blocks (bf16 4096x128, fp32 N=128, CPU configs[0])')
     ap.add_argument('--aux', action='store_true',
                     help='also run the per-image point-cloud / reprojection losses of the first training phase (not the headline metric)')
     ap.add_argument('--bf16', action='store_true',
-                    help='bf16-MFMA mode of the MLP forward / input-gradient kernels (BASELINE configs[2] arithmetic; not the headline metric)')
+                    help='bf16-MFMA mode of the MLP kernels for the MAIN measurement (BASELINE configs[2] arithmetic; not the headline metric)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / rendezvous check without a GPU: every rank joins a gloo group, all-reduces and rank 0 prints the line skeleton')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+
+    if args.dry_run:
+        if world > 1:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            seen = 1
+        if rank == 0:
+            print(json.dumps({'metric': 'training rays/sec', 'value': None, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+                              'warmup': args.warmup, 'dry_run': True, 'ranks_seen': seen, 'backend': 'gloo'}), flush=True)
+        return
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the HIP render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    n_dev = torch.cuda.device_count()
+    shared = world > n_dev
+    if shared and os.environ.get('NNR_ALLOW_SHARED_GPU') != '1':
+        raise SystemExit(f"--gpus {world} but only {n_dev} GPU(s) visible (set NNR_ALLOW_SHARED_GPU=1 to share them through gloo)")
+    torch.cuda.set_device(local_rank % n_dev)
+    device = torch.device('cuda', local_rank % n_dev)
+    backend = 'gloo' if shared else 'nccl'      # RCCL refuses two ranks on one device; gloo carries device tensors through the host
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1"
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
 
-    trainer, net = build_trainer(device, world, args.aux, args.bf16)
+    R, N = args.rays_per_gpu, args.samples
+    trainer, net = build_trainer(device, world, args.aux, args.bf16, R, N)
     data = synthetic_batch(device)
-
-    def step(i):
-        return trainer.train_step(data, it=i, epoch=0, scheduling_start=10000, render_path=None)
-
-    for i in range(args.warmup):
-        step(i)
+    elapsed, loss_val = _timed_steps(trainer, data, args.warmup, args.steps, world)
+    ranks_seen, ar_us = (1, None)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ld = step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss_val = float(ld['loss'].detach())
+        n_grad = sum(p.numel() for m in (net, trainer.pose_param_net, trainer.distortion_net) for p in m.parameters()) + 9
+        ranks_seen, ar_us = allreduce_probe(device, n_grad)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        rays = R_PER_GPU * world
+        rays = R * world
+        headline = (R, N) == (R_PER_GPU, N_SAMPLES) and not args.bf16
+        what = ('BASELINE configs[1]: 1024 rays/GPU x 192 samples (64 coarse + 128 fine pinned as one 192-sample stratified pass)'
+                if headline else f'{R} rays/GPU x {N} samples')
         out = {
             'metric': 'training rays/sec', 'value': round(rays / (ms * 1e-3), 1), 'unit': 'rays/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 products / f32 accumulate' if args.bf16 else 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: 1024 rays/GPU x 192 samples (64 coarse + 128 fine pinned as one '
-                                   '192-sample stratified pass), 8-layer-256 MLP, pose + distortion learnable, fp32; '
-                                   'full Trainer.train_step incl. 3 Adam steps; aux per-image losses ' + ('ON (pc + rgb_s)' if args.aux else 'off'),
-                       'rays_per_gpu': R_PER_GPU, 'n_samples': N_SAMPLES, 'hidden': HIDDEN, 'image': [IMG_H, IMG_W],
+            'config': {'workload': what + ', 8-layer-256 MLP, pose + distortion learnable, ' + ('bf16 MFMA' if args.bf16 else 'fp32') +
+                                   '; full Trainer.train_step incl. 3 Adam steps; aux per-image losses ' + ('ON (pc + rgb_s)' if args.aux else 'off'),
+                       'rays_per_gpu': R, 'n_samples': N, 'hidden': HIDDEN, 'image': [IMG_H, IMG_W],
                        'parallelism': f'dp{world} (ray-sharded, one flat all-reduce)'},
             'final_loss': round(loss_val, 6),
         }
-        out['roofline'] = kernel_roofline(net, device, bf16=args.bf16)
+        if world > 1:
+            out['collective'] = {'backend': 'rccl' if backend == 'nccl' else 'gloo (shared GPU dry run)', 'rccl_ranks_seen': ranks_seen,
+                                 'allreduce_us': round(ar_us, 1), 'bucket_floats': n_grad}
+        out['roofline'] = kernel_roofline(net, device, bf16=args.bf16, rays=R, n_samples=N)
         out['cpu_baseline'] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
+        if world == 1 and not args.no_extra and headline:
+            del trainer
+            torch.cuda.empty_cache()
+            out['configs'] = {
+                'bf16_4096x128': extra_config(device, 'BASELINE configs[2]: 4096 rays x 128 samples, bf16 MFMA products with fp32 accumulate',
+                                              4096, 128, True),
+                'fp32_1024x128': extra_config(device, "the reference's stock default: 1024 rays x 128 samples (configs/default.yaml:37,76), fp32",
+                                              1024, 128, False),
+                'cpu_32x64_d128': None if args.no_cpu_baseline else cpu_config0(),
+            }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -193,6 +193,8 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
  * inverse and the relative transform Rt_rel_12; scale2: device scalar.  out[4] = {loss_pc, loss_rgb_s, n_valid, 0}.
  * The backward takes g_out[2] = dL/d{loss_pc, loss_rgb_s} (device) and ACCUMULATES into g_d1_img / g_d2_img (hd,wd;
  * zero-fill first; either may be null) and OVERWRITES g_rel_scale[16] = {dL/d rel rows 0..2 (12 floats), dL/d scale2, 0..}.
+ * Every sum is taken in a fixed order (per-block partials added in block order; shared-destination scatters in 64-bit fixed
+ * point), so losses and gradients are bit-reproducible from run to run.
  * Both calls use the same workspace (nnr_aux_workspace_floats) and the same inputs. */
 #define NNR_AUX_RGBS 1u         /* rgb_s_weight != 0 */
 #define NNR_AUX_PC 2u           /* pc_weight != 0 */
@@ -202,6 +204,12 @@ typedef struct nnr_aux_cfg {
     int32_t hd, wd, hr, wr;
     float nearest_limit;
     uint32_t flags;
+    /* Data parallelism: both losses are means over SOURCE points, so a rank evaluates the sums over the points
+     * [shard_lo, shard_hi) of the hr*wr grid only (the nearest-neighbour search, O(S^2), shrinks by the world size; the O(S)
+     * per-point passes still cover every point, because a rank's sources pull on arbitrary destinations) with the GLOBAL
+     * normalisers (S, the number of valid re-projections): the SUM over ranks of the losses and of every gradient equals the
+     * single-GPU value.  0, 0 = all points. */
+    int32_t shard_lo, shard_hi;
 } nnr_aux_cfg;
 size_t nnr_aux_workspace_floats(const nnr_aux_cfg* cfg);
 int nnr_aux_terms_fwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* d2_img, const float* img1r, const float* img2r,
@@ -215,8 +223,9 @@ int nnr_aux_terms_bwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* 
  * randperm would have drawn (keys = empty(n, int64).random_(INT64_MIN, INT64_MAX)), the number of key bits it sorts by, and
  * the generator's (seed, philox offset) at the point where torch re-shuffles duplicate keys -- without sorting all n keys.
  * scratch: nnr_randperm_scratch_bytes(r) bytes = 8 + 20 * capacity (capacity 4096 up to r = 1401, 16384 up to r = 9943, 65536
- * up to r = 51463), 8-byte aligned; scratch word [1] becomes 1 if the candidate buffer under/overflowed (probability < 1e-50 by
- * construction: the threshold leaves >= 16 sigma below and >= 40 sigma above the expected count).  NNR_E_UNSUPPORTED where the
+ * up to r = 51463), 8-byte aligned; if the candidate buffer under/overflowed (probability < 1e-50 by construction: the threshold
+ * leaves >= 16 sigma below and >= 40 sigma above the expected count) scratch word [1] becomes 1 and the kernel TRAPS -- the
+ * process aborts at its next synchronisation instead of training on a truncated pixel pick.  NNR_E_UNSUPPORTED where the
  * packing does not fit or r is beyond the largest buffer (bits + ceil(log2 n) > 64, scratch_bytes(r) == 0, n < 8r): callers fall
  * back to torch.randperm. */
 size_t nnr_randperm_scratch_bytes(int32_t r);

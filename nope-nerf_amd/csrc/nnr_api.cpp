@@ -587,7 +587,10 @@ namespace {
 size_t aux_fill(const nnr_aux_cfg* c, float* ws, nnr::AuxArgs& a) {   // returns the workspace size in floats, 0 = bad cfg
     if (!c || c->hd <= 0 || c->wd <= 0 || c->hr < 2 || c->wr < 2 || c->hr > c->hd || c->wr > c->wd) return 0;
     const int64_t S = (int64_t)c->hr * c->wr;
+    if (c->shard_lo < 0 || c->shard_hi < c->shard_lo || c->shard_hi > S) return 0;
     a.hd = c->hd; a.wd = c->wd; a.hr = c->hr; a.wr = c->wr; a.S = (int)S;
+    a.s_lo = c->shard_lo;
+    a.s_hi = (c->shard_lo == 0 && c->shard_hi == 0) ? (int)S : c->shard_hi;   // 0, 0 = every point (one GPU)
     a.nl = c->nearest_limit;
     a.flags = c->flags;
     float* p = ws;
@@ -595,12 +598,16 @@ size_t aux_fill(const nnr_aux_cfg* c, float* ws, nnr::AuxArgs& a) {   // returns
     a.keys = reinterpret_cast<unsigned long long*>(take(4 * S));
     a.idx_xy = reinterpret_cast<int64_t*>(take(2 * S));
     a.idx_yx = reinterpret_cast<int64_t*>(take(2 * S));
-    a.X = take(3 * S); a.Y = take(3 * S); a.gX = take(3 * S); a.gY = take(3 * S);
+    a.gXq = reinterpret_cast<long long*>(take(6 * S));
+    a.gYq = reinterpret_cast<long long*>(take(6 * S));
+    a.X = take(3 * S); a.Y = take(3 * S);
     a.gxy = take(2 * S);
     a.dist_xy = take(S); a.dist_yx = take(S);
     a.pflags = reinterpret_cast<uint32_t*>(take(S));
     a.acc = take(8);
-    a.g_acc = take(16);
+    const int64_t nb = (S + 255) / 256;
+    a.part_fwd = take(4 * nb);
+    a.part_bwd = take(16 * nb);
     return (size_t)(p - ws);
 }
 }  // namespace
@@ -634,10 +641,7 @@ int nnr_aux_terms_bwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* 
     if (((uintptr_t)ws & 7) != 0) return NNR_E_ALIGN;
     a.d1_img = d1_img; a.d2_img = d2_img; a.img1r = img1r; a.img2r = img2r; a.K = K; a.Kinv = Kinv; a.rel = rel; a.scale2 = scale2;
     a.g_out = g_out; a.g_d1_img = g_d1_img; a.g_d2_img = g_d2_img;
-    hipError_t e = launch_aux_bwd(a, (hipStream_t)stream);
-    if (e != hipSuccess) return hip_fail(e);
-    e = hipMemcpyAsync(g_rel_scale, a.g_acc, 16 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
-    return e == hipSuccess ? NNR_OK : hip_fail(e);
+    NNR_LAUNCH(launch_aux_bwd(a, g_rel_scale, (hipStream_t)stream));
 }
 
 }  // extern "C"

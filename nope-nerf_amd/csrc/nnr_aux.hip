@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void aux_points_fwd_kernel(AuxArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     float lsum = 0.f, lcnt = 0.f;
     if (i < a.S) {
+        const bool mine = i >= a.s_lo && i < a.s_hi;   // data-parallel shard of the source points: this rank's share of the SUMS
         const AuxGeom g = aux_geometry(a, i);
         const float s2 = (a.flags & NNR_AUX_SCALE_PCS) ? a.scale2[0] : 1.f;
 #pragma unroll
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void aux_points_fwd_kernel(AuxArgs a) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float u = s1.v[c] - s2b.v[c], au = fabsf(u);
-                    lsum += fminf(au, 1.f);
+                    if (mine) lsum += fminf(au, 1.f);
                     // d clamp(|u|,0,1)/d rgb2 = -sign(u) inside (0,1), 0 at the clamps (torch: clamp passes the gradient at the
                     // bounds, abs gives 0 at 0)
                     const float gu = (au > 0.f && au <= 1.f) ? (u > 0.f ? -1.f : 1.f) : 0.f;
@@ -143,10 +144,11 @@ __global__ __launch_bounds__(256) void aux_points_fwd_kernel(AuxArgs a) {
         }
         a.pflags[i] = fl;
     }
+    // per-block partial sums, added up in block order by aux_finish_kernel: bit-reproducible (float atomics are not)
     const float bs = block_sum(lsum, scratch), bc = block_sum(lcnt, scratch);
-    if (threadIdx.x == 0 && (a.flags & NNR_AUX_RGBS)) {
-        atomicAdd(a.acc + 0, bs);
-        atomicAdd(a.acc + 1, bc);
+    if (threadIdx.x == 0) {
+        a.part_fwd[4 * blockIdx.x + 0] = bs;
+        a.part_fwd[4 * blockIdx.x + 1] = bc;
     }
 }
 
@@ -156,43 +158,72 @@ __global__ void aux_fill_keys_kernel(unsigned long long* keys, int n) {
     if (i < n) keys[i] = ~0ull;
 }
 
-// decode (distance bits << 32 | index) and sum the distances of one direction into acc[slot]
-__global__ __launch_bounds__(256) void aux_decode_kernel(const unsigned long long* keys, int S, int64_t* idx, float* dist, float* acc_slot) {
+// decode (distance bits << 32 | index) of this rank's source points and leave the block's distance sum in its partial slot
+__global__ __launch_bounds__(256) void aux_decode_kernel(const unsigned long long* keys, int S, int s_lo, int s_hi, int64_t* idx, float* dist,
+                                                         float* part, int slot) {
     __shared__ float scratch[4];
     const int s = blockIdx.x * 256 + threadIdx.x;
     float d = 0.f;
-    if (s < S) {
+    if (s < S && s >= s_lo && s < s_hi) {
         const unsigned long long k = keys[s];
         idx[s] = (int64_t)(unsigned int)(k & 0xffffffffu);
         d = __uint_as_float((unsigned int)(k >> 32));
         dist[s] = d;
     }
     const float bs = block_sum(d, scratch);
-    if (threadIdx.x == 0) atomicAdd(acc_slot, bs);
+    if (threadIdx.x == 0) part[4 * blockIdx.x + slot] = bs;
 }
 
-// out = [loss_pc, loss_rgb_s, n_valid, 0]
-__global__ void aux_finish_kernel(AuxArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    a.out[0] = (a.flags & NNR_AUX_PC) ? (a.acc[2] + a.acc[3]) / (float)a.S : 0.f;
-    a.out[1] = (a.flags & NNR_AUX_RGBS) && a.acc[1] > 0.f ? a.acc[0] / (3.f * a.acc[1]) : 0.f;
-    a.out[2] = a.acc[1];
+// column `k` of an [nb][stride] table of per-block partials, summed in a fixed order by one wave: lane l adds blocks l, l + 64, ...,
+// then the lane tree.  Every lane returns the total.
+__device__ __forceinline__ float ordered_column_sum(const float* part, int nb, int stride, int k) {
+    float v = 0.f;
+    for (int b = threadIdx.x; b < nb; b += 64) v += part[stride * b + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// out = [loss_pc, loss_rgb_s, n_valid, 0]; sums over this rank's shard of the source points, normalisers global
+__global__ __launch_bounds__(64) void aux_finish_kernel(AuxArgs a) {
+    const int nb = (a.S + 255) / 256;
+    const bool rgbs = (a.flags & NNR_AUX_RGBS) != 0, pc = (a.flags & NNR_AUX_PC) != 0;
+    const float lsum = rgbs ? ordered_column_sum(a.part_fwd, nb, 4, 0) : 0.f;
+    const float lcnt = rgbs ? ordered_column_sum(a.part_fwd, nb, 4, 1) : 0.f;
+    const float dxy = pc ? ordered_column_sum(a.part_fwd, nb, 4, 2) : 0.f;
+    const float dyx = pc ? ordered_column_sum(a.part_fwd, nb, 4, 3) : 0.f;
+    if (threadIdx.x != 0) return;
+    a.acc[0] = lsum; a.acc[1] = lcnt; a.acc[2] = dxy; a.acc[3] = dyx;
+    a.out[0] = pc ? (dxy + dyx) / (float)a.S : 0.f;
+    a.out[1] = rgbs && lcnt > 0.f ? lsum / (3.f * lcnt) : 0.f;
+    a.out[2] = lcnt;
     a.out[3] = 0.f;
 }
 
-// d mean_s dist[s] * coef, ACCUMULATED: g_src[s] += w (src_s - dst_j), g_dst[j] -= the same (atomics: shared destinations)
+// Gradients of the two clouds are accumulated as 64-bit FIXED-POINT numbers (units of 2^-44): several sources may share a
+// destination, and integer atomics commute exactly where float atomics make the sum depend on arrival order.  Every term is
+// bounded by |g_out[0]| / S and a destination collects at most S of them, so the range (+-2^19) is never approached; the
+// resolution is 6e-14, nine orders of magnitude below a term.
+constexpr double kFixScale = 17592186044416.0;   // 2^44
+__device__ __forceinline__ void fix_add(long long* p, float v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * kFixScale));
+}
+__device__ __forceinline__ float fix_get(const long long* p) { return (float)((double)*p * (1.0 / kFixScale)); }
+
+// d mean_s dist[s] * coef for the sources [s_lo, s_hi) of this rank, ACCUMULATED: g_src[s] += w (src_s - dst_j), g_dst[j] -= the same
 __global__ void aux_pc_bwd_kernel(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_out, int S,
-                                  float* g_src, float* g_dst) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
+                                  int s_lo, int s_hi, long long* g_src, long long* g_dst) {
+    const int s = s_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= s_hi) return;
     const int64_t j = idx[s];
+    if (j < 0 || j >= S) return;   // no finite distance was found (NaN / inf coordinates): no match, no gradient -- and no wild address
     const float dd = dist[s];
     const float w = dd > 0.f ? g_out[0] / ((float)S * dd) : 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = w * (src[3 * s + c] - dst[3 * j + c]);
-        atomicAdd(g_src + 3 * s + c, v);
-        atomicAdd(g_dst + 3 * j + c, -v);
+        fix_add(g_src + 3 * s + c, v);
+        fix_add(g_dst + 3 * j + c, -v);
     }
 }
 
@@ -213,13 +244,13 @@ __global__ __launch_bounds__(256) void aux_points_bwd_kernel(AuxArgs a) {
         if (a.flags & NNR_AUX_PC) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const float gx = a.gX[3 * i + r], gy = a.gY[3 * i + r];
+                const float gx = fix_get(a.gXq + 3 * i + r), gy = fix_get(a.gYq + 3 * i + r);
                 g_rot[r] = gx / s2;
                 g_pc2[r] = gy / s2;
                 if (scale) acc[12] -= (gx * a.X[3 * i + r] + gy * a.Y[3 * i + r]) / s2;
             }
         }
-        if ((a.flags & NNR_AUX_RGBS) && (fl & kValid) && !(fl & kBehind) && a.acc[1] > 0.f) {
+        if ((a.flags & NNR_AUX_RGBS) && (fl & kValid) && !(fl & kBehind) && a.acc[1] > 0.f && i >= a.s_lo && i < a.s_hi) {
             float q[3], xy[2];
             aux_project(a, g, q, xy);
             const float coef = a.g_out[1] / (3.f * a.acc[1]);
@@ -256,39 +287,52 @@ __global__ __launch_bounds__(256) void aux_points_bwd_kernel(AuxArgs a) {
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
         const float bs = block_sum(acc[k], scratch);
-        if (threadIdx.x == 0 && bs != 0.f) atomicAdd(a.g_acc + k, bs);
+        if (threadIdx.x == 0) a.part_bwd[16 * blockIdx.x + k] = bs;
+    }
+}
+
+// g_rel_scale[16] = block partials summed in block order (bit-reproducible)
+__global__ __launch_bounds__(64) void aux_bwd_finish_kernel(AuxArgs a, float* g_rel_scale) {
+    const int nb = (a.S + 255) / 256;
+    for (int k = 0; k < 16; ++k) {
+        const float t = k < 13 ? ordered_column_sum(a.part_bwd, nb, 16, k) : 0.f;
+        if (threadIdx.x == 0) g_rel_scale[k] = t;
     }
 }
 
 hipError_t launch_aux_fwd(const AuxArgs& a, hipStream_t st) {
     const int S = a.S, nb = (S + 255) / 256;
-    hipError_t e = hipMemsetAsync(a.acc, 0, 8 * sizeof(float), st);
-    if (e != hipSuccess) return e;
+    const int n = a.s_hi - a.s_lo;   // this rank's source points (all of them without data parallelism)
     hipLaunchKernelGGL(aux_points_fwd_kernel, dim3(nb), dim3(256), 0, st, a);
     if (a.flags & NNR_AUX_PC) {
         hipLaunchKernelGGL(aux_fill_keys_kernel, dim3((2 * S + 255) / 256), dim3(256), 0, st, a.keys, 2 * S);
-        e = launch_pc_nearest_keys(a.X, a.Y, S, S, a.keys, st);
-        if (e != hipSuccess) return e;
-        e = launch_pc_nearest_keys(a.Y, a.X, S, S, a.keys + S, st);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(aux_decode_kernel, dim3(nb), dim3(256), 0, st, a.keys, S, a.idx_xy, a.dist_xy, a.acc + 2);
-        hipLaunchKernelGGL(aux_decode_kernel, dim3(nb), dim3(256), 0, st, a.keys + S, S, a.idx_yx, a.dist_yx, a.acc + 3);
+        if (n > 0) {   // the O(S^2 / W) part: only this rank's sources search the whole destination cloud
+            hipError_t e = launch_pc_nearest_keys(a.X + 3 * a.s_lo, a.Y, n, S, a.keys + a.s_lo, st);
+            if (e != hipSuccess) return e;
+            e = launch_pc_nearest_keys(a.Y + 3 * a.s_lo, a.X, n, S, a.keys + S + a.s_lo, st);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(aux_decode_kernel, dim3(nb), dim3(256), 0, st, a.keys, S, a.s_lo, a.s_hi, a.idx_xy, a.dist_xy, a.part_fwd, 2);
+        hipLaunchKernelGGL(aux_decode_kernel, dim3(nb), dim3(256), 0, st, a.keys + S, S, a.s_lo, a.s_hi, a.idx_yx, a.dist_yx, a.part_fwd, 3);
     }
     hipLaunchKernelGGL(aux_finish_kernel, dim3(1), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_aux_bwd(const AuxArgs& a, hipStream_t st) {
+hipError_t launch_aux_bwd(const AuxArgs& a, float* g_rel_scale, hipStream_t st) {
     const int S = a.S, nb = (S + 255) / 256;
-    hipError_t e = hipMemsetAsync(a.g_acc, 0, 16 * sizeof(float), st);
-    if (e != hipSuccess) return e;
+    const int n = a.s_hi - a.s_lo;
     if (a.flags & NNR_AUX_PC) {
-        e = hipMemsetAsync(a.gX, 0, (size_t)6 * S * sizeof(float), st);   // gX and gY are adjacent
+        hipError_t e = hipMemsetAsync(a.gXq, 0, (size_t)6 * S * sizeof(long long), st);   // gXq and gYq are adjacent
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(aux_pc_bwd_kernel, dim3(nb), dim3(256), 0, st, a.X, a.Y, a.idx_xy, a.dist_xy, a.g_out, S, a.gX, a.gY);
-        hipLaunchKernelGGL(aux_pc_bwd_kernel, dim3(nb), dim3(256), 0, st, a.Y, a.X, a.idx_yx, a.dist_yx, a.g_out, S, a.gY, a.gX);
+        if (n > 0) {
+            const int nbs = (n + 255) / 256;
+            hipLaunchKernelGGL(aux_pc_bwd_kernel, dim3(nbs), dim3(256), 0, st, a.X, a.Y, a.idx_xy, a.dist_xy, a.g_out, S, a.s_lo, a.s_hi, a.gXq, a.gYq);
+            hipLaunchKernelGGL(aux_pc_bwd_kernel, dim3(nbs), dim3(256), 0, st, a.Y, a.X, a.idx_yx, a.dist_yx, a.g_out, S, a.s_lo, a.s_hi, a.gYq, a.gXq);
+        }
     }
     hipLaunchKernelGGL(aux_points_bwd_kernel, dim3(nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(aux_bwd_finish_kernel, dim3(1), dim3(64), 0, st, a, g_rel_scale);
     return hipGetLastError();
 }
 

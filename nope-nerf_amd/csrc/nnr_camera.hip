@@ -187,16 +187,22 @@ __global__ __launch_bounds__(256) void ray_setup_fwd_kernel(RaySetupArgs a) {
     a.mask[i] = (isfinite(dgt) && dgt != 0.f) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void ray_setup_bwd_kernel(RaySetupArgs a) {
-    __shared__ float red[12][4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// One workgroup of 1024 threads strides over the rays and reduces in a FIXED order (lane tree, then the 16 waves in index order):
+// the 12 sums -- and with them every pose gradient of the step -- are bit-reproducible from run to run, which float atomics
+// across workgroups are not.  R is a few thousand rays per rank; the work is O(R) and latency-bound either way, and the
+// matrix chain rule (formerly a second launch behind a memset) runs in the same kernel.
+__global__ __launch_bounds__(1024) void ray_setup_bwd_kernel(RaySetupArgs a) {
+    __shared__ float red[12][16];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
-    if (i < a.R) {
-        M4 kinv, winv, sinv, m;
+    M4 m;
+    {
+        M4 kinv, winv, sinv;
         pixel_to_world(a, kinv, winv, sinv, m);
+    }
+    for (int i = threadIdx.x; i < a.R; i += 1024) {
         const float px = a.pixels[2 * i], py = a.pixels[2 * i + 1];
         const float dep = a.depth ? a.depth[i] : 1.f;
         float ray[3], gdir[3], gray[3];
@@ -229,10 +235,10 @@ __global__ __launch_bounds__(256) void ray_setup_bwd_kernel(RaySetupArgs a) {
         if (a.g_depth) a.g_depth[i] = gdep;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            acc[4 * c + 0] = gray[c] * px;
-            acc[4 * c + 1] = gray[c] * py;
-            acc[4 * c + 2] = gray[c];
-            acc[4 * c + 3] = a.g_o ? a.g_o[3 * i + c] : 0.f;
+            acc[4 * c + 0] += gray[c] * px;
+            acc[4 * c + 1] += gray[c] * py;
+            acc[4 * c + 2] += gray[c];
+            acc[4 * c + 3] += a.g_o ? a.g_o[3 * i + c] : 0.f;
         }
     }
 #pragma unroll
@@ -243,17 +249,18 @@ __global__ __launch_bounds__(256) void ray_setup_bwd_kernel(RaySetupArgs a) {
         if (lane == 0) red[k][wv] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 12) atomicAdd(a.acc + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
-}
-
-// dL/dM (12 accumulated floats) -> dL/dK, dL/dW, dL/dS through M = S^-1 W^-1 K^-1
-__global__ void ray_setup_mat_bwd_kernel(RaySetupArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    M4 kinv, winv, sinv, m;
-    pixel_to_world(a, kinv, winv, sinv, m);
+    if (threadIdx.x != 0) return;
+    // dL/dM (12 sums) -> dL/dK, dL/dW, dL/dS through M = S^-1 W^-1 K^-1
     M4 dm;
-    for (int k = 0; k < 12; ++k) dm.m[k] = a.acc[k];
+    for (int k = 0; k < 12; ++k) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[k][w];
+        dm.m[k] = t;
+        a.acc[k] = t;
+    }
     for (int k = 12; k < 16; ++k) dm.m[k] = 0.f;
+    M4 kinv, winv, sinv, m2;
+    pixel_to_world(a, kinv, winv, sinv, m2);
     const M4 sw = mul4(sinv, winv);
     const M4 d_kinv = mul4(transpose4(sw), dm);             // M = (S^-1 W^-1) K^-1
     const M4 d_sw = mul4(dm, transpose4(kinv));
@@ -297,22 +304,22 @@ __global__ void depth_gather_affine_fwd_kernel(const float* img, const int64_t* 
     const float raw = img[(int64_t)nearest_src(y, h, hd) * wd + nearest_src(x, w, wd)];
     out[i] = shift_first ? __fmul_rn(__fadd_rn(raw, shift[0]), scale[0]) : __fadd_rn(__fmul_rn(raw, scale[0]), shift[0]);
 }
-// g_ss[0] += d loss / d scale, g_ss[1] += d loss / d shift (block-reduced, one atomic pair per workgroup); the raw map has no gradient
-__global__ __launch_bounds__(256) void depth_gather_affine_bwd_kernel(const float* g, const float* img, const int64_t* ray_idx,
-                                                                      const float* scale, const float* shift, int shift_first,
-                                                                      float* g_ss, int R, int h, int w, int hd, int wd) {
-    __shared__ float red[2][4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// g_ss[0] = d loss / d scale, g_ss[1] = d loss / d shift; the raw map has no gradient.  One workgroup, fixed summation order
+// (see ray_setup_bwd_kernel): the distortion gradients are bit-reproducible.
+__global__ __launch_bounds__(1024) void depth_gather_affine_bwd_kernel(const float* g, const float* img, const int64_t* ray_idx,
+                                                                       const float* scale, const float* shift, int shift_first,
+                                                                       float* g_ss, int R, int h, int w, int hd, int wd) {
+    __shared__ float red[2][16];
     float gs = 0.f, gh = 0.f;
-    if (i < R) {
+    for (int i = threadIdx.x; i < R; i += 1024) {
         const int64_t q = ray_idx[i];
         const int y = (int)(q / w), x = (int)(q - (int64_t)y * w);
         const float raw = img[(int64_t)nearest_src(y, h, hd) * wd + nearest_src(x, w, wd)];
         const float gi = g[i];
         // a non-finite raw depth (masked ray) carries a zero upstream gradient; keep 0 * inf out of the sums
         if (gi != 0.f) {
-            gs = shift_first ? gi * (raw + shift[0]) : gi * raw;
-            gh = shift_first ? gi * scale[0] : gi;
+            gs += shift_first ? gi * (raw + shift[0]) : gi * raw;
+            gh += shift_first ? gi * scale[0] : gi;
         }
     }
 #pragma unroll
@@ -322,7 +329,11 @@ __global__ __launch_bounds__(256) void depth_gather_affine_bwd_kernel(const floa
     }
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = gs; red[1][threadIdx.x >> 6] = gh; }
     __syncthreads();
-    if (threadIdx.x < 2) atomicAdd(g_ss + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (threadIdx.x < 2) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += red[threadIdx.x][k];
+        g_ss[threadIdx.x] = t;
+    }
 }
 
 // scaled pixel coordinates of flat indices: x' = 2 x/(w-1) - 1, y' = 2 y/(h-1) - 1, same float op order as arange_pixels
@@ -433,10 +444,7 @@ hipError_t launch_ray_setup_fwd(const RaySetupArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t launch_ray_setup_bwd(const RaySetupArgs& a, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(a.acc, 0, 12 * sizeof(float), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ray_setup_bwd_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(ray_setup_mat_bwd_kernel, dim3(1), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(ray_setup_bwd_kernel, dim3(1), dim3(1024), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_depth_gather_fwd(const float* img, const int64_t* idx, float* out, int R, int h, int w, int hd, int wd, hipStream_t st) {
@@ -514,9 +522,7 @@ hipError_t launch_depth_gather_affine_fwd(const float* img, const int64_t* idx, 
 }
 hipError_t launch_depth_gather_affine_bwd(const float* g, const float* img, const int64_t* idx, const float* scale, const float* shift,
                                           int shift_first, float* g_ss, int R, int h, int w, int hd, int wd, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(g_ss, 0, 2 * sizeof(float), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(depth_gather_affine_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, st, g, img, idx, scale, shift, shift_first, g_ss,
+    hipLaunchKernelGGL(depth_gather_affine_bwd_kernel, dim3(1), dim3(1024), 0, st, g, img, idx, scale, shift, shift_first, g_ss,
                        R, h, w, hd, wd);
     return hipGetLastError();
 }

@@ -124,23 +124,25 @@ struct AuxArgs {
     const float *K, *Kinv, *rel;    // 4x4 row-major
     const float* scale2;            // device scalar (read only with NNR_AUX_SCALE_PCS)
     int hd, wd, hr, wr, S;
+    int s_lo, s_hi;                 // this rank's shard of the source points (data parallelism): [0, S) on one GPU
     float nl;
     uint32_t flags;
     // workspace
-    float *X, *Y, *gxy, *gX, *gY;   // (S,3) (S,3) (S,2) (S,3) (S,3); gX and gY adjacent
+    float *X, *Y, *gxy;             // (S,3) (S,3) (S,2)
+    long long *gXq, *gYq;           // (S,3) each, adjacent: cloud gradients in 2^-44 fixed point (order-independent atomics)
+    float *part_fwd, *part_bwd;     // per-block partial sums: [ceil(S/256)][4] and [ceil(S/256)][16]
     uint32_t* pflags;               // (S)
     unsigned long long* keys;       // (2S)
     int64_t *idx_xy, *idx_yx;
     float *dist_xy, *dist_yx;
-    float* acc;                     // 8: rgb_s sum, valid count, sum dist xy, sum dist yx
+    float* acc;                     // 8: rgb_s sum, valid count, sum dist xy, sum dist yx (written by the finishing kernel)
     float* out;                     // 4: loss_pc, loss_rgb_s, n_valid, 0
     // backward
     const float* g_out;             // 2: dL/d loss_pc, dL/d loss_rgb_s
     float *g_d1_img, *g_d2_img;     // (hd, wd), accumulated into; may be null
-    float* g_acc;                   // 16: dL/d rel rows 0..2 (12), dL/d scale2 (1)
 };
 hipError_t launch_aux_fwd(const AuxArgs& a, hipStream_t st);
-hipError_t launch_aux_bwd(const AuxArgs& a, hipStream_t st);
+hipError_t launch_aux_bwd(const AuxArgs& a, float* g_rel_scale, hipStream_t st);   // g_rel_scale[16]: dL/d rel rows 0..2 (12), dL/d scale2 (1)
 hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int D, unsigned long long* keys, hipStream_t st);
 hipError_t launch_pc_nearest(const float* src, const float* dst, int S, int D, int64_t* idx, float* dist, unsigned long long* keys,
                              hipStream_t st);

@@ -103,6 +103,13 @@ __global__ void pc_error_bwd_kernel(const float* __restrict__ src, const float* 
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     const int64_t j = idx[s];
+    // A source with NaN / inf coordinates never beats the initial key: its decoded index is 0xffffffff and its "distance" a NaN
+    // bit pattern.  No match -> no gradient (and no access 51 GB past the destination cloud); the trainer's NaN check stops the
+    // run on the loss value.
+    if (j == 0xffffffffll) {
+        if (g_src) g_src[3 * s] = g_src[3 * s + 1] = g_src[3 * s + 2] = 0.f;
+        return;
+    }
     const float dd = dist[s];
     const float w = dd > 0.f ? g_loss[0] / ((float)S * dd) : 0.f;
 #pragma unroll

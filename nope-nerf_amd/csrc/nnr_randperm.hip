@@ -97,7 +97,15 @@ __global__ __launch_bounds__(1024) void randperm_finish_kernel(unsigned int* __r
     const unsigned int* rank = rp_rank(scratch);               // sort by key leaves
     const unsigned int count = scratch[0];
     const int m = (int)min(count, cap);
-    if (threadIdx.x == 0) scratch[1] = (count < (unsigned)r || count > cap) ? 1u : 0u;
+    if (count < (unsigned)r || count > cap) {
+        // The candidate buffer under- or overflowed: the output would be zero-filled or truncated.  By construction this has
+        // probability < 1e-50 (16 sigma below, 40 sigma above the expected count), so nobody polls a status word for it -- but a
+        // wrong pixel pick must never pass silently: record the status and abort the launch (the process dies with a HIP
+        // exception at its next synchronisation).
+        if (threadIdx.x == 0) scratch[1] = 1u;
+        __threadfence_system();
+        __builtin_trap();
+    }
     for (int i = threadIdx.x; i < m; i += 1024) s[rank[i]] = cand[i];
     __syncthreads();
     // islands of equal keys that begin inside the first r positions: torch's randperm_handle_duplicate_keys_kernel, one thread

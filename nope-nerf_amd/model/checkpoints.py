@@ -10,6 +10,12 @@ import torch
 from torch.utils import model_zoo
 
 
+# Callables run before every CheckpointIO.save (model.Trainer registers its deferred NaN check here: the training step reads the
+# loss's NaN flag one step late to stay free of host syncs, so a NaN in the very last step before a save would otherwise be
+# written to model.pt unnoticed -- the reference stops on the NaN before its backward, reference model/losses.py:204).
+PRE_SAVE_HOOKS = []
+
+
 def is_url(url):
     return urllib.parse.urlparse(url).scheme in ('http', 'https')
 
@@ -27,6 +33,8 @@ class CheckpointIO(object):
         return filename if os.path.isabs(filename) else os.path.join(self.checkpoint_dir, filename)
 
     def save(self, filename, **kwargs):
+        for hook in list(PRE_SAVE_HOOKS):
+            hook()
         blob = dict(kwargs)
         blob.update({name: mod.state_dict() for name, mod in self.module_dict.items()})
         torch.save(blob, self._path(filename))
@@ -49,7 +57,11 @@ class CheckpointIO(object):
             raise FileExistsError          # sic: train.py:64-67 resumes on exactly this exception type
         print(path)
         print('=> Loading checkpoint from local file...')
-        blob = torch.load(path, map_location=device) if device is not None else torch.load(path)
+        # weights_only=False: these are trusted local checkpoints, and train.py stores numpy scalars in them
+        # (`loss_val_best = np.array(psnr_window).mean()`), which torch >= 2.6's default weights_only=True refuses to unpickle
+        # with an UnpicklingError -- not the FileExistsError train.py:64-67 knows how to handle.  The reference's torch 1.7
+        # has no such restriction.
+        blob = torch.load(path, map_location=device, weights_only=False)
         if load_model_only:
             blob = {'model': blob['model']}
         return self.parse_state_dict(blob)
@@ -57,7 +69,7 @@ class CheckpointIO(object):
     def load_url(self, url):
         print(url)
         print('=> Loading checkpoint from url...')
-        return self.parse_state_dict(model_zoo.load_url(url, progress=True, check_hash=False))
+        return self.parse_state_dict(model_zoo.load_url(url, progress=True, check_hash=False, weights_only=False))
 
     def parse_state_dict(self, state_dict):
         for name, mod in self.module_dict.items():

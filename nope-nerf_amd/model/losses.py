@@ -80,10 +80,16 @@ class Loss(nn.Module):
         raise ValueError(self.depth_loss_type)
 
     # ---- per-image auxiliary terms ----
-    def mean_on_mask(self, diff, valid_mask):
+    def mean_on_mask(self, diff, valid_mask, shard=None):
+        """Mean of diff over the valid points.  shard = (lo, hi): only the points [lo, hi) of the flattened (h, w) grid enter the
+        sum, the count stays global -- a data-parallel rank's share; the shares of all ranks add up to the mean."""
         mask = valid_mask.expand_as(diff)
         n = mask.sum()
         if n > 0:
+            if shard is not None:
+                mine = torch.zeros(valid_mask.shape[0], valid_mask.shape[1] * valid_mask.shape[2], dtype=torch.bool, device=diff.device)
+                mine[:, shard[0]:shard[1]] = True
+                mask = mask & mine.view(valid_mask.shape).expand_as(diff)
             return diff[mask].sum() / n
         print('============invalid mask==========')
         return _zero(diff)
@@ -101,19 +107,28 @@ class Loss(nn.Module):
             out.append(torch.argmin(d, dim=1))
         return torch.cat(out)
 
-    def comp_point_point_error(self, Xt, Yt):
-        """(3,S), (3,D) -> mean distance of every Xt column to its nearest Yt column (reference losses.py:143-148)."""
+    def comp_point_point_error(self, Xt, Yt, shard=None):
+        """(3,S), (3,D) -> mean distance of every Xt column to its nearest Yt column (reference losses.py:143-148).
+        shard = (lo, hi): the sum over the source columns [lo, hi) only, still divided by S (a data-parallel rank's share of the
+        mean: the nearest-neighbour search, the O(S D) part, shrinks by the world size)."""
+        S = Xt.shape[1]
+        if shard is not None:
+            Xt = Xt[:, shard[0]:shard[1]]
+            if Xt.shape[1] == 0:
+                return Xt.sum() * 0.0
         if Xt.is_cuda:   # one HIP launch instead of the (3, S, D) difference tensor; same argmin, same fp32 distances
             from nnr import pointcloud
-            return pointcloud.point_point_error(Xt.permute(1, 0), Yt.permute(1, 0))
+            err = pointcloud.point_point_error(Xt.permute(1, 0), Yt.permute(1, 0))
+            return err if shard is None else err * (Xt.shape[1] / float(S))
         idx = self.comp_closest_pts_idx_with_split(Xt, Yt)
-        return torch.linalg.norm(Xt - Yt[:, idx], dim=0).mean()
+        d = torch.linalg.norm(Xt - Yt[:, idx], dim=0)
+        return d.mean() if shard is None else d.sum() / float(S)
 
-    def get_pc_loss(self, Xt, Yt):
+    def get_pc_loss(self, Xt, Yt, shard=None):
         if self.cfg['match_method'] != 'dense':
             raise ValueError(self.cfg['match_method'])
         x, y = Xt[0].permute(1, 0), Yt[0].permute(1, 0)
-        return self.comp_point_point_error(x, y) + self.comp_point_point_error(y, x)
+        return self.comp_point_point_error(x, y, shard) + self.comp_point_point_error(y, x, shard)
 
     def get_depth_consistency_loss(self, d1_proj, d2, d2_proj=None, d1=None):
         loss = (d1_proj - d2).abs().sum() / float(d1_proj.shape[1])
@@ -121,24 +136,25 @@ class Loss(nn.Module):
             loss = 0.5 * loss + 0.5 * (d2_proj - d1).abs().sum() / float(d2_proj.shape[1])
         return loss
 
-    def get_rgb_s_loss(self, rgb1, rgb2, valid_points):
+    def get_rgb_s_loss(self, rgb1, rgb2, valid_points, shard=None):
         diff = (rgb1 - rgb2).abs().clamp(0, 1)
         if self.cfg['with_ssim'] == True:  # noqa: E712  (YAML booleans)
             diff = 0.15 * diff + 0.85 * compute_ssim_loss.to(diff.device)(rgb1, rgb2)
-        return self.mean_on_mask(diff, valid_points)
+        return self.mean_on_mask(diff, valid_points, shard)
 
     def aux_terms(self, ref, t_list=None, X=None, Y=None, rgb_pc1=None, rgb_pc1_proj=None, valid_points=None, d1_proj=None,
-                  d2=None, d2_proj=None, d1=None, weights={}, fused_aux=None, **kwargs):
+                  d2=None, d2_proj=None, d1=None, weights={}, fused_aux=None, point_shard=None, **kwargs):
         """The per-image terms (point cloud, surface reprojection, trajectory smoothness, depth consistency) and their
         weighted sum; `ref` is any tensor on the target device.  `fused_aux` = (loss_pc, loss_rgb_s) already computed by the
-        fused HIP path (nnr/aux.py) from the same inputs."""
+        fused HIP path (nnr/aux.py) from the same inputs.  `point_shard` = (lo, hi): under data parallelism loss_pc and
+        loss_rgb_s are this rank's share (sums over its source points, global normalisers; model/training.py)."""
         z = _zero(ref)
         on = lambda k: weights[k] != 0.0
         if fused_aux is not None:
             l_pc, l_rgbs = fused_aux
         else:
-            l_pc = self.get_pc_loss(X, Y) if on('pc_weight') else z
-            l_rgbs = self.get_rgb_s_loss(rgb_pc1, rgb_pc1_proj, valid_points) if on('rgb_s_weight') else z
+            l_pc = self.get_pc_loss(X, Y, point_shard) if on('pc_weight') else z
+            l_rgbs = self.get_rgb_s_loss(rgb_pc1, rgb_pc1_proj, valid_points, point_shard) if on('rgb_s_weight') else z
         parts = {
             'loss_pc': l_pc if on('pc_weight') else z,
             'loss_rgb_s': l_rgbs if on('rgb_s_weight') else z,

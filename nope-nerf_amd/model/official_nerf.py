@@ -80,12 +80,24 @@ class OfficialStaticNerf(nn.Module):
         return (rgb, occ) if return_addocc else rgb
 
     def infer_occ(self, p):
-        raise NotImplementedError("infer_occ exposes the trunk activations for the normal loss / phong renderer "
-                                  "(reference official_nerf.py:46-67); those paths are outside the HIP hot path")
+        """Trunk activations and raw density of points p (..., 3) through the nn.Linear children in stock torch (reference
+        official_nerf.py:60-67).  This is the UNSUPPORTED-configuration route of SURVEY section 8(b): the normal-consistency term needs
+        d(sigma)/dp with create_graph=True, i.e. double backward through the trunk, which the fused kernels do not provide -- so
+        the few surface points it is evaluated on (2 M <= 2 R per step, against R N samples in the fused render) go through
+        autograd over the SAME parameters.  Works on any device."""
+        enc = encode_position(p, levels=POS_LEVELS, inc_input=True)
+        x = self.layers0(enc)
+        x = self.layers1(torch.cat([x, enc], dim=-1))        # skip connection, input order [h, posenc] (official_nerf.py:63)
+        return x, self.fc_density(x)
 
     def gradient(self, p, it):
-        raise NotImplementedError("second-order d(sigma)/dp (normal loss, phong renderer; reference "
-                                  "official_nerf.py:46-58) is not part of the HIP hot path")
+        """-d(raw density)/dp as (S, 1, 3), differentiable (reference official_nerf.py:46-58)."""
+        with torch.enable_grad():
+            p.requires_grad_(True)
+            _, y = self.infer_occ(p)
+            grads = torch.autograd.grad(outputs=y, inputs=p, grad_outputs=torch.ones_like(y), create_graph=True, retain_graph=True,
+                                        only_inputs=True, allow_unused=True)[0]
+            return -grads.unsqueeze(1)
 
 
 def encode_position(input, levels, inc_input):

@@ -7,8 +7,12 @@ distortion exactly as they do through the reference's matrix inverses), and ONE 
 `nnr.render_rays` for everything per-sample: stratified / NDC sampling, positional encoding, the 12-layer MLP,
 alpha-compositing, and their backward.
 
+`rendering.normal_loss: True` (reference :133-143; off by default, and no loss term of the reference consumes it) adds the
+normal-consistency vector `out['normal']`: second-order autograd through the MLP trunk for the 2 M surface points, in stock torch
+over the same nn.Linear parameters (OfficialStaticNerf.gradient) -- the fused kernels still render.
+
 Not provided (outside the hot path): the phong / ray-marching visualiser
-(`phong_renderer`, `ray_marching`, `secant`) and the normal-loss branch; they raise NotImplementedError.
+(`phong_renderer`, `ray_marching`, `secant`); they raise NotImplementedError.
 """
 import torch
 import torch.nn as nn
@@ -59,6 +63,7 @@ class Renderer(nn.Module):
         self.model = model.to(device)
         self._z_cache = {}
         self.jitter_window = None   # (first ray, rays in the whole step) when this process renders a shard
+        self.normal_window = None   # (validity of ALL rays of the step, first ray) for the normal term of a shard
 
     def forward(self, pixels, depth, camera_mat, world_mat, scale_mat, rendering_technique, add_noise=True,
                 eval_=False, it=1000000):
@@ -94,9 +99,6 @@ class Renderer(nn.Module):
         batch_size, n_rays, _ = pixels.shape
         if batch_size != 1:
             raise NotImplementedError("batch size 1 is baked into the reference (rendering.py:86-87); so it is here")
-        if cfg['normal_loss'] and not eval_:
-            raise NotImplementedError("rendering.normal_loss needs second-order MLP gradients (reference "
-                                      "rendering.py:133-143); not part of the HIP hot path")
         n_samples = cfg['num_points'] - cfg['outside_steps']
         device = pixels.device
 
@@ -149,13 +151,17 @@ class Renderer(nn.Module):
             relu_sigma=(net.occ_activation != 'softplus'),
             bf16=(str(cfg.get('mfma_dtype', 'fp32')).lower() == 'bf16'))   # rendering.mfma_dtype: fp32 (default) | bf16
 
+        diff_norm = None
+        if cfg['normal_loss'] and not eval_:
+            diff_norm = self._normal_consistency(origin, ray, d_gt, object_mask, it)
+
         if eval_ and cfg['normalise_ray']:                                          # distance -> depth for evaluation (:150-154)
             dist_pred = dist_pred / ray_norm
             d_gt = d_gt / ray_norm
         return RenderOutput({
             'rgb': rgb.reshape(batch_size, -1, 3),
             'z_vals': z_val,
-            'normal': None,
+            'normal': diff_norm,
             'alpha': alpha,
             # dense per-ray values + validity mask; 'depth_pred' / 'depth_gt' (masked) are derived lazily from these
             'dist_dense': dist_pred,
@@ -163,6 +169,25 @@ class Renderer(nn.Module):
             'mask': object_mask,
             'ndc': cfg['sample_option'] == 'ndc',
         })
+
+    def _normal_consistency(self, origin, ray, d_gt, mask, it):
+        """|n(x) - n(x + eps)| at the surface points x the mono depth puts on the valid rays, n = normalised -d(sigma)/dx
+        (reference rendering.py:76-93,133-141).  Stock autograd over the MLP's own parameters (OfficialStaticNerf.gradient); the
+        perturbation draws torch.rand_like(surface_points) right after the jitter draw, as the reference does.  A data-parallel
+        shard draws the whole step's perturbations and keeps the rows of its own valid rays, so every rank's generator stays where
+        the single-process run leaves it."""
+        surface = (origin + ray * d_gt.unsqueeze(-1))[mask]            # dists == d_i on the valid rays (:80-82,92)
+        n = surface.shape[0]
+        if self.normal_window is None:
+            noise = torch.rand_like(surface)
+        else:
+            valid_all, lo = self.normal_window
+            first = int(valid_all[:lo].sum())
+            noise = torch.rand(int(valid_all.sum()), 3, dtype=surface.dtype, device=surface.device)[first:first + n]
+        neigh = surface + (noise - 0.5) * 0.01
+        g = self.model.gradient(torch.cat([surface, neigh], dim=0), it)
+        normals = g[:, 0, :] / (g[:, 0, :].norm(2, dim=1).unsqueeze(-1) + 10 ** (-5))
+        return torch.norm(normals[:n] - normals[n:], dim=-1)
 
     # ------------------------------------------------------------------------------------------------ not on the hot path
     def phong_renderer(self, *args, **kwargs):

@@ -6,9 +6,11 @@ What is different underneath:
   * data-parallel training: when torch.distributed is initialised, every rank sees the same image, the same
     `ray_idx` permutation and the same jitter stream (same seed), renders only its contiguous slice of the rays, scales
     the per-ray losses by the *global* ray / valid-depth counts, and ONE flat all-reduce (RCCL over xGMI) of all
-    gradients after backward reproduces the single-GPU gradient.  Per-image auxiliary losses are
-    computed redundantly and weighted 1/world_size.
-The auxiliary point-cloud / reprojection losses (training.py:280-365) are stock torch, as in the reference.
+    gradients after backward reproduces the single-GPU gradient.  The point-cloud / re-projection
+    losses (training.py:280-365) are means over source points: rank k sums over its shard of the sampling grid with the
+    global normalisers (the O(S^2) nearest-neighbour search shrinks by the world size); the O(cameras) trajectory terms
+    are replicated and weighted 1/world_size.
+The per-image losses run as two fused HIP calls (nnr/aux.py); stock torch only for with_ssim / a learnable focal / CPU.
 """
 import logging
 import os
@@ -72,6 +74,14 @@ class Trainer(object):
         self._warned_geo = False
         self._nan_flag = None      # (pinned host flag, event) of the previous step's isnan(loss), read one step late
         self._nan_host = None
+        # the deferred NaN flag of the newest step is looked at before anything is written to disk (model/checkpoints.py)
+        import weakref
+        from model import checkpoints as _ck
+        ref = weakref.ref(self)
+        _ck.PRE_SAVE_HOOKS[:] = [h for h in _ck.PRE_SAVE_HOOKS if getattr(h, '_trainer', lambda: None)() is not None]
+        hook = lambda: (ref() is not None and ref().flush_nan_check())
+        hook._trainer = ref
+        _ck.PRE_SAVE_HOOKS.append(hook)
         if cfg.get('fuse_optimizers', True):   # training.fuse_optimizers: False keeps torch's default multi-kernel Adam
             for opt in (optimizer, optimizer_pose, optimizer_focal, optimizer_distortion):
                 _use_fused_adam(opt)
@@ -175,9 +185,15 @@ class Trainer(object):
         if render_model:
             renderer = self.model.renderer
             renderer.jitter_window = (lo, n_total) if world > 1 else None
+            renderer.normal_window = None
+            if world > 1 and renderer.cfg.get('normal_loss'):
+                # the normal term perturbs one surface point per VALID ray: the shard needs the validity of all rays to find its rows
+                with torch.no_grad():
+                    d_all = self._gather_depth_all(depth_input, ray_idx, (h, w), depth_affine)
+                renderer.normal_window = (torch.isfinite(d_all) & (d_all != 0), lo)
             out = self.model(p, ray_loc, camera_mat, world_mat, scale_mat, self.rendering_technique, it=it,
                              eval_mode=eval_mode, depth_img=depth_input, img_size=(h, w), depth_affine=depth_affine)
-            renderer.jitter_window = None
+            renderer.jitter_window = renderer.normal_window = None
             rendered_rgb = out['rgb']
             if not (rendered_rgb.is_cuda and self.loss.depth_loss_type == 'l1'):
                 rendered_depth, gt_depth = out['depth_pred'], out['depth_gt']     # masked views, only where the torch loss needs them
@@ -200,6 +216,16 @@ class Trainer(object):
     @staticmethod
     def _inverse(m):
         return camera.inverse4(m) if m.is_cuda else torch.inverse(m)
+
+    def flush_nan_check(self):
+        """Wait for the NaN flag of the newest training step and raise if it is set.  Called before every checkpoint save
+        (CheckpointIO.save -> PRE_SAVE_HOOKS) and by training loops at their end: the per-step check is one step late by design."""
+        if self._nan_flag is not None:
+            host, ev = self._nan_flag
+            self._nan_flag = None
+            ev.synchronize()
+            if bool(host):
+                raise FloatingPointError('NaN loss in the last training step')
 
     def _check_nan(self, loss):
         """The reference stops on a NaN loss (losses.py:204-205).  Reading the flag synchronously (or even enqueueing its
@@ -232,19 +258,7 @@ class Trainer(object):
         if world > 1:
             h_img, w_img = img_size
             with torch.no_grad():   # global count of rays with a usable mono depth (finite, non-zero): no collective needed
-                if depth_input.is_cuda and depth_affine is not None:
-                    d_all = camera.depth_gather_affine(depth_input, ray_idx, depth_affine[0], depth_affine[1], h_img, w_img,
-                                                       depth_affine[2])
-                elif depth_input.is_cuda:
-                    d_all = camera.depth_gather(depth_input, ray_idx, h_img, w_img)          # one launch
-                else:
-                    from model.network import nearest_source_index
-                    hd, wd = depth_input.shape[-2:]
-                    ys = nearest_source_index(torch.div(ray_idx, w_img, rounding_mode='floor'), h_img, hd)
-                    xs = nearest_source_index(ray_idx % w_img, w_img, wd)
-                    d_all = depth_input[0, 0][ys, xs]
-                    if depth_affine is not None:
-                        d_all = (d_all + depth_affine[1]) * depth_affine[0] if depth_affine[2] else d_all * depth_affine[0] + depth_affine[1]
+                d_all = self._gather_depth_all(depth_input, ray_idx, (h_img, w_img), depth_affine)
                 m_total = (torch.isfinite(d_all) & (d_all != 0)).sum().float()   # stays on the device: no sync
         fused = (out is not None and rgb.is_cuda and self.loss.depth_loss_type == 'l1' and 'dist_dense' in out)
         if not fused and world == 1:
@@ -252,9 +266,18 @@ class Trainer(object):
             return loss_dict
         aux, parts = self.loss.aux_terms(rgb_gt, **kwargs)
         if world > 1:
+            # loss_pc / loss_rgb_s arrive as this rank's SHARE (sums over its shard of the source points, _reference_terms); the
+            # remaining per-image terms (trajectory smoothness, depth consistency) are O(cameras) and replicated: weight 1/W
             zero = _zero(rgb_gt)
-            parts = {k: (v if v is zero else v / world) for k, v in parts.items()}   # inactive terms stay the cached 0
-            aux = aux / world if aux is not None else None
+            sharded = ('loss_pc', 'loss_rgb_s') if 'point_shard' in kwargs else ()
+            parts = {k: (v if (v is zero or k in sharded) else v / world) for k, v in parts.items()}   # inactive terms stay the cached 0
+            aux = None
+            for wk, pk in (('weight_dist_1st_loss', 'loss_dist_1st'), ('weight_dist_2nd_loss', 'loss_dist_2nd'),
+                           ('pc_weight', 'loss_pc'), ('rgb_s_weight', 'loss_rgb_s'),
+                           ('depth_consistency_weight', 'loss_depth_consistency')):
+                if w[wk] != 0.0:
+                    term = w[wk] * parts[pk]
+                    aux = term if aux is None else aux + term
         loss_dict = dict(parts)
         zero = _zero(rgb_gt)
         if out is None:
@@ -295,6 +318,24 @@ class Trainer(object):
         self._check_nan(loss_dict['loss'])
         return loss_dict
 
+    @staticmethod
+    def _gather_depth_all(depth_input, ray_idx, img_size, depth_affine):
+        """The (distorted) mono depth of EVERY ray of the step, flat (n_total,) -- what a data-parallel rank needs to know about
+        the rays it does not render: their validity."""
+        h_img, w_img = img_size
+        if depth_input.is_cuda and depth_affine is not None:
+            return camera.depth_gather_affine(depth_input, ray_idx, depth_affine[0], depth_affine[1], h_img, w_img, depth_affine[2]).reshape(-1)
+        if depth_input.is_cuda:
+            return camera.depth_gather(depth_input, ray_idx, h_img, w_img).reshape(-1)          # one launch
+        from model.network import nearest_source_index
+        hd, wd = depth_input.shape[-2:]
+        ys = nearest_source_index(torch.div(ray_idx, w_img, rounding_mode='floor'), h_img, hd)
+        xs = nearest_source_index(ray_idx % w_img, w_img, wd)
+        d_all = depth_input[0, 0][ys, xs]
+        if depth_affine is not None:
+            d_all = (d_all + depth_affine[1]) * depth_affine[0] if depth_affine[2] else d_all * depth_affine[0] + depth_affine[1]
+        return d_all.reshape(-1)
+
     def _reference_terms(self, kwargs, data, img, depth_input, camera_mat, world_mat, scale_input, img_idx, num_cams,
                          h_depth, w_depth, weights, it, out_render_path):
         """Inputs of the point-cloud and surface-reprojection losses between this frame and its reference frame
@@ -323,6 +364,11 @@ class Trainer(object):
         r_rel, t_rel = rel[:, :3, :3], rel[:, :3, 3]
 
         res = (int(h_depth / self.pc_ratio), int(w_depth / self.pc_ratio))
+        world = parallel.world_size()
+        # data parallelism: both losses are means over source points -- rank k owns the points [lo, hi) of the sampling grid
+        shard = parallel.shard_bounds(res[0] * res[1], parallel.rank(), world) if world > 1 else None
+        if shard is not None:
+            kwargs['point_shard'] = shard
         dump = (weights['rgb_s_weight'] != 0.0 and (it % self.vis_reprojection_every) == 0 and out_render_path is not None)
         if d1.is_cuda and not self.optimizer_focal and not self.loss.cfg['with_ssim'] and img.shape[0] == 1 and not dump:
             # one fused forward / backward pair (nnr/aux.py) instead of ~290 small launches; same inputs, same losses
@@ -332,7 +378,7 @@ class Trainer(object):
             i2 = F.interpolate(img2, res, mode='bilinear') if rgb_s else None
             l_pc, l_rgbs, _ = nnr_aux.aux_terms(d1, d2, rel, scale2, i1, i2, camera_mat, self._inverse(camera_mat), res, nl,
                                                 rgb_s=rgb_s, pc=weights['pc_weight'] != 0.0, scale_pcs=bool(self.scale_pcs),
-                                                detach_rgbs_scale=self.detach_rgbs_scale)
+                                                detach_rgbs_scale=self.detach_rgbs_scale, shard=shard or (0, 0))
             kwargs.update(fused_aux=(l_pc, l_rgbs), sample_resolution=res)
             return
         pixel_locations, p_pc = arange_pixels(resolution=res, device=device)

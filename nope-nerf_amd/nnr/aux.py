@@ -15,13 +15,13 @@ def _st():
 
 class _AuxTerms(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, d1_img, d2_img, rel, scale2, img1r, img2r, K, Kinv, hr, wr, nl, flags):
+    def forward(ctx, d1_img, d2_img, rel, scale2, img1r, img2r, K, Kinv, hr, wr, nl, flags, shard):
         lib = L.load()
         dev = d1_img.device
         f32 = dict(dtype=torch.float32, device=dev)
         d1, d2 = d1_img.detach().contiguous().float(), d2_img.detach().contiguous().float()
         hd, wd = d1.shape[-2:]
-        cfg = L.AuxCfg(int(hd), int(wd), int(hr), int(wr), float(nl), int(flags))
+        cfg = L.AuxCfg(int(hd), int(wd), int(hr), int(wr), float(nl), int(flags), int(shard[0]), int(shard[1]))
         n_ws = lib.nnr_aux_workspace_floats(C.byref(cfg))
         if n_ws == 0:
             raise RuntimeError("nnr_aux: bad configuration %r" % ((hd, wd, hr, wr),))
@@ -64,16 +64,18 @@ class _AuxTerms(torch.autograd.Function):
             g_rel = torch.cat([g_rs[:12], torch.zeros(4, **f32)]).view(shr)
         g_s2 = g_rs[12].view(shs) if (need_s2 and shs is not None) else None
         return (g_d1.view(sh1) if need_d1 else None, g_d2.view(sh2) if need_d2 else None, g_rel, g_s2,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 def aux_terms(d1_img, d2_img, rel, scale2, img1r, img2r, K, Kinv, res, nearest_limit, *, rgb_s=True, pc=True, scale_pcs=True,
-              detach_rgbs_scale=False):
+              detach_rgbs_scale=False, shard=(0, 0)):
     """(loss_pc, loss_rgb_s, n_valid) for one frame pair.  d1_img/d2_img: (..., hd, wd) depth maps (scaled + shifted), rel:
-    (..., 4, 4) relative transform, scale2: scalar tensor, img1r/img2r: (..., 3, hr, wr), K/Kinv: (..., 4, 4)."""
+    (..., 4, 4) relative transform, scale2: scalar tensor, img1r/img2r: (..., 3, hr, wr), K/Kinv: (..., 4, 4).
+    shard = (lo, hi): data parallelism -- only the sums over the source points [lo, hi) of the res[0]*res[1] grid, with the global
+    normalisers, so that the SUM over ranks is the single-GPU loss / gradient ((0, 0) = all points)."""
     if not d1_img.is_cuda:
         raise RuntimeError("nnr.aux needs CUDA tensors (no CPU fallback)")
     flags = (L.AUX_RGBS if rgb_s else 0) | (L.AUX_PC if pc else 0) | (L.AUX_SCALE_PCS if scale_pcs else 0) | \
             (L.AUX_DETACH_RGBS if detach_rgbs_scale else 0)
     return _AuxTerms.apply(d1_img, d2_img, rel, scale2 if scale_pcs else None, img1r, img2r, K, Kinv, int(res[0]), int(res[1]),
-                           float(nearest_limit), flags)
+                           float(nearest_limit), flags, tuple(shard))

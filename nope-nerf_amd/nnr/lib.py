@@ -43,7 +43,7 @@ class Params(C.Structure):
 
 class AuxCfg(C.Structure):
     _fields_ = [("hd", C.c_int32), ("wd", C.c_int32), ("hr", C.c_int32), ("wr", C.c_int32), ("nearest_limit", C.c_float),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("shard_lo", C.c_int32), ("shard_hi", C.c_int32)]
 
 
 AUX_RGBS, AUX_PC, AUX_SCALE_PCS, AUX_DETACH_RGBS = 1, 2, 4, 8

@@ -189,6 +189,38 @@ def mlp(params: Dict[str, torch.Tensor], pts: torch.Tensor, viewdir: torch.Tenso
     return rgb, occ
 
 
+def density_gradient(params: Dict[str, torch.Tensor], p: torch.Tensor, pos_levels: int = 10) -> torch.Tensor:
+    """OfficialStaticNerf.gradient -- model/official_nerf.py:46-67: -d(raw density)/dp as (S,1,3), with create_graph=True
+    (the normal-consistency term differentiates it again)."""
+    lin = lambda n, v: F.linear(v, params[n + ".weight"], params[n + ".bias"])
+    with torch.enable_grad():
+        if not p.requires_grad:
+            p = p.requires_grad_(True)
+        e = posenc(p, pos_levels)
+        h = e
+        for n in ("layers0.0", "layers0.2", "layers0.4", "layers0.6"):
+            h = F.relu(lin(n, h))
+        h = torch.cat([h, e], dim=-1)
+        for n in ("layers1.0", "layers1.2", "layers1.4", "layers1.6"):
+            h = F.relu(lin(n, h))
+        y = lin("fc_density", h)
+        g = torch.autograd.grad(outputs=y, inputs=p, grad_outputs=torch.ones_like(y), create_graph=True, retain_graph=True,
+                                only_inputs=True, allow_unused=True)[0]
+    return -g.unsqueeze(1)
+
+
+def normal_consistency(params, cam2: torch.Tensor, ray2: torch.Tensor, d_gt0: torch.Tensor, obj_mask: torch.Tensor,
+                       noise: torch.Tensor) -> torch.Tensor:
+    """model/rendering.py:76-93,133-141: normalised density gradients at the surface points (camera + ray * depth distance, valid
+    rays only) and at neighbours perturbed by (noise - 0.5) * 0.01; `noise` replaces torch.rand_like(surface_points) at :137."""
+    surface = (cam2 + ray2 * d_gt0.unsqueeze(-1))[obj_mask]
+    n = surface.shape[0]
+    neigh = surface + (noise - 0.5) * 0.01
+    g = density_gradient(params, torch.cat([surface, neigh], dim=0))
+    normals = g[:, 0, :] / (g[:, 0, :].norm(2, dim=1).unsqueeze(-1) + 10 ** (-5))
+    return torch.norm(normals[:n] - normals[n:], dim=-1)
+
+
 # ----------------------------------------------------------------------------------------
 # sampling + renderer  (model/rendering.py:36-197)
 # ----------------------------------------------------------------------------------------
@@ -207,11 +239,13 @@ def sample_z(n_rays: int, n_samples: int, near: float, far: float, jitter: Optio
 
 
 def render(params, pixels, depth, camera_mat, world_mat, scale_mat, cfg: dict, *,
-           jitter: Optional[torch.Tensor] = None, eval_: bool = False, chunk: int = 64000) -> dict:
-    """Renderer.nope_nerf -- model/rendering.py:36-167 (normal-loss branch :133-143 excluded).
+           jitter: Optional[torch.Tensor] = None, eval_: bool = False, chunk: int = 64000,
+           normal_noise: Optional[torch.Tensor] = None) -> dict:
+    """Renderer.nope_nerf -- model/rendering.py:36-167.
 
     pixels (1,R,2), depth (1,R,1), matrices (1,4,4).  cfg keys as configs/default.yaml `rendering`
-    plus `occ_activation`.  `jitter` replaces torch.rand at :189 (None == add_noise False)."""
+    plus `occ_activation`.  `jitter` replaces torch.rand at :189 (None == add_noise False); `normal_noise` (M,3) replaces
+    torch.rand_like at :137 when cfg['normal_loss'] is on (the normal-consistency branch :133-143)."""
     n_samples = cfg["num_points"]
     dist_alpha = cfg["dist_alpha"]
     option = cfg["sample_option"]
@@ -270,6 +304,9 @@ def render(params, pixels, depth, camera_mat, world_mat, scale_mat, cfg: dict, *
         rgb_out = rgb_out + (1.0 - torch.sum(w, -1).unsqueeze(-1))                  # :145-147
 
     d_gt0 = d_gt[0]
+    normal = None
+    if cfg.get("normal_loss", False) and not eval_:                                 # :133-143
+        normal = normal_consistency(params, cam2, ray2, d_gt0, obj_mask, normal_noise)
     if eval_ and cfg["normalise_ray"]:                                              # :150-154
         dist = dist / ray_norm[0]
         d_gt0 = d_gt0 / ray_norm[0]
@@ -279,7 +316,7 @@ def render(params, pixels, depth, camera_mat, world_mat, scale_mat, cfg: dict, *
     return {
         "rgb": rgb_out.reshape(1, -1, 3),
         "z_vals": z.squeeze(-1),
-        "normal": None,
+        "normal": normal,
         "depth_pred": dist[obj_mask],
         "depth_gt": depth_gt,
         "alpha": alpha,
@@ -406,7 +443,7 @@ def aux_scope(pose_r, pose_t, scales, shifts, cam: int, ref: int, camera_mat, de
 
 def train_step_scope(params, pose_r, pose_t, scales, shifts, cam: int, camera_mat, depth_img, img, img_size,
                      ray_idx, jitter, cfg: dict, *, rgb_weight=1.0, depth_weight=0.04, rgb_type="l1",
-                     shift_first=False):
+                     shift_first=False, normal_noise=None):
     """The slice of Trainer.compute_loss that is on the hot path -- model/training.py:235-274 + loss heads.
     All leaves (params, pose_r, pose_t, scales, shifts) may require grad.  Returns (loss, out)."""
     h, w = img_size
@@ -418,7 +455,7 @@ def train_step_scope(params, pose_r, pose_t, scales, shifts, cam: int, camera_ma
     rgb_gt = img.view(1, 3, h * w).permute(0, 2, 1)[:, ray_idx]                     # :258-259
     p = pixel_grid(h, w)[:, ray_idx]                                                # :260-261
     depth = nearest_gather(d_img, (h, w), ray_idx)
-    out = render(params, p, depth, camera_mat, world_mat, torch.eye(4).unsqueeze(0), cfg, jitter=jitter)
+    out = render(params, p, depth, camera_mat, world_mat, torch.eye(4).unsqueeze(0), cfg, jitter=jitter, normal_noise=normal_noise)
     loss, lrgb, ldep = loss_heads(out, rgb_gt, rgb_weight, depth_weight, rgb_type)
     out["loss_rgb"], out["loss_depth"] = lrgb, ldep
     return loss, out

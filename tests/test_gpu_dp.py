@@ -90,3 +90,41 @@ def test_rccl_flat_allreduce_world1():
         assert float(a.grad.sum()) == 3000.0 and float(b.grad.abs().sum()) == 0.0 and float(ld['loss']) == 2.5
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("mid", 2), ("last", 3), ("mid", 8)])
+def test_virtual_ranks_shard_the_per_image_losses(name, world, monkeypatch):
+    """First training phase (pc_weight = rgb_s_weight = 1): each virtual rank runs the fused per-image kernels on its shard of the
+    source points (nnr_aux_cfg.shard_lo/hi); the SUM of the ranks' losses and gradients is the reference's single-process step
+    (tests/golden/aux_terms.npz, minted from the reference Trainer.train_step)."""
+    import numpy as np
+    import test_aux_terms as ta
+    from nnr import parallel
+    G = ta.GOLD
+    inp = ta._inp(name)
+    cam, ref = int(G[f"{name}.cam"]), int(G[f"{name}.ref"])
+    ray_idx, jitter = torch.from_numpy(G[f"{name}.ray_idx"]), torch.from_numpy(G[f"{name}.jitter"])
+    monkeypatch.setattr(torch, "randperm", lambda n, device=None, **kw: torch.cat([ray_idx, torch.zeros(n - ta.R, dtype=torch.int64)]).to(device))
+    real_rand = torch.rand
+    monkeypatch.setattr(torch, "rand", lambda *s, device=None, **kw: jitter.to(device) if tuple(s) == (1, ta.R, ta.N) else real_rand(*s, device=device, **kw))
+    monkeypatch.setattr(parallel.dist, "all_reduce", lambda t, op=None: t)
+    monkeypatch.setattr(parallel, "world_size", lambda: world)
+    dev = torch.device(DEV)
+    data = {"img": inp["img"].to(dev), "img.idx": cam, "img.dpt": inp["dpt"].to(dev), "img.camera_mat": inp["K"].to(dev),
+            "img.scale_mat": torch.eye(4).unsqueeze(0).to(dev), "img.ref_imgs": inp["ref_img"].to(dev),
+            "img.ref_dpts": inp["ref_dpt"].to(dev), "img.ref_idxs": ref}
+    tot_l, tot_g = {}, {}
+    for r in range(world):
+        monkeypatch.setattr(parallel, "rank", lambda r=r: r)
+        tr, pose, distn = ta._trainer(inp, dev)
+        ld = tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
+        for k in ("loss", "loss_pc", "loss_rgb_s", "loss_rgb", "loss_depth"):
+            tot_l[k] = tot_l.get(k, 0.0) + float(ld[k])
+        for k, p in (("pose_r", pose.r), ("pose_t", pose.t), ("scales", distn.global_scales), ("shifts", distn.global_shifts)):
+            g = p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+            tot_g[k] = tot_g.get(k, 0.0) + g
+    for k, v in tot_l.items():
+        np.testing.assert_allclose(v, float(G[f"{name}.out.{k}"]), rtol=0, atol=2e-5, err_msg=k)
+    for k, g in tot_g.items():
+        ref_g = G[f"{name}.g.{k}"]
+        assert float(np.abs(g - ref_g).max()) / max(1.0, float(np.abs(ref_g).max())) <= 1e-4, k

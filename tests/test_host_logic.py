@@ -192,8 +192,30 @@ def test_bench_traffic_lookup_finds_the_committed_pmc_summary():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     for k in ("mlp_fwd", "mlp_dgrad", "mlp_wgrad"):
-        t = bench._hbm_traffic(k)
+        t, src = bench._hbm_traffic(k, False, (1024, 192))
         assert t is not None and 1e9 < t < 1e10, (k, t)
+        assert src.startswith("profiles/") and "offline" in src       # the line says the figure is not measured in the run
+    assert bench._hbm_traffic("mlp_fwd", False, (7, 7)) == (None, None)   # no summary at that shape: null, never a stale number
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it re-executes under torch.distributed.run (one rank per GPU).  Here, without
+    a GPU: --dry-run joins a gloo group instead of touching the device, all-reduces, and rank 0 prints the one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["dry_run"] is True
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run"], capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0 and json.loads(r1.stdout.strip().splitlines()[-1])["n_gpus"] == 1
 
 
 def test_scene_training_loop_on_the_cpu_stand_in(monkeypatch, tmp_path):
@@ -290,3 +312,26 @@ def test_ctypes_signatures_have_the_arity_of_the_header():
             assert len(argtypes) == n, (name, len(argtypes), n)
             checked += 1
     assert checked >= 30
+
+
+def test_checkpoint_roundtrip_with_numpy_scalar(tmp_path):
+    """train.py stores `loss_val_best = np.array(psnr_window).mean()` (a numpy.float64) in model.pt once the PSNR window is full;
+    torch >= 2.6 refuses to unpickle that with its default weights_only=True.  Trusted local files: they must load."""
+    import model as mdl
+    cfg = make_cfg()
+    net = mdl.OfficialStaticNerf(cfg)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    io = mdl.CheckpointIO(str(tmp_path), model=net, optimizer=opt)
+    best = np.array([21.5, 22.5]).mean()
+    assert isinstance(best, np.floating)
+    io.save("model.pt", epoch_it=1001, it=14014, loss_val_best=best)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(1.0)
+    scalars = io.load("model.pt")
+    assert scalars["epoch_it"] == 1001 and scalars["it"] == 14014 and float(scalars["loss_val_best"]) == 22.0
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    with pytest.raises(FileExistsError):       # sic: the exception type train.py:64-67 catches for "no checkpoint yet"
+        io.load("missing.pt")

@@ -158,3 +158,70 @@ def test_two_rank_training_loop_follows_the_single_process_run(tmp_path):
     assert len(curves[1]) == len(curves[2]) == 4
     # Adam divides by sqrt(v) + 1e-8: fp32 summation-order differences of the all-reduce show up at 1e-5 in the poses
     assert abs(a["psnr"] - b["psnr"]) <= 2e-3 and abs(a["ate"] - b["ate"]) <= 1e-4 and abs(a["rpe_rot_deg"] - b["rpe_rot_deg"]) <= 5e-3, (a, b)
+
+
+# ---- first-phase per-image losses (point cloud + surface re-projection) sharded by source points ---------------------------
+def _aux_step(name, monkeypatch_like=None):
+    """One Trainer.train_step with pc_weight = rgb_s_weight = 1 on the reference golden's inputs and draws (tests/golden/aux_terms.npz,
+    minted from the REFERENCE Trainer.train_step)."""
+    import numpy as np
+    import model.rendering as rendering
+    import oracle_backend
+    import test_aux_terms as ta
+    rendering.nnr.render_rays = oracle_backend.render_rays
+    G = ta.GOLD
+    inp = ta._inp(name)
+    cam, ref = int(G[f"{name}.cam"]), int(G[f"{name}.ref"])
+    tr, pose, distn = ta._trainer(inp, torch.device("cpu"))
+    ray_idx, jitter = torch.from_numpy(G[f"{name}.ray_idx"]), torch.from_numpy(G[f"{name}.jitter"])
+    real_randperm, real_rand = torch.randperm, torch.rand
+    torch.randperm = lambda n, device=None, **kw: torch.cat([ray_idx, torch.zeros(n - ta.R, dtype=torch.int64)])
+    torch.rand = lambda *s, device=None, **kw: jitter if tuple(s) == (1, ta.R, ta.N) else real_rand(*s, device=device, **kw)
+    try:
+        data = {"img": inp["img"], "img.idx": cam, "img.dpt": inp["dpt"], "img.camera_mat": inp["K"], "img.scale_mat": torch.eye(4).unsqueeze(0),
+                "img.ref_imgs": inp["ref_img"], "img.ref_dpts": inp["ref_dpt"], "img.ref_idxs": ref}
+        ld = tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
+    finally:
+        torch.randperm, torch.rand = real_randperm, real_rand
+    losses = {k: float(ld[k]) for k in ("loss", "loss_pc", "loss_rgb_s", "loss_rgb", "loss_depth")}
+    zeros = lambda p: torch.zeros_like(p)
+    grads = {"pose_r": pose.r.grad if pose.r.grad is not None else zeros(pose.r), "pose_t": pose.t.grad if pose.t.grad is not None else zeros(pose.t),
+             "scales": distn.global_scales.grad, "shifts": distn.global_shifts.grad}
+    return losses, {k: v.detach().numpy().copy() for k, v in grads.items()}
+
+
+def _aux_worker(rank, world, port, name, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        out = _aux_step(name)
+        if rank == 0:
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("mid", 2), ("last", 3)])
+def test_per_image_losses_sharded_by_source_points_equal_the_reference_golden(name, world):
+    """Rank k evaluates the point-cloud / re-projection sums over its shard of the sampling grid (the O(S^2) nearest-neighbour
+    search shrinks by the world size), normalisers stay global; after the flat all-reduce losses and pose / distortion
+    gradients are the REFERENCE's single-process values (golden minted by oracle/gen_golden_aux.py)."""
+    import numpy as np
+    import test_aux_terms as ta
+    G = ta.GOLD
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_aux_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    losses, grads = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k, v in losses.items():
+        np.testing.assert_allclose(v, float(G[f"{name}.out.{k}"]), rtol=0, atol=1e-5, err_msg=k)
+    for k, g in grads.items():
+        ref_g = G[f"{name}.g.{k}"]
+        assert float(np.abs(g - ref_g).max()) / max(1.0, float(np.abs(ref_g).max())) <= 1e-4, k
