@@ -287,7 +287,7 @@ def cpu_baseline(sample_rays=192, warmup=2, steps=5):
                       f'warm-ups, torch {torch.__version__} CPU, {threads} threads on a {host_cores}-core host'}
 
 
-def cpu_config0(warmup=2, steps=5):
+def cpu_config0(warmup=1, steps=3):
     """BASELINE configs[0] -- the reference's own CPU-runnable case: configs/Tanks/Ignatius.yaml settings, 32 rays x 64 samples,
     hidden_dim 128 (the reference architecture at D=128; `model.num_layers` is unused there), FULL training step
     with the first-phase per-image losses on (point cloud + surface re-projection, on 216x384 mono-depth maps -> a 54x96 sampling
@@ -297,7 +297,7 @@ def cpu_config0(warmup=2, steps=5):
     host_cores, cpu_model = _host_cpu()
     threads = min(host_cores, 32)
     torch.set_num_threads(threads)
-    R, N, D, dh, dw = 32, 64, 128, 216, 384
+    R, N, D, dh, dw = 32, 64, 128, 108, 192
     g = torch.Generator().manual_seed(0)
     params = {k: v.requires_grad_(True) for k, v in orc.init_params(D, 1).items()}
     pose_r = (0.01 * torch.randn(N_CAMS, 3, generator=g)).requires_grad_(True)
@@ -321,7 +321,7 @@ def cpu_config0(warmup=2, steps=5):
         ts.append(time.perf_counter() - t0)
     med = float(np.median(ts[warmup:]))
     return {'workload': 'BASELINE configs[0]: Tanks/Ignatius settings, 32 rays x 64 samples, D=128, full step incl. per-image losses '
-                        '(54x96 grid), CPU', 'ms_per_step': round(med * 1e3, 3), 'value': round(R / med, 1), 'unit': 'rays/s',
+                        '(27x48 grid), CPU', 'ms_per_step': round(med * 1e3, 3), 'value': round(R / med, 1), 'unit': 'rays/s',
             'kind': 'port', 'threads': threads, 'host_cores': host_cores, 'cpu': cpu_model,
             'sample': f'median of {steps} steps after {warmup} warm-ups'}
 

@@ -223,6 +223,115 @@ Plan build_plan(const nnr_cfg* c) {
 
 size_t plan_bytes(const Plan& p) { return p.jobs.size() * sizeof(WgradJob) + p.wave_first.size() * sizeof(int32_t); }
 
+// ---- weight-gradient plan of the bf16 training mode (nnr_wgrad_bf16.hip) ------------------------------------------------------
+// Units = the products dW = Dlt^T X of the 12 layers (the D + 63 wide skip layer as two units, the feature layer merged into the
+// colour-hidden one, the density head riding on the merged unit's extra gradient group), each with its tiling over the four
+// waves of a workgroup.  The kernel is bound by streaming the operands once, so a unit's cost per 32-sample chunk is the KiB it
+// stages; the units form one tape of (unit, chunk) positions that is cut into equal spans, one per workgroup (a span that
+// crosses a unit boundary becomes two jobs).  Outputs = where the rectangles of a unit's product go.
+struct BUnit {
+    int d_plane, d_g0, d_groups, x_plane, x_g0, x_groups, MT, NT, WR, WC, bias;
+};
+struct BPlan {
+    std::vector<WgradJobB> jobs;
+    std::vector<int32_t> block_first;   // n_blocks + 1
+    std::vector<WgradOutB> outs;
+};
+
+void bf16_units(int D, std::vector<BUnit>& units, std::vector<WgradOutB>& outs) {
+    const int G = D / 16, Gh = D / 32;            // groups of a D-wide / D/2-wide plane
+    const bool big = D == 256;
+    auto out = [&](int unit, int layer, int d_row, int n_rows, int w_row, int x_col, int n_cols, int w_col, int ldw, int bias) {
+        const BUnit& u = units[unit];
+        outs.push_back(WgradOutB{unit, layer, d_row, n_rows, w_row, x_col, n_cols, w_col, ldw, bias, -1, u.MT, u.NT, u.WR, u.WC, 0});
+    };
+    auto dxd = [&](int layer, int dpl, int xpl, int ldw) {          // D x D: 256 -> four waves of 4 x 4 tiles, 128 -> of 2 x 2
+        units.push_back(BUnit{dpl, 0, G, xpl, 0, G, big ? 4 : 2, big ? 4 : 2, 2, 2, 1});
+        out((int)units.size() - 1, layer, 0, D, 0, 0, D, 0, ldw, 1);
+    };
+    auto dxe = [&](int layer, int dpl, int w_col, int ldw, int bias) {   // D x 63 against the bf16 copy of the position encoding
+        units.push_back(BUnit{dpl, 0, G, P_XE16, 0, kPosPad / 16, big ? 2 : 1, 2, 4, 1, bias});
+        out((int)units.size() - 1, layer, 0, D, 0, 0, kPosReal, w_col, ldw, bias);
+    };
+    dxe(0, P_DH1 + 0, 0, kPosReal, 1);
+    dxd(1, P_DH1 + 1, P_XH1 + 0, D);
+    dxd(2, P_DH1 + 2, P_XH1 + 1, D);
+    dxd(3, P_DH1 + 3, P_XH1 + 2, D);
+    dxd(4, P_DH1 + 4, P_XH1 + 3, D + kPosReal);
+    dxe(4, P_DH1 + 4, D, D + kPosReal, 0);
+    dxd(5, P_DH1 + 5, P_XH1 + 4, D);
+    dxd(6, P_DH1 + 6, P_XH1 + 5, D);
+    dxd(7, P_DH1 + 7, P_XH1 + 6, D);
+    // merged colour-hidden matrix W' (D/2 x D) and the density row: gradient operand = P_DG groups 0..Gh (the last group holds
+    // d rgb_pre[0..2], d sigma_raw), activation operand = hidden 8
+    units.push_back(BUnit{P_DG, 0, Gh + 1, P_XH1 + 7, 0, G, big ? 5 : 3, big ? 2 : 1, 1, 4, 1});
+    out((int)units.size() - 1, kMergedLayer, 0, D / 2, 0, 0, D, 0, D, 1);
+    out((int)units.size() - 1, 8, D / 2 + 3, 1, 0, 0, D, 0, D, 1);
+    // direction-encoding columns of the colour-hidden layer
+    units.push_back(BUnit{P_DG, 0, Gh, P_XF16, 0, kDirPad / 16, 1, 1, big ? 4 : 2, 1, 0});
+    out((int)units.size() - 1, 10, 0, D / 2, 0, 0, kDirReal, D, D + kDirReal, 0);
+    // rgb head: the 3 output-gradient rows against the colour-hidden activations
+    units.push_back(BUnit{P_DG, Gh, 1, P_XG, 0, Gh, 1, 1, 1, big ? 4 : 2, 1});
+    out((int)units.size() - 1, 11, 0, 3, 0, 0, D / 2, 0, D / 2, 1);
+}
+
+constexpr int64_t kMinTapePerBlock = 16 * 32;   // KiB: at least ~16 full stages per workgroup, or the ring never fills
+
+BPlan build_plan_bf16(const nnr_cfg* c) {
+    const WsLayout w = ws_layout(c);
+    BPlan p;
+    std::vector<BUnit> units;
+    bf16_units(c->hidden, units, p.outs);
+    const int64_t chunks = w.S_pad / 32;
+    std::vector<int64_t> cost(units.size()), start(units.size() + 1, 0);
+    for (size_t u = 0; u < units.size(); ++u) {
+        cost[u] = units[u].d_groups + units[u].x_groups;
+        start[u + 1] = start[u] + cost[u] * chunks;
+    }
+    const int64_t tape = start[units.size()];
+    static const int max_blocks = [] {
+        const char* e = std::getenv("NNR_WGRAD_MAX_BLOCKS");
+        return e ? std::max(1, std::atoi(e)) : kMaxBlocks;
+    }();
+    const int n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(max_blocks, tape / kMinTapePerBlock));
+    // cut u-th unit at chunk boundaries: position x on the tape inside unit u -> chunk round((x - start[u]) / cost[u])
+    auto cut_chunk = [&](size_t u, int64_t x) {
+        if (x <= start[u]) return (int64_t)0;
+        if (x >= start[u + 1]) return chunks;
+        return std::min(chunks, (x - start[u] + cost[u] / 2) / cost[u]);
+    };
+    p.block_first.push_back(0);
+    for (int b = 0; b < n_blocks; ++b) {
+        const int64_t lo = tape * b / n_blocks, hi = tape * (b + 1) / n_blocks;
+        for (size_t u = 0; u < units.size(); ++u) {
+            if (hi <= start[u] || lo >= start[u + 1]) continue;
+            const int64_t c0 = cut_chunk(u, lo), c1 = cut_chunk(u, hi);
+            if (c1 <= c0) continue;
+            const BUnit& un = units[u];
+            int dp = 0, xp = 0;
+            const int64_t d_off = w.plane(un.d_plane, &dp), x_off = w.plane(un.x_plane, &xp);   // floats; pitch = floats per sample
+            p.jobs.push_back(WgradJobB{4 * d_off + 1024ll * un.d_g0, 4 * x_off + 1024ll * un.x_g0, 4 * 32 * dp, 4 * 32 * xp, un.d_groups,
+                                       un.x_groups, (int32_t)u, un.MT, un.NT, un.WR, un.WC, (int32_t)c0, (int32_t)c1, un.bias, 0, -1});
+        }
+        p.block_first.push_back((int32_t)p.jobs.size());
+    }
+    // chain the jobs of every unit in sample order (they are generated in that order)
+    std::vector<int> last(units.size(), -1), count(units.size(), 0), first(units.size(), -1);
+    for (size_t j = 0; j < p.jobs.size(); ++j) {
+        const int u = p.jobs[j].unit;
+        p.jobs[j].split = count[u]++;
+        if (last[u] >= 0) p.jobs[last[u]].next_split = (int32_t)j;
+        else first[u] = (int)j;
+        last[u] = (int)j;
+    }
+    for (auto& o : p.outs) o.first_job = first[o.unit];
+    return p;
+}
+
+size_t plan_bytes(const BPlan& p) {
+    return p.jobs.size() * sizeof(WgradJobB) + p.block_first.size() * sizeof(int32_t) + p.outs.size() * sizeof(WgradOutB);
+}
+
 }  // namespace
 
 extern "C" {
@@ -250,9 +359,12 @@ size_t nnr_packed_floats(const nnr_cfg* cfg) {
 size_t nnr_workspace_floats(const nnr_cfg* cfg) {
     if (check_cfg(cfg) != NNR_OK) return 0;
     const WsLayout w = ws_layout(cfg);
-    // training: the planes, one partial slot per weight-gradient job, then dW' (D/2 x D) and db' (D/2)
+    // training: the planes, one partial slot per weight-gradient job (bf16 mode: four wave slots per workgroup job), then dW'
+    // (D/2 x D) and db' (D/2)
     const size_t merged = (size_t)(cfg->hidden / 2) * cfg->hidden + cfg->hidden / 2;
-    return (size_t)w.total() + (w.train ? build_plan(cfg).jobs.size() * (size_t)kSlotFloats + merged : 0);
+    if (!w.train) return (size_t)w.total();
+    const size_t slots = w.bf16 ? build_plan_bf16(cfg).jobs.size() * 4 * (size_t)kSlotBFloats : build_plan(cfg).jobs.size() * (size_t)kSlotFloats;
+    return (size_t)w.total() + slots + merged;
 }
 
 int64_t nnr_ws_plane(const nnr_cfg* cfg, int pl, int32_t* pitch_out) {
@@ -265,34 +377,39 @@ int64_t nnr_ws_plane(const nnr_cfg* cfg, int pl, int32_t* pitch_out) {
 
 size_t nnr_plan_bytes(const nnr_cfg* cfg) {
     if (check_cfg(cfg) != NNR_OK) return 0;
+    if (is_bf16(cfg)) return plan_bytes(build_plan_bf16(cfg));
     return plan_bytes(build_plan(cfg));
 }
 
 int nnr_plan_counts(const nnr_cfg* cfg, int32_t* n_jobs, int32_t* n_waves) {
     int rc = check_cfg(cfg);
     if (rc != NNR_OK) return rc;
+    if (is_bf16(cfg)) {   // bf16 mode: workgroup jobs, four waves per workgroup
+        const BPlan p = build_plan_bf16(cfg);
+        if (n_jobs) *n_jobs = (int32_t)p.jobs.size();
+        if (n_waves) *n_waves = 4 * ((int32_t)p.block_first.size() - 1);
+        return NNR_OK;
+    }
     const Plan p = build_plan(cfg);
     if (n_jobs) *n_jobs = (int32_t)p.jobs.size();
     if (n_waves) *n_waves = (int32_t)p.wave_first.size() - 1;
     return NNR_OK;
 }
 
-// The bf16 weight-gradient jobs decide at compile time, from the tile shape alone, which operand planes are stored as bf16
-// (nnr_wgrad.hip): verify that rule against the planes the units actually name.
-static bool bf16_operand_rule_holds(int D) {
-    auto is_bf16_plane = [](int p) { return (p >= P_XH1 && p < P_XH1 + 8) || p == P_XG || (p >= P_DH1 && p < P_DH1 + 8) || p == P_DG; };
-    for (const Unit& u : wgrad_units(D)) {
-        const bool d_rule = u.j.MI != 1, x_rule = u.j.NI == 4 || u.j.MI == 1;
-        if (is_bf16_plane(u.j.d_plane) != d_rule || is_bf16_plane(u.j.x_plane) != x_rule) return false;
-    }
-    return true;
-}
-
 int nnr_plan_build(const nnr_cfg* cfg, void* plan_host) {
     int rc = check_cfg(cfg);
     if (rc != NNR_OK) return rc;
     if (!plan_host) return NNR_E_BADCFG;
-    if (is_bf16(cfg) && !bf16_operand_rule_holds(cfg->hidden)) return NNR_E_UNSUPPORTED;
+    if (is_bf16(cfg)) {   // layout: WgradJobB[n_jobs], int32 block_first[n_blocks + 1], WgradOutB[n_outs]
+        const BPlan p = build_plan_bf16(cfg);
+        char* out = static_cast<char*>(plan_host);
+        std::memcpy(out, p.jobs.data(), p.jobs.size() * sizeof(WgradJobB));
+        out += p.jobs.size() * sizeof(WgradJobB);
+        std::memcpy(out, p.block_first.data(), p.block_first.size() * sizeof(int32_t));
+        out += p.block_first.size() * sizeof(int32_t);
+        std::memcpy(out, p.outs.data(), p.outs.size() * sizeof(WgradOutB));
+        return NNR_OK;
+    }
     const Plan p = build_plan(cfg);   // layout: WgradJob[n_jobs], then int32 wave_first[n_waves + 1]
     std::memcpy(plan_host, p.jobs.data(), p.jobs.size() * sizeof(WgradJob));
     std::memcpy(static_cast<char*>(plan_host) + p.jobs.size() * sizeof(WgradJob), p.wave_first.data(),
@@ -333,6 +450,10 @@ int nnr_mlp_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, cons
         a.ws_xh = ws + plane(w, P_XH1);
         a.ws_xf = ws + plane(w, P_XF);
         a.ws_xg = ws + plane(w, P_XG);
+        if (w.bf16) {
+            a.ws_xe16 = ws + plane(w, P_XE16);
+            a.ws_xf16 = ws + plane(w, P_XF16);
+        }
         a.ws_mask = reinterpret_cast<uint32_t*>(ws + plane(w, P_MASK));
     }
     a.S = w.S; a.S_pad = w.S_pad; a.N = cfg->n_samples;
@@ -403,6 +524,29 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const float* packed, const nnr_param_grads
     if (rc != NNR_OK) return rc;
     if (!(cfg->flags & NNR_F_TRAIN) || !packed || !g || !plan || !ws) return NNR_E_BADCFG;
     const WsLayout w = ws_layout(cfg);
+    if (w.bf16) {
+        WgradBArgs b{};
+        for (int i = 0; i < 12; ++i) {
+            if (!g->weight[i] || !g->bias[i]) return NNR_E_BADCFG;
+            b.gw[i] = g->weight[i];
+            b.gb[i] = g->bias[i];
+        }
+        const BPlan p = build_plan_bf16(cfg);   // host-only arithmetic, microseconds: the counts that locate the tables in `plan`
+        b.n_jobs = (int)p.jobs.size();
+        b.n_blocks = (int)p.block_first.size() - 1;
+        b.n_outs = (int)p.outs.size();
+        b.jobs = static_cast<const WgradJobB*>(plan);
+        b.block_first = reinterpret_cast<const int32_t*>(b.jobs + b.n_jobs);
+        b.outs = reinterpret_cast<const WgradOutB*>(b.block_first + b.n_blocks + 1);
+        b.ws = ws;
+        b.slots = ws + w.total();
+        b.gw[kMergedLayer] = b.slots + (size_t)b.n_jobs * 4 * kSlotBFloats;
+        b.gb[kMergedLayer] = b.gw[kMergedLayer] + (size_t)(cfg->hidden / 2) * cfg->hidden;
+        b.packed = packed;
+        b.D = cfg->hidden;
+        hipError_t e = launch_wgrad_bf16(b, (hipStream_t)stream);
+        return e == hipSuccess ? NNR_OK : hip_fail(e);
+    }
     WgradArgs a{};
     for (int i = 0; i < 12; ++i) {
         if (!g->weight[i] || !g->bias[i]) return NNR_E_BADCFG;
@@ -427,7 +571,7 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const float* packed, const nnr_param_grads
     a.gb[kMergedLayer] = a.gw[kMergedLayer] + (size_t)(cfg->hidden / 2) * cfg->hidden;
     a.packed = packed;
     a.D = cfg->hidden;
-    a.bf16 = is_bf16(cfg) ? 1 : 0;
+    a.bf16 = 0;
     hipError_t e = launch_wgrad(a, (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }

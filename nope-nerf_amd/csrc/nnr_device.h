@@ -266,6 +266,7 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
 // stash, masks.  Per row: MT MFMAs of 32 cycles against the same non-MFMA work as two fp32 k-groups, so this variant is
 // bound by issue / HBM, not by the matrix pipe.  PPG counts units per fp32 k-group; a row runs twice as many.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kBlockBf16 = 512;   // bf16 elements per 1 KiB block of a tile-major plane (nnr_layout.h)
 
 template <int NIN>
 __device__ __forceinline__ bf16x8 pack_row(const float (&in)[NIN], int b) {
@@ -275,10 +276,10 @@ __device__ __forceinline__ bf16x8 pack_row(const float (&in)[NIN], int b) {
     return q;
 }
 
-// STASH: 0 = none; 1 = the input rows go to a bf16 plane (hidden activations, pre-activation gradients: exactly the 8 bf16 values
-// the MFMA of that row consumes, one 16-byte store per lane -- `stash` is then a bf16 element pointer in disguise, see
-// stash_row()); 2 = to an fp32 plane as in the fp32 kernels (the encodings, which the backward of the encodings reads back at
-// full precision).
+// STASH: 0 = none; 1 = the input rows go to a tile-major bf16 plane (hidden activations, pre-activation gradients: exactly the 8
+// bf16 values the MFMA of that row consumes, one 16-byte store per lane = one 1 KiB block per wave -- `stash` is then a bf16
+// element pointer in disguise, see stash_row()); 2 = to an fp32 plane as in the fp32 kernels (the encodings, which the backward
+// of the encodings reads back at full precision).
 template <int KT, int MT, int STASH, int NSIDE_, int PPG_, int SHIFT, class Side, int NACC, int NIN>
 __device__ __forceinline__ void gemm_part_bf16(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
                                                float* stash, const Side& side) {
@@ -326,8 +327,8 @@ __device__ __forceinline__ void gemm_part_bf16(f32x16 (&acc)[NACC], const float 
                         *reinterpret_cast<f32x4*>(stash + 16 * g) = f32x4{in[8 * g], in[8 * g + 1], in[8 * g + 2], in[8 * g + 3]};
                         *reinterpret_cast<f32x4*>(stash + 16 * g + 8) = f32x4{in[8 * g + 4], in[8 * g + 5], in[8 * g + 6], in[8 * g + 7]};
                     } else if constexpr (STASH == 1) {   // bq = features 16g + 4h + {0..3}, 16g + 8 + 4h + {0..3} of this lane's sample:
-                        // ONE 16-byte store: inside every 16-feature group of a bf16 plane the two middle quads are swapped (stash_row)
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(stash) + 16 * g) = __builtin_bit_cast(f32x4, bq);
+                        // the lane's 16 bytes of block (chunk, g) of a tile-major plane -- the wave writes the whole 1 KiB block
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(stash) + kBlockBf16 * g) = __builtin_bit_cast(f32x4, bq);
                     }
                 } else if (f == 2) {
                     if constexpr (NSIDE > 0) {
@@ -371,16 +372,19 @@ __device__ __forceinline__ void gemm_sel(f32x16 (&acc)[NACC], const float (&in)[
     if constexpr (BF16) gemm_part_bf16<KT, MT, STASH, NSIDE, PPG, SHIFT>(acc, in, pipe, p0, stash, side);
     else gemm_part<KT, MT, (STASH != 0), NSIDE, PPG, SHIFT>(acc, in, pipe, p0, stash, side);
 }
-// Where a lane starts writing its sample's row of a stash plane of `width` features: row-major [sample][feature] planes.
-// In the bf16 planes (bf16 training mode) the features of every group of 16 are stored in the order 0-3, 8-11, 4-7, 12-15: a
-// lane's MFMA operand row -- features 16 g + 4 half + {0..3} and 16 g + 8 + 4 half + {0..3} -- is then 16 contiguous bytes at
-// element 16 g + 8 half, ONE store per row where the natural order needs two 8-byte ones (the bf16 kernels are bound by
-// instruction issue: forward 0.46 -> 0.33 ms, dgrad 0.45 -> 0.31 ms), and the weight-gradient kernel still finds every sample's
-// features in one row.  Feature f of a row sits at element 16 (f / 16) + 8 ((f % 8) / 4) + 4 ((f % 16) / 8) + f % 4.
+// Where a lane starts writing its sample's part of a stash plane of `width` features.  fp32 planes are row-major [sample][feature]:
+// the lane's row, + 4 * half.  The bf16 planes of the bf16 training mode are TILE-MAJOR (nnr_layout.h): 1 KiB blocks [chunk of 32
+// samples][group of 16 features][lane][8 bf16]; the lane's 16 bytes of group g sit at the returned pointer + 512 g bf16 elements, so
+// that a row-step's stash store is one fully coalesced 1 KiB wave-store (gemm_part_bf16).  `row` may carry a plane index (row = plane
+// * S_pad + sample; S_pad is a multiple of 32).
 template <bool BF16>
-__device__ __forceinline__ float* stash_row(float* plane, int64_t row, int width, int col) {
-    if constexpr (BF16) return reinterpret_cast<float*>(reinterpret_cast<__bf16*>(plane) + row * width + 2 * col);
-    else return plane + row * width + col;
+__device__ __forceinline__ float* stash_row(float* plane, int64_t row, int width, int half) {
+    if constexpr (BF16) {
+        const int64_t c = row & 31;
+        return reinterpret_cast<float*>(reinterpret_cast<__bf16*>(plane) + (row - c) * width + (32 * half + c) * 8);
+    } else {
+        return plane + row * width + 4 * half;
+    }
 }
 template <bool BF16, int KT, int MT, int STASH = 0, int NACC, int NIN>
 __device__ __forceinline__ void gemm_sel(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,

@@ -18,6 +18,7 @@ struct MlpFwdArgs {
     float* ws_xh;     // 8 x (S_pad,D)
     float* ws_xf;     // (S_pad,32): direction encoding
     float* ws_xg;     // (S_pad,D/2)
+    float *ws_xe16, *ws_xf16;   // bf16 training: tile-major bf16 copies of the encodings (nnr_layout.h)
     uint32_t* ws_mask;
     int64_t S, S_pad;
     int N;
@@ -70,6 +71,19 @@ struct WgradArgs {
     int32_t plane_pitch[48];
     const int32_t* wave_first; // wave w runs jobs [wave_first[w], wave_first[w+1])
     int n_jobs, n_waves;
+};
+
+struct WgradBArgs {            // bf16 training mode (nnr_wgrad_bf16.hip)
+    float* gw[13];             // [12] = dW' scratch (D/2 x D) in the workspace
+    float* gb[13];
+    const float* packed;
+    int D;
+    const WgradJobB* jobs;     // n_jobs, grouped by workgroup
+    const int32_t* block_first;   // workgroup b runs jobs [block_first[b], block_first[b+1])
+    const WgradOutB* outs;     // n_outs destination rectangles
+    const float* ws;           // workspace base (the jobs carry byte offsets into it)
+    float* slots;              // 4 * n_jobs wave slots of kSlotBFloats
+    int n_jobs, n_blocks, n_outs;
 };
 
 struct RaySetupArgs {
@@ -158,5 +172,7 @@ hipError_t launch_composite_fwd(const CompositeArgs& a, hipStream_t st);
 hipError_t launch_composite_bwd(const CompositeArgs& a, hipStream_t st);
 hipError_t launch_ray_reduce(const RayReduceArgs& a, hipStream_t st);
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st);
+hipError_t launch_wgrad_unmerge(const WgradArgs& a, hipStream_t st);   // uses gw, gb, packed, D, bf16 only
+hipError_t launch_wgrad_bf16(const WgradBArgs& a, hipStream_t st);
 
 }  // namespace nnr

@@ -160,9 +160,28 @@ struct Layout {
 enum Plane {
     P_OUT4 = 0, P_Z = 1, P_DOUT4 = 2, P_DPTS = 3, P_DVIEW = 4,
     P_XE = 10, P_XH1 = 11, /* .. P_XH8 = 18 */ P_XF = 19 /* direction encoding only */, P_XG = 20,
+    P_XE16 = 21, P_XF16 = 22,   /* bf16 training only: tile-major bf16 copies of the two encodings for the weight-gradient kernel */
     P_MASK = 25,
     P_DH1 = 31, /* .. P_DH8 = 38 */ P_DG = 40,
 };
+
+// ---- tile-major bf16 planes (bf16 training mode) ------------------------------------------------------------------
+// The operands of the weight-gradient products -- hidden activations P_XH1.., P_XG, the encodings' copies P_XE16 / P_XF16 and the
+// pre-activation gradients P_DH1.., P_DG -- are stored as the very bf16 values the forward / input-gradient MFMAs consumed, in
+// the order the producing wave holds them: a plane of G groups of 16 features is an array of 1 KiB BLOCKS [chunk][group], chunk =
+// 32 consecutive samples (one wave of the MLP kernels), and a block is [lane = 32 h + c][8 bf16] with lane (h, c) holding, for
+// sample 32 chunk + c, features 16 g + 4 h + {0..3} and 16 g + 8 + 4 h + {0..3} -- its packed MFMA B operand of that row-step.
+// Element (sample s, feature f) sits at bf16 index
+//     (((s / 32) * G + f / 16) * 64 + 32 * ((f % 8) / 4) + s % 32) * 8 + 4 * ((f % 16) / 8) + f % 4.
+// Every stash store of the producers is then ONE fully coalesced 1 KiB wave-store (8 whole cache lines; the row-major planes of
+// round 1 wrote 16 bytes into each of 32 lines per store), and the weight-gradient kernel streams whole blocks into LDS with
+// global_load_lds_dwordx4 -- the transposition [sample][feature] -> [feature][8 samples] its MFMA operands need happens in the LDS
+// read (ds_read_b64_tr_b16), not in HBM.
+// P_DG carries one extra group in this mode: group D/32 = the per-sample output gradients as bf16 (d rgb_pre[0..2], d sigma_raw,
+// 12 zeros), so that the two head layers are ordinary tiles of the same kernel.
+NNR_HD constexpr int64_t tile_major_index(int64_t s, int f, int G) {
+    return ((((s >> 5) * G + (f >> 4)) * 64 + 32 * ((f & 7) >> 2) + (s & 31)) << 3) + 4 * ((f & 15) >> 3) + (f & 3);
+}
 
 struct WsLayout {
     int64_t S, S_pad;
@@ -176,6 +195,7 @@ struct WsLayout {
         int64_t o = 0;
         int w = 0;
         const int wD = bf16 ? D / 2 : D, wDh = bf16 ? D / 4 : D / 2;
+        const int wDg = bf16 ? D / 4 + 8 : D / 2;   // bf16: D/32 groups of colour-hidden gradients + 1 group of output gradients
         auto step = [&](int id, int width) -> bool {
             if (id == p) { w = width; return true; }
             o += S_pad * (int64_t)width;
@@ -187,11 +207,12 @@ struct WsLayout {
         for (int l = 0; l < 8; ++l)
             if (step(P_XH1 + l, wD)) { *pitch = w; return o; }
         if (step(P_XF, kDirPad) || step(P_XG, wDh)) { *pitch = w; return o; }
+        if (bf16 && (step(P_XE16, kPosPad / 2) || step(P_XF16, kDirPad / 2))) { *pitch = w; return o; }
         // masks: [S_pad/32 chunks][9 layers][64 lanes][D/64 words]  == S_pad * 9 * 2 * (D/64) / ... words per sample: 9*2*(D/64)
         if (step(P_MASK, 9 * 2 * (D / 64))) { *pitch = w; return o; }
         for (int l = 0; l < 8; ++l)
             if (step(P_DH1 + l, wD)) { *pitch = w; return o; }
-        if (step(P_DG, wDh)) { *pitch = w; return o; }
+        if (step(P_DG, wDg)) { *pitch = w; return o; }
         if (p == -1) { *pitch = 0; return o; }  // total
         return -1;
     }
@@ -223,6 +244,37 @@ struct WgradJob {
     int32_t split, next_split;  // this job is split `split` (in sample order) of its tile; job index of the next one, -1 = last
     int32_t reserved;
 };
+// ---- weight-gradient plan of the bf16 mode: one entry per WORKGROUP job (nnr_wgrad_bf16.hip) --------------------------------
+// A job streams the 32-sample chunks [c0, c1) of two tile-major planes -- d_groups consecutive blocks per chunk of the gradient
+// operand, x_groups of the activation operand -- through LDS; wave w < WR * WC owns the MT x NT MFMA tiles (32 x 32)
+// at tile row MT * (w / WC), tile column NT * (w % WC) of  dW_unit[d feature][x feature] = sum_s Dlt[s][d] X[s][x], keeps them in
+// accumulators for the whole range and writes them to its slot (4 * job + w); waves of tile column 0 also sum the gradient
+// operand over the samples (d bias).  Feature i of tile t is feature 32 t + i of the staged groups, in natural order.
+struct WgradJobB {
+    int64_t d_base, x_base;             // byte offset in the workspace of block (chunk 0, first staged group) of either operand
+    int32_t d_stride, x_stride;         // bytes per chunk of either plane (1 KiB x its groups)
+    int32_t d_groups, x_groups;         // blocks staged per chunk
+    int32_t unit;                       // index into the unit table (which tile of which dW this is: BUnit in nnr_api.cpp)
+    int32_t MT, NT, WR, WC;
+    int32_t c0, c1;                     // chunk range
+    int32_t bias;                       // 1: tile-column-0 waves reduce d(bias)
+    int32_t split, next_split;          // position in the chain of the unit's jobs (sample order), next job or -1
+};
+// one destination rectangle of a unit: rows [d_row, d_row + n_rows) x columns [x_col, x_col + n_cols) of the unit's product (feature
+// offsets relative to the staged groups) go to W[layer][w_row + ..][w_col + ..]; bias rows likewise when `bias`
+struct WgradOutB {
+    int32_t unit, layer;
+    int32_t d_row, n_rows, w_row;
+    int32_t x_col, n_cols, w_col, ldw;
+    int32_t bias;
+    int32_t first_job;                  // head of the unit's job chain
+    int32_t MT, NT, WR, WC;             // copy of the unit's tiling (to find an element's wave slot)
+    int32_t reserved;
+};
+constexpr int kSlotBTile = 32 * 32;     // floats per MFMA tile in a slot, row-major
+// slot of (job, wave): [MT * NT tiles][32][32] floats, then [MT][2 k-step halves][32] bias partials; fixed pitch for every shape
+constexpr int kSlotBFloats = 16 * kSlotBTile + 5 * 2 * 32;
+
 // partial slot of job i: floats [i*kSlotFloats, (i+1)*kSlotFloats) of the slot region = tile (32*MI rows x 32*NI cols,
 // row-major, pitch 32*NI) followed by the two half-wave bias partials [2][32*MI]
 constexpr int kSlotTile = 128 * 128;

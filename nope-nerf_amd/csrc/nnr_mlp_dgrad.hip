@@ -151,7 +151,16 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     };
     load_mask(mwA, 7, 0);
     init_sigma(accA, 0);
-    gemm_sel<BF16, HT, HT, 1>(accA, dg, pipe, p0(B_RGBH_FA), stash_row<BF16>(a.ws_dg, ss, D / 2, 4 * half));
+    // d g goes to P_DG; in the bf16 mode that plane is tile-major and has one more group: the output gradients themselves
+    // (d rgb_pre[0..2], d sigma_raw, zeros) as bf16, the gradient operand of the two head layers in the weight-gradient kernel
+    float* const dg_stash = stash_row<BF16>(a.ws_dg, ss, BF16 ? D / 2 + 16 : D / 2, half);
+    if constexpr (BF16) {
+        bf16x8 q;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = (__bf16)((half == 0 && i < 4) ? dout[i & 3] : 0.f);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(dg_stash) + kBlockBf16 * (D / 32)) = __builtin_bit_cast(f32x4, q);
+    }
+    gemm_sel<BF16, HT, HT, 1>(accA, dg, pipe, p0(B_RGBH_FA), dg_stash);
     load_mask(mwB, 7, 1);
     init_sigma(accB, 1);
     gemm_sel<BF16, HT, HT, false, NP, 2, 0>(accB, dg, pipe, p0(B_RGBH_FB), nullptr, NNR_SEL_PAIR(accA, 0, mwA));
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     NNR_STAMP(tl_dgrad, 3);
 
     // ---- trunk ----
-    auto dh = [&](int hidden_idx /*0..7*/) -> float* { return stash_row<BF16>(a.ws_dh, (int64_t)hidden_idx * a.S_pad + ss, D, 4 * half); };
+    auto dh = [&](int hidden_idx /*0..7*/) -> float* { return stash_row<BF16>(a.ws_dh, (int64_t)hidden_idx * a.S_pad + ss, D, half); };
     // Invariant from here on: d[0, HR) holds half A of the newest gradient, accB its half B still to be masked (mwB).
 
     // one transposed D x D layer at panel pa: consumes the gradient in d (stashing it to `stash`), produces the gradient of

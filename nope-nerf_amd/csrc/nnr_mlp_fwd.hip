@@ -144,8 +144,18 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     auto p0 = [&](int part) { return L::fwd_panel0(part); };
     float* const xe = TRAIN ? a.ws_xe + ss * kPosPad + 4 * half : nullptr;
     auto xh = [&](int hidden_idx /*0..7*/) -> float* {
-        return TRAIN ? stash_row<BF16>(a.ws_xh, (int64_t)hidden_idx * a.S_pad + ss, D, 4 * half) : nullptr;
+        return TRAIN ? stash_row<BF16>(a.ws_xh, (int64_t)hidden_idx * a.S_pad + ss, D, half) : nullptr;
     };
+    if constexpr (TRAIN && BF16) {
+        // tile-major bf16 copies of the two encodings for the weight-gradient kernel (the fp32 planes stay: the backward of the
+        // encodings reads sin / cos back at full precision)
+        __bf16* e16 = reinterpret_cast<__bf16*>(stash_row<true>(a.ws_xe16, ss, kPosPad, half));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(e16 + kBlockBf16 * b) = __builtin_bit_cast(f32x4, pack_row(e, b));
+        __bf16* f16 = reinterpret_cast<__bf16*>(stash_row<true>(a.ws_xf16, ss, kDirPad, half));
+#pragma unroll
+        for (int b = 0; b < 2; ++b) *reinterpret_cast<f32x4*>(f16 + kBlockBf16 * b) = __builtin_bit_cast(f32x4, pack_row(dirv, b));
+    }
 
     // ---- hidden 1: 63 -> D, input = posenc.  Pass A, then pass B with A's epilogue hidden under it. ----
     init_acc(accA, L::bias_off(0));
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // model/official_nerf.py:87-89) is folded into this one by the pack kernel, see nnr_layout.h.  One pass (D/2 outputs).
     // Its side work first finishes hidden 8 (half B), then evaluates the density head -- a per-lane dot product of h8 with
     // the density row (a 1-row GEMM is not MFMA work).
-    float* const xf = TRAIN ? a.ws_xf + ss * kDirPad + 4 * half : nullptr;
+    float* const xf = TRAIN ? a.ws_xf + ss * kDirPad + 4 * half : nullptr;   // fp32, row-major in either mode
     init_acc(accA, L::bias_off(10));
     clear_mask(mwB);
     float sg0 = 0.f, sg1 = 0.f;
@@ -243,11 +253,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     for (int u = 0; u < NP; ++u) NNR_RELU_PAIR(accA, 0, mwA)(u);   // g = h[0, HR)
     store_mask(mwA, 8, 0);
     if (TRAIN) {
-        float* xg = stash_row<BF16>(a.ws_xg, ss, D / 2, 4 * half);
-        if constexpr (BF16) {   // bf16 plane (quads 1 and 2 of every 16 swapped): group g = registers 8g .. 8g+7 of this lane, 16 bytes
+        float* xg = stash_row<BF16>(a.ws_xg, ss, D / 2, half);
+        if constexpr (BF16) {   // tile-major bf16 plane: group g = registers 8g .. 8g+7 of this lane, 16 bytes of block (chunk, g)
 #pragma unroll
             for (int gq = 0; gq < HR / 8; ++gq)
-                *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(xg) + 16 * gq) = __builtin_bit_cast(f32x4, pack_row(h, gq));
+                *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(xg) + kBlockBf16 * gq) = __builtin_bit_cast(f32x4, pack_row(h, gq));
         } else {
 #pragma unroll
             for (int q = 0; q < HR / 4; ++q)

@@ -1,4 +1,5 @@
-// nnr_wgrad.hip -- weight / bias gradients of the 12 nn.Linear layers from the stashed layer inputs X and the stashed
+// nnr_wgrad.hip -- (fp32 mode; the bf16 training mode has its own HBM-bound kernel, nnr_wgrad_bf16.hip)
+// weight / bias gradients of the 12 nn.Linear layers from the stashed layer inputs X and the stashed
 // pre-activation gradients Dlt:   dW_l[out][in] = sum_s Dlt_l[s][out] * X_l[s][in],   db_l[out] = sum_s Dlt_l[s][out].
 // Replaces autograd's `mm` wgrad calls (24 of the 36 backward GEMMs) for model/official_nerf.py:20-37.
 //
@@ -142,167 +143,6 @@ extern "C" int nnr_timeline_wgrad(unsigned long long* host32) {
 }
 #endif
 
-// bf16-MFMA variant (NNR_F_BF16): the same tile / job structure, but one v_mfma_f32_32x32x16_bf16 contracts 16 samples:
-// lane (m, half) supplies the 8 samples k + 8*half + 0..7 of its MI rows / NI columns (fp32 accumulation, fp32 bias sums).
-// In this mode the forward and the input-gradient kernels store the hidden activations and the pre-activation gradients as the
-// very bf16 values their own MFMAs consumed (WsLayout::bf16), so most operands arrive as bf16 -- half the bytes of the fp32
-// planes and half the registers per stage in flight -- and only need their 16-bit halves regrouped (v_perm_b32) from
-// [sample][feature] to the MFMA's [feature][8 samples].  The encodings (P_XE, P_XF) and the 4-wide output gradients (P_DOUT4)
-// stay fp32 and are converted here.  Which operand is which follows from the tile shape (checked on the host by
-// nnr_plan_build): the gradient operand is bf16 unless MI == 1 (heads: P_DOUT4); the activation operand is bf16 when NI == 4
-// or MI == 1 (hidden activations), fp32 otherwise (NI 2 / 1 against the encodings).
-// HBM-bound (about 9 KB per sample); two stages (2 x 16 samples) are in flight per wave.
-template <int W, bool B16>
-struct RawRow {   // W consecutive features of one sample, as loaded
-    static constexpr int NW = B16 ? W / 2 : W;
-    uint32_t w[NW];
-};
-
-template <int W, bool B16>
-__device__ __forceinline__ RawRow<W, B16> load_raw(const char* p) {
-    RawRow<W, B16> r;
-    constexpr int NW = RawRow<W, B16>::NW;
-    if constexpr (NW == 4) {
-        const u32x4 t = *reinterpret_cast<const u32x4*>(p);
-        r.w[0] = t[0]; r.w[1] = t[1]; r.w[2] = t[2]; r.w[3] = t[3];
-    } else if constexpr (NW == 2) {
-        const u32x2 t = *reinterpret_cast<const u32x2*>(p);
-        r.w[0] = t[0]; r.w[1] = t[1];
-    } else {
-        r.w[0] = *reinterpret_cast<const uint32_t*>(p);
-    }
-    return r;
-}
-
-// feature i of 8 consecutive samples -> one MFMA operand row (8 bf16)
-template <int W, bool B16>
-__device__ __forceinline__ bf16x8 gather_feature(const RawRow<W, B16> (&rows)[8], int i) {
-    u32x4 out;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if constexpr (B16) {   // halves i of words rows[2j], rows[2j+1]:  low <- sample 2j, high <- sample 2j + 1
-            const uint32_t lo = rows[2 * j].w[i >> 1], hi = rows[2 * j + 1].w[i >> 1];
-            out[j] = __builtin_amdgcn_perm(hi, lo, (i & 1) ? 0x07060302u : 0x05040100u);
-        } else {
-            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-            const bf16x2 v = {(__bf16)__builtin_bit_cast(float, rows[2 * j].w[i]), (__bf16)__builtin_bit_cast(float, rows[2 * j + 1].w[i])};
-            out[j] = __builtin_bit_cast(uint32_t, v);
-        }
-    }
-    return __builtin_bit_cast(bf16x8, out);
-}
-
-template <int W, bool B16>
-__device__ __forceinline__ float raw_value(const RawRow<W, B16>& row, int i) {
-    if constexpr (B16) return __builtin_bit_cast(float, (i & 1) ? (row.w[i >> 1] & 0xffff0000u) : (row.w[i >> 1] << 16));
-    else return __builtin_bit_cast(float, row.w[i]);
-}
-
-template <int MI, int NI, int BIAS>
-__device__ __forceinline__ void wgrad_job_bf16(const WgradJob& jb, const WgradArgs& a, int lane, int ji) {
-    constexpr bool DB = MI != 1, XB = NI == 4 || MI == 1;        // operand planes stored as bf16 (see above)
-    const int half = lane >> 5, m = lane & 31;
-    const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
-    // Address of the lane's W features of sample kk + 8 * half + u.  All planes are row-major; inside every 16-feature group of a
-    // bf16 plane the two middle quads are swapped (stash_row in nnr_device.h), so the lane's quad q sits where quad
-    // ((q & 1) << 1 | q >> 1) would.
-    struct Operand {
-        const char* base;
-        int64_t stride;     // bytes per sample row
-        __device__ __forceinline__ const char* at(int64_t kk, int u) const { return base + (kk + u) * stride; }
-    };
-    auto operand = [&](int plane, int col0, int W, bool ok, bool b16) {
-        const char* p = reinterpret_cast<const char*>(a.ws + a.plane_off[plane]);
-        int f0 = col0 + (ok ? W * m : 0);
-        const int64_t stride = 4ll * a.plane_pitch[plane];
-        if (b16) {
-            const int q = (f0 >> 2) & 3;
-            f0 += 4 * ((((q & 1) << 1) | (q >> 1)) - q);
-        }
-        return Operand{p + (b16 ? 2 : 4) * f0 + (8 * half) * stride, stride};
-    };
-    const Operand dop = operand(jb.d_plane, jb.d_col0, MI, dok, DB), xop = operand(jb.x_plane, jb.x_col0, NI, xok, XB);
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bsum[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
-
-    struct Stage {
-        RawRow<MI, DB> d[8];
-        RawRow<NI, XB> x[8];
-    };
-    auto load_stage = [&](Stage& st, int64_t kk) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            st.d[u] = load_raw<MI, DB>(dop.at(kk, u));
-            st.x[u] = load_raw<NI, XB>(xop.at(kk, u));
-        }
-    };
-    // consume one stage: regroup / convert, refill the stage's registers with the samples two stages ahead, multiply
-    auto step = [&](Stage& st, int64_t next_k) __attribute__((always_inline)) {
-        bf16x8 av[MI], bv[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            av[i] = gather_feature<MI, DB>(st.d, i);
-            if constexpr (BIAS != 0) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (BIAS == 1 || (BIAS == 2 && u % 2 == 0) || (BIAS == 3 && u % 2 == 1)) bsum[i] += raw_value<MI, DB>(st.d[u], i);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) bv[j] = gather_feature<NI, XB>(st.x, j);
-        __builtin_amdgcn_sched_barrier(0);
-        load_stage(st, next_k);   // no branch around loads: past the end it re-reads the last stage
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // Sample ranges are multiples of 16 (kGranule) = one MFMA per sub-tile and stage.  Three stages of 16 samples rotate; the
-    // loop body is unconditional (a branch inside it made hipcc spill 600 registers), the 0-2 left-over stages follow.
-    Stage sa, sb, sc;
-    const int64_t last = jb.k1 - 16;
-    auto at = [&](int64_t kk) { return kk <= last ? kk : last; };
-    load_stage(sa, jb.k0);
-    load_stage(sb, at(jb.k0 + 16));
-    load_stage(sc, at(jb.k0 + 32));
-    int64_t k = jb.k0;
-    for (; k + 48 <= jb.k1; k += 48) {
-        step(sa, at(k + 48));
-        step(sb, at(k + 64));
-        step(sc, at(k + 80));
-    }
-    if (k < jb.k1) step(sa, last);
-    if (k + 16 < jb.k1) step(sb, last);
-    float* slot = a.slots + (int64_t)ji * kSlotFloats;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mr = (r & 3) + 8 * (r >> 2) + 4 * half;
-            float* dst = slot + (MI * mr + i) * (32 * NI) + NI * m;
-            if constexpr (NI == 4) *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-            else if constexpr (NI == 2) *reinterpret_cast<f32x2*>(dst) = f32x2{acc[i][0][r], acc[i][1][r]};
-            else *dst = acc[i][0][r];
-        }
-    if constexpr (BIAS != 0) {
-        float* dst = slot + kSlotTile + half * (32 * MI) + MI * m;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) dst[i] = bsum[i];
-    }
-}
-
-template <bool BF16>
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wslot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -314,11 +154,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
         const WgradJob jb = a.jobs[ji];
         // bias reduction (MI VALU adds per k-step inside the MFMA stream) only in the jobs that own it
         const int key = __builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI + 64 * jb.bias);
-#define NNR_WGRAD_RUN(MI_, NI_, B_)                                                      \
-    do {                                                                                 \
-        if constexpr (BF16) wgrad_job_bf16<MI_, NI_, B_>(jb, a, lane, ji);               \
-        else wgrad_job<MI_, NI_, B_>(jb, a, lane, ji);                                   \
-    } while (0)
+#define NNR_WGRAD_RUN(MI_, NI_, B_) wgrad_job<MI_, NI_, B_>(jb, a, lane, ji)
 #define NNR_WGRAD_CASE(MI_, NI_)                                 \
     case MI_ * 8 + NI_: NNR_WGRAD_RUN(MI_, NI_, 0); break;        \
     case MI_ * 8 + NI_ + 64: NNR_WGRAD_RUN(MI_, NI_, 1); break;
@@ -414,9 +250,13 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const size_t merged = ((size_t)(a.D / 2) * a.D + a.D / 2) * sizeof(float);
     hipError_t e = hipMemsetAsync(a.gw[kMergedLayer], 0, merged, st);   // dW', db' are accumulated into like any gradient
     if (e != hipSuccess) return e;
-    if (a.bf16) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(a.n_waves / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_jobs * 16), dim3(256), 0, st, a);
+    e = hipGetLastError();
+    return e != hipSuccess ? e : launch_wgrad_unmerge(a, st);
+}
+
+hipError_t launch_wgrad_unmerge(const WgradArgs& a, hipStream_t st) {
     const int threads = a.D * a.D + (a.D / 2) * a.D + a.D + a.D / 2;
     const dim3 grid((threads + 255) / 256), block(256);
     if (a.D == 256 && a.bf16) hipLaunchKernelGGL((wgrad_unmerge_kernel<256, true>), grid, block, 0, st, a);

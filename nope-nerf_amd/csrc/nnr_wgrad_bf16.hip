@@ -1,0 +1,316 @@
+// nnr_wgrad_bf16.hip -- weight / bias gradients of the bf16 training mode (NNR_F_BF16):
+//     dW_l[out][in] = sum_s Dlt_l[s][out] * X_l[s][in],   db_l[out] = sum_s Dlt_l[s][out]
+// for the 12 nn.Linear layers of model/official_nerf.py:20-37 (autograd's 24 `mm` wgrad calls), bf16 products, fp32 accumulation.
+//
+// Roofline: HBM.  Both operands were left in HBM by the forward / input-gradient kernels as bf16 (9.1 KB per sample at D = 256:
+// 2 x (8 D + D/2) x 2 B of activations and gradients + the two encodings + the output gradients) and every byte is needed exactly
+// once; the products are 593 408 MACs per sample = 0.9 us of bf16 MFMA per 128 samples and CU against 4 us of streaming at 6 TB/s.
+// So the kernel is a streaming kernel with an MFMA consumer:
+//   * a WORKGROUP job (4 waves, one per SIMD, one workgroup per CU) owns ALL tiles of one layer's dW -- 256 x 256 as four 128 x 128
+//     wave tiles of 4 x 4 MFMA tiles (v_mfma_f32_32x32x16_bf16) -- for a contiguous range of 32-sample chunks, so each operand byte
+//     is fetched once per layer (round 1: one wave per tile, every operand half fetched by two waves, 1.26x the bytes over HBM);
+//   * the operands are tile-major planes (nnr_layout.h): a chunk of 32 samples x 16 features is one contiguous 1 KiB block, and a
+//     stage = the 16 + 16 blocks of one chunk of both operands = 32 KiB arrives by 32 LDS-DMA pieces (global_load_lds_dwordx4,
+//     1 KiB per wave-instruction, 8 per wave) into a ring of four stages -- three chunks (96 KiB) in flight per CU, counted vmcnt,
+//     one barrier per stage.  tools/ubench/hbm_stream.hip: this staging pattern alone streams 6.1 TB/s on the box;
+//   * the MFMA wants [feature][8 consecutive samples] per lane, the planes hold [sample][features]: the transposition is the LDS
+//     read, ds_read_b64_tr_b16 (two per operand tile and k-step).  The DMA stores the 64 16-byte units of a block to LDS slots
+//     permuted by an XOR on the sample index (applied to the per-lane SOURCE address, the LDS image of a DMA is lane-linear) such
+//     that the 32 lanes a transposing read services together hit 64 distinct banks;
+//   * d(bias): the A operand registers of a tile row are its gradient values, [feature = lane & 31][8 samples]; the tile-column-0
+//     waves add them up with v_dot2c_f32_bf16 against (1, 1) -- 4 VALU instructions per tile row and k-step, one fp32 register
+//     per tile row (64 more accumulator registers for an all-ones MFMA do not fit beside 256: the 4 x 4 variant spilled);
+//   * each wave writes its accumulators once to its own slot; wgrad_b_reduce_kernel adds the slots of a unit's jobs in sample order
+//     (fixed order: bit-reproducible) into dW / db.  The feature layer and the first D columns of the colour-hidden layer get their
+//     gradients from the merged matrix W' (wgrad_unmerge_kernel in nnr_wgrad.hip), the density and rgb heads are ordinary tiles:
+//     their gradient operand is the 16-wide group the input-gradient kernel appends to the colour-hidden gradient plane.
+#include "nnr_device.h"
+#include "nnr_kernels.h"
+
+namespace nnr {
+
+constexpr int kNStage = 4;                  // LDS ring depth
+constexpr int kStageBytes = 32 * 1024;      // up to 32 blocks of 1 KiB per stage
+constexpr int kBlockBytes = 1024;
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the count field is an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    }
+}
+
+// 8 bf16 (k = 8 consecutive samples of one feature) of MFMA operand tile `t` of the operand image at LDS byte address `img`:
+// two transposing reads.  a0 / a1 = the lane's byte offsets for the samples 0-3 / 4-7 of its half of the k-step (see wgrad_b_job).
+__device__ __forceinline__ bf16x8 read_operand(const char* lds, int img, int t, int ks, int a0, int a1) {
+    const int base = img + t * (2 * kBlockBytes) + ks * 256;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + base + a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + base + a1));
+    const s16x8 q = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, q);
+}
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from (wave-uniform base + per-lane 32-bit offset) to the LDS bytes [dst, dst + 1 KiB).
+// Inline assembly for two reasons: the address stays an SGPR pair + ONE VGPR (the builtin's flat per-lane pointers were hoisted out of
+// the streaming loop as eight 64-bit VGPR pairs, spilled, and every reload carried an s_waitcnt vmcnt(0) that drained the DMA queue);
+// and hipcc does not count asm memory operations, so no compiler-inserted wait ever covers them -- the counted waits below are the
+// only ones.  M0 (the LDS destination) is written and restored inside the statement.
+__device__ __forceinline__ void dma_piece(const char* base, unsigned lane_off, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_off), "s"(base), "s"(dst)
+                 : "memory");
+}
+
+struct StageFeed {      // everything a wave needs to issue its pieces of a stage; all fields wave-uniform except src0 / src1
+    const char *d_base, *x_base;
+    int64_t d_stride, x_stride;
+    int d_groups, nblk, P, c0, wave;
+    unsigned lds0;      // LDS byte address of the ring
+    unsigned src0, src1;
+
+    // Lane p of a piece fetches the 16-byte unit that belongs in LDS slot p of the block.  Slot of unit (h, c) [h = which quad pair,
+    // c = sample in chunk] is 32 h + (c ^ (4 h + 8 par)), par = parity of the block inside its operand image: the samples the
+    // transposing reads of one 32-lane group address then fall on 64 distinct banks (see the read offsets in wgrad_b_job).
+    __device__ __forceinline__ StageFeed(const WgradJobB& jb, const char* ws, unsigned lds_addr, int wave_, int lane) {
+        d_base = ws + jb.d_base;
+        x_base = ws + jb.x_base;
+        d_stride = jb.d_stride;
+        x_stride = jb.x_stride;
+        d_groups = jb.d_groups;
+        nblk = jb.d_groups + jb.x_groups;
+        P = (nblk + 3) >> 2;          // DMA pieces per wave and stage (the last ones may repeat a block)
+        c0 = jb.c0;
+        wave = wave_;
+        lds0 = lds_addr;
+        const int ph = lane >> 5, pc = lane & 31;
+        src0 = (32 * ph + (pc ^ (4 * ph))) * 16;
+        src1 = (32 * ph + (pc ^ (4 * ph + 8))) * 16;
+    }
+    __device__ __forceinline__ void issue(int s) const {
+        const int64_t ch = c0 + s;
+        const char* dch = d_base + ch * d_stride;
+        const char* xch = x_base + ch * x_stride;
+        const unsigned stage = lds0 + (s % kNStage) * kStageBytes;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q < P) {
+                int i = wave + 4 * q;
+                i = i < nblk ? i : nblk - 1;
+                const bool is_d = i < d_groups;
+                const int k = is_d ? i : i - d_groups;     // block index inside its operand image
+                dma_piece((is_d ? dch : xch) + (int64_t)k * kBlockBytes, (k & 1) ? src1 : src0, stage + i * kBlockBytes);
+            }
+        }
+    }
+    // stage s has landed when at most the pieces of the (kNStage - 2) younger stages are outstanding; near the end of the range
+    // fewer stages are in flight: drain.  Then the barrier: every wave's pieces of stage s are in LDS and everybody is done
+    // reading stage s - 1, whose buffer the next issue overwrites.
+    __device__ __forceinline__ void enter(int s, int n) const {
+        wait_vmcnt(s + kNStage - 2 < n ? (kNStage - 2) * P : 0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + kNStage - 1 < n) issue(s + kNStage - 1);
+    }
+    __device__ __forceinline__ void start(int n) const {
+        for (int s = 0; s < kNStage - 1 && s < n; ++s) issue(s);
+    }
+};
+
+template <int MT, int NT>
+__device__ __forceinline__ void pin_tiles(f32x16 (&acc)[MT][NT]) {   // keep the accumulators where they are: AGPRs (see pin_acc)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" : "+a"(acc[i][j]));
+}
+
+// a wave without tiles in this job: it still moves its share of the data and keeps the barrier count
+__device__ __forceinline__ void wgrad_b_idle(const WgradJobB& jb, const WgradBArgs& a, unsigned lds_addr, int wave, int lane) {
+    const StageFeed feed(jb, reinterpret_cast<const char*>(a.ws), lds_addr, wave, lane);
+    const int n = jb.c1 - jb.c0;
+    feed.start(n);
+    for (int s = 0; s < n; ++s) feed.enter(s, n);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+template <int MT, int NT, bool BIAS>
+__device__ __forceinline__ void wgrad_b_job(const WgradJobB& jb, const WgradBArgs& a, const char* lds, unsigned lds_addr, int wave, int lane,
+                                            int ji) {
+    const StageFeed feed(jb, reinterpret_cast<const char*>(a.ws), lds_addr, wave, lane);
+    const int n = jb.c1 - jb.c0;                         // stages = chunks
+    const int d_groups = jb.d_groups;
+    const int tr0 = MT * (wave / jb.WC), tc0 = NT * (wave % jb.WC);
+
+    // ---- LDS read offsets of this lane.  A transposing read hands lane i of a 16-lane group the four 16-bit elements number i
+    // of the four rows the group's lanes 4 r + m (r = row, m = which quarter) point at.  Rows = 4 consecutive samples, quarters =
+    // the 4 feature quads of a 16-feature block in natural order (quad m = unit half m & 1, second 8 bytes if m >> 1): lane i then
+    // holds feature i of the block for 4 samples.  16-lane group 0 / 1 = block 2 t / 2 t + 1 of the tile, groups 2 / 3 the same
+    // blocks for the second half of the k-step's 16 samples (the MFMA's k = 8 (lane >> 5) + 0..7).
+    const int grp = lane >> 4, qq = lane & 15, rr = qq >> 2, mm = qq & 3;
+    const int par = grp & 1, khalf = grp >> 1, hh = mm & 1, jj = mm >> 1;
+    const int lane_off = par * kBlockBytes + hh * 512 + (rr + 8 * (khalf ^ par)) * 16 + jj * 8;
+    // samples 0-3 / 4-7 of the lane's half: slot bit 2 is XORed with hh.  The tile origins are folded in here once per job.
+    const int a0 = lane_off + 64 * hh + tr0 * (2 * kBlockBytes), a1 = lane_off + 64 * (1 - hh) + tr0 * (2 * kBlockBytes);
+    const int b0 = lane_off + 64 * hh + (d_groups + 2 * tc0) * kBlockBytes, b1 = lane_off + 64 * (1 - hh) + (d_groups + 2 * tc0) * kBlockBytes;
+
+    f32x16 acc[MT][NT];
+    float bsum[MT];      // this lane's share of d(bias): feature lane & 31 of tile row i, the samples of its k-step half
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+
+    feed.start(n);
+    for (int s = 0; s < n; ++s) {
+        feed.enter(s, n);
+        pin_tiles<MT, NT>(acc);
+        const int img = (s % kNStage) * kStageBytes;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 av[MT], bv[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = read_operand(lds, img, i, ks, a0, a1);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = read_operand(lds, img, j, ks, b0, b1);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                if constexpr (BIAS) {
+                    const u32x4 w = __builtin_bit_cast(u32x4, av[i]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)   // bsum += lo(w) * 1 + hi(w) * 1.  Spelled out: __builtin_amdgcn_fdot2_f32_bf16 on the four
+                                                  // words of an operand was compiled (ROCm 7.2) to four instructions on the FIRST word
+                        asm("v_dot2c_f32_bf16 %0, 0x3f803f80, %1" : "+v"(bsum[i]) : "v"(w[q]));
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of stage s have returned before it reports "done"
+    }
+    __builtin_amdgcn_s_barrier();              // the ring is free for the next job's prologue
+
+    // ---- flush: tile (i, j) row-major [32][32]; register r of lane (half, col) is row (r & 3) + 8 (r >> 2) + 4 half
+    float* slot = a.slots + ((int64_t)ji * 4 + wave) * kSlotBFloats;
+    int lane_f = lane;
+    asm volatile("" : "+v"(lane_f));   // opaque here: otherwise the 256 lane-constant store offsets are hoisted to kernel entry and
+                                       // spilled around the streaming loop
+    const int col = lane_f & 31, half = lane_f >> 5;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                slot[((i * NT + j) * 32 + row) * 32 + col] = acc[i][j][r];
+            }
+    if constexpr (BIAS) {   // [tile row][k-step half][feature]: the reduction adds the two halves
+#pragma unroll
+        for (int i = 0; i < MT; ++i) slot[16 * kSlotBTile + (2 * i + half) * 32 + col] = bsum[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flush stores are the compiler's; start the next job's counted waits from zero
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_b_kernel(WgradBArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j0 = a.block_first[blockIdx.x], j1 = a.block_first[blockIdx.x + 1];
+    for (int ji = j0; ji < j1; ++ji) {
+        const WgradJobB jb = a.jobs[ji];
+        if (wave >= jb.WR * jb.WC) {   // no tile of this job
+            wgrad_b_idle(jb, a, lds_addr, wave, lane);
+            continue;
+        }
+        const bool bias = jb.bias && (wave % jb.WC) == 0;
+        const int key = __builtin_amdgcn_readfirstlane(jb.MT * 8 + jb.NT + (bias ? 64 : 0));
+#define NNR_WB_CASE(MT_, NT_)                                                                            \
+    case MT_ * 8 + NT_: wgrad_b_job<MT_, NT_, false>(jb, a, lds, lds_addr, wave, lane, ji); break;       \
+    case MT_ * 8 + NT_ + 64: wgrad_b_job<MT_, NT_, true>(jb, a, lds, lds_addr, wave, lane, ji); break;
+        switch (key) {
+            NNR_WB_CASE(4, 4)
+            NNR_WB_CASE(2, 2)
+            NNR_WB_CASE(5, 2)
+            NNR_WB_CASE(3, 1)
+            NNR_WB_CASE(1, 2)
+            NNR_WB_CASE(1, 1)
+            default: break;
+        }
+#undef NNR_WB_CASE
+    }
+}
+
+// dW[output rectangle] += sum over the unit's jobs, in sample order, of their slots; d(bias) likewise.  grid = (64, n_outputs).
+__global__ __launch_bounds__(256) void wgrad_b_reduce_kernel(WgradBArgs a) {
+    const WgradOutB o = a.outs[blockIdx.y];
+    const int total = o.n_rows * o.n_cols;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += 64 * 256) {
+        const int r = e / o.n_cols, c = e - r * o.n_cols;
+        const int dr = o.d_row + r, xc = o.x_col + c;                  // position in the unit's product
+        const int rt = dr >> 5, ct = xc >> 5;
+        const int wave = (rt / o.MT) * o.WC + ct / o.NT;
+        const int tile = (rt % o.MT) * o.NT + ct % o.NT;
+        const int64_t off = (int64_t)wave * kSlotBFloats + (tile * 32 + (dr & 31)) * 32 + (xc & 31);
+        float sum = 0.f;
+        for (int j = o.first_job; j >= 0; j = a.jobs[j].next_split) sum += a.slots[(int64_t)j * 4 * kSlotBFloats + off];
+        a.gw[o.layer][(int64_t)(o.w_row + r) * o.ldw + o.w_col + c] += sum;
+    }
+    if (o.bias && blockIdx.x == 0) {
+        for (int r = threadIdx.x; r < o.n_rows; r += 256) {
+            const int dr = o.d_row + r, rt = dr >> 5;
+            const int64_t off = (int64_t)((rt / o.MT) * o.WC) * kSlotBFloats + 16 * kSlotBTile + 2 * (rt % o.MT) * 32 + (dr & 31);
+            float sum = 0.f;
+            for (int j = o.first_job; j >= 0; j = a.jobs[j].next_split) {
+                const float* p = a.slots + (int64_t)j * 4 * kSlotBFloats + off;
+                sum += p[0] + p[32];
+            }
+            a.gb[o.layer][o.w_row + r] += sum;
+        }
+    }
+}
+
+hipError_t launch_wgrad_bf16(const WgradBArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kNStage * kStageBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const size_t merged = ((size_t)(a.D / 2) * a.D + a.D / 2) * sizeof(float);
+    hipError_t e = hipMemsetAsync(a.gw[kMergedLayer], 0, merged, st);   // dW', db' are accumulated into like any gradient
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wgrad_b_kernel, dim3(a.n_blocks), dim3(256), kNStage * kStageBytes, st, a);
+    hipLaunchKernelGGL(wgrad_b_reduce_kernel, dim3(64, a.n_outs), dim3(256), 0, st, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    WgradArgs u{};
+    for (int i = 0; i < 13; ++i) { u.gw[i] = a.gw[i]; u.gb[i] = a.gb[i]; }
+    u.packed = a.packed;
+    u.D = a.D;
+    u.bf16 = 1;
+    return launch_wgrad_unmerge(u, st);
+}
+
+}  // namespace nnr

@@ -49,6 +49,17 @@ class AuxCfg(C.Structure):
 AUX_RGBS, AUX_PC, AUX_SCALE_PCS, AUX_DETACH_RGBS = 1, 2, 4, 8
 
 
+class WgradJobB(C.Structure):      # bf16 training mode: one workgroup job (nnr_layout.h)
+    _fields_ = [("d_base", C.c_int64), ("x_base", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("d_stride", "x_stride", "d_groups", "x_groups", "unit", "MT", "NT", "WR", "WC", "c0", "c1", "bias",
+                                         "split", "next_split")]
+
+
+class WgradOutB(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("unit", "layer", "d_row", "n_rows", "w_row", "x_col", "n_cols", "w_col", "ldw", "bias",
+                                         "first_job", "MT", "NT", "WR", "WC", "reserved")]
+
+
 class WgradJob(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("layer", "MI", "NI", "d_plane", "d_col0", "d_valid", "x_plane", "x_col0",
                                          "x_valid", "row0", "wcol0", "rows_real", "cols_real", "ldw", "k0", "k1", "bias",

@@ -150,23 +150,43 @@ def plan_jobs(cfg: L.Cfg, with_waves: bool = False):
     return jobs, first
 
 
+def plan_bf16(cfg: L.Cfg):
+    """Host copy of the bf16-mode weight-gradient plan: (jobs, block_first, outputs) -- for tests / DESIGN inspection."""
+    lib = L.load()
+    nj, nw = C.c_int32(0), C.c_int32(0)
+    L.check(lib.nnr_plan_counts(C.byref(cfg), C.byref(nj), C.byref(nw)), "nnr_plan_counts")
+    nbytes = lib.nnr_plan_bytes(C.byref(cfg))
+    raw = (C.c_uint8 * nbytes)()
+    L.check(lib.nnr_plan_build(C.byref(cfg), C.cast(raw, C.c_void_p)), "nnr_plan_build")
+    n_blocks = nw.value // 4
+    o1 = nj.value * C.sizeof(L.WgradJobB)
+    o2 = o1 + 4 * (n_blocks + 1)
+    n_out = (nbytes - o2) // C.sizeof(L.WgradOutB)
+    assert o2 + n_out * C.sizeof(L.WgradOutB) == nbytes
+    jobs = list((L.WgradJobB * nj.value).from_buffer_copy(raw, 0))
+    first = list((C.c_int32 * (n_blocks + 1)).from_buffer_copy(raw, o1))
+    outs = list((L.WgradOutB * n_out).from_buffer_copy(raw, o2))
+    return jobs, first, outs
+
+
 def workspace_plane(cfg: L.Cfg, ws: torch.Tensor, plane: int, n_rows: Optional[int] = None) -> torch.Tensor:
     """One workspace plane as (rows, width) -- used by the parity tests to localise a mismatch.  A view for the fp32 planes; the
-    planes a bf16 training workspace stores as bf16 (hidden activations 11..18, 20 and their gradients 31..38, 40:
-    WsLayout in nnr_layout.h) come back re-ordered and converted to fp32."""
+    planes a bf16 training workspace stores as tile-major bf16 (hidden activations 11..18, 20, the encodings' copies 21, 22 and the
+    gradients 31..38, 40: nnr_layout.h) come back in natural [sample][feature] order, converted to fp32."""
     pitch = C.c_int32(0)
     off = L.load().nnr_ws_plane(C.byref(cfg), plane, C.byref(pitch))
     if off < 0:
         raise KeyError(plane)
     S = cfg.n_rays * cfg.n_samples
     rows = n_rows if n_rows is not None else S
-    stored_bf16 = (cfg.flags & L.NNR_F_BF16) and (cfg.flags & L.NNR_F_TRAIN) and (11 <= plane <= 18 or plane == 20 or 31 <= plane <= 38 or plane == 40)
+    stored_bf16 = (cfg.flags & L.NNR_F_BF16) and (cfg.flags & L.NNR_F_TRAIN) and (11 <= plane <= 18 or 20 <= plane <= 22 or 31 <= plane <= 38 or plane == 40)
     if not stored_bf16:
         return ws[off: off + rows * pitch.value].view(rows, pitch.value)
-    # bf16 plane: row-major with the two middle quads of every 16 features swapped (stash_row in nnr_device.h)
-    width = 2 * pitch.value
-    t = ws[off: off + rows * pitch.value].view(torch.bfloat16).view(rows, width // 16, 2, 2, 4)     # [row][group][half][half-group][4]
-    return t.permute(0, 1, 3, 2, 4).reshape(rows, width).float()
+    # tile-major: [chunk of 32 samples][group of 16 features][half h][sample c][second quad j][i]; feature = 16 g + 4 h + 8 j + i
+    G = pitch.value // 8
+    chunks = (rows + 31) // 32
+    t = ws[off: off + chunks * 32 * pitch.value].view(torch.bfloat16).view(chunks, G, 2, 32, 2, 4)    # [chunk][g][h][c][j][i]
+    return t.permute(0, 3, 1, 4, 2, 5).reshape(chunks * 32, G * 16)[:rows].float()                    # [chunk][c] x [g][j][h][i]
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -167,6 +167,84 @@ def posenc(x: torch.Tensor, levels: int) -> torch.Tensor:
     return torch.cat(parts, dim=-1)
 
 
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> bf16 (round to nearest even, what v_cvt_pk_bf16_f32 does) -> fp32."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _Bf16Matmul(torch.autograd.Function):
+    """y = bf16(x) bf16(W)^T with fp32 accumulation -- the arithmetic of BASELINE configs[2] ("MFMA bf16 with fp32 accumulate") as
+    the HIP kernels of the bf16 mode carry it out, forward AND backward: the input-gradient product rounds the incoming gradient
+    and the weights, the weight-gradient product rounds the incoming gradient and the input (both kernels consume the very bf16
+    values that were stored), the bias gradient sums the rounded gradient.  bf16 x bf16 products are exact in fp32, so this
+    emulation differs from the MFMA only in the order of the fp32 additions."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xr, wr = bf16_round(x), bf16_round(w)
+        ctx.save_for_backward(xr, wr)
+        return xr @ wr.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        xr, wr = ctx.saved_tensors
+        gr = bf16_round(g)
+        return gr @ wr, gr.t() @ xr
+
+
+class _RoundGrad(torch.autograd.Function):
+    """Identity whose gradient is rounded to bf16: the bias gradients of the bf16 mode are sums of the ROUNDED pre-activation
+    gradients (the weight-gradient kernel reads them from the bf16 planes)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return bf16_round(g)
+
+
+def mlp_bf16(params: Dict[str, torch.Tensor], pts: torch.Tensor, viewdir: torch.Tensor, *, dist_alpha: bool,
+             occ_activation: str = "softplus", pos_levels: int = 10, dir_levels: int = 4):
+    """The MLP of `mlp` with every MFMA-shaped contraction in bf16 x bf16 -> fp32 (rendering.mfma_dtype: bf16), restating what
+    the bf16 kernels compute (nnr_mlp_fwd.hip / nnr_mlp_dgrad.hip / nnr_wgrad_bf16.hip): all hidden layers incl. the two encoding
+    inputs; the feature layer folded into the colour-hidden layer (W' = Wg[:, :D] Wf and b' = Wg[:, :D] bf + bg formed in fp32,
+    then W' rounded); the 1-row density head and the 3-row rgb head in fp32 on the forward / input-gradient side, their WEIGHT
+    gradients from rounded operands like every other layer.  The reference for the tight parity test of the bf16 mode; the fp32
+    `mlp` stays the reference for how far bf16 arithmetic is from the reference's fp32."""
+    W = lambda n: params[n + ".weight"]
+    B = lambda n: params[n + ".bias"]
+
+    def lin16(n, v):       # hidden layer: rounded product + fp32 bias; bias gradient = sum of the rounded gradient
+        return _RoundGrad.apply(_Bf16Matmul.apply(v, W(n))) + B(n)
+
+    def head(n, v):        # forward / input gradient in fp32, weight gradient from rounded operands
+        y_fwd = F.linear(v, W(n).detach(), None)                          # carries d/dv in fp32
+        y_w = _Bf16Matmul.apply(v.detach(), W(n))                          # carries d/dW from bf16(g), bf16(v)
+        return y_fwd + (y_w - y_w.detach()) + _RoundGrad.apply(B(n).expand(v.shape[0], -1))
+
+    e = posenc(pts, pos_levels)
+    h = e
+    for n in ("layers0.0", "layers0.2", "layers0.4", "layers0.6"):
+        h = F.relu(lin16(n, h))
+    h = torch.cat([h, e], dim=-1)
+    for n in ("layers1.0", "layers1.2", "layers1.4", "layers1.6"):
+        h = F.relu(lin16(n, h))
+    raw = head("fc_density", h)
+    occ = F.softplus(raw) if occ_activation == "softplus" else raw.relu()
+    if not dist_alpha:
+        occ = 1 - torch.exp(-1.0 * occ)
+    D = W("fc_feature").shape[0]
+    wg = W("rgb_layers.0")
+    w_merged = wg[:, :D] @ W("fc_feature")                                # fp32, as the pack kernel forms it
+    b_merged = wg[:, :D] @ B("fc_feature") + B("rgb_layers.0")
+    pre = _RoundGrad.apply(_Bf16Matmul.apply(h, w_merged) + _Bf16Matmul.apply(posenc(viewdir, dir_levels), wg[:, D:])) + b_merged
+    g = F.relu(pre)
+    rgb = torch.sigmoid(head("fc_rgb", g))
+    return rgb, occ
+
+
 def mlp(params: Dict[str, torch.Tensor], pts: torch.Tensor, viewdir: torch.Tensor, *, dist_alpha: bool,
         occ_activation: str = "softplus", pos_levels: int = 10, dir_levels: int = 4):
     """OfficialStaticNerf.forward(return_addocc=True) -- model/official_nerf.py:60-96.
@@ -282,8 +360,9 @@ def render(params, pixels, depth, camera_mat, world_mat, scale_mat, cfg: dict, *
     z = z.view(-1, n_samples, 1)
 
     rgbs, occs = [], []
+    net = mlp_bf16 if str(cfg.get("mfma_dtype", "fp32")).lower() == "bf16" else mlp   # bf16: emulation of the bf16 kernels' arithmetic
     for i in range(0, pts.shape[0], chunk):                                         # :108-117
-        c, a = mlp(params, pts[i:i + chunk], view[i:i + chunk], dist_alpha=dist_alpha,
+        c, a = net(params, pts[i:i + chunk], view[i:i + chunk], dist_alpha=dist_alpha,
                    occ_activation=cfg.get("occ_activation", "softplus"))
         rgbs.append(c)
         occs.append(a)

@@ -335,6 +335,52 @@ def test_bf16_mfma_mode_against_fp32_golden(name, capsys):
               % (name, errs["rgb"], errs["depth_pred"], worst_l2[1], worst_l2[0], worst_max[1], worst_max[0]))
 
 
+def _oracle_bf16(case):
+    """The oracle with every MFMA-shaped product in bf16 x bf16 -> fp32 (nerf_oracle.mlp_bf16: the arithmetic BASELINE configs[2]
+    names, restated op by op as the bf16 kernels carry it out), on a golden case's inputs."""
+    t = gu.tensors(case)
+    cfg = gu.render_cfg(case)
+    cfg["mfma_dtype"] = "bf16"
+    h, w, cam = int(case["cfg.h"]), int(case["cfg.w"]), int(case["cfg.cam"])
+    params = {k: v.clone().requires_grad_(True) for k, v in case["weights"].items()}
+    leaves = {k: t[k].clone().requires_grad_(True) for k in ("pose_r", "pose_t", "scales", "shifts")}
+    loss, out = orc.train_step_scope(params, leaves["pose_r"], leaves["pose_t"], leaves["scales"], leaves["shifts"], cam, t["K"],
+                                     t["depth_img"], t["img"], (h, w), t["ray_idx"], t["jitter"], cfg)
+    loss.backward()
+    grads = {"w." + k: v.grad for k, v in params.items()}
+    grads.update({k: v.grad for k, v in leaves.items()})
+    return out, grads
+
+
+@pytest.mark.parametrize("name", ["tanks_d128", "tanks_d256_n192", "llff_ndc_d128", "uniform_distalpha_masked_d128"])
+def test_bf16_kernels_match_the_bf16_arithmetic_oracle(name, capsys):
+    """The TIGHT parity statement of the bf16 mode.  Against the fp32 reference the bf16 gradients are 5-15 % off in relative L2
+    (test above) -- that is what bf16 products do to a ReLU network, not a property of these kernels: the CPU oracle run with the
+    same arithmetic (operands of every hidden-layer product rounded to bf16, fp32 accumulation, fp32 everything else) lands on
+    the same numbers.  HIP kernels vs that oracle: outputs 1e-4, every gradient tensor within 2.5e-2 in relative L2 (measured
+    1e-3 .. 1e-2, against 5e-2 .. 1.5e-1 for bf16 vs fp32).  What is left: the device's sincosf and the host's sin / cos differ in
+    the last bit for some encodings, and the order of the fp32 additions differs; a last-bit difference that straddles a bf16
+    rounding boundary becomes a 0.4 % difference of that operand (2^16 ulps) and moves ReLU decisions downstream of it."""
+    case = gu.load_case(name)
+    out, grads = run_hip(case, mfma_dtype='bf16')
+    ref, rgrads = _oracle_bf16(case)
+    for k in ("rgb", "depth_pred"):
+        err = float((out[k].detach().cpu() - ref[k].detach()).abs().max())
+        assert err <= 1e-4, (k, err)
+    worst = ("", 0.0)
+    for k, r in rgrads.items():
+        g = grads[k].detach().cpu().double()
+        r = (r if r is not None else torch.zeros_like(g)).double()
+        if float(r.abs().max()) == 0:
+            assert float(g.abs().max()) == 0, k
+            continue
+        l2 = float((g - r).norm() / r.norm())
+        worst = max(worst, (k, l2), key=lambda t: t[1])
+        assert l2 <= (5e-2 if k.startswith("pose") else 2.5e-2), (k, l2)      # 6 pose numbers: a handful of rays carry their gradient
+    with capsys.disabled():
+        print("\nbf16 kernels vs bf16-arithmetic oracle [%s]: worst gradient relative L2 %.2e (%s)" % (name, worst[1], worst[0]))
+
+
 def test_config4_eight_shards_of_4096_rays_equal_one_32768_ray_pass():
     """BASELINE.json config 4 (8 ranks x 4096 rays of one image, Ballroom settings: uniform sampling, no dist_alpha, D=256, N=128):
     the gradients of the eight shards sum to the gradients of a single 32 768-ray pass -- the data-parallel identity at the

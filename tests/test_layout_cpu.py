@@ -165,3 +165,116 @@ def test_wgrad_plan_covers_every_weight_once(D, R, N):
     if (D, R, N) == (256, 1024, 192):
         work = [sum(allj[i].MI * allj[i].NI * (allj[i].k1 - allj[i].k0) for i in range(first[w], first[w + 1])) for w in range(len(first) - 1)]
         assert len(work) == 1024 and max(work) <= 1.02 * sum(work) / len(work)   # narrow tiles are weighted up, so they get LESS
+
+
+# ---- bf16 training mode: tile-major planes, the workgroup-job plan, the DMA swizzle / transposing-read index algebra --------
+def tile_major_index(s, f, G):
+    """nnr_layout.h: bf16 index of (sample s, feature f) in a tile-major plane of G 16-feature groups."""
+    return (((s // 32) * G + f // 16) * 64 + 32 * ((f % 8) // 4) + s % 32) * 8 + 4 * ((f % 16) // 8) + f % 4
+
+
+@pytest.mark.parametrize("D,R,N", [(128, 32, 64), (256, 4096, 128), (256, 5, 33), (256, 1024, 192)])
+def test_bf16_wgrad_plan_covers_every_weight_once(D, R, N):
+    """bf16 mode: every (layer, row, col) of the weight tensors is the destination of exactly one output rectangle, the jobs of a
+    unit partition the sample chunks, every job's tiles are owned by exactly one wave, and the staged groups exist in their planes."""
+    from nnr import lib as L
+    from nnr.ops import plan_bf16
+    lib = L.load()
+    cfg = L.make_cfg(R, N, D, train=True, bf16=True)
+    jobs, first, outs = plan_bf16(cfg)
+    S_pad = (R * N + 127) // 128 * 128
+    chunks = S_pad // 32
+    shapes = [(D, 63), (D, D), (D, D), (D, D), (D, D + 63), (D, D), (D, D), (D, D), (1, D), (D, D), (D // 2, D + 27), (3, D // 2),
+              (D // 2, D)]
+    cover = [np.zeros(s, dtype=np.int64) for s in shapes]
+    bias_cover = [np.zeros(s[0], dtype=np.int64) for s in shapes]
+    units = {}
+    for j in jobs:
+        units.setdefault(j.unit, []).append(j)
+        assert (j.MT, j.NT) in {(4, 4), (2, 2), (5, 2), (3, 1), (1, 2), (1, 1)} and 1 <= j.WR * j.WC <= 4
+        assert 0 <= j.c0 < j.c1 <= chunks and j.d_groups + j.x_groups <= 32 and j.d_base % 1024 == 0 and j.x_base % 1024 == 0
+        # every tile row / column a wave reads lies inside the staged image (a tile = two blocks)
+        assert 2 * j.MT * j.WR <= j.d_groups + j.x_groups + 1 and 2 * j.NT * j.WC <= j.x_groups
+    for u, js in units.items():                      # chunk ranges of a unit: a partition, chained in order
+        js = sorted(js, key=lambda j: j.c0)
+        assert js[0].c0 == 0 and js[-1].c1 == chunks and all(a.c1 == b.c0 for a, b in zip(js, js[1:]))
+        assert [j.split for j in js] == list(range(len(js)))
+    for o in outs:
+        head = jobs[o.first_job]
+        assert head.unit == o.unit and head.split == 0 and (o.MT, o.NT, o.WR, o.WC) == (head.MT, head.NT, head.WR, head.WC)
+        n, cur = 0, o.first_job
+        while cur >= 0:
+            assert jobs[cur].unit == o.unit
+            n, cur = n + 1, jobs[cur].next_split
+        assert n == len(units[o.unit])
+        # the rectangle lies inside the tiles the unit's waves own
+        assert o.d_row + o.n_rows <= 32 * o.MT * o.WR and o.x_col + o.n_cols <= 32 * o.NT * o.WC
+        assert o.ldw == shapes[o.layer][1]
+        cover[o.layer][o.w_row:o.w_row + o.n_rows, o.w_col:o.w_col + o.n_cols] += 1
+        if o.bias:
+            assert head.bias == 1
+            bias_cover[o.layer][o.w_row:o.w_row + o.n_rows] += 1
+    for l in range(13):
+        if l == 9:       # feature layer: from the merged matrix (un-merge step)
+            assert not cover[l].any() and not bias_cover[l].any()
+        elif l == 10:
+            assert not cover[l][:, :D].any() and np.all(cover[l][:, D:] == 1) and not bias_cover[l].any()
+        else:
+            assert np.all(cover[l] == 1), l
+            assert np.all(bias_cover[l] == 1), l
+    n_blocks = len(first) - 1
+    assert 1 <= n_blocks <= 256 and first[0] == 0 and first[-1] == len(jobs) and all(a <= b for a, b in zip(first, first[1:]))
+    # balance at BASELINE configs[2]: the staged KiB per workgroup differ by at most one chunk of the widest unit
+    if (R, N) == (4096, 128):
+        kib = [sum((jobs[i].d_groups + jobs[i].x_groups) * (jobs[i].c1 - jobs[i].c0) for i in range(first[b], first[b + 1])) for b in range(n_blocks)]
+        assert n_blocks == 256 and max(kib) - min(kib) <= 2 * 32
+    # workspace: planes + four wave slots per job + the merged-matrix scratch
+    nj = C.c_int32(0)
+    assert lib.nnr_plan_counts(C.byref(cfg), C.byref(nj), None) == 0 and nj.value == len(jobs)
+    pitch = C.c_int32(0)
+    assert lib.nnr_ws_plane(C.byref(cfg), 40, C.byref(pitch)) >= 0 and pitch.value == 8 * (D // 32 + 1)     # P_DG: one extra group
+    assert lib.nnr_ws_plane(C.byref(cfg), 21, C.byref(pitch)) >= 0 and pitch.value == 32                    # P_XE16
+    assert lib.nnr_ws_plane(C.byref(cfg), 22, C.byref(pitch)) >= 0 and pitch.value == 16                    # P_XF16
+
+
+def test_bf16_wgrad_lds_addressing_delivers_mfma_operands_without_bank_conflicts():
+    """The index algebra of nnr_wgrad_bf16.hip, emulated: a tile-major block pair goes through the DMA's source-lane permutation
+    into LDS; the lanes' transposing reads (ds_read_b64_tr_b16: lane i of a 16-lane group receives element i of each of the four
+    8-byte rows the group's lanes 4 r + m address) must hand lane l feature 32 t + (l & 31) for the samples 16 ks + 8 (l >> 5) + 0..7
+    -- the A / B operand of v_mfma_f32_32x32x16_bf16 -- and the 32 lanes serviced together must touch 64 distinct banks."""
+    G = 4                                             # two tiles
+    S = 32
+    plane = np.zeros(S * G * 16, dtype=np.int64)      # element value encodes (sample, feature)
+    for s in range(S):
+        for f in range(16 * G):
+            plane[tile_major_index(s, f, G)] = 1000 * s + f
+    # DMA: block k of the image, LDS slot p (16-byte unit) <- global unit src(p, k & 1) of the same block
+    lds = np.zeros(G * 512, dtype=np.int64)           # bf16 elements
+    for k in range(G):
+        for p in range(64):
+            ph, pc = p >> 5, p & 31
+            src = 32 * ph + (pc ^ (4 * ph + (8 if k & 1 else 0)))
+            lds[k * 512 + p * 8: k * 512 + p * 8 + 8] = plane[k * 512 + src * 8: k * 512 + src * 8 + 8]
+    for t in range(G // 2):
+        for ks in range(2):
+            got = np.zeros((64, 8), dtype=np.int64)
+            for rd in range(2):
+                addr = np.zeros(64, dtype=np.int64)   # byte address of every lane's 8-byte row
+                for l in range(64):
+                    grp, qq = l >> 4, l & 15
+                    rr, mm = qq >> 2, qq & 3
+                    par, khalf, hh, jj = grp & 1, grp >> 1, mm & 1, mm >> 1
+                    lane_off = par * 1024 + hh * 512 + (rr + 8 * (khalf ^ par)) * 16 + jj * 8
+                    addr[l] = t * 2048 + ks * 256 + lane_off + 64 * (hh if rd == 0 else 1 - hh)
+                for half in range(2):                 # bank check per group of 32 lanes: 8 bytes each over 64 four-byte banks
+                    banks = np.concatenate([[(a // 4) % 64, (a // 4 + 1) % 64] for a in addr[32 * half: 32 * half + 32]])
+                    assert len(set(banks.tolist())) == 64
+                for l in range(64):                   # the transposing read
+                    base = l & ~15
+                    i = l & 15
+                    for r in range(4):
+                        src_lane = base + 4 * r + (i >> 2)
+                        got[l, 4 * rd + r] = lds[addr[src_lane] // 2 + (i & 3)]
+            for l in range(64):
+                for e in range(8):
+                    assert got[l, e] == 1000 * (16 * ks + 8 * (l >> 5) + e) + 32 * t + (l & 31), (t, ks, l, e, got[l, e])

@@ -24,7 +24,7 @@ import torch
 
 
 def scene_cfg(path, scene, style="tanks", n_rays=1024, n_samples=128, hidden=256, resident=True, aux=True, resize_factor=None,
-              sample_rate=8, workers=0):
+              sample_rate=8, workers=0, mfma_dtype="fp32"):
     """The keys configs/default.yaml + configs/Tanks/*.yaml (style 'tanks') or configs/LLFF/fern.yaml (style 'llff') would set."""
     llff = style == "llff"
     on = [1.0, 0.0] if aux else [0.0, 0.0]
@@ -38,7 +38,7 @@ def scene_cfg(path, scene, style="tanks", n_rays=1024, n_samples=128, hidden=256
         "rendering": {"type": "nope_nerf", "n_max_network_queries": 64000, "white_background": False, "radius": 4.0,
                       "num_points": n_samples, "depth_range": [0.0, 1.0] if llff else [0.01, 10], "dist_alpha": llff,
                       "use_ray_dir": True, "normalise_ray": True, "normal_loss": False,
-                      "sample_option": "ndc" if llff else "uniform", "outside_steps": 0},
+                      "sample_option": "ndc" if llff else "uniform", "outside_steps": 0, "mfma_dtype": mfma_dtype},
         "depth": {"type": "None"},
         "pose": {"learn_pose": True, "learn_R": True, "learn_t": True, "init_pose": False, "learn_focal": False},
         "distortion": {"learn_distortion": True, "fix_scaleN": True, "learn_scale": True, "learn_shift": True},
@@ -154,6 +154,7 @@ def run(path, scene, style="tanks", epochs=100, seed=42, log_every=10, device=No
             curve.append(dict(epoch=epoch, psnr=float(mse2psnr(mse)), **pose_errors(pose, gt, n_views)))
             if parallel.rank() == 0:
                 print(json.dumps(curve[-1]), flush=True)
+    trainer.flush_nan_check()        # the step's NaN check is one step late by design: look at the last one too
     n_rays = cfg["training"]["n_training_points"]
     novel = None
     if eval_epochs > 0:
@@ -181,13 +182,15 @@ def main():
     ap.add_argument("--host-loader", action="store_true")
     ap.add_argument("--workers", type=int, default=0, help="DataLoader worker processes of the host loader (reference default: 1)")
     ap.add_argument("--no-aux", action="store_true")
+    ap.add_argument("--bf16", action="store_true", help="rendering.mfma_dtype: bf16 (bf16 MFMA products, fp32 accumulation)")
     ap.add_argument("--log-every", type=int, default=10)
     ap.add_argument("--eval-epochs", type=int, default=0, help="test-time pose optimisation epochs before scoring the held-out views")
     ap.add_argument("--eval-dir", default=None, help="where the rendered held-out frames go (default: a temporary directory)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     res = run(a.path, a.scene, style=a.style, epochs=a.epochs, log_every=a.log_every, eval_epochs=a.eval_epochs, eval_dir=a.eval_dir, n_rays=a.rays, n_samples=a.samples,
-              hidden=a.hidden, resident=not a.host_loader, aux=not a.no_aux, resize_factor=a.factor, workers=a.workers)
+              hidden=a.hidden, resident=not a.host_loader, aux=not a.no_aux, resize_factor=a.factor, workers=a.workers,
+              mfma_dtype="bf16" if a.bf16 else "fp32")
     print(json.dumps({k: v for k, v in res.items() if k != "curve"}))
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
