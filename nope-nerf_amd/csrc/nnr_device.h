@@ -280,6 +280,11 @@ __device__ __forceinline__ bf16x8 pack_row(const float (&in)[NIN], int b) {
 // bf16 values the MFMA of that row consumes, one 16-byte store per lane = one 1 KiB block per wave -- `stash` is then a bf16
 // element pointer in disguise, see stash_row()); 2 = to an fp32 plane as in the fp32 kernels (the encodings, which the backward
 // of the encodings reads back at full precision).
+#ifdef NNR_BF16_FREE_SCHED      // profiling experiment: let hipcc place the fillers of the bf16 rows itself
+#define NNR_BF16_SB() ((void)0)
+#else
+#define NNR_BF16_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <int KT, int MT, int STASH, int NSIDE_, int PPG_, int SHIFT, class Side, int NACC, int NIN>
 __device__ __forceinline__ void gemm_part_bf16(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
                                                float* stash, const Side& side) {
@@ -307,9 +312,9 @@ __device__ __forceinline__ void gemm_part_bf16(f32x16 (&acc)[NACC], const float 
         bf16x8 nq;
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-            __builtin_amdgcn_sched_barrier(0);
+            NNR_BF16_SB();
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.v[j]), bq, acc[j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            NNR_BF16_SB();
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 if (f * MT / 4 != j) continue;
@@ -354,7 +359,7 @@ __device__ __forceinline__ void gemm_part_bf16(f32x16 (&acc)[NACC], const float 
             }
         }
         pin_acc<MT>(acc);
-        __builtin_amdgcn_sched_barrier(0);
+        NNR_BF16_SB();
         if (g + 1 < G) { cur = nxt; bq = nq; }
     }
     if constexpr (NSIDE > 0) {
@@ -401,11 +406,51 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N]) {
 }
 
 // feature index held by register r (any tile) in half h
-__device__ __forceinline__ int frag_feature(int r, int h) { return 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h; }
+__device__ __forceinline__ constexpr int frag_feature(int r, int h) { return 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h; }
 
-// One element of gamma_L(x) = [x, sin(2^0 x), cos(2^0 x), ...] in the reference's 3-wide block order
-// (model/official_nerf.py:112-118).  f >= 3*(2L+1) is padding (0).  Accurate sincosf (full range reduction): arguments
-// reach 2^9 * |p| ~ 5e3 rad, so the fast hardware sin is not usable at 1e-4 parity.
+// sin(a) or cos(a) (want_cos) of one lane's argument, accurate to ~1 ulp for |a| < 2^15 -- the arguments reach 2^9 |p| ~ 5e3 rad, so the
+// fast hardware sin (1e-6 ABSOLUTE error in revolutions) is not usable at 1e-4 parity, and ocml's sincosf, which is, spends ~80
+// instructions per call on a Payne-Hanek path these arguments never need (the 48 calls per sample were 16-32 k cycles per wave: 5 % of
+// the fp32 forward, a quarter of the bf16 one).  Two-term Cody-Waite reduction with fma (exact for the product, the remainder is < 1:
+// error ~3e-8) to r in [-pi/4, pi/4], quadrant n; cos(a) = sin(a + pi/2) shifts the quadrant; then the cephes minimax polynomials
+// (|error| < 1 ulp on the reduced range).  ~20 VALU instructions.
+__device__ __forceinline__ float sin_or_cos(float a, bool want_cos) {
+    const float n = __builtin_rintf(a * 0.63661977236758134308f);          // a / (pi/2), round to nearest even
+    float r = __builtin_fmaf(-n, 1.57079637050628662109375f, a);             // pi/2 rounded to fp32 ...
+    r = __builtin_fmaf(-n, -4.37113900018624283e-8f, r);                     // ... and what it leaves out
+    const int q = (int)n + (want_cos ? 1 : 0);
+    const float z = r * r;
+    const float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                                    __builtin_fmaf(-0.5f, z, 1.0f));
+    const float v = (q & 1) ? cp : sp;
+    return (q & 2) ? -v : v;
+}
+
+// What feature f of gamma_L is, at compile time (same 3-wide block order as the reference: model/official_nerf.py:112-118)
+struct EncWhat { int coord, lvl; bool identity, is_cos, pad; };
+__device__ __forceinline__ constexpr EncWhat enc_what(int f, int n_real) {
+    if (f >= n_real) return {0, 0, false, false, true};
+    if (f < 3) return {f, 0, true, false, false};
+    const int t = f - 3, lvl = t / 6, rem = t - 6 * lvl;
+    return {rem >= 3 ? rem - 3 : rem, lvl, false, rem >= 3, false};
+}
+
+// Register r of the lane's half of gamma_L(x, y, z) = [x, sin(2^0 x), cos(2^0 x), ...] in fragment layout: feature
+// frag_feature(r, half) -- frag_feature(r, 0) for the lower half-wave, + 4 for the upper.  Both candidates are decoded at compile
+// time; at run time the lane picks its argument (one select per field that differs) and evaluates ONE sin_or_cos.
+// f >= n_real is padding (0).
+__device__ __forceinline__ float enc_register(int r, int half, int n_real, float x, float y, float z) {
+    const EncWhat w0 = enc_what(frag_feature(r, 0), n_real), w1 = enc_what(frag_feature(r, 1), n_real);
+    const float c0 = w0.coord == 0 ? x : (w0.coord == 1 ? y : z), c1 = w1.coord == 0 ? x : (w1.coord == 1 ? y : z);
+    const float v = half ? c1 : c0;
+    const float a = v * (half ? (float)(1 << w1.lvl) : (float)(1 << w0.lvl));        // exact: a power of two
+    const float sc = sin_or_cos(a, half ? w1.is_cos : w0.is_cos);
+    const bool ident = half ? w1.identity : w0.identity, pad = half ? w1.pad : w0.pad;
+    return pad ? 0.f : (ident ? v : sc);
+}
+
+// One element of gamma_L(x) for a run-time feature index (kept for callers outside the hot loop)
 __device__ __forceinline__ float enc_feature(int f, int n_real, float x, float y, float z) {
     if (f >= n_real) return 0.f;
     int t = f < 3 ? f : f - 3;
@@ -414,9 +459,7 @@ __device__ __forceinline__ float enc_feature(int f, int n_real, float x, float y
     int c = f < 3 ? f : (rem >= 3 ? rem - 3 : rem);
     float v = c == 0 ? x : (c == 1 ? y : z);
     if (f < 3) return v;
-    float s, co;
-    sincosf(ldexpf(v, lvl), &s, &co);
-    return rem >= 3 ? co : s;
+    return sin_or_cos(ldexpf(v, lvl), rem >= 3);
 }
 
 // d gamma_L / d x contracted with the upstream gradient `ge` of feature f, using the *stored* encoding `e`:

@@ -69,10 +69,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // ---- encodings, straight into fragment layout ----
     float e[32];  // gamma_10(p): 63 -> 64
 #pragma unroll
-    for (int r = 0; r < 32; ++r) e[r] = enc_feature(frag_feature(r, half), kPosReal, px, py, pz);
+    for (int r = 0; r < 32; ++r) e[r] = enc_register(r, half, kPosReal, px, py, pz);
     float dirv[16];  // gamma_4(v): 27 -> 32
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dirv[r] = enc_feature(frag_feature(r, half), kDirReal, vx, vy, vz);
+    for (int r = 0; r < 16; ++r) dirv[r] = enc_register(r, half, kDirReal, vx, vy, vz);
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 1);
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 2);
 

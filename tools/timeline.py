@@ -19,7 +19,10 @@ if __name__ == "__main__":
     cfg = bench.full_cfg(bench.R_PER_GPU)
     torch.manual_seed(42)
     net = mdl.OfficialStaticNerf(cfg).to(dev)
-    out = bench.kernel_roofline(net, dev, reps=2)
+    # python tools/timeline.py [R N [bf16]]
+    R, N = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (bench.R_PER_GPU, bench.N_SAMPLES)
+    bf16 = len(sys.argv) > 3 and sys.argv[3] == "bf16"
+    out = bench.kernel_roofline(net, dev, reps=2, bf16=bf16, rays=R, n_samples=N)
     print(json.dumps(out["kernels"]))
     handle = ctypes.CDLL(nnrlib.LIB_PATH)
     for name in ("nnr_timeline_fwd", "nnr_timeline_dgrad", "nnr_timeline_wgrad"):
@@ -38,7 +41,7 @@ if __name__ == "__main__":
                 continue
             n = max(i for i, x in enumerate(v) if x) + 1
             print(name, tag, "rc", rc, "total", v[n - 1] - v[0], "deltas", [v[i + 1] - v[i] for i in range(n - 1)])
-    if hasattr(handle, "nnr_timeline_wgrad_all"):
+    if hasattr(handle, "nnr_timeline_wgrad_all") and not bf16:
         import numpy as np
         buf = (ctypes.c_ulonglong * 4096)()
         handle.nnr_timeline_wgrad_all(buf)
