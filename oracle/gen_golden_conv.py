@@ -1,0 +1,124 @@
+"""Convergence through the REFERENCE code path (BASELINE configs[4]: LLFF-style NDC rays, train to convergence, PSNR + ATE against
+the reference): the reference's own Trainer / Renderer / OfficialStaticNerf / LearnPose / Learn_Distortion / Loss and pose metrics
+(utils_poses/comp_ate.py:33-73, align_traj.py:26-69) run the training loop of train.py:157-230 on CPU over a synthetic
+forward-facing scene (tools/scene_writer.py: 8 views of 48 x 64, LLFF layout) for 100 epochs = 800 Adam steps -- LLFF settings
+(configs/LLFF/fern.yaml: sample_option ndc, dist_alpha, depth_range [0, 1]), D = 128, 128 rays x 32 samples, first-phase losses on,
+poses from (almost) identity.  Every step's frame, neighbour and pixel permutation are recorded; tests/test_conv_reference.py replays them
+through this repository's loop (HIP kernels on the GPU, the oracle stand-in on the CPU) and must track the curve.
+
+TEST INFRASTRUCTURE; authoring container only:   python oracle/gen_golden_conv.py      -> tests/golden/conv_llff.npz"""
+import copy
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import gen_golden as gg  # noqa: E402
+
+FRAMES, SIZE, SEED_SCENE = 8, (48, 64), 5
+R, N, D, EPOCHS = 128, 32, 128, 100
+LOGGED = ("loss", "loss_rgb", "loss_depth", "loss_pc", "loss_rgb_s", "l2_mean")
+
+LOAD_SCENE = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1] + "/nope-nerf_amd"); sys.path.insert(0, sys.argv[1] + "/tools")
+import scene_writer, train_scene, dataloading as dl
+scene_writer.write_scene(sys.argv[2], scene="toy", frames=%d, size=%r, seed=%d)
+cfg = train_scene.scene_cfg(sys.argv[2], "toy", style="llff", n_rays=%d, n_samples=%d, hidden=%d, resident=False, sample_rate=10 ** 6)
+_, fields = dl.get_dataloader(cfg, mode="train", shuffle=True)
+f = fields["img"]
+np.savez(sys.argv[3], imgs=f.imgs, dpt=f.dpt_depth, K=f.K, c2ws=np.asarray(f.c2ws), refs=np.array([f.pick_reference(i) for i in range(f.N_imgs)]))
+''' % (FRAMES, SIZE, SEED_SCENE, R, N, D)
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        # the scene goes through THIS repository's loader (pinned bit-exact against the reference's DataField: tests/test_dataloading.py)
+        # in a separate process: `model` / `dataloading` of the reference are imported below under the same names
+        npz = os.path.join(tmp, "scene.npz")
+        subprocess.run([sys.executable, "-c", LOAD_SCENE, ROOT, tmp, npz], check=True)
+        sc = np.load(npz)
+        imgs, dpt, K, gt, refs = (torch.from_numpy(sc[k]) for k in ("imgs", "dpt", "K", "c2ws", "refs"))
+    ref = gg.import_reference()
+    sys.path.insert(0, gg.REF)
+    from utils_poses.align_traj import align_ate_c2b_use_a2b
+    from utils_poses.comp_ate import compute_ATE, compute_rpe
+    from model.common import mse2psnr
+    torch.set_num_threads(8)
+    cfg = copy.deepcopy(gg.base_cfg(D))
+    cfg["training"].update(n_training_points=R, pc_weight=[1.0, 0.0], rgb_s_weight=[1.0, 0.0], vis_reprojection_every=10 ** 9)
+    cfg["rendering"].update(num_points=N, sample_option="ndc", dist_alpha=True, depth_range=[0.0, 1.0])
+    dev = torch.device("cpu")
+    np.random.seed(42)
+    torch.manual_seed(42)                                            # train.py:22-23
+    net = ref.OfficialStaticNerf(cfg)
+    base = np.load(os.path.join(gg.OUT, "weights_d128.npz"))
+    assert all(np.array_equal(base[k], v.numpy()) for k, v in net.state_dict().items())      # the seed-42 D=128 network
+    model = ref.get_model(ref.Renderer(net, cfg["rendering"], device=dev), cfg, device=dev)
+    pose, dist = ref.LearnPose(FRAMES, True, True, cfg), ref.Learn_Distortion(FRAMES, True, True, cfg)
+    # Not exactly the identity: with all cameras at the identity the surface re-projection maps the sampling grid onto itself, every
+    # bilinear lookup sits exactly on a pixel centre and every border point exactly on |xy| = 1 -- floor() and the validity test
+    # then hinge on the last bit, and two correct implementations disagree by a whole point (1/192 of the term) at step 0.
+    g = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        pose.r.copy_(0.01 * torch.randn(FRAMES, 3, generator=g))
+        pose.t.copy_(0.01 * torch.randn(FRAMES, 3, generator=g))
+    init_r, init_t = pose.r.detach().clone().numpy(), pose.t.detach().clone().numpy()
+    adam = lambda m, lr: torch.optim.Adam(m.parameters(), lr=lr)
+    tr = ref.Trainer(model, adam(model, 1e-3), cfg["training"], device=dev, optimizer_pose=adam(pose, 5e-4), pose_param_net=pose,
+                     optimizer_distortion=adam(dist, 5e-4), distortion_net=dist)
+    real_randperm = torch.randperm
+    drawn = {}
+
+    def randperm(n, *a, **k):
+        drawn["perm"] = real_randperm(n, *a, **k)
+        return drawn["perm"]
+
+    def pose_errors():
+        with torch.no_grad():
+            learned = torch.stack([pose(i) for i in range(FRAMES)])
+        aligned = align_ate_c2b_use_a2b(learned, gt).cpu().numpy()
+        rpe_t, rpe_r = compute_rpe(gt.numpy(), aligned)
+        return float(compute_ATE(gt.numpy(), aligned)), float(rpe_t * 100), float(np.degrees(rpe_r))
+
+    Kt = K.unsqueeze(0) if K.dim() == 2 else K
+    eye = torch.eye(4).unsqueeze(0)
+    order, picks, losses, curve = [], [], [], [(-1, float("nan")) + pose_errors()]
+    torch.randperm = randperm
+    try:
+        it = 0          # train.py starts at -1 + 1 = 0, where the first step also dumps the re-projection PNGs (it % vis_reprojection_every): start at 1
+        for epoch in range(EPOCHS):
+            l2 = []
+            for cam in real_randperm(FRAMES).tolist():              # the shuffled DataLoader of train.py:35
+                it += 1
+                nb = int(refs[cam])
+                data = {"img": imgs[cam:cam + 1], "img.idx": cam, "img.dpt": dpt[cam:cam + 1], "img.camera_mat": Kt,
+                        "img.scale_mat": eye, "img.ref_imgs": imgs[nb:nb + 1], "img.ref_dpts": dpt[nb:nb + 1], "img.ref_idxs": nb}
+                ld = tr.train_step(data, it, epoch, 10 ** 6, None)
+                order.append((cam, nb))
+                picks.append(drawn["perm"][:R].numpy().astype(np.int16))
+                losses.append([float(ld[k]) for k in LOGGED])
+                l2.append(float(ld["l2_mean"]))
+            if epoch % 10 == 0 or epoch == EPOCHS - 1:
+                curve.append((epoch, float(mse2psnr(np.mean(l2)))) + pose_errors())
+                print("epoch %3d  PSNR %.2f dB  ATE %.4f  RPE_t %.3f  RPE_r %.3f deg" % curve[-1])
+    finally:
+        torch.randperm = real_randperm
+    blob = {"order": np.array(order, dtype=np.int16), "ray_idx": np.stack(picks), "losses": np.array(losses, dtype=np.float64),
+            "logged": np.array(LOGGED), "curve": np.array(curve, dtype=np.float64),
+            "init.pose_r": init_r, "init.pose_t": init_t, "final.pose_r": pose.r.detach().numpy(), "final.pose_t": pose.t.detach().numpy(),
+            "final.scales": dist.global_scales.detach().numpy(), "final.shifts": dist.global_shifts.detach().numpy(),
+            "cfg": np.array([FRAMES, SIZE[0], SIZE[1], SEED_SCENE, R, N, D, EPOCHS])}
+    out = os.path.join(gg.OUT, "conv_llff.npz")
+    np.savez_compressed(out, **blob)
+    print("wrote", out, os.path.getsize(out), "bytes;", len(order), "steps")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,10 @@
 """Helper process for tests/test_dropin_scripts.py (not a pytest module): runs one of the REFERENCE's own, unmodified entry scripts
 (train.py, evaluation/eval_poses.py) with this repository's `model`, `dataloading` and `utils_poses` packages on the import path
-in place of the reference's -- the drop-in scenario of SURVEY.md 8(b).  CPU only: the HIP render operator is swapped for the
-oracle-backed stand-in (tests/oracle_backend.py), tensorboard (absent in this image) for a recorder.
+in place of the reference's -- the drop-in scenario of SURVEY.md 8(b).  By default the HIP render operator is swapped for the
+oracle-backed CPU stand-in (tests/oracle_backend.py); DROPIN_BACKEND=hip leaves the HIP kernels in place (the GPU box: the reference's
+train.py, unmodified, on libnnr.so).  tensorboard (absent in this image) is replaced by a recorder.  DROPIN_CPU_DRAWS=1 makes every
+random draw of the step (pixel permutation, jitter) come from torch's CPU generator and then move to the device, so that a CPU
+run and a GPU run of the same script see the same pixels and jitter and can be compared step by step.
 
     python tests/dropin_runner.py <script> <config.yaml> [extra args]        (cwd = the reference checkout, for configs/default.yaml)
 """
@@ -63,9 +66,22 @@ def main():
     import utils_poses.comp_ate
     for mod in (model, dataloading, utils_poses.comp_ate):
         assert mod.__file__.startswith(ROOT), mod.__file__             # ours, not the reference's
-    import oracle_backend
-    from model import rendering
-    rendering.nnr.render_rays = oracle_backend.render_rays
+    if os.environ.get("DROPIN_BACKEND", "oracle") != "hip":
+        import oracle_backend
+        from model import rendering
+        rendering.nnr.render_rays = oracle_backend.render_rays
+    if os.environ.get("DROPIN_CPU_DRAWS") == "1":
+        from nnr import sampling
+        real_randperm, real_rand = torch.randperm, torch.rand
+
+        def cpu_randperm(n, *a, device=None, **k):
+            return real_randperm(n, *a, **k).to(device if device is not None else "cpu")
+
+        def cpu_rand(*shape, device=None, **k):
+            return real_rand(*shape, **k).to(device if device is not None else "cpu")
+
+        torch.randperm, torch.rand = cpu_randperm, cpu_rand
+        sampling.randperm_prefix = lambda n, r, device: cpu_randperm(n, device=device)[:r]
 
     sys.argv = [script] + argv
     try:

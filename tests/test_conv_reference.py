@@ -1,0 +1,93 @@
+"""Convergence against the REFERENCE code path (BASELINE configs[4]: LLFF-style NDC rays, PSNR + ATE vs the reference).
+tests/golden/conv_llff.npz (oracle/gen_golden_conv.py) is the reference's own Trainer / Renderer / MLP / Loss / pose metrics
+training a synthetic forward-facing scene for 800 Adam steps on CPU, with every step's frame, neighbour and pixel permutation
+recorded.  Here the same scene is rebuilt (tools/scene_writer.py is deterministic), read by this repository's loader, and trained by
+this repository's loop fed the same frames and pixels: the per-step losses must track the reference's, and the run must end at the
+reference's PSNR and pose error (pose metrics: this repository's utils_poses, pinned to the reference's in tests/test_pose_metrics.py).
+
+Training is a chaotic map: two fp32 evaluation orders of the same step differ in the last bit, and Adam amplifies that over hundreds
+of steps -- measured here: every logged term agrees to 1e-6 .. 1e-5 for the first 15 steps, then the deviation grows about tenfold every
+ten steps until it saturates at the batch-noise level.  So the step-wise comparison is tight where it can be (the first 20 steps: 2e-4;
+the first 50: 5e-3) and statistical afterwards (the smoothed loss curve within 2 %, final PSNR within 0.2 dB, ATE / RPE within 5 %).
+r02 on the MI355X: 1.0e-4 / 3.3e-3 / 0.85 %; PSNR 20.18 dB vs 20.32, ATE 0.0733 vs 0.0739, RPE_r 3.94 deg vs 3.89."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in ("nope-nerf_amd", "tools", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+GOLD = np.load(os.path.join(HERE, "golden", "conv_llff.npz"))
+FRAMES, H, W, SEED_SCENE, R, N, D, EPOCHS = (int(x) for x in GOLD["cfg"])
+LOGGED = [str(k) for k in GOLD["logged"]]
+
+
+def _replay(tmp_path, dev, monkeypatch, n_steps):
+    import scene_writer
+    import train_scene
+    import dataloading as dl
+    from model.common import mse2psnr
+    scene_writer.write_scene(str(tmp_path), scene="toy", frames=FRAMES, size=(H, W), seed=SEED_SCENE)
+    cfg = train_scene.scene_cfg(str(tmp_path), "toy", style="llff", n_rays=R, n_samples=N, hidden=D, resident=False, sample_rate=10 ** 6)
+    _, fields = dl.get_dataloader(cfg, mode="train", shuffle=True)
+    f = fields["img"]
+    np.random.seed(42)
+    torch.manual_seed(42)
+    trainer, pose, dist = train_scene.build(cfg, dev, FRAMES)
+    base = np.load(os.path.join(HERE, "golden", "weights_d128.npz"))     # the reference's seed-42 network (asserted by the generator)
+    trainer.model.renderer.model.load_state_dict({k: torch.from_numpy(base[k]) for k in base.files})
+    with torch.no_grad():
+        pose.r.copy_(torch.from_numpy(GOLD["init.pose_r"]))
+        pose.t.copy_(torch.from_numpy(GOLD["init.pose_t"]))
+    imgs, dpt = torch.from_numpy(np.ascontiguousarray(f.imgs)).to(dev), torch.from_numpy(np.ascontiguousarray(f.dpt_depth)).to(dev)
+    K, eye = torch.from_numpy(f.K).unsqueeze(0).to(dev), torch.eye(4).unsqueeze(0).to(dev)
+    gt = torch.as_tensor(np.asarray(f.c2ws)).to(dev)
+    losses = []
+    for s in range(n_steps):
+        cam, nb = (int(x) for x in GOLD["order"][s])
+        ray_idx = torch.from_numpy(GOLD["ray_idx"][s].astype(np.int64))
+        monkeypatch.setattr(torch, "randperm", lambda n, device=None, **kw: torch.cat([ray_idx, torch.zeros(n - R, dtype=torch.int64)]).to(device))
+        data = {"img": imgs[cam:cam + 1], "img.idx": cam, "img.dpt": dpt[cam:cam + 1], "img.camera_mat": K, "img.scale_mat": eye,
+                "img.ref_imgs": imgs[nb:nb + 1], "img.ref_dpts": dpt[nb:nb + 1], "img.ref_idxs": nb}
+        ld = trainer.train_step(data, s + 1, s // FRAMES, 10 ** 6, None)
+        losses.append(torch.stack([ld[k].detach().float().reshape(()) for k in LOGGED]))
+    trainer.flush_nan_check()
+    losses = torch.stack(losses).cpu().numpy().astype(np.float64)
+    errs = train_scene.pose_errors(pose, gt, FRAMES)
+    l2 = losses[-FRAMES:, LOGGED.index("l2_mean")].mean()
+    return losses, float(mse2psnr(l2)), errs, pose, dist
+
+
+def test_first_steps_track_the_reference_run_on_the_cpu_stand_in(tmp_path, monkeypatch):
+    import oracle_backend
+    from model import rendering
+    monkeypatch.setattr(rendering.nnr, "render_rays", oracle_backend.render_rays)
+    losses, _, _, _, _ = _replay(tmp_path, torch.device("cpu"), monkeypatch, 24)
+    ref = GOLD["losses"][:24]
+    assert np.abs(losses - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), float(np.abs(losses - ref).max())
+
+
+@pytest.mark.gpu
+def test_hip_training_run_tracks_the_reference_run(tmp_path, monkeypatch):
+    n = len(GOLD["order"])
+    losses, psnr, errs, pose, dist = _replay(tmp_path, torch.device("cuda"), monkeypatch, n)
+    ref = GOLD["losses"]
+    dev = np.abs(losses - ref)
+    scale = np.maximum(1.0, np.abs(ref))
+    first20, early = float((dev[:20] / scale[:20]).max()), float((dev[:50] / scale[:50]).max())
+    k = LOGGED.index("loss")
+    smooth = lambda x: np.convolve(x, np.ones(40) / 40, mode="valid")
+    curve_dev = float(np.abs(smooth(losses[:, k]) - smooth(ref[:, k])).max() / smooth(ref[:, k]).max())
+    ref_epoch, ref_psnr, ref_ate, ref_rpe_t, ref_rpe_r = GOLD["curve"][-1]
+    print("HIP vs reference run over %d steps: max loss deviation first 20 steps %.2e, first 50 steps %.2e, smoothed loss curve %.2e of its "
+          "scale; final PSNR %.2f dB (reference %.2f), ATE %.4f (%.4f), RPE_r %.3f deg (%.3f)"
+          % (n, first20, early, curve_dev, psnr, ref_psnr, errs["ate"], ref_ate, errs["rpe_rot_deg"], ref_rpe_r))
+    assert first20 <= 2e-4 and early <= 5e-3, (first20, early)
+    assert curve_dev <= 2e-2, curve_dev
+    assert abs(psnr - ref_psnr) <= 0.2, (psnr, ref_psnr)
+    assert abs(errs["ate"] - ref_ate) <= 0.05 * ref_ate, (errs["ate"], ref_ate)
+    assert abs(errs["rpe_rot_deg"] - ref_rpe_r) <= 0.05 * ref_rpe_r
