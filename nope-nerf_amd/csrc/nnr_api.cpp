@@ -52,6 +52,13 @@ size_t packed_floats(int D, bool bf16) {
 }
 bool is_bf16(const nnr_cfg* c) { return (c->flags & NNR_F_BF16) != 0; }
 
+// Ray mode of the two MLP kernels (nnr_mlp_fwd.hip): a wave walks the N / 32 chunks of ONE ray, a workgroup four rays.  Needs whole
+// chunks per ray and whole workgroups; everything else runs the flat decomposition (same sample numbering, same planes).
+int chunks_per_ray(const nnr_cfg* c) {
+    static const bool off = std::getenv("NNR_FLAT_GRID") != nullptr;    // experiments: force the flat decomposition
+    return (!off && c->n_samples % kChunk == 0 && c->n_rays % kWavesPerBlock == 0) ? c->n_samples / kChunk : 0;
+}
+
 // ---- weight-gradient plan -------------------------------------------------------------------------------------------
 struct Unit {  // a wave tile before the split over samples
     WgradJob j;
@@ -457,6 +464,7 @@ int nnr_mlp_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, cons
         a.ws_mask = reinterpret_cast<uint32_t*>(ws + plane(w, P_MASK));
     }
     a.S = w.S; a.S_pad = w.S_pad; a.N = cfg->n_samples;
+    a.chunks_per_ray = chunks_per_ray(cfg);
     hipError_t e = launch_mlp_fwd(cfg->hidden, a, w.train, is_bf16(cfg), (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
@@ -515,6 +523,7 @@ int nnr_mlp_dgrad(const nnr_cfg* cfg, const float* packed, float* ws, void* stre
     a.ws_dpts = ws + plane(w, P_DPTS);
     a.ws_dview = ws + plane(w, P_DVIEW);
     a.S = w.S; a.S_pad = w.S_pad;
+    a.chunks_per_ray = chunks_per_ray(cfg);
     hipError_t e = launch_mlp_dgrad(cfg->hidden, a, is_bf16(cfg), (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }

@@ -46,8 +46,23 @@ struct PanelPipe {
     f32x4* lds;        // base of the three panel buffers in LDS
     int wave, lane;    // wave is wave-uniform (readfirstlane'd by the caller)
     int n_panels;      // panels in the stream
+    // A workgroup may run the stream several times in a row (one pass per 32-sample chunk of its rays, see mlp_fwd_kernel): the
+    // stream then WRAPS -- while the last panels of one pass are consumed, the first panels of the next pass are already on their
+    // way, so only the first pass of a workgroup waits for weights.  A panel index p >= n_panels names panel p - n_panels of the
+    // next pass; `phase` = (panels of the earlier passes) % kNBuf keeps the ring position running across passes.
+    int phase = 0;
+    bool more = false;   // another pass follows this one
 
-    // This wave copies fragments [8*wave, 8*wave+8) of panel p into buffer p % 3 as 8 DMA "pieces" of 1 KiB, always
+    __device__ __forceinline__ int buffer(int p) const {   // ring slot of panel p of the current pass (p compile-time in the callers)
+        const int b = p % kNBuf + phase;
+        return b >= kNBuf ? b - kNBuf : b;
+    }
+    __device__ __forceinline__ void next_pass(bool more_after) {
+        phase = (phase + n_panels % kNBuf) % kNBuf;
+        more = more_after;
+    }
+
+    // This wave copies fragments [8*wave, 8*wave+8) of panel p into its ring slot as 8 DMA "pieces" of 1 KiB, always
     // exactly 8 per panel -- the counted wait below relies on it.  With a uniform base the address is
     // SGPR base + lane*16 and the LDS destination (M0) is scalar: no VALU work per piece.
     __device__ __forceinline__ void piece(int p, int i) const {
@@ -57,8 +72,9 @@ struct PanelPipe {
         // One address pair per PANEL (global: VGPRs, LDS: M0), both pointing at piece 4; the piece is selected by the
         // instruction's signed 13-bit immediate, which offsets the global and the LDS address alike -- so a piece costs
         // one VMEM issue and no address arithmetic.
-        const f32x4* g = src + (int64_t)p * kPanelF4 + 4 * 64 + lane;
-        f32x4* l = lds + (p % kNBuf) * kPanelF4 + wave * (8 * 64) + 4 * 64;
+        const int ps = p < n_panels ? p : p - n_panels;
+        const f32x4* g = src + (int64_t)ps * kPanelF4 + 4 * 64 + lane;
+        f32x4* l = lds + buffer(p) * kPanelF4 + wave * (8 * 64) + 4 * 64;
         switch (i) {   // the offset operand must be a literal
             case 0: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -4096, 0); break;
             case 1: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -3072, 0); break;
@@ -70,9 +86,9 @@ struct PanelPipe {
             default: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 3072, 0); break;
         }
     }
-    // pieces [first, first+count) of panel p (nothing past the end of the stream; p is wave-uniform)
+    // pieces [first, first+count) of panel p (nothing past the end of the LAST pass's stream; p is wave-uniform)
     __device__ __forceinline__ void pieces(int p, int first, int count) const {
-        if (p < n_panels) {
+        if (p < n_panels || more) {
 #pragma unroll
             for (int i = first; i < first + count && i < 8; ++i) piece(p, i);
         }
@@ -93,14 +109,14 @@ struct PanelPipe {
 #endif
         static_assert(8 + EXTRA < 64, "vmcnt is a 6-bit field");
         // lgkmcnt(0): this wave's ds_reads of panel p-1 have returned before it reports "done reading" at the barrier
-        if (p + 1 < n_panels)
+        if (p + 1 < n_panels || more)
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + EXTRA) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    __device__ __forceinline__ void start() const {  // prologue: two panels in flight
+    __device__ __forceinline__ void start() const {  // prologue of a workgroup's FIRST pass: two panels in flight
         pieces(0, 0, 8);
         pieces(1, 0, 8);
     }
@@ -124,7 +140,7 @@ template <int KT, int MT>
 __device__ __forceinline__ Frags<MT> gemm_open(const PanelPipe& pipe, int p0) {
     pipe.enter(p0);
     pipe.pieces(p0 + 2, 0, panel_ppk<KT, MT>(0));
-    const f32x4* buf = pipe.lds + (p0 % kNBuf) * kPanelF4 + pipe.lane;
+    const f32x4* buf = pipe.lds + pipe.buffer(p0) * kPanelF4 + pipe.lane;
     Frags<MT> f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) f.v[mt] = buf[mt * 64];
@@ -204,7 +220,7 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
 #else
                         if (f == 0 && (g + 1) % GP == 0) pipe.template enter<STASH ? GP - 1 : 0>(pn);
 #endif
-                        const f32x4* buf = pipe.lds + (pn % kNBuf) * kPanelF4 + pipe.lane;
+                        const f32x4* buf = pipe.lds + pipe.buffer(pn) * kPanelF4 + pipe.lane;
                         nxt.v[f] = buf[(((g + 1) % GP) * MT + f) * 64];
                     }
                 } else if (f == MT) {
@@ -300,7 +316,7 @@ __device__ __forceinline__ void gemm_part_bf16(f32x16 (&acc)[NACC], const float 
     pipe.pieces(p0 + 2, 0, (8 + rows_in(0) - 1) / rows_in(0));
     Frags<MT> cur;
     {
-        const f32x4* buf = pipe.lds + (p0 % kNBuf) * kPanelF4 + pipe.lane;
+        const f32x4* buf = pipe.lds + pipe.buffer(p0) * kPanelF4 + pipe.lane;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) cur.v[mt] = buf[mt * 64];
     }
@@ -322,7 +338,7 @@ __device__ __forceinline__ void gemm_part_bf16(f32x16 (&acc)[NACC], const float 
                     if (g + 1 < G) {
                         const int pn = p0 + (g + 1) / GP;
                         if ((g + 1) % GP == 0) pipe.template enter<STASH != 0 ? 2 * (GP - 1) : 0>(pn);
-                        const f32x4* buf = pipe.lds + (pn % kNBuf) * kPanelF4 + pipe.lane;
+                        const f32x4* buf = pipe.lds + pipe.buffer(pn) * kPanelF4 + pipe.lane;
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) nxt.v[mt] = buf[(((g + 1) % GP) * MT + mt) * 64];
                     }

@@ -22,6 +22,7 @@ struct MlpFwdArgs {
     uint32_t* ws_mask;
     int64_t S, S_pad;
     int N;
+    int chunks_per_ray;   // N / 32 in ray mode (N % 32 == 0 and R % 4 == 0: a wave walks one ray), 0 = flat decomposition
 };
 
 struct MlpDgradArgs {
@@ -35,6 +36,7 @@ struct MlpDgradArgs {
     float* ws_dpts;  // (S_pad,4)
     float* ws_dview; // (S_pad,4)
     int64_t S, S_pad;
+    int chunks_per_ray;   // as in MlpFwdArgs
 };
 
 struct CompositeArgs {

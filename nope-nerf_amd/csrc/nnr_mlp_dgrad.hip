@@ -59,35 +59,44 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     constexpr int NP = HR / 2;               // register pairs per half (the unit of hidden epilogue work)
     constexpr int HW = (HR + 31) / 32;       // mask words per half
     constexpr int PP = part_panels(DT, HT, BF16);  // panels of one D x D/2 pass
-    const int lane = threadIdx.x & 63;
+    const int lane0 = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+
+    // LDS: the panel ring of the transposed (backward) weight stream, a parking area for d(posenc) of the skip layer and
+    // the head tables (density row, rgb rows, register order) -- one array, see PanelPipe in nnr_device.h
+    constexpr int kPark = kWavesPerBlock * 8 * 64;
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kPark + (L::head_floats + 3) / 4];
+    float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4 + kPark);
+    for (int i = threadIdx.x; i < L::head_floats; i += 256) ltab[i] = a.packed[L::head_base + i];
+    __syncthreads();   // before any DMA is in flight: the only full barrier of the kernel
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed + L::bwd_base) + wave_u * (8 * 64), smem, wave_u, lane0, L::bwd_panels};
+    // flat or ray-mode decomposition, exactly as in mlp_fwd_kernel: in ray mode a wave walks the chunks of one ray and the transposed
+    // weight stream wraps around from pass to pass
+    const int n_pass = a.chunks_per_ray > 0 ? a.chunks_per_ray : 1;
+    pipe.more = n_pass > 1;
+    pipe.start();
+    NNR_STAMP(tl_dgrad, 1);
+    auto p0 = [&](int part) { return L::bwd_panel0(part); };
+#pragma unroll 1
+    for (int pass = 0; pass < n_pass; ++pass) {
+    int lane = lane0;                 // opaque per pass: keeps lane-constant addresses from being hoisted and spilled (mlp_fwd_kernel)
+    asm volatile("" : "+v"(lane));
+    pipe.lane = lane;
     const int half = lane >> 5;
     const int col = lane & 31;
-    const int64_t s = (int64_t)blockIdx.x * kBlockSamples + wave * kChunk + col;
+    f32x4* const de_lds = smem + kNBuf * kPanelF4 + wave * (8 * 64) + lane;
+    const float* const wsig = ltab + half * (16 * DT);   // density row, this half's registers
+    const float* const wrgb = ltab + 2 * 16 * DT;        // rgb rows: [(2c + half) * HR + r]
+    const int64_t chunk = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * kWavesPerBlock + wave) * n_pass + pass
+                                                : (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    const int64_t s = chunk * kChunk + col;
 #ifdef NNR_ABLATE_STASH_L2
     const int64_t ss = s & 127;   // profiling build only: every stash store hits the same 128 rows (L2-resident)
 #else
     const int64_t ss = s;         // row of the stash planes
 #endif
     const bool live = s < a.S;  // padded samples carry zero gradients so they add nothing to the weight gradients
-
-    // LDS: the panel ring of the transposed (backward) weight stream, a parking area for d(posenc) of the skip layer and
-    // the head tables (density row, rgb rows, register order) -- one array, see PanelPipe in nnr_device.h
-    constexpr int kPark = kWavesPerBlock * 8 * 64;
-    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kPark + (L::head_floats + 3) / 4];
-    f32x4* const de_lds = smem + kNBuf * kPanelF4 + wave * (8 * 64) + lane;
-    float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4 + kPark);
-    for (int i = threadIdx.x; i < L::head_floats; i += 256) ltab[i] = a.packed[L::head_base + i];
-    __syncthreads();   // before any DMA is in flight: the only full barrier of the kernel
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed + L::bwd_base) + wave_u * (8 * 64), smem, wave_u, lane,
-                         L::bwd_panels};
-    pipe.start();
-    NNR_STAMP(tl_dgrad, 1);
-    const float* const wsig = ltab + half * (16 * DT);   // density row, this half's registers
-    const float* const wrgb = ltab + 2 * 16 * DT;        // rgb rows: [(2c + half) * HR + r]
-    auto p0 = [&](int part) { return L::bwd_panel0(part); };
-    const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const uint32_t* mask_base = a.ws_mask + ((chunk * L::n_mask_layers) * 64 + lane) * L::mask_words;
 
     f32x4 dout = {0.f, 0.f, 0.f, 0.f};
@@ -237,6 +246,8 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     NNR_STAMP(tl_dgrad, 7);
 #undef NNR_SEL_PAIR
 #undef NNR_MOVE_PAIR
+    pipe.next_pass(pass + 2 < n_pass);
+    }   // pass
 }
 
 #ifdef NNR_TIMELINE
@@ -247,7 +258,7 @@ extern "C" int nnr_timeline_dgrad(unsigned long long* host32) {
 
 template <int D>
 static hipError_t launch(const MlpDgradArgs& a, bool bf16, hipStream_t st) {
-    dim3 grid((unsigned)(a.S_pad / kBlockSamples)), block(256);
+    dim3 grid((unsigned)(a.chunks_per_ray > 0 ? a.S_pad / kBlockSamples / a.chunks_per_ray : a.S_pad / kBlockSamples)), block(256);
     if (bf16) hipLaunchKernelGGL((mlp_dgrad_kernel<D, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((mlp_dgrad_kernel<D, false>), grid, block, 0, st, a);
     return hipGetLastError();

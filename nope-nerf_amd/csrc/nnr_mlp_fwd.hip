@@ -27,11 +27,39 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 0);
     using L = Layout<D, BF16>;
     constexpr int DT = L::DT, HT = L::HT;
-    const int lane = threadIdx.x & 63;
+    const int lane0 = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+
+    // ---- weight panels (LDS ring, DMA two panels ahead) and the bias / head tables, all in ONE __shared__ array. ----
+    constexpr int kPark = kWavesPerBlock * 12 * 64;   // per wave 12 float4 slots per lane: posenc (8) + direnc (4)
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kPark + (L::table_floats + 3) / 4];
+    float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4 + kPark);
+    for (int i = threadIdx.x; i < L::table_floats; i += 256) ltab[i] = a.packed[L::bias_base + i];
+    __syncthreads();   // before any DMA is in flight: this is the only full barrier of the kernel
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave_u * (8 * 64), smem, wave_u, lane0, L::fwd_panels};
+    // Work decomposition.  Flat (a.chunks_per_ray == 0): workgroup b takes the samples [128 b, 128 b + 128), wave w the 32 from
+    // 32 w on -- one pass over the weight stream per workgroup.  Ray mode (N a multiple of 32, R a multiple of 4): workgroup b takes
+    // the rays 4 b .. 4 b + 3, wave w ray 4 b + w, and walks its N / 32 chunks one after the other; the weight stream wraps around
+    // (PanelPipe), so only the first chunk of a workgroup waits for its first panels, the tables are copied once, and the grid is
+    // R / 4 workgroups -- one per CU at 1024 rays, no tail.  Sample numbering, planes and masks are the same in both modes.
+    const int n_pass = a.chunks_per_ray > 0 ? a.chunks_per_ray : 1;
+    pipe.more = n_pass > 1;
+    pipe.start();
+#pragma unroll 1
+    for (int pass = 0; pass < n_pass; ++pass) {
+    // Everything lane-dependent is derived INSIDE the pass from an opaque copy of the lane id: left to itself the compiler hoists the
+    // dozens of lane-constant addresses and table pointers out of the pass loop and then spills them around the MFMA stream -- and a
+    // spill reload is a VMEM load whose wait (vmcnt) drains the weight DMA queue.
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    pipe.lane = lane;
     const int half = lane >> 5;
     const int col = lane & 31;
-    const int64_t s = (int64_t)blockIdx.x * kBlockSamples + wave * kChunk + col;  // this lane's sample
+    f32x4* const park = smem + kNBuf * kPanelF4 + wave * (12 * 64) + lane;
+    const int64_t chunk_id = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * kWavesPerBlock + wave) * n_pass + pass
+                                                   : (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    const int64_t s = chunk_id * kChunk + col;                                     // this lane's sample
     const int64_t sc = s < a.S ? s : a.S - 1;                                      // clamp: padded samples recompute the last one
 #ifdef NNR_ABLATE_STASH_L2
     const int64_t ss = s & 127;   // profiling build only: every stash store hits the same 128 rows (L2-resident)
@@ -53,19 +81,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     const float pz = __fadd_rn(ro[2], __fmul_rn(rd[2], z));
     const float vx = rv[0], vy = rv[1], vz = rv[2];
     if (half == 0 && s < a.S) a.ws_z[s] = z;
-
-    // ---- weight panels (LDS ring, DMA two panels ahead) and the bias / head tables, all in ONE __shared__ array.
-    // Started BEFORE the encodings: the table copy overlaps the latency of the sampling loads above, and the first two
-    // panels arrive while the ~90 sincosf evaluations below run. ----
-    constexpr int kPark = kWavesPerBlock * 12 * 64;   // per wave 12 float4 slots per lane: posenc (8) + direnc (4)
-    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kPark + (L::table_floats + 3) / 4];
-    f32x4* const park = smem + kNBuf * kPanelF4 + wave * (12 * 64) + lane;
-    float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4 + kPark);
-    for (int i = threadIdx.x; i < L::table_floats; i += 256) ltab[i] = a.packed[L::bias_base + i];
-    __syncthreads();   // before any DMA is in flight: this is the only full barrier of the kernel
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave_u * (8 * 64), smem, wave_u, lane, L::fwd_panels};
-    pipe.start();
     // ---- encodings, straight into fragment layout ----
     float e[32];  // gamma_10(p): 63 -> 64
 #pragma unroll
@@ -84,8 +99,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     uint32_t* mask_base = nullptr;
     if (TRAIN) {
         // masks: [chunk][layer][lane][mask_words]; half A of a layer owns the low words, half B the high words
-        int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-        mask_base = a.ws_mask + ((chunk * L::n_mask_layers) * 64 + lane) * L::mask_words;
+        mask_base = a.ws_mask + ((chunk_id * L::n_mask_layers) * 64 + lane) * L::mask_words;
     }
     constexpr int HR = 16 * HT;              // registers of half a layer's outputs
     constexpr int NP = HR / 2;               // register pairs per half (the unit of hidden epilogue work)
@@ -293,6 +307,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 9);
 #undef NNR_RELU_PAIR
 #undef NNR_MOVE_PAIR
+    pipe.next_pass(pass + 2 < n_pass);
+    }   // pass
 }
 
 #ifdef NNR_TIMELINE
@@ -303,7 +319,8 @@ extern "C" int nnr_timeline_fwd(unsigned long long* host32) {
 
 template <int D>
 static hipError_t launch(const MlpFwdArgs& a, bool train, bool bf16, hipStream_t st) {
-    dim3 grid((unsigned)(a.S_pad / kBlockSamples)), block(256);
+    // ray mode: one workgroup per 4 rays, chunks_per_ray passes each; flat mode: one workgroup per 128 samples
+    dim3 grid((unsigned)(a.chunks_per_ray > 0 ? a.S_pad / kBlockSamples / a.chunks_per_ray : a.S_pad / kBlockSamples)), block(256);
     if (train && bf16) hipLaunchKernelGGL((mlp_fwd_kernel<D, true, true>), grid, block, 0, st, a);
     else if (train) hipLaunchKernelGGL((mlp_fwd_kernel<D, true, false>), grid, block, 0, st, a);
     else if (bf16) hipLaunchKernelGGL((mlp_fwd_kernel<D, false, true>), grid, block, 0, st, a);

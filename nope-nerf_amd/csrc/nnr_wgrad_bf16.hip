@@ -29,8 +29,12 @@
 
 namespace nnr {
 
-constexpr int kNStage = 4;                  // LDS ring depth
+#ifndef NNR_WB_NSTAGE
+#define NNR_WB_NSTAGE 4
+#endif
 constexpr int kStageBytes = 32 * 1024;      // up to 32 blocks of 1 KiB per stage
+constexpr int kRingBytes = NNR_WB_NSTAGE * kStageBytes;   // the LDS ring: as many stages as fit (4 of the widest unit's, 14 of the rgb head's)
+constexpr int kMaxInFlight = 56;            // DMA pieces a wave keeps outstanding at most (vmcnt is a 6-bit counter)
 constexpr int kBlockBytes = 1024;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -38,19 +42,22 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the count field is an immediate)
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the count field is an immediate; 6 bits on gfx9)
 __device__ __forceinline__ void wait_vmcnt(int n) {
+#define NNR_W1(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+#define NNR_W8(a, b, c, d, e, f, g, h) NNR_W1(a) NNR_W1(b) NNR_W1(c) NNR_W1(d) NNR_W1(e) NNR_W1(f) NNR_W1(g) NNR_W1(h)
     switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        NNR_W8(0, 1, 2, 3, 4, 5, 6, 7)
+        NNR_W8(8, 9, 10, 11, 12, 13, 14, 15)
+        NNR_W8(16, 17, 18, 19, 20, 21, 22, 23)
+        NNR_W8(24, 25, 26, 27, 28, 29, 30, 31)
+        NNR_W8(32, 33, 34, 35, 36, 37, 38, 39)
+        NNR_W8(40, 41, 42, 43, 44, 45, 46, 47)
+        NNR_W8(48, 49, 50, 51, 52, 53, 54, 55)
+        default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
     }
+#undef NNR_W8
+#undef NNR_W1
 }
 
 // 8 bf16 (k = 8 consecutive samples of one feature) of MFMA operand tile `t` of the operand image at LDS byte address `img`:
@@ -80,6 +87,11 @@ struct StageFeed {      // everything a wave needs to issue its pieces of a stag
     const char *d_base, *x_base;
     int64_t d_stride, x_stride;
     int d_groups, nblk, P, c0, wave;
+    int nst;            // ring depth for this job: narrow units (the heads: 9-10 KiB a stage) get a deeper ring, so that every
+                        // workgroup keeps about the same number of bytes in flight -- with 3 stages of 9 KiB a CU streams at half
+                        // the rate of one with 3 stages of 32 KiB, and the kernel ends with its slowest workgroup
+    int stage_bytes;
+    int head, tail;     // ring slot the next issue fills / the current stage occupies
     unsigned lds0;      // LDS byte address of the ring
     unsigned src0, src1;
 
@@ -94,6 +106,10 @@ struct StageFeed {      // everything a wave needs to issue its pieces of a stag
         d_groups = jb.d_groups;
         nblk = jb.d_groups + jb.x_groups;
         P = (nblk + 3) >> 2;          // DMA pieces per wave and stage (the last ones may repeat a block)
+        stage_bytes = nblk * kBlockBytes;
+        const int fit = kRingBytes / stage_bytes, cap = kMaxInFlight / P + 1;
+        nst = fit < cap ? fit : cap;
+        head = tail = 0;
         c0 = jb.c0;
         wave = wave_;
         lds0 = lds_addr;
@@ -101,11 +117,12 @@ struct StageFeed {      // everything a wave needs to issue its pieces of a stag
         src0 = (32 * ph + (pc ^ (4 * ph))) * 16;
         src1 = (32 * ph + (pc ^ (4 * ph + 8))) * 16;
     }
-    __device__ __forceinline__ void issue(int s) const {
+    __device__ __forceinline__ void issue(int s) {
         const int64_t ch = c0 + s;
         const char* dch = d_base + ch * d_stride;
         const char* xch = x_base + ch * x_stride;
-        const unsigned stage = lds0 + (s % kNStage) * kStageBytes;
+        const unsigned stage = lds0 + head * stage_bytes;
+        head = head + 1 == nst ? 0 : head + 1;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (q < P) {
@@ -117,17 +134,20 @@ struct StageFeed {      // everything a wave needs to issue its pieces of a stag
             }
         }
     }
-    // stage s has landed when at most the pieces of the (kNStage - 2) younger stages are outstanding; near the end of the range
+    // stage s has landed when at most the pieces of the (nst - 2) younger stages are outstanding; near the end of the range
     // fewer stages are in flight: drain.  Then the barrier: every wave's pieces of stage s are in LDS and everybody is done
-    // reading stage s - 1, whose buffer the next issue overwrites.
-    __device__ __forceinline__ void enter(int s, int n) const {
-        wait_vmcnt(s + kNStage - 2 < n ? (kNStage - 2) * P : 0);
+    // reading stage s - 1, whose buffer the next issue overwrites.  Returns the LDS byte offset of stage s in the ring.
+    __device__ __forceinline__ int enter(int s, int n) {
+        wait_vmcnt(s + nst - 2 < n ? (nst - 2) * P : 0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + kNStage - 1 < n) issue(s + kNStage - 1);
+        if (s + nst - 1 < n) issue(s + nst - 1);
+        const int img = tail * stage_bytes;
+        tail = tail + 1 == nst ? 0 : tail + 1;
+        return img;
     }
-    __device__ __forceinline__ void start(int n) const {
-        for (int s = 0; s < kNStage - 1 && s < n; ++s) issue(s);
+    __device__ __forceinline__ void start(int n) {
+        for (int s = 0; s < nst - 1 && s < n; ++s) issue(s);
     }
 };
 
@@ -141,7 +161,7 @@ __device__ __forceinline__ void pin_tiles(f32x16 (&acc)[MT][NT]) {   // keep the
 
 // a wave without tiles in this job: it still moves its share of the data and keeps the barrier count
 __device__ __forceinline__ void wgrad_b_idle(const WgradJobB& jb, const WgradBArgs& a, unsigned lds_addr, int wave, int lane) {
-    const StageFeed feed(jb, reinterpret_cast<const char*>(a.ws), lds_addr, wave, lane);
+    StageFeed feed(jb, reinterpret_cast<const char*>(a.ws), lds_addr, wave, lane);
     const int n = jb.c1 - jb.c0;
     feed.start(n);
     for (int s = 0; s < n; ++s) feed.enter(s, n);
@@ -152,7 +172,7 @@ __device__ __forceinline__ void wgrad_b_idle(const WgradJobB& jb, const WgradBAr
 template <int MT, int NT, bool BIAS>
 __device__ __forceinline__ void wgrad_b_job(const WgradJobB& jb, const WgradBArgs& a, const char* lds, unsigned lds_addr, int wave, int lane,
                                             int ji) {
-    const StageFeed feed(jb, reinterpret_cast<const char*>(a.ws), lds_addr, wave, lane);
+    StageFeed feed(jb, reinterpret_cast<const char*>(a.ws), lds_addr, wave, lane);
     const int n = jb.c1 - jb.c0;                         // stages = chunks
     const int d_groups = jb.d_groups;
     const int tr0 = MT * (wave / jb.WC), tc0 = NT * (wave % jb.WC);
@@ -182,9 +202,11 @@ __device__ __forceinline__ void wgrad_b_job(const WgradJobB& jb, const WgradBArg
 
     feed.start(n);
     for (int s = 0; s < n; ++s) {
-        feed.enter(s, n);
+        const int img = feed.enter(s, n);
         pin_tiles<MT, NT>(acc);
-        const int img = (s % kNStage) * kStageBytes;
+#ifdef NNR_ABLATE_WB_NO_COMPUTE     // profiling build only: the DMA stream alone
+        continue;
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 av[MT], bv[NT];
@@ -262,8 +284,25 @@ __global__ __launch_bounds__(256, 1) void wgrad_b_kernel(WgradBArgs a) {
 }
 
 // dW[output rectangle] += sum over the unit's jobs, in sample order, of their slots; d(bias) likewise.  grid = (64, n_outputs).
+// The unit's jobs are first collected into LDS by their position in the chain (every thread inspects its share of the job table: no
+// dependent walk of next_split), then each element is summed with independent loads -- the order of the additions stays the chain's.
+constexpr int kMaxSplits = 512;
 __global__ __launch_bounds__(256) void wgrad_b_reduce_kernel(WgradBArgs a) {
+    __shared__ int list[kMaxSplits];
+    __shared__ int n_list;
     const WgradOutB o = a.outs[blockIdx.y];
+    if (threadIdx.x == 0) n_list = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < a.n_jobs; j += 256) {
+        if (a.jobs[j].unit != o.unit) continue;
+        const int s = a.jobs[j].split;
+        if (s >= kMaxSplits) __builtin_trap();     // the plan builder bounds the splits of a unit (nnr_api.cpp)
+        list[s] = j;
+        atomicMax(&n_list, s + 1);
+    }
+    __syncthreads();
+    const int n = n_list;
+    const int64_t stride = 4 * (int64_t)kSlotBFloats;
     const int total = o.n_rows * o.n_cols;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += 64 * 256) {
         const int r = e / o.n_cols, c = e - r * o.n_cols;
@@ -271,19 +310,27 @@ __global__ __launch_bounds__(256) void wgrad_b_reduce_kernel(WgradBArgs a) {
         const int rt = dr >> 5, ct = xc >> 5;
         const int wave = (rt / o.MT) * o.WC + ct / o.NT;
         const int tile = (rt % o.MT) * o.NT + ct % o.NT;
-        const int64_t off = (int64_t)wave * kSlotBFloats + (tile * 32 + (dr & 31)) * 32 + (xc & 31);
+        const float* p = a.slots + (int64_t)wave * kSlotBFloats + (tile * 32 + (dr & 31)) * 32 + (xc & 31);
         float sum = 0.f;
-        for (int j = o.first_job; j >= 0; j = a.jobs[j].next_split) sum += a.slots[(int64_t)j * 4 * kSlotBFloats + off];
+        int s = 0;
+        for (; s + 8 <= n; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[list[s + u] * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; s < n; ++s) sum += p[list[s] * stride];
         a.gw[o.layer][(int64_t)(o.w_row + r) * o.ldw + o.w_col + c] += sum;
     }
     if (o.bias && blockIdx.x == 0) {
         for (int r = threadIdx.x; r < o.n_rows; r += 256) {
             const int dr = o.d_row + r, rt = dr >> 5;
-            const int64_t off = (int64_t)((rt / o.MT) * o.WC) * kSlotBFloats + 16 * kSlotBTile + 2 * (rt % o.MT) * 32 + (dr & 31);
+            const float* p = a.slots + (int64_t)((rt / o.MT) * o.WC) * kSlotBFloats + 16 * kSlotBTile + 2 * (rt % o.MT) * 32 + (dr & 31);
             float sum = 0.f;
-            for (int j = o.first_job; j >= 0; j = a.jobs[j].next_split) {
-                const float* p = a.slots + (int64_t)j * 4 * kSlotBFloats + off;
-                sum += p[0] + p[32];
+            for (int s = 0; s < n; ++s) {
+                const float* q = p + list[s] * stride;
+                sum += q[0] + q[32];
             }
             a.gb[o.layer][o.w_row + r] += sum;
         }
@@ -294,14 +341,14 @@ hipError_t launch_wgrad_bf16(const WgradBArgs& a, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           kNStage * kStageBytes);
+                                           kRingBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const size_t merged = ((size_t)(a.D / 2) * a.D + a.D / 2) * sizeof(float);
     hipError_t e = hipMemsetAsync(a.gw[kMergedLayer], 0, merged, st);   // dW', db' are accumulated into like any gradient
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(wgrad_b_kernel, dim3(a.n_blocks), dim3(256), kNStage * kStageBytes, st, a);
+    hipLaunchKernelGGL(wgrad_b_kernel, dim3(a.n_blocks), dim3(256), kRingBytes, st, a);
     hipLaunchKernelGGL(wgrad_b_reduce_kernel, dim3(64, a.n_outs), dim3(256), 0, st, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -1,0 +1,11 @@
+mkdir -p gpurun_out/r2i
+export PYTHONUNBUFFERED=1
+R=$PWD
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_determinism.py -q -m gpu -x 2>&1 | tail -3 > gpurun_out/r2i/tests.txt
+for v in "" wbstrided wbnt; do
+  echo "== variant '$v'" >> gpurun_out/r2i/time.txt
+  NNR_LIB_VARIANT=$v timeout 200 python tools/time_kernels.py 4096 128 bf16 20 2>&1 | grep -i "wgrad\|step" >> gpurun_out/r2i/time.txt
+done
+cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r2i/prof -o wg -- python $R/tools/time_kernels.py 4096 128 bf16 8 > /dev/null 2>&1
+cd $R; f=$(find gpurun_out/r2i/prof -name "*kernel_stats.csv" | head -1); cut -d, -f1-4,6-7 $f | head -8 > gpurun_out/r2i/stats.txt
+cat gpurun_out/r2i/tests.txt gpurun_out/r2i/time.txt gpurun_out/r2i/stats.txt

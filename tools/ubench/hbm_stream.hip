@@ -76,6 +76,46 @@ static double time_ms(F launch, int reps = 5) {
     return ms / reps;
 }
 
+// The access pattern of the bf16 weight-gradient kernel (nnr_wgrad_bf16.hip): every stage is half from one plane, half from another
+// (`two`), the planes advance by `stride_kib` per stage instead of the bytes read (17 KiB for 16 read), waves take 1 KiB blocks
+// round-robin (`rr`) and lanes read permuted 64-byte groups of their block (`swz`).
+template <int NST>
+__global__ __launch_bounds__(256) void dma_pattern(const char* __restrict__ src, int n_stage, float* out, int two, int stride_kib,
+                                                   int rr, int swz, size_t plane_gap) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t stage_stride = two ? (size_t)stride_kib * 1024 : (size_t)stride_kib * 2048;
+    const char* base = src + (size_t)blockIdx.x * n_stage * stage_stride;
+    const int ph = lane >> 5, pc = lane & 31;
+    const int lane_off = swz ? (32 * ph + (pc ^ (4 * ph))) * 16 : lane * 16;
+    auto issue = [&](int s) {
+        f32x4* l = lds + (s % NST) * 2048;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int blk = rr ? wave + 4 * q : wave * 8 + q;     // 32 blocks of 1 KiB per stage
+            const char* g = two ? base + (blk >> 4) * plane_gap + (size_t)s * stage_stride + (blk & 15) * 1024
+                                : base + (size_t)s * stage_stride + blk * 1024;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + lane_off), (lds_ptr_t)(l + blk * 64), 16, 0, 0);
+        }
+    };
+    for (int s = 0; s < NST - 1 && s < n_stage; ++s) issue(s);
+    float acc = 0.f;
+    for (int s = 0; s < n_stage; ++s) {
+        if (s + NST - 1 < n_stage) {
+            issue(s + NST - 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NST - 1)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        acc += lds[(s % NST) * 2048 + threadIdx.x][0];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (acc == 12345.678f) out[0] = 1.f;
+}
+
 int main() {
     const size_t bytes = (size_t)4 << 30;
     f32x4* src;
@@ -115,5 +155,23 @@ int main() {
     RUN_DMA(4, 2, 8, 1);
     RUN_DMA(8, 2, 8, 1);
     RUN_DMA(4, 2, 4, 4);
+    {
+        auto k = dma_pattern<4>;
+        CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+        struct { int two, stride, rr, swz; const char* what; } cases[] = {
+            {0, 16, 0, 0, "one stream (as above)"}, {0, 16, 1, 0, "blocks round-robin over the waves"},
+            {0, 16, 0, 1, "lanes permuted in 64 B groups"}, {1, 16, 0, 0, "two planes, 16 KiB each per stage"},
+            {1, 17, 0, 0, "two planes, 17 KiB stride"}, {1, 17, 1, 1, "two planes, 17 KiB stride, round-robin, permuted (the wgrad pattern)"},
+            {1, 24, 0, 0, "two planes, 24 KiB stride"}};
+        for (auto& c : cases)
+            for (size_t gap : {(size_t)2 << 30, ((size_t)2 << 30) - (5 << 20) - 13 * 4096}) {
+                if (!c.two && gap != (size_t)2 << 30) continue;
+                const size_t per_wg = (c.two ? bytes / 2 : bytes) / 256;
+                const int n_stage = (int)(per_wg / ((size_t)c.stride * (c.two ? 1024 : 2048))) - 1;
+                double ms = time_ms([&] { hipLaunchKernelGGL(k, dim3(256), dim3(256), 4 * 32768, 0, (const char*)src, n_stage, out, c.two, c.stride,
+                                                             c.rr, c.swz, gap); });
+                printf("pattern: %-70s gap %zu: %.3f ms  %.2f TB/s\n", c.what, gap, ms, 256.0 * n_stage * 32768 / ms / 1e9);
+            }
+    }
     return 0;
 }
