@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(os.path.dirname(HERE), "nnr", "libnnr.so")
-SOURCES = ["nnr_api.cpp", "nnr_pack.hip", "nnr_mlp_fwd.hip", "nnr_mlp_dgrad.hip", "nnr_wgrad.hip", "nnr_wgrad_bf16.hip", "nnr_composite.hip", "nnr_camera.hip", "nnr_pointcloud.hip", "nnr_aux.hip", "nnr_randperm.hip"]
+SOURCES = ["nnr_api.cpp", "nnr_pack.hip", "nnr_mlp_fwd.hip", "nnr_mlp_dgrad.hip", "nnr_mlp_fwd_bf16.hip", "nnr_mlp_dgrad_bf16.hip", "nnr_wgrad.hip", "nnr_wgrad_bf16.hip", "nnr_composite.hip", "nnr_camera.hip", "nnr_pointcloud.hip", "nnr_aux.hip", "nnr_randperm.hip"]
 HEADERS = ["nnr_layout.h", "nnr_device.h", "nnr_kernels.h", os.path.join("..", "..", "include", "nnr.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-I" + HERE,
          "-I" + os.path.join(HERE, "..", "..", "include"), "-x", "hip"]

@@ -54,9 +54,11 @@ bool is_bf16(const nnr_cfg* c) { return (c->flags & NNR_F_BF16) != 0; }
 
 // Ray mode of the two MLP kernels (nnr_mlp_fwd.hip): a wave walks the N / 32 chunks of ONE ray, a workgroup four rays.  Needs whole
 // chunks per ray and whole workgroups; everything else runs the flat decomposition (same sample numbering, same planes).
+// The bf16 kernels (nnr_mlp_fwd_bf16.hip) work on PAIRS of chunks: their unit is 64 samples.
 int chunks_per_ray(const nnr_cfg* c) {
     static const bool off = std::getenv("NNR_FLAT_GRID") != nullptr;    // experiments: force the flat decomposition
-    return (!off && c->n_samples % kChunk == 0 && c->n_rays % kWavesPerBlock == 0) ? c->n_samples / kChunk : 0;
+    const int unit = is_bf16(c) ? 2 * kChunk : kChunk;
+    return (!off && c->n_samples % unit == 0 && c->n_rays % kWavesPerBlock == 0) ? c->n_samples / unit : 0;
 }
 
 // ---- weight-gradient plan -------------------------------------------------------------------------------------------
@@ -465,7 +467,8 @@ int nnr_mlp_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, cons
     }
     a.S = w.S; a.S_pad = w.S_pad; a.N = cfg->n_samples;
     a.chunks_per_ray = chunks_per_ray(cfg);
-    hipError_t e = launch_mlp_fwd(cfg->hidden, a, w.train, is_bf16(cfg), (hipStream_t)stream);
+    hipError_t e = is_bf16(cfg) ? launch_mlp_fwd_bf16(cfg->hidden, a, w.train, (hipStream_t)stream)
+                                : launch_mlp_fwd(cfg->hidden, a, w.train, (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
@@ -524,7 +527,8 @@ int nnr_mlp_dgrad(const nnr_cfg* cfg, const float* packed, float* ws, void* stre
     a.ws_dview = ws + plane(w, P_DVIEW);
     a.S = w.S; a.S_pad = w.S_pad;
     a.chunks_per_ray = chunks_per_ray(cfg);
-    hipError_t e = launch_mlp_dgrad(cfg->hidden, a, is_bf16(cfg), (hipStream_t)stream);
+    hipError_t e = is_bf16(cfg) ? launch_mlp_dgrad_bf16(cfg->hidden, a, (hipStream_t)stream)
+                                : launch_mlp_dgrad(cfg->hidden, a, (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 

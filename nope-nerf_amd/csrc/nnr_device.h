@@ -275,142 +275,17 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
     gemm_part<KT, MT, STASH, 0, 1, 0>(acc, in, pipe, p0, stash, NoSide{});
 }
 
-// ---- bf16-MFMA variant (NNR_F_BF16) ---------------------------------------------------------------------------------
-// Same contract as gemm_part, but a fragment row covers a DOUBLE k-group: 8 consecutive activation registers, converted
-// to bf16 (round to nearest even, v_cvt_pk_bf16_f32), against one 16-byte fragment of 8 bf16 weights through
-// v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Everything outside the product stays fp32: accumulators, bias, side work,
-// stash, masks.  Per row: MT MFMAs of 32 cycles against the same non-MFMA work as two fp32 k-groups, so this variant is
-// bound by issue / HBM, not by the matrix pipe.  PPG counts units per fp32 k-group; a row runs twice as many.
+// ---- bf16 training mode: tile-major planes (the kernels themselves: nnr_mlp_bf16.h) ------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kBlockBf16 = 512;   // bf16 elements per 1 KiB block of a tile-major plane (nnr_layout.h)
 
-template <int NIN>
-__device__ __forceinline__ bf16x8 pack_row(const float (&in)[NIN], int b) {
-    bf16x8 q;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) q[i] = (__bf16)in[8 * b + i];
-    return q;
-}
-
-// STASH: 0 = none; 1 = the input rows go to a tile-major bf16 plane (hidden activations, pre-activation gradients: exactly the 8
-// bf16 values the MFMA of that row consumes, one 16-byte store per lane = one 1 KiB block per wave -- `stash` is then a bf16
-// element pointer in disguise, see stash_row()); 2 = to an fp32 plane as in the fp32 kernels (the encodings, which the backward
-// of the encodings reads back at full precision).
-#ifdef NNR_BF16_FREE_SCHED      // profiling experiment: let hipcc place the fillers of the bf16 rows itself
-#define NNR_BF16_SB() ((void)0)
-#else
-#define NNR_BF16_SB() __builtin_amdgcn_sched_barrier(0)
-#endif
-template <int KT, int MT, int STASH, int NSIDE_, int PPG_, int SHIFT, class Side, int NACC, int NIN>
-__device__ __forceinline__ void gemm_part_bf16(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
-                                               float* stash, const Side& side) {
-#ifdef NNR_ABLATE_NO_SIDE
-    constexpr int NSIDE = 0;   // profiling build only
-#else
-    constexpr int NSIDE = NSIDE_;
-#endif
-    static_assert(MT <= NACC && 16 * KT <= NIN, "tile counts exceed the register arrays");
-    constexpr int G = 2 * KT, GP = part_gp(MT), PPG = 2 * PPG_;
-    auto rows_in = [](int pi) { return (G - pi * GP) < GP ? (G - pi * GP) : GP; };
-    pipe.enter(p0);
-    pipe.pieces(p0 + 2, 0, (8 + rows_in(0) - 1) / rows_in(0));
-    Frags<MT> cur;
-    {
-        const f32x4* buf = pipe.lds + pipe.buffer(p0) * kPanelF4 + pipe.lane;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) cur.v[mt] = buf[mt * 64];
-    }
-    bf16x8 bq = pack_row(in, 0);
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int u0 = (g - SHIFT) * PPG, um = u0 + (PPG + 1) / 2, u1 = u0 + PPG;
-        Frags<MT> nxt;
-        bf16x8 nq;
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            NNR_BF16_SB();
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.v[j]), bq, acc[j], 0, 0, 0);
-            NNR_BF16_SB();
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                if (f * MT / 4 != j) continue;
-                if (f == 0) {          // fragment reads of the next row (panel switch in front of them)
-                    if (g + 1 < G) {
-                        const int pn = p0 + (g + 1) / GP;
-                        if ((g + 1) % GP == 0) pipe.template enter<STASH != 0 ? 2 * (GP - 1) : 0>(pn);
-                        const f32x4* buf = pipe.lds + pipe.buffer(pn) * kPanelF4 + pipe.lane;
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) nxt.v[mt] = buf[(((g + 1) % GP) * MT + mt) * 64];
-                    }
-                } else if (f == 1) {   // next row's B operand; this row's stash (two quads = two 16-byte stores)
-                    if (g + 1 < G) nq = pack_row(in, g + 1);
-                    if constexpr (STASH == 2) {
-                        *reinterpret_cast<f32x4*>(stash + 16 * g) = f32x4{in[8 * g], in[8 * g + 1], in[8 * g + 2], in[8 * g + 3]};
-                        *reinterpret_cast<f32x4*>(stash + 16 * g + 8) = f32x4{in[8 * g + 4], in[8 * g + 5], in[8 * g + 6], in[8 * g + 7]};
-                    } else if constexpr (STASH == 1) {   // bq = features 16g + 4h + {0..3}, 16g + 8 + 4h + {0..3} of this lane's sample:
-                        // the lane's 16 bytes of block (chunk, g) of a tile-major plane -- the wave writes the whole 1 KiB block
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(stash) + kBlockBf16 * g) = __builtin_bit_cast(f32x4, bq);
-                    }
-                } else if (f == 2) {
-                    if constexpr (NSIDE > 0) {
-#pragma unroll
-                        for (int u = u0; u < um; ++u)
-                            if (u >= 0 && u < NSIDE) side(u);
-                    }
-                } else {
-                    const int pi = g / GP, gi = g % GP;
-                    const int n_in = rows_in(pi);
-                    if (gi == n_in - 1) {
-                        if (g + 1 < G) pipe.pieces(p0 + pi + 3, 0, (8 + rows_in(pi + 1) - 1) / rows_in(pi + 1));
-                    } else {
-                        const int ppk = (8 + n_in - 1) / n_in;
-                        pipe.pieces(p0 + pi + 2, (gi + 1) * ppk, ppk);
-                    }
-                    if constexpr (NSIDE > 0) {
-#pragma unroll
-                        for (int u = um; u < u1; ++u)
-                            if (u >= 0 && u < NSIDE) side(u);
-                    }
-                }
-            }
-        }
-        pin_acc<MT>(acc);
-        NNR_BF16_SB();
-        if (g + 1 < G) { cur = nxt; bq = nq; }
-    }
-    if constexpr (NSIDE > 0) {
-#pragma unroll
-        for (int u = (G - SHIFT) * PPG; u < NSIDE; ++u)
-            if (u >= 0) side(u);
-    }
-}
-
-// fp32 or bf16 product, chosen at compile time by the kernel's BF16 template parameter
-// STASH: 0 none, 1 the plane of the kernel's mode (bf16 plane in the bf16 kernels), 2 an fp32 plane in either mode
-template <bool BF16, int KT, int MT, int STASH, int NSIDE, int PPG, int SHIFT, class Side, int NACC, int NIN>
-__device__ __forceinline__ void gemm_sel(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0, float* stash,
-                                         const Side& side) {
-    if constexpr (BF16) gemm_part_bf16<KT, MT, STASH, NSIDE, PPG, SHIFT>(acc, in, pipe, p0, stash, side);
-    else gemm_part<KT, MT, (STASH != 0), NSIDE, PPG, SHIFT>(acc, in, pipe, p0, stash, side);
-}
-// Where a lane starts writing its sample's part of a stash plane of `width` features.  fp32 planes are row-major [sample][feature]:
-// the lane's row, + 4 * half.  The bf16 planes of the bf16 training mode are TILE-MAJOR (nnr_layout.h): 1 KiB blocks [chunk of 32
-// samples][group of 16 features][lane][8 bf16]; the lane's 16 bytes of group g sit at the returned pointer + 512 g bf16 elements, so
-// that a row-step's stash store is one fully coalesced 1 KiB wave-store (gemm_part_bf16).  `row` may carry a plane index (row = plane
-// * S_pad + sample; S_pad is a multiple of 32).
-template <bool BF16>
-__device__ __forceinline__ float* stash_row(float* plane, int64_t row, int width, int half) {
-    if constexpr (BF16) {
-        const int64_t c = row & 31;
-        return reinterpret_cast<float*>(reinterpret_cast<__bf16*>(plane) + (row - c) * width + (32 * half + c) * 8);
-    } else {
-        return plane + row * width + 4 * half;
-    }
-}
-template <bool BF16, int KT, int MT, int STASH = 0, int NACC, int NIN>
-__device__ __forceinline__ void gemm_sel(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
-                                         float* stash = nullptr) {
-    gemm_sel<BF16, KT, MT, STASH, 0, 1, 0>(acc, in, pipe, p0, stash, NoSide{});
+// Where a lane starts writing its sample's part of a TILE-MAJOR bf16 plane of `width` features (nnr_layout.h): 1 KiB blocks [chunk
+// of 32 samples][group of 16 features][lane][8 bf16]; the lane's 16 bytes of group g sit at the returned pointer + 512 g elements,
+// so that a row-step's stash store is one fully coalesced 1 KiB wave-store.  `row` may carry a plane index (row = plane * S_pad +
+// sample; S_pad is a multiple of 32).
+__device__ __forceinline__ __bf16* tile_row(float* plane, int64_t row, int width, int half) {
+    const int64_t c = row & 31;
+    return reinterpret_cast<__bf16*>(plane) + (row - c) * width + (32 * half + c) * 8;
 }
 
 template <int N>

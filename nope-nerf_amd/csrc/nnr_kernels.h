@@ -22,7 +22,8 @@ struct MlpFwdArgs {
     uint32_t* ws_mask;
     int64_t S, S_pad;
     int N;
-    int chunks_per_ray;   // N / 32 in ray mode (N % 32 == 0 and R % 4 == 0: a wave walks one ray), 0 = flat decomposition
+    int chunks_per_ray;   // passes per ray in ray mode (R % 4 == 0 and N a multiple of the wave's samples -- 32, bf16 kernels 64: a
+                          // wave walks one ray), 0 = flat decomposition
 };
 
 struct MlpDgradArgs {
@@ -168,8 +169,10 @@ unsigned int randperm_capacity(int r);   // candidates the scratch buffer must h
 hipError_t launch_randperm_prefix(const int64_t* keys, int64_t n, int bits, int r, unsigned long long seed, unsigned long long offset,
                                   int64_t* out, unsigned int* scratch, hipStream_t st);
 hipError_t launch_pack(int D, const PackArgs& a, bool bf16, hipStream_t st);
-hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, bool bf16, hipStream_t st);
-hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, bool bf16, hipStream_t st);
+hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st);                 // fp32 products
+hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st);
+hipError_t launch_mlp_fwd_bf16(int D, const MlpFwdArgs& a, bool train, hipStream_t st);     // nnr_mlp_fwd_bf16.hip
+hipError_t launch_mlp_dgrad_bf16(int D, const MlpDgradArgs& a, hipStream_t st);              // nnr_mlp_dgrad_bf16.hip
 hipError_t launch_composite_fwd(const CompositeArgs& a, hipStream_t st);
 hipError_t launch_composite_bwd(const CompositeArgs& a, hipStream_t st);
 hipError_t launch_ray_reduce(const RayReduceArgs& a, hipStream_t st);

@@ -1,0 +1,203 @@
+// nnr_mlp_bf16.h -- building blocks of the bf16-MFMA MLP kernels (nnr_mlp_fwd_bf16.hip, nnr_mlp_dgrad_bf16.hip), gfx950 only.
+//
+// Why these kernels are not the fp32 ones with another MFMA: one v_mfma_f32_32x32x16_bf16 (32 cycles) consumes a whole 1 KiB weight
+// fragment, so a wave of 32 samples needs 1 KiB of LDS per 32 matrix-pipe cycles -- four waves = 128 B/clk, the LDS read peak of a CU:
+// with 32-sample waves the bf16 layers run at the LDS roofline, not the MFMA one (measured: 8 000 cycles per D x D layer and workgroup
+// against 4 096 of MFMA).  Here a wave owns TWO chunks of 32 samples (kTiles): every fragment read feeds two MFMAs, the LDS stream
+// halves, and the per-row overhead (fragment reads, DMA pieces, panel switches) is spread over twice the matrix work.
+//
+// That needs the activations PACKED between layers -- 2 x 32 x 256 values per wave do not fit as fp32 beside 256 accumulator
+// registers.  A lane keeps, per tile, the layer input as 8 * DT packed registers: packed register p = (bf16 of fragment register 2p,
+// bf16 of 2p + 1) (nnr_layout.h), so the four registers 4g .. 4g+3 ARE the MFMA B operand of row g -- no conversion at the MFMA, and
+// the same 16 bytes are what the training stash stores (one tile-major block row per store).  The epilogue of a half-output pass
+// (bias is in the accumulator; ReLU + sign bit, or the ReLU' select) produces one packed register per unit (v_cvt_pk_bf16_f32).
+// Everything else is the design of the fp32 kernels: weights through the DMA-fed LDS panel ring, two half-output passes per layer
+// with the epilogue of one pass hidden in the MFMA stream of the next, heads on the VALU.
+#pragma once
+#include "nnr_device.h"
+
+namespace nnr {
+
+constexpr int kTiles = 2;   // 32-sample chunks per wave in the bf16 kernels
+constexpr int kWideSamples = kTiles * kChunk * kWavesPerBlock;   // samples per workgroup
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// (bf16(lo), bf16(hi)) in one register, round to nearest even.  Spelled as the instruction: written as two __bf16 conversions and a
+// bit cast, the <2 x bfloat> stores into the packed arrays keep SROA from promoting parts of them (mixed-type slices) -- some rows
+// of the MFMA operands then live in scratch memory.
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// acc += lo(a) * lo(b) + hi(a) * hi(b), the pairs bf16, the sum fp32 (the per-lane dot products of the two heads)
+__device__ __forceinline__ void dot2_bf16(float& acc, uint32_t a, uint32_t b) {
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+// A value the compiler must treat as new at this program point.  The kernels derive every plane address from a 32-bit sample index
+// THROUGH this, right where the address is needed: otherwise the dozens of lane-constant 64-bit addresses of a pass are computed at
+// its start and spilled around the MFMA streams (a spill reload is a VMEM load whose wait drains the weight DMA queue).
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// The value of a dot2_bf16 chain, safe to use.  gfx950 needs 3 wait states between a DOT instruction's write and a read by any other
+// kind of instruction (and 2 before another instruction overwrites the register); hipcc inserts them for instructions it knows, but an
+// inline-asm DOT is opaque to its hazard recogniser: without this the first consumer saw the accumulator before the last DOT's
+// write (rgb off by 1e-2).  The s_nop sits between the chain and the only instruction allowed to touch the register.
+__device__ __forceinline__ float dot2_result(float acc) {
+    float r;
+    asm volatile("s_nop 3\n\tv_mov_b32 %0, %1" : "=v"(r) : "v"(acc));
+    return r;
+}
+
+template <int NIN>
+__device__ __forceinline__ bf16x8 row_operand(const uint32_t (&in)[NIN], int g) {
+    const u32x4 q = {in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]};
+    return __builtin_bit_cast(bf16x8, q);
+}
+
+// Stash stores are NON-TEMPORAL: the 2.4 GB a launch writes are read next by another kernel, not by this one, and as ordinary
+// stores they stream through the L2 and push the packed weights out of it -- every workgroup re-reads those ~1.2 MB per pass, and a
+// weight panel that misses L2 arrives late at its panel switch.  Measured at 4096 x 128: forward 0.94 -> 0.78 ms, input-gradient
+// 0.88 -> 0.75 ms (with the row-major planes of round 1, 16 bytes per line and instruction, the same hint made things worse).
+template <class V>
+__device__ __forceinline__ void stash_store(void* dst, V v) {
+#if defined(NNR_ABLATE_NO_STASH)
+    (void)dst; (void)v;      // profiling builds only
+#elif defined(NNR_STASH_TEMPORAL)
+    *reinterpret_cast<V*>(dst) = v;
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<V*>(dst));
+#endif
+}
+
+// relu of a packed bf16 pair in ONE instruction: as 16-bit integers the non-negative bf16 values are the non-negative integers, and
+// everything with the sign bit set (negative numbers, -0) is a negative integer -- v_pk_max_i16 with 0 is exactly relu
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t p) {
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(p));
+    return r;
+}
+
+template <int MT, int NACC>
+__device__ __forceinline__ void pin_acc2(f32x16 (&acc)[kTiles][NACC]) {   // see pin_acc
+    static_assert(kTiles == 2, "written for two tiles");
+    if constexpr (MT == 1) asm volatile("" : "+a"(acc[0][0]), "+a"(acc[1][0]));
+    else if constexpr (MT == 2) asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));
+    else if constexpr (MT == 4)
+        asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),
+                     "+a"(acc[1][2]), "+a"(acc[1][3]));
+    else static_assert(MT == 1 || MT == 2 || MT == 4, "unsupported tile count");
+}
+
+template <int N>
+__device__ __forceinline__ void zero_acc2(f32x16 (&acc)[kTiles][N]) {
+#pragma unroll
+    for (int n = 0; n < kTiles; ++n) zero_acc(acc[n]);
+}
+
+// acc[n][mt] += A_part[32 mt .., :] * in[n]   for both tiles n, one layer part whose packed bf16 panels start at stream panel p0.
+//   in    : per tile 8 * KT packed registers (see above); row g = registers 4g .. 4g+3 = 16 k-values
+//   STASH : the row operands also go to a tile-major bf16 plane -- stash[n] = the lane's 16 bytes of block (chunk of tile n, group 0),
+//           row g at + 512 g elements: one fully coalesced 1 KiB wave-store per row and tile
+//   side  : VALU work hidden under this part's MFMAs, NSIDE units side(0 .. NSIDE-1), PPG per row, starting at row SHIFT (units that
+//           do not fit run after the last row).  SHIFT = 0: the units write registers of `in` this part reads later; SHIFT = 1: they
+//           overwrite `in` behind the read pointer (the caller's unit order guarantees it, see the kernels).
+// A row is MT * kTiles MFMAs of 32 cycles; its non-MFMA work -- MT fragment reads of the next row (behind the panel switch, if any),
+// kTiles stash stores, the DMA piece(s) of the panel two ahead, PPG side units -- is placed in different MFMA gaps and pinned with
+// sched_barrier(0), as in gemm_part (nnr_device.h).
+//   PRE   : VMEM operations (stash stores) this wave has certainly issued AFTER the last DMA piece of this part's first panel -- i.e.
+//           while it consumed the panel(s) before: they may stay in flight at the first panel switch.  Without it that switch waits
+//           for stores issued a few hundred cycles earlier to be acknowledged (a full HBM write latency with the matrix pipe idle,
+//           once per stashing pass: the training kernels lost a third of their time there).  Use stash_tail<>() of the previous part.
+template <int KT, int MT, bool STASH, int NSIDE_, int PPG, int SHIFT, int PRE, class Side, int NACC, int NIN>
+__device__ __forceinline__ void gemm_wide(f32x16 (&acc)[kTiles][NACC], const uint32_t (&in)[kTiles][NIN], const PanelPipe& pipe, int p0,
+                                          __bf16* const (&stash)[kTiles], const Side& side) {
+#ifdef NNR_ABLATE_NO_SIDE
+    constexpr int NSIDE = 0;   // profiling build only
+#else
+    constexpr int NSIDE = NSIDE_;
+#endif
+    static_assert(MT <= NACC && 8 * KT <= NIN, "tile counts exceed the register arrays");
+    constexpr int G = 2 * KT, GP = part_gp(MT), NM = MT * kTiles;
+    constexpr int kGapDma = NM / 2;
+    auto rows_in = [](int pi) { return (G - pi * GP) < GP ? (G - pi * GP) : GP; };
+    auto gap_stash = [](int n) { return n * (NM / kTiles); };   // the even gaps are free of fragment reads
+    pipe.template enter<PRE>(p0);
+    pipe.pieces(p0 + 2, 0, (8 + rows_in(0) - 1) / rows_in(0));
+    Frags<MT> cur;
+    {
+        const f32x4* buf = pipe.lds + pipe.buffer(p0) * kPanelF4 + pipe.lane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) cur.v[mt] = buf[mt * 64];
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int j = 0; j < NM; ++j) {
+            const int mt = j / kTiles, n = j % kTiles;
+            __builtin_amdgcn_sched_barrier(0);
+            acc[n][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.v[mt]), row_operand(in[n], g), acc[n][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // Fragment mt is refilled IN PLACE for the next row right after its last MFMA of this row (no second fragment set: 16
+            // registers the kernels need elsewhere); the read has (MT - 1) * kTiles MFMAs = 192 cycles to land.  A panel switch
+            // (counted wait + barrier) sits in front of the first read from the new panel.
+            if (n == kTiles - 1 && g + 1 < G) {
+                const int pn = p0 + (g + 1) / GP;
+                // the stash stores of this panel's earlier rows are younger than the pieces waited for
+                if (mt == 0 && (g + 1) % GP == 0) pipe.template enter<STASH ? kTiles * (GP - 1) : 0>(pn);
+                const f32x4* buf = pipe.lds + pipe.buffer(pn) * kPanelF4 + pipe.lane;
+                cur.v[mt] = buf[(((g + 1) % GP) * MT + mt) * 64];
+            }
+            if constexpr (STASH) {
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t)
+                    if (j == gap_stash(t)) stash_store(stash[t] + kBlockBf16 * g, u32x4{in[t][4 * g], in[t][4 * g + 1], in[t][4 * g + 2], in[t][4 * g + 3]});
+            }
+            if (j == kGapDma) {   // DMA pieces of the panel two ahead, spread over the rows of the current panel
+                const int pi = g / GP, gi = g % GP;
+                const int n_in = rows_in(pi);
+                if (gi == n_in - 1) {
+                    if (g + 1 < G) pipe.pieces(p0 + pi + 3, 0, (8 + rows_in(pi + 1) - 1) / rows_in(pi + 1));
+                } else {
+                    const int ppk = (8 + n_in - 1) / n_in;
+                    pipe.pieces(p0 + pi + 2, (gi + 1) * ppk, ppk);
+                }
+            }
+            if constexpr (NSIDE > 0) {
+#pragma unroll
+                for (int i = 0; i < PPG; ++i) {
+                    const int u = (g - SHIFT) * PPG + i;
+                    if (j == (i * NM) / PPG && u >= 0 && u < NSIDE) side(u);
+                }
+            }
+        }
+        pin_acc2<MT>(acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (NSIDE > 0) {
+#pragma unroll
+        for (int u = (G - SHIFT) * PPG; u < NSIDE; ++u)
+            if (u >= 0) side(u);
+    }
+}
+
+template <int KT, int MT, int PRE = 0, int NACC, int NIN>
+__device__ __forceinline__ void gemm_wide(f32x16 (&acc)[kTiles][NACC], const uint32_t (&in)[kTiles][NIN], const PanelPipe& pipe, int p0) {
+    __bf16* const none[kTiles] = {nullptr, nullptr};
+    gemm_wide<KT, MT, false, 0, 1, 0, PRE>(acc, in, pipe, p0, none, NoSide{});
+}
+
+// stash stores a STASH part (KT x MT tiles) issues while it consumes its LAST panel = the PRE of the part that follows it
+template <int KT, int MT>
+__device__ __forceinline__ constexpr int stash_tail() {
+    constexpr int G = 2 * KT, GP = part_gp(MT), last = G % GP == 0 ? GP : G % GP;
+    return kTiles * last;
+}
+
+}  // namespace nnr

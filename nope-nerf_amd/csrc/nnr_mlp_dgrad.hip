@@ -50,15 +50,15 @@ __device__ __forceinline__ f32x4 enc_backward(const G& g, const float (&pv)[NR],
 
 NNR_TL_DECL(tl_dgrad)
 
-template <int D, bool BF16>
+template <int D>
 __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     NNR_STAMP(tl_dgrad, 0);
-    using L = Layout<D, BF16>;
+    using L = Layout<D>;
     constexpr int DT = L::DT, HT = L::HT;
     constexpr int HR = 16 * HT;              // registers of half a layer's outputs
     constexpr int NP = HR / 2;               // register pairs per half (the unit of hidden epilogue work)
     constexpr int HW = (HR + 31) / 32;       // mask words per half
-    constexpr int PP = part_panels(DT, HT, BF16);  // panels of one D x D/2 pass
+    constexpr int PP = part_panels(DT, HT);  // panels of one D x D/2 pass
     const int lane0 = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
@@ -116,12 +116,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     [&](int u) __attribute__((always_inline)) {                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
             const int r = 2 * u + i;                                                                         \
-            if constexpr (BF16) {   /* issue-bound kernel: sign-extended bit field + and (2 instructions, not 3) */ \
-                const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe((int)MW[r >> 5], r & 31, 1);           \
-                d[(OFF) + r] = __uint_as_float(__float_as_uint(ACC[r >> 4][r & 15]) & keep);                 \
-            } else {                                                                                         \
-                d[(OFF) + r] = ((MW[r >> 5] >> (r & 31)) & 1u) ? ACC[r >> 4][r & 15] : 0.f;                  \
-            }                                                                                                \
+            d[(OFF) + r] = ((MW[r >> 5] >> (r & 31)) & 1u) ? ACC[r >> 4][r & 15] : 0.f;                      \
         }                                                                                                    \
     }
 #define NNR_MOVE_PAIR(ACC, OFF)                                                                              \
@@ -160,25 +155,17 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     };
     load_mask(mwA, 7, 0);
     init_sigma(accA, 0);
-    // d g goes to P_DG; in the bf16 mode that plane is tile-major and has one more group: the output gradients themselves
-    // (d rgb_pre[0..2], d sigma_raw, zeros) as bf16, the gradient operand of the two head layers in the weight-gradient kernel
-    float* const dg_stash = stash_row<BF16>(a.ws_dg, ss, BF16 ? D / 2 + 16 : D / 2, half);
-    if constexpr (BF16) {
-        bf16x8 q;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = (__bf16)((half == 0 && i < 4) ? dout[i & 3] : 0.f);
-        *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(dg_stash) + kBlockBf16 * (D / 32)) = __builtin_bit_cast(f32x4, q);
-    }
-    gemm_sel<BF16, HT, HT, 1>(accA, dg, pipe, p0(B_RGBH_FA), dg_stash);
+    float* const dg_stash = a.ws_dg + ss * (D / 2) + 4 * half;   // d g goes to P_DG
+    gemm_part<HT, HT, true>(accA, dg, pipe, p0(B_RGBH_FA), dg_stash);
     load_mask(mwB, 7, 1);
     init_sigma(accB, 1);
-    gemm_sel<BF16, HT, HT, false, NP, 2, 0>(accB, dg, pipe, p0(B_RGBH_FB), nullptr, NNR_SEL_PAIR(accA, 0, mwA));
+    gemm_part<HT, HT, false, NP, 2, 0>(accB, dg, pipe, p0(B_RGBH_FB), nullptr, NNR_SEL_PAIR(accA, 0, mwA));
     {
         float pvd[16];   // stored direction encoding (sin<->cos partners): the loads land under this short pass
         enc_partners(pvd, a.ws_xf + (live ? s : 0) * kDirPad, kDirReal, half);
         f32x16 accd[1];
         zero_acc(accd);
-        gemm_sel<BF16, HT, 1>(accd, dg, pipe, p0(B_RGBH_D));
+        gemm_part<HT, 1>(accd, dg, pipe, p0(B_RGBH_D));
         const f32x4 gv = enc_backward<16>([&](int r) { return accd[0][r]; }, pvd, half);
         if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dview + 4 * s) = gv;
     }
@@ -186,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     NNR_STAMP(tl_dgrad, 3);
 
     // ---- trunk ----
-    auto dh = [&](int hidden_idx /*0..7*/) -> float* { return stash_row<BF16>(a.ws_dh, (int64_t)hidden_idx * a.S_pad + ss, D, half); };
+    auto dh = [&](int hidden_idx /*0..7*/) -> float* { return a.ws_dh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half; };
     // Invariant from here on: d[0, HR) holds half A of the newest gradient, accB its half B still to be masked (mwB).
 
     // one transposed D x D layer at panel pa: consumes the gradient in d (stashing it to `stash`), produces the gradient of
@@ -195,11 +182,11 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
         zero_acc(accA);
         load_mask(mwA, mask_idx, 0);
         // pass A: the first half of the k-groups only reads d[0,HR); the previous gradient's half B is finished meanwhile
-        gemm_sel<BF16, DT, HT, true, NP, 2, 0>(accA, d, pipe, pa, stash, NNR_SEL_PAIR(accB, HR, mwB));
+        gemm_part<DT, HT, true, NP, 2, 0>(accA, d, pipe, pa, stash, NNR_SEL_PAIR(accB, HR, mwB));
         load_mask(mwB, mask_idx, 1);
         zero_acc(accB);
         // pass B: half A of the new gradient replaces d[0,HR) in place, one k-group behind the reads
-        gemm_sel<BF16, DT, HT, false, NP, 2, 1>(accB, d, pipe, pa + PP, nullptr, NNR_SEL_PAIR(accA, 0, mwA));
+        gemm_part<DT, HT, false, NP, 2, 1>(accB, d, pipe, pa + PP, nullptr, NNR_SEL_PAIR(accA, 0, mwA));
     };
     // hidden 8,7,6 -> d pre-activation of 7,6,5
 #pragma unroll 1
@@ -210,17 +197,17 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
         f32x16 acce[2];
         zero_acc(acce);
         load_mask(mwA, 3, 0);
-        gemm_sel<BF16, DT, 2, true, NP, 2, 0>(acce, d, pipe, p0(B_L5E), dh(4), NNR_SEL_PAIR(accB, HR, mwB));
+        gemm_part<DT, 2, true, NP, 2, 0>(acce, d, pipe, p0(B_L5E), dh(4), NNR_SEL_PAIR(accB, HR, mwB));
         load_mask(mwB, 3, 1);
         zero_acc(accA);
         auto park = [&](int q) __attribute__((always_inline)) {
             de_lds[q * 64] = f32x4{acce[q >> 2][4 * (q & 3)], acce[q >> 2][4 * (q & 3) + 1], acce[q >> 2][4 * (q & 3) + 2],
                                    acce[q >> 2][4 * (q & 3) + 3]};
         };
-        gemm_sel<BF16, DT, HT, false, 8, 1, 0>(accA, d, pipe, p0(B_L5HA), nullptr, park);
+        gemm_part<DT, HT, false, 8, 1, 0>(accA, d, pipe, p0(B_L5HA), nullptr, park);
     }
     zero_acc(accB);
-    gemm_sel<BF16, DT, HT, false, NP, 2, 1>(accB, d, pipe, p0(B_L5HB), nullptr, NNR_SEL_PAIR(accA, 0, mwA));
+    gemm_part<DT, HT, false, NP, 2, 1>(accB, d, pipe, p0(B_L5HB), nullptr, NNR_SEL_PAIR(accA, 0, mwA));
     NNR_STAMP(tl_dgrad, 5);
     // hidden 4,3,2 -> d pre-activation of 3,2,1
 #pragma unroll 1
@@ -232,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
         enc_partners(pve, a.ws_xe + (live ? s : 0) * kPosPad, kPosReal, half);
         f32x16 acc2[2];
         zero_acc(acc2);
-        gemm_sel<BF16, DT, 2, true, NP, 2, 0>(acc2, d, pipe, p0(B_L1), dh(0), NNR_SEL_PAIR(accB, HR, mwB));
+        gemm_part<DT, 2, true, NP, 2, 0>(acc2, d, pipe, p0(B_L1), dh(0), NNR_SEL_PAIR(accB, HR, mwB));
         float de[32];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -257,15 +244,14 @@ extern "C" int nnr_timeline_dgrad(unsigned long long* host32) {
 #endif
 
 template <int D>
-static hipError_t launch(const MlpDgradArgs& a, bool bf16, hipStream_t st) {
+static hipError_t launch(const MlpDgradArgs& a, hipStream_t st) {
     dim3 grid((unsigned)(a.chunks_per_ray > 0 ? a.S_pad / kBlockSamples / a.chunks_per_ray : a.S_pad / kBlockSamples)), block(256);
-    if (bf16) hipLaunchKernelGGL((mlp_dgrad_kernel<D, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((mlp_dgrad_kernel<D, false>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((mlp_dgrad_kernel<D>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, bool bf16, hipStream_t st) {
-    return D == 256 ? launch<256>(a, bf16, st) : launch<128>(a, bf16, st);
+hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st) {
+    return D == 256 ? launch<256>(a, st) : launch<128>(a, st);
 }
 
 }  // namespace nnr

@@ -1,0 +1,286 @@
+// nnr_mlp_dgrad_bf16.hip -- fused input-gradient chain of the NeRF MLP with bf16 MFMA products (NNR_F_BF16), gfx950.  Same function
+// as nnr_mlp_dgrad.hip (autograd's chain through model/official_nerf.py:60-96 for the data path: d rgb_pre, d sigma_raw per sample
+// down to d point, d view dir, every layer's pre-activation gradient left in the workspace -- as bf16, tile-major -- for the
+// weight-gradient kernel), in the arithmetic of the bf16 mode: every transposed hidden layer is bf16(gradient) x bf16(W^T) with fp32
+// accumulation; the two heads' input gradients (3 FMAs / 1 FMA per value) and the chain rule through the encodings stay fp32.
+// One wave = TWO chunks of 32 samples, gradients packed bf16 between layers: see nnr_mlp_bf16.h.
+#include "nnr_kernels.h"
+#include "nnr_mlp_bf16.h"
+
+namespace nnr {
+
+// ---- chain rule through gamma_L (same as nnr_mlp_dgrad.hip) ----
+struct EncMeta16 { int coord; float scale; int partner; };
+__device__ __forceinline__ constexpr EncMeta16 enc_meta16(int f, int n_real) {
+    if (f >= n_real) return {0, 0.f, 0};
+    if (f < 3) return {f, 1.f, -1};
+    const int t = f - 3, lvl = t / 6, rem = t - 6 * lvl;
+    const bool is_cos = rem >= 3;
+    const float a = (float)(1 << lvl);
+    return {is_cos ? rem - 3 : rem, is_cos ? -a : a, is_cos ? f - 3 : f + 3};
+}
+// d/d(x,y,z) of sum_r g(r) * gamma(.)_{f(r,half)}, the partner values (cos for a sin feature, -sin for a cos feature, 1 for the identity
+// block, times the octave) read from the stashed fp32 encoding `enc` of the lane's sample
+template <int NR, class G>
+__device__ __forceinline__ f32x4 enc_chain(const G& g, const float* enc, int n_real, int half) {
+    float g3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const EncMeta16 m0 = enc_meta16(frag_feature(r, 0), n_real), m1 = enc_meta16(frag_feature(r, 1), n_real);
+        const int partner = half ? m1.partner : m0.partner;
+        const float sc = half ? m1.scale : m0.scale;
+        const float pv = sc * (partner >= 0 ? enc[partner] : 1.f);
+        const int f0 = frag_feature(r, 0);
+        const int c0 = f0 < 3 ? f0 : (f0 - 3) % 3;     // coordinate of register r in half 0; half 1 is rotated by one (f -> f + 4)
+        g3[c0] = fmaf(g(r), pv, g3[c0]);
+    }
+    float o[3] = {half ? g3[2] : g3[0], half ? g3[0] : g3[1], half ? g3[1] : g3[2]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
+    return f32x4{o[0], o[1], o[2], 0.f};
+}
+
+NNR_TL_DECL(tl_dgrad16)
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) {
+    NNR_STAMP(tl_dgrad16, 0);
+    using L = Layout<D, true>;
+    constexpr int DT = L::DT, HT = L::HT;
+    constexpr int HR = 16 * HT;              // fragment registers of half a layer's outputs (fp32 numbering)
+    constexpr int NP = HR / 2;               // packed registers per half and tile = epilogue units per half and tile
+    constexpr int HW = (HR + 31) / 32;       // mask words per half
+    constexpr int PP = part_panels(DT, HT, true);
+    constexpr int NQ = 8 * DT;               // packed registers of a D-wide vector
+    constexpr int NU = kTiles * NP;          // epilogue units of one half-output pass
+    const int lane0 = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    // LDS: the panel ring of the transposed weight stream and the fp32 head tables (density row, rgb rows, register order)
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + (L::head_floats + 3) / 4];
+    float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4);
+    for (int i = threadIdx.x; i < L::head_floats; i += 256) ltab[i] = a.packed[L::head_base + i];
+    __syncthreads();   // before any DMA is in flight: the only full barrier of the kernel
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed + L::bwd_base) + wave_u * (8 * 64), smem, wave_u, lane0, L::bwd_panels};
+    // flat or ray-mode decomposition in pairs of chunks, exactly as in mlp_fwd_bf16_kernel
+    const int n_pass = a.chunks_per_ray > 0 ? a.chunks_per_ray : 1;
+    const int64_t last_chunk = a.S_pad / kChunk - 1;
+    pipe.more = n_pass > 1;
+    pipe.start();
+    auto p0 = [&](int part) { return L::bwd_panel0(part); };
+#pragma unroll 1
+    for (int pass = 0; pass < n_pass; ++pass) {
+    int lane = lane0;                 // opaque per pass (mlp_fwd_kernel)
+    asm volatile("" : "+v"(lane));
+    pipe.lane = lane;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const float* const wsig = ltab + half * (16 * DT);   // density row, this half's registers
+    const float* const wrgb = ltab + 2 * 16 * DT;        // rgb rows: [(2c + half) * HR + r]
+    const int64_t pair = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * kWavesPerBlock + wave) * n_pass + pass
+                                               : (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    int chunk[kTiles];   // chunk index of either tile
+    f32x4 dout[kTiles];
+#pragma unroll
+    for (int n = 0; n < kTiles; ++n) chunk[n] = (int)(kTiles * pair + n < last_chunk ? kTiles * pair + n : last_chunk);
+    // this lane's sample of tile n; every address is derived from it where it is needed (opaque(), nnr_mlp_bf16.h)
+    auto sample = [&](int n) -> int64_t { return (int64_t)opaque(chunk[n]) * kChunk + col; };
+#pragma unroll
+    for (int n = 0; n < kTiles; ++n) {
+        const int64_t sn = sample(n);
+        dout[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // padded samples carry zero gradients so they add nothing to the weight gradients
+        if (sn < a.S) dout[n] = *reinterpret_cast<const f32x4*>(a.ws_dout4 + 4 * sn);
+        else if (half == 0) *reinterpret_cast<f32x4*>(a.ws_dout4 + 4 * sn) = dout[n];   // padded rows feed the weight-gradient kernel
+    }
+
+    // (the row dimension of the packed arrays is padded by 4: with rows adjacent in memory hipcc forms a 32-byte access across the
+    // row boundary and then leaves those 8 registers in scratch memory)
+    uint32_t dq[kTiles][NQ + 4];   // current D-wide gradient, packed (d pre-activation of hidden 8..1), rewritten in place
+    f32x16 accA[kTiles][HT], accB[kTiles][HT];   // halves A ([0,D/2)) and B ([D/2,D)) of the gradient being computed
+    uint32_t mwA[kTiles][HW], mwB[kTiles][HW];   // ReLU sign bits of the layer whose gradient sits in accA / accB
+    auto load_mask = [&](uint32_t(&mw)[kTiles][HW], int layer_idx, int hb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) {
+            const uint32_t* m = a.ws_mask + (((int64_t)opaque(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane) * L::mask_words + hb * HW;
+#pragma unroll
+            for (int w = 0; w < HW; ++w) mw[n][w] = m[w];
+        }
+    };
+// one epilogue unit u: tile u & 1, packed register (u >> 1) of the half -- dq[tile][OFF + (u >> 1)] = (relu'(.) ? acc : 0) x 2 as bf16
+// (sign-extended mask bit + and: two instructions per value)
+#define NNR_SEL_UNIT(ACC, OFF, MW)                                                                           \
+    [&](int u) __attribute__((always_inline)) {                                                              \
+        const int n = u & 1, p = u >> 1;                                                                     \
+        float v[2];                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+            const int r = 2 * p + i;                                                                         \
+            const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe((int)MW[n][r >> 5], r & 31, 1);            \
+            v[i] = __uint_as_float(__float_as_uint(ACC[n][r >> 4][r & 15]) & keep);                          \
+        }                                                                                                    \
+        dq[n][(OFF) + p] = pack_bf16(v[0], v[1]);                                                            \
+    }
+    __bf16* const no_stash[kTiles] = {nullptr, nullptr};
+
+    // ---- colour branch ----
+    // d g = relu'(g) .* (Wc^T d rgb_pre): three FMAs per value against the rgb rows in LDS (a 3-deep GEMM is not MFMA work)
+    uint32_t dgq[kTiles][NP + 4];
+    load_mask(mwA, 8, 0);
+#pragma unroll
+    for (int q = 0; q < HR / 4; ++q) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrgb + (0 + half) * HR + 4 * q);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(wrgb + (2 + half) * HR + 4 * q);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(wrgb + (4 + half) * HR + 4 * q);
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * q + i;
+                const float x = fmaf(w2[i], dout[n][2], fmaf(w1[i], dout[n][1], w0[i] * dout[n][0]));
+                v[i] = ((mwA[n][r >> 5] >> (r & 31)) & 1u) ? x : 0.f;
+            }
+            dgq[n][2 * q] = pack_bf16(v[0], v[1]);
+            dgq[n][2 * q + 1] = pack_bf16(v[2], v[3]);
+        }
+    }
+    // [d h8 ; d gamma(v)] from d g.  The feature layer is folded into the colour-hidden layer (nnr_layout.h): d h8 =
+    // relu'(h8) .* (W'^T d g + w_sigma^T d sigma_raw), the rank-1 density term being the accumulator's initial value.
+    auto init_sigma = [&](f32x16(&acc)[kTiles][HT], int hb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wsig + hb * HR + 16 * t + 4 * q);
+#pragma unroll
+                for (int n = 0; n < kTiles; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[n][t][4 * q + i] = w4[i] * dout[n][3];
+            }
+    };
+    load_mask(mwA, 7, 0);
+    init_sigma(accA, 0);
+    // d g goes to P_DG (tile-major, one more group than D/32: the output gradients themselves -- d rgb_pre[0..2], d sigma_raw, zeros --
+    // as bf16, the gradient operand of the two head layers in the weight-gradient kernel)
+    __bf16* dg_stash[kTiles];
+#pragma unroll
+    for (int n = 0; n < kTiles; ++n) {
+        dg_stash[n] = tile_row(a.ws_dg, sample(n), D / 2 + 16, half);
+        u32x4 q = {0u, 0u, 0u, 0u};
+        if (half == 0) {
+            q[0] = pack_bf16(dout[n][0], dout[n][1]);
+            q[1] = pack_bf16(dout[n][2], dout[n][3]);
+        }
+        stash_store(dg_stash[n] + kBlockBf16 * (D / 32), q);
+    }
+    gemm_wide<HT, HT, true, 0, 1, 0, 0>(accA, dgq, pipe, p0(B_RGBH_FA), dg_stash, NoSide{});
+    load_mask(mwB, 7, 1);
+    init_sigma(accB, 1);
+    // G = 2 HT rows; unit u writes dq[.][u >> 1] -- not an input of this part
+    gemm_wide<HT, HT, false, NU, NU / (2 * HT), 0, stash_tail<HT, HT>()>(accB, dgq, pipe, p0(B_RGBH_FB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
+    {
+        f32x16 accd[kTiles][1];
+        zero_acc2(accd);
+        gemm_wide<HT, 1>(accd, dgq, pipe, p0(B_RGBH_D));
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) {
+            const int64_t sn = sample(n);
+            const bool live = sn < a.S;
+            const f32x4 gv = enc_chain<16>([&](int r) { return accd[n][0][r]; }, a.ws_xf + (live ? sn : 0) * kDirPad, kDirReal, half);
+            if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dview + 4 * sn) = gv;
+        }
+    }
+    NNR_STAMP(tl_dgrad16, 1);
+
+    // ---- trunk ----
+    auto dh = [&](int hidden_idx /*0..7*/, int n) -> __bf16* { return tile_row(a.ws_dh, (int64_t)hidden_idx * a.S_pad + sample(n), D, half); };
+    // Invariant from here on: dq[.][0, NP) holds half A of the newest gradient, accB its half B still to be masked (mwB).
+
+    // one transposed D x D layer at panel pa: consumes the gradient in dq (stashing it to st[]), produces the gradient of the layer
+    // below, masked by the sign bits of hidden layer `mask_idx`
+    auto bwd_layer = [&](int pa, __bf16* const (&st)[kTiles], int mask_idx) __attribute__((always_inline)) {
+        zero_acc2(accA);
+        load_mask(mwA, mask_idx, 0);
+        // pass A: rows [0, G/2) only read dq[.][0, NP); the previous gradient's half B is finished meanwhile (unit u at row u / 5, see
+        // mlp_fwd_bf16_kernel)
+        gemm_wide<DT, HT, true, NU, 5, 0, 0>(accA, dq, pipe, pa, st, NNR_SEL_UNIT(accB, NP, mwB));
+        load_mask(mwB, mask_idx, 1);
+        zero_acc2(accB);
+        // pass B: half A of the new gradient replaces dq[.][0, NP) in place behind the reads (unit u at row u / 4 + 1)
+        gemm_wide<DT, HT, false, NU, 4, 1, stash_tail<DT, HT>()>(accB, dq, pipe, pa + PP, no_stash, NNR_SEL_UNIT(accA, 0, mwA));
+    };
+    // hidden 8,7,6 -> d pre-activation of 7,6,5
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+        __bf16* const st[kTiles] = {dh(7 - l, 0), dh(7 - l, 1)};
+        bwd_layer(p0(B_L8A) + 2 * PP * l, st, 6 - l);
+    }
+    NNR_STAMP(tl_dgrad16, 2);
+    // hidden 5 (skip layer), three passes over W5^T: rows [D, D+63) -> d posenc, rows [0,D) -> d h4.  The chain rule through gamma_10
+    // is linear in d posenc, so this part's share of d point is formed right away and added to the first layer's at the end.
+    f32x4 gp5[kTiles];
+    {
+        __bf16* const st[kTiles] = {dh(4, 0), dh(4, 1)};
+        f32x16 acce[kTiles][2];
+        zero_acc2(acce);
+        load_mask(mwA, 3, 0);
+        gemm_wide<DT, 2, true, NU, 5, 0, 0>(acce, dq, pipe, p0(B_L5E), st, NNR_SEL_UNIT(accB, NP, mwB));
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) {
+            const int64_t sn = sample(n);
+            gp5[n] = enc_chain<32>([&](int r) { return acce[n][r >> 4][r & 15]; }, a.ws_xe + (sn < a.S ? sn : 0) * kPosPad, kPosReal, half);
+        }
+    }
+    load_mask(mwB, 3, 1);
+    zero_acc2(accA);
+    gemm_wide<DT, HT>(accA, dq, pipe, p0(B_L5HA));   // (the chain-rule loads above were waited for: nothing of B_L5E is in flight)
+    zero_acc2(accB);
+    gemm_wide<DT, HT, false, NU, 4, 1, 0>(accB, dq, pipe, p0(B_L5HB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
+    NNR_STAMP(tl_dgrad16, 3);
+    // hidden 4,3,2 -> d pre-activation of 3,2,1
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+        __bf16* const st[kTiles] = {dh(3 - l, 0), dh(3 - l, 1)};
+        bwd_layer(p0(B_L4A) + 2 * PP * l, st, 2 - l);
+    }
+    NNR_STAMP(tl_dgrad16, 4);
+    // hidden 1: d posenc = W1^T d1, chain rule through gamma_10, + the skip layer's share -> d point
+    {
+        __bf16* const st[kTiles] = {dh(0, 0), dh(0, 1)};
+        f32x16 acc2[kTiles][2];
+        zero_acc2(acc2);
+        gemm_wide<DT, 2, true, NU, 5, 0, 0>(acc2, dq, pipe, p0(B_L1), st, NNR_SEL_UNIT(accB, NP, mwB));
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) {
+            const int64_t sn = sample(n);
+            const bool live = sn < a.S;
+            const f32x4 gp = enc_chain<32>([&](int r) { return acc2[n][r >> 4][r & 15]; }, a.ws_xe + (live ? sn : 0) * kPosPad, kPosReal, half);
+            if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dpts + 4 * sn) = gp + gp5[n];
+        }
+    }
+    NNR_STAMP(tl_dgrad16, 5);
+#undef NNR_SEL_UNIT
+    pipe.next_pass(pass + 2 < n_pass);
+    }   // pass
+}
+
+#ifdef NNR_TIMELINE
+extern "C" int nnr_timeline_dgrad16(unsigned long long* host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_dgrad16), 32 * sizeof(unsigned long long));
+}
+#endif
+
+template <int D>
+static hipError_t launch(const MlpDgradArgs& a, hipStream_t st) {
+    const int64_t per_block = (int64_t)kWideSamples * (a.chunks_per_ray > 0 ? a.chunks_per_ray : 1);
+    dim3 grid((unsigned)((a.S_pad + per_block - 1) / per_block)), block(256);
+    hipLaunchKernelGGL((mlp_dgrad_bf16_kernel<D>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_dgrad_bf16(int D, const MlpDgradArgs& a, hipStream_t st) {
+    return D == 256 ? launch<256>(a, st) : launch<128>(a, st);
+}
+
+}  // namespace nnr

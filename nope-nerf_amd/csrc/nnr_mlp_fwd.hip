@@ -8,7 +8,7 @@
 // 63 / 27-wide edges) = 541 k cycles per wave against ~40-90 k cycles of everything else.
 // Every D-wide layer runs as two half-output passes so that epilogues execute inside the MFMA stream (nnr_device.h).
 // HBM per sample: 4 B jitter in, 20 B out (+ the 9.4 KB activation stash when training, written once, never re-read here).
-// BF16 = true: the same kernel with bf16 MFMA products (gemm_part_bf16); then issue / the stash write is the bound.
+// (fp32 products; the bf16-MFMA mode has its own kernel, nnr_mlp_fwd_bf16.hip)
 #include "nnr_device.h"
 #include "nnr_kernels.h"
 
@@ -22,10 +22,10 @@ constexpr bool kAblateNoMask = false;
 
 NNR_TL_DECL(tl_fwd)
 
-template <int D, bool TRAIN, bool BF16>
+template <int D, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 0);
-    using L = Layout<D, BF16>;
+    using L = Layout<D>;
     constexpr int DT = L::DT, HT = L::HT;
     const int lane0 = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     constexpr int HR = 16 * HT;              // registers of half a layer's outputs
     constexpr int NP = HR / 2;               // register pairs per half (the unit of hidden epilogue work)
     constexpr int HW = (HR + 31) / 32;       // mask words per half
-    constexpr int PP = part_panels(DT, HT, BF16);  // panels of one D x D/2 pass
+    constexpr int PP = part_panels(DT, HT);  // panels of one D x D/2 pass
 
     float h[16 * DT];    // current layer input (activations of the previous layer), rewritten in place
     f32x16 accA[HT], accB[HT];   // halves A ([0,D/2)) and B ([D/2,D)) of the layer being computed
@@ -130,25 +130,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         if (TRAIN) {
             uint32_t* m = mask_base + (int64_t)layer_idx * 64 * L::mask_words + hb * HW;
 #pragma unroll
-            for (int w = 0; w < HW; ++w) m[w] = BF16 ? ~__builtin_bitreverse32(mw[w]) : mw[w];
+            for (int w = 0; w < HW; ++w) m[w] = mw[w];
         }
     };
-// one epilogue unit u (registers 2u, 2u+1 of the half): h[off + 2u + i] = relu(acc) (+ sign bit) or plain move.
-// Mask bit r = (x > 0).  The bf16 kernels are bound by instruction issue, not by the matrix pipe, so there the three
-// instructions per value (compare, select, or) become one: the SIGN bits are shifted into the word in register order
-// (v_alignbit_b32), and store_mask reverses and inverts the finished word.  The two differ only for x == +0.0 exactly
-// (sign clear, not > 0), which an fp32 sum of bf16 products does not produce outside all-zero rows -- and those have no
-// gradient to pass on either way.
+// one epilogue unit u (registers 2u, 2u+1 of the half): h[off + 2u + i] = relu(acc) (+ sign bit) or plain move.  Mask bit r = (x > 0).
 #define NNR_RELU_PAIR(ACC, OFF, MW)                                                                          \
     [&](int u) __attribute__((always_inline)) {                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
             const int r = 2 * u + i;                                                                         \
             const float x = ACC[r >> 4][r & 15];                                                             \
             h[(OFF) + r] = relu1(x);                                                                         \
-            if (TRAIN && !kAblateNoMask) {                                                                   \
-                if constexpr (BF16) MW[r >> 5] = __builtin_amdgcn_alignbit(MW[r >> 5], __float_as_uint(x), 31); \
-                else MW[r >> 5] |= x > 0.f ? (1u << (r & 31)) : 0u;                                          \
-            }                                                                                                \
+            if (TRAIN && !kAblateNoMask) MW[r >> 5] |= x > 0.f ? (1u << (r & 31)) : 0u;                      \
         }                                                                                                    \
     }
 #define NNR_MOVE_PAIR(ACC, OFF)                                                                              \
@@ -158,25 +150,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     auto p0 = [&](int part) { return L::fwd_panel0(part); };
     float* const xe = TRAIN ? a.ws_xe + ss * kPosPad + 4 * half : nullptr;
     auto xh = [&](int hidden_idx /*0..7*/) -> float* {
-        return TRAIN ? stash_row<BF16>(a.ws_xh, (int64_t)hidden_idx * a.S_pad + ss, D, half) : nullptr;
+        return TRAIN ? a.ws_xh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half : nullptr;
     };
-    if constexpr (TRAIN && BF16) {
-        // tile-major bf16 copies of the two encodings for the weight-gradient kernel (the fp32 planes stay: the backward of the
-        // encodings reads sin / cos back at full precision)
-        __bf16* e16 = reinterpret_cast<__bf16*>(stash_row<true>(a.ws_xe16, ss, kPosPad, half));
-#pragma unroll
-        for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(e16 + kBlockBf16 * b) = __builtin_bit_cast(f32x4, pack_row(e, b));
-        __bf16* f16 = reinterpret_cast<__bf16*>(stash_row<true>(a.ws_xf16, ss, kDirPad, half));
-#pragma unroll
-        for (int b = 0; b < 2; ++b) *reinterpret_cast<f32x4*>(f16 + kBlockBf16 * b) = __builtin_bit_cast(f32x4, pack_row(dirv, b));
-    }
 
     // ---- hidden 1: 63 -> D, input = posenc.  Pass A, then pass B with A's epilogue hidden under it. ----
     init_acc(accA, L::bias_off(0));
-    gemm_sel<BF16, 2, HT, TRAIN ? 2 : 0>(accA, e, pipe, p0(F_L1A), xe);            // the encodings stay fp32 in either mode
+    gemm_part<2, HT, TRAIN>(accA, e, pipe, p0(F_L1A), xe);
     init_acc(accB, L::bias_off(0) + L::Dh);
     clear_mask(mwA);
-    gemm_sel<BF16, 2, HT, false, NP, NP / 8, 0>(accB, e, pipe, p0(F_L1B), nullptr, NNR_RELU_PAIR(accA, 0, mwA));
+    gemm_part<2, HT, false, NP, NP / 8, 0>(accB, e, pipe, p0(F_L1B), nullptr, NNR_RELU_PAIR(accA, 0, mwA));
     store_mask(mwA, 0, 0);
     // posenc is needed again only by the skip layer: park it in LDS meanwhile
 #pragma unroll
@@ -189,12 +171,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         init_acc(accA, L::bias_off(li));
         clear_mask(mwB);
         // pass A: the first half of the k-groups only needs h[0,HR); the previous layer's half B is finished meanwhile
-        gemm_sel<BF16, DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, pa, stash, NNR_RELU_PAIR(accB, HR, mwB));
+        gemm_part<DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, pa, stash, NNR_RELU_PAIR(accB, HR, mwB));
         store_mask(mwB, li - 1, 1);
         init_acc(accB, L::bias_off(li) + L::Dh);
         clear_mask(mwA);
         // pass B: half A of the new layer replaces h[0,HR) in place, one k-group behind the reads
-        gemm_sel<BF16, DT, HT, false, NP, 2, 1>(accB, h, pipe, pa + PP, nullptr, NNR_RELU_PAIR(accA, 0, mwA));
+        gemm_part<DT, HT, false, NP, 2, 1>(accB, h, pipe, pa + PP, nullptr, NNR_RELU_PAIR(accA, 0, mwA));
         store_mask(mwA, li, 0);
     };
     // hidden 2..4
@@ -204,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // hidden 5: [h4 ; e] -> D   (skip connection, input order [h, posenc]: model/official_nerf.py:63)
     init_acc(accA, L::bias_off(4));
     clear_mask(mwB);
-    gemm_sel<BF16, DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, p0(F_L5HA), xh(3), NNR_RELU_PAIR(accB, HR, mwB));
+    gemm_part<DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, p0(F_L5HA), xh(3), NNR_RELU_PAIR(accB, HR, mwB));
     store_mask(mwB, 3, 1);
     float e5[32];
 #pragma unroll
@@ -213,11 +195,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) e5[4 * q + i] = v[i];
     }
-    gemm_sel<BF16, 2, HT>(accA, e5, pipe, p0(F_L5EA));
+    gemm_part<2, HT>(accA, e5, pipe, p0(F_L5EA));
     init_acc(accB, L::bias_off(4) + L::Dh);
     clear_mask(mwA);
-    gemm_sel<BF16, DT, HT, false, NP, 2, 1>(accB, h, pipe, p0(F_L5HB), nullptr, NNR_RELU_PAIR(accA, 0, mwA));
-    gemm_sel<BF16, 2, HT>(accB, e5, pipe, p0(F_L5EB));
+    gemm_part<DT, HT, false, NP, 2, 1>(accB, h, pipe, p0(F_L5HB), nullptr, NNR_RELU_PAIR(accA, 0, mwA));
+    gemm_part<2, HT>(accB, e5, pipe, p0(F_L5EB));
     store_mask(mwA, 4, 0);
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 5);
     // hidden 6..8
@@ -229,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // model/official_nerf.py:87-89) is folded into this one by the pack kernel, see nnr_layout.h.  One pass (D/2 outputs).
     // Its side work first finishes hidden 8 (half B), then evaluates the density head -- a per-lane dot product of h8 with
     // the density row (a 1-row GEMM is not MFMA work).
-    float* const xf = TRAIN ? a.ws_xf + ss * kDirPad + 4 * half : nullptr;   // fp32, row-major in either mode
+    float* const xf = TRAIN ? a.ws_xf + ss * kDirPad + 4 * half : nullptr;
     init_acc(accA, L::bias_off(10));
     clear_mask(mwB);
     float sg0 = 0.f, sg1 = 0.f;
@@ -247,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         };
         // 4 units per k-group: the NP finishing units occupy k-groups [0, NP/4) -- long before k-group 2*DT first reads
         // h[HR..] -- and the 2*NP density units k-groups [NP/4, 3*NP/4) <= 4*DT
-        gemm_sel<BF16, DT, HT, TRAIN, 3 * NP, 4, 0>(accA, h, pipe, p0(F_RGBH_F), xh(7), finish_then_sigma);
+        gemm_part<DT, HT, TRAIN, 3 * NP, 4, 0>(accA, h, pipe, p0(F_RGBH_F), xh(7), finish_then_sigma);
     }
     store_mask(mwB, 7, 1);
     const float sg = sg0 + sg1;
@@ -260,23 +242,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dir2[4 * q + i] = v[i];
     }
-    gemm_sel<BF16, 1, HT, TRAIN ? 2 : 0>(accA, dir2, pipe, p0(F_RGBH_D), xf);
+    gemm_part<1, HT, TRAIN>(accA, dir2, pipe, p0(F_RGBH_D), xf);
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 8);
     clear_mask(mwA);
 #pragma unroll
     for (int u = 0; u < NP; ++u) NNR_RELU_PAIR(accA, 0, mwA)(u);   // g = h[0, HR)
     store_mask(mwA, 8, 0);
     if (TRAIN) {
-        float* xg = stash_row<BF16>(a.ws_xg, ss, D / 2, half);
-        if constexpr (BF16) {   // tile-major bf16 plane: group g = registers 8g .. 8g+7 of this lane, 16 bytes of block (chunk, g)
+        float* xg = a.ws_xg + ss * (D / 2) + 4 * half;
 #pragma unroll
-            for (int gq = 0; gq < HR / 8; ++gq)
-                *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(xg) + kBlockBf16 * gq) = __builtin_bit_cast(f32x4, pack_row(h, gq));
-        } else {
-#pragma unroll
-            for (int q = 0; q < HR / 4; ++q)
-                *reinterpret_cast<f32x4*>(xg + 8 * q) = f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
-        }
+        for (int q = 0; q < HR / 4; ++q)
+            *reinterpret_cast<f32x4*>(xg + 8 * q) = f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
     }
     // rgb head: 3 per-lane dot products over the lane's half of g, halves combined by one shuffle, then sigmoid
     float rgbv[3];
@@ -318,18 +294,16 @@ extern "C" int nnr_timeline_fwd(unsigned long long* host32) {
 #endif
 
 template <int D>
-static hipError_t launch(const MlpFwdArgs& a, bool train, bool bf16, hipStream_t st) {
+static hipError_t launch(const MlpFwdArgs& a, bool train, hipStream_t st) {
     // ray mode: one workgroup per 4 rays, chunks_per_ray passes each; flat mode: one workgroup per 128 samples
     dim3 grid((unsigned)(a.chunks_per_ray > 0 ? a.S_pad / kBlockSamples / a.chunks_per_ray : a.S_pad / kBlockSamples)), block(256);
-    if (train && bf16) hipLaunchKernelGGL((mlp_fwd_kernel<D, true, true>), grid, block, 0, st, a);
-    else if (train) hipLaunchKernelGGL((mlp_fwd_kernel<D, true, false>), grid, block, 0, st, a);
-    else if (bf16) hipLaunchKernelGGL((mlp_fwd_kernel<D, false, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((mlp_fwd_kernel<D, false, false>), grid, block, 0, st, a);
+    if (train) hipLaunchKernelGGL((mlp_fwd_kernel<D, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<D, false>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, bool bf16, hipStream_t st) {
-    return D == 256 ? launch<256>(a, train, bf16, st) : launch<128>(a, train, bf16, st);
+hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st) {
+    return D == 256 ? launch<256>(a, train, st) : launch<128>(a, train, st);
 }
 
 }  // namespace nnr

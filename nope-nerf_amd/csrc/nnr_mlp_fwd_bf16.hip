@@ -1,0 +1,354 @@
+// nnr_mlp_fwd_bf16.hip -- fused NeRF MLP forward with bf16 MFMA products (NNR_F_BF16), gfx950.  Same function as nnr_mlp_fwd.hip
+// (model/rendering.py:184-195 sampling + encodings, model/official_nerf.py:60-96 the MLP) in the arithmetic of BASELINE configs[2]:
+// every nn.Linear is a bf16 x bf16 product with fp32 accumulation -- hidden layers on the matrix pipe, the 1-row density head and
+// the 3-row rgb head as per-lane bf16 dot products (v_dot2c_f32_bf16) -- biases, activations functions and outputs in fp32.
+// One wave = TWO chunks of 32 samples, activations packed bf16 between layers: see nnr_mlp_bf16.h for why.
+//
+// Roofline: with the stash (training) HBM writes, 4.6 KB/sample; the matrix pipe needs 0.24 ms for 4096 x 128 samples at D = 256.
+#include "nnr_kernels.h"
+#include "nnr_mlp_bf16.h"
+
+namespace nnr {
+
+NNR_TL_DECL(tl_fwd16)
+
+template <int D, bool TRAIN>
+__global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
+    NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 0);
+    using L = Layout<D, true>;
+    constexpr int DT = L::DT, HT = L::HT;
+    constexpr int HR = 16 * HT;              // fragment registers of half a layer's outputs (fp32 numbering)
+    constexpr int NP = HR / 2;               // = packed registers per half and tile = epilogue units per half and tile
+    constexpr int HW = (HR + 31) / 32;       // mask words per half
+    constexpr int PP = part_panels(DT, HT, true);   // panels of one D x D/2 pass
+    constexpr int NQ = 8 * DT;               // packed registers of a D-wide vector
+    const int lane0 = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    // LDS: the panel ring, a parking area (per wave and lane 12 x 16 bytes: the packed encodings of both tiles), the fp32 bias / head
+    // tables of the packed buffer and the two heads' rows once more as packed bf16 pairs in register order
+    constexpr int kPark = kWavesPerBlock * 12 * 64;
+    constexpr int kHead16 = 2 * NQ + 3 * 2 * NP;   // uint32: density row [half][NQ], rgb rows [c][half][NP]
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kPark + (L::table_floats + 3) / 4 + (kHead16 + 3) / 4];
+    float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4 + kPark);
+    uint32_t* const head16 = reinterpret_cast<uint32_t*>(smem + kNBuf * kPanelF4 + kPark + (L::table_floats + 3) / 4);
+    for (int i = threadIdx.x; i < L::table_floats; i += 256) ltab[i] = a.packed[L::bias_base + i];
+    __syncthreads();
+    {
+        const float* hd = ltab + (L::head_base - L::bias_base);   // [2][16 DT] density row, then [3][2][16 HT] rgb rows, register order
+        for (int i = threadIdx.x; i < kHead16; i += 256) head16[i] = pack_bf16(hd[2 * i], hd[2 * i + 1]);
+    }
+    __syncthreads();   // before any DMA is in flight: the last full barrier of the kernel
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave_u * (8 * 64), smem, wave_u, lane0, L::fwd_panels};
+    // Work decomposition as in mlp_fwd_kernel, in PAIRS of chunks: flat -- workgroup b takes the samples [256 b, 256 b + 256), wave w
+    // the 64 from 64 w on; ray mode (a.chunks_per_ray = N / 64 > 0) -- wave w of workgroup b walks the chunk pairs of ray 4 b + w, the
+    // weight stream wrapping around from pass to pass.  A chunk index past the end is clamped: the wave recomputes the last chunk and
+    // stores the same values again.
+    const int n_pass = a.chunks_per_ray > 0 ? a.chunks_per_ray : 1;
+    const int64_t last_chunk = a.S_pad / kChunk - 1;
+    pipe.more = n_pass > 1;
+    pipe.start();
+#pragma unroll 1
+    for (int pass = 0; pass < n_pass; ++pass) {
+    int lane = lane0;                 // opaque per pass: keeps lane-constant addresses from being hoisted and spilled (mlp_fwd_kernel)
+    asm volatile("" : "+v"(lane));
+    pipe.lane = lane;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    f32x4* const park = smem + kNBuf * kPanelF4 + wave * (12 * 64) + lane;
+    const float* bias = ltab - L::bias_base;   // index with L::bias_off(layer)
+    const uint32_t* const wsig16 = head16 + half * NQ;
+    const int64_t pair = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * kWavesPerBlock + wave) * n_pass + pass
+                                               : (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    int chunk[kTiles];   // chunk index of either tile (< 2^26: S_pad < 2^31)
+#pragma unroll
+    for (int n = 0; n < kTiles; ++n) chunk[n] = (int)(kTiles * pair + n < last_chunk ? kTiles * pair + n : last_chunk);
+    auto sample = [&](int n) -> int64_t { return (int64_t)opaque(chunk[n]) * kChunk + col; };   // this lane's sample of tile n
+
+    // (the row dimension of the packed arrays is padded by 4: with rows adjacent in memory hipcc forms a 32-byte access across the
+    // row boundary and then leaves those 8 registers in scratch memory)
+    uint32_t hq[kTiles][NQ + 4];   // current layer input, packed; rewritten in place
+    f32x16 accA[kTiles][HT], accB[kTiles][HT];   // halves A ([0,D/2)) and B ([D/2,D)) of the layer being computed
+    uint32_t mwA[kTiles][HW], mwB[kTiles][HW];
+    uint32_t eq[kTiles][16 + 4];   // gamma_10(p) packed: 63 -> 64
+
+    // ---- sampling (model/rendering.py:184-195; unfused mul/add to round like the reference) and encodings, tile by tile ----
+#pragma unroll
+    for (int n = 0; n < kTiles; ++n) {
+        const int64_t sn = sample(n);
+        const int64_t sc = sn < a.S ? sn : a.S - 1;   // padded samples recompute the last one
+        const int ray = (int)(sc / a.N);
+        const int j = (int)(sc - (int64_t)ray * a.N);
+        const float zlo = a.z_lo[j], zhi = a.z_hi[j];
+        float z = zlo;
+        if (a.jitter) z = __fadd_rn(zlo, __fmul_rn(__fsub_rn(zhi, zlo), a.jitter[sc]));
+        const float* ro = a.pts_o + 3 * (int64_t)ray;
+        const float* rd = a.pts_d + 3 * (int64_t)ray;
+        const float* rv = a.view_d + 3 * (int64_t)ray;
+        const float px = __fadd_rn(ro[0], __fmul_rn(rd[0], z));
+        const float py = __fadd_rn(ro[1], __fmul_rn(rd[1], z));
+        const float pz = __fadd_rn(ro[2], __fmul_rn(rd[2], z));
+        const float vx = rv[0], vy = rv[1], vz = rv[2];
+        if (half == 0 && sn < a.S) a.ws_z[sn] = z;
+        float e[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) e[r] = enc_register(r, half, kPosReal, px, py, pz);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) eq[n][p] = pack_bf16(e[2 * p], e[2 * p + 1]);
+        float dirv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dirv[r] = enc_register(r, half, kDirReal, vx, vy, vz);
+        uint32_t dq[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) dq[p] = pack_bf16(dirv[2 * p], dirv[2 * p + 1]);
+        // both encodings wait in LDS: the position encoding for the skip layer, the direction encoding for the colour layer
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            park[(6 * n + q) * 64] = __builtin_bit_cast(f32x4, u32x4{eq[n][4 * q], eq[n][4 * q + 1], eq[n][4 * q + 2], eq[n][4 * q + 3]});
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            park[(6 * n + 4 + q) * 64] = __builtin_bit_cast(f32x4, u32x4{dq[4 * q], dq[4 * q + 1], dq[4 * q + 2], dq[4 * q + 3]});
+        if constexpr (TRAIN) {
+            // fp32 row-major copies for the backward of the encodings (sin / cos partners at full precision), tile-major bf16 copies
+            // = the MFMA operands, for the weight-gradient kernel
+            float* xe = a.ws_xe + sn * kPosPad + 4 * half;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) stash_store(xe + 8 * q, f32x4{e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]});
+            float* xf = a.ws_xf + sn * kDirPad + 4 * half;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) stash_store(xf + 8 * q, f32x4{dirv[4 * q], dirv[4 * q + 1], dirv[4 * q + 2], dirv[4 * q + 3]});
+            __bf16* e16 = tile_row(a.ws_xe16, sn, kPosPad, half);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                stash_store(e16 + kBlockBf16 * b, u32x4{eq[n][4 * b], eq[n][4 * b + 1], eq[n][4 * b + 2], eq[n][4 * b + 3]});
+            __bf16* f16 = tile_row(a.ws_xf16, sn, kDirPad, half);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) stash_store(f16 + kBlockBf16 * b, u32x4{dq[4 * b], dq[4 * b + 1], dq[4 * b + 2], dq[4 * b + 3]});
+        }
+    }
+    NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 1);
+
+    // accumulators start at the bias (the same for both tiles), so an epilogue is only ReLU + sign bit + pack
+    auto init_acc = [&](f32x16(&acc)[kTiles][HT], int bias_offset) __attribute__((always_inline)) {
+        const float* b = bias + bias_offset + 4 * half;
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 32 * t + 8 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int n = 0; n < kTiles; ++n) acc[n][t][4 * q + i] = bb[i];
+                }
+            }
+    };
+    auto clear_mask = [&](uint32_t(&mw)[kTiles][HW]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n)
+#pragma unroll
+            for (int w = 0; w < HW; ++w) mw[n][w] = 0;
+    };
+    auto store_mask = [&](const uint32_t(&mw)[kTiles][HW], int layer_idx, int hb) __attribute__((always_inline)) {
+        if (TRAIN) {
+#pragma unroll
+            for (int n = 0; n < kTiles; ++n) {
+                // masks: [chunk][layer][lane][mask_words]; half A of a layer owns the low words, half B the high words
+                uint32_t* m = a.ws_mask + (((int64_t)opaque(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane) * L::mask_words + hb * HW;
+#pragma unroll
+                for (int w = 0; w < HW; ++w) stash_store(m + w, ~__builtin_bitreverse32(mw[n][w]));
+            }
+        }
+    };
+// One epilogue unit u: tile u & 1, packed register (u >> 1) of the half -- hq[tile][OFF + (u >> 1)] = (relu(x0), relu(x1)) as bf16.
+// Mask bit r = (x > 0), collected as SIGN bits shifted into the word in register order (v_alignbit_b32); store_mask reverses and
+// inverts the finished word.  The two differ only for x == +0.0 exactly, which has no gradient to pass on either way.
+#define NNR_RELU_UNIT(ACC, OFF, MW)                                                                          \
+    [&](int u) __attribute__((always_inline)) {                                                              \
+        const int n = u & 1, p = u >> 1;                                                                     \
+        const float x0 = ACC[n][(2 * p) >> 4][(2 * p) & 15], x1 = ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]; \
+        hq[n][(OFF) + p] = relu_bf16x2(pack_bf16(x0, x1));   /* rounding keeps the sign: relu commutes with it */                                                  \
+        if (TRAIN) {                                                                                         \
+            MW[n][p >> 4] = __builtin_amdgcn_alignbit(MW[n][p >> 4], __float_as_uint(x0), 31);               \
+            MW[n][p >> 4] = __builtin_amdgcn_alignbit(MW[n][p >> 4], __float_as_uint(x1), 31);               \
+        }                                                                                                    \
+    }
+    auto p0 = [&](int part) { return L::fwd_panel0(part); };
+    __bf16* const no_stash[kTiles] = {nullptr, nullptr};
+    auto xh = [&](int hidden_idx /*0..7*/, int n) -> __bf16* {
+        return TRAIN ? tile_row(a.ws_xh, (int64_t)hidden_idx * a.S_pad + sample(n), D, half) : nullptr;
+    };
+    constexpr int NU = kTiles * NP;   // epilogue units of one half-output pass
+    constexpr int TAIL = TRAIN ? stash_tail<DT, HT>() : 0;   // stores a stashing D-wide pass leaves in flight for the part after it
+
+    // ---- hidden 1: 63 -> D, input = posenc.  Pass A, then pass B with A's epilogue hidden under it. ----
+    init_acc(accA, L::bias_off(0));
+    // (training: the 36 stash stores of the encodings above are younger than every piece of the first two panels)
+    gemm_wide<2, HT, TRAIN ? kTiles * 18 : 0>(accA, eq, pipe, p0(F_L1A));
+    init_acc(accB, L::bias_off(0) + L::Dh);
+    clear_mask(mwA);
+    gemm_wide<2, HT, false, NU, NU / 4, 0, 0>(accB, eq, pipe, p0(F_L1B), no_stash, NNR_RELU_UNIT(accA, 0, mwA));
+    store_mask(mwA, 0, 0);
+    NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 2);
+    // Invariant from here on: hq[.][0, NP) holds half A of the newest layer, accB holds its half B still to be finished.
+
+    // one D -> D ReLU layer (state_dict index `li`), packed at panel pa; its input goes to the stash planes st[]
+    auto dense_layer = [&](int li, int pa, __bf16* const (&st)[kTiles]) __attribute__((always_inline)) {
+        init_acc(accA, L::bias_off(li));
+        clear_mask(mwB);
+        // pass A: rows [0, G/2) only read hq[.][0, NP); the previous layer's half B is finished meanwhile, unit u at row u / 5 --
+        // packed register NP + (u >> 1) is first read at row G/2 + (u >> 1) / 4, always a later row
+        gemm_wide<DT, HT, TRAIN, NU, 5, 0, 0>(accA, hq, pipe, pa, st, NNR_RELU_UNIT(accB, NP, mwB));
+        store_mask(mwB, li - 1, 1);
+        init_acc(accB, L::bias_off(li) + L::Dh);
+        clear_mask(mwA);
+        // pass B: half A of the new layer replaces hq[.][0, NP) in place behind the reads -- unit u runs at row u / 4 + 1, its
+        // register (u >> 1) was last read at row (u >> 1) / 4
+        gemm_wide<DT, HT, false, NU, 4, 1, TAIL>(accB, hq, pipe, pa + PP, no_stash, NNR_RELU_UNIT(accA, 0, mwA));
+        store_mask(mwA, li, 0);
+    };
+    // hidden 2..4
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+        __bf16* const st[kTiles] = {xh(l, 0), xh(l, 1)};
+        dense_layer(1 + l, p0(F_L2A) + 2 * PP * l, st);
+    }
+    NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 3);
+    // hidden 5: [h4 ; e] -> D   (skip connection, input order [h, posenc]: model/official_nerf.py:63)
+    {
+        __bf16* const st[kTiles] = {xh(3, 0), xh(3, 1)};
+        init_acc(accA, L::bias_off(4));
+        clear_mask(mwB);
+        gemm_wide<DT, HT, TRAIN, NU, 5, 0, 0>(accA, hq, pipe, p0(F_L5HA), st, NNR_RELU_UNIT(accB, NP, mwB));
+        store_mask(mwB, 3, 1);
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4 v = __builtin_bit_cast(u32x4, park[(6 * n + q) * 64]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) eq[n][4 * q + i] = v[i];
+            }
+        gemm_wide<2, HT, TAIL>(accA, eq, pipe, p0(F_L5EA));
+        init_acc(accB, L::bias_off(4) + L::Dh);
+        clear_mask(mwA);
+        gemm_wide<DT, HT, false, NU, 4, 1, 0>(accB, hq, pipe, p0(F_L5HB), no_stash, NNR_RELU_UNIT(accA, 0, mwA));
+        gemm_wide<2, HT>(accB, eq, pipe, p0(F_L5EB));
+        store_mask(mwA, 4, 0);
+    }
+    NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 4);
+    // hidden 6..8
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+        __bf16* const st[kTiles] = {xh(4 + l, 0), xh(4 + l, 1)};
+        dense_layer(5 + l, p0(F_L6A) + 2 * PP * l, st);
+    }
+    NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 5);
+
+    // colour hidden: g = relu(W' h8 + Wg[:, D:] gamma_4(v) + b'), the feature layer folded in by the pack kernel (nnr_layout.h); one
+    // pass (D/2 outputs).  Its side work first finishes hidden 8 (half B), then evaluates the density head: a per-lane dot product
+    // of the packed h8 with the packed density row, four registers per unit.
+    float sg[kTiles][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    {
+        __bf16* const st[kTiles] = {xh(7, 0), xh(7, 1)};
+        init_acc(accA, L::bias_off(10));
+        clear_mask(mwB);
+        auto finish_then_sigma = [&](int u) __attribute__((always_inline)) {
+            if (u < NU) {
+                NNR_RELU_UNIT(accB, NP, mwB)(u);
+            } else {   // registers 4v .. 4v+3 of h8, both tiles; every register is final by now: the NU finishing units come first
+                const int v = u - NU;
+                const u32x4 w4 = *reinterpret_cast<const u32x4*>(wsig16 + 4 * v);
+#pragma unroll
+                for (int n = 0; n < kTiles; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dot2_bf16(sg[n][i & 1], hq[n][4 * v + i], w4[i]);
+            }
+        };
+        // 5 units per row: finishing unit u (register NP + (u >> 1), first read at row G/2 + (u >> 1) / 4) runs at row u / 5
+        gemm_wide<DT, HT, TRAIN, NU + NQ / 4, 5, 0, 0>(accA, hq, pipe, p0(F_RGBH_F), st, finish_then_sigma);
+        store_mask(mwB, 7, 1);
+    }
+    NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 6);
+    {
+        uint32_t dq[kTiles][8];
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u32x4 v = __builtin_bit_cast(u32x4, park[(6 * n + 4 + q) * 64]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dq[n][4 * q + i] = v[i];
+            }
+        gemm_wide<1, HT, TAIL>(accA, dq, pipe, p0(F_RGBH_D));
+    }
+    clear_mask(mwA);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) NNR_RELU_UNIT(accA, 0, mwA)(u);   // g = hq[.][0, NP)
+    store_mask(mwA, 8, 0);
+#pragma unroll
+    for (int n = 0; n < kTiles; ++n) {
+        const int64_t sn = sample(n);
+        if constexpr (TRAIN) {   // tile-major bf16 plane: group gq = packed registers 4 gq .. 4 gq + 3
+            __bf16* xg = tile_row(a.ws_xg, sn, D / 2, half);
+#pragma unroll
+            for (int gq = 0; gq < NP / 4; ++gq)
+                stash_store(xg + kBlockBf16 * gq, u32x4{hq[n][4 * gq], hq[n][4 * gq + 1], hq[n][4 * gq + 2], hq[n][4 * gq + 3]});
+        }
+        const float sgn = dot2_result(sg[n][0]) + dot2_result(sg[n][1]);
+        const float sigma_raw = sgn + __shfl_xor(sgn, 32, 64) + bias[L::bias_off(8)];
+        // rgb head: 3 per-lane dot products over the lane's half of g, halves combined by one shuffle, then sigmoid
+        float rgbv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t* wc = head16 + 2 * NQ + (2 * c + half) * NP;
+            float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < NP / 4; ++q) {
+                const u32x4 w4 = *reinterpret_cast<const u32x4*>(wc + 4 * q);
+                dot2_bf16(acc0, hq[n][4 * q], w4[0]);
+                dot2_bf16(acc1, hq[n][4 * q + 1], w4[1]);
+                dot2_bf16(acc0, hq[n][4 * q + 2], w4[2]);
+                dot2_bf16(acc1, hq[n][4 * q + 3], w4[3]);
+            }
+            const float part = dot2_result(acc0) + dot2_result(acc1);
+            rgbv[c] = part + __shfl_xor(part, 32, 64);
+        }
+        if (half == 0 && sn < a.S) {
+            const float* b = bias + L::bias_off(11);
+            f32x4 o;
+            o[0] = sigmoid_ref(rgbv[0] + b[0]);
+            o[1] = sigmoid_ref(rgbv[1] + b[1]);
+            o[2] = sigmoid_ref(rgbv[2] + b[2]);
+            o[3] = sigma_raw;
+            *reinterpret_cast<f32x4*>(a.ws_out4 + 4 * sn) = o;
+        }
+    }
+    NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 7);
+#undef NNR_RELU_UNIT
+    pipe.next_pass(pass + 2 < n_pass);
+    }   // pass
+}
+
+#ifdef NNR_TIMELINE
+extern "C" int nnr_timeline_fwd16(unsigned long long* host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_fwd16), 32 * sizeof(unsigned long long));
+}
+#endif
+
+template <int D>
+static hipError_t launch(const MlpFwdArgs& a, bool train, hipStream_t st) {
+    // ray mode: one workgroup per 4 rays, chunks_per_ray passes of 64 samples each; flat: one workgroup per 256 samples
+    const int64_t per_block = (int64_t)kWideSamples * (a.chunks_per_ray > 0 ? a.chunks_per_ray : 1);
+    dim3 grid((unsigned)((a.S_pad + per_block - 1) / per_block)), block(256);
+    if (train) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<D, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<D, false>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_fwd_bf16(int D, const MlpFwdArgs& a, bool train, hipStream_t st) {
+    return D == 256 ? launch<256>(a, train, st) : launch<128>(a, train, st);
+}
+
+}  // namespace nnr

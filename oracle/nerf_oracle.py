@@ -192,6 +192,24 @@ class _Bf16Matmul(torch.autograd.Function):
         return gr @ wr, gr.t() @ xr
 
 
+class _Bf16Head(torch.autograd.Function):
+    """The two narrow heads (1-row density, 3-row rgb) of the bf16 mode: the value is the bf16 x bf16 product with fp32 accumulation
+    like every other layer (the forward kernel holds the activations only as bf16 and evaluates the heads as per-lane bf16 dot
+    products); the INPUT gradient is g W in fp32 (3 / 1 FMAs per value on the VALU in the input-gradient kernel, from the unrounded
+    gradient and weights); the weight gradient comes from the rounded operands like every other layer's."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xr, wr = bf16_round(x), bf16_round(w)
+        ctx.save_for_backward(xr, w)
+        return xr @ wr.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        xr, w = ctx.saved_tensors
+        return g @ w, bf16_round(g).t() @ xr
+
+
 class _RoundGrad(torch.autograd.Function):
     """Identity whose gradient is rounded to bf16: the bias gradients of the bf16 mode are sums of the ROUNDED pre-activation
     gradients (the weight-gradient kernel reads them from the bf16 planes)."""
@@ -208,10 +226,9 @@ class _RoundGrad(torch.autograd.Function):
 def mlp_bf16(params: Dict[str, torch.Tensor], pts: torch.Tensor, viewdir: torch.Tensor, *, dist_alpha: bool,
              occ_activation: str = "softplus", pos_levels: int = 10, dir_levels: int = 4):
     """The MLP of `mlp` with every MFMA-shaped contraction in bf16 x bf16 -> fp32 (rendering.mfma_dtype: bf16), restating what
-    the bf16 kernels compute (nnr_mlp_fwd.hip / nnr_mlp_dgrad.hip / nnr_wgrad_bf16.hip): all hidden layers incl. the two encoding
+    the bf16 kernels compute (nnr_mlp_fwd_bf16.hip / nnr_mlp_dgrad_bf16.hip / nnr_wgrad_bf16.hip): all hidden layers incl. the two encoding
     inputs; the feature layer folded into the colour-hidden layer (W' = Wg[:, :D] Wf and b' = Wg[:, :D] bf + bg formed in fp32,
-    then W' rounded); the 1-row density head and the 3-row rgb head in fp32 on the forward / input-gradient side, their WEIGHT
-    gradients from rounded operands like every other layer.  The reference for the tight parity test of the bf16 mode; the fp32
+    then W' rounded); the 1-row density head and the 3-row rgb head as bf16 products too, their input gradients in fp32 (_Bf16Head).  The reference for the tight parity test of the bf16 mode; the fp32
     `mlp` stays the reference for how far bf16 arithmetic is from the reference's fp32."""
     W = lambda n: params[n + ".weight"]
     B = lambda n: params[n + ".bias"]
@@ -219,10 +236,8 @@ def mlp_bf16(params: Dict[str, torch.Tensor], pts: torch.Tensor, viewdir: torch.
     def lin16(n, v):       # hidden layer: rounded product + fp32 bias; bias gradient = sum of the rounded gradient
         return _RoundGrad.apply(_Bf16Matmul.apply(v, W(n))) + B(n)
 
-    def head(n, v):        # forward / input gradient in fp32, weight gradient from rounded operands
-        y_fwd = F.linear(v, W(n).detach(), None)                          # carries d/dv in fp32
-        y_w = _Bf16Matmul.apply(v.detach(), W(n))                          # carries d/dW from bf16(g), bf16(v)
-        return y_fwd + (y_w - y_w.detach()) + _RoundGrad.apply(B(n).expand(v.shape[0], -1))
+    def head(n, v):        # bf16 product; input gradient in fp32, weight gradient from rounded operands (_Bf16Head)
+        return _Bf16Head.apply(v, W(n)) + _RoundGrad.apply(B(n).expand(v.shape[0], -1))
 
     e = posenc(pts, pos_levels)
     h = e

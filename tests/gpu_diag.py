@@ -98,6 +98,14 @@ def run(D, R, N, dist_alpha, white_bg, seed=0):
     report("direnc stash", plane(19)[:, :27], t["dir"])   # the feature vector is never formed (merged into the colour layer)
     report("colour hidden", plane(20), t["g"])
     report("rgb (per sample)", out4[:, :3], t["rgb"])
+    if os.environ.get("NNR_DIAG_RGB"):
+        e = (out4[:, :3].detach().cpu() - t["rgb"].detach()).abs()
+        idx = torch.arange(S)
+        print("    per channel max", e.max(0).values.tolist())
+        print("    tile 0 / tile 1 max", float(e[(idx // 32) % 2 == 0].max()), float(e[(idx // 32) % 2 == 1].max()))
+        print("    per sample-in-chunk max (first 8 cols)", e.view(-1, 32, 3).amax((0, 2))[:8].tolist())
+        pre_ref = torch.logit(t["rgb"].detach().double()); pre_got = torch.logit(out4[:, :3].detach().cpu().double())
+        print("    pre-activation diff max", float((pre_got - pre_ref).abs().max()), "ref max", float(pre_ref.abs().max()))
     report("alpha", alpha, t["alpha"])
     report("RGB (composited)", rgb, orgb)
     report("dist (composited)", dist, odist)

@@ -25,7 +25,7 @@ if __name__ == "__main__":
     out = bench.kernel_roofline(net, dev, reps=2, bf16=bf16, rays=R, n_samples=N)
     print(json.dumps(out["kernels"]))
     handle = ctypes.CDLL(nnrlib.LIB_PATH)
-    for name in ("nnr_timeline_fwd", "nnr_timeline_dgrad", "nnr_timeline_wgrad"):
+    for name in ("nnr_timeline_fwd", "nnr_timeline_dgrad", "nnr_timeline_fwd16", "nnr_timeline_dgrad16", "nnr_timeline_wgrad"):
         if not hasattr(handle, name):
             continue
         buf = (ctypes.c_ulonglong * 32)()
