@@ -117,10 +117,10 @@ def build_trainer(device, world, aux=False, bf16=False, rays_per_gpu=None, n_sam
     return trainer, net
 
 
-_TRAFFIC_FILES = ('profiles/r02/hbm_traffic.json', 'profiles/r01/hbm_traffic.json')
+_TRAFFIC_FILES = ('profiles/r02/hbm_traffic.json', 'profiles/r02/hbm_traffic_bf16_4096x128.json')
 _KERNEL_KEYS = {
-    False: {'mlp_fwd': 'mlp_fwd_kernel<256, true, false>', 'mlp_dgrad': 'mlp_dgrad_kernel<256, false>', 'mlp_wgrad': 'wgrad_kernel<false>'},
-    True: {'mlp_fwd': 'mlp_fwd_kernel<256, true, true>', 'mlp_dgrad': 'mlp_dgrad_kernel<256, true>', 'mlp_wgrad': 'wgrad'},
+    False: {'mlp_fwd': 'mlp_fwd_kernel<256, true>', 'mlp_dgrad': 'mlp_dgrad_kernel<256>', 'mlp_wgrad': 'nnr::wgrad_kernel('},
+    True: {'mlp_fwd': 'mlp_fwd_bf16_kernel<256, true>', 'mlp_dgrad': 'mlp_dgrad_bf16_kernel<256>', 'mlp_wgrad': 'wgrad_b_kernel'},
 }
 
 

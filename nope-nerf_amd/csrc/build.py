@@ -11,9 +11,33 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(os.path.dirname(HERE), "nnr", "libnnr.so")
 SOURCES = ["nnr_api.cpp", "nnr_pack.hip", "nnr_mlp_fwd.hip", "nnr_mlp_dgrad.hip", "nnr_mlp_fwd_bf16.hip", "nnr_mlp_dgrad_bf16.hip", "nnr_wgrad.hip", "nnr_wgrad_bf16.hip", "nnr_composite.hip", "nnr_camera.hip", "nnr_pointcloud.hip", "nnr_aux.hip", "nnr_randperm.hip"]
-HEADERS = ["nnr_layout.h", "nnr_device.h", "nnr_kernels.h", os.path.join("..", "..", "include", "nnr.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-I" + HERE,
-         "-I" + os.path.join(HERE, "..", "..", "include"), "-x", "hip"]
+HEADERS = ["nnr_layout.h", "nnr_device.h", "nnr_kernels.h", "nnr_mlp_bf16.h", os.path.join("..", "..", "include", "nnr.h")]
+# -pragma-unroll-threshold: the MLP kernels are straight-line code by construction (every `#pragma unroll` loop must unroll fully, or
+# the register arrays they index fall back to scratch memory).  LLVM caps `#pragma unroll` at 16 K instructions per loop; one GEMM part
+# of the fp32 input-gradient kernel sat right at that cap, and an unrelated clean-up pushed it over: the kernel compiled without a
+# warning, kept passing every parity test and ran 8x slower (832 bytes of scratch per lane).  Hence the raised cap AND the check below.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-mllvm", "-pragma-unroll-threshold=1048576",
+         "-Rpass-analysis=kernel-resource-usage", "-I" + HERE, "-I" + os.path.join(HERE, "..", "..", "include"), "-x", "hip"]
+# scratch bytes per lane a hot kernel may use (spills of lane-constant addresses outside the MFMA streams in the bf16 training kernels)
+SCRATCH_LIMIT = {"mlp_fwd_kernel": 0, "mlp_dgrad_kernel": 0, "wgrad_kernel": 0, "wgrad_b_kernel": 0, "mlp_fwd_bf16_kernel": 256,
+                 "mlp_dgrad_bf16_kernel": 160, "composite_fwd_kernel": 0, "composite_bwd_kernel": 0}
+
+
+def check_resources(remarks, what):
+    """Parse hipcc's kernel-resource-usage remarks and fail the build when a hot kernel went to scratch memory."""
+    import re
+    name, bad = None, []
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name:
+            for key, limit in SCRATCH_LIMIT.items():
+                if ("3nnr%d%sI" % (len(key), key) in name or "3nnr%d%sE" % (len(key), key) in name) and int(m.group(1)) > limit:
+                    bad.append("%s: %s bytes of scratch per lane (limit %d)" % (name, m.group(1), limit))
+    if bad:
+        raise RuntimeError("%s: a hot kernel uses scratch memory -- a loop did not unroll or registers spilled:\n  " % what + "\n  ".join(bad))
 
 
 def _stale(target, deps):
@@ -33,6 +57,8 @@ def build_variant(name, defines):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr)
+    if not any(d.startswith("NNR_ABLATE") or d == "NNR_TIMELINE" for d in defines):
+        check_resources(r.stderr, name)
     return out
 
 
@@ -50,8 +76,16 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
-        if verbose and r.stderr:
-            print(r.stderr, file=sys.stderr)
+        try:
+            check_resources(r.stderr, cmd[-3] if len(cmd) > 3 else "link")
+        except RuntimeError:
+            if os.path.exists(cmd[-1]) and cmd[-1].endswith(".o"):
+                os.remove(cmd[-1])       # so that the next build compiles (and checks) this file again
+            raise
+        if verbose:
+            other = "\n".join(l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l and l.strip())
+            if other:
+                print(other, file=sys.stderr)
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))

@@ -11,10 +11,19 @@
 namespace nnr {
 
 NNR_TL_DECL(tl_fwd16)
+#ifdef NNR_TIMELINE
+__device__ unsigned long long tl_fwd16_all[3 * 4096];   // per workgroup: start, end (s_memtime), HW_ID
+#endif
 
 template <int D, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 0);
+#ifdef NNR_TIMELINE
+    if (TRAIN && threadIdx.x == 0 && blockIdx.x < 4096) {
+        tl_fwd16_all[3 * blockIdx.x] = __builtin_amdgcn_s_memtime();
+        tl_fwd16_all[3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+    }
+#endif
     using L = Layout<D, true>;
     constexpr int DT = L::DT, HT = L::HT;
     constexpr int HR = 16 * HT;              // fragment registers of half a layer's outputs (fp32 numbering)
@@ -154,10 +163,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         if (TRAIN) {
 #pragma unroll
             for (int n = 0; n < kTiles; ++n) {
-                // masks: [chunk][layer][lane][mask_words]; half A of a layer owns the low words, half B the high words
+                // masks: [chunk][layer][lane][mask_words]; half A of a layer owns the low words, half B the high words.  An ordinary
+                // store: the two halves of a lane's 16 bytes arrive from different passes and rely on L2 to merge them into lines.
                 uint32_t* m = a.ws_mask + (((int64_t)opaque(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane) * L::mask_words + hb * HW;
+                if constexpr (HW == 2) {
+                    *reinterpret_cast<u32x2*>(m) = u32x2{~__builtin_bitreverse32(mw[n][0]), ~__builtin_bitreverse32(mw[n][1])};
+                } else {
 #pragma unroll
-                for (int w = 0; w < HW; ++w) stash_store(m + w, ~__builtin_bitreverse32(mw[n][w]));
+                    for (int w = 0; w < HW; ++w) m[w] = ~__builtin_bitreverse32(mw[n][w]);
+                }
             }
         }
     };
@@ -329,9 +343,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
 #undef NNR_RELU_UNIT
     pipe.next_pass(pass + 2 < n_pass);
     }   // pass
+#ifdef NNR_TIMELINE
+    if (TRAIN && threadIdx.x == 0 && blockIdx.x < 4096) tl_fwd16_all[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 #ifdef NNR_TIMELINE
+extern "C" int nnr_timeline_fwd16_all(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tl_fwd16_all), 3 * 4096 * sizeof(unsigned long long));
+}
 extern "C" int nnr_timeline_fwd16(unsigned long long* host32) {
     return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_fwd16), 32 * sizeof(unsigned long long));
 }

@@ -278,7 +278,7 @@ def test_committed_bench_line_follows_the_contract():
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = json.loads(open(os.path.join(root, "profiles", "r01", "h_round_end_bench.json.txt")).read())
+    line = json.loads(open(os.path.join(root, "profiles", "r02", "z_round_end_bench.json.txt")).read())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
@@ -335,3 +335,21 @@ def test_checkpoint_roundtrip_with_numpy_scalar(tmp_path):
         assert torch.equal(v, before[k]), k
     with pytest.raises(FileExistsError):       # sic: the exception type train.py:64-67 catches for "no checkpoint yet"
         io.load("missing.pt")
+
+
+def test_build_rejects_hot_kernels_that_use_scratch_memory():
+    """csrc/build.py parses hipcc's resource report: an MLP kernel whose register arrays fell back to scratch memory (a loop that did
+    not unroll) fails the build instead of shipping 8x slower with every parity test green."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("nnr_build", os.path.join(root, "nope-nerf_amd", "csrc", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    rep = ("x.hip:1:1: remark: Function Name: _ZN3nnr16mlp_dgrad_kernelILi256EEEvNS_12MlpDgradArgsE [-Rpass-analysis=kernel-resource-usage]\n"
+           "x.hip:1:1: remark:     ScratchSize [bytes/lane]: %d [-Rpass-analysis=kernel-resource-usage]\n")
+    b.check_resources(rep % 0, "ok")
+    with pytest.raises(RuntimeError, match="scratch"):
+        b.check_resources(rep % 832, "bad")
+    b.check_resources((rep % 96).replace("16mlp_dgrad_kernel", "21mlp_dgrad_bf16_kernel"), "bf16: spills of addresses are tolerated")
+    assert "-pragma-unroll-threshold=1048576" in b.FLAGS

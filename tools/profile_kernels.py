@@ -1,5 +1,5 @@
-"""Run only the fused-MLP kernels of one BASELINE configs[1] step (1024 rays x 192 samples, D=256) a few times --
-the command rocprofv3 wraps for --kernel-trace/--stats and for the --pmc counter passes."""
+"""Run only the fused-MLP kernels of one step a few times -- the command rocprofv3 wraps for --kernel-trace/--stats and for the
+--pmc counter passes.   python tools/profile_kernels.py [reps [R N [bf16]]]   (default: BASELINE configs[1], 1024 x 192, fp32)"""
 import json
 import os
 import sys
@@ -18,4 +18,6 @@ if __name__ == "__main__":
     torch.manual_seed(42)
     net = mdl.OfficialStaticNerf(cfg).to(dev)
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    print(json.dumps(bench.kernel_roofline(net, dev, reps=reps)))
+    R, N = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (bench.R_PER_GPU, bench.N_SAMPLES)
+    bf16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"
+    print(json.dumps(bench.kernel_roofline(net, dev, reps=reps, bf16=bf16, rays=R, n_samples=N)))

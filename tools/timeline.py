@@ -67,3 +67,22 @@ if __name__ == "__main__":
             bytype[key].append(dur[wv] / max(cost, 1))
         for k, x in sorted(bytype.items()):
             print("class B/A wave types", k, "n", len(x), "cycles per cost-granule min/mean/max %.1f %.1f %.1f" % (min(x), sum(x) / len(x), max(x)))
+    if hasattr(handle, "nnr_timeline_fwd16_all") and bf16:
+        import numpy as np
+        buf = (ctypes.c_ulonglong * (3 * 4096))()
+        handle.nnr_timeline_fwd16_all(buf)
+        v = np.array(buf, dtype=np.int64).reshape(-1, 3)
+        v = v[v[:, 0] > 0]
+        t0 = v[:, 0].min()
+        dur = v[:, 1] - v[:, 0]
+        print("fwd16 workgroups", len(v), "kernel span", int(v[:, 1].max() - t0), "dur min/mean/max", int(dur.min()), int(dur.mean()), int(dur.max()))
+        hw = v[:, 2]
+        cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7
+        key = se * 64 + sh * 16 + cu
+        starts = np.sort(v[:, 0] - t0)
+        print("start times of the first/last 8 workgroups", starts[:8].tolist(), starts[-8:].tolist())
+        ends = np.sort(v[:, 1] - t0)
+        print("end time percentiles 10/50/90/100", [int(np.percentile(ends, q)) for q in (10, 50, 90, 100)])
+        # gaps between consecutive workgroups on the same (se, sh, cu) -- XCDs share ids, so this mixes 8 of them; still shows the idle time
+        order = np.argsort(v[:, 0])
+        print("durations of the first 4 and last 4 started", dur[order[:4]].tolist(), dur[order[-4:]].tolist())
