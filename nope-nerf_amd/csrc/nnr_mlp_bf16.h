@@ -19,6 +19,10 @@
 namespace nnr {
 
 constexpr int kTiles = 2;   // 32-sample chunks per wave in the bf16 kernels
+#ifndef NNR_DMA_BURST
+#define NNR_DMA_BURST 4
+#endif
+constexpr int kDmaBurst = NNR_DMA_BURST;   // DMA pieces (1 KiB each) a wave issues per row until the 8 of a panel are out
 constexpr int kWideSamples = kTiles * kChunk * kWavesPerBlock;   // samples per workgroup
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -84,6 +88,39 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t p) {
     return r;
 }
 
+// ---- weight fragments: LDS reads the compiler does not see ------------------------------------------------------------------
+// hipcc waits lgkmcnt(0) before the first MFMA that uses a fragment it loaded itself -- i.e. for EVERY outstanding LDS read, also the
+// refill issued one instruction earlier: a full LDS latency per row with the matrix pipe idle (a third of the layer loop).  LDS reads
+// return in order, so the right wait is "all but the MT - 1 younger refills".  As in the weight-gradient kernel the reads are inline
+// asm (invisible to the compiler's counter model) and the counted waits are placed by hand; the compiler's own LDS / scalar loads only
+// make them more conservative.
+__device__ __forceinline__ f32x4 frag_read(unsigned addr, int slot) {   // 16 bytes per lane at LDS byte address addr + 1 KiB * slot
+    f32x4 v;
+#define NNR_FR(k) case k: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(1024 * (k))); break;
+#define NNR_FR8(a) NNR_FR(a) NNR_FR(a + 1) NNR_FR(a + 2) NNR_FR(a + 3) NNR_FR(a + 4) NNR_FR(a + 5) NNR_FR(a + 6) NNR_FR(a + 7)
+    switch (slot) {   // the offset is an instruction immediate; `slot` is a constant after unrolling
+        NNR_FR8(0) NNR_FR8(8) NNR_FR8(16)
+        NNR_FR(24) NNR_FR(25) NNR_FR(26) NNR_FR(27) NNR_FR(28) NNR_FR(29) NNR_FR(30)
+        default: asm volatile("ds_read_b128 %0, %1 offset:31744" : "=v"(v) : "v"(addr)); break;
+    }
+#undef NNR_FR8
+#undef NNR_FR
+    return v;
+}
+// Wait until at most n LDS reads are outstanding; the fragment is an in/out operand so that the MFMA that consumes it cannot be
+// scheduled above the wait (the MFMA builtin has no other tie to it).
+__device__ __forceinline__ void wait_frag(f32x4& frag, int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(frag)); break;
+        case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(frag)); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(frag)); break;
+        default: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(frag)); break;
+    }
+}
+__device__ __forceinline__ unsigned lds_byte_address(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 template <int MT, int NACC>
 __device__ __forceinline__ void pin_acc2(f32x16 (&acc)[kTiles][NACC]) {   // see pin_acc
     static_assert(kTiles == 2, "written for two tiles");
@@ -128,20 +165,26 @@ __device__ __forceinline__ void gemm_wide(f32x16 (&acc)[kTiles][NACC], const uin
     constexpr int kGapDma = NM / 2;
     auto rows_in = [](int pi) { return (G - pi * GP) < GP ? (G - pi * GP) : GP; };
     auto gap_stash = [](int n) { return n * (NM / kTiles); };   // the even gaps are free of fragment reads
+    // DMA pieces of the panel two ahead, issued per row of the current panel: kDmaBurst at a time right after the switch, so that the
+    // last piece has almost two panels (~2 x 2048 matrix-pipe cycles) to land -- one piece per row left the last one barely one
+    // panel, less than the L2 -> LDS latency under load: a quarter of the wave cycles sat in the panel switch's s_waitcnt
+    auto ppk_of = [&](int pi) { return (8 + rows_in(pi) - 1) / rows_in(pi) > kDmaBurst ? (8 + rows_in(pi) - 1) / rows_in(pi) : kDmaBurst; };
     pipe.template enter<PRE>(p0);
-    pipe.pieces(p0 + 2, 0, (8 + rows_in(0) - 1) / rows_in(0));
+    pipe.pieces(p0 + 2, 0, ppk_of(0));
     Frags<MT> cur;
-    {
-        const f32x4* buf = pipe.lds + pipe.buffer(p0) * kPanelF4 + pipe.lane;
+    const unsigned lane_base = lds_byte_address(pipe.lds) + 16u * pipe.lane;
+    unsigned panel_addr = lane_base + pipe.buffer(p0) * (kPanelF4 * 16);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) cur.v[mt] = buf[mt * 64];
-    }
+    for (int mt = 0; mt < MT; ++mt) cur.v[mt] = frag_read(panel_addr, mt);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
         for (int j = 0; j < NM; ++j) {
             const int mt = j / kTiles, n = j % kTiles;
             __builtin_amdgcn_sched_barrier(0);
+            // fragment mt has landed when at most the reads issued after it are outstanding: the MT - 1 other refills -- fewer in
+            // the last row, which issues none
+            if (n == 0) wait_frag(cur.v[mt], g + 1 < G ? MT - 1 : MT - 1 - mt);
             acc[n][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.v[mt]), row_operand(in[n], g), acc[n][mt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             // Fragment mt is refilled IN PLACE for the next row right after its last MFMA of this row (no second fragment set: 16
@@ -149,10 +192,12 @@ __device__ __forceinline__ void gemm_wide(f32x16 (&acc)[kTiles][NACC], const uin
             // (counted wait + barrier) sits in front of the first read from the new panel.
             if (n == kTiles - 1 && g + 1 < G) {
                 const int pn = p0 + (g + 1) / GP;
-                // the stash stores of this panel's earlier rows are younger than the pieces waited for
-                if (mt == 0 && (g + 1) % GP == 0) pipe.template enter<STASH ? kTiles * (GP - 1) : 0>(pn);
-                const f32x4* buf = pipe.lds + pipe.buffer(pn) * kPanelF4 + pipe.lane;
-                cur.v[mt] = buf[(((g + 1) % GP) * MT + mt) * 64];
+                if (mt == 0 && (g + 1) % GP == 0) {
+                    // the stash stores of this panel's earlier rows are younger than the pieces waited for
+                    pipe.template enter<STASH ? kTiles * (GP - 1) : 0>(pn);
+                    panel_addr = lane_base + pipe.buffer(pn) * (kPanelF4 * 16);
+                }
+                cur.v[mt] = frag_read(panel_addr, ((g + 1) % GP) * MT + mt);
             }
             if constexpr (STASH) {
 #pragma unroll
@@ -163,9 +208,9 @@ __device__ __forceinline__ void gemm_wide(f32x16 (&acc)[kTiles][NACC], const uin
                 const int pi = g / GP, gi = g % GP;
                 const int n_in = rows_in(pi);
                 if (gi == n_in - 1) {
-                    if (g + 1 < G) pipe.pieces(p0 + pi + 3, 0, (8 + rows_in(pi + 1) - 1) / rows_in(pi + 1));
+                    if (g + 1 < G) pipe.pieces(p0 + pi + 3, 0, ppk_of(pi + 1));
                 } else {
-                    const int ppk = (8 + n_in - 1) / n_in;
+                    const int ppk = ppk_of(pi);
                     pipe.pieces(p0 + pi + 2, (gi + 1) * ppk, ppk);
                 }
             }

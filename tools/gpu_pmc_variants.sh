@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in product "$@"; do
   if [ "$v" != product ]; then export NNR_LIB=$R/nope-nerf_amd/nnr/libnnr_$v.so; else unset NNR_LIB; fi
   P=/tmp/pmcv_$v; mkdir -p $P
-  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM_WR -d $P -o pmc -- python $R/tools/profile_kernels.py 2 > $R/gpurun_out/pmcv/$v.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM_WR -d $P -o pmc -- python $R/tools/profile_kernels.py 2 $PROFILE_SHAPE > $R/gpurun_out/pmcv/$v.log 2>&1
   f=$(find $P -name "*counter_collection.csv" | head -1)
   python - "$f" "$v" <<'PY' | tee $R/gpurun_out/pmcv/$v.txt
 import csv,sys,collections
