@@ -146,8 +146,12 @@ def _hbm_traffic(kernel, bf16=False, shape=None):
     return None, None
 
 
-def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None):
-    """Time the three fused-MLP kernels of one step individually with HIP events on the launch stream.
+def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, in_step=None):
+    """Roofline block of the three fused-MLP kernels.  `in_step` = their mean durations INSIDE the timed training steps (HIP events
+    on the launch stream around every launch, nnr_prof_begin / nnr_prof_end: _timed_steps): the basis of `achieved` when given.
+    Each kernel is also timed in isolation (`reps` back-to-back launches between two events; reported as `isolated_ms`): that
+    figure is systematically slower for the kernels that write the stash -- five forwards in a row push 10 GB to HBM and the chip
+    clocks down, which the same kernel between the step's other kernels does not see.
     bf16=True: the bf16-product kernels, whose bound is HBM, not the matrix pipe."""
     from nnr import lib as L
     from nnr import ops
@@ -198,9 +202,14 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None):
         e1.record()
         torch.cuda.synchronize()
         times[name] = e0.elapsed_time(e1) / reps   # ms per launch
+    isolated = dict(times)
+    if in_step:
+        times.update({k: in_step[k] for k in ('mlp_fwd', 'mlp_dgrad', 'mlp_wgrad')})
+    how = ('HIP events on the launch stream around every launch of the kernel inside the %d timed training steps' % in_step['launches']
+           if in_step else 'HIP events around %d back-to-back launches of the kernel alone' % reps)
     flops = 2 * MACS_PER_SAMPLE[D] * R * N
-    per = {k: {'ms': round(v, 4), 'tflops': round(flops / (v * 1e-3) / 1e12, 2) if k.startswith('mlp_') else None}
-           for k, v in times.items()}
+    per = {k: {'ms': round(v, 4), 'tflops': round(flops / (v * 1e-3) / 1e12, 2) if k.startswith('mlp_') else None,
+               'isolated_ms': round(isolated[k], 4)} for k, v in times.items()}
     dom = max(('mlp_fwd', 'mlp_dgrad', 'mlp_wgrad'), key=lambda k: times[k])
     achieved = flops / (times[dom] * 1e-3) / 1e12
     mlp_ms = times['mlp_fwd'] + times['mlp_dgrad'] + times['mlp_wgrad']
@@ -220,13 +229,13 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None):
         three['gbytes_per_s'] = round(sum(byts.values()) * R * N / (mlp_ms * 1e-3) / 1e9, 1)
         three['frac_of_hbm_peak'] = round(three['gbytes_per_s'] / PEAK_HBM_GBS, 4)
         return {'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs[dom], 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                'frac': round(gbs[dom] / PEAK_HBM_GBS, 4), 'traffic': traffic, 'traffic_source': src,
+                'frac': round(gbs[dom] / PEAK_HBM_GBS, 4), 'traffic': traffic, 'traffic_source': src, 'timing': how,
                 'bytes_per_launch': byts[dom] * R * N, 'kernels': per, 'fused_mlp_all_three': three}
     traffic, src = _hbm_traffic(dom, False, (R, N))
     three['frac'] = round(three['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4)
     return {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': src,
+        'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': src, 'timing': how,
         'flop_per_launch': flops, 'kernels': per, 'fused_mlp_all_three': three,
     }
 
@@ -335,6 +344,9 @@ def _timed_steps(trainer, data, warmup, steps, world):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    from nnr import lib as L
+    lib = L.load()
+    L.check(lib.nnr_prof_begin(steps), 'nnr_prof_begin')      # two event records per MLP kernel launch: microseconds of host time per step
     t0 = time.perf_counter()
     for i in range(steps):
         ld = step(warmup + i)
@@ -343,26 +355,30 @@ def _timed_steps(trainer, data, warmup, steps, world):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ms4, n4 = (C.c_float * 4)(), (C.c_int32 * 4)()
+    L.check(lib.nnr_prof_end(ms4, n4), 'nnr_prof_end')
+    in_step = {'mlp_fwd': float(ms4[0]), 'mlp_dgrad': float(ms4[1]), 'mlp_wgrad': float(ms4[2]), 'launches': int(n4[0])}
     if world > 1:
         t = torch.tensor([elapsed], device=data['img'].device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     trainer.flush_nan_check()
-    return elapsed, float(ld['loss'].detach())
+    return elapsed, float(ld['loss'].detach()), in_step
 
 
 def extra_config(device, name, rays, n_samples, bf16, steps=10, warmup=3):
     """One more BASELINE configuration measured in the same run on one GPU: full Trainer.train_step + the kernels' roofline."""
     trainer, net = build_trainer(device, 1, False, bf16, rays, n_samples)
     data = synthetic_batch(device)
-    elapsed, loss = _timed_steps(trainer, data, warmup, steps, 1)
+    elapsed, loss, in_step = _timed_steps(trainer, data, warmup, steps, 1)
     ms = elapsed / steps * 1e3
-    roof = kernel_roofline(net, device, reps=3, bf16=bf16, rays=rays, n_samples=n_samples)
+    roof = kernel_roofline(net, device, reps=3, bf16=bf16, rays=rays, n_samples=n_samples, in_step=in_step)
     out = {'workload': name, 'rays_per_gpu': rays, 'n_samples': n_samples, 'hidden': HIDDEN,
            'dtype': 'bf16 products / f32 accumulate' if bf16 else 'f32', 'steps': steps, 'warmup': warmup,
            'ms_per_step': round(ms, 4), 'value': round(rays / (ms * 1e-3), 1), 'unit': 'rays/s', 'final_loss': round(loss, 6),
-           'roofline': {k: roof[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source')},
-           'kernels_ms': {k: v['ms'] for k, v in roof['kernels'].items()}, 'fused_mlp_all_three': roof['fused_mlp_all_three']}
+           'roofline': {k: roof[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'timing')},
+           'kernels_ms': {k: v['ms'] for k, v in roof['kernels'].items()},
+           'kernels_isolated_ms': {k: v['isolated_ms'] for k, v in roof['kernels'].items()}, 'fused_mlp_all_three': roof['fused_mlp_all_three']}
     del trainer, net, data
     torch.cuda.empty_cache()
     return out
@@ -462,7 +478,7 @@ def main():
     R, N = args.rays_per_gpu, args.samples
     trainer, net = build_trainer(device, world, args.aux, args.bf16, R, N)
     data = synthetic_batch(device)
-    elapsed, loss_val = _timed_steps(trainer, data, args.warmup, args.steps, world)
+    elapsed, loss_val, in_step = _timed_steps(trainer, data, args.warmup, args.steps, world)
     ranks_seen, ar_us = (1, None)
     if world > 1:
         n_grad = sum(p.numel() for m in (net, trainer.pose_param_net, trainer.distortion_net) for p in m.parameters()) + 9
@@ -487,7 +503,7 @@ def main():
         if world > 1:
             out['collective'] = {'backend': 'rccl' if backend == 'nccl' else 'gloo (shared GPU dry run)', 'rccl_ranks_seen': ranks_seen,
                                  'allreduce_us': round(ar_us, 1), 'bucket_floats': n_grad}
-        out['roofline'] = kernel_roofline(net, device, bf16=args.bf16, rays=R, n_samples=N)
+        out['roofline'] = kernel_roofline(net, device, bf16=args.bf16, rays=R, n_samples=N, in_step=in_step)
         out['cpu_baseline'] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
         if world == 1 and not args.no_extra and headline:
             del trainer

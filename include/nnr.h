@@ -269,6 +269,13 @@ int nnr_render_loss(const float* rgb, const float* rgb_gt, const float* dist, co
                     int32_t detach_gt, const float* m_total_dev, float* out5, float* g_rgb, float* g_dist, float* g_d_gt,
                     void* stream);
 
+/* In-step kernel timing for benchmarks (no reference counterpart: the reference has no profiling hooks).  Between nnr_prof_begin and
+ * nnr_prof_end every launch of a main MLP kernel -- training forward, input gradient, weight gradient, inference forward, in this
+ * order in the result arrays -- is bracketed by two HIP events on its launch stream; nnr_prof_end waits for them and returns the
+ * mean duration in milliseconds and the number of launches recorded per kind (at most max_launches each; later ones are not timed). */
+int nnr_prof_begin(int32_t max_launches);
+int nnr_prof_end(float* mean_ms4, int32_t* launches4);
+
 #ifdef __cplusplus
 }
 #endif

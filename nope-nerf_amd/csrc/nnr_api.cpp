@@ -343,6 +343,28 @@ size_t plan_bytes(const BPlan& p) {
 
 }  // namespace
 
+// ---- in-step kernel timing -------------------------------------------------------------------------------------------------
+// bench.py switches this on for its timed steps: every launch of a main MLP kernel is bracketed by two HIP events recorded on the
+// launch stream, so the durations are those of the kernels INSIDE the training step (between the step's other kernels, at the clocks
+// and cache state of the step), not of a kernel run back to back with itself.  One process, one stream at a time: plain globals.
+namespace {
+struct ProfState {
+    bool on = false;
+    int cap = 0;
+    int n[nnr::PROF_KINDS] = {0, 0, 0, 0};
+    std::vector<hipEvent_t> ev[nnr::PROF_KINDS][2];
+} g_prof;
+}  // namespace
+namespace nnr {
+void prof_before(int kind, hipStream_t st) {
+    if (g_prof.on && g_prof.n[kind] < g_prof.cap) (void)hipEventRecord(g_prof.ev[kind][0][g_prof.n[kind]], st);
+}
+void prof_after(int kind, hipStream_t st) {
+    if (g_prof.on && g_prof.n[kind] < g_prof.cap) (void)hipEventRecord(g_prof.ev[kind][1][g_prof.n[kind]++], st);
+}
+}  // namespace nnr
+
+
 extern "C" {
 
 int nnr_abi_version(void) { return NNR_ABI_VERSION; }
@@ -359,6 +381,43 @@ const char* nnr_strerror(int code) {
 }
 
 int nnr_last_hip_error(void) { return g_last_hip; }
+
+int nnr_prof_begin(int32_t max_launches) {
+    if (g_prof.on || max_launches <= 0 || max_launches > 4096) return NNR_E_BADCFG;
+    for (int k = 0; k < nnr::PROF_KINDS; ++k) {
+        g_prof.n[k] = 0;
+        for (int s = 0; s < 2; ++s) {
+            g_prof.ev[k][s].resize(max_launches);
+            for (auto& e : g_prof.ev[k][s])
+                if (hipEventCreate(&e) != hipSuccess) return NNR_E_HIP;
+        }
+    }
+    g_prof.cap = max_launches;
+    g_prof.on = true;
+    return NNR_OK;
+}
+
+int nnr_prof_end(float* mean_ms4, int32_t* launches4) {
+    if (!g_prof.on || !mean_ms4 || !launches4) return NNR_E_BADCFG;
+    g_prof.on = false;
+    int rc = NNR_OK;
+    for (int k = 0; k < nnr::PROF_KINDS; ++k) {
+        double sum = 0.0;
+        for (int i = 0; i < g_prof.n[k]; ++i) {
+            float ms = 0.f;
+            if (hipEventSynchronize(g_prof.ev[k][1][i]) != hipSuccess || hipEventElapsedTime(&ms, g_prof.ev[k][0][i], g_prof.ev[k][1][i]) != hipSuccess)
+                rc = NNR_E_HIP;
+            sum += ms;
+        }
+        launches4[k] = g_prof.n[k];
+        mean_ms4[k] = g_prof.n[k] ? (float)(sum / g_prof.n[k]) : 0.f;
+        for (int s = 0; s < 2; ++s) {
+            for (auto& e : g_prof.ev[k][s]) (void)hipEventDestroy(e);
+            g_prof.ev[k][s].clear();
+        }
+    }
+    return rc;
+}
 
 size_t nnr_packed_floats(const nnr_cfg* cfg) {
     if (check_cfg(cfg) != NNR_OK) return 0;

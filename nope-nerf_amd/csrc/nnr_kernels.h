@@ -117,6 +117,11 @@ struct LossArgs {
     int rgb_l2, ndc, detach_gt;
 };
 
+// ---- in-step kernel timing (nnr_prof_begin / nnr_prof_end, nnr_api.cpp): HIP events on the launch stream around the main MLP kernels
+enum ProfKind { PROF_FWD_TRAIN = 0, PROF_DGRAD = 1, PROF_WGRAD = 2, PROF_FWD_INFER = 3, PROF_KINDS = 4 };
+void prof_before(int kind, hipStream_t st);   // no-ops unless profiling is on
+void prof_after(int kind, hipStream_t st);
+
 hipError_t launch_se3_exp_fwd(const float* r_all, const float* t_all, int idx, float* c2w, hipStream_t st);
 hipError_t launch_se3_exp_bwd(const float* r_all, int idx, int n_cams, const float* d_c2w, float* d_r, float* d_t, hipStream_t st);
 hipError_t launch_inv4(const float* a, float* y, int batch, hipStream_t st);

@@ -246,7 +246,9 @@ extern "C" int nnr_timeline_dgrad(unsigned long long* host32) {
 template <int D>
 static hipError_t launch(const MlpDgradArgs& a, hipStream_t st) {
     dim3 grid((unsigned)(a.chunks_per_ray > 0 ? a.S_pad / kBlockSamples / a.chunks_per_ray : a.S_pad / kBlockSamples)), block(256);
+    prof_before(PROF_DGRAD, st);
     hipLaunchKernelGGL((mlp_dgrad_kernel<D>), grid, block, 0, st, a);
+    prof_after(PROF_DGRAD, st);
     return hipGetLastError();
 }
 

@@ -275,7 +275,9 @@ template <int D>
 static hipError_t launch(const MlpDgradArgs& a, hipStream_t st) {
     const int64_t per_block = (int64_t)kWideSamples * (a.chunks_per_ray > 0 ? a.chunks_per_ray : 1);
     dim3 grid((unsigned)((a.S_pad + per_block - 1) / per_block)), block(256);
+    prof_before(PROF_DGRAD, st);
     hipLaunchKernelGGL((mlp_dgrad_bf16_kernel<D>), grid, block, 0, st, a);
+    prof_after(PROF_DGRAD, st);
     return hipGetLastError();
 }
 

@@ -297,8 +297,10 @@ template <int D>
 static hipError_t launch(const MlpFwdArgs& a, bool train, hipStream_t st) {
     // ray mode: one workgroup per 4 rays, chunks_per_ray passes each; flat mode: one workgroup per 128 samples
     dim3 grid((unsigned)(a.chunks_per_ray > 0 ? a.S_pad / kBlockSamples / a.chunks_per_ray : a.S_pad / kBlockSamples)), block(256);
+    prof_before(train ? PROF_FWD_TRAIN : PROF_FWD_INFER, st);
     if (train) hipLaunchKernelGGL((mlp_fwd_kernel<D, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((mlp_fwd_kernel<D, false>), grid, block, 0, st, a);
+    prof_after(train ? PROF_FWD_TRAIN : PROF_FWD_INFER, st);
     return hipGetLastError();
 }
 

@@ -362,8 +362,10 @@ static hipError_t launch(const MlpFwdArgs& a, bool train, hipStream_t st) {
     // ray mode: one workgroup per 4 rays, chunks_per_ray passes of 64 samples each; flat: one workgroup per 256 samples
     const int64_t per_block = (int64_t)kWideSamples * (a.chunks_per_ray > 0 ? a.chunks_per_ray : 1);
     dim3 grid((unsigned)((a.S_pad + per_block - 1) / per_block)), block(256);
+    prof_before(train ? PROF_FWD_TRAIN : PROF_FWD_INFER, st);
     if (train) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<D, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<D, false>), grid, block, 0, st, a);
+    prof_after(train ? PROF_FWD_TRAIN : PROF_FWD_INFER, st);
     return hipGetLastError();
 }
 

@@ -250,7 +250,9 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const size_t merged = ((size_t)(a.D / 2) * a.D + a.D / 2) * sizeof(float);
     hipError_t e = hipMemsetAsync(a.gw[kMergedLayer], 0, merged, st);   // dW', db' are accumulated into like any gradient
     if (e != hipSuccess) return e;
+    prof_before(PROF_WGRAD, st);
     hipLaunchKernelGGL(wgrad_kernel, dim3(a.n_waves / 4), dim3(256), 0, st, a);
+    prof_after(PROF_WGRAD, st);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_jobs * 16), dim3(256), 0, st, a);
     e = hipGetLastError();
     return e != hipSuccess ? e : launch_wgrad_unmerge(a, st);

@@ -348,7 +348,9 @@ hipError_t launch_wgrad_bf16(const WgradBArgs& a, hipStream_t st) {
     const size_t merged = ((size_t)(a.D / 2) * a.D + a.D / 2) * sizeof(float);
     hipError_t e = hipMemsetAsync(a.gw[kMergedLayer], 0, merged, st);   // dW', db' are accumulated into like any gradient
     if (e != hipSuccess) return e;
+    prof_before(PROF_WGRAD, st);
     hipLaunchKernelGGL(wgrad_b_kernel, dim3(a.n_blocks), dim3(256), kRingBytes, st, a);
+    prof_after(PROF_WGRAD, st);
     hipLaunchKernelGGL(wgrad_b_reduce_kernel, dim3(64, a.n_outs), dim3(256), 0, st, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -83,6 +83,7 @@ class _RaySetup(torch.autograd.Function):
         ctx.flags = (int(normalise), int(use_dir))
         ctx.shapes = (None if depth is None else depth.shape, K.shape, W.shape, S.shape)
         ctx.mark_non_differentiable(mask)
+        ctx.set_materialize_grads(False)     # outputs a step does not use arrive as None in backward, not as zero-filled tensors (a launch each)
         return pts_o, dirs, view, norm, d_gt, mask
 
     @staticmethod

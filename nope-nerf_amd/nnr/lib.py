@@ -30,7 +30,7 @@ EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_
            "nnr_depth_gather_fwd", "nnr_depth_gather_bwd", "nnr_render_loss", "nnr_pixels_from_index", "nnr_pc_nearest",
            "nnr_pc_error_bwd", "nnr_aux_workspace_floats", "nnr_aux_terms_fwd", "nnr_aux_terms_bwd", "nnr_randperm_prefix",
            "nnr_randperm_scratch_bytes", "nnr_ndc_rays_fwd", "nnr_ndc_rays_bwd",
-           "nnr_depth_gather_affine_fwd", "nnr_depth_gather_affine_bwd")
+           "nnr_depth_gather_affine_fwd", "nnr_depth_gather_affine_bwd", "nnr_prof_begin", "nnr_prof_end")
 
 
 class Cfg(C.Structure):
@@ -125,6 +125,8 @@ def load():
     lib.nnr_aux_terms_bwd.argtypes = [auxp] + [vp] * 14
     lib.nnr_pc_error_bwd.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
     lib.nnr_render_loss.argtypes = [vp] * 5 + [i32] + [f32] * 4 + [i32] * 3 + [vp] * 6
+    lib.nnr_prof_begin.argtypes = [i32]
+    lib.nnr_prof_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     for n in EXPORTS:
         if not hasattr(lib, n):
             raise RuntimeError(f"libnnr.so does not export {n}")

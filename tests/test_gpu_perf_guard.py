@@ -32,3 +32,28 @@ def test_mlp_kernels_are_not_an_order_of_magnitude_off(shape):
     for k, bound in BOUNDS[shape].items():
         ms = out["kernels"][k]["ms"]
         assert ms <= bound, (shape, k, ms, bound)
+
+
+def test_in_step_kernel_timing_hooks():
+    """nnr_prof_begin / nnr_prof_end (what bench.py's roofline block is based on): every launch of a main MLP kernel between the two
+    calls is timed with HIP events on its launch stream; counts and plausibility of the means, and the error paths."""
+    import ctypes as C
+
+    import bench
+    from nnr import lib as L
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    trainer, net = bench.build_trainer(dev, 1, False, False, 256, 64)
+    data = bench.synthetic_batch(dev)
+    for i in range(2):
+        trainer.train_step(data, it=i, epoch=0, scheduling_start=10000, render_path=None)
+    ms, n = (C.c_float * 4)(), (C.c_int32 * 4)()
+    assert lib.nnr_prof_end(ms, n) != 0                       # not started
+    L.check(lib.nnr_prof_begin(3), "nnr_prof_begin")
+    assert lib.nnr_prof_begin(3) != 0                         # already on
+    for i in range(5):                                        # more launches than the capacity: the surplus is simply not timed
+        trainer.train_step(data, it=2 + i, epoch=0, scheduling_start=10000, render_path=None)
+    L.check(lib.nnr_prof_end(ms, n), "nnr_prof_end")
+    assert list(n) == [3, 3, 3, 0], list(n)                   # training forward, input gradient, weight gradient; no inference forward
+    assert all(0.005 < ms[k] < 5.0 for k in range(3)), list(ms)
+    trainer.flush_nan_check()

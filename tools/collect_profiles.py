@@ -23,7 +23,8 @@ if __name__ == '__main__':
     rnd, tag = sys.argv[1], sys.argv[2]
     src, dst = os.path.join(ROOT, 'gpurun_out'), os.path.join(ROOT, 'profiles', rnd)
     os.makedirs(dst, exist_ok=True)
-    for rel, name in (('prof/bench/bench_kernel_stats.csv', 'bench_kernel_stats.csv'), ('prof/pmc1/pmc1_counter_collection.csv', 'pmc_sq.csv'),
+    for rel, name in (('prof/bench/bench_kernel_stats.csv', 'bench_kernel_stats.csv'), ('prof/headline/headline_kernel_stats.csv', 'bench_headline_only_kernel_stats.csv'),
+                      ('bench_headline_only.txt', 'bench_headline_only.json.txt'), ('prof/pmc1/pmc1_counter_collection.csv', 'pmc_sq.csv'),
                       ('prof/pmc3/pmc3_counter_collection.csv', 'pmc_fetch.csv'), ('prof/pmc4/pmc4_counter_collection.csv', 'pmc_write.csv'),
                       ('timelines.txt', 'timeline.txt'), ('bench.txt', 'bench.json.txt'), ('pmcv/product.txt', 'pmc_clock.txt')):
         p = os.path.join(src, rel)

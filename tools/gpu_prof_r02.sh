@@ -7,6 +7,7 @@ R=$PWD
 cd /tmp && export TMPDIR=/tmp
 P=/tmp/prof; mkdir -p $P
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P/bench -o bench -- python $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/bench.txt 2> $R/gpurun_out/prof_bench.log
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P/headline -o headline -- python $R/bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline > $R/gpurun_out/bench_headline_only.txt 2> $R/gpurun_out/prof_headline.log
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $P/pmc1 -o pmc1 -- python $R/tools/profile_kernels.py 2 > $R/gpurun_out/pmc1.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $P/pmc3 -o pmc3 -- python $R/tools/profile_kernels.py 2 > $R/gpurun_out/pmc3.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $P/pmc4 -o pmc4 -- python $R/tools/profile_kernels.py 2 > $R/gpurun_out/pmc4.log 2>&1
