@@ -1,11 +1,13 @@
-mkdir -p gpurun_out/r2r
+# Per-step GPU time of a training step by kernel (rocprofv3 --kernel-trace over bench.py, bf16 4096 x 128): is the GPU ever idle, and what do
+# the small launches cost?  -> profiles/r02/l_bf16_4096x128_step_kernel_breakdown.txt (gpu_r2s.sh was the fp32 1024 x 192 twin)
+mkdir -p gpurun_out/step_breakdown
 export PYTHONUNBUFFERED=1
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r2r -o st -- python $R/bench.py --bf16 --rays-per-gpu 4096 --samples 128 --no-extra --no-cpu-baseline --steps 40 --warmup 10 > $R/gpurun_out/r2r/bench.txt 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/step_breakdown -o st -- python $R/bench.py --bf16 --rays-per-gpu 4096 --samples 128 --no-extra --no-cpu-baseline --steps 40 --warmup 10 > $R/gpurun_out/step_breakdown/bench.txt 2>/dev/null
 cd $R
-f=$(find /tmp/r2r -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/r2r/stats.csv
-t=$(find /tmp/r2r -name "*kernel_trace.csv" | head -1)
+f=$(find /tmp/step_breakdown -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/step_breakdown/stats.csv
+t=$(find /tmp/step_breakdown -name "*kernel_trace.csv" | head -1)
 python - "$t" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -28,6 +30,6 @@ for k, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:40]:
 PY
 python - <<'PY'
 import json
-d = json.loads(open('gpurun_out/r2r/bench.txt').read().strip().splitlines()[-1])
+d = json.loads(open('gpurun_out/step_breakdown/bench.txt').read().strip().splitlines()[-1])
 print('bench line of the traced run: %.3f ms/step' % d['ms_per_step'])
 PY
