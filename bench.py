@@ -189,8 +189,9 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
     cfg_inf = L.make_cfg(R, N, D, bf16=bf16)      # forward-only variant (eval / visualisation): no stash
     ws_inf = torch.empty(lib.nnr_workspace_floats(C.byref(cfg_inf)), device=device)
     packed_inf = ops._packed_for(cfg_inf, w, b)
-    stages['mlp_fwd_infer'] = lambda: lib.nnr_mlp_fwd(C.byref(cfg_inf), L.ptr(o), L.ptr(d), L.ptr(view), L.ptr(lo), L.ptr(hi),
-                                                      L.ptr(jit), L.ptr(packed_inf), L.ptr(ws_inf), st)
+    # the product inference path (imaging.render_full_image): compositing in the kernel's epilogue, 16 bytes written per ray
+    stages['mlp_fwd_infer'] = lambda: lib.nnr_render_fwd(C.byref(cfg_inf), L.ptr(o), L.ptr(d), L.ptr(view), L.ptr(lo), L.ptr(hi),
+                                                         L.ptr(jit), L.ptr(packed_inf), L.ptr(rgb), L.ptr(dst), None, None, L.ptr(ws_inf), st)
     times = {}
     for name, fn in stages.items():
         L.check(fn(), name)            # warm-up + makes the workspace valid for the next stage

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/nnr.h"
+#include "nnr_device.h"
 #include "nnr_kernels.h"
 #include "nnr_layout.h"
 
@@ -365,6 +366,9 @@ void prof_after(int kind, hipStream_t st) {
 }  // namespace nnr
 
 
+static_assert(nnr::kFlagDistAlpha == NNR_F_DIST_ALPHA && nnr::kFlagWhiteBg == NNR_F_WHITE_BG && nnr::kFlagReluSigma == NNR_F_RELU_SIGMA,
+              "the device-side copies of the rendering switches (nnr_device.h) must equal include/nnr.h");
+
 extern "C" {
 
 int nnr_abi_version(void) { return NNR_ABI_VERSION; }
@@ -501,8 +505,10 @@ int nnr_pack_weights(const nnr_cfg* cfg, const nnr_params* p, float* packed, voi
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
-int nnr_mlp_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, const float* view_d, const float* z_lo,
-                const float* z_hi, const float* jitter, const float* packed, float* ws, void* stream) {
+// the forward MLP launch; fuse_rgb / fuse_dist != null: inference with the compositing in the kernel's epilogue (ray mode only)
+static int mlp_fwd_impl(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, const float* view_d, const float* z_lo,
+                        const float* z_hi, const float* jitter, const float* packed, float* ws, float* fuse_rgb, float* fuse_dist,
+                        void* stream) {
     int rc = check_cfg(cfg);
     if (rc != NNR_OK) return rc;
     if (!pts_o || !pts_d || !view_d || !z_lo || !z_hi || !packed || !ws) return NNR_E_BADCFG;
@@ -526,9 +532,15 @@ int nnr_mlp_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, cons
     }
     a.S = w.S; a.S_pad = w.S_pad; a.N = cfg->n_samples;
     a.chunks_per_ray = chunks_per_ray(cfg);
+    a.fuse_rgb = fuse_rgb; a.fuse_dist = fuse_dist; a.flags = cfg->flags;
     hipError_t e = is_bf16(cfg) ? launch_mlp_fwd_bf16(cfg->hidden, a, w.train, (hipStream_t)stream)
                                 : launch_mlp_fwd(cfg->hidden, a, w.train, (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
+}
+
+int nnr_mlp_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, const float* view_d, const float* z_lo,
+                const float* z_hi, const float* jitter, const float* packed, float* ws, void* stream) {
+    return mlp_fwd_impl(cfg, pts_o, pts_d, view_d, z_lo, z_hi, jitter, packed, ws, nullptr, nullptr, stream);
 }
 
 int nnr_composite_fwd(const nnr_cfg* cfg, float* rgb, float* dist, float* opt_alpha, float* opt_z, float* ws, void* stream) {
@@ -548,6 +560,11 @@ int nnr_composite_fwd(const nnr_cfg* cfg, float* rgb, float* dist, float* opt_al
 int nnr_render_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, const float* view_d, const float* z_lo,
                    const float* z_hi, const float* jitter, const float* packed, float* rgb, float* dist, float* opt_alpha,
                    float* opt_z, float* ws, void* stream) {
+    // Inference without the per-sample outputs, whole chunks per ray: the forward kernel composites in its epilogue and writes 16
+    // bytes per ray -- no per-sample (rgb, sigma, z) round trip through HBM, no second launch.
+    static const bool no_fuse = std::getenv("NNR_NO_FUSED_COMPOSITE") != nullptr;     // experiments / A-B tests
+    if (cfg && !(cfg->flags & NNR_F_TRAIN) && !opt_alpha && !opt_z && rgb && dist && !no_fuse && chunks_per_ray(cfg) > 0)
+        return mlp_fwd_impl(cfg, pts_o, pts_d, view_d, z_lo, z_hi, jitter, packed, ws, rgb, dist, stream);
     int rc = nnr_mlp_fwd(cfg, pts_o, pts_d, view_d, z_lo, z_hi, jitter, packed, ws, stream);
     if (rc != NNR_OK) return rc;
     return nnr_composite_fwd(cfg, rgb, dist, opt_alpha, opt_z, ws, stream);

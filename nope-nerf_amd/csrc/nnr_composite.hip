@@ -9,24 +9,8 @@
 
 namespace nnr {
 
-constexpr float kEpsT = 1e-6f;  // model/rendering.py:9
 constexpr int kMaxSamplesBwd = 1024;
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-
-// inclusive product scan across the 64 lanes
-__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float t = __shfl_up(v, d, 64);
-        if (lane >= d) v *= t;
-    }
-    return v;
-}
 // inclusive suffix-sum scan (lane i gets sum of lanes >= i)
 __device__ __forceinline__ float wave_rscan_add(float v, int lane) {
 #pragma unroll
@@ -35,29 +19,6 @@ __device__ __forceinline__ float wave_rscan_add(float v, int lane) {
         if (lane + d < 64) v += t;
     }
     return v;
-}
-
-// density / alpha of one sample.  Returns alpha; d_alpha_d_raw receives d alpha / d sigma_raw.
-__device__ __forceinline__ float sample_alpha(float raw, float delta, bool last, uint32_t flags, float& d_alpha_d_raw) {
-    float sigma, dsig;
-    if (flags & NNR_F_RELU_SIGMA) {
-        sigma = fmaxf(raw, 0.f);
-        dsig = raw > 0.f ? 1.f : 0.f;
-    } else {
-        sigma = softplus_ref(raw);
-        dsig = raw > 20.f ? 1.f : sigmoid_ref(raw);
-    }
-    float alpha;
-    if (flags & NNR_F_DIST_ALPHA) {                    // rendering.py:122-128
-        const float e = expf(-1.0f * sigma * delta);
-        alpha = last ? 1.f : 1.f - e;                  // alpha[:, -1] = 1 *after* the exp: no gradient through it
-        d_alpha_d_raw = last ? 0.f : delta * e * dsig;
-    } else {                                           // official_nerf.py:82-83
-        const float e = expf(-1.0f * sigma);
-        alpha = 1.f - e;
-        d_alpha_d_raw = e * dsig;
-    }
-    return alpha;
 }
 
 __global__ __launch_bounds__(256) void composite_fwd_kernel(CompositeArgs a) {

@@ -383,4 +383,47 @@ __device__ __forceinline__ float softplus_ref(float x) {  // F.softplus, beta=1,
 }
 __device__ __forceinline__ float sigmoid_ref(float x) { return 1.f / (1.f + expf(-x)); }
 
+// ---- alpha compositing pieces shared by nnr_composite.hip and the fused epilogue of the inference forward -----------------
+constexpr float kEpsT = 1e-6f;  // model/rendering.py:9
+// the rendering switches of nnr_cfg.flags (include/nnr.h: NNR_F_DIST_ALPHA, NNR_F_WHITE_BG, NNR_F_RELU_SIGMA; checked in nnr_api.cpp)
+constexpr uint32_t kFlagDistAlpha = 1u, kFlagWhiteBg = 2u, kFlagReluSigma = 4u;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// inclusive product scan across the 64 lanes
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float t = __shfl_up(v, d, 64);
+        if (lane >= d) v *= t;
+    }
+    return v;
+}
+// density / alpha of one sample.  Returns alpha; d_alpha_d_raw receives d alpha / d sigma_raw.
+__device__ __forceinline__ float sample_alpha(float raw, float delta, bool last, uint32_t flags, float& d_alpha_d_raw) {
+    float sigma, dsig;
+    if (flags & kFlagReluSigma) {
+        sigma = fmaxf(raw, 0.f);
+        dsig = raw > 0.f ? 1.f : 0.f;
+    } else {
+        sigma = softplus_ref(raw);
+        dsig = raw > 20.f ? 1.f : sigmoid_ref(raw);
+    }
+    float alpha;
+    if (flags & kFlagDistAlpha) {                    // rendering.py:122-128
+        const float e = expf(-1.0f * sigma * delta);
+        alpha = last ? 1.f : 1.f - e;                  // alpha[:, -1] = 1 *after* the exp: no gradient through it
+        d_alpha_d_raw = last ? 0.f : delta * e * dsig;
+    } else {                                           // official_nerf.py:82-83
+        const float e = expf(-1.0f * sigma);
+        alpha = 1.f - e;
+        d_alpha_d_raw = e * dsig;
+    }
+    return alpha;
+}
+
 }  // namespace nnr

@@ -22,6 +22,10 @@ struct MlpFwdArgs {
     uint32_t* ws_mask;
     int64_t S, S_pad;
     int N;
+    // Inference only, ray mode only: composite in the kernel's epilogue (one HBM write of 16 bytes per ray instead of 20 bytes per
+    // sample + a second kernel).  fuse_rgb != null selects it; ws_out4 / ws_z are then not written.
+    float *fuse_rgb, *fuse_dist;   // (R,3), (R)
+    uint32_t flags;                // nnr_cfg.flags (dist_alpha / white background / ReLU density)
     int chunks_per_ray;   // passes per ray in ray mode (R % 4 == 0 and N a multiple of the wave's samples -- 32, bf16 kernels 64: a
                           // wave walks one ray), 0 = flat decomposition
 };

@@ -46,6 +46,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     const int n_pass = a.chunks_per_ray > 0 ? a.chunks_per_ray : 1;
     pipe.more = n_pass > 1;
     pipe.start();
+    // fused compositing (inference, ray mode): running transmittance and weighted sums of this wave's ray, carried across its chunks
+    float cT = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, cz = 0.f, cw = 0.f;
 #pragma unroll 1
     for (int pass = 0; pass < n_pass; ++pass) {
     // Everything lane-dependent is derived INSIDE the pass from an opaque copy of the lane id: left to itself the compiler hoists the
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     const float py = __fadd_rn(ro[1], __fmul_rn(rd[1], z));
     const float pz = __fadd_rn(ro[2], __fmul_rn(rd[2], z));
     const float vx = rv[0], vy = rv[1], vz = rv[2];
-    if (half == 0 && s < a.S) a.ws_z[s] = z;
+    const bool fuse = !TRAIN && a.fuse_rgb != nullptr;
+    if (half == 0 && s < a.S && !fuse) a.ws_z[s] = z;
     // ---- encodings, straight into fragment layout ----
     float e[32];  // gamma_10(p): 63 -> 64
 #pragma unroll
@@ -271,14 +274,43 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         const float part = acc0 + acc1;
         rgbv[c] = part + __shfl_xor(part, 32, 64);
     }
-    if (half == 0 && s < a.S) {
+    {
         const float* b = bias + L::bias_off(11);
         f32x4 o;
         o[0] = sigmoid_ref(rgbv[0] + b[0]);
         o[1] = sigmoid_ref(rgbv[1] + b[1]);
         o[2] = sigmoid_ref(rgbv[2] + b[2]);
         o[3] = sigma_raw;
-        *reinterpret_cast<f32x4*>(a.ws_out4 + 4 * s) = o;
+        if (!fuse) {
+            if (half == 0 && s < a.S) *reinterpret_cast<f32x4*>(a.ws_out4 + 4 * s) = o;
+        } else if constexpr (!TRAIN) {
+            // model/rendering.py:119-132,145-147 for the 32 samples of this chunk (lanes 0..31; the upper half is neutral), exactly as
+            // composite_fwd_kernel does it 64 at a time: alpha from the density and the distance to the NEXT sample (whose z this
+            // lane recomputes from the interval table), transmittance by a product scan across the lanes on top of the carry
+            const int jn = j + 1;
+            float zn = 0.f;
+            if (jn < a.N) {
+                const float lo1 = a.z_lo[jn], hi1 = a.z_hi[jn];
+                zn = a.jitter ? __fadd_rn(lo1, __fmul_rn(__fsub_rn(hi1, lo1), a.jitter[sc + 1])) : lo1;
+            }
+            float unused;
+            const float alpha = half == 0 ? sample_alpha(o[3], jn < a.N ? zn - z : 1e10f, jn == a.N, a.flags, unused) : 0.f;
+            const float incl = wave_scan_mul(half == 0 ? (1.f - alpha) + kEpsT : 1.f, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.f;
+            const float w = alpha * cT * excl;
+            cT *= __shfl(incl, 31, 64);
+            cr += w * o[0]; cg += w * o[1]; cb += w * o[2]; cz += w * z; cw += w;
+            if (pass + 1 == n_pass) {
+                const float sr = wave_sum(cr), sg = wave_sum(cg), sb = wave_sum(cb), sz = wave_sum(cz), sw = wave_sum(cw);
+                if (lane == 0) {
+                    const float bg = (a.flags & kFlagWhiteBg) ? 1.f - sw : 0.f;
+                    float* out = a.fuse_rgb + 3 * (int64_t)ray;
+                    out[0] = sr + bg; out[1] = sg + bg; out[2] = sb + bg;
+                    a.fuse_dist[ray] = sz;
+                }
+            }
+        }
     }
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 9);
 #undef NNR_RELU_PAIR

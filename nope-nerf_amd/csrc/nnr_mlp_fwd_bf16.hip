@@ -58,6 +58,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     const int64_t last_chunk = a.S_pad / kChunk - 1;
     pipe.more = n_pass > 1;
     pipe.start();
+    // fused compositing (inference, ray mode): running transmittance and weighted sums of this wave's ray, carried across its chunks
+    float cT = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, cz = 0.f, cw = 0.f;
+    const bool fuse = !TRAIN && a.fuse_rgb != nullptr;
 #pragma unroll 1
     for (int pass = 0; pass < n_pass; ++pass) {
     int lane = lane0;                 // opaque per pass: keeps lane-constant addresses from being hoisted and spilled (mlp_fwd_kernel)
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         const float py = __fadd_rn(ro[1], __fmul_rn(rd[1], z));
         const float pz = __fadd_rn(ro[2], __fmul_rn(rd[2], z));
         const float vx = rv[0], vy = rv[1], vz = rv[2];
-        if (half == 0 && sn < a.S) a.ws_z[sn] = z;
+        if (half == 0 && sn < a.S && !fuse) a.ws_z[sn] = z;
         float e[32];
 #pragma unroll
         for (int r = 0; r < 32; ++r) e[r] = enc_register(r, half, kPosReal, px, py, pz);
@@ -329,14 +332,42 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
             const float part = dot2_result(acc0) + dot2_result(acc1);
             rgbv[c] = part + __shfl_xor(part, 32, 64);
         }
-        if (half == 0 && sn < a.S) {
-            const float* b = bias + L::bias_off(11);
-            f32x4 o;
-            o[0] = sigmoid_ref(rgbv[0] + b[0]);
-            o[1] = sigmoid_ref(rgbv[1] + b[1]);
-            o[2] = sigmoid_ref(rgbv[2] + b[2]);
-            o[3] = sigma_raw;
-            *reinterpret_cast<f32x4*>(a.ws_out4 + 4 * sn) = o;
+        const float* bo = bias + L::bias_off(11);
+        f32x4 o;
+        o[0] = sigmoid_ref(rgbv[0] + bo[0]);
+        o[1] = sigmoid_ref(rgbv[1] + bo[1]);
+        o[2] = sigmoid_ref(rgbv[2] + bo[2]);
+        o[3] = sigma_raw;
+        if (!fuse) {
+            if (half == 0 && sn < a.S) *reinterpret_cast<f32x4*>(a.ws_out4 + 4 * sn) = o;
+        } else if constexpr (!TRAIN) {
+            // compositing of this chunk's 32 samples on top of the ray's carry, as in mlp_fwd_kernel (ray mode: sn < S, whole chunks)
+            const int ray = (int)(sn / a.N);
+            const int j = (int)(sn - (int64_t)ray * a.N), jn = j + 1;
+            const float lo0 = a.z_lo[j], hi0 = a.z_hi[j];
+            const float z = a.jitter ? __fadd_rn(lo0, __fmul_rn(__fsub_rn(hi0, lo0), a.jitter[sn])) : lo0;
+            float zn = 0.f;
+            if (jn < a.N) {
+                const float lo1 = a.z_lo[jn], hi1 = a.z_hi[jn];
+                zn = a.jitter ? __fadd_rn(lo1, __fmul_rn(__fsub_rn(hi1, lo1), a.jitter[sn + 1])) : lo1;
+            }
+            float unused;
+            const float alpha = half == 0 ? sample_alpha(o[3], jn < a.N ? zn - z : 1e10f, jn == a.N, a.flags, unused) : 0.f;
+            const float incl = wave_scan_mul(half == 0 ? (1.f - alpha) + kEpsT : 1.f, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.f;
+            const float w = alpha * cT * excl;
+            cT *= __shfl(incl, 31, 64);
+            cr += w * o[0]; cg += w * o[1]; cb += w * o[2]; cz += w * z; cw += w;
+            if (pass + 1 == n_pass && n == kTiles - 1) {
+                const float sr = wave_sum(cr), sg2 = wave_sum(cg), sb = wave_sum(cb), sz = wave_sum(cz), sw = wave_sum(cw);
+                if (lane == 0) {
+                    const float bg = (a.flags & kFlagWhiteBg) ? 1.f - sw : 0.f;
+                    float* out = a.fuse_rgb + 3 * (int64_t)ray;
+                    out[0] = sr + bg; out[1] = sg2 + bg; out[2] = sb + bg;
+                    a.fuse_dist[ray] = sz;
+                }
+            }
         }
     }
     NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 7);

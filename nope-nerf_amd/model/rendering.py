@@ -30,11 +30,16 @@ class RenderOutput(dict):
     kernels and a device->host sync, and the trainer's fused loss works on the dense tensors + mask instead
     (keys `dist_dense`, `d_gt_dense`, `mask`)."""
 
-    _LAZY = ('depth_pred', 'depth_gt')
+    _LAZY = ('depth_pred', 'depth_gt', 'alpha', 'z_vals')
 
     def __missing__(self, key):
         if key not in self._LAZY:
             raise KeyError(key)
+        if key in ('alpha', 'z_vals'):
+            # forward-only renders composite inside the MLP kernel and write nothing per sample; whoever does want the per-sample
+            # weights of an evaluation render gets them from a second, unfused pass
+            self['alpha'], self['z_vals'] = dict.__getitem__(self, '_samples')()
+            return dict.__getitem__(self, key)
         mask = dict.__getitem__(self, 'mask')
         if key == 'depth_pred':
             val = dict.__getitem__(self, 'dist_dense')[mask]
@@ -145,11 +150,12 @@ class Renderer(nn.Module):
             raise ValueError('unknown sample_option %r' % (cfg['sample_option'],))
 
         net = self.model
-        rgb, dist_pred, alpha, z_val = nnr.render_rays(
-            pts_o, pts_d, view, z_lo, z_hi, jitter, net.weights(), net.biases(), hidden=net.hidden_dim,
-            dist_alpha=bool(cfg['dist_alpha']), white_bg=bool(self.white_background),
-            relu_sigma=(net.occ_activation != 'softplus'),
-            bf16=(str(cfg.get('mfma_dtype', 'fp32')).lower() == 'bf16'))   # rendering.mfma_dtype: fp32 (default) | bf16
+        kw = dict(hidden=net.hidden_dim, dist_alpha=bool(cfg['dist_alpha']), white_bg=bool(self.white_background),
+                  relu_sigma=(net.occ_activation != 'softplus'),
+                  bf16=(str(cfg.get('mfma_dtype', 'fp32')).lower() == 'bf16'))   # rendering.mfma_dtype: fp32 (default) | bf16
+        lazy_samples = not torch.is_grad_enabled()   # evaluation / visualisation: per-sample outputs only if somebody reads them
+        rgb, dist_pred, alpha, z_val = nnr.render_rays(pts_o, pts_d, view, z_lo, z_hi, jitter, net.weights(), net.biases(),
+                                                       samples=not lazy_samples, **kw)
 
         diff_norm = None
         if cfg['normal_loss'] and not eval_:
@@ -160,9 +166,9 @@ class Renderer(nn.Module):
             d_gt = d_gt / ray_norm
         return RenderOutput({
             'rgb': rgb.reshape(batch_size, -1, 3),
-            'z_vals': z_val,
             'normal': diff_norm,
-            'alpha': alpha,
+            **({'_samples': lambda: nnr.render_rays(pts_o, pts_d, view, z_lo, z_hi, jitter, net.weights(), net.biases(), **kw)[2:]}
+               if lazy_samples else {'z_vals': z_val, 'alpha': alpha}),
             # dense per-ray values + validity mask; 'depth_pred' / 'depth_gt' (masked) are derived lazily from these
             'dist_dense': dist_pred,
             'd_gt_dense': d_gt,

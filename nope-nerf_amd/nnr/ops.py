@@ -211,8 +211,11 @@ class _RenderRays(torch.autograd.Function):
         ws = _take_workspace(cfg, dev)
         rgb = torch.empty(R, 3, **f32)
         dist = torch.empty(R, **f32)
-        alpha = torch.empty(R, N, **f32)
-        zv = torch.empty(R, N, **f32)
+        # forward-only callers that do not want the per-sample outputs (samples=False) get the fused path of nnr_render_fwd: the
+        # compositing happens in the MLP kernel's epilogue and nothing per-sample is written to HBM
+        want_samples = need_grad or opts.get("samples", True)
+        alpha = torch.empty(R, N, **f32) if want_samples else None
+        zv = torch.empty(R, N, **f32) if want_samples else None
         st = L.stream()
         L.check(lib.nnr_render_fwd(C.byref(cfg), L.ptr(pts_o), L.ptr(pts_d), L.ptr(view_d), L.ptr(z_lo), L.ptr(z_hi),
                                    L.ptr(jit), L.ptr(packed), L.ptr(rgb), L.ptr(dist), L.ptr(alpha), L.ptr(zv), L.ptr(ws), st),
@@ -222,7 +225,8 @@ class _RenderRays(torch.autograd.Function):
             ctx.shapes = [tuple(p.shape) for p in params]
         else:
             _give_workspace(cfg, dev, ws)
-        ctx.mark_non_differentiable(alpha, zv)
+        if want_samples:
+            ctx.mark_non_differentiable(alpha, zv)
         ctx.set_materialize_grads(False)      # undefined upstream gradients arrive as None, not as zero-filled tensors
         return rgb, dist, alpha, zv
 
@@ -261,12 +265,13 @@ class _RenderRays(torch.autograd.Function):
 
 def render_rays(pts_o: torch.Tensor, pts_d: torch.Tensor, view_d: torch.Tensor, z_lo: torch.Tensor, z_hi: torch.Tensor,
                 jitter: Optional[torch.Tensor], weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], *,
-                hidden: int, dist_alpha: bool, white_bg: bool, relu_sigma: bool, bf16: bool = False):
+                hidden: int, dist_alpha: bool, white_bg: bool, relu_sigma: bool, bf16: bool = False, samples: bool = True):
     """(R,3) sampling origin / direction / view direction, (N) z interval tables, optional (R,N) jitter, the 12
     nn.Linear weights and biases in state_dict order  ->  rgb (R,3), dist (R), alpha (R,N), z (R,N).
     Differentiable w.r.t. pts_o, pts_d, view_d, weights, biases.  bf16: bf16-MFMA products (fp32 accumulation) in the MLP
-    forward and input-gradient kernels (NNR_F_BF16); weight gradients stay fp32."""
-    opts = dict(hidden=hidden, dist_alpha=dist_alpha, white_bg=white_bg, relu_sigma=relu_sigma, bf16=bool(bf16),
+    forward and input-gradient kernels (NNR_F_BF16); weight gradients stay fp32.  samples=False (only honoured under torch.no_grad):
+    alpha and z come back as None and the renderer composites inside the MLP kernel (16 bytes written per ray)."""
+    opts = dict(hidden=hidden, dist_alpha=dist_alpha, white_bg=white_bg, relu_sigma=relu_sigma, bf16=bool(bf16), samples=bool(samples),
                 params=(list(weights), list(biases)))    # the caller's own tensor objects: identity keys the pack cache
     if not torch.is_grad_enabled():
         # forward-only (eval / visualisation inside torch.no_grad): no stash, small workspace

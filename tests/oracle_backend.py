@@ -7,7 +7,7 @@ import nerf_oracle as orc
 from nnr import LAYER_NAMES
 
 
-def render_rays(pts_o, pts_d, view_d, z_lo, z_hi, jitter, weights, biases, *, hidden, dist_alpha, white_bg, relu_sigma, bf16=False):
+def render_rays(pts_o, pts_d, view_d, z_lo, z_hi, jitter, weights, biases, *, hidden, dist_alpha, white_bg, relu_sigma, bf16=False, samples=True):
     R, N = pts_o.shape[0], z_lo.shape[0]
     params = {}
     for n, w, b in zip(LAYER_NAMES, weights, biases):

@@ -381,6 +381,39 @@ def test_bf16_kernels_match_the_bf16_arithmetic_oracle(name, capsys):
         print("\nbf16 kernels vs bf16-arithmetic oracle [%s]: worst gradient relative L2 %.2e (%s)" % (name, worst[1], worst[0]))
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("D,R,N,dist_alpha,white_bg,relu_sigma,jittered", [
+    (256, 8, 192, False, False, False, False),    # the evaluation shape class: whole chunks per ray, no jitter
+    (128, 12, 64, True, True, False, True),       # dist_alpha (needs the next sample's z across the chunk boundary), white background
+    (256, 4, 128, True, False, True, False),      # ReLU density
+])
+def test_inference_composites_in_the_kernel_epilogue(D, R, N, dist_alpha, white_bg, relu_sigma, jittered, bf16):
+    """Forward-only renders that do not ask for per-sample outputs (samples=False) take the fused path of nnr_render_fwd: the MLP kernel
+    composites its ray in the epilogue and writes 16 bytes per ray.  Same numbers as MLP kernel + composite kernel (the product scan
+    associates differently: 32 lanes + carry instead of 64), and the per-sample planes of the workspace stay untouched."""
+    import ctypes as C
+    import nnr
+    from nnr import lib as L
+    from nnr import ops
+    dev = torch.device("cuda")
+    params, o, d, lo, hi, jit = _synthetic(D, R, N, seed=3 + R, dist_alpha=dist_alpha)
+    w = [params[n + ".weight"].to(dev) for n in L.LAYER_NAMES]
+    b = [params[n + ".bias"].to(dev) for n in L.LAYER_NAMES]
+    args = (o.to(dev), d.to(dev), (-d).to(dev), lo.to(dev), hi.to(dev), jit.to(dev) if jittered else None, w, b)
+    kw = dict(hidden=D, dist_alpha=dist_alpha, white_bg=white_bg, relu_sigma=relu_sigma, bf16=bf16)
+    with torch.no_grad():
+        rgb0, dist0, alpha0, z0 = nnr.render_rays(*args, **kw)                       # unfused: per-sample outputs requested
+        cfg = L.make_cfg(R, N, D, dist_alpha=dist_alpha, white_bg=white_bg, relu_sigma=relu_sigma, bf16=bf16)
+        ws = ops._take_workspace(cfg, dev)
+        ws.fill_(-7.0)
+        ops._give_workspace(cfg, dev, ws)                                          # the next forward-only render takes this one
+        rgb1, dist1, alpha1, z1 = nnr.render_rays(*args, samples=False, **kw)
+        torch.cuda.synchronize()
+    assert alpha1 is None and z1 is None and alpha0.shape == (R, N)
+    assert float((rgb1 - rgb0).abs().max()) <= 2e-6 and float((dist1 - dist0).abs().max()) <= 2e-5 * max(1.0, float(dist0.abs().max()))
+    assert bool((ws == -7.0).all())                                                # nothing per-sample went to HBM
+
+
 def _render_bf16_oracle(params, o, d, v, lo, hi, jit, *, dist_alpha, white_bg, relu_sigma):
     """nnr.render_rays' contract on the CPU with the MLP of the bf16 mode (oracle mlp_bf16): sampling and compositing as in
     oracle/nerf_oracle.py::render."""
