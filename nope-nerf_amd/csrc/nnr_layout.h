@@ -179,6 +179,8 @@ enum Plane {
 // read (ds_read_b64_tr_b16), not in HBM.
 // P_DG carries one extra group in this mode: group D/32 = the per-sample output gradients as bf16 (d rgb_pre[0..2], d sigma_raw,
 // 12 zeros), so that the two head layers are ordinary tiles of the same kernel.
+// P_XE / P_XF stay fp32 in this mode but change meaning: they hold the chain-rule FACTORS of the encodings (scale * partner value) in
+// fragment-register order, tile-major -- block (chunk, q) = [lane][factors of registers 4q .. 4q+3] (enc_factor, nnr_mlp_bf16.h).
 NNR_HD constexpr int64_t tile_major_index(int64_t s, int f, int G) {
     return ((((s >> 5) * G + (f >> 4)) * 64 + 32 * ((f & 7) >> 2) + (s & 31)) << 3) + 4 * ((f & 15) >> 3) + (f & 3);
 }

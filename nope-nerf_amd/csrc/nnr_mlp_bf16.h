@@ -245,4 +245,39 @@ __device__ __forceinline__ constexpr int stash_tail() {
     return kTiles * last;
 }
 
+// ---- chain rule through the encodings: factors in fragment-register order ---------------------------------------------------
+// d gamma_f / d coordinate = scale_f * partner_f: a sin feature's partner is the cos of the same argument (scale +2^l), a cos feature's
+// the sin (scale -2^l), the identity block has factor 1, padding 0.  The input-gradient kernel needs, per lane and fragment register,
+// exactly that product -- and the forward kernel holds every sin / cos of the sample in the two lanes (half 0 / 1) that own it.  In the
+// bf16 mode the planes P_XE / P_XF therefore store the FACTORS, tile-major in register order (block (chunk, q) = [lane][factors of
+// registers 4q .. 4q+3]): one coalesced 1 KiB store / load per four registers on either side.  Reading the partners out of a row-major
+// (sample, feature) plane instead took 32 single-dword loads per tile whose lanes are 256 bytes apart: a fifth of the
+// input-gradient kernel's time.
+struct EncMeta16 { int coord; float scale; int partner; };
+__device__ __forceinline__ constexpr EncMeta16 enc_meta16(int f, int n_real) {
+    if (f >= n_real) return {0, 0.f, 0};
+    if (f < 3) return {f, 1.f, -1};
+    const int t = f - 3, lvl = t / 6, rem = t - 6 * lvl;
+    const bool is_cos = rem >= 3;
+    const float a = (float)(1 << lvl);
+    return {is_cos ? rem - 3 : rem, is_cos ? -a : a, is_cos ? f - 3 : f + 3};
+}
+// factor of fragment register r for the lane's half, from the lane's own encoding registers and the other half's (own[] swapped
+// across the two 32-lane halves of the wave)
+template <int NR>
+__device__ __forceinline__ float enc_factor(int r, int half, int n_real, const float (&own)[NR], const float (&other)[NR]) {
+    float v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const EncMeta16 m = enc_meta16(frag_feature(r, h), n_real);
+        if (m.scale == 0.f) v[h] = 0.f;
+        else if (m.partner < 0) v[h] = m.scale;
+        else {
+            const int fp = m.partner, hp = (fp % 8) / 4, rp = 16 * (fp / 32) + (fp % 4) + 4 * ((fp % 32) / 8);   // frag_feature^-1
+            v[h] = m.scale * (hp == h ? own[rp] : other[rp]);
+        }
+    }
+    return half ? v[1] : v[0];
+}
+
 }  // namespace nnr

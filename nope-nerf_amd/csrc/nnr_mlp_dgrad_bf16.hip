@@ -9,30 +9,31 @@
 
 namespace nnr {
 
-// ---- chain rule through gamma_L (same as nnr_mlp_dgrad.hip) ----
-struct EncMeta16 { int coord; float scale; int partner; };
-__device__ __forceinline__ constexpr EncMeta16 enc_meta16(int f, int n_real) {
-    if (f >= n_real) return {0, 0.f, 0};
-    if (f < 3) return {f, 1.f, -1};
-    const int t = f - 3, lvl = t / 6, rem = t - 6 * lvl;
-    const bool is_cos = rem >= 3;
-    const float a = (float)(1 << lvl);
-    return {is_cos ? rem - 3 : rem, is_cos ? -a : a, is_cos ? f - 3 : f + 3};
+// d/d(x,y,z) of sum_r g(r) * gamma(.)_{f(r,half)}: the chain-rule factors (scale * partner value, enc_factor in nnr_mlp_bf16.h) come from
+// the forward kernel's stash in register order, `factors` = this lane's 16 bytes of block (chunk, 0); block q is 256 floats further
+template <int NQ4>
+__device__ __forceinline__ void enc_factors_load(f32x4 (&fac)[NQ4], const float* factors) {
+#pragma unroll
+    for (int q = 0; q < NQ4; ++q) {
+#ifdef NNR_ABLATE_NO_ENCLOAD
+        fac[q] = f32x4{1.f, 1.f, 1.f, 1.f};     // profiling build only
+#else
+        fac[q] = *reinterpret_cast<const f32x4*>(factors + q * 256);
+#endif
+    }
 }
-// d/d(x,y,z) of sum_r g(r) * gamma(.)_{f(r,half)}, the partner values (cos for a sin feature, -sin for a cos feature, 1 for the identity
-// block, times the octave) read from the stashed fp32 encoding `enc` of the lane's sample
 template <int NR, class G>
-__device__ __forceinline__ f32x4 enc_chain(const G& g, const float* enc, int n_real, int half) {
+__device__ __forceinline__ f32x4 enc_chain(const G& g, const f32x4 (&fac)[NR / 4], int half) {
     float g3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const EncMeta16 m0 = enc_meta16(frag_feature(r, 0), n_real), m1 = enc_meta16(frag_feature(r, 1), n_real);
-        const int partner = half ? m1.partner : m0.partner;
-        const float sc = half ? m1.scale : m0.scale;
-        const float pv = sc * (partner >= 0 ? enc[partner] : 1.f);
-        const int f0 = frag_feature(r, 0);
-        const int c0 = f0 < 3 ? f0 : (f0 - 3) % 3;     // coordinate of register r in half 0; half 1 is rotated by one (f -> f + 4)
-        g3[c0] = fmaf(g(r), pv, g3[c0]);
+    for (int q = 0; q < NR / 4; ++q) {
+        const f32x4 v = fac[q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f0 = frag_feature(4 * q + i, 0);
+            const int c0 = f0 < 3 ? f0 : (f0 - 3) % 3;     // coordinate of the register in half 0; half 1 is rotated by one (f -> f + 4)
+            g3[c0] = fmaf(g(4 * q + i), v[i], g3[c0]);
+        }
     }
     float o[3] = {half ? g3[2] : g3[0], half ? g3[0] : g3[1], half ? g3[1] : g3[2]};
 #pragma unroll
@@ -180,6 +181,11 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) 
     // G = 2 HT rows; unit u writes dq[.][u >> 1] -- not an input of this part
     gemm_wide<HT, HT, false, NU, NU / (2 * HT), 0, stash_tail<HT, HT>()>(accB, dgq, pipe, p0(B_RGBH_FB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
     {
+        // the chain-rule factors are fetched BEFORE the GEMM whose result they multiply: the loads land under it, and the wait for them
+        // does not drain the weight DMA issued meanwhile
+        f32x4 facd[kTiles][4];
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) enc_factors_load(facd[n], a.ws_xf + ((int64_t)opaque(chunk[n]) * 4) * 256 + lane * 4);
         f32x16 accd[kTiles][1];
         zero_acc2(accd);
         gemm_wide<HT, 1>(accd, dgq, pipe, p0(B_RGBH_D));
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) 
         for (int n = 0; n < kTiles; ++n) {
             const int64_t sn = sample(n);
             const bool live = sn < a.S;
-            const f32x4 gv = enc_chain<16>([&](int r) { return accd[n][0][r]; }, a.ws_xf + (live ? sn : 0) * kDirPad, kDirReal, half);
+            const f32x4 gv = enc_chain<16>([&](int r) { return accd[n][0][r]; }, facd[n], half);
             if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dview + 4 * sn) = gv;
         }
     }
@@ -227,14 +233,15 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) 
         load_mask(mwA, 3, 0);
         gemm_wide<DT, 2, true, NU, 5, 0, 0>(acce, dq, pipe, p0(B_L5E), st, NNR_SEL_UNIT(accB, NP, mwB));
 #pragma unroll
-        for (int n = 0; n < kTiles; ++n) {
-            const int64_t sn = sample(n);
-            gp5[n] = enc_chain<32>([&](int r) { return acce[n][r >> 4][r & 15]; }, a.ws_xe + (sn < a.S ? sn : 0) * kPosPad, kPosReal, half);
+        for (int n = 0; n < kTiles; ++n) {   // (64 more live registers during the GEMM would spill: the factors are fetched here)
+            f32x4 face[8];
+            enc_factors_load(face, a.ws_xe + ((int64_t)opaque(chunk[n]) * 8) * 256 + lane * 4);
+            gp5[n] = enc_chain<32>([&](int r) { return acce[n][r >> 4][r & 15]; }, face, half);
         }
     }
     load_mask(mwB, 3, 1);
     zero_acc2(accA);
-    gemm_wide<DT, HT>(accA, dq, pipe, p0(B_L5HA));   // (the chain-rule loads above were waited for: nothing of B_L5E is in flight)
+    gemm_wide<DT, HT>(accA, dq, pipe, p0(B_L5HA));   // (the factor loads above were waited for: nothing of B_L5E is in flight)
     zero_acc2(accB);
     gemm_wide<DT, HT, false, NU, 4, 1, 0>(accB, dq, pipe, p0(B_L5HB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
     NNR_STAMP(tl_dgrad16, 3);
@@ -255,7 +262,9 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) 
         for (int n = 0; n < kTiles; ++n) {
             const int64_t sn = sample(n);
             const bool live = sn < a.S;
-            const f32x4 gp = enc_chain<32>([&](int r) { return acc2[n][r >> 4][r & 15]; }, a.ws_xe + (live ? sn : 0) * kPosPad, kPosReal, half);
+            f32x4 face[8];
+            enc_factors_load(face, a.ws_xe + ((int64_t)opaque(chunk[n]) * 8) * 256 + lane * 4);
+            const f32x4 gp = enc_chain<32>([&](int r) { return acc2[n][r >> 4][r & 15]; }, face, half);
             if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dpts + 4 * sn) = gp + gp5[n];
         }
     }

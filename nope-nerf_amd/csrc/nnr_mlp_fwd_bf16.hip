@@ -122,14 +122,23 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         for (int q = 0; q < 2; ++q)
             park[(6 * n + 4 + q) * 64] = __builtin_bit_cast(f32x4, u32x4{dq[4 * q], dq[4 * q + 1], dq[4 * q + 2], dq[4 * q + 3]});
         if constexpr (TRAIN) {
-            // fp32 row-major copies for the backward of the encodings (sin / cos partners at full precision), tile-major bf16 copies
-            // = the MFMA operands, for the weight-gradient kernel
-            float* xe = a.ws_xe + sn * kPosPad + 4 * half;
+            // the chain-rule factors of both encodings in register order for the input-gradient kernel (enc_factor, nnr_mlp_bf16.h),
+            // and tile-major bf16 copies of the encodings = the MFMA operands, for the weight-gradient kernel
+            float es[32], ds[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) stash_store(xe + 8 * q, f32x4{e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]});
-            float* xf = a.ws_xf + sn * kDirPad + 4 * half;
+            for (int r = 0; r < 32; ++r) es[r] = __shfl_xor(e[r], 32, 64);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) stash_store(xf + 8 * q, f32x4{dirv[4 * q], dirv[4 * q + 1], dirv[4 * q + 2], dirv[4 * q + 3]});
+            for (int r = 0; r < 16; ++r) ds[r] = __shfl_xor(dirv[r], 32, 64);
+            float* pe = a.ws_xe + ((int64_t)opaque(chunk[n]) * 8) * 256 + lane * 4;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                stash_store(pe + q * 256, f32x4{enc_factor(4 * q, half, kPosReal, e, es), enc_factor(4 * q + 1, half, kPosReal, e, es),
+                                                enc_factor(4 * q + 2, half, kPosReal, e, es), enc_factor(4 * q + 3, half, kPosReal, e, es)});
+            float* pf = a.ws_xf + ((int64_t)opaque(chunk[n]) * 4) * 256 + lane * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                stash_store(pf + q * 256, f32x4{enc_factor(4 * q, half, kDirReal, dirv, ds), enc_factor(4 * q + 1, half, kDirReal, dirv, ds),
+                                                enc_factor(4 * q + 2, half, kDirReal, dirv, ds), enc_factor(4 * q + 3, half, kDirReal, dirv, ds)});
             __bf16* e16 = tile_row(a.ws_xe16, sn, kPosPad, half);
 #pragma unroll
             for (int b = 0; b < 4; ++b)
