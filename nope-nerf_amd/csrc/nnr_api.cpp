@@ -58,8 +58,9 @@ bool is_bf16(const nnr_cfg* c) { return (c->flags & NNR_F_BF16) != 0; }
 // The bf16 kernels (nnr_mlp_fwd_bf16.hip) work on PAIRS of chunks: their unit is 64 samples.
 int chunks_per_ray(const nnr_cfg* c) {
     static const bool off = std::getenv("NNR_FLAT_GRID") != nullptr;    // experiments: force the flat decomposition
-    const int unit = is_bf16(c) ? 2 * kChunk : kChunk;
-    return (!off && c->n_samples % unit == 0 && c->n_rays % kWavesPerBlock == 0) ? c->n_samples / unit : 0;
+    const int unit = is_bf16(c) ? kBf16Tiles * kChunk : kChunk;         // samples a wave takes per pass
+    const int waves = is_bf16(c) ? kBf16Waves : kWavesPerBlock;         // = rays per workgroup in ray mode
+    return (!off && c->n_samples % unit == 0 && c->n_rays % waves == 0) ? c->n_samples / unit : 0;
 }
 
 // ---- weight-gradient plan -------------------------------------------------------------------------------------------

@@ -41,7 +41,10 @@ constexpr int kPanelF4 = kPanelFrags * 64;  // float4 elements per panel
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-struct PanelPipe {
+// W = waves of the workgroup that share the stream; each copies PW = 32 / W of a panel's 32 fragments (8 with the usual 4 waves).
+template <int W>
+struct PanelPipeT {
+    static constexpr int PW = kPanelFrags / W;   // DMA pieces (1 KiB) per wave and panel
     const f32x4* src;  // stream base in global memory offset by this wave's fragment slice (wave-uniform: SGPRs)
     f32x4* lds;        // base of the three panel buffers in LDS
     int wave, lane;    // wave is wave-uniform (readfirstlane'd by the caller)
@@ -73,16 +76,16 @@ struct PanelPipe {
         // instruction's signed 13-bit immediate, which offsets the global and the LDS address alike -- so a piece costs
         // one VMEM issue and no address arithmetic.
         const int ps = p < n_panels ? p : p - n_panels;
-        const f32x4* g = src + (int64_t)ps * kPanelF4 + 4 * 64 + lane;
-        f32x4* l = lds + buffer(p) * kPanelF4 + wave * (8 * 64) + 4 * 64;
-        switch (i) {   // the offset operand must be a literal
-            case 0: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -4096, 0); break;
-            case 1: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -3072, 0); break;
-            case 2: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -2048, 0); break;
-            case 3: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -1024, 0); break;
-            case 4: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0); break;
-            case 5: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 1024, 0); break;
-            case 6: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 2048, 0); break;
+        const f32x4* g = src + (int64_t)ps * kPanelF4 + (PW / 2) * 64 + lane;
+        f32x4* l = lds + buffer(p) * kPanelF4 + wave * (PW * 64) + (PW / 2) * 64;
+        switch (i - PW / 2) {   // the offset operand must be a literal
+            case -4: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -4096, 0); break;
+            case -3: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -3072, 0); break;
+            case -2: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -2048, 0); break;
+            case -1: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -1024, 0); break;
+            case 0: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0); break;
+            case 1: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 1024, 0); break;
+            case 2: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 2048, 0); break;
             default: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 3072, 0); break;
         }
     }
@@ -90,7 +93,7 @@ struct PanelPipe {
     __device__ __forceinline__ void pieces(int p, int first, int count) const {
         if (p < n_panels || more) {
 #pragma unroll
-            for (int i = first; i < first + count && i < 8; ++i) piece(p, i);
+            for (int i = first; i < first + count && i < PW; ++i) piece(p, i);
         }
     }
     // Make panel p readable and release the buffer of panel p-1 (which the pieces of panel p+2 overwrite; the caller
@@ -107,20 +110,21 @@ struct PanelPipe {
 #ifdef NNR_ABLATE_NO_SYNC
         return;
 #endif
-        static_assert(8 + EXTRA < 64, "vmcnt is a 6-bit field");
+        static_assert(PW + EXTRA < 64, "vmcnt is a 6-bit field");
         // lgkmcnt(0): this wave's ds_reads of panel p-1 have returned before it reports "done reading" at the barrier
         if (p + 1 < n_panels || more)
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + EXTRA) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PW + EXTRA) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
     __device__ __forceinline__ void start() const {  // prologue of a workgroup's FIRST pass: two panels in flight
-        pieces(0, 0, 8);
-        pieces(1, 0, 8);
+        pieces(0, 0, PW);
+        pieces(1, 0, PW);
     }
 };
+using PanelPipe = PanelPipeT<kWavesPerBlock>;
 
 // One k-group of A fragments (MT x 16 bytes per lane) in registers.
 template <int MT>

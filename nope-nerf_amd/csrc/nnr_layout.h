@@ -31,6 +31,15 @@ namespace nnr {
 constexpr int kChunk = 32;         // samples per wave
 constexpr int kWavesPerBlock = 4;  // one wave per SIMD
 constexpr int kBlockSamples = kChunk * kWavesPerBlock;
+// Shape of the bf16 MLP kernels (nnr_mlp_bf16.h): 32-sample chunks per wave x waves per workgroup = 256 samples.  2 x 4 is the
+// product; -DNNR_BF16_TILES=1 builds the 1 x 8 shape (two waves per SIMD) for comparison: measured slower, 0.82 / 0.78 ms against
+// 0.77 / 0.68 ms (forward / input gradient, 4096 x 128) -- twice the LDS reads and DMA instructions per MFMA outweigh what the second
+// wave hides of the epilogue.
+#ifndef NNR_BF16_TILES
+#define NNR_BF16_TILES 2
+#endif
+constexpr int kBf16Tiles = NNR_BF16_TILES, kBf16Waves = 8 / kBf16Tiles;
+static_assert(kBf16Tiles == 1 || kBf16Tiles == 2, "one or two chunks per wave");
 constexpr int kPosLevels = 10, kDirLevels = 4;  // hard-wired in the reference (model/official_nerf.py:61,87)
 constexpr int kPosReal = 63, kDirReal = 27;     // (2L+1)*3
 constexpr int kPosPad = 64, kDirPad = 32;

@@ -18,12 +18,18 @@
 
 namespace nnr {
 
-constexpr int kTiles = 2;   // 32-sample chunks per wave in the bf16 kernels
+// Two shapes of the same kernels (template parameters T = 32-sample chunks per wave, W = waves per workgroup):
+//   T = 2, W = 4  one wave per SIMD, 512 registers each, every weight fragment read feeds two MFMAs ("wide");
+//   T = 1, W = 8  two waves per SIMD, 256 registers each: one wave's epilogue VALU work runs while the other's MFMAs occupy the
+//                 matrix pipe -- within ONE wave the two do not overlap (measured: every VALU instruction between two MFMAs costs
+//                 its issue time).
+// Either way a workgroup covers 256 samples per pass.
+constexpr int kMaxTiles = 2;
 #ifndef NNR_DMA_BURST
 #define NNR_DMA_BURST 4
 #endif
 constexpr int kDmaBurst = NNR_DMA_BURST;   // DMA pieces (1 KiB each) a wave issues per row until the 8 of a panel are out
-constexpr int kWideSamples = kTiles * kChunk * kWavesPerBlock;   // samples per workgroup
+constexpr int kWideSamples = 256;   // samples per workgroup and pass (T * 32 * W)
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -121,21 +127,25 @@ __device__ __forceinline__ unsigned lds_byte_address(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-template <int MT, int NACC>
-__device__ __forceinline__ void pin_acc2(f32x16 (&acc)[kTiles][NACC]) {   // see pin_acc
-    static_assert(kTiles == 2, "written for two tiles");
-    if constexpr (MT == 1) asm volatile("" : "+a"(acc[0][0]), "+a"(acc[1][0]));
-    else if constexpr (MT == 2) asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));
-    else if constexpr (MT == 4)
-        asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),
-                     "+a"(acc[1][2]), "+a"(acc[1][3]));
-    else static_assert(MT == 1 || MT == 2 || MT == 4, "unsupported tile count");
+template <int MT, int T, int NACC>
+__device__ __forceinline__ void pin_acc2(f32x16 (&acc)[T][NACC]) {   // see pin_acc
+    static_assert(T == 1 || T == 2, "one or two tiles per wave");
+    if constexpr (T == 1) {
+        pin_acc<MT>(acc[0]);
+    } else {
+        if constexpr (MT == 1) asm volatile("" : "+a"(acc[0][0]), "+a"(acc[1][0]));
+        else if constexpr (MT == 2) asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));
+        else if constexpr (MT == 4)
+            asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),
+                         "+a"(acc[1][2]), "+a"(acc[1][3]));
+        else static_assert(MT == 1 || MT == 2 || MT == 4, "unsupported tile count");
+    }
 }
 
-template <int N>
-__device__ __forceinline__ void zero_acc2(f32x16 (&acc)[kTiles][N]) {
+template <int T, int N>
+__device__ __forceinline__ void zero_acc2(f32x16 (&acc)[T][N]) {
 #pragma unroll
-    for (int n = 0; n < kTiles; ++n) zero_acc(acc[n]);
+    for (int n = 0; n < T; ++n) zero_acc(acc[n]);
 }
 
 // acc[n][mt] += A_part[32 mt .., :] * in[n]   for both tiles n, one layer part whose packed bf16 panels start at stream panel p0.
@@ -152,9 +162,10 @@ __device__ __forceinline__ void zero_acc2(f32x16 (&acc)[kTiles][N]) {
 //           while it consumed the panel(s) before: they may stay in flight at the first panel switch.  Without it that switch waits
 //           for stores issued a few hundred cycles earlier to be acknowledged (a full HBM write latency with the matrix pipe idle,
 //           once per stashing pass: the training kernels lost a third of their time there).  Use stash_tail<>() of the previous part.
-template <int KT, int MT, bool STASH, int NSIDE_, int PPG, int SHIFT, int PRE, class Side, int NACC, int NIN>
-__device__ __forceinline__ void gemm_wide(f32x16 (&acc)[kTiles][NACC], const uint32_t (&in)[kTiles][NIN], const PanelPipe& pipe, int p0,
-                                          __bf16* const (&stash)[kTiles], const Side& side) {
+template <int KT, int MT, bool STASH, int NSIDE_, int PPG, int SHIFT, int PRE, class Side, class Pipe, int T, int NACC, int NIN>
+__device__ __forceinline__ void gemm_wide(f32x16 (&acc)[T][NACC], const uint32_t (&in)[T][NIN], const Pipe& pipe, int p0,
+                                          __bf16* const (&stash)[T], const Side& side) {
+    constexpr int kTiles = T, PW = Pipe::PW;
 #ifdef NNR_ABLATE_NO_SIDE
     constexpr int NSIDE = 0;   // profiling build only
 #else
@@ -168,7 +179,8 @@ __device__ __forceinline__ void gemm_wide(f32x16 (&acc)[kTiles][NACC], const uin
     // DMA pieces of the panel two ahead, issued per row of the current panel: kDmaBurst at a time right after the switch, so that the
     // last piece has almost two panels (~2 x 2048 matrix-pipe cycles) to land -- one piece per row left the last one barely one
     // panel, less than the L2 -> LDS latency under load: a quarter of the wave cycles sat in the panel switch's s_waitcnt
-    auto ppk_of = [&](int pi) { return (8 + rows_in(pi) - 1) / rows_in(pi) > kDmaBurst ? (8 + rows_in(pi) - 1) / rows_in(pi) : kDmaBurst; };
+    constexpr int kBurst = kDmaBurst < PW ? kDmaBurst : PW;
+    auto ppk_of = [&](int pi) { return (PW + rows_in(pi) - 1) / rows_in(pi) > kBurst ? (PW + rows_in(pi) - 1) / rows_in(pi) : kBurst; };
     pipe.template enter<PRE>(p0);
     pipe.pieces(p0 + 2, 0, ppk_of(0));
     Frags<MT> cur;
@@ -222,7 +234,7 @@ __device__ __forceinline__ void gemm_wide(f32x16 (&acc)[kTiles][NACC], const uin
                 }
             }
         }
-        pin_acc2<MT>(acc);
+        pin_acc2<MT, T>(acc);
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (NSIDE > 0) {
@@ -232,17 +244,17 @@ __device__ __forceinline__ void gemm_wide(f32x16 (&acc)[kTiles][NACC], const uin
     }
 }
 
-template <int KT, int MT, int PRE = 0, int NACC, int NIN>
-__device__ __forceinline__ void gemm_wide(f32x16 (&acc)[kTiles][NACC], const uint32_t (&in)[kTiles][NIN], const PanelPipe& pipe, int p0) {
-    __bf16* const none[kTiles] = {nullptr, nullptr};
+template <int KT, int MT, int PRE = 0, class Pipe, int T, int NACC, int NIN>
+__device__ __forceinline__ void gemm_wide(f32x16 (&acc)[T][NACC], const uint32_t (&in)[T][NIN], const Pipe& pipe, int p0) {
+    __bf16* const none[T] = {};
     gemm_wide<KT, MT, false, 0, 1, 0, PRE>(acc, in, pipe, p0, none, NoSide{});
 }
 
-// stash stores a STASH part (KT x MT tiles) issues while it consumes its LAST panel = the PRE of the part that follows it
-template <int KT, int MT>
+// stash stores a STASH part (KT x MT tiles, T tiles per wave) issues while it consumes its LAST panel = the PRE of the part that follows it
+template <int KT, int MT, int T>
 __device__ __forceinline__ constexpr int stash_tail() {
     constexpr int G = 2 * KT, GP = part_gp(MT), last = G % GP == 0 ? GP : G % GP;
-    return kTiles * last;
+    return T * last;
 }
 
 // ---- chain rule through the encodings: factors in fragment-register order ---------------------------------------------------

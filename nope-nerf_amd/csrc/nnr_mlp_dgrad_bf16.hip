@@ -43,8 +43,11 @@ __device__ __forceinline__ f32x4 enc_chain(const G& g, const f32x4 (&fac)[NR / 4
 
 NNR_TL_DECL(tl_dgrad16)
 
-template <int D>
-__global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) {
+template <int D, int T, int W>
+__global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) {
+    constexpr int kTiles = T;            // 32-sample chunks per wave (nnr_mlp_bf16.h)
+    static_assert(T * W * kChunk == kWideSamples, "a workgroup covers 256 samples per pass");
+    using Pipe = PanelPipeT<W>;
     NNR_STAMP(tl_dgrad16, 0);
     using L = Layout<D, true>;
     constexpr int DT = L::DT, HT = L::HT;
@@ -60,10 +63,10 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) 
     // LDS: the panel ring of the transposed weight stream and the fp32 head tables (density row, rgb rows, register order)
     __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + (L::head_floats + 3) / 4];
     float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4);
-    for (int i = threadIdx.x; i < L::head_floats; i += 256) ltab[i] = a.packed[L::head_base + i];
+    for (int i = threadIdx.x; i < L::head_floats; i += 64 * W) ltab[i] = a.packed[L::head_base + i];
     __syncthreads();   // before any DMA is in flight: the only full barrier of the kernel
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed + L::bwd_base) + wave_u * (8 * 64), smem, wave_u, lane0, L::bwd_panels};
+    Pipe pipe{reinterpret_cast<const f32x4*>(a.packed + L::bwd_base) + wave_u * (Pipe::PW * 64), smem, wave_u, lane0, L::bwd_panels};
     // flat or ray-mode decomposition in pairs of chunks, exactly as in mlp_fwd_bf16_kernel
     const int n_pass = a.chunks_per_ray > 0 ? a.chunks_per_ray : 1;
     const int64_t last_chunk = a.S_pad / kChunk - 1;
@@ -79,8 +82,8 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) 
     const int col = lane & 31;
     const float* const wsig = ltab + half * (16 * DT);   // density row, this half's registers
     const float* const wrgb = ltab + 2 * 16 * DT;        // rgb rows: [(2c + half) * HR + r]
-    const int64_t pair = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * kWavesPerBlock + wave) * n_pass + pass
-                                               : (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    const int64_t pair = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * W + wave) * n_pass + pass
+                                               : (int64_t)blockIdx.x * W + wave;
     int chunk[kTiles];   // chunk index of either tile
     f32x4 dout[kTiles];
 #pragma unroll
@@ -109,11 +112,11 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) 
             for (int w = 0; w < HW; ++w) mw[n][w] = m[w];
         }
     };
-// one epilogue unit u: tile u & 1, packed register (u >> 1) of the half -- dq[tile][OFF + (u >> 1)] = (relu'(.) ? acc : 0) x 2 as bf16
+// one epilogue unit u: tile u % T, packed register u / T of the half -- dq[tile][OFF + u / T] = (relu'(.) ? acc : 0) x 2 as bf16
 // (sign-extended mask bit + and: two instructions per value)
 #define NNR_SEL_UNIT(ACC, OFF, MW)                                                                           \
     [&](int u) __attribute__((always_inline)) {                                                              \
-        const int n = u & 1, p = u >> 1;                                                                     \
+        const int n = u % T, p = u / T;                                                                      \
         float v[2];                                                                                          \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
             const int r = 2 * p + i;                                                                         \
@@ -122,7 +125,8 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) 
         }                                                                                                    \
         dq[n][(OFF) + p] = pack_bf16(v[0], v[1]);                                                            \
     }
-    __bf16* const no_stash[kTiles] = {nullptr, nullptr};
+    __bf16* const no_stash[kTiles] = {};
+    constexpr int PA = 2 * T + 1, PB = 2 * T;   // epilogue units per row of a pass A / pass B (mlp_fwd_bf16_kernel)
 
     // ---- colour branch ----
     // d g = relu'(g) .* (Wc^T d rgb_pre): three FMAs per value against the rgb rows in LDS (a 3-deep GEMM is not MFMA work)
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) 
     load_mask(mwB, 7, 1);
     init_sigma(accB, 1);
     // G = 2 HT rows; unit u writes dq[.][u >> 1] -- not an input of this part
-    gemm_wide<HT, HT, false, NU, NU / (2 * HT), 0, stash_tail<HT, HT>()>(accB, dgq, pipe, p0(B_RGBH_FB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
+    gemm_wide<HT, HT, false, NU, NU / (2 * HT), 0, stash_tail<HT, HT, T>()>(accB, dgq, pipe, p0(B_RGBH_FB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
     {
         // the chain-rule factors are fetched BEFORE the GEMM whose result they multiply: the loads land under it, and the wait for them
         // does not drain the weight DMA issued meanwhile
@@ -208,18 +212,20 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) 
     auto bwd_layer = [&](int pa, __bf16* const (&st)[kTiles], int mask_idx) __attribute__((always_inline)) {
         zero_acc2(accA);
         load_mask(mwA, mask_idx, 0);
-        // pass A: rows [0, G/2) only read dq[.][0, NP); the previous gradient's half B is finished meanwhile (unit u at row u / 5, see
+        // pass A: rows [0, G/2) only read dq[.][0, NP); the previous gradient's half B is finished meanwhile (unit u at row u / PA, see
         // mlp_fwd_bf16_kernel)
-        gemm_wide<DT, HT, true, NU, 5, 0, 0>(accA, dq, pipe, pa, st, NNR_SEL_UNIT(accB, NP, mwB));
+        gemm_wide<DT, HT, true, NU, PA, 0, 0>(accA, dq, pipe, pa, st, NNR_SEL_UNIT(accB, NP, mwB));
         load_mask(mwB, mask_idx, 1);
         zero_acc2(accB);
-        // pass B: half A of the new gradient replaces dq[.][0, NP) in place behind the reads (unit u at row u / 4 + 1)
-        gemm_wide<DT, HT, false, NU, 4, 1, stash_tail<DT, HT>()>(accB, dq, pipe, pa + PP, no_stash, NNR_SEL_UNIT(accA, 0, mwA));
+        // pass B: half A of the new gradient replaces dq[.][0, NP) in place behind the reads (unit u at row u / PB + 1)
+        gemm_wide<DT, HT, false, NU, PB, 1, stash_tail<DT, HT, T>()>(accB, dq, pipe, pa + PP, no_stash, NNR_SEL_UNIT(accA, 0, mwA));
     };
     // hidden 8,7,6 -> d pre-activation of 7,6,5
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
-        __bf16* const st[kTiles] = {dh(7 - l, 0), dh(7 - l, 1)};
+        __bf16* st[kTiles];
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) st[n] = dh(7 - l, n);
         bwd_layer(p0(B_L8A) + 2 * PP * l, st, 6 - l);
     }
     NNR_STAMP(tl_dgrad16, 2);
@@ -227,11 +233,13 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) 
     // is linear in d posenc, so this part's share of d point is formed right away and added to the first layer's at the end.
     f32x4 gp5[kTiles];
     {
-        __bf16* const st[kTiles] = {dh(4, 0), dh(4, 1)};
+        __bf16* st[kTiles];
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) st[n] = dh(4, n);
         f32x16 acce[kTiles][2];
         zero_acc2(acce);
         load_mask(mwA, 3, 0);
-        gemm_wide<DT, 2, true, NU, 5, 0, 0>(acce, dq, pipe, p0(B_L5E), st, NNR_SEL_UNIT(accB, NP, mwB));
+        gemm_wide<DT, 2, true, NU, PA, 0, 0>(acce, dq, pipe, p0(B_L5E), st, NNR_SEL_UNIT(accB, NP, mwB));
 #pragma unroll
         for (int n = 0; n < kTiles; ++n) {   // (64 more live registers during the GEMM would spill: the factors are fetched here)
             f32x4 face[8];
@@ -243,21 +251,25 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs a) 
     zero_acc2(accA);
     gemm_wide<DT, HT>(accA, dq, pipe, p0(B_L5HA));   // (the factor loads above were waited for: nothing of B_L5E is in flight)
     zero_acc2(accB);
-    gemm_wide<DT, HT, false, NU, 4, 1, 0>(accB, dq, pipe, p0(B_L5HB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
+    gemm_wide<DT, HT, false, NU, PB, 1, 0>(accB, dq, pipe, p0(B_L5HB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
     NNR_STAMP(tl_dgrad16, 3);
     // hidden 4,3,2 -> d pre-activation of 3,2,1
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
-        __bf16* const st[kTiles] = {dh(3 - l, 0), dh(3 - l, 1)};
+        __bf16* st[kTiles];
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) st[n] = dh(3 - l, n);
         bwd_layer(p0(B_L4A) + 2 * PP * l, st, 2 - l);
     }
     NNR_STAMP(tl_dgrad16, 4);
     // hidden 1: d posenc = W1^T d1, chain rule through gamma_10, + the skip layer's share -> d point
     {
-        __bf16* const st[kTiles] = {dh(0, 0), dh(0, 1)};
+        __bf16* st[kTiles];
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) st[n] = dh(0, n);
         f32x16 acc2[kTiles][2];
         zero_acc2(acc2);
-        gemm_wide<DT, 2, true, NU, 5, 0, 0>(acc2, dq, pipe, p0(B_L1), st, NNR_SEL_UNIT(accB, NP, mwB));
+        gemm_wide<DT, 2, true, NU, PA, 0, 0>(acc2, dq, pipe, p0(B_L1), st, NNR_SEL_UNIT(accB, NP, mwB));
 #pragma unroll
         for (int n = 0; n < kTiles; ++n) {
             const int64_t sn = sample(n);
@@ -280,18 +292,18 @@ extern "C" int nnr_timeline_dgrad16(unsigned long long* host32) {
 }
 #endif
 
-template <int D>
+template <int D, int T, int W>
 static hipError_t launch(const MlpDgradArgs& a, hipStream_t st) {
     const int64_t per_block = (int64_t)kWideSamples * (a.chunks_per_ray > 0 ? a.chunks_per_ray : 1);
-    dim3 grid((unsigned)((a.S_pad + per_block - 1) / per_block)), block(256);
+    dim3 grid((unsigned)((a.S_pad + per_block - 1) / per_block)), block(64 * W);
     prof_before(PROF_DGRAD, st);
-    hipLaunchKernelGGL((mlp_dgrad_bf16_kernel<D>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((mlp_dgrad_bf16_kernel<D, T, W>), grid, block, 0, st, a);
     prof_after(PROF_DGRAD, st);
     return hipGetLastError();
 }
 
 hipError_t launch_mlp_dgrad_bf16(int D, const MlpDgradArgs& a, hipStream_t st) {
-    return D == 256 ? launch<256>(a, st) : launch<128>(a, st);
+    return D == 256 ? launch<256, kBf16Tiles, kBf16Waves>(a, st) : launch<128, kBf16Tiles, kBf16Waves>(a, st);
 }
 
 }  // namespace nnr

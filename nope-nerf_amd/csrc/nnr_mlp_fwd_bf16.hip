@@ -15,8 +15,11 @@ NNR_TL_DECL(tl_fwd16)
 __device__ unsigned long long tl_fwd16_all[3 * 4096];   // per workgroup: start, end (s_memtime), HW_ID
 #endif
 
-template <int D, bool TRAIN>
-__global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
+template <int D, bool TRAIN, int T, int W>
+__global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
+    constexpr int kTiles = T;            // 32-sample chunks per wave
+    static_assert(T * W * kChunk == kWideSamples, "a workgroup covers 256 samples per pass");
+    using Pipe = PanelPipeT<W>;
     NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 0);
 #ifdef NNR_TIMELINE
     if (TRAIN && threadIdx.x == 0 && blockIdx.x < 4096) {
@@ -36,20 +39,20 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
 
     // LDS: the panel ring, a parking area (per wave and lane 12 x 16 bytes: the packed encodings of both tiles), the fp32 bias / head
     // tables of the packed buffer and the two heads' rows once more as packed bf16 pairs in register order
-    constexpr int kPark = kWavesPerBlock * 12 * 64;
+    constexpr int kPark = W * (6 * T) * 64;   // per wave and tile: 4 + 2 slots of 16 bytes per lane
     constexpr int kHead16 = 2 * NQ + 3 * 2 * NP;   // uint32: density row [half][NQ], rgb rows [c][half][NP]
     __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kPark + (L::table_floats + 3) / 4 + (kHead16 + 3) / 4];
     float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4 + kPark);
     uint32_t* const head16 = reinterpret_cast<uint32_t*>(smem + kNBuf * kPanelF4 + kPark + (L::table_floats + 3) / 4);
-    for (int i = threadIdx.x; i < L::table_floats; i += 256) ltab[i] = a.packed[L::bias_base + i];
+    for (int i = threadIdx.x; i < L::table_floats; i += 64 * W) ltab[i] = a.packed[L::bias_base + i];
     __syncthreads();
     {
         const float* hd = ltab + (L::head_base - L::bias_base);   // [2][16 DT] density row, then [3][2][16 HT] rgb rows, register order
-        for (int i = threadIdx.x; i < kHead16; i += 256) head16[i] = pack_bf16(hd[2 * i], hd[2 * i + 1]);
+        for (int i = threadIdx.x; i < kHead16; i += 64 * W) head16[i] = pack_bf16(hd[2 * i], hd[2 * i + 1]);
     }
     __syncthreads();   // before any DMA is in flight: the last full barrier of the kernel
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave_u * (8 * 64), smem, wave_u, lane0, L::fwd_panels};
+    Pipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave_u * (Pipe::PW * 64), smem, wave_u, lane0, L::fwd_panels};
     // Work decomposition as in mlp_fwd_kernel, in PAIRS of chunks: flat -- workgroup b takes the samples [256 b, 256 b + 256), wave w
     // the 64 from 64 w on; ray mode (a.chunks_per_ray = N / 64 > 0) -- wave w of workgroup b walks the chunk pairs of ray 4 b + w, the
     // weight stream wrapping around from pass to pass.  A chunk index past the end is clamped: the wave recomputes the last chunk and
@@ -68,11 +71,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     pipe.lane = lane;
     const int half = lane >> 5;
     const int col = lane & 31;
-    f32x4* const park = smem + kNBuf * kPanelF4 + wave * (12 * 64) + lane;
+    f32x4* const park = smem + kNBuf * kPanelF4 + wave * (6 * T * 64) + lane;
     const float* bias = ltab - L::bias_base;   // index with L::bias_off(layer)
     const uint32_t* const wsig16 = head16 + half * NQ;
-    const int64_t pair = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * kWavesPerBlock + wave) * n_pass + pass
-                                               : (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    const int64_t pair = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * W + wave) * n_pass + pass
+                                               : (int64_t)blockIdx.x * W + wave;
     int chunk[kTiles];   // chunk index of either tile (< 2^26: S_pad < 2^31)
 #pragma unroll
     for (int n = 0; n < kTiles; ++n) chunk[n] = (int)(kTiles * pair + n < last_chunk ? kTiles * pair + n : last_chunk);
@@ -187,12 +190,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
             }
         }
     };
-// One epilogue unit u: tile u & 1, packed register (u >> 1) of the half -- hq[tile][OFF + (u >> 1)] = (relu(x0), relu(x1)) as bf16.
+// One epilogue unit u: tile u % T, packed register u / T of the half -- hq[tile][OFF + u / T] = (relu(x0), relu(x1)) as bf16.
 // Mask bit r = (x > 0), collected as SIGN bits shifted into the word in register order (v_alignbit_b32); store_mask reverses and
 // inverts the finished word.  The two differ only for x == +0.0 exactly, which has no gradient to pass on either way.
 #define NNR_RELU_UNIT(ACC, OFF, MW)                                                                          \
     [&](int u) __attribute__((always_inline)) {                                                              \
-        const int n = u & 1, p = u >> 1;                                                                     \
+        const int n = u % T, p = u / T;                                                                      \
         const float x0 = ACC[n][(2 * p) >> 4][(2 * p) & 15], x1 = ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]; \
         hq[n][(OFF) + p] = relu_bf16x2(pack_bf16(x0, x1));   /* rounding keeps the sign: relu commutes with it */                                                  \
         if (TRAIN) {                                                                                         \
@@ -201,17 +204,18 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         }                                                                                                    \
     }
     auto p0 = [&](int part) { return L::fwd_panel0(part); };
-    __bf16* const no_stash[kTiles] = {nullptr, nullptr};
+    __bf16* const no_stash[kTiles] = {};
     auto xh = [&](int hidden_idx /*0..7*/, int n) -> __bf16* {
         return TRAIN ? tile_row(a.ws_xh, (int64_t)hidden_idx * a.S_pad + sample(n), D, half) : nullptr;
     };
     constexpr int NU = kTiles * NP;   // epilogue units of one half-output pass
-    constexpr int TAIL = TRAIN ? stash_tail<DT, HT>() : 0;   // stores a stashing D-wide pass leaves in flight for the part after it
+    constexpr int TAIL = TRAIN ? stash_tail<DT, HT, T>() : 0;
+    constexpr int PA = 2 * T + 1, PB = 2 * T;   // epilogue units per row of a pass A (strictly ahead of the reads) / pass B (behind them)   // stores a stashing D-wide pass leaves in flight for the part after it
 
     // ---- hidden 1: 63 -> D, input = posenc.  Pass A, then pass B with A's epilogue hidden under it. ----
     init_acc(accA, L::bias_off(0));
     // (training: the 36 stash stores of the encodings above are younger than every piece of the first two panels)
-    gemm_wide<2, HT, TRAIN ? kTiles * 18 : 0>(accA, eq, pipe, p0(F_L1A));
+    gemm_wide<2, HT, TRAIN ? T * 18 : 0>(accA, eq, pipe, p0(F_L1A));
     init_acc(accB, L::bias_off(0) + L::Dh);
     clear_mask(mwA);
     gemm_wide<2, HT, false, NU, NU / 4, 0, 0>(accB, eq, pipe, p0(F_L1B), no_stash, NNR_RELU_UNIT(accA, 0, mwA));
@@ -223,30 +227,34 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     auto dense_layer = [&](int li, int pa, __bf16* const (&st)[kTiles]) __attribute__((always_inline)) {
         init_acc(accA, L::bias_off(li));
         clear_mask(mwB);
-        // pass A: rows [0, G/2) only read hq[.][0, NP); the previous layer's half B is finished meanwhile, unit u at row u / 5 --
-        // packed register NP + (u >> 1) is first read at row G/2 + (u >> 1) / 4, always a later row
-        gemm_wide<DT, HT, TRAIN, NU, 5, 0, 0>(accA, hq, pipe, pa, st, NNR_RELU_UNIT(accB, NP, mwB));
+        // pass A: rows [0, G/2) only read hq[.][0, NP); the previous layer's half B is finished meanwhile, unit u at row u / PA --
+        // packed register NP + u / T is first read at row G/2 + (u / T) / 4, always a later row (PA = 2 T + 1 units per row)
+        gemm_wide<DT, HT, TRAIN, NU, PA, 0, 0>(accA, hq, pipe, pa, st, NNR_RELU_UNIT(accB, NP, mwB));
         store_mask(mwB, li - 1, 1);
         init_acc(accB, L::bias_off(li) + L::Dh);
         clear_mask(mwA);
-        // pass B: half A of the new layer replaces hq[.][0, NP) in place behind the reads -- unit u runs at row u / 4 + 1, its
-        // register (u >> 1) was last read at row (u >> 1) / 4
-        gemm_wide<DT, HT, false, NU, 4, 1, TAIL>(accB, hq, pipe, pa + PP, no_stash, NNR_RELU_UNIT(accA, 0, mwA));
+        // pass B: half A of the new layer replaces hq[.][0, NP) in place behind the reads -- unit u runs at row u / PB + 1, its
+        // register u / T was last read at row (u / T) / 4
+        gemm_wide<DT, HT, false, NU, PB, 1, TAIL>(accB, hq, pipe, pa + PP, no_stash, NNR_RELU_UNIT(accA, 0, mwA));
         store_mask(mwA, li, 0);
     };
     // hidden 2..4
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
-        __bf16* const st[kTiles] = {xh(l, 0), xh(l, 1)};
+        __bf16* st[kTiles];
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) st[n] = xh(l, n);
         dense_layer(1 + l, p0(F_L2A) + 2 * PP * l, st);
     }
     NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 3);
     // hidden 5: [h4 ; e] -> D   (skip connection, input order [h, posenc]: model/official_nerf.py:63)
     {
-        __bf16* const st[kTiles] = {xh(3, 0), xh(3, 1)};
+        __bf16* st[kTiles];
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) st[n] = xh(3, n);
         init_acc(accA, L::bias_off(4));
         clear_mask(mwB);
-        gemm_wide<DT, HT, TRAIN, NU, 5, 0, 0>(accA, hq, pipe, p0(F_L5HA), st, NNR_RELU_UNIT(accB, NP, mwB));
+        gemm_wide<DT, HT, TRAIN, NU, PA, 0, 0>(accA, hq, pipe, p0(F_L5HA), st, NNR_RELU_UNIT(accB, NP, mwB));
         store_mask(mwB, 3, 1);
 #pragma unroll
         for (int n = 0; n < kTiles; ++n)
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         gemm_wide<2, HT, TAIL>(accA, eq, pipe, p0(F_L5EA));
         init_acc(accB, L::bias_off(4) + L::Dh);
         clear_mask(mwA);
-        gemm_wide<DT, HT, false, NU, 4, 1, 0>(accB, hq, pipe, p0(F_L5HB), no_stash, NNR_RELU_UNIT(accA, 0, mwA));
+        gemm_wide<DT, HT, false, NU, PB, 1, 0>(accB, hq, pipe, p0(F_L5HB), no_stash, NNR_RELU_UNIT(accA, 0, mwA));
         gemm_wide<2, HT>(accB, eq, pipe, p0(F_L5EB));
         store_mask(mwA, 4, 0);
     }
@@ -267,7 +275,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     // hidden 6..8
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
-        __bf16* const st[kTiles] = {xh(4 + l, 0), xh(4 + l, 1)};
+        __bf16* st[kTiles];
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) st[n] = xh(4 + l, n);
         dense_layer(5 + l, p0(F_L6A) + 2 * PP * l, st);
     }
     NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 5);
@@ -275,9 +285,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     // colour hidden: g = relu(W' h8 + Wg[:, D:] gamma_4(v) + b'), the feature layer folded in by the pack kernel (nnr_layout.h); one
     // pass (D/2 outputs).  Its side work first finishes hidden 8 (half B), then evaluates the density head: a per-lane dot product
     // of the packed h8 with the packed density row, four registers per unit.
-    float sg[kTiles][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float sg[kTiles][2] = {};
     {
-        __bf16* const st[kTiles] = {xh(7, 0), xh(7, 1)};
+        __bf16* st[kTiles];
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) st[n] = xh(7, n);
         init_acc(accA, L::bias_off(10));
         clear_mask(mwB);
         auto finish_then_sigma = [&](int u) __attribute__((always_inline)) {
@@ -292,8 +304,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
                     for (int i = 0; i < 4; ++i) dot2_bf16(sg[n][i & 1], hq[n][4 * v + i], w4[i]);
             }
         };
-        // 5 units per row: finishing unit u (register NP + (u >> 1), first read at row G/2 + (u >> 1) / 4) runs at row u / 5
-        gemm_wide<DT, HT, TRAIN, NU + NQ / 4, 5, 0, 0>(accA, hq, pipe, p0(F_RGBH_F), st, finish_then_sigma);
+        // all units spread evenly over the rows: finishing unit u (register NP + u / T, first read at row G/2 + (u / T) / 4) runs
+        // well before that row
+        gemm_wide<DT, HT, TRAIN, NU + NQ / 4, (NU + NQ / 4 + 2 * DT - 1) / (2 * DT), 0, 0>(accA, hq, pipe, p0(F_RGBH_F), st, finish_then_sigma);
         store_mask(mwB, 7, 1);
     }
     NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 6);
@@ -397,20 +410,20 @@ extern "C" int nnr_timeline_fwd16(unsigned long long* host32) {
 }
 #endif
 
-template <int D>
+template <int D, int T, int W>
 static hipError_t launch(const MlpFwdArgs& a, bool train, hipStream_t st) {
-    // ray mode: one workgroup per 4 rays, chunks_per_ray passes of 64 samples each; flat: one workgroup per 256 samples
+    // ray mode: one workgroup per W rays, chunks_per_ray passes of 32 T samples each; flat: one workgroup per 256 samples
     const int64_t per_block = (int64_t)kWideSamples * (a.chunks_per_ray > 0 ? a.chunks_per_ray : 1);
-    dim3 grid((unsigned)((a.S_pad + per_block - 1) / per_block)), block(256);
+    dim3 grid((unsigned)((a.S_pad + per_block - 1) / per_block)), block(64 * W);
     prof_before(train ? PROF_FWD_TRAIN : PROF_FWD_INFER, st);
-    if (train) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<D, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<D, false>), grid, block, 0, st, a);
+    if (train) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<D, true, T, W>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<D, false, T, W>), grid, block, 0, st, a);
     prof_after(train ? PROF_FWD_TRAIN : PROF_FWD_INFER, st);
     return hipGetLastError();
 }
 
 hipError_t launch_mlp_fwd_bf16(int D, const MlpFwdArgs& a, bool train, hipStream_t st) {
-    return D == 256 ? launch<256>(a, train, st) : launch<128>(a, train, st);
+    return D == 256 ? launch<256, kBf16Tiles, kBf16Waves>(a, train, st) : launch<128, kBf16Tiles, kBf16Waves>(a, train, st);
 }
 
 }  // namespace nnr
