@@ -11,6 +11,16 @@
 namespace nnr {
 
 NNR_TL_DECL(tl_fwd16)
+#ifdef NNR_ABLATE_NO_MASK
+constexpr bool kAblateMask = true;    // profiling builds only
+#else
+constexpr bool kAblateMask = false;
+#endif
+#ifdef NNR_ABLATE_NO_ENCSTASH
+constexpr bool kAblateEncStash = true;
+#else
+constexpr bool kAblateEncStash = false;
+#endif
 #ifdef NNR_TIMELINE
 __device__ unsigned long long tl_fwd16_all[3 * 4096];   // per workgroup: start, end (s_memtime), HW_ID
 #endif
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
             park[(6 * n + 4 + q) * 64] = __builtin_bit_cast(f32x4, u32x4{dq[4 * q], dq[4 * q + 1], dq[4 * q + 2], dq[4 * q + 3]});
-        if constexpr (TRAIN) {
+        if constexpr (TRAIN && !kAblateEncStash) {
             // the chain-rule factors of both encodings in register order for the input-gradient kernel (enc_factor, nnr_mlp_bf16.h),
             // and tile-major bf16 copies of the encodings = the MFMA operands, for the weight-gradient kernel
             float es[32], ds[16];
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
             for (int w = 0; w < HW; ++w) mw[n][w] = 0;
     };
     auto store_mask = [&](const uint32_t(&mw)[kTiles][HW], int layer_idx, int hb) __attribute__((always_inline)) {
-        if (TRAIN) {
+        if (TRAIN && !kAblateMask) {
 #pragma unroll
             for (int n = 0; n < kTiles; ++n) {
                 // masks: [chunk][layer][lane][mask_words]; half A of a layer owns the low words, half B the high words.  An ordinary
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         const int n = u % T, p = u / T;                                                                      \
         const float x0 = ACC[n][(2 * p) >> 4][(2 * p) & 15], x1 = ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]; \
         hq[n][(OFF) + p] = relu_bf16x2(pack_bf16(x0, x1));   /* rounding keeps the sign: relu commutes with it */                                                  \
-        if (TRAIN) {                                                                                         \
+        if (TRAIN && !kAblateMask) {                                                                         \
             MW[n][p >> 4] = __builtin_amdgcn_alignbit(MW[n][p >> 4], __float_as_uint(x0), 31);               \
             MW[n][p >> 4] = __builtin_amdgcn_alignbit(MW[n][p >> 4], __float_as_uint(x1), 31);               \
         }                                                                                                    \
