@@ -120,7 +120,7 @@ def build_trainer(device, world, aux=False, bf16=False, rays_per_gpu=None, n_sam
 _TRAFFIC_FILES = ('profiles/r02/hbm_traffic.json', 'profiles/r02/hbm_traffic_bf16_4096x128.json')
 _KERNEL_KEYS = {
     False: {'mlp_fwd': 'mlp_fwd_kernel<256, true>', 'mlp_dgrad': 'mlp_dgrad_kernel<256>', 'mlp_wgrad': 'nnr::wgrad_kernel('},
-    True: {'mlp_fwd': 'mlp_fwd_bf16_kernel<256, true>', 'mlp_dgrad': 'mlp_dgrad_bf16_kernel<256>', 'mlp_wgrad': 'wgrad_b_kernel'},
+    True: {'mlp_fwd': 'mlp_fwd_bf16_kernel<256, true,', 'mlp_dgrad': 'mlp_dgrad_bf16_kernel<256,', 'mlp_wgrad': 'wgrad_b_kernel'},
 }
 
 

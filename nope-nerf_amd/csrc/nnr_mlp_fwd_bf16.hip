@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     gemm_wide<2, HT, TRAIN ? T * 18 : 0>(accA, eq, pipe, p0(F_L1A));
     init_acc(accB, L::bias_off(0) + L::Dh);
     clear_mask(mwA);
-    gemm_wide<2, HT, false, NU, NU / 4, 0, 0>(accB, eq, pipe, p0(F_L1B), no_stash, NNR_RELU_UNIT(accA, 0, mwA));
+    gemm_wide<2, HT, false, NU, NU / 4, 0, TRAIN ? T * 18 : 0>(accB, eq, pipe, p0(F_L1B), no_stash, NNR_RELU_UNIT(accA, 0, mwA));   // (the same stores are younger than panel 1's pieces too)
     store_mask(mwA, 0, 0);
     NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 2);
     // Invariant from here on: hq[.][0, NP) holds half A of the newest layer, accB holds its half B still to be finished.
