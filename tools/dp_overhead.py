@@ -3,7 +3,10 @@
 flat gradient bucket, an all-reduce issued on a real one-rank RCCL group (launch cost without link time) and the copy-back.
 The driver measures the real N-GPU runs; this isolates the host/launch overhead we control.
 
-    python tools/dp_overhead.py [--world 8] [--steps 40]"""
+    python tools/dp_overhead.py [--world 8] [--steps 40] [--aux]
+
+--aux: with the first-phase per-image losses on (point cloud + surface reprojection).  Their block is sharded by source points
+(nnr_aux_cfg.shard_lo / shard_hi): the extra time of a rank over its aux-free step should fall as 1 / W."""
 import argparse
 import json
 import os
@@ -36,11 +39,12 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--rank", type=int, default=0, help="which rank of the virtual job this process plays")
     ap.add_argument("--skip-single", action="store_true", help="only the virtual-rank run (for a kernel trace of it)")
+    ap.add_argument("--aux", action="store_true", help="first-phase per-image losses on")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     data = bench.synthetic_batch(dev)
-    trainer, _ = bench.build_trainer(dev, 1)
+    trainer, _ = bench.build_trainer(dev, 1, a.aux)
     single = float('nan') if a.skip_single else timed(trainer, data, a.steps)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
@@ -48,8 +52,8 @@ if __name__ == "__main__":
     from nnr import parallel
     parallel.world_size = lambda: a.world
     parallel.rank = lambda: a.rank
-    trainer, _ = bench.build_trainer(dev, a.world)
+    trainer, _ = bench.build_trainer(dev, a.world, a.aux)
     virtual = timed(trainer, data, a.steps)
-    print(json.dumps({"world": a.world, "single_ms": round(single, 4), "virtual_rank": a.rank, "virtual_rank_ms": round(virtual, 4),
+    print(json.dumps({"aux": a.aux, "world": a.world, "single_ms": round(single, 4), "virtual_rank": a.rank, "virtual_rank_ms": round(virtual, 4),
                       "overhead_ms": round(virtual - single, 4), "overhead_frac": round(virtual / single - 1, 4)}))
     dist.destroy_process_group()
