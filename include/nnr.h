@@ -41,13 +41,14 @@ extern "C" {
 #define NNR_F_WHITE_BG 2u   /* rendering.white_background (model/rendering.py:145-147) */
 #define NNR_F_RELU_SIGMA 4u /* model.occ_activation != 'softplus' (model/official_nerf.py:77-80) */
 #define NNR_F_TRAIN 8u      /* keep what the backward needs (activation stash, ReLU masks) */
-#define NNR_F_BF16 16u      /* bf16 MFMA products with fp32 accumulation in the three MLP kernels (BASELINE configs[2]); bias,
-                             * activations between layers and every reduction stay fp32.  The packed-weight buffer has its
-                             * own size and layout in this mode (nnr_packed_floats), and so has a TRAINING workspace
-                             * (nnr_workspace_floats): the hidden-activation planes 11..18, 20 and their gradient planes
-                             * 31..38, 40 hold bf16 elements -- the values the MFMAs consumed, the two middle quads of every 16
-                             * features swapped -- so nnr_ws_plane reports a pitch of half the feature
-                             * count for them; all other planes stay fp32. */
+#define NNR_F_BF16 16u      /* every nn.Linear as a bf16 x bf16 product with fp32 accumulation in the three MLP kernels (BASELINE
+                             * configs[2]); biases, activation functions, compositing and every reduction stay fp32.  The
+                             * packed-weight buffer has its own size and layout in this mode (nnr_packed_floats), and so has a
+                             * TRAINING workspace (nnr_workspace_floats): the hidden-activation planes 11..18, 20, the encodings'
+                             * copies 21, 22 and the gradient planes 31..38, 40 hold bf16 elements -- the values the MFMAs
+                             * consumed -- in TILE-MAJOR order (1 KiB blocks [chunk of 32 samples][16 features], DESIGN.md
+                             * section 3); nnr_ws_plane reports a pitch of half the feature count for them.  Planes 10 and 19 hold
+                             * the chain-rule factors of the encodings in register order; all other planes are as in fp32. */
 
 /* Problem description.  POD, passed by pointer, read on the host only. */
 typedef struct nnr_cfg {

@@ -198,10 +198,10 @@ struct WsLayout {
     int64_t S, S_pad;
     int D;
     bool train;
-    bool bf16 = false;   // NNR_F_BF16 training: the operands of the weight-gradient products that the MFMAs consume as bf16 anyway
-                         // -- hidden activations (P_XH1.., P_XG) and pre-activation gradients (P_DH1.., P_DG) -- are STORED as
-                         // bf16, the two middle quads of every 16 features swapped (stash_row in nnr_device.h; pitch below =
-                         // floats per row = elements / 2); encodings, masks and the 4-wide planes stay fp32
+    bool bf16 = false;   // NNR_F_BF16 training: the operands of the weight-gradient products -- hidden activations (P_XH1.., P_XG),
+                         // the encodings' copies (P_XE16, P_XF16) and the pre-activation gradients (P_DH1.., P_DG) -- are tile-major
+                         // bf16 planes (see above; pitch below = floats per sample = elements / 2); P_XE / P_XF hold the fp32
+                         // chain-rule factors in register order; masks and the 4-wide planes are as in the fp32 mode
     NNR_HD int64_t plane(int p, int* pitch) const {
         int64_t o = 0;
         int w = 0;
