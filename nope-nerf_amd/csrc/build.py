@@ -10,7 +10,19 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(os.path.dirname(HERE), "nnr", "libnnr.so")
-SOURCES = ["nnr_api.cpp", "nnr_pack.hip", "nnr_mlp_fwd.hip", "nnr_mlp_dgrad.hip", "nnr_mlp_fwd_bf16.hip", "nnr_mlp_dgrad_bf16.hip", "nnr_wgrad.hip", "nnr_wgrad_bf16.hip", "nnr_composite.hip", "nnr_camera.hip", "nnr_pointcloud.hip", "nnr_aux.hip", "nnr_randperm.hip"]
+# (source, defines): the two fp32 MLP kernels are compiled one template instantiation per translation unit -- each is minutes of hipcc
+# time (straight-line code of ~8 000 MFMAs), in one unit the forward alone took 8.5 minutes; the longest unit first
+SOURCES = [("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1")), ("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=0")),
+           ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=256",)), ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=1")),
+           ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=0")), ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=128",)),
+           ("nnr_mlp_fwd_bf16.hip", ()), ("nnr_mlp_dgrad_bf16.hip", ()), ("nnr_mlp_fwd.hip", ()), ("nnr_mlp_dgrad.hip", ()),
+           ("nnr_api.cpp", ()), ("nnr_pack.hip", ()), ("nnr_wgrad.hip", ()), ("nnr_wgrad_bf16.hip", ()), ("nnr_composite.hip", ()),
+           ("nnr_camera.hip", ()), ("nnr_pointcloud.hip", ()), ("nnr_aux.hip", ()), ("nnr_randperm.hip", ())]
+
+
+def _obj_name(src, defines):
+    tag = "".join("_" + d.split("=")[0].lower().replace("nnr_", "") + d.split("=")[1] for d in defines)
+    return os.path.splitext(src)[0] + tag + ".o"
 HEADERS = ["nnr_layout.h", "nnr_device.h", "nnr_kernels.h", "nnr_mlp_bf16.h", os.path.join("..", "..", "include", "nnr.h")]
 # -pragma-unroll-threshold: the MLP kernels are straight-line code by construction (every `#pragma unroll` loop must unroll fully, or
 # the register arrays they index fall back to scratch memory).  LLVM caps `#pragma unroll` at 16 K instructions per loop; one GEMM part
@@ -40,6 +52,9 @@ def check_resources(remarks, what):
         raise RuntimeError("%s: a hot kernel uses scratch memory -- a loop did not unroll or registers spilled:\n  " % what + "\n  ".join(bad))
 
 
+WORKERS = max(2, min(12, (os.cpu_count() or 4)))
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -52,13 +67,21 @@ def build_variant(name, defines):
     Written to nnr/libnnr_<name>.so and selected with NNR_LIB=<path> (see nnr/lib.py)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = os.path.join(os.path.dirname(HERE), "nnr", "libnnr_%s.so" % name)
-    cmd = [hipcc] + [f for f in FLAGS if f not in ("-x", "hip")] + ["-D" + d for d in defines] + ["-shared", "-x", "hip"] + \
-          [os.path.join(HERE, s) for s in SOURCES] + ["-o", out]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(r.stderr)
-    if not any(d.startswith("NNR_ABLATE") or d == "NNR_TIMELINE" for d in defines):
-        check_resources(r.stderr, name)
+    tmp = os.path.join(OUT_DIR, "variant_" + name)
+    os.makedirs(tmp, exist_ok=True)
+    jobs = [[hipcc] + FLAGS + ["-D" + d for d in list(defines) + list(extra)] + ["-c", os.path.join(HERE, src), "-o", os.path.join(tmp, _obj_name(src, extra))]
+            for src, extra in SOURCES]
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr)
+        if not any(d.startswith("NNR_ABLATE") or d == "NNR_TIMELINE" for d in defines):
+            check_resources(r.stderr, name)
+
+    with ThreadPoolExecutor(max_workers=WORKERS) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [j[-1] for j in jobs])
     return out
 
 
@@ -67,10 +90,10 @@ def build(force=False, verbose=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     jobs = []
-    for src in SOURCES:
-        obj = os.path.join(OUT_DIR, os.path.splitext(src)[0] + ".o")
+    for src, defines in SOURCES:
+        obj = os.path.join(OUT_DIR, _obj_name(src, defines))
         if force or _stale(obj, [os.path.join(HERE, src)] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj])
+            jobs.append([hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(HERE, src), "-o", obj])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -87,9 +110,9 @@ def build(force=False, verbose=False):
             if other:
                 print(other, file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(WORKERS, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(OUT_DIR, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+    objs = [os.path.join(OUT_DIR, _obj_name(src, defines)) for src, defines in SOURCES]
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

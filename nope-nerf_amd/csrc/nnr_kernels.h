@@ -179,6 +179,8 @@ hipError_t launch_randperm_prefix(const int64_t* keys, int64_t n, int bits, int 
                                   int64_t* out, unsigned int* scratch, hipStream_t st);
 hipError_t launch_pack(int D, const PackArgs& a, bool bf16, hipStream_t st);
 hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st);                 // fp32 products
+template <int D, bool TRAIN> hipError_t launch_mlp_fwd_variant(const MlpFwdArgs& a, hipStream_t st);   // one translation unit each
+template <int D> hipError_t launch_mlp_dgrad_variant(const MlpDgradArgs& a, hipStream_t st);
 hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st);
 hipError_t launch_mlp_fwd_bf16(int D, const MlpFwdArgs& a, bool train, hipStream_t st);     // nnr_mlp_fwd_bf16.hip
 hipError_t launch_mlp_dgrad_bf16(int D, const MlpDgradArgs& a, hipStream_t st);              // nnr_mlp_dgrad_bf16.hip

@@ -237,23 +237,26 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     }   // pass
 }
 
-#ifdef NNR_TIMELINE
+#if defined(NNR_TIMELINE) && defined(NNR_DGRAD_D) && NNR_DGRAD_D == 256
 extern "C" int nnr_timeline_dgrad(unsigned long long* host32) {
     return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_dgrad), 32 * sizeof(unsigned long long));
 }
 #endif
 
-template <int D>
-static hipError_t launch(const MlpDgradArgs& a, hipStream_t st) {
+// one D per translation unit, see nnr_mlp_fwd.hip
+#ifdef NNR_DGRAD_D
+template <>
+hipError_t launch_mlp_dgrad_variant<NNR_DGRAD_D>(const MlpDgradArgs& a, hipStream_t st) {
     dim3 grid((unsigned)(a.chunks_per_ray > 0 ? a.S_pad / kBlockSamples / a.chunks_per_ray : a.S_pad / kBlockSamples)), block(256);
     prof_before(PROF_DGRAD, st);
-    hipLaunchKernelGGL((mlp_dgrad_kernel<D>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((mlp_dgrad_kernel<NNR_DGRAD_D>), grid, block, 0, st, a);
     prof_after(PROF_DGRAD, st);
     return hipGetLastError();
 }
-
+#else
 hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st) {
-    return D == 256 ? launch<256>(a, st) : launch<128>(a, st);
+    return D == 256 ? launch_mlp_dgrad_variant<256>(a, st) : launch_mlp_dgrad_variant<128>(a, st);
 }
+#endif
 
 }  // namespace nnr

@@ -319,25 +319,31 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     }   // pass
 }
 
-#ifdef NNR_TIMELINE
+#if defined(NNR_TIMELINE) && defined(NNR_FWD_D) && NNR_FWD_D == 256 && NNR_FWD_TRAIN
 extern "C" int nnr_timeline_fwd(unsigned long long* host32) {
     return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_fwd), 32 * sizeof(unsigned long long));
 }
 #endif
 
-template <int D>
-static hipError_t launch(const MlpFwdArgs& a, bool train, hipStream_t st) {
+// One (D, TRAIN) instantiation per translation unit: the kernel is ~8 000 MFMAs of straight-line code and hipcc spends minutes on each;
+// csrc/build.py compiles this file once per variant (-DNNR_FWD_D=.. -DNNR_FWD_TRAIN=..) in parallel and once without the macros
+// for the dispatcher below.
+#ifdef NNR_FWD_D
+template <>
+hipError_t launch_mlp_fwd_variant<NNR_FWD_D, (NNR_FWD_TRAIN != 0)>(const MlpFwdArgs& a, hipStream_t st) {
     // ray mode: one workgroup per 4 rays, chunks_per_ray passes each; flat mode: one workgroup per 128 samples
     dim3 grid((unsigned)(a.chunks_per_ray > 0 ? a.S_pad / kBlockSamples / a.chunks_per_ray : a.S_pad / kBlockSamples)), block(256);
+    constexpr bool train = NNR_FWD_TRAIN != 0;
     prof_before(train ? PROF_FWD_TRAIN : PROF_FWD_INFER, st);
-    if (train) hipLaunchKernelGGL((mlp_fwd_kernel<D, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((mlp_fwd_kernel<D, false>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((mlp_fwd_kernel<NNR_FWD_D, train>), grid, block, 0, st, a);
     prof_after(train ? PROF_FWD_TRAIN : PROF_FWD_INFER, st);
     return hipGetLastError();
 }
-
+#else
 hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st) {
-    return D == 256 ? launch<256>(a, train, st) : launch<128>(a, train, st);
+    if (D == 256) return train ? launch_mlp_fwd_variant<256, true>(a, st) : launch_mlp_fwd_variant<256, false>(a, st);
+    return train ? launch_mlp_fwd_variant<128, true>(a, st) : launch_mlp_fwd_variant<128, false>(a, st);
 }
+#endif
 
 }  // namespace nnr
