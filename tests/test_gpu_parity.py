@@ -444,6 +444,7 @@ def _render_bf16_oracle(params, o, d, v, lo, hi, jit, *, dist_alpha, white_bg, r
     (256, 33, 65, False, True, True, True),      # white background, ReLU density; 2145 samples = 17 workgroups, the last one ragged
     (256, 5, 130, True, True, False, False),     # no jitter, long rays
     (256, 8, 128, False, False, False, True),    # ray mode (N % 64 == 0, R % 4 == 0): two passes per wave, the weight stream wraps
+    (128, 8, 192, True, True, False, True),      # ray mode at D = 128: three passes per wave (one panel per pass in that layout)
     (128, 129, 3, False, False, True, True),     # more rays than a wave, three samples each
 ])
 def test_bf16_ragged_shapes_and_every_flag_against_the_bf16_oracle(D, R, N, dist_alpha, white_bg, relu_sigma, jittered):
