@@ -242,6 +242,7 @@ size_t plan_bytes(const Plan& p) { return p.jobs.size() * sizeof(WgradJob) + p.w
 // crosses a unit boundary becomes two jobs).  Outputs = where the rectangles of a unit's product go.
 struct BUnit {
     int d_plane, d_g0, d_groups, x_plane, x_g0, x_groups, MT, NT, WR, WC, bias;
+    int x2_plane = -1, x2_groups = 0;     // a second activation plane behind the first (x_groups even): one pass over the gradient
 };
 struct BPlan {
     std::vector<WgradJobB> jobs;
@@ -252,6 +253,8 @@ struct BPlan {
 void bf16_units(int D, std::vector<BUnit>& units, std::vector<WgradOutB>& outs) {
     const int G = D / 16, Gh = D / 32;            // groups of a D-wide / D/2-wide plane
     const bool big = D == 256;
+    static const bool no_merge = std::getenv("NNR_WGRAD_NO_MERGE") != nullptr;   // profiling knob: the two-plane units as separate passes
+    const bool merge = big && !no_merge;
     auto out = [&](int unit, int layer, int d_row, int n_rows, int w_row, int x_col, int n_cols, int w_col, int ldw, int bias) {
         const BUnit& u = units[unit];
         outs.push_back(WgradOutB{unit, layer, d_row, n_rows, w_row, x_col, n_cols, w_col, ldw, bias, -1, u.MT, u.NT, u.WR, u.WC, 0});
@@ -268,19 +271,32 @@ void bf16_units(int D, std::vector<BUnit>& units, std::vector<WgradOutB>& outs) 
     dxd(1, P_DH1 + 1, P_XH1 + 0, D);
     dxd(2, P_DH1 + 2, P_XH1 + 1, D);
     dxd(3, P_DH1 + 3, P_XH1 + 2, D);
-    dxd(4, P_DH1 + 4, P_XH1 + 3, D + kPosReal);
-    dxe(4, P_DH1 + 4, D, D + kPosReal, 0);
+    if (merge) {      // skip layer, input = hidden 4 | position encoding: 8 x 10 tiles as four waves of 4 x 5, the gradient read once
+        units.push_back(BUnit{P_DH1 + 4, 0, G, P_XH1 + 3, 0, G, 4, 5, 2, 2, 1, P_XE16, kPosPad / 16});
+        out((int)units.size() - 1, 4, 0, D, 0, 0, D, 0, D + kPosReal, 1);
+        out((int)units.size() - 1, 4, 0, D, 0, D, kPosReal, D, D + kPosReal, 0);
+    } else {
+        dxd(4, P_DH1 + 4, P_XH1 + 3, D + kPosReal);
+        dxe(4, P_DH1 + 4, D, D + kPosReal, 0);
+    }
     dxd(5, P_DH1 + 5, P_XH1 + 4, D);
     dxd(6, P_DH1 + 6, P_XH1 + 5, D);
     dxd(7, P_DH1 + 7, P_XH1 + 6, D);
     // merged colour-hidden matrix W' (D/2 x D) and the density row: gradient operand = P_DG groups 0..Gh (the last group holds
-    // d rgb_pre[0..2], d sigma_raw), activation operand = hidden 8
-    units.push_back(BUnit{P_DG, 0, Gh + 1, P_XH1 + 7, 0, G, big ? 5 : 3, big ? 2 : 1, 1, 4, 1});
-    out((int)units.size() - 1, kMergedLayer, 0, D / 2, 0, 0, D, 0, D, 1);
-    out((int)units.size() - 1, 8, D / 2 + 3, 1, 0, 0, D, 0, D, 1);
-    // direction-encoding columns of the colour-hidden layer
-    units.push_back(BUnit{P_DG, 0, Gh, P_XF16, 0, kDirPad / 16, 1, 1, big ? 4 : 2, 1, 0});
-    out((int)units.size() - 1, 10, 0, D / 2, 0, 0, kDirReal, D, D + kDirReal, 0);
+    // d rgb_pre[0..2], d sigma_raw), activation operand = hidden 8; the direction-encoding columns of the colour-hidden layer are
+    // the same gradient against the encoding
+    if (merge) {      // 5 x 9 tiles: three waves of 5 x 3 (the fourth only moves data)
+        units.push_back(BUnit{P_DG, 0, Gh + 1, P_XH1 + 7, 0, G, 5, 3, 1, 3, 1, P_XF16, kDirPad / 16});
+        out((int)units.size() - 1, kMergedLayer, 0, D / 2, 0, 0, D, 0, D, 1);
+        out((int)units.size() - 1, 8, D / 2 + 3, 1, 0, 0, D, 0, D, 1);
+        out((int)units.size() - 1, 10, 0, D / 2, 0, D, kDirReal, D, D + kDirReal, 0);
+    } else {
+        units.push_back(BUnit{P_DG, 0, Gh + 1, P_XH1 + 7, 0, G, big ? 5 : 3, big ? 2 : 1, 1, 4, 1});
+        out((int)units.size() - 1, kMergedLayer, 0, D / 2, 0, 0, D, 0, D, 1);
+        out((int)units.size() - 1, 8, D / 2 + 3, 1, 0, 0, D, 0, D, 1);
+        units.push_back(BUnit{P_DG, 0, Gh, P_XF16, 0, kDirPad / 16, 1, 1, big ? 4 : 2, 1, 0});
+        out((int)units.size() - 1, 10, 0, D / 2, 0, 0, kDirReal, D, D + kDirReal, 0);
+    }
     // rgb head: the 3 output-gradient rows against the colour-hidden activations
     units.push_back(BUnit{P_DG, Gh, 1, P_XG, 0, Gh, 1, 1, 1, big ? 4 : 2, 1});
     out((int)units.size() - 1, 11, 0, 3, 0, 0, D / 2, 0, D / 2, 1);
@@ -296,7 +312,7 @@ BPlan build_plan_bf16(const nnr_cfg* c) {
     const int64_t chunks = w.S_pad / 32;
     std::vector<int64_t> cost(units.size()), start(units.size() + 1, 0);
     for (size_t u = 0; u < units.size(); ++u) {
-        cost[u] = units[u].d_groups + units[u].x_groups;
+        cost[u] = units[u].d_groups + units[u].x_groups + units[u].x2_groups;
         start[u + 1] = start[u] + cost[u] * chunks;
     }
     const int64_t tape = start[units.size()];
@@ -320,9 +336,12 @@ BPlan build_plan_bf16(const nnr_cfg* c) {
             if (c1 <= c0) continue;
             const BUnit& un = units[u];
             int dp = 0, xp = 0;
+            int x2p = 0;
             const int64_t d_off = w.plane(un.d_plane, &dp), x_off = w.plane(un.x_plane, &xp);   // floats; pitch = floats per sample
+            const int64_t x2_off = un.x2_groups ? w.plane(un.x2_plane, &x2p) : 0;
             p.jobs.push_back(WgradJobB{4 * d_off + 1024ll * un.d_g0, 4 * x_off + 1024ll * un.x_g0, 4 * 32 * dp, 4 * 32 * xp, un.d_groups,
-                                       un.x_groups, (int32_t)u, un.MT, un.NT, un.WR, un.WC, (int32_t)c0, (int32_t)c1, un.bias, 0, -1});
+                                       un.x_groups, (int32_t)u, un.MT, un.NT, un.WR, un.WC, (int32_t)c0, (int32_t)c1, un.bias, 0, -1,
+                                       4 * x2_off, 4 * 32 * x2p, un.x2_groups});
         }
         p.block_first.push_back((int32_t)p.jobs.size());
     }

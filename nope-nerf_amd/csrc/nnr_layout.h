@@ -256,8 +256,9 @@ struct WgradJob {
     int32_t reserved;
 };
 // ---- weight-gradient plan of the bf16 mode: one entry per WORKGROUP job (nnr_wgrad_bf16.hip) --------------------------------
-// A job streams the 32-sample chunks [c0, c1) of two tile-major planes -- d_groups consecutive blocks per chunk of the gradient
-// operand, x_groups of the activation operand -- through LDS; wave w < WR * WC owns the MT x NT MFMA tiles (32 x 32)
+// A job streams the 32-sample chunks [c0, c1) of two or three tile-major planes -- d_groups consecutive blocks per chunk of the
+// gradient operand, x_groups of the activation operand, then x2_groups of a second activation plane that continues the first one's
+// feature axis (the skip layer's input = hidden | position encoding: one pass over the gradient for both) -- through LDS; wave w < WR * WC owns the MT x NT MFMA tiles (32 x 32)
 // at tile row MT * (w / WC), tile column NT * (w % WC) of  dW_unit[d feature][x feature] = sum_s Dlt[s][d] X[s][x], keeps them in
 // accumulators for the whole range and writes them to its slot (4 * job + w); waves of tile column 0 also sum the gradient
 // operand over the samples (d bias).  Feature i of tile t is feature 32 t + i of the staged groups, in natural order.
@@ -270,6 +271,8 @@ struct WgradJobB {
     int32_t c0, c1;                     // chunk range
     int32_t bias;                       // 1: tile-column-0 waves reduce d(bias)
     int32_t split, next_split;          // position in the chain of the unit's jobs (sample order), next job or -1
+    int64_t x2_base;                    // second activation plane (x2_groups = 0: none); x_groups is even when it is used
+    int32_t x2_stride, x2_groups;
 };
 // one destination rectangle of a unit: rows [d_row, d_row + n_rows) x columns [x_col, x_col + n_cols) of the unit's product (feature
 // offsets relative to the staged groups) go to W[layer][w_row + ..][w_col + ..]; bias rows likewise when `bias`
@@ -284,7 +287,8 @@ struct WgradOutB {
 };
 constexpr int kSlotBTile = 32 * 32;     // floats per MFMA tile in a slot, row-major
 // slot of (job, wave): [MT * NT tiles][32][32] floats, then [MT][2 k-step halves][32] bias partials; fixed pitch for every shape
-constexpr int kSlotBFloats = 16 * kSlotBTile + 5 * 2 * 32;
+constexpr int kSlotBMaxTiles = 20;      // the widest wave tiling: 4 x 5
+constexpr int kSlotBFloats = kSlotBMaxTiles * kSlotBTile + 5 * 2 * 32;
 
 // partial slot of job i: floats [i*kSlotFloats, (i+1)*kSlotFloats) of the slot region = tile (32*MI rows x 32*NI cols,
 // row-major, pitch 32*NI) followed by the two half-wave bias partials [2][32*MI]

@@ -29,11 +29,11 @@
 
 namespace nnr {
 
-#ifndef NNR_WB_NSTAGE
-#define NNR_WB_NSTAGE 4
+#ifndef NNR_WB_RING_KIB
+#define NNR_WB_RING_KIB 144
 #endif
-constexpr int kStageBytes = 32 * 1024;      // up to 32 blocks of 1 KiB per stage
-constexpr int kRingBytes = NNR_WB_NSTAGE * kStageBytes;   // the LDS ring: as many stages as fit (4 of the widest unit's, 14 of the rgb head's)
+constexpr int kMaxStageBlocks = 36;         // blocks of 1 KiB per stage at most (the skip layer: 16 gradient + 16 + 4 activation groups)
+constexpr int kRingBytes = NNR_WB_RING_KIB * 1024;   // the LDS ring: as many stages as fit (4 of the widest unit's, 14 of the rgb head's)
 constexpr int kMaxInFlight = 56;            // DMA pieces a wave keeps outstanding at most (vmcnt is a 6-bit counter)
 constexpr int kBlockBytes = 1024;
 
@@ -70,23 +70,22 @@ __device__ __forceinline__ bf16x8 read_operand(const char* lds, int img, int t, 
     return __builtin_bit_cast(bf16x8, q);
 }
 
-// One LDS-DMA piece: 64 lanes x 16 bytes from (wave-uniform base + per-lane 32-bit offset) to the LDS bytes [dst, dst + 1 KiB).
+// LDS-DMA pieces (StageFeed::issue): 64 lanes x 16 bytes from (wave-uniform base + per-lane 32-bit offset) to the LDS bytes [M0, M0 + 1 KiB).
 // Inline assembly for two reasons: the address stays an SGPR pair + ONE VGPR (the builtin's flat per-lane pointers were hoisted out of
 // the streaming loop as eight 64-bit VGPR pairs, spilled, and every reload carried an s_waitcnt vmcnt(0) that drained the DMA queue);
 // and hipcc does not count asm memory operations, so no compiler-inserted wait ever covers them -- the counted waits below are the
-// only ones.  M0 (the LDS destination) is written and restored inside the statement.
-__device__ __forceinline__ void dma_piece(const char* base, unsigned lane_off, unsigned dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane_off), "s"(base), "s"(dst)
-                 : "memory");
-}
+// only ones.
+constexpr int kMaxPieces = (kMaxStageBlocks + 3) / 4;    // DMA pieces per wave and stage
 
 struct StageFeed {      // everything a wave needs to issue its pieces of a stage; all fields wave-uniform except src0 / src1
-    const char *d_base, *x_base;
-    int64_t d_stride, x_stride;
-    int d_groups, nblk, P, c0, wave;
+    // Piece q of a wave is block min(wave + 4 q, nblk - 1) of the stage image; which plane that block comes from is fixed for the
+    // job, so the wave keeps one running source pointer per piece (chunk s, then += the plane's bytes per chunk): two scalar adds
+    // per piece and stage.  (Deriving the source from the three plane descriptors per piece cost ~25 scalar instructions each and
+    // one third of the kernel's rate.)
+    const char* ptr[kMaxPieces];
+    int stride[kMaxPieces];
+    unsigned parity;    // bit q: block parity of piece q inside its operand image (selects the source permutation)
+    int nblk, P, wave;
     int nst;            // ring depth for this job: narrow units (the heads: 9-10 KiB a stage) get a deeper ring, so that every
                         // workgroup keeps about the same number of bytes in flight -- with 3 stages of 9 KiB a CU streams at half
                         // the rate of one with 3 stages of 32 KiB, and the kernel ends with its slowest workgroup
@@ -99,40 +98,56 @@ struct StageFeed {      // everything a wave needs to issue its pieces of a stag
     // c = sample in chunk] is 32 h + (c ^ (4 h + 8 par)), par = parity of the block inside its operand image: the samples the
     // transposing reads of one 32-lane group address then fall on 64 distinct banks (see the read offsets in wgrad_b_job).
     __device__ __forceinline__ StageFeed(const WgradJobB& jb, const char* ws, unsigned lds_addr, int wave_, int lane) {
-        d_base = ws + jb.d_base;
-        x_base = ws + jb.x_base;
-        d_stride = jb.d_stride;
-        x_stride = jb.x_stride;
-        d_groups = jb.d_groups;
-        nblk = jb.d_groups + jb.x_groups;
-        P = (nblk + 3) >> 2;          // DMA pieces per wave and stage (the last ones may repeat a block)
+        // the job's fields as opaque scalars: left as loads, the selects below became indexed loads from a scratch copy of the job
+        const auto sc = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+        const auto sc64 = [&](int64_t v) { return (int64_t)(((uint64_t)(unsigned)sc((int)(v >> 32)) << 32) | (unsigned)sc((int)v)); };
+        const int d_groups = sc(jb.d_groups), x_groups = sc(jb.x_groups), dx_groups = d_groups + x_groups;
+        const int d_stride = sc(jb.d_stride), x_stride = sc(jb.x_stride), x2_stride = sc(jb.x2_stride), c0 = sc(jb.c0);
+        const int64_t d_base = sc64(jb.d_base), x_base = sc64(jb.x_base), x2_base = sc64(jb.x2_base) - (int64_t)x_groups * kBlockBytes;
+        nblk = dx_groups + sc(jb.x2_groups);
+        wave = wave_;
+        P = (nblk - wave + 3) >> 2;   // DMA pieces of THIS wave per stage: blocks wave, wave + 4, ... (vmcnt counts per wave)
         stage_bytes = nblk * kBlockBytes;
-        const int fit = kRingBytes / stage_bytes, cap = kMaxInFlight / P + 1;
+        const int fit = kRingBytes / stage_bytes, cap = kMaxInFlight / ((nblk + 3) >> 2) + 1;   // the same ring depth for all waves
         nst = fit < cap ? fit : cap;
         head = tail = 0;
-        c0 = jb.c0;
-        wave = wave_;
         lds0 = lds_addr;
+        parity = 0;
+#pragma unroll
+        for (int q = 0; q < kMaxPieces; ++q) {
+            int i = wave + 4 * q;
+            i = i < nblk ? i : nblk - 1;
+            const bool is_d = i < d_groups, is_x = i < dx_groups;
+            const int k = is_d ? i : i - d_groups;     // block index inside its operand image (the second activation plane
+                                                       // continues the first: x_groups is even, the parity carries over)
+            const int st = is_d ? d_stride : is_x ? x_stride : x2_stride;
+            const int64_t base = is_d ? d_base : is_x ? x_base : x2_base;
+            ptr[q] = ws + base + (int64_t)k * kBlockBytes + (int64_t)c0 * st;
+            stride[q] = st;
+            parity |= (unsigned)(k & 1) << q;
+        }
         const int ph = lane >> 5, pc = lane & 31;
         src0 = (32 * ph + (pc ^ (4 * ph))) * 16;
         src1 = (32 * ph + (pc ^ (4 * ph + 8))) * 16;
     }
-    __device__ __forceinline__ void issue(int s) {
-        const int64_t ch = c0 + s;
-        const char* dch = d_base + ch * d_stride;
-        const char* xch = x_base + ch * x_stride;
-        const unsigned stage = lds0 + head * stage_bytes;
+    // M0 (the LDS destination of a DMA) is saved, walked from block to block (+ 4 KiB per piece) and restored across the run of asm
+    // statements: they are volatile, so nothing of the compiler's that could want M0 comes between them.
+    __device__ __forceinline__ void issue() {          // the next chunk
+        const unsigned stage = lds0 + head * stage_bytes + wave * kBlockBytes;
         head = head + 1 == nst ? 0 : head + 1;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0" : "=&s"(keep) : "s"(stage) : "memory");
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < kMaxPieces; ++q) {
             if (q < P) {
-                int i = wave + 4 * q;
-                i = i < nblk ? i : nblk - 1;
-                const bool is_d = i < d_groups;
-                const int k = is_d ? i : i - d_groups;     // block index inside its operand image
-                dma_piece((is_d ? dch : xch) + (int64_t)k * kBlockBytes, (k & 1) ? src1 : src0, stage + i * kBlockBytes);
+                asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, 0x1000\n\ts_nop 0"
+                             :
+                             : "v"((parity >> q & 1) ? src1 : src0), "s"(ptr[q])
+                             : "memory", "scc");
+                ptr[q] += stride[q];
             }
         }
+        asm volatile("s_mov_b32 m0, %0" : : "s"(keep) : "memory");
     }
     // stage s has landed when at most the pieces of the (nst - 2) younger stages are outstanding; near the end of the range
     // fewer stages are in flight: drain.  Then the barrier: every wave's pieces of stage s are in LDS and everybody is done
@@ -141,22 +156,35 @@ struct StageFeed {      // everything a wave needs to issue its pieces of a stag
         wait_vmcnt(s + nst - 2 < n ? (nst - 2) * P : 0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + nst - 1 < n) issue(s + nst - 1);
+        if (s + nst - 1 < n) issue();
         const int img = tail * stage_bytes;
         tail = tail + 1 == nst ? 0 : tail + 1;
         return img;
     }
     __device__ __forceinline__ void start(int n) {
-        for (int s = 0; s < nst - 1 && s < n; ++s) issue(s);
+        for (int s = 0; s < nst - 1 && s < n; ++s) issue();
     }
 };
 
 template <int MT, int NT>
-__device__ __forceinline__ void pin_tiles(f32x16 (&acc)[MT][NT]) {   // keep the accumulators where they are: AGPRs (see pin_acc)
+__device__ __forceinline__ void pin_tiles(f32x16 (&acc)[MT][NT]) {   // keep the accumulators where they are: AGPRs (see pin_acc);
+                                                                      // the 4 x 5 tiling has 320: the last 64 stay in VGPRs
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) asm volatile("" : "+a"(acc[i][j]));
+        for (int j = 0; j < NT; ++j) {
+            if ((i * NT + j + 1) * 16 <= 256) asm volatile("" : "+a"(acc[i][j]));
+            else asm volatile("" : "+v"(acc[i][j]));
+        }
+}
+
+// The 4 x 5 tiling holds 320 accumulators: 256 in AGPRs, 64 in VGPRs.  With the builtin the register allocator treats all of them
+// as one either-file class and shuffles whole tiles between the files inside the streaming loop (and spills some); an MFMA written
+// as an asm statement fixes the file of its accumulator at every use.  hipcc's hazard recognizer does not look inside asm statements:
+// the callers keep dependent MFMAs >= 16 MFMAs apart and put s_nops between the last MFMA and the first ordinary read.
+__device__ __forceinline__ void mfma_pinned(bool agpr, f32x16& c, bf16x8 a, bf16x8 b) {   // `agpr` folds after unrolling
+    if (agpr) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
 // a wave without tiles in this job: it still moves its share of the data and keeps the barrier count
@@ -217,7 +245,10 @@ __device__ __forceinline__ void wgrad_b_job(const WgradJobB& jb, const WgradBArg
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) {
+                    if constexpr (MT * NT * 16 <= 256) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    else mfma_pinned((i * NT + j + 1) * 16 <= 256, acc[i][j], av[i], bv[j]);
+                }
                 if constexpr (BIAS) {
                     const u32x4 w = __builtin_bit_cast(u32x4, av[i]);
 #pragma unroll
@@ -229,6 +260,7 @@ __device__ __forceinline__ void wgrad_b_job(const WgradJobB& jb, const WgradBArg
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of stage s have returned before it reports "done"
     }
+    if constexpr (MT * NT * 16 > 256) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // asm MFMAs: their results are read below
     __builtin_amdgcn_s_barrier();              // the ring is free for the next job's prologue
 
     // ---- flush: tile (i, j) row-major [32][32]; register r of lane (half, col) is row (r & 3) + 8 (r >> 2) + 4 half
@@ -248,7 +280,7 @@ __device__ __forceinline__ void wgrad_b_job(const WgradJobB& jb, const WgradBArg
             }
     if constexpr (BIAS) {   // [tile row][k-step half][feature]: the reduction adds the two halves
 #pragma unroll
-        for (int i = 0; i < MT; ++i) slot[16 * kSlotBTile + (2 * i + half) * 32 + col] = bsum[i];
+        for (int i = 0; i < MT; ++i) slot[kSlotBMaxTiles * kSlotBTile + (2 * i + half) * 32 + col] = bsum[i];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flush stores are the compiler's; start the next job's counted waits from zero
 }
@@ -271,6 +303,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_b_kernel(WgradBArgs a) {
     case MT_ * 8 + NT_: wgrad_b_job<MT_, NT_, false>(jb, a, lds, lds_addr, wave, lane, ji); break;       \
     case MT_ * 8 + NT_ + 64: wgrad_b_job<MT_, NT_, true>(jb, a, lds, lds_addr, wave, lane, ji); break;
         switch (key) {
+            NNR_WB_CASE(4, 5)
+            NNR_WB_CASE(5, 3)
             NNR_WB_CASE(4, 4)
             NNR_WB_CASE(2, 2)
             NNR_WB_CASE(5, 2)
@@ -326,7 +360,7 @@ __global__ __launch_bounds__(256) void wgrad_b_reduce_kernel(WgradBArgs a) {
     if (o.bias && blockIdx.x == 0) {
         for (int r = threadIdx.x; r < o.n_rows; r += 256) {
             const int dr = o.d_row + r, rt = dr >> 5;
-            const float* p = a.slots + (int64_t)((rt / o.MT) * o.WC) * kSlotBFloats + 16 * kSlotBTile + 2 * (rt % o.MT) * 32 + (dr & 31);
+            const float* p = a.slots + (int64_t)((rt / o.MT) * o.WC) * kSlotBFloats + kSlotBMaxTiles * kSlotBTile + 2 * (rt % o.MT) * 32 + (dr & 31);
             float sum = 0.f;
             for (int s = 0; s < n; ++s) {
                 const float* q = p + list[s] * stride;

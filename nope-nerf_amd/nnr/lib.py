@@ -52,7 +52,8 @@ AUX_RGBS, AUX_PC, AUX_SCALE_PCS, AUX_DETACH_RGBS = 1, 2, 4, 8
 class WgradJobB(C.Structure):      # bf16 training mode: one workgroup job (nnr_layout.h)
     _fields_ = [("d_base", C.c_int64), ("x_base", C.c_int64)] + \
                [(n, C.c_int32) for n in ("d_stride", "x_stride", "d_groups", "x_groups", "unit", "MT", "NT", "WR", "WC", "c0", "c1", "bias",
-                                         "split", "next_split")]
+                                         "split", "next_split")] + \
+               [("x2_base", C.c_int64), ("x2_stride", C.c_int32), ("x2_groups", C.c_int32)]
 
 
 class WgradOutB(C.Structure):

@@ -191,10 +191,12 @@ def test_bf16_wgrad_plan_covers_every_weight_once(D, R, N):
     units = {}
     for j in jobs:
         units.setdefault(j.unit, []).append(j)
-        assert (j.MT, j.NT) in {(4, 4), (2, 2), (5, 2), (3, 1), (1, 2), (1, 1)} and 1 <= j.WR * j.WC <= 4
-        assert 0 <= j.c0 < j.c1 <= chunks and j.d_groups + j.x_groups <= 32 and j.d_base % 1024 == 0 and j.x_base % 1024 == 0
+        assert (j.MT, j.NT) in {(4, 5), (5, 3), (4, 4), (2, 2), (5, 2), (3, 1), (1, 2), (1, 1)} and 1 <= j.WR * j.WC <= 4
+        staged = j.d_groups + j.x_groups + j.x2_groups
+        assert 0 <= j.c0 < j.c1 <= chunks and staged <= 36 and j.d_base % 1024 == 0 and j.x_base % 1024 == 0 and j.x2_base % 1024 == 0
+        assert j.x2_groups == 0 or j.x_groups % 2 == 0       # the second activation plane continues the first one's tile grid
         # every tile row / column a wave reads lies inside the staged image (a tile = two blocks)
-        assert 2 * j.MT * j.WR <= j.d_groups + j.x_groups + 1 and 2 * j.NT * j.WC <= j.x_groups
+        assert 2 * j.MT * j.WR <= staged + 1 and 2 * j.NT * j.WC <= j.x_groups + j.x2_groups
     for u, js in units.items():                      # chunk ranges of a unit: a partition, chained in order
         js = sorted(js, key=lambda j: j.c0)
         assert js[0].c0 == 0 and js[-1].c1 == chunks and all(a.c1 == b.c0 for a, b in zip(js, js[1:]))
@@ -226,8 +228,8 @@ def test_bf16_wgrad_plan_covers_every_weight_once(D, R, N):
     assert 1 <= n_blocks <= 256 and first[0] == 0 and first[-1] == len(jobs) and all(a <= b for a, b in zip(first, first[1:]))
     # balance at BASELINE configs[2]: the staged KiB per workgroup differ by at most one chunk of the widest unit
     if (R, N) == (4096, 128):
-        kib = [sum((jobs[i].d_groups + jobs[i].x_groups) * (jobs[i].c1 - jobs[i].c0) for i in range(first[b], first[b + 1])) for b in range(n_blocks)]
-        assert n_blocks == 256 and max(kib) - min(kib) <= 2 * 32
+        kib = [sum((jobs[i].d_groups + jobs[i].x_groups + jobs[i].x2_groups) * (jobs[i].c1 - jobs[i].c0) for i in range(first[b], first[b + 1])) for b in range(n_blocks)]
+        assert n_blocks == 256 and max(kib) - min(kib) <= 2 * 36
     # workspace: planes + four wave slots per job + the merged-matrix scratch
     nj = C.c_int32(0)
     assert lib.nnr_plan_counts(C.byref(cfg), C.byref(nj), None) == 0 and nj.value == len(jobs)
