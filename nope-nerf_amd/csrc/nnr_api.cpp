@@ -235,9 +235,9 @@ Plan build_plan(const nnr_cfg* c) {
 size_t plan_bytes(const Plan& p) { return p.jobs.size() * sizeof(WgradJob) + p.wave_first.size() * sizeof(int32_t); }
 
 // ---- weight-gradient plan of the bf16 training mode (nnr_wgrad_bf16.hip) ------------------------------------------------------
-// Units = the products dW = Dlt^T X of the 12 layers (the D + 63 wide skip layer as two units, the feature layer merged into the
-// colour-hidden one, the density head riding on the merged unit's extra gradient group), each with its tiling over the four
-// waves of a workgroup.  The kernel is bound by streaming the operands once, so a unit's cost per 32-sample chunk is the KiB it
+// Units = the products dW = Dlt^T X of the 12 layers (the feature layer merged into the colour-hidden one, the density head riding
+// on the merged unit's extra gradient group; at D = 256 the skip layer and the colour-hidden layer take their two input planes --
+// hidden | encoding -- in one unit, at D = 128 as two units), each with its tiling over the four waves of a workgroup.  The kernel is bound by streaming the operands once, so a unit's cost per 32-sample chunk is the KiB it
 // stages; the units form one tape of (unit, chunk) positions that is cut into equal spans, one per workgroup (a span that
 // crosses a unit boundary becomes two jobs).  Outputs = where the rectangles of a unit's product go.
 struct BUnit {

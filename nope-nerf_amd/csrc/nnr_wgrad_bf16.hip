@@ -13,6 +13,9 @@
 //     stage = the 16 + 16 blocks of one chunk of both operands = 32 KiB arrives by 32 LDS-DMA pieces (global_load_lds_dwordx4,
 //     1 KiB per wave-instruction, 8 per wave) into a ring of four stages -- three chunks (96 KiB) in flight per CU, counted vmcnt,
 //     one barrier per stage.  tools/ubench/hbm_stream.hip: this staging pattern alone streams 6.1 TB/s on the box;
+//   * the two layers whose input is two planes (skip layer: hidden | position encoding; colour-hidden: feature | direction encoding)
+//     are ONE job type with a second activation plane behind the first in the LDS image (36 / 27 blocks a stage, 4 x 5 / 5 x 3 tiles
+//     per wave), so that their gradient plane is streamed once, not once per activation plane;
 //   * the MFMA wants [feature][8 consecutive samples] per lane, the planes hold [sample][features]: the transposition is the LDS
 //     read, ds_read_b64_tr_b16 (two per operand tile and k-step).  The DMA stores the 64 16-byte units of a block to LDS slots
 //     permuted by an XOR on the sample index (applied to the per-lane SOURCE address, the LDS image of a DMA is lane-linear) such
