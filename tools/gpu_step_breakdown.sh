@@ -13,7 +13,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # the last 20 steps: find the last 21 launches of mlp_fwd_bf16 train
-idx = [i for i, r in enumerate(rows) if 'mlp_fwd_bf16_kernel<256, true>' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'mlp_fwd_bf16_kernel<256, true' in r['Kernel_Name']]
 idx = idx[:50]          # the 10 + 40 steps of the training loop (later launches belong to the kernel-roofline block)
 a, b = idx[-21], idx[-1]
 seg = rows[a:b]
