@@ -1,0 +1,224 @@
+"""GPU tests (-m gpu) of the three bf16 MLP kernels against THEIR OWN operands, layer by layer.
+
+The whole-step parity tests compare the bf16 mode with the bf16 oracle at a few 1e-3 (outputs) / 1e-2 (gradients): an activation that
+rounds the other way in one layer moves everything downstream that far, so those bars cannot show a rare wrong term.  Here every
+layer is checked against the operands the kernels themselves left in the workspace (tile-major bf16 planes, nnr_layout.h, located
+with nnr_ws_plane and decoded on the host) -- no error propagates from layer to layer:
+  * forward:         hidden_{l+1} = bf16(relu(bf16(W_l) in_l + b_l))   -- every stored value is the correctly rounded bf16 of the
+                     float64 pre-activation to within the fp32 accumulation slack; the heads likewise in fp32
+  * input gradient:  Dlt_l = bf16(relu'(hidden_{l+1}) .* (Dlt_{l+1} bf16(W_{l+1})))   -- the same statement for the transposed chain
+  * weight gradient: dW_l = Dlt_l^T in_l, db_l = sum_s Dlt_l[s] in float64 -- bf16 x bf16 products are exact in fp32, so the only
+                     freedom is the order of the additions.  This pins the two-plane units (skip layer: hidden | position encoding,
+                     colour-hidden layer: hidden | direction encoding), the 4 x 5 tiling whose MFMAs are asm statements the
+                     compiler's hazard recogniser does not see, the per-wave DMA bookkeeping and the slot reduction.
+The workspace starts as NaN: a kernel that read a byte it or its producers did not write would return NaN."""
+import ctypes as C
+
+import pytest
+import torch
+
+import nerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+P_XH1, P_XG, P_XE16, P_XF16, P_DH1, P_DG = 11, 20, 21, 22, 31, 40
+
+
+def _plane(lib, cfg, ws, plane, S_pad, groups):
+    """(S_pad, 16 * groups) float64 from a tile-major bf16 plane: blocks [chunk][group], block = [lane 32 h + c][8 bf16] holding,
+    for sample 32 chunk + c, features 16 g + 4 h + k and 16 g + 8 + 4 h + k (k < 4)."""
+    pitch = C.c_int32(0)
+    off = lib.nnr_ws_plane(C.byref(cfg), plane, C.byref(pitch))
+    assert off >= 0 and pitch.value == 8 * groups, (plane, off, pitch.value)
+    raw = ws[off: off + S_pad * 8 * groups].view(torch.bfloat16)
+    t = raw.view(S_pad // 32, groups, 2, 32, 2, 4)           # chunk, g, h, c, j, k   (feature = 16 g + 8 j + 4 h + k)
+    return t.permute(0, 3, 1, 4, 2, 5).reshape(S_pad, 16 * groups).double()
+
+
+P_OUT4, P_DOUT4 = 0, 2
+SHAPES = [(256, 37, 64), (256, 300, 128), (128, 50, 33), (256, 64, 192)]
+
+
+def run_passes(D, R, N):
+    """forward (training) -> compositing -> its backward -> input gradient -> weight gradient through the C ABI on seeded inputs;
+    returns what the checks need."""
+    from nnr import lib as L
+    from nnr import ops
+    lib = L.load()
+    dev = torch.device("cuda")
+    params = orc.init_params(D, 11)
+    w = [params[n + ".weight"].to(dev) for n in L.LAYER_NAMES]
+    g = torch.Generator().manual_seed(5)
+    b = [(params[n + ".bias"] + 0.05 * torch.randn(params[n + ".bias"].shape, generator=g)).to(dev) for n in L.LAYER_NAMES]
+    cfg = L.make_cfg(R, N, D, train=True, bf16=True)
+    d = torch.randn(R, 3, generator=g)
+    d = (d / d.norm(dim=-1, keepdim=True)).to(dev)
+    o = (0.3 * torch.randn(R, 3, generator=g)).to(dev)
+    z = torch.linspace(0, 1, N)
+    z = 0.01 * (1 - z) + 4 * z
+    mid = 0.5 * (z[1:] + z[:-1])
+    lo, hi = torch.cat([z[:1], mid]).to(dev), torch.cat([mid, z[-1:]]).to(dev)
+    jit = torch.rand(R, N, generator=g).to(dev)
+    view = (-d).contiguous()
+    packed = ops._packed_for(cfg, w, b)
+    ws = torch.full((lib.nnr_workspace_floats(C.byref(cfg)),), float("nan"), device=dev)
+    rgb, dst = torch.empty(R, 3, device=dev), torch.empty(R, device=dev)
+    d_rgb, d_dst = torch.randn(R, 3, generator=g).to(dev), torch.randn(R, generator=g).to(dev)
+    gw, gb = [torch.zeros_like(x) for x in w], [torch.zeros_like(x) for x in b]
+    gs = L.params_struct(gw, gb)
+    plan = ops._plan_for(cfg, dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.nnr_mlp_fwd(C.byref(cfg), L.ptr(o), L.ptr(d), L.ptr(view), L.ptr(lo), L.ptr(hi), L.ptr(jit), L.ptr(packed), L.ptr(ws), st), "fwd")
+    L.check(lib.nnr_composite_fwd(C.byref(cfg), L.ptr(rgb), L.ptr(dst), None, None, L.ptr(ws), st), "composite")
+    L.check(lib.nnr_composite_bwd(C.byref(cfg), L.ptr(d_rgb), L.ptr(d_dst), L.ptr(ws), st), "composite_bwd")
+    L.check(lib.nnr_mlp_dgrad(C.byref(cfg), L.ptr(packed), L.ptr(ws), st), "dgrad")
+    L.check(lib.nnr_mlp_wgrad(C.byref(cfg), L.ptr(packed), C.byref(gs), L.ptr(plan), L.ptr(ws), st), "wgrad")
+    torch.cuda.synchronize()
+    S_pad = (R * N + 127) // 128 * 128
+    G, Gh = D // 16, D // 32
+    pl = lambda plane, groups: _plane(lib, cfg, ws, plane, S_pad, groups)
+    out = dict(w=w, b=b, gw=gw, gb=gb, S=R * N, S_pad=S_pad, ws=ws, lib=lib, cfg=cfg,
+               X={l: pl(P_XH1 + l - 1, G) for l in range(1, 9)},           # hidden 1..8
+               Dl={l: pl(P_DH1 + l, G) for l in range(8)},                 # d pre-activation of layer l (= of hidden l + 1)
+               E=pl(P_XE16, 4)[:, :63], F=pl(P_XF16, 2)[:, :27], Gc=pl(P_XG, Gh), DG=pl(P_DG, Gh + 1))
+    for t in list(out["X"].values()) + list(out["Dl"].values()) + [out["E"], out["F"], out["Gc"], out["DG"]]:
+        assert torch.isfinite(t).all()
+    return out
+
+
+def _rows(lib, cfg, ws, plane, S, width):
+    """(S, width) float64 of a row-major fp32 plane"""
+    pitch = C.c_int32(0)
+    off = lib.nnr_ws_plane(C.byref(cfg), plane, C.byref(pitch))
+    assert off >= 0 and pitch.value == width, (plane, off, pitch.value)
+    return ws[off: off + S * width].view(S, width).double()
+
+
+@pytest.mark.parametrize("D,R,N", SHAPES)
+def test_bf16_weight_gradient_is_the_exact_product_of_the_stashed_operands(D, R, N):
+    r = run_passes(D, R, N)
+    w, b, gw, gb, X, Dl, E, F, Gc, DG = (r[k] for k in ("w", "b", "gw", "gb", "X", "Dl", "E", "F", "Gc", "DG"))
+    Dh = D // 2
+    dg, dout = DG[:, :Dh], DG[:, Dh:Dh + 4]                                          # d colour hidden; d rgb_pre[0..2], d sigma_raw
+    assert float(dg.abs().max()) > 0 and float(Dl[0].abs().max()) > 0               # the backward did reach the first layer
+
+    def prod(dlt, x):          # expected product and the sum of |terms| (the scale of the fp32 accumulation error)
+        return dlt.T @ x, dlt.abs().T @ x.abs()
+
+    exp_w, scale_w, exp_b, scale_b = {}, {}, {}, {}
+    exp_w[0], scale_w[0] = prod(Dl[0], E)
+    for l in (1, 2, 3, 5, 6, 7):
+        exp_w[l], scale_w[l] = prod(Dl[l], X[l])
+    exp_w[4], scale_w[4] = prod(Dl[4], torch.cat([X[4], E], dim=1))
+    for l in range(8):
+        exp_b[l], scale_b[l] = Dl[l].sum(0), Dl[l].abs().sum(0)
+    exp_w[8], scale_w[8] = prod(dout[:, 3:4], X[8])
+    exp_b[8], scale_b[8] = dout[:, 3:4].sum(0), dout[:, 3:4].abs().sum(0)
+    exp_w[11], scale_w[11] = prod(dout[:, :3], Gc)
+    exp_b[11], scale_b[11] = dout[:, :3].sum(0), dout[:, :3].abs().sum(0)
+    dWm, _ = prod(dg, X[8])                                                          # the merged matrix W' = Wg[:, :D] Wf
+    dbm = dg.sum(0)
+    dir_w, dir_scale = prod(dg, F)
+
+    tol = 5e-6      # x sum of |terms| (measured: <= 5e-7): fp32 roundings of the chained sums stay inside, a wrong or missing term does not
+    for l in sorted(exp_w):
+        got = gw[l].double()
+        err = (got - exp_w[l]).abs()
+        assert bool((err <= tol * scale_w[l] + 1e-30).all()), (l, float(err.max()), float(exp_w[l].abs().max()))
+        assert float(exp_w[l].abs().max()) > 0
+        errb = (gb[l].double() - exp_b[l]).abs()
+        assert bool((errb <= tol * scale_b[l] + 1e-30).all()), (l, float(errb.max()), float(exp_b[l].abs().max()))
+    err = (gw[10][:, D:].double() - dir_w).abs()
+    assert bool((err <= tol * dir_scale + 1e-30).all()), float(err.max())
+    # the un-merge step (wgrad_unmerge_kernel: fp32 fma chains over the fp32 weights):
+    #   dWf = Wg1^T dW'   dWg[:, :D] = dW' Wf^T + db' bf^T   dbf = Wg1^T db'   dbg = db'
+    Wg1, Wf, bf = w[10][:, :D].double(), w[9].double(), b[9].double()
+    for got, exp in ((gw[9], Wg1.T @ dWm), (gw[10][:, :D], dWm @ Wf.T + torch.outer(dbm, bf)), (gb[9], Wg1.T @ dbm), (gb[10], dbm)):
+        assert float((got.double() - exp).abs().max()) <= 1e-4 * float(exp.abs().max()), (float((got.double() - exp).abs().max()), float(exp.abs().max()))
+
+
+def _q(t):
+    """bf16 rounding (nearest even) of an fp32 tensor, as float64: what the pack kernel stores for the MFMA operands"""
+    return t.to(torch.bfloat16).double()
+
+
+def _merged(Wg1, Wf):
+    """W' = Wg[:, :D] Wf as the pack kernel forms it (nnr_pack.hip merge_kernel): per element one fp32 fma chain in index order.
+    Emulated in float64 (a product of two fp32 values is exact there; the sum is rounded to fp32 after every step): a plain fp32
+    matmul adds in another order, and an element that rounds to the other bf16 neighbour moves a whole output column by far more than
+    half an ulp."""
+    acc = torch.zeros(Wg1.shape[0], Wf.shape[1], dtype=torch.float64, device=Wf.device)
+    a, b = Wg1.double(), Wf.double()
+    for j in range(Wf.shape[0]):
+        acc = (a[:, j:j + 1] * b[j:j + 1, :] + acc).float().double()
+    return acc.float()
+
+
+def _assert_rounded(got, exact, scale, what, slack=4e-6, max_inexact=0.03):
+    """`got` (values read from a bf16 plane) is the nearest bf16 of `exact` up to the fp32 accumulation error of the kernel's sum
+    (`slack` x sum of |terms|): |got - exact| <= half a bf16 ulp + slack.  Also counts how often got differs from the bf16 rounding
+    of the float64 value at all (a sum that lands on the other side of a rounding boundary): a small fraction."""
+    mag = torch.maximum(got.abs(), exact.abs()).clamp_min(1e-30)
+    ulp = torch.exp2(torch.floor(torch.log2(mag)) - 7)
+    err = (got - exact).abs()
+    bad = err > 0.5 * ulp + slack * scale + 1e-30
+    assert not bool(bad.any()), (what, int(bad.sum()), float((err / ulp).max()))
+    inexact = float((got != exact.float().to(torch.bfloat16).double()).double().mean())
+    assert inexact <= max_inexact, (what, inexact)
+
+
+@pytest.mark.parametrize("D,R,N", SHAPES)
+def test_bf16_forward_layers_round_the_exact_products_of_their_stashed_inputs(D, R, N):
+    """model/official_nerf.py:60-96 layer by layer, each from the input the kernel itself stashed."""
+    r = run_passes(D, R, N)
+    w, b, X, E, F, Gc, S = (r[k] for k in ("w", "b", "X", "E", "F", "Gc", "S"))
+
+    def layer(inp, W, bias):
+        Wq = _q(W)
+        return inp @ Wq.T + bias.double(), inp.abs() @ Wq.abs().T + bias.double().abs()
+
+    ins = {0: E, 1: X[1], 2: X[2], 3: X[3], 4: torch.cat([X[4], E], dim=1), 5: X[5], 6: X[6], 7: X[7]}
+    for l in range(8):                       # hidden l + 1 = relu(layer l)
+        pre, scale = layer(ins[l][:S], w[l], b[l])
+        _assert_rounded(X[l + 1][:S], pre.clamp_min(0), scale, "hidden %d" % (l + 1))
+    # colour-hidden layer on the merged matrix W' = Wg[:, :D] Wf (formed in fp32 by the pack kernel, then rounded), b' = Wg[:, :D] bf + bg
+    Wg, Wf = w[10], w[9]
+    Wm = _merged(Wg[:, :D], Wf)
+    bm = Wg[:, :D].double() @ b[9].double() + b[10].double()
+    Wmq, Wdq = _q(Wm), _q(Wg[:, D:].contiguous())
+    pre = X[8][:S] @ Wmq.T + F[:S] @ Wdq.T + bm
+    scale = X[8][:S].abs() @ Wmq.abs().T + F[:S].abs() @ Wdq.abs().T + bm.abs()
+    _assert_rounded(Gc[:S], pre.clamp_min(0), scale, "colour hidden")
+    # the two heads: bf16 products, fp32 results in plane 0 = (rgb after the sigmoid, raw density)
+    out4 = _rows(r["lib"], r["cfg"], r["ws"], P_OUT4, S, 4)
+    raw = X[8][:S] @ _q(w[8]).T + b[8].double()
+    raw_scale = X[8][:S].abs() @ _q(w[8]).abs().T + b[8].double().abs()
+    assert bool(((out4[:, 3:4] - raw).abs() <= 4e-6 * raw_scale).all()), float((out4[:, 3:4] - raw).abs().max())
+    rgb = torch.sigmoid(Gc[:S] @ _q(w[11]).T + b[11].double())
+    assert float((out4[:, :3] - rgb).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("D,R,N", SHAPES)
+def test_bf16_input_gradient_layers_round_the_exact_products_of_their_stashed_gradients(D, R, N):
+    """The transposed chain, each layer from the gradient the kernel itself stashed for the layer above and the ReLU pattern of the
+    stashed activations; the two heads feed their input in fp32 (oracle/nerf_oracle.py _Bf16Head)."""
+    r = run_passes(D, R, N)
+    w, X, Dl, Gc, DG, S = (r[k] for k in ("w", "X", "Dl", "Gc", "DG", "S"))
+    Dh = D // 2
+    dout = _rows(r["lib"], r["cfg"], r["ws"], P_DOUT4, S, 4)            # fp32: d rgb_pre[0..2], d sigma_raw
+    # the bf16 copies of the output gradients the weight-gradient kernel reads (P_DG's extra group)
+    assert torch.equal(DG[:S, Dh:Dh + 4], dout.float().to(torch.bfloat16).double())
+    assert float(DG[:S, Dh + 4:].abs().max()) == 0.0
+    # d colour hidden = relu'(g) .* (d rgb_pre Wc), fp32 weights
+    Wc = w[11].double()
+    exact = (dout[:, :3] @ Wc) * (Gc[:S] > 0)
+    _assert_rounded(DG[:S, :Dh], exact, dout[:, :3].abs() @ Wc.abs(), "d colour hidden")
+    # d pre-activation of layer 7 (hidden 8) = relu'(h8) .* (d g bf16(W') + d sigma_raw w_sigma)
+    Wmq = _q(_merged(w[10][:, :D], w[9]))
+    dg = DG[:S, :Dh]
+    exact = (dg @ Wmq + dout[:, 3:4] @ w[8].double()) * (X[8][:S] > 0)
+    _assert_rounded(Dl[7][:S], exact, dg.abs() @ Wmq.abs() + dout[:, 3:4].abs() @ w[8].double().abs(), "d layer 7")
+    for l in range(6, -1, -1):              # d pre-activation of layer l = relu'(hidden l + 1) .* (Dlt_{l+1} bf16(W_{l+1})[:, :D])
+        Wq = _q(w[l + 1])[:, :D]
+        exact = (Dl[l + 1][:S] @ Wq) * (X[l + 1][:S] > 0)
+        _assert_rounded(Dl[l][:S], exact, Dl[l + 1][:S].abs() @ Wq.abs(), "d layer %d" % l)
