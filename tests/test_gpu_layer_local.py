@@ -1,4 +1,4 @@
-"""GPU tests (-m gpu) of the three bf16 MLP kernels against THEIR OWN operands, layer by layer.
+"""GPU tests (-m gpu) of the three MLP kernels -- bf16 mode and fp32 -- against THEIR OWN operands, layer by layer.
 
 The whole-step parity tests compare the bf16 mode with the bf16 oracle at a few 1e-3 (outputs) / 1e-2 (gradients): an activation that
 rounds the other way in one layer moves everything downstream that far, so those bars cannot show a rare wrong term.  Here every
@@ -39,9 +39,9 @@ P_OUT4, P_DOUT4 = 0, 2
 SHAPES = [(256, 37, 64), (256, 300, 128), (128, 50, 33), (256, 64, 192)]
 
 
-def run_passes(D, R, N):
+def run_passes(D, R, N, bf16=True):
     """forward (training) -> compositing -> its backward -> input gradient -> weight gradient through the C ABI on seeded inputs;
-    returns what the checks need."""
+    returns what the checks need.  bf16=False: the fp32 kernels, whose planes are row-major fp32."""
     from nnr import lib as L
     from nnr import ops
     lib = L.load()
@@ -50,7 +50,7 @@ def run_passes(D, R, N):
     w = [params[n + ".weight"].to(dev) for n in L.LAYER_NAMES]
     g = torch.Generator().manual_seed(5)
     b = [(params[n + ".bias"] + 0.05 * torch.randn(params[n + ".bias"].shape, generator=g)).to(dev) for n in L.LAYER_NAMES]
-    cfg = L.make_cfg(R, N, D, train=True, bf16=True)
+    cfg = L.make_cfg(R, N, D, train=True, bf16=bf16)
     d = torch.randn(R, 3, generator=g)
     d = (d / d.norm(dim=-1, keepdim=True)).to(dev)
     o = (0.3 * torch.randn(R, 3, generator=g)).to(dev)
@@ -76,7 +76,12 @@ def run_passes(D, R, N):
     torch.cuda.synchronize()
     S_pad = (R * N + 127) // 128 * 128
     G, Gh = D // 16, D // 32
-    pl = lambda plane, groups: _plane(lib, cfg, ws, plane, S_pad, groups)
+    pl = (lambda plane, groups: _plane(lib, cfg, ws, plane, S_pad, groups)) if bf16 else \
+         (lambda plane, groups: _rows(lib, cfg, ws, plane, S_pad, 16 * groups))
+    if not bf16:       # fp32 mode: the encodings are planes 10 / 19 themselves, the colour-hidden gradient has no extra group
+        return dict(w=w, b=b, gw=gw, gb=gb, S=R * N, S_pad=S_pad, ws=ws, lib=lib, cfg=cfg,
+                    X={l: pl(P_XH1 + l - 1, G) for l in range(1, 9)}, Dl={l: pl(P_DH1 + l, G) for l in range(8)},
+                    E=pl(10, 4)[:, :63], F=pl(19, 2)[:, :27], Gc=pl(P_XG, Gh), DG=pl(P_DG, Gh))
     out = dict(w=w, b=b, gw=gw, gb=gb, S=R * N, S_pad=S_pad, ws=ws, lib=lib, cfg=cfg,
                X={l: pl(P_XH1 + l - 1, G) for l in range(1, 9)},           # hidden 1..8
                Dl={l: pl(P_DH1 + l, G) for l in range(8)},                 # d pre-activation of layer l (= of hidden l + 1)
@@ -222,3 +227,53 @@ def test_bf16_input_gradient_layers_round_the_exact_products_of_their_stashed_gr
         Wq = _q(w[l + 1])[:, :D]
         exact = (Dl[l + 1][:S] @ Wq) * (X[l + 1][:S] > 0)
         _assert_rounded(Dl[l][:S], exact, Dl[l + 1][:S].abs() @ Wq.abs(), "d layer %d" % l)
+
+
+@pytest.mark.parametrize("D,R,N", [(256, 37, 64), (128, 50, 33), (256, 64, 192)])
+def test_fp32_kernels_layer_by_layer_against_their_stashed_operands(D, R, N):
+    """The same three statements for the fp32 kernels (row-major fp32 planes): each layer of the forward and of the input-gradient
+    chain from the operands the kernel stashed, and the weight gradients as their products, all to fp32 accumulation error
+    (no rounding step in between: a plain bound relative to the sum of |terms|)."""
+    r = run_passes(D, R, N, bf16=False)
+    w, b, gw, gb, X, Dl, E, F, Gc, DG, S = (r[k] for k in ("w", "b", "gw", "gb", "X", "Dl", "E", "F", "Gc", "DG", "S"))
+    tol = 3e-6          # measured: <= 7e-7
+    worst = 0.0
+
+    def check(got, exact, scale, what):
+        nonlocal worst
+        ratio = float(((got - exact).abs() / (scale + 1e-30)).max())
+        worst = max(worst, ratio)
+        assert ratio <= tol, (what, ratio)
+
+    dbl = lambda t: t.double()
+    # forward
+    ins = {0: E, 1: X[1], 2: X[2], 3: X[3], 4: torch.cat([X[4], E], dim=1), 5: X[5], 6: X[6], 7: X[7]}
+    for l in range(8):
+        pre = ins[l][:S] @ dbl(w[l]).T + dbl(b[l])
+        check(X[l + 1][:S], pre.clamp_min(0), ins[l][:S].abs() @ dbl(w[l]).abs().T + dbl(b[l]).abs(), "hidden %d" % (l + 1))
+    Wm = dbl(_merged(w[10][:, :D], w[9]))
+    Wd = dbl(w[10][:, D:])
+    bm = dbl(w[10][:, :D]) @ dbl(b[9]) + dbl(b[10])
+    pre = X[8][:S] @ Wm.T + F[:S] @ Wd.T + bm
+    check(Gc[:S], pre.clamp_min(0), X[8][:S].abs() @ Wm.abs().T + F[:S].abs() @ Wd.abs().T + bm.abs(), "colour hidden")
+    out4 = _rows(r["lib"], r["cfg"], r["ws"], P_OUT4, S, 4)
+    check(out4[:, 3:4], X[8][:S] @ dbl(w[8]).T + dbl(b[8]), X[8][:S].abs() @ dbl(w[8]).abs().T + dbl(b[8]).abs(), "raw density")
+    assert float((out4[:, :3] - torch.sigmoid(Gc[:S] @ dbl(w[11]).T + dbl(b[11]))).abs().max()) <= 2e-6
+    # input gradient
+    dout = _rows(r["lib"], r["cfg"], r["ws"], P_DOUT4, S, 4)
+    dg = DG[:S]
+    check(dg, (dout[:, :3] @ dbl(w[11])) * (Gc[:S] > 0), dout[:, :3].abs() @ dbl(w[11]).abs(), "d colour hidden")
+    check(Dl[7][:S], (dg @ Wm + dout[:, 3:4] @ dbl(w[8])) * (X[8][:S] > 0), dg.abs() @ Wm.abs() + dout[:, 3:4].abs() @ dbl(w[8]).abs(), "d layer 7")
+    for l in range(6, -1, -1):
+        Wl = dbl(w[l + 1])[:, :D]
+        check(Dl[l][:S], (Dl[l + 1][:S] @ Wl) * (X[l + 1][:S] > 0), Dl[l + 1][:S].abs() @ Wl.abs(), "d layer %d" % l)
+    # weight gradient (all S_pad rows: what the kernel streams)
+    Sp = r["S_pad"]
+    doutp = _rows(r["lib"], r["cfg"], r["ws"], P_DOUT4, Sp, 4)
+    pairs = {0: (Dl[0], E), 4: (Dl[4], torch.cat([X[4], E], dim=1)), 8: (doutp[:, 3:4], X[8]), 11: (doutp[:, :3], Gc)}
+    pairs.update({l: (Dl[l], X[l]) for l in (1, 2, 3, 5, 6, 7)})
+    for l, (dl, x) in sorted(pairs.items()):
+        check(dbl(gw[l]), dl.T @ x, dl.abs().T @ x.abs(), "dW %d" % l)
+        check(dbl(gb[l]), dl.sum(0), dl.abs().sum(0), "db %d" % l)
+    check(dbl(gw[10][:, D:]), DG.T @ F, DG.abs().T @ F.abs(), "dW colour hidden, direction columns")
+    print("worst error / sum of |terms|: %.2e" % worst)
