@@ -202,7 +202,9 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     };
 // One epilogue unit u: tile u % T, packed register u / T of the half -- hq[tile][OFF + u / T] = (relu(x0), relu(x1)) as bf16.
 // Mask bit r = (x > 0), collected as SIGN bits shifted into the word in register order (v_alignbit_b32); store_mask reverses and
-// inverts the finished word.  The two differ only for x == +0.0 exactly, which has no gradient to pass on either way.
+// inverts the finished word.  The two differ only for x == +0.0 exactly -- an fp32 sum that cancelled to zero, 2 of 6.7e7 values at
+// 4096 x 128 -- where this kernel lets the gradient pass and torch's relu backward does not (the stored activation is 0 either way;
+// tests/test_gpu_layer_local.py counts these elements).
 #define NNR_RELU_UNIT(ACC, OFF, MW)                                                                          \
     [&](int u) __attribute__((always_inline)) {                                                              \
         const int n = u % T, p = u / T;                                                                      \

@@ -36,7 +36,8 @@ def _plane(lib, cfg, ws, plane, S_pad, groups):
 
 
 P_OUT4, P_DOUT4 = 0, 2
-SHAPES = [(256, 37, 64), (256, 300, 128), (128, 50, 33), (256, 64, 192)]
+SHAPES = [(256, 37, 64), (256, 300, 128), (128, 50, 33), (256, 64, 192),
+          (256, 4096, 128)]      # the last: BASELINE configs[2] (the full 256-workgroup plans; ~25 GB of float64 operands on the GPU)
 
 
 def run_passes(D, R, N, bf16=True):
@@ -159,15 +160,27 @@ def _merged(Wg1, Wf):
     return acc.float()
 
 
-def _assert_rounded(got, exact, scale, what, slack=4e-6, max_inexact=0.03):
-    """`got` (values read from a bf16 plane) is the nearest bf16 of `exact` up to the fp32 accumulation error of the kernel's sum
-    (`slack` x sum of |terms|): |got - exact| <= half a bf16 ulp + slack.  Also counts how often got differs from the bf16 rounding
-    of the float64 value at all (a sum that lands on the other side of a rounding boundary): a small fraction."""
+def _off_by(got, exact, scale, slack):
     mag = torch.maximum(got.abs(), exact.abs()).clamp_min(1e-30)
     ulp = torch.exp2(torch.floor(torch.log2(mag)) - 7)
-    err = (got - exact).abs()
-    bad = err > 0.5 * ulp + slack * scale + 1e-30
-    assert not bool(bad.any()), (what, int(bad.sum()), float((err / ulp).max()))
+    return (got - exact).abs() > 0.5 * ulp + slack * scale + 1e-30
+
+
+def _assert_rounded(got, exact, scale, what, slack=4e-6, max_inexact=0.03, ungated=None):
+    """`got` (values read from a bf16 plane) is the nearest bf16 of `exact` up to the fp32 accumulation error of the kernel's sum
+    (`slack` x sum of |terms|): |got - exact| <= half a bf16 ulp + slack.  Also counts how often got differs from the bf16 rounding
+    of the float64 value at all (a sum that lands on the other side of a rounding boundary): a small fraction.
+    ungated = (value before the ReLU gate, stored activation): the kernels take relu'(x) from the SIGN bit of the fp32 accumulator, so
+    an accumulator that cancelled to exactly +0.0 passes its gradient on where torch's relu backward does not.  Such elements must
+    carry the ungated value, sit on a stored activation of 0, and be rare (measured: 2 of 6.7e7 at 4096 x 128)."""
+    bad = _off_by(got, exact, scale, slack)
+    if ungated is not None and bool(bad.any()):
+        value, act = ungated
+        assert bool((act[bad] == 0).all()) and not bool(_off_by(got, value, scale, slack)[bad].any()), what
+        assert int(bad.sum()) <= 2 + 1e-6 * bad.numel(), (what, int(bad.sum()))
+        exact = torch.where(bad, value, exact)
+        bad = _off_by(got, exact, scale, slack)
+    assert not bool(bad.any()), (what, int(bad.sum()))
     inexact = float((got != exact.float().to(torch.bfloat16).double()).double().mean())
     assert inexact <= max_inexact, (what, inexact)
 
@@ -216,20 +229,21 @@ def test_bf16_input_gradient_layers_round_the_exact_products_of_their_stashed_gr
     assert float(DG[:S, Dh + 4:].abs().max()) == 0.0
     # d colour hidden = relu'(g) .* (d rgb_pre Wc), fp32 weights
     Wc = w[11].double()
-    exact = (dout[:, :3] @ Wc) * (Gc[:S] > 0)
-    _assert_rounded(DG[:S, :Dh], exact, dout[:, :3].abs() @ Wc.abs(), "d colour hidden")
+    full = dout[:, :3] @ Wc
+    _assert_rounded(DG[:S, :Dh], full * (Gc[:S] > 0), dout[:, :3].abs() @ Wc.abs(), "d colour hidden", ungated=(full, Gc[:S]))
     # d pre-activation of layer 7 (hidden 8) = relu'(h8) .* (d g bf16(W') + d sigma_raw w_sigma)
     Wmq = _q(_merged(w[10][:, :D], w[9]))
     dg = DG[:S, :Dh]
-    exact = (dg @ Wmq + dout[:, 3:4] @ w[8].double()) * (X[8][:S] > 0)
-    _assert_rounded(Dl[7][:S], exact, dg.abs() @ Wmq.abs() + dout[:, 3:4].abs() @ w[8].double().abs(), "d layer 7")
+    full = dg @ Wmq + dout[:, 3:4] @ w[8].double()
+    _assert_rounded(Dl[7][:S], full * (X[8][:S] > 0), dg.abs() @ Wmq.abs() + dout[:, 3:4].abs() @ w[8].double().abs(), "d layer 7",
+                    ungated=(full, X[8][:S]))
     for l in range(6, -1, -1):              # d pre-activation of layer l = relu'(hidden l + 1) .* (Dlt_{l+1} bf16(W_{l+1})[:, :D])
         Wq = _q(w[l + 1])[:, :D]
-        exact = (Dl[l + 1][:S] @ Wq) * (X[l + 1][:S] > 0)
-        _assert_rounded(Dl[l][:S], exact, Dl[l + 1][:S].abs() @ Wq.abs(), "d layer %d" % l)
+        full = Dl[l + 1][:S] @ Wq
+        _assert_rounded(Dl[l][:S], full * (X[l + 1][:S] > 0), Dl[l + 1][:S].abs() @ Wq.abs(), "d layer %d" % l, ungated=(full, X[l + 1][:S]))
 
 
-@pytest.mark.parametrize("D,R,N", [(256, 37, 64), (128, 50, 33), (256, 64, 192)])
+@pytest.mark.parametrize("D,R,N", [(256, 37, 64), (128, 50, 33), (256, 64, 192), (256, 1024, 192)])      # the last: the headline shape
 def test_fp32_kernels_layer_by_layer_against_their_stashed_operands(D, R, N):
     """The same three statements for the fp32 kernels (row-major fp32 planes): each layer of the forward and of the input-gradient
     chain from the operands the kernel stashed, and the weight gradients as their products, all to fp32 accumulation error
