@@ -10,7 +10,7 @@
 // registers.  A lane keeps, per tile, the layer input as 8 * DT packed registers: packed register p = (bf16 of fragment register 2p,
 // bf16 of 2p + 1) (nnr_layout.h), so the four registers 4g .. 4g+3 ARE the MFMA B operand of row g -- no conversion at the MFMA, and
 // the same 16 bytes are what the training stash stores (one tile-major block row per store).  The epilogue of a half-output pass
-// (bias is in the accumulator; ReLU + sign bit, or the ReLU' select) produces one packed register per unit (v_cvt_pk_bf16_f32).
+// (bias is in the accumulator; ReLU + gate bits, or the ReLU' select) produces one packed register per unit (v_cvt_pk_bf16_f32).
 // Everything else is the design of the fp32 kernels: weights through the DMA-fed LDS panel ring, two half-output passes per layer
 // with the epilogue of one pass hidden in the MFMA stream of the next, heads on the VALU.
 #pragma once
@@ -92,6 +92,23 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t p) {
     uint32_t r;
     asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(p));
     return r;
+}
+
+// ---- ReLU gates of the training mode, one bit per value, in the layout the input-gradient kernel's select wants ---------------------
+// A mask word covers 16 consecutive packed registers (32 values) of a lane: the gate of the LOW value of pair j sits at bit 15 - j, of
+// the HIGH value at bit 31 - j.  The forward appends a pair with two instructions -- (v_pk_min_u16 relu'd pair, (1, 1)) turns each
+// non-zero half into 1, v_lshl_or_b32 shifts it in -- so the gate is (stored activation != 0): exactly torch's relu backward, also for
+// an accumulator that cancelled to +0.0 (the sign-bit gate of the first version let those pass).  The input-gradient kernel shifts
+// the pair's two bits to the sign positions of the halves and smears them (v_pk_ashrrev_i16 by 15): the AND mask of the packed pair.
+__device__ __forceinline__ uint32_t gate_append(uint32_t word, uint32_t relu_pair) {
+    uint32_t t;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(relu_pair), "s"(0x00010001u));
+    return (word << 1) | t;
+}
+__device__ __forceinline__ uint32_t gate_mask(uint32_t word, int j /* pair index inside the word, compile-time */) {
+    uint32_t m;
+    asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(m) : "s"(0x000f000fu), "v"(word << j));
+    return m;
 }
 
 // ---- weight fragments: LDS reads the compiler does not see ------------------------------------------------------------------

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     // row boundary and then leaves those 8 registers in scratch memory)
     uint32_t dq[kTiles][NQ + 4];   // current D-wide gradient, packed (d pre-activation of hidden 8..1), rewritten in place
     f32x16 accA[kTiles][HT], accB[kTiles][HT];   // halves A ([0,D/2)) and B ([D/2,D)) of the gradient being computed
-    uint32_t mwA[kTiles][HW], mwB[kTiles][HW];   // ReLU sign bits of the layer whose gradient sits in accA / accB
+    uint32_t mwA[kTiles][HW], mwB[kTiles][HW];   // ReLU gates of the layer whose gradient sits in accA / accB (gate_append's layout)
     auto load_mask = [&](uint32_t(&mw)[kTiles][HW], int layer_idx, int hb) __attribute__((always_inline)) {
 #pragma unroll
         for (int n = 0; n < kTiles; ++n) {
@@ -113,17 +113,11 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         }
     };
 // one epilogue unit u: tile u % T, packed register u / T of the half -- dq[tile][OFF + u / T] = (relu'(.) ? acc : 0) x 2 as bf16
-// (sign-extended mask bit + and: two instructions per value)
+// (the gates of a pair as the AND mask of the packed pair: shift, smear, and -- gate_mask, nnr_mlp_bf16.h)
 #define NNR_SEL_UNIT(ACC, OFF, MW)                                                                           \
     [&](int u) __attribute__((always_inline)) {                                                              \
         const int n = u % T, p = u / T;                                                                      \
-        float v[2];                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
-            const int r = 2 * p + i;                                                                         \
-            const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe((int)MW[n][r >> 5], r & 31, 1);            \
-            v[i] = __uint_as_float(__float_as_uint(ACC[n][r >> 4][r & 15]) & keep);                          \
-        }                                                                                                    \
-        dq[n][(OFF) + p] = pack_bf16(v[0], v[1]);                                                            \
+        dq[n][(OFF) + p] = pack_bf16(ACC[n][(2 * p) >> 4][(2 * p) & 15], ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]) & gate_mask(MW[n][p >> 4], p & 15); \
     }
     __bf16* const no_stash[kTiles] = {};
     constexpr int PA = 2 * T + 1, PB = 2 * T;   // epilogue units per row of a pass A / pass B (mlp_fwd_bf16_kernel)
@@ -141,13 +135,9 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         for (int n = 0; n < kTiles; ++n) {
             float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * q + i;
-                const float x = fmaf(w2[i], dout[n][2], fmaf(w1[i], dout[n][1], w0[i] * dout[n][0]));
-                v[i] = ((mwA[n][r >> 5] >> (r & 31)) & 1u) ? x : 0.f;
-            }
-            dgq[n][2 * q] = pack_bf16(v[0], v[1]);
-            dgq[n][2 * q + 1] = pack_bf16(v[2], v[3]);
+            for (int i = 0; i < 4; ++i) v[i] = fmaf(w2[i], dout[n][2], fmaf(w1[i], dout[n][1], w0[i] * dout[n][0]));
+            dgq[n][2 * q] = pack_bf16(v[0], v[1]) & gate_mask(mwA[n][(2 * q) >> 4], (2 * q) & 15);
+            dgq[n][2 * q + 1] = pack_bf16(v[2], v[3]) & gate_mask(mwA[n][(2 * q + 1) >> 4], (2 * q + 1) & 15);
         }
     }
     // [d h8 ; d gamma(v)] from d g.  The feature layer is folded into the colour-hidden layer (nnr_layout.h): d h8 =
@@ -208,7 +198,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     // Invariant from here on: dq[.][0, NP) holds half A of the newest gradient, accB its half B still to be masked (mwB).
 
     // one transposed D x D layer at panel pa: consumes the gradient in dq (stashing it to st[]), produces the gradient of the layer
-    // below, masked by the sign bits of hidden layer `mask_idx`
+    // below, masked by the ReLU gates of hidden layer `mask_idx`
     auto bwd_layer = [&](int pa, __bf16* const (&st)[kTiles], int mask_idx) __attribute__((always_inline)) {
         zero_acc2(accA);
         load_mask(mwA, mask_idx, 0);

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     }
     NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 1);
 
-    // accumulators start at the bias (the same for both tiles), so an epilogue is only ReLU + sign bit + pack
+    // accumulators start at the bias (the same for both tiles), so an epilogue is only ReLU + gate bits + pack
     auto init_acc = [&](f32x16(&acc)[kTiles][HT], int bias_offset) __attribute__((always_inline)) {
         const float* b = bias + bias_offset + 4 * half;
 #pragma unroll
@@ -192,28 +192,22 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
                 // store: the two halves of a lane's 16 bytes arrive from different passes and rely on L2 to merge them into lines.
                 uint32_t* m = a.ws_mask + (((int64_t)opaque(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane) * L::mask_words + hb * HW;
                 if constexpr (HW == 2) {
-                    *reinterpret_cast<u32x2*>(m) = u32x2{~__builtin_bitreverse32(mw[n][0]), ~__builtin_bitreverse32(mw[n][1])};
+                    *reinterpret_cast<u32x2*>(m) = u32x2{mw[n][0], mw[n][1]};
                 } else {
 #pragma unroll
-                    for (int w = 0; w < HW; ++w) m[w] = ~__builtin_bitreverse32(mw[n][w]);
+                    for (int w = 0; w < HW; ++w) m[w] = mw[n][w];
                 }
             }
         }
     };
 // One epilogue unit u: tile u % T, packed register u / T of the half -- hq[tile][OFF + u / T] = (relu(x0), relu(x1)) as bf16.
-// Mask bit r = (x > 0), collected as SIGN bits shifted into the word in register order (v_alignbit_b32); store_mask reverses and
-// inverts the finished word.  The two differ only for x == +0.0 exactly -- an fp32 sum that cancelled to zero, 2 of 6.7e7 values at
-// 4096 x 128 -- where this kernel lets the gradient pass and torch's relu backward does not (the stored activation is 0 either way;
-// tests/test_gpu_layer_local.py counts these elements).
+// The ReLU gates of the pair are appended to the mask word of its 16 registers (gate_append, nnr_mlp_bf16.h): units run in register order.
 #define NNR_RELU_UNIT(ACC, OFF, MW)                                                                          \
     [&](int u) __attribute__((always_inline)) {                                                              \
         const int n = u % T, p = u / T;                                                                      \
         const float x0 = ACC[n][(2 * p) >> 4][(2 * p) & 15], x1 = ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]; \
         hq[n][(OFF) + p] = relu_bf16x2(pack_bf16(x0, x1));   /* rounding keeps the sign: relu commutes with it */                                                  \
-        if (TRAIN && !kAblateMask) {                                                                         \
-            MW[n][p >> 4] = __builtin_amdgcn_alignbit(MW[n][p >> 4], __float_as_uint(x0), 31);               \
-            MW[n][p >> 4] = __builtin_amdgcn_alignbit(MW[n][p >> 4], __float_as_uint(x1), 31);               \
-        }                                                                                                    \
+        if (TRAIN && !kAblateMask) MW[n][p >> 4] = gate_append(MW[n][p >> 4], hq[n][(OFF) + p]);             \
     }
     auto p0 = [&](int part) { return L::fwd_panel0(part); };
     __bf16* const no_stash[kTiles] = {};
