@@ -94,6 +94,11 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t p) {
     return r;
 }
 
+#ifndef NNR_UNIT_PHASES
+#define NNR_UNIT_PHASES 1
+#endif
+constexpr int kPh = NNR_UNIT_PHASES;   // epilogue units issued whole (1) or as two half-units in different MFMA gaps (2)
+
 // ---- ReLU gates of the training mode, one bit per value, in the layout the input-gradient kernel's select wants ---------------------
 // A mask word covers 16 consecutive packed registers (32 values) of a lane: the gate of the LOW value of pair j sits at bit 15 - j, of
 // the HIGH value at bit 31 - j.  The forward appends a pair with two instructions -- (v_pk_min_u16 relu'd pair, (1, 1)) turns each

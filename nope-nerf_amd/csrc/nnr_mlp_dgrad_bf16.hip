@@ -115,9 +115,12 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
 // one epilogue unit u: tile u % T, packed register u / T of the half -- dq[tile][OFF + u / T] = (relu'(.) ? acc : 0) x 2 as bf16
 // (the gates of a pair as the AND mask of the packed pair: shift, smear, and -- gate_mask, nnr_mlp_bf16.h)
 #define NNR_SEL_UNIT(ACC, OFF, MW)                                                                           \
-    [&](int u) __attribute__((always_inline)) {                                                              \
+    [&](int uu) __attribute__((always_inline)) {                                                             \
+        const int u = uu / kPh, ph = uu % kPh;                                                               \
         const int n = u % T, p = u / T;                                                                      \
-        dq[n][(OFF) + p] = pack_bf16(ACC[n][(2 * p) >> 4][(2 * p) & 15], ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]) & gate_mask(MW[n][p >> 4], p & 15); \
+        if (kPh == 1 || ph == 0)                                                                             \
+            dq[n][(OFF) + p] = pack_bf16(ACC[n][(2 * p) >> 4][(2 * p) & 15], ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]); \
+        if (kPh == 1 || ph == 1) dq[n][(OFF) + p] &= gate_mask(MW[n][p >> 4], p & 15);                       \
     }
     __bf16* const no_stash[kTiles] = {};
     constexpr int PA = 2 * T + 1, PB = 2 * T;   // epilogue units per row of a pass A / pass B (mlp_fwd_bf16_kernel)
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     load_mask(mwB, 7, 1);
     init_sigma(accB, 1);
     // G = 2 HT rows; unit u writes dq[.][u >> 1] -- not an input of this part
-    gemm_wide<HT, HT, false, NU, NU / (2 * HT), 0, stash_tail<HT, HT, T>()>(accB, dgq, pipe, p0(B_RGBH_FB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
+    gemm_wide<HT, HT, false, kPh * NU, kPh * (NU / (2 * HT)), 0, stash_tail<HT, HT, T>()>(accB, dgq, pipe, p0(B_RGBH_FB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
     {
         // the chain-rule factors are fetched BEFORE the GEMM whose result they multiply: the loads land under it, and the wait for them
         // does not drain the weight DMA issued meanwhile
@@ -204,11 +207,11 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         load_mask(mwA, mask_idx, 0);
         // pass A: rows [0, G/2) only read dq[.][0, NP); the previous gradient's half B is finished meanwhile (unit u at row u / PA, see
         // mlp_fwd_bf16_kernel)
-        gemm_wide<DT, HT, true, NU, PA, 0, 0>(accA, dq, pipe, pa, st, NNR_SEL_UNIT(accB, NP, mwB));
+        gemm_wide<DT, HT, true, kPh * NU, kPh * PA, 0, 0>(accA, dq, pipe, pa, st, NNR_SEL_UNIT(accB, NP, mwB));
         load_mask(mwB, mask_idx, 1);
         zero_acc2(accB);
         // pass B: half A of the new gradient replaces dq[.][0, NP) in place behind the reads (unit u at row u / PB + 1)
-        gemm_wide<DT, HT, false, NU, PB, 1, stash_tail<DT, HT, T>()>(accB, dq, pipe, pa + PP, no_stash, NNR_SEL_UNIT(accA, 0, mwA));
+        gemm_wide<DT, HT, false, kPh * NU, kPh * PB, 1, stash_tail<DT, HT, T>()>(accB, dq, pipe, pa + PP, no_stash, NNR_SEL_UNIT(accA, 0, mwA));
     };
     // hidden 8,7,6 -> d pre-activation of 7,6,5
 #pragma unroll 1
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         f32x16 acce[kTiles][2];
         zero_acc2(acce);
         load_mask(mwA, 3, 0);
-        gemm_wide<DT, 2, true, NU, PA, 0, 0>(acce, dq, pipe, p0(B_L5E), st, NNR_SEL_UNIT(accB, NP, mwB));
+        gemm_wide<DT, 2, true, kPh * NU, kPh * PA, 0, 0>(acce, dq, pipe, p0(B_L5E), st, NNR_SEL_UNIT(accB, NP, mwB));
 #pragma unroll
         for (int n = 0; n < kTiles; ++n) {   // (64 more live registers during the GEMM would spill: the factors are fetched here)
             f32x4 face[8];
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     zero_acc2(accA);
     gemm_wide<DT, HT>(accA, dq, pipe, p0(B_L5HA));   // (the factor loads above were waited for: nothing of B_L5E is in flight)
     zero_acc2(accB);
-    gemm_wide<DT, HT, false, NU, PB, 1, 0>(accB, dq, pipe, p0(B_L5HB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
+    gemm_wide<DT, HT, false, kPh * NU, kPh * PB, 1, 0>(accB, dq, pipe, p0(B_L5HB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
     NNR_STAMP(tl_dgrad16, 3);
     // hidden 4,3,2 -> d pre-activation of 3,2,1
 #pragma unroll 1
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         for (int n = 0; n < kTiles; ++n) st[n] = dh(0, n);
         f32x16 acc2[kTiles][2];
         zero_acc2(acc2);
-        gemm_wide<DT, 2, true, NU, PA, 0, 0>(acc2, dq, pipe, p0(B_L1), st, NNR_SEL_UNIT(accB, NP, mwB));
+        gemm_wide<DT, 2, true, kPh * NU, kPh * PA, 0, 0>(acc2, dq, pipe, p0(B_L1), st, NNR_SEL_UNIT(accB, NP, mwB));
 #pragma unroll
         for (int n = 0; n < kTiles; ++n) {
             const int64_t sn = sample(n);

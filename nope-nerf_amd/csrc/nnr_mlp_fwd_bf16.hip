@@ -202,12 +202,17 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     };
 // One epilogue unit u: tile u % T, packed register u / T of the half -- hq[tile][OFF + u / T] = (relu(x0), relu(x1)) as bf16.
 // The ReLU gates of the pair are appended to the mask word of its 16 registers (gate_append, nnr_mlp_bf16.h): units run in register order.
+// With kPh = 2 a unit is issued as two half-units (index 2 u: read + pack, 2 u + 1: ReLU + gates) in different gaps between MFMAs.
 #define NNR_RELU_UNIT(ACC, OFF, MW)                                                                          \
-    [&](int u) __attribute__((always_inline)) {                                                              \
+    [&](int uu) __attribute__((always_inline)) {                                                             \
+        const int u = uu / kPh, ph = uu % kPh;                                                               \
         const int n = u % T, p = u / T;                                                                      \
-        const float x0 = ACC[n][(2 * p) >> 4][(2 * p) & 15], x1 = ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]; \
-        hq[n][(OFF) + p] = relu_bf16x2(pack_bf16(x0, x1));   /* rounding keeps the sign: relu commutes with it */                                                  \
-        if (TRAIN && !kAblateMask) MW[n][p >> 4] = gate_append(MW[n][p >> 4], hq[n][(OFF) + p]);             \
+        if (kPh == 1 || ph == 0)                                                                             \
+            hq[n][(OFF) + p] = pack_bf16(ACC[n][(2 * p) >> 4][(2 * p) & 15], ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]); \
+        if (kPh == 1 || ph == 1) {                                                                           \
+            hq[n][(OFF) + p] = relu_bf16x2(hq[n][(OFF) + p]);   /* rounding keeps the sign: relu commutes with it */ \
+            if (TRAIN && !kAblateMask) MW[n][p >> 4] = gate_append(MW[n][p >> 4], hq[n][(OFF) + p]);         \
+        }                                                                                                    \
     }
     auto p0 = [&](int part) { return L::fwd_panel0(part); };
     __bf16* const no_stash[kTiles] = {};
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     gemm_wide<2, HT, TRAIN ? T * 18 : 0>(accA, eq, pipe, p0(F_L1A));
     init_acc(accB, L::bias_off(0) + L::Dh);
     clear_mask(mwA);
-    gemm_wide<2, HT, false, NU, NU / 4, 0, TRAIN ? T * 18 : 0>(accB, eq, pipe, p0(F_L1B), no_stash, NNR_RELU_UNIT(accA, 0, mwA));   // (the same stores are younger than panel 1's pieces too)
+    gemm_wide<2, HT, false, kPh * NU, kPh * (NU / 4), 0, TRAIN ? T * 18 : 0>(accB, eq, pipe, p0(F_L1B), no_stash, NNR_RELU_UNIT(accA, 0, mwA));   // (the same stores are younger than panel 1's pieces too)
     store_mask(mwA, 0, 0);
     NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 2);
     // Invariant from here on: hq[.][0, NP) holds half A of the newest layer, accB holds its half B still to be finished.
@@ -235,13 +240,13 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         clear_mask(mwB);
         // pass A: rows [0, G/2) only read hq[.][0, NP); the previous layer's half B is finished meanwhile, unit u at row u / PA --
         // packed register NP + u / T is first read at row G/2 + (u / T) / 4, always a later row (PA = 2 T + 1 units per row)
-        gemm_wide<DT, HT, TRAIN, NU, PA, 0, 0>(accA, hq, pipe, pa, st, NNR_RELU_UNIT(accB, NP, mwB));
+        gemm_wide<DT, HT, TRAIN, kPh * NU, kPh * PA, 0, 0>(accA, hq, pipe, pa, st, NNR_RELU_UNIT(accB, NP, mwB));
         store_mask(mwB, li - 1, 1);
         init_acc(accB, L::bias_off(li) + L::Dh);
         clear_mask(mwA);
         // pass B: half A of the new layer replaces hq[.][0, NP) in place behind the reads -- unit u runs at row u / PB + 1, its
         // register u / T was last read at row (u / T) / 4
-        gemm_wide<DT, HT, false, NU, PB, 1, TAIL>(accB, hq, pipe, pa + PP, no_stash, NNR_RELU_UNIT(accA, 0, mwA));
+        gemm_wide<DT, HT, false, kPh * NU, kPh * PB, 1, TAIL>(accB, hq, pipe, pa + PP, no_stash, NNR_RELU_UNIT(accA, 0, mwA));
         store_mask(mwA, li, 0);
     };
     // hidden 2..4
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         for (int n = 0; n < kTiles; ++n) st[n] = xh(3, n);
         init_acc(accA, L::bias_off(4));
         clear_mask(mwB);
-        gemm_wide<DT, HT, TRAIN, NU, PA, 0, 0>(accA, hq, pipe, p0(F_L5HA), st, NNR_RELU_UNIT(accB, NP, mwB));
+        gemm_wide<DT, HT, TRAIN, kPh * NU, kPh * PA, 0, 0>(accA, hq, pipe, p0(F_L5HA), st, NNR_RELU_UNIT(accB, NP, mwB));
         store_mask(mwB, 3, 1);
 #pragma unroll
         for (int n = 0; n < kTiles; ++n)
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         gemm_wide<2, HT, TAIL>(accA, eq, pipe, p0(F_L5EA));
         init_acc(accB, L::bias_off(4) + L::Dh);
         clear_mask(mwA);
-        gemm_wide<DT, HT, false, NU, PB, 1, 0>(accB, hq, pipe, p0(F_L5HB), no_stash, NNR_RELU_UNIT(accA, 0, mwA));
+        gemm_wide<DT, HT, false, kPh * NU, kPh * PB, 1, 0>(accB, hq, pipe, p0(F_L5HB), no_stash, NNR_RELU_UNIT(accA, 0, mwA));
         gemm_wide<2, HT>(accB, eq, pipe, p0(F_L5EB));
         store_mask(mwA, 4, 0);
     }
@@ -299,10 +304,10 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         init_acc(accA, L::bias_off(10));
         clear_mask(mwB);
         auto finish_then_sigma = [&](int u) __attribute__((always_inline)) {
-            if (u < NU) {
+            if (u < kPh * NU) {
                 NNR_RELU_UNIT(accB, NP, mwB)(u);
             } else {   // registers 4v .. 4v+3 of h8, both tiles; every register is final by now: the NU finishing units come first
-                const int v = u - NU;
+                const int v = u - kPh * NU;
                 const u32x4 w4 = *reinterpret_cast<const u32x4*>(wsig16 + 4 * v);
 #pragma unroll
                 for (int n = 0; n < kTiles; ++n)
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         };
         // all units spread evenly over the rows: finishing unit u (register NP + u / T, first read at row G/2 + (u / T) / 4) runs
         // well before that row
-        gemm_wide<DT, HT, TRAIN, NU + NQ / 4, (NU + NQ / 4 + 2 * DT - 1) / (2 * DT), 0, 0>(accA, hq, pipe, p0(F_RGBH_F), st, finish_then_sigma);
+        gemm_wide<DT, HT, TRAIN, kPh * NU + NQ / 4, (kPh * NU + NQ / 4 + 2 * DT - 1) / (2 * DT), 0, 0>(accA, hq, pipe, p0(F_RGBH_F), st, finish_then_sigma);
         store_mask(mwB, 7, 1);
     }
     NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 6);
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     }
     clear_mask(mwA);
 #pragma unroll
-    for (int u = 0; u < NU; ++u) NNR_RELU_UNIT(accA, 0, mwA)(u);   // g = hq[.][0, NP)
+    for (int u = 0; u < kPh * NU; ++u) NNR_RELU_UNIT(accA, 0, mwA)(u);   // g = hq[.][0, NP)
     store_mask(mwA, 8, 0);
 #pragma unroll
     for (int n = 0; n < kTiles; ++n) {
