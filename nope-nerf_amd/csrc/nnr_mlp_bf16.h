@@ -116,6 +116,54 @@ __device__ __forceinline__ uint32_t gate_mask(uint32_t word, int j /* pair index
     return m;
 }
 
+// The epilogue of a value pair as ONE asm statement each.  Written as separate statements (pack_bf16, relu_bf16x2, gate_append /
+// gate_mask) hipcc puts an s_nop between two of them whenever the second reads what the first wrote -- it cannot know the first is not
+// a DOT or a transcendental -- and with one wave per SIMD an s_nop costs the wave the same ~4 cycles of issue as a real instruction
+// (tools/ubench/mfma_valu_overlap.hip): 1.7 of the forward's 10.9 non-MFMA instructions per MFMA were s_nops.
+// forward, training: packed relu'd pair; `word` gets the pair's two gates appended (gate_append's layout)
+__device__ __forceinline__ uint32_t relu_pack_gate(float x0, float x1, uint32_t& word) {
+    uint32_t h, t;
+    asm("v_cvt_pk_bf16_f32 %0, %3, %4\n\tv_pk_max_i16 %0, %0, 0\n\tv_pk_min_u16 %1, %0, %5\n\tv_lshl_or_b32 %2, %2, 1, %1"
+        : "=&v"(h), "=&v"(t), "+v"(word)
+        : "v"(x0), "v"(x1), "s"(0x00010001u));
+    return h;
+}
+// forward, inference: packed relu'd pair
+__device__ __forceinline__ uint32_t relu_pack(float x0, float x1) {
+    uint32_t h;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=&v"(h) : "v"(x0), "v"(x1));
+    return h;
+}
+// input gradient: packed pair gated by pair j of `word` (gate_mask's shift / smear / and); J is a compile-time constant
+template <int J>
+__device__ __forceinline__ uint32_t pack_gated(float x0, float x1, uint32_t word) {
+    uint32_t d, m;
+    if constexpr (J == 0)
+        asm("v_pk_ashrrev_i16 %1, %5, %4\n\tv_cvt_pk_bf16_f32 %0, %2, %3\n\tv_and_b32 %0, %0, %1"
+            : "=&v"(d), "=&v"(m)
+            : "v"(x0), "v"(x1), "v"(word), "s"(0x000f000fu));
+    else
+        asm("v_lshlrev_b32 %1, %6, %4\n\tv_cvt_pk_bf16_f32 %0, %2, %3\n\tv_pk_ashrrev_i16 %1, %5, %1\n\tv_and_b32 %0, %0, %1"
+            : "=&v"(d), "=&v"(m)
+            : "v"(x0), "v"(x1), "v"(word), "s"(0x000f000fu), "n"(J));
+    return d;
+}
+
+__device__ __forceinline__ uint32_t sel_pair(float x0, float x1, uint32_t word, int j) {   // j folds after unrolling
+    switch (j) {
+#define NNR_SEL_CASE(J) case J: return pack_gated<J>(x0, x1, word);
+        NNR_SEL_CASE(0) NNR_SEL_CASE(1) NNR_SEL_CASE(2) NNR_SEL_CASE(3) NNR_SEL_CASE(4) NNR_SEL_CASE(5) NNR_SEL_CASE(6) NNR_SEL_CASE(7)
+        NNR_SEL_CASE(8) NNR_SEL_CASE(9) NNR_SEL_CASE(10) NNR_SEL_CASE(11) NNR_SEL_CASE(12) NNR_SEL_CASE(13) NNR_SEL_CASE(14)
+#undef NNR_SEL_CASE
+        default: return pack_gated<15>(x0, x1, word);
+    }
+}
+#ifdef NNR_SPLIT_ASM        // profiling builds only: the epilogue as separate asm statements (the A/B of the fused ones)
+constexpr bool kSplitAsm = true;
+#else
+constexpr bool kSplitAsm = false;
+#endif
+
 // ---- weight fragments: LDS reads the compiler does not see ------------------------------------------------------------------
 // hipcc waits lgkmcnt(0) before the first MFMA that uses a fragment it loaded itself -- i.e. for EVERY outstanding LDS read, also the
 // refill issued one instruction earlier: a full LDS latency per row with the matrix pipe idle (a third of the layer loop).  LDS reads

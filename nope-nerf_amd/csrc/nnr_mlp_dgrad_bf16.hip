@@ -118,9 +118,13 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     [&](int uu) __attribute__((always_inline)) {                                                             \
         const int u = uu / kPh, ph = uu % kPh;                                                               \
         const int n = u % T, p = u / T;                                                                      \
-        if (kPh == 1 || ph == 0)                                                                             \
-            dq[n][(OFF) + p] = pack_bf16(ACC[n][(2 * p) >> 4][(2 * p) & 15], ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]); \
-        if (kPh == 1 || ph == 1) dq[n][(OFF) + p] &= gate_mask(MW[n][p >> 4], p & 15);                       \
+        const float x0 = ACC[n][(2 * p) >> 4][(2 * p) & 15], x1 = ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]; \
+        if constexpr (kPh == 1 && !kSplitAsm) {   /* one asm statement per pair: no compiler-inserted s_nops (nnr_mlp_bf16.h) */ \
+            dq[n][(OFF) + p] = sel_pair(x0, x1, MW[n][p >> 4], p & 15);                                      \
+        } else {                                                                                             \
+            if (kPh == 1 || ph == 0) dq[n][(OFF) + p] = pack_bf16(x0, x1);                                   \
+            if (kPh == 1 || ph == 1) dq[n][(OFF) + p] &= gate_mask(MW[n][p >> 4], p & 15);                   \
+        }                                                                                                    \
     }
     __bf16* const no_stash[kTiles] = {};
     constexpr int PA = 2 * T + 1, PB = 2 * T;   // epilogue units per row of a pass A / pass B (mlp_fwd_bf16_kernel)

@@ -207,11 +207,16 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     [&](int uu) __attribute__((always_inline)) {                                                             \
         const int u = uu / kPh, ph = uu % kPh;                                                               \
         const int n = u % T, p = u / T;                                                                      \
-        if (kPh == 1 || ph == 0)                                                                             \
-            hq[n][(OFF) + p] = pack_bf16(ACC[n][(2 * p) >> 4][(2 * p) & 15], ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]); \
-        if (kPh == 1 || ph == 1) {                                                                           \
-            hq[n][(OFF) + p] = relu_bf16x2(hq[n][(OFF) + p]);   /* rounding keeps the sign: relu commutes with it */ \
-            if (TRAIN && !kAblateMask) MW[n][p >> 4] = gate_append(MW[n][p >> 4], hq[n][(OFF) + p]);         \
+        const float x0 = ACC[n][(2 * p) >> 4][(2 * p) & 15], x1 = ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]; \
+        if constexpr (kPh == 1 && !kSplitAsm) {   /* one asm statement per pair: no compiler-inserted s_nops (nnr_mlp_bf16.h) */ \
+            if (TRAIN && !kAblateMask) hq[n][(OFF) + p] = relu_pack_gate(x0, x1, MW[n][p >> 4]);             \
+            else hq[n][(OFF) + p] = relu_pack(x0, x1);                                                       \
+        } else {                                                                                             \
+            if (kPh == 1 || ph == 0) hq[n][(OFF) + p] = pack_bf16(x0, x1);                                   \
+            if (kPh == 1 || ph == 1) {                                                                       \
+                hq[n][(OFF) + p] = relu_bf16x2(hq[n][(OFF) + p]);   /* rounding keeps the sign: relu commutes with it */ \
+                if (TRAIN && !kAblateMask) MW[n][p >> 4] = gate_append(MW[n][p >> 4], hq[n][(OFF) + p]);     \
+            }                                                                                                \
         }                                                                                                    \
     }
     auto p0 = [&](int part) { return L::fwd_panel0(part); };

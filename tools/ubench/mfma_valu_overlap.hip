@@ -134,6 +134,75 @@ static void run_row(unsigned long long* out) {
            READS ? "6 in-place fragment refills (ds_read_b128, counted waits)" : "fragments in registers", UNITS, K, per, per / g_alone);
 }
 
+// Issue cost of single instruction kinds: 8 INDEPENDENT copies (different registers) of one op after every MFMA.
+template <int OP>
+__global__ __launch_bounds__(256, 1) void op_bench(unsigned long long* out, int iters) {
+    f32x16 acc[kAcc], other[4];
+#pragma unroll
+    for (int i = 0; i < kAcc; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) other[i][r] = (float)(threadIdx.x + r);
+    uint32_t x[8], y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[i] = threadIdx.x * 77 + i; y[i] = 0; }
+    const bf16x8 a = {1, 1, 1, 1, 1, 1, 1, 1}, b = {1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+a"(other[i]));
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < kAcc; ++j) {
+            if (OP < 100) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (OP == 107) asm volatile("v_and_b32 %0, %1, %2" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
+                if (OP == 0) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(y[i]) : "a"(other[i & 3][i]));
+                if (OP == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
+                if (OP == 2) asm volatile("v_pk_max_i16 %0, %1, 0" : "=v"(y[i]) : "v"(x[i]));
+                if (OP == 3) asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(y[i]) : "v"(x[i]), "s"(0x00010001u));
+                if (OP == 4) asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
+                if (OP == 5) asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
+                if (OP == 6) asm volatile("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(y[i]) : "s"(0x000f000fu), "v"(x[i]));
+                if (OP == 7) asm volatile("v_and_b32 %0, %1, %2" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
+                if (OP == 8) asm volatile("v_alignbit_b32 %0, %1, %2, 31" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
+                if (OP == 9) asm volatile("s_nop 0");
+                if (OP == 10) asm volatile("v_max_f32 %0, %1, 0" : "=v"(y[i]) : "v"(x[i]));
+                if (OP == 11) asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(y[i]) : "v"(x[i]));
+                if (OP == 12) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x[i]) : "v"(x[(i + 1) & 7]));
+                if (OP == 13) asm volatile("v_fma_f32 %0, %1, %2, %1" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
+                if (OP == 14) asm volatile("v_mov_b32 %0, %1" : "=v"(y[i]) : "v"(x[i]));
+                if (OP == 15) asm volatile("v_and_b32 %0, %1, %1" : "=v"(y[i]) : "v"(x[i]));
+            }
+        }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (float)y[i];
+#pragma unroll
+    for (int i = 0; i < kAcc; ++i) s += acc[i][0];
+    if (s == 12345.678f) out[1] = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = t1 - t0;
+}
+
+template <int OP>
+static void run_op(const char* what, unsigned long long* out) {
+    const int iters = 2000;
+    hipLaunchKernelGGL((op_bench<OP>), dim3(256), dim3(256), 4096, 0, out, iters);
+    hipLaunchKernelGGL((op_bench<OP>), dim3(256), dim3(256), 4096, 0, out, iters);
+    CK(hipDeviceSynchronize());
+    unsigned long long t;
+    CK(hipMemcpy(&t, out, 8, hipMemcpyDeviceToHost));
+    const double per = (double)t / (iters * (double)kAcc);
+    printf("8 independent %-34s after each MFMA: %7.3f ticks per MFMA -> ~%.1f cycles per instruction beyond the MFMA's own 8\n", what, per,
+           (per - 8.0) / 8.0);
+}
+
 template <int KIND, int K>
 static void run(const char* what, unsigned long long* out) {
     const int iters = 2000;
@@ -163,6 +232,23 @@ int main() {
     run<1, 8>("+ K instructions of the epilogue mix", out);
     run<2, 1>("+ K ds_read_b128 (waited) after each MFMA", out);
     run<2, 2>("+ K ds_read_b128 (waited) after each MFMA", out);
+    run_op<0>("v_accvgpr_read_b32", out);
+    run_op<1>("v_cvt_pk_bf16_f32", out);
+    run_op<2>("v_pk_max_i16 (inline 0)", out);
+    run_op<3>("v_pk_min_u16 (SGPR operand)", out);
+    run_op<4>("v_pk_min_u16 (VGPR operands)", out);
+    run_op<5>("v_lshl_or_b32", out);
+    run_op<6>("v_pk_ashrrev_i16 (SGPR shift)", out);
+    run_op<7>("v_and_b32", out);
+    run_op<8>("v_alignbit_b32", out);
+    run_op<9>("s_nop 0", out);
+    run_op<10>("v_max_f32", out);
+    run_op<11>("v_bfe_i32", out);
+    run_op<12>("v_and_b32 in place", out);
+    run_op<13>("v_fma_f32 y = x * x' + x", out);
+    run_op<14>("v_mov_b32", out);
+    run_op<15>("v_and_b32 y = x & x", out);
+    run_op<107>("v_and_b32, NO MFMA", out);
     run_row<0, 0, 4>(out);
     run_row<1, 0, 4>(out);
     run_row<1, 4, 4>(out);
