@@ -134,7 +134,8 @@ static void run_row(unsigned long long* out) {
            READS ? "6 in-place fragment refills (ds_read_b128, counted waits)" : "fragments in registers", UNITS, K, per, per / g_alone);
 }
 
-// Issue cost of single instruction kinds: 8 INDEPENDENT copies (different registers) of one op after every MFMA.
+// Issue cost of single instruction kinds: 8 independent copies of one op after every MFMA (in-place ops on 8 registers; a dead or
+// shared destination would make hipcc put an s_nop between two asm statements and double the count).
 template <int OP>
 __global__ __launch_bounds__(256, 1) void op_bench(unsigned long long* out, int iters) {
     f32x16 acc[kAcc], other[4];
@@ -159,23 +160,8 @@ __global__ __launch_bounds__(256, 1) void op_bench(unsigned long long* out, int 
             if (OP < 100) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(a), "v"(b));
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (OP == 107) asm volatile("v_and_b32 %0, %1, %2" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
-                if (OP == 0) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(y[i]) : "a"(other[i & 3][i]));
-                if (OP == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
-                if (OP == 2) asm volatile("v_pk_max_i16 %0, %1, 0" : "=v"(y[i]) : "v"(x[i]));
-                if (OP == 3) asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(y[i]) : "v"(x[i]), "s"(0x00010001u));
-                if (OP == 4) asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
-                if (OP == 5) asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
-                if (OP == 6) asm volatile("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(y[i]) : "s"(0x000f000fu), "v"(x[i]));
-                if (OP == 7) asm volatile("v_and_b32 %0, %1, %2" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
-                if (OP == 8) asm volatile("v_alignbit_b32 %0, %1, %2, 31" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
                 if (OP == 9) asm volatile("s_nop 0");
-                if (OP == 10) asm volatile("v_max_f32 %0, %1, 0" : "=v"(y[i]) : "v"(x[i]));
-                if (OP == 11) asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(y[i]) : "v"(x[i]));
                 if (OP == 12) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x[i]) : "v"(x[(i + 1) & 7]));
-                if (OP == 13) asm volatile("v_fma_f32 %0, %1, %2, %1" : "=v"(y[i]) : "v"(x[i]), "v"(x[(i + 1) & 7]));
-                if (OP == 14) asm volatile("v_mov_b32 %0, %1" : "=v"(y[i]) : "v"(x[i]));
-                if (OP == 15) asm volatile("v_and_b32 %0, %1, %1" : "=v"(y[i]) : "v"(x[i]));
             }
         }
     }
@@ -232,23 +218,8 @@ int main() {
     run<1, 8>("+ K instructions of the epilogue mix", out);
     run<2, 1>("+ K ds_read_b128 (waited) after each MFMA", out);
     run<2, 2>("+ K ds_read_b128 (waited) after each MFMA", out);
-    run_op<0>("v_accvgpr_read_b32", out);
-    run_op<1>("v_cvt_pk_bf16_f32", out);
-    run_op<2>("v_pk_max_i16 (inline 0)", out);
-    run_op<3>("v_pk_min_u16 (SGPR operand)", out);
-    run_op<4>("v_pk_min_u16 (VGPR operands)", out);
-    run_op<5>("v_lshl_or_b32", out);
-    run_op<6>("v_pk_ashrrev_i16 (SGPR shift)", out);
-    run_op<7>("v_and_b32", out);
-    run_op<8>("v_alignbit_b32", out);
+    run_op<12>("v_and_b32 (in place)", out);
     run_op<9>("s_nop 0", out);
-    run_op<10>("v_max_f32", out);
-    run_op<11>("v_bfe_i32", out);
-    run_op<12>("v_and_b32 in place", out);
-    run_op<13>("v_fma_f32 y = x * x' + x", out);
-    run_op<14>("v_mov_b32", out);
-    run_op<15>("v_and_b32 y = x & x", out);
-    run_op<107>("v_and_b32, NO MFMA", out);
     run_row<0, 0, 4>(out);
     run_row<1, 0, 4>(out);
     run_row<1, 4, 4>(out);
