@@ -336,13 +336,13 @@ def cpu_config0(warmup=1, steps=3):
             'sample': f'median of {steps} steps after {warmup} warm-ups'}
 
 
-def _timed_steps(trainer, data, warmup, steps, world):
+def _timed_steps(trainer, data, warmup, steps, use_dist):
     def step(i):
         return trainer.train_step(data, it=i, epoch=0, scheduling_start=10000, render_path=None)
     ld = None
     for i in range(warmup):
         ld = step(i)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     from nnr import lib as L
@@ -352,14 +352,14 @@ def _timed_steps(trainer, data, warmup, steps, world):
     for i in range(steps):
         ld = step(warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ms4, n4 = (C.c_float * 4)(), (C.c_int32 * 4)()
     L.check(lib.nnr_prof_end(ms4, n4), 'nnr_prof_end')
     in_step = {'mlp_fwd': float(ms4[0]), 'mlp_dgrad': float(ms4[1]), 'mlp_wgrad': float(ms4[2]), 'launches': int(n4[0])}
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=data['img'].device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -371,7 +371,7 @@ def extra_config(device, name, rays, n_samples, bf16, steps=10, warmup=3):
     """One more BASELINE configuration measured in the same run on one GPU: full Trainer.train_step + the kernels' roofline."""
     trainer, net = build_trainer(device, 1, False, bf16, rays, n_samples)
     data = synthetic_batch(device)
-    elapsed, loss, in_step = _timed_steps(trainer, data, warmup, steps, 1)
+    elapsed, loss, in_step = _timed_steps(trainer, data, warmup, steps, False)
     ms = elapsed / steps * 1e3
     roof = kernel_roofline(net, device, reps=3, bf16=bf16, rays=rays, n_samples=n_samples, in_step=in_step)
     out = {'workload': name, 'rays_per_gpu': rays, 'n_samples': n_samples, 'hidden': HIDDEN,
@@ -470,7 +470,13 @@ def main():
     torch.cuda.set_device(local_rank % n_dev)
     device = torch.device('cuda', local_rank % n_dev)
     backend = 'gloo' if shared else 'nccl'      # RCCL refuses two ranks on one device; gloo carries device tensors through the host
-    if world > 1:
+    # NNR_BENCH_FORCE_DIST=1: join the process group, all-reduce the gradients and report the `collective` block at world size 1
+    # too -- the RCCL leg of this script (init with device_id, the step's all-reduce, the probe) on a one-GPU box (tests/test_gpu_bench_ranks.py)
+    use_dist = world > 1 or os.environ.get('NNR_BENCH_FORCE_DIST') == '1'
+    if use_dist:
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        if world == 1:
+            os.environ['NNR_DP_ALWAYS_REDUCE'] = '1'
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
@@ -479,9 +485,9 @@ def main():
     R, N = args.rays_per_gpu, args.samples
     trainer, net = build_trainer(device, world, args.aux, args.bf16, R, N)
     data = synthetic_batch(device)
-    elapsed, loss_val, in_step = _timed_steps(trainer, data, args.warmup, args.steps, world)
+    elapsed, loss_val, in_step = _timed_steps(trainer, data, args.warmup, args.steps, use_dist)
     ranks_seen, ar_us = (1, None)
-    if world > 1:
+    if use_dist:
         n_grad = sum(p.numel() for m in (net, trainer.pose_param_net, trainer.distortion_net) for p in m.parameters()) + 9
         ranks_seen, ar_us = allreduce_probe(device, n_grad)
 
@@ -501,7 +507,7 @@ def main():
                        'parallelism': f'dp{world} (ray-sharded, one flat all-reduce)'},
             'final_loss': round(loss_val, 6),
         }
-        if world > 1:
+        if use_dist:
             out['collective'] = {'backend': 'rccl' if backend == 'nccl' else 'gloo (shared GPU dry run)', 'rccl_ranks_seen': ranks_seen,
                                  'allreduce_us': round(ar_us, 1), 'bucket_floats': n_grad}
         out['roofline'] = kernel_roofline(net, device, bf16=args.bf16, rays=R, n_samples=N, in_step=in_step)
@@ -517,7 +523,7 @@ def main():
                 'cpu_32x64_d128': None if args.no_cpu_baseline else cpu_config0(),
             }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

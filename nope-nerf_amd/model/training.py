@@ -103,7 +103,7 @@ class Trainer(object):
         loss_dict = self.compute_loss(data, it=it, epoch=epoch, scheduling_start=scheduling_start,
                                       out_render_path=render_path)
         loss_dict['loss'].backward()
-        if parallel.world_size() > 1:
+        if parallel.world_size() > 1 or parallel.always_reduce():
             nets = [self.model] + [n for n, _ in self._groups() if n]
             parallel.allreduce_gradients([p for n in nets for p in n.parameters()], loss_dict)
         self.optimizer.step()

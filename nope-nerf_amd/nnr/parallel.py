@@ -19,6 +19,13 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def always_reduce() -> bool:
+    """NNR_DP_ALWAYS_REDUCE=1: run the step's gradient all-reduce on a ONE-rank group too (a no-op numerically) -- lets a one-GPU box
+    exercise the RCCL path of the step (bench.py with NNR_BENCH_FORCE_DIST=1, tests/test_gpu_bench_ranks.py)."""
+    import os
+    return os.environ.get('NNR_DP_ALWAYS_REDUCE') == '1' and dist.is_available() and dist.is_initialized()
+
+
 def shard_bounds(n: int, rank_: int, world: int):
     """Contiguous [lo, hi) slice of n rays owned by `rank_`; slices differ by at most one ray and cover [0, n)."""
     base, rem = divmod(n, world)
