@@ -47,6 +47,9 @@ R_PER_GPU, N_SAMPLES, HIDDEN = 1024, 192, 256     # BASELINE configs[1]
 IMG_H, IMG_W, N_CAMS = 540, 960, 16
 MACS_PER_SAMPLE = {256: 593408, 128: 157440}   # sum of in x out over the 12 nn.Linear
 FLOP_PER_SAMPLE_PASS = 2 * MACS_PER_SAMPLE[256]   # forward == dgrad == wgrad
+# MACs the kernels EXECUTE per sample and pass: fc_feature folded into the colour-hidden layer by the pack kernel (an exact algebraic
+# rewrite, DESIGN.md section 4.1 "merged layer": -D*D), odd widths padded inside the MFMA fragments (63 -> 64, 27 -> 32)
+EXECUTED_MACS_PER_SAMPLE = {D: 64 * D + 3 * D * D + (D + 64) * D + 3 * D * D + D + (D + 32) * (D // 2) + (D // 2) * 3 for D in (128, 256)}
 PEAK_FP32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0               # dense bf16 MFMA (not the 2:1-sparsity headline figure)
 PEAK_HBM_GBS = 8000.0                        # HBM3E
@@ -209,7 +212,9 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
     how = ('HIP events on the launch stream around every launch of the kernel inside the %d timed training steps' % in_step['launches']
            if in_step else 'HIP events around %d back-to-back launches of the kernel alone' % reps)
     flops = 2 * MACS_PER_SAMPLE[D] * R * N
+    executed = 2 * EXECUTED_MACS_PER_SAMPLE[D] * R * N
     per = {k: {'ms': round(v, 4), 'tflops': round(flops / (v * 1e-3) / 1e12, 2) if k.startswith('mlp_') else None,
+               'executed_tflops': round(executed / (v * 1e-3) / 1e12, 2) if k.startswith('mlp_') else None,
                'isolated_ms': round(isolated[k], 4)} for k, v in times.items()}
     dom = max(('mlp_fwd', 'mlp_dgrad', 'mlp_wgrad'), key=lambda k: times[k])
     achieved = flops / (times[dom] * 1e-3) / 1e12
@@ -237,7 +242,8 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
     return {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': src, 'timing': how,
-        'flop_per_launch': flops, 'kernels': per, 'fused_mlp_all_three': three,
+        'flop_per_launch': flops, 'executed_flop_per_launch': executed, 'executed_tflops': round(executed / (times[dom] * 1e-3) / 1e12, 2),
+        'executed_frac': round(executed / (times[dom] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), 'kernels': per, 'fused_mlp_all_three': three,
     }
 
 
@@ -260,7 +266,42 @@ def _host_cpu():
     return os.cpu_count() or 1, model
 
 
+def cpu_baseline_reference(rays=R_PER_GPU, warmup=2, steps=5):
+    """The REFERENCE ITSELF on this host's cores (`kind: "reference"`): tools/cpu_reference_baseline.py, in its own process, runs the
+    staged, unmodified copy of /root/reference/model (gpurun_stage/reference_cpu/, git-ignored, put there by tools/stage_reference.py /
+    __graft_entry__.build() in the authoring container) -- nope_nerf.forward + the reference's loss heads + backward on the headline
+    workload, 2 warm-ups + 5 timed steps, median.  None when nothing is staged or the worker fails (the caller falls back to the port)."""
+    stage = os.path.join(ROOT, 'gpurun_stage', 'reference_cpu')
+    if not os.path.isfile(os.path.join(stage, 'model', 'rendering.py')):
+        return None, 'no staged reference (gpurun_stage/reference_cpu/model missing)'
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'cpu_reference_baseline.py'), '--rays', str(rays), '--samples', str(N_SAMPLES),
+           '--hidden', str(HIDDEN), '--warmup', str(warmup), '--steps', str(steps)]
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'PYTHONPATH')}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        if r.returncode != 0 or not lines:
+            return None, 'reference worker failed: ' + (r.stderr.strip().splitlines() or ['?'])[-1][:300]
+        return json.loads(lines[-1]), None
+    except Exception as e:        # noqa: BLE001 -- a baseline must never take the benchmark down
+        return None, 'reference worker failed: %r' % (e,)
+
+
 def cpu_baseline(sample_rays=192, warmup=2, steps=5):
+    """`cpu_baseline` of the JSON line: the reference's own code when it is staged (cpu_baseline_reference: kind "reference", the
+    whole 1024-ray headline step), otherwise the oracle port on a bounded sample (cpu_baseline_port: kind "port"); the block says
+    which ran and, for the port, why."""
+    ref, why = cpu_baseline_reference()
+    if ref is not None:
+        port = cpu_baseline_port(sample_rays, warmup, steps)      # the oracle beside it: the port runs at the reference's speed
+        ref['oracle_port_cross_check'] = {k: port[k] for k in ('value', 'unit', 'sample')}
+        return ref
+    out = cpu_baseline_port(sample_rays, warmup, steps)
+    out['fallback_reason'] = why
+    return out
+
+
+def cpu_baseline_port(sample_rays=192, warmup=2, steps=5):
     """The CPU oracle (oracle/nerf_oracle.py, a port of the reference's PyTorch path: the reference itself cannot travel to the GPU
     box) on this host's cores, on a bounded sample of the headline workload: `sample_rays` rays x 192 samples, D=256, forward +
     loss heads + backward; median of `steps` timed steps after `warmup` untimed ones."""

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNR_ABI_VERSION 1
+#define NNR_ABI_VERSION 2
 
 /* error codes */
 #define NNR_OK 0
@@ -181,11 +181,12 @@ int nnr_pixels_from_index(const int64_t* ray_idx, float* pixels, int32_t n_rays,
  * (model/losses.py:125-148) without the (3, S, D) difference tensor.  Same fp32 distance as torch.linalg.norm, first
  * index on ties.  scratch: n_src * 8 bytes, 8-byte aligned.
  * nnr_pc_error_bwd: gradient of mean_s dist[s] times the device scalar g_loss[0]: g_src (n_src,3) is overwritten,
- * g_dst (n_dst,3) is ACCUMULATED into (zero-fill first); either may be null. */
+ * g_dst (n_dst,3) is ACCUMULATED into (zero-fill first); either may be null.  Bit-reproducible: destination j gathers the terms
+ * of the sources matched to it in source order (no float atomics). */
 int nnr_pc_nearest(const float* src, const float* dst, int32_t n_src, int32_t n_dst, int64_t* idx, float* dist, void* scratch,
                    void* stream);
 int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_loss, int32_t n_src,
-                     float* g_src, float* g_dst, void* stream);
+                     int32_t n_dst, float* g_src, float* g_dst, void* stream);
 
 /* Per-image losses between a frame ("1") and its neighbour ("2"), fused (SURVEY 8 f1 + f2): the inputs of reference
  * model/training.py:315-358 and the point-cloud / surface re-projection losses of model/losses.py:114-157 (with_ssim off)

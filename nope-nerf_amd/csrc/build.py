@@ -28,7 +28,7 @@ HEADERS = ["nnr_layout.h", "nnr_device.h", "nnr_kernels.h", "nnr_mlp_bf16.h", os
 # the register arrays they index fall back to scratch memory).  LLVM caps `#pragma unroll` at 16 K instructions per loop; one GEMM part
 # of the fp32 input-gradient kernel sat right at that cap, and an unrelated clean-up pushed it over: the kernel compiled without a
 # warning, kept passing every parity test and ran 8x slower (832 bytes of scratch per lane).  Hence the raised cap AND the check below.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-mllvm", "-pragma-unroll-threshold=1048576",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-pragma-unroll-threshold=1048576",
          "-Rpass-analysis=kernel-resource-usage", "-I" + HERE, "-I" + os.path.join(HERE, "..", "..", "include"), "-x", "hip"]
 # scratch bytes per lane a hot kernel may use (spills of lane-constant addresses outside the MFMA streams in the bf16 training kernels)
 SCRATCH_LIMIT = {"mlp_fwd_kernel": 0, "mlp_dgrad_kernel": 0, "wgrad_kernel": 0, "wgrad_b_kernel": 0, "mlp_fwd_bf16_kernel": 256,

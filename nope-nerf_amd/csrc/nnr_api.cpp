@@ -815,9 +815,9 @@ int nnr_pc_nearest(const float* src, const float* dst, int32_t n_src, int32_t n_
 }
 
 int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_loss, int32_t n_src,
-                     float* g_src, float* g_dst, void* stream) {
-    if (!src || !dst || !idx || !dist || !g_loss || n_src <= 0 || (!g_src && !g_dst)) return NNR_E_BADCFG;
-    NNR_LAUNCH(launch_pc_error_bwd(src, dst, idx, dist, g_loss, n_src, g_src, g_dst, (hipStream_t)stream));
+                     int32_t n_dst, float* g_src, float* g_dst, void* stream) {
+    if (!src || !dst || !idx || !dist || !g_loss || n_src <= 0 || n_dst <= 0 || (!g_src && !g_dst)) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_pc_error_bwd(src, dst, idx, dist, g_loss, n_src, n_dst, g_src, g_dst, (hipStream_t)stream));
 }
 
 size_t nnr_randperm_scratch_bytes(int32_t r) {

@@ -227,8 +227,66 @@ __global__ void aux_pc_bwd_kernel(const float* src, const float* dst, const int6
     }
 }
 
-// backward per point: chain gX, gY (point-cloud loss) and the saved d(point loss)/d(xy) (re-projection loss) back to the
-// two depth images, the relative transform and scale2
+// d loss / d (d1, d2) of point i, the chain of gX, gY (point-cloud loss) and of the saved d(point loss)/d(xy) (re-projection loss)
+// back to the two depth values; with ACC also this point's contribution to dL/d rel[r][0..3] (r = 0..2) and dL/d scale2 in acc[13]
+template <bool ACC>
+__device__ __forceinline__ void aux_point_grads(const AuxArgs& a, int i, float& gd1, float& gd2, uint32_t& fl, int& src1, float (&acc)[13]) {
+    const AuxGeom g = aux_geometry(a, i);
+    fl = a.pflags[i];
+    src1 = g.src1;
+    const bool scale = (a.flags & NNR_AUX_SCALE_PCS) != 0;
+    const float s2 = scale ? a.scale2[0] : 1.f;
+    float g_rot[3] = {0.f, 0.f, 0.f}, g_rot_s[3] = {0.f, 0.f, 0.f}, g_pc2[3] = {0.f, 0.f, 0.f};
+    if (a.flags & NNR_AUX_PC) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float gx = fix_get(a.gXq + 3 * i + r), gy = fix_get(a.gYq + 3 * i + r);
+            g_rot[r] = gx / s2;
+            g_pc2[r] = gy / s2;
+            if (ACC && scale) acc[12] -= (gx * a.X[3 * i + r] + gy * a.Y[3 * i + r]) / s2;
+        }
+    }
+    if ((a.flags & NNR_AUX_RGBS) && (fl & kValid) && !(fl & kBehind) && a.acc[1] > 0.f && i >= a.s_lo && i < a.s_hi) {
+        float q[3], xy[2];
+        aux_project(a, g, q, xy);
+        const float coef = a.g_out[1] / (3.f * a.acc[1]);
+        const float gx = a.gxy[2 * i] * coef, gy = a.gxy[2 * i + 1] * coef;
+        const float gq[3] = {gx / q[2], gy / q[2], -(gx * q[0] + gy * q[1]) / (q[2] * q[2])};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g_rot_s[c] = a.K[c] * gq[0] + a.K[4 + c] * gq[1] + a.K[8 + c] * gq[2];
+    }
+    float g_pc1[3] = {0.f, 0.f, 0.f};
+    const bool detach = (a.flags & NNR_AUX_DETACH_RGBS) != 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float gt = g_rot[r] + g_rot_s[r];
+        if (ACC) {
+            acc[4 * r + 0] = gt * g.pc1[0];
+            acc[4 * r + 1] = gt * g.pc1[1];
+            acc[4 * r + 2] = gt * g.pc1[2];
+            acc[4 * r + 3] = gt;
+        }
+        const float gp = g_rot[r] + (detach ? 0.f : g_rot_s[r]);   // detach_rgbs_scale: the re-projection sees a detached cloud
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g_pc1[c] += a.rel[4 * r + c] * gp;
+    }
+    // pc = Kinv[:, :3] (x' d, y' d, d) + Kinv[:, 3]  ->  d pc / d d = Kinv[:, :3] (x', y', 1)
+    gd1 = 0.f;
+    gd2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float* k = a.Kinv + 4 * r;
+        const float dir = k[0] * g.xp + k[1] * g.yp + k[2];
+        gd1 += g_pc1[r] * dir;
+        gd2 += g_pc2[r] * dir;
+    }
+}
+
+// backward per point.  The depth-image gradients: the (hr, wr) sampling grid reads the (hd, wd) depth maps through a nearest resize, so
+// the points that share a depth pixel form a RECTANGLE of the grid (the source index is monotone in y and in x).  Its first point (row-
+// major) owns the pixel: it re-evaluates the other points of the rectangle and adds their gradients in row-major order -- no float
+// atomics, bit-reproducible.  With a depth map at least as fine as the grid (the usual case: the grid is the image / pc_ratio) every
+// rectangle is one point and nothing is evaluated twice.
 __global__ __launch_bounds__(256) void aux_points_bwd_kernel(AuxArgs a) {
     __shared__ float scratch[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -236,53 +294,30 @@ __global__ __launch_bounds__(256) void aux_points_bwd_kernel(AuxArgs a) {
 #pragma unroll
     for (int k = 0; k < 13; ++k) acc[k] = 0.f;
     if (i < a.S) {
-        const AuxGeom g = aux_geometry(a, i);
-        const uint32_t fl = a.pflags[i];
-        const bool scale = (a.flags & NNR_AUX_SCALE_PCS) != 0;
-        const float s2 = scale ? a.scale2[0] : 1.f;
-        float g_rot[3] = {0.f, 0.f, 0.f}, g_rot_s[3] = {0.f, 0.f, 0.f}, g_pc2[3] = {0.f, 0.f, 0.f};
-        if (a.flags & NNR_AUX_PC) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const float gx = fix_get(a.gXq + 3 * i + r), gy = fix_get(a.gYq + 3 * i + r);
-                g_rot[r] = gx / s2;
-                g_pc2[r] = gy / s2;
-                if (scale) acc[12] -= (gx * a.X[3 * i + r] + gy * a.Y[3 * i + r]) / s2;
+        float gd1, gd2;
+        uint32_t fl;
+        int src1;
+        aux_point_grads<true>(a, i, gd1, gd2, fl, src1, acc);
+        if (a.g_d1_img || a.g_d2_img) {
+            const int y = i / a.wr, x = i - y * a.wr;
+            const int sy = aux_nearest_src(y, a.hr, a.hd), sx = aux_nearest_src(x, a.wr, a.wd);
+            const bool owner = (y == 0 || aux_nearest_src(y - 1, a.hr, a.hd) != sy) && (x == 0 || aux_nearest_src(x - 1, a.wr, a.wd) != sx);
+            if (owner) {
+                float s1 = 0.f, s2 = 0.f;
+                for (int yy = y; yy < a.hr && aux_nearest_src(yy, a.hr, a.hd) == sy; ++yy) {
+                    for (int xx = x; xx < a.wr && aux_nearest_src(xx, a.wr, a.wd) == sx; ++xx) {
+                        float e1 = gd1, e2 = gd2, none[13];
+                        uint32_t fj = fl;
+                        int sj = src1;
+                        if (yy != y || xx != x) aux_point_grads<false>(a, yy * a.wr + xx, e1, e2, fj, sj, none);
+                        if (!(fj & kClamp1)) s1 += e1;
+                        if (!(fj & kClamp2)) s2 += e2;
+                    }
+                }
+                if (a.g_d1_img) a.g_d1_img[src1] += s1;      // the only writer of this pixel
+                if (a.g_d2_img) a.g_d2_img[src1] += s2;
             }
         }
-        if ((a.flags & NNR_AUX_RGBS) && (fl & kValid) && !(fl & kBehind) && a.acc[1] > 0.f && i >= a.s_lo && i < a.s_hi) {
-            float q[3], xy[2];
-            aux_project(a, g, q, xy);
-            const float coef = a.g_out[1] / (3.f * a.acc[1]);
-            const float gx = a.gxy[2 * i] * coef, gy = a.gxy[2 * i + 1] * coef;
-            const float gq[3] = {gx / q[2], gy / q[2], -(gx * q[0] + gy * q[1]) / (q[2] * q[2])};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) g_rot_s[c] = a.K[c] * gq[0] + a.K[4 + c] * gq[1] + a.K[8 + c] * gq[2];
-        }
-        float g_pc1[3] = {0.f, 0.f, 0.f};
-        const bool detach = (a.flags & NNR_AUX_DETACH_RGBS) != 0;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float gt = g_rot[r] + g_rot_s[r];
-            acc[4 * r + 0] = gt * g.pc1[0];
-            acc[4 * r + 1] = gt * g.pc1[1];
-            acc[4 * r + 2] = gt * g.pc1[2];
-            acc[4 * r + 3] = gt;
-            const float gp = g_rot[r] + (detach ? 0.f : g_rot_s[r]);   // detach_rgbs_scale: the re-projection sees a detached cloud
-#pragma unroll
-            for (int c = 0; c < 3; ++c) g_pc1[c] += a.rel[4 * r + c] * gp;
-        }
-        // pc = Kinv[:, :3] (x' d, y' d, d) + Kinv[:, 3]  ->  d pc / d d = Kinv[:, :3] (x', y', 1)
-        float gd1 = 0.f, gd2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float* k = a.Kinv + 4 * r;
-            const float dir = k[0] * g.xp + k[1] * g.yp + k[2];
-            gd1 += g_pc1[r] * dir;
-            gd2 += g_pc2[r] * dir;
-        }
-        if (a.g_d1_img && !(fl & kClamp1) && gd1 != 0.f) atomicAdd(a.g_d1_img + g.src1, gd1);
-        if (a.g_d2_img && !(fl & kClamp2) && gd2 != 0.f) atomicAdd(a.g_d2_img + g.src1, gd2);
     }
 #pragma unroll
     for (int k = 0; k < 13; ++k) {

@@ -284,12 +284,38 @@ __global__ void depth_gather_fwd_kernel(const float* img, const int64_t* ray_idx
     const int y = (int)(q / w), x = (int)(q - (int64_t)y * w);
     out[i] = img[(int64_t)nearest_src(y, h, hd) * wd + nearest_src(x, w, wd)];
 }
-__global__ void depth_gather_bwd_kernel(const float* g, const int64_t* ray_idx, float* g_img, int R, int h, int w, int hd, int wd) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R) return;
-    const int64_t q = ray_idx[i];
-    const int y = (int)(q / w), x = (int)(q - (int64_t)y * w);
-    atomicAdd(g_img + (int64_t)nearest_src(y, h, hd) * wd + nearest_src(x, w, wd), g[i]);
+// Several rays share a depth pixel whenever the mono-depth map is coarser than the image (the DPT default), and float atomics would
+// make that pixel's sum depend on arrival order.  Instead ONE ray owns each hit pixel -- the lowest-numbered ray that maps to it -- and
+// adds the gradients of all rays of that pixel in ray order: every ray compares its target with every other ray's (LDS tiles of 256;
+// R^2 integer compares, 1 M at 1024 rays), no atomics, bit-reproducible.  g_img must hold zeros (or whatever is to be accumulated into).
+__global__ __launch_bounds__(256) void depth_gather_bwd_kernel(const float* g, const int64_t* ray_idx, float* g_img, int R, int h, int w,
+                                                               int hd, int wd) {
+    __shared__ int tgt[256];
+    __shared__ float gv[256];
+    auto target = [&](int k) {
+        const int64_t q = ray_idx[k];
+        const int y = (int)(q / w), x = (int)(q - (int64_t)y * w);
+        return nearest_src(y, h, hd) * wd + nearest_src(x, w, wd);
+    };
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ti = i < R ? target(i) : -1;
+    bool owner = i < R;
+    float sum = 0.f;
+    for (int base = 0; base < R; base += 256) {
+        const int j = base + threadIdx.x;
+        __syncthreads();
+        tgt[threadIdx.x] = j < R ? target(j) : -2;
+        gv[threadIdx.x] = j < R ? g[j] : 0.f;
+        __syncthreads();
+        const int n = R - base < 256 ? R - base : 256;
+        for (int k = 0; k < n; ++k) {
+            if (tgt[k] == ti) {
+                sum += gv[k];
+                if (base + k < i) owner = false;
+            }
+        }
+    }
+    if (owner) g_img[ti] += sum;     // the only writer of this pixel
 }
 
 // The same gather with the per-image affine depth distortion applied to the R gathered values instead of the whole map

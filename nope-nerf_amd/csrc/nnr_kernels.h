@@ -173,7 +173,7 @@ hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int
 hipError_t launch_pc_nearest(const float* src, const float* dst, int S, int D, int64_t* idx, float* dist, unsigned long long* keys,
                              hipStream_t st);
 hipError_t launch_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_loss, int S,
-                               float* g_src, float* g_dst, hipStream_t st);
+                               int D, float* g_src, float* g_dst, hipStream_t st);
 unsigned int randperm_capacity(int r);   // candidates the scratch buffer must hold for a pick of r; 0 = r not supported
 hipError_t launch_randperm_prefix(const int64_t* keys, int64_t n, int bits, int r, unsigned long long seed, unsigned long long offset,
                                   int64_t* out, unsigned int* scratch, hipStream_t st);

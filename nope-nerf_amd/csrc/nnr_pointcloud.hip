@@ -96,27 +96,51 @@ __global__ void pc_decode_kernel(const unsigned long long* keys, int S, int64_t*
 }
 
 // d mean_s ||src_s - dst_idx(s)|| : g_src[s] = g/S * (src_s - dst_idx)/dist  (0 where dist == 0, like torch's norm backward),
-// g_dst[idx(s)] -= the same (several sources may share a destination: float atomics).
-__global__ void pc_error_bwd_kernel(const float* __restrict__ src, const float* __restrict__ dst, const int64_t* __restrict__ idx,
-                                    const float* __restrict__ dist, const float* __restrict__ g_loss, int S, float* __restrict__ g_src,
-                                    float* __restrict__ g_dst) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    const int64_t j = idx[s];
-    // A source with NaN / inf coordinates never beats the initial key: its decoded index is 0xffffffff and its "distance" a NaN
-    // bit pattern.  No match -> no gradient (and no access 51 GB past the destination cloud); the trainer's NaN check stops the
-    // run on the loss value.
-    if (j == 0xffffffffll) {
-        if (g_src) g_src[3 * s] = g_src[3 * s + 1] = g_src[3 * s + 2] = 0.f;
-        return;
-    }
-    const float dd = dist[s];
-    const float w = dd > 0.f ? g_loss[0] / ((float)S * dd) : 0.f;
+// g_dst[j] -= the same for every source matched to j.  Several sources may share a destination; instead of float atomics (whose sum
+// depends on arrival order) thread j GATHERS: it walks all sources in index order (LDS tiles of the match table) and adds the terms of
+// those matched to it -- S x D integer compares, no atomics, bit-reproducible.
+__global__ __launch_bounds__(256) void pc_error_bwd_kernel(const float* __restrict__ src, const float* __restrict__ dst,
+                                                           const int64_t* __restrict__ idx, const float* __restrict__ dist,
+                                                           const float* __restrict__ g_loss, int S, int D, float* __restrict__ g_src,
+                                                           float* __restrict__ g_dst) {
+    __shared__ int match[256];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g_src && t < S) {
+        const int64_t j = idx[t];
+        // A source with NaN / inf coordinates never beats the initial key: its decoded index is 0xffffffff and its "distance" a NaN
+        // bit pattern.  No match -> no gradient (and no access 51 GB past the destination cloud); the trainer's NaN check stops the
+        // run on the loss value.
+        const float dd = dist[t];
+        const float w = (j != 0xffffffffll && dd > 0.f) ? g_loss[0] / ((float)S * dd) : 0.f;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float v = w * (src[3 * s + c] - dst[3 * j + c]);
-        if (g_src) g_src[3 * s + c] = v;
-        if (g_dst) atomicAdd(g_dst + 3 * j + c, -v);
+        for (int c = 0; c < 3; ++c) g_src[3 * t + c] = j != 0xffffffffll ? w * (src[3 * t + c] - dst[3 * j + c]) : 0.f;
+    }
+    if (!g_dst) return;
+    float acc[3] = {0.f, 0.f, 0.f};
+    float dj[3] = {0.f, 0.f, 0.f};
+    if (t < D) { dj[0] = dst[3 * t]; dj[1] = dst[3 * t + 1]; dj[2] = dst[3 * t + 2]; }
+    for (int base = 0; base < S; base += 256) {
+        const int s = base + threadIdx.x;
+        __syncthreads();
+        match[threadIdx.x] = (s < S && idx[s] != 0xffffffffll) ? (int)idx[s] : -1;
+        __syncthreads();
+        const int n = S - base < 256 ? S - base : 256;
+        if (t < D) {
+#pragma unroll 8
+            for (int k = 0; k < n; ++k) {
+                if (match[k] == t) {
+                    const int q = base + k;
+                    const float dd = dist[q];
+                    const float w = dd > 0.f ? g_loss[0] / ((float)S * dd) : 0.f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[c] -= w * (src[3 * q + c] - dj[c]);
+                }
+            }
+        }
+    }
+    if (t < D) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g_dst[3 * t + c] += acc[c];
     }
 }
 
@@ -143,8 +167,9 @@ hipError_t launch_pc_nearest(const float* src, const float* dst, int S, int D, i
 }
 
 hipError_t launch_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_loss, int S,
-                               float* g_src, float* g_dst, hipStream_t st) {
-    hipLaunchKernelGGL(pc_error_bwd_kernel, dim3((S + 255) / 256), dim3(256), 0, st, src, dst, idx, dist, g_loss, S, g_src, g_dst);
+                               int D, float* g_src, float* g_dst, hipStream_t st) {
+    const int n = g_dst && D > S ? D : S;
+    hipLaunchKernelGGL(pc_error_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, dst, idx, dist, g_loss, S, D, g_src, g_dst);
     return hipGetLastError();
 }
 

@@ -252,10 +252,11 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     prof_before(PROF_WGRAD, st);
     hipLaunchKernelGGL(wgrad_kernel, dim3(a.n_waves / 4), dim3(256), 0, st, a);
-    prof_after(PROF_WGRAD, st);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_jobs * 16), dim3(256), 0, st, a);
     e = hipGetLastError();
-    return e != hipSuccess ? e : launch_wgrad_unmerge(a, st);
+    if (e == hipSuccess) e = launch_wgrad_unmerge(a, st);
+    prof_after(PROF_WGRAD, st);      // the bracket covers the whole stage: main kernel + slot reduction + un-merge
+    return e;
 }
 
 hipError_t launch_wgrad_unmerge(const WgradArgs& a, hipStream_t st) {

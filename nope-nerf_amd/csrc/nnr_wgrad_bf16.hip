@@ -387,7 +387,6 @@ hipError_t launch_wgrad_bf16(const WgradBArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     prof_before(PROF_WGRAD, st);
     hipLaunchKernelGGL(wgrad_b_kernel, dim3(a.n_blocks), dim3(256), kRingBytes, st, a);
-    prof_after(PROF_WGRAD, st);
     hipLaunchKernelGGL(wgrad_b_reduce_kernel, dim3(64, a.n_outs), dim3(256), 0, st, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -396,7 +395,9 @@ hipError_t launch_wgrad_bf16(const WgradBArgs& a, hipStream_t st) {
     u.packed = a.packed;
     u.D = a.D;
     u.bf16 = 1;
-    return launch_wgrad_unmerge(u, st);
+    e = launch_wgrad_unmerge(u, st);
+    prof_after(PROF_WGRAD, st);      // the bracket covers the whole stage: main kernel + slot reduction + un-merge
+    return e;
 }
 
 }  // namespace nnr

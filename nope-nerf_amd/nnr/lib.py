@@ -23,6 +23,9 @@ N_LAYERS = 12
 LAYER_NAMES = ("layers0.0", "layers0.2", "layers0.4", "layers0.6", "layers1.0", "layers1.2", "layers1.4",
                "layers1.6", "fc_density", "fc_feature", "rgb_layers.0", "fc_rgb")
 
+# = NNR_ABI_VERSION of include/nnr.h; bumped whenever a signature, a struct or a blob layout that crosses the C ABI changes
+# (2: nnr_pc_error_bwd takes n_dst; round-2 layouts of nnr_aux_cfg and the bf16 plan blob)
+ABI_VERSION = 2
 EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_floats", "nnr_workspace_floats",
            "nnr_plan_bytes", "nnr_plan_counts", "nnr_plan_build", "nnr_pack_weights", "nnr_render_fwd", "nnr_render_bwd", "nnr_ws_plane",
            "nnr_mlp_fwd", "nnr_composite_fwd", "nnr_composite_bwd", "nnr_mlp_dgrad", "nnr_mlp_wgrad", "nnr_ray_reduce",
@@ -124,15 +127,16 @@ def load():
     lib.nnr_aux_workspace_floats.argtypes = [auxp]
     lib.nnr_aux_terms_fwd.argtypes = [auxp] + [vp] * 11
     lib.nnr_aux_terms_bwd.argtypes = [auxp] + [vp] * 14
-    lib.nnr_pc_error_bwd.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
+    lib.nnr_pc_error_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.nnr_render_loss.argtypes = [vp] * 5 + [i32] + [f32] * 4 + [i32] * 3 + [vp] * 6
     lib.nnr_prof_begin.argtypes = [i32]
     lib.nnr_prof_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     for n in EXPORTS:
         if not hasattr(lib, n):
             raise RuntimeError(f"libnnr.so does not export {n}")
-    if lib.nnr_abi_version() != 1:
-        raise RuntimeError("libnnr.so ABI version mismatch")
+    if lib.nnr_abi_version() != ABI_VERSION:
+        raise RuntimeError("libnnr.so ABI version %d, these bindings expect %d: rebuild with `python nope-nerf_amd/csrc/build.py`"
+                           % (lib.nnr_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

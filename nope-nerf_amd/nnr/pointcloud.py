@@ -48,7 +48,7 @@ class _PointPointError(torch.autograd.Function):
         g_d = torch.zeros_like(d) if need_d else None
         if need_s or need_d:
             g = g.contiguous().float()
-            L.check(L.load().nnr_pc_error_bwd(L.ptr(s), L.ptr(d), L.ptr(idx), L.ptr(dist), L.ptr(g), s.shape[0],
+            L.check(L.load().nnr_pc_error_bwd(L.ptr(s), L.ptr(d), L.ptr(idx), L.ptr(dist), L.ptr(g), s.shape[0], d.shape[0],
                                               L.ptr(g_s) if need_s else None, L.ptr(g_d) if need_d else None, _st()),
                     "nnr_pc_error_bwd")
         return g_s, g_d
