@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNR_ABI_VERSION 2
+#define NNR_ABI_VERSION 3
 
 /* error codes */
 #define NNR_OK 0
@@ -66,7 +66,7 @@ typedef struct nnr_params {
     const float* weight[NNR_N_LAYERS];
     const float* bias[NNR_N_LAYERS];
 } nnr_params;
-typedef struct nnr_param_grads { /* accumulated into (+=); caller zero-fills or passes .grad storage */
+typedef struct nnr_param_grads { /* OVERWRITTEN by the weight-gradient stage (ABI 3; accumulated into up to ABI 2): no zero-fill needed */
     float* weight[NNR_N_LAYERS];
     float* bias[NNR_N_LAYERS];
 } nnr_param_grads;
@@ -112,7 +112,7 @@ int nnr_render_fwd(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, c
  * Replaces autograd through the same region (loss.backward(), model/training.py:89).  Must follow an
  * nnr_render_fwd with NNR_F_TRAIN on the same workspace.  d_rgb (R,3), d_dist (R) are the upstream
  * gradients from the loss heads (model/losses.py:27-32,59-64).  Gradients w.r.t. the 24 parameter
- * tensors are ACCUMULATED into `grads`; d_pts_o/d_pts_d/d_view (R,3) are overwritten.  `plan` is the
+ * tensors are written to `grads` (OVERWRITTEN: the buffers may be uninitialised); d_pts_o/d_pts_d/d_view (R,3) are overwritten.  `plan` is the
  * device copy of nnr_plan_build's table. */
 int nnr_render_bwd(const nnr_cfg* cfg, const float* packed, const float* d_rgb, const float* d_dist,
                    const nnr_param_grads* grads_host, float* d_pts_o, float* d_pts_d, float* d_view,
@@ -225,7 +225,8 @@ int nnr_aux_terms_bwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* 
  * randperm would have drawn (keys = empty(n, int64).random_(INT64_MIN, INT64_MAX)), the number of key bits it sorts by, and
  * the generator's (seed, philox offset) at the point where torch re-shuffles duplicate keys -- without sorting all n keys.
  * scratch: nnr_randperm_scratch_bytes(r) bytes = 8 + 20 * capacity (capacity 4096 up to r = 1401, 16384 up to r = 9943, 65536
- * up to r = 51463), 8-byte aligned; if the candidate buffer under/overflowed (probability < 1e-50 by construction: the threshold
+ * up to r = 51463), 8-byte aligned, its first 8 + 4 * capacity bytes (count, status, ranks) ZERO on entry -- zero-fill the buffer once,
+ * every call leaves them zeroed again (no memset launch per pick; calls that share a buffer must be ordered on one stream); if the candidate buffer under/overflowed (probability < 1e-50 by construction: the threshold
  * leaves >= 16 sigma below and >= 40 sigma above the expected count) scratch word [1] becomes 1 and the kernel TRAPS -- the
  * process aborts at its next synchronisation instead of training on a truncated pixel pick.  NNR_E_UNSUPPORTED where the
  * packing does not fit or r is beyond the largest buffer (bits + ceil(log2 n) > 64, scratch_bytes(r) == 0, n < 8r): callers fall
@@ -252,6 +253,56 @@ int nnr_ndc_rays_fwd(const float* rays_o, const float* rays_d, const float* came
                      int32_t n_rays, void* stream);
 int nnr_ndc_rays_bwd(const float* rays_o, const float* rays_d, const float* camera_mat, float near_plane, const float* g_o_ndc,
                      const float* g_d_ndc, float* g_rays_o, float* g_rays_d, int32_t n_rays, void* stream);
+
+/* ONE launch for the Adam updates of a training step (reference model/training.py:90-96 steps up to four torch.optim.Adam per
+ * iteration).  Plain Adam, weight_decay 0, no amsgrad, no maximize; the arithmetic is torch's fused implementation type by type
+ * (double hyper-parameters, moments evaluated in double and rounded once, float bias corrections): bitwise the same parameters and
+ * moments as torch.optim.Adam(fused=True).  The table is passed BY VALUE (host struct, <= NNR_ADAM_MAX_TENSORS tensors, all fp32,
+ * contiguous).  step_in[i] / step_out[i]: one-element float counters; the kernel reads step_in, uses step_in + 1 and writes it to
+ * step_out (distinct buffers: no block may see a counter another block has advanced).  block_first: prefix table in units of 1024
+ * elements, block_first[i+1] - block_first[i] = ceil(numel[i] / 1024). */
+#define NNR_ADAM_MAX_TENSORS 40
+typedef struct nnr_adam_table {
+    float* param[NNR_ADAM_MAX_TENSORS];
+    const float* grad[NNR_ADAM_MAX_TENSORS];
+    float* exp_avg[NNR_ADAM_MAX_TENSORS];
+    float* exp_avg_sq[NNR_ADAM_MAX_TENSORS];
+    const float* step_in[NNR_ADAM_MAX_TENSORS];
+    float* step_out[NNR_ADAM_MAX_TENSORS];
+    double lr[NNR_ADAM_MAX_TENSORS], beta1[NNR_ADAM_MAX_TENSORS], beta2[NNR_ADAM_MAX_TENSORS], eps[NNR_ADAM_MAX_TENSORS];
+    int64_t numel[NNR_ADAM_MAX_TENSORS];
+    int32_t block_first[NNR_ADAM_MAX_TENSORS + 1];
+    int32_t n_tensors;
+} nnr_adam_table;
+int nnr_adam_step(const nnr_adam_table* table, void* stream);
+
+/* Fused front end of a training step: everything between the learnable tables and the per-ray inputs of the render operator, ONE
+ * launch each way.  Replaces, with the same arithmetic in the same order, nnr_se3_exp_fwd + nnr_inv4_fwd (world_mat = c2w^-1,
+ * reference model/training.py:238) + Learn_Distortion.forward (model/distortions.py:19-26: scale floored at the constant 0.01, the
+ * last camera's scale pinned to 1 with fix_scaleN) + nnr_pixels_from_index + nnr_depth_gather_affine_fwd + the colour-target gather
+ * (training.py:258-259) + nnr_ray_setup_fwd, and on the way back nnr_ray_setup_bwd + nnr_depth_gather_affine_bwd + nnr_inv4_bwd +
+ * nnr_se3_exp_bwd + the autograd of the distortion lookup.  Reductions run in the fixed order of those kernels (bit-reproducible).
+ * r_all, t_all (n_cams,3); scales, shifts (n_cams); K, S 4x4 row-major; ray_idx (n_rays) int64; depth_img (hd,wd) RAW mono depth;
+ * img (3,h,w) or null.  Outputs as nnr_ray_setup_fwd, plus rgb_gt (n_rays,3) [if img], pixels (n_rays,2) and mats[34] = c2w (16),
+ * world_mat (16), effective scale, shift.  Backward: d_r, d_t (n_cams,3), d_scales, d_shifts (n_cams) are OVERWRITTEN (zeros outside
+ * row cam). */
+#define NNR_STEP_NORMALISE 1u       /* rendering.normalise_ray */
+#define NNR_STEP_USE_DIR 2u         /* rendering.use_ray_dir */
+#define NNR_STEP_SHIFT_FIRST 4u     /* training.shift_first: (depth + shift) * scale */
+#define NNR_STEP_FIX_LAST_SCALE 8u  /* distortion.fix_scaleN */
+typedef struct nnr_step_cfg {
+    int32_t n_rays, h, w, hd, wd; /* image size, mono-depth map size */
+    int32_t cam, n_cams;
+    uint32_t flags;
+} nnr_step_cfg;
+int nnr_step_rays_fwd(const nnr_step_cfg* cfg, const float* r_all, const float* t_all, const float* scales, const float* shifts,
+                      const float* K, const float* S, const int64_t* ray_idx, const float* depth_img, const float* img, float* pts_o,
+                      float* dir, float* view, float* ray_norm, float* d_gt, uint8_t* mask, float* rgb_gt, float* pixels, float* mats,
+                      void* stream);
+int nnr_step_rays_bwd(const nnr_step_cfg* cfg, const float* r_all, const float* t_all, const float* scales, const float* shifts,
+                      const float* K, const float* S, const int64_t* ray_idx, const float* depth_img, const float* g_pts_o,
+                      const float* g_dir, const float* g_view, const float* g_ray_norm, const float* g_d_gt, float* d_r, float* d_t,
+                      float* d_scales, float* d_shifts, void* stream);
 
 /* depth = nearest-resize(depth_img (hd,wd) -> (h,w)).flatten()[ray_idx]  (model/network.py:22-24) without materialising
  * the resized image; backward scatter-adds into a zero-filled (hd,wd) gradient image. */

@@ -681,6 +681,11 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const float* packed, const nnr_param_grads
     a.packed = packed;
     a.D = cfg->hidden;
     a.bf16 = 0;
+    {
+        const int D = cfg->hidden;
+        const int rows[13] = {D, D, D, D, D, D, D, D, 1, D, D / 2, 3, D / 2};   // outputs of the 12 nn.Linear + the merged colour-hidden matrix
+        for (int l = 0; l < 13; ++l) a.bias_rows[l] = rows[l];
+    }
     hipError_t e = launch_wgrad(a, (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
@@ -752,6 +757,52 @@ int nnr_ray_setup_bwd(const float* pixels, const float* depth, const float* K, c
     a.g_depth = d_depth; a.acc = scratch; a.gK = dK; a.gW = dW; a.gS = dS;
     a.R = n_rays; a.normalise = normalise; a.use_dir = use_dir;
     NNR_LAUNCH(launch_ray_setup_bwd(a, (hipStream_t)stream));
+}
+int nnr_adam_step(const nnr_adam_table* t, void* stream) {
+    if (!t || t->n_tensors < 0 || t->n_tensors > NNR_ADAM_MAX_TENSORS) return NNR_E_BADCFG;
+    if (t->block_first[0] != 0) return NNR_E_BADCFG;
+    for (int i = 0; i < t->n_tensors; ++i) {
+        if (!t->param[i] || !t->grad[i] || !t->exp_avg[i] || !t->exp_avg_sq[i] || !t->step_in[i] || !t->step_out[i] || t->numel[i] <= 0 ||
+            t->step_in[i] == t->step_out[i])
+            return NNR_E_BADCFG;
+        if (t->block_first[i + 1] - t->block_first[i] != (int32_t)((t->numel[i] + 1023) / 1024)) return NNR_E_BADCFG;
+    }
+    NNR_LAUNCH(launch_adam_multi(*t, (hipStream_t)stream));
+}
+static bool step_fill(const nnr_step_cfg* c, nnr::StepRaysArgs& a) {
+    if (!c || c->n_rays <= 0 || c->h < 2 || c->w < 2 || c->hd <= 0 || c->wd <= 0 || c->n_cams <= 0 || c->cam < 0 || c->cam >= c->n_cams)
+        return false;
+    a.R = c->n_rays; a.h = c->h; a.w = c->w; a.hd = c->hd; a.wd = c->wd; a.cam = c->cam; a.n_cams = c->n_cams;
+    a.normalise = (c->flags & NNR_STEP_NORMALISE) != 0; a.use_dir = (c->flags & NNR_STEP_USE_DIR) != 0;
+    a.shift_first = (c->flags & NNR_STEP_SHIFT_FIRST) != 0; a.fix_last_scale = (c->flags & NNR_STEP_FIX_LAST_SCALE) != 0;
+    return true;
+}
+int nnr_step_rays_fwd(const nnr_step_cfg* cfg, const float* r_all, const float* t_all, const float* scales, const float* shifts,
+                      const float* K, const float* S, const int64_t* ray_idx, const float* depth_img, const float* img, float* pts_o,
+                      float* dir, float* view, float* ray_norm, float* d_gt, uint8_t* mask, float* rgb_gt, float* pixels, float* mats,
+                      void* stream) {
+    nnr::StepRaysArgs a{};
+    if (!step_fill(cfg, a)) return NNR_E_BADCFG;
+    if (!r_all || !t_all || !scales || !shifts || !K || !S || !ray_idx || !depth_img || !pts_o || !dir || !view || !ray_norm || !d_gt ||
+        !mask || !pixels || !mats || (img && !rgb_gt))
+        return NNR_E_BADCFG;
+    a.r_all = r_all; a.t_all = t_all; a.scales = scales; a.shifts = shifts; a.K = K; a.S = S; a.ray_idx = ray_idx;
+    a.depth_img = depth_img; a.img = img; a.pts_o = pts_o; a.dir = dir; a.view = view; a.ray_norm = ray_norm; a.d_gt = d_gt;
+    a.mask = mask; a.rgb_gt = rgb_gt; a.pixels = pixels; a.mats = mats;
+    NNR_LAUNCH(launch_step_rays_fwd(a, (hipStream_t)stream));
+}
+int nnr_step_rays_bwd(const nnr_step_cfg* cfg, const float* r_all, const float* t_all, const float* scales, const float* shifts,
+                      const float* K, const float* S, const int64_t* ray_idx, const float* depth_img, const float* g_pts_o,
+                      const float* g_dir, const float* g_view, const float* g_ray_norm, const float* g_d_gt, float* d_r, float* d_t,
+                      float* d_scales, float* d_shifts, void* stream) {
+    nnr::StepRaysArgs a{};
+    if (!step_fill(cfg, a)) return NNR_E_BADCFG;
+    if (!r_all || !t_all || !scales || !shifts || !K || !S || !ray_idx || !depth_img || !d_r || !d_t || !d_scales || !d_shifts)
+        return NNR_E_BADCFG;
+    a.r_all = r_all; a.t_all = t_all; a.scales = scales; a.shifts = shifts; a.K = K; a.S = S; a.ray_idx = ray_idx;
+    a.depth_img = depth_img; a.g_o = g_pts_o; a.g_dir = g_dir; a.g_view = g_view; a.g_norm = g_ray_norm; a.g_dgt = g_d_gt;
+    a.d_r = d_r; a.d_t = d_t; a.d_scales = d_scales; a.d_shifts = d_shifts;
+    NNR_LAUNCH(launch_step_rays_bwd(a, (hipStream_t)stream));
 }
 int nnr_depth_gather_affine_fwd(const float* depth_img, const int64_t* ray_idx, const float* scale, const float* shift, int32_t shift_first,
                                 float* out, int32_t n_rays, int32_t h, int32_t w, int32_t hd, int32_t wd, void* stream) {

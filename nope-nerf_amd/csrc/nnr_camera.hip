@@ -80,10 +80,7 @@ __device__ __forceinline__ M4 inv_backward(const M4& y, const M4& dy) {
 
 // ------------------------------------------------------------------------------------------------ SE(3) exp
 // R = I + sin(th)/th K + (1-cos(th))/th^2 K^2, th = |r| + 1e-15 (model/common.py:290-299), c2w = [[R,t],[0,0,0,1]].
-__global__ void se3_exp_fwd_kernel(const float* r_all, const float* t_all, int idx, float* c2w) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float* r = r_all + 3 * idx;
-    const float* t = t_all + 3 * idx;
+__device__ __forceinline__ void se3_exp_matrix(const float* r, const float* t, float* c2w) {
     const float x = r[0], y = r[1], z = r[2];
     const float n = sqrtf(x * x + y * y + z * z);
     const float th = n + 1e-15f;
@@ -98,13 +95,15 @@ __global__ void se3_exp_fwd_kernel(const float* r_all, const float* t_all, int i
     }
     c2w[12] = 0.f; c2w[13] = 0.f; c2w[14] = 0.f; c2w[15] = 1.f;
 }
+__global__ void se3_exp_fwd_kernel(const float* r_all, const float* t_all, int idx, float* c2w) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float m[16];
+    se3_exp_matrix(r_all + 3 * idx, t_all + 3 * idx, m);
+    for (int k = 0; k < 16; ++k) c2w[k] = m[k];
+}
 
-// gradients into full (n_cams,3) tables: zero everywhere except row idx
-__global__ void se3_exp_bwd_kernel(const float* r_all, int idx, int n_cams, const float* d_c2w, float* d_r_all, float* d_t_all) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 3 * n_cams && i / 3 != idx) { d_r_all[i] = 0.f; d_t_all[i] = 0.f; }
-    if (i != 0) return;
-    const float* r = r_all + 3 * idx;
+// d loss / d (r, t) of one camera from d loss / d c2w
+__device__ __forceinline__ void se3_exp_grad(const float* r, const float* d_c2w, float* d_r, float* d_t) {
     const float x = r[0], y = r[1], z = r[2];
     const float n = sqrtf(x * x + y * y + z * z);
     const float th = n + 1e-15f;
@@ -131,12 +130,21 @@ __global__ void se3_exp_bwd_kernel(const float* r_all, int idx, int n_cams, cons
         }
     const float gth = ga * da + gb * db;
     const float inv_n = n > 0.f ? 1.f / n : 0.f;                              // d|r|/dr = r/|r|, subgradient 0 at r = 0
-    d_r_all[3 * idx + 0] = gK[7] - gK[5] + gth * x * inv_n;
-    d_r_all[3 * idx + 1] = gK[2] - gK[6] + gth * y * inv_n;
-    d_r_all[3 * idx + 2] = gK[3] - gK[1] + gth * z * inv_n;
-    d_t_all[3 * idx + 0] = d_c2w[3];
-    d_t_all[3 * idx + 1] = d_c2w[7];
-    d_t_all[3 * idx + 2] = d_c2w[11];
+    d_r[0] = gK[7] - gK[5] + gth * x * inv_n;
+    d_r[1] = gK[2] - gK[6] + gth * y * inv_n;
+    d_r[2] = gK[3] - gK[1] + gth * z * inv_n;
+    d_t[0] = d_c2w[3];
+    d_t[1] = d_c2w[7];
+    d_t[2] = d_c2w[11];
+}
+// gradients into full (n_cams,3) tables: zero everywhere except row idx
+__global__ void se3_exp_bwd_kernel(const float* r_all, int idx, int n_cams, const float* d_c2w, float* d_r_all, float* d_t_all) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * n_cams && i / 3 != idx) { d_r_all[i] = 0.f; d_t_all[i] = 0.f; }
+    if (i != 0) return;
+    float g[16];
+    for (int k = 0; k < 16; ++k) g[k] = d_c2w[k];
+    se3_exp_grad(r_all + 3 * idx, g, d_r_all + 3 * idx, d_t_all + 3 * idx);
 }
 
 // ------------------------------------------------------------------------------------------------ batched 4x4 inverse
@@ -377,6 +385,183 @@ hipError_t launch_pixels_from_index(const int64_t* idx, float* out, int R, int h
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ fused front end of a training step
+// Everything between the learnable tables and the per-ray inputs of the render operator in ONE launch each way (model/training.py:
+// 235-262 + model/network.py:22-24 + model/rendering.py:54-87 of the reference): pose row -> c2w (se3_exp_matrix) -> world_mat = c2w^-1
+// (the trainer's torch.inverse), the frame's depth distortion (scale floored at the constant 0.01, the last camera's scale pinned to
+// 1: model/distortions.py:19-26), pixel coordinates, the nearest-resize depth gather with the distortion applied to the gathered values,
+// the colour targets, and ray_setup -- the arithmetic of se3_exp_fwd / inv4_fwd / pixels_from_index / depth_gather_affine_fwd /
+// ray_setup_fwd in the same order, so the numbers are those of the separate launches.  Every thread rebuilds the five 4x4 matrices
+// (a few hundred flops) instead of waiting for a one-thread kernel to publish them.
+__device__ __forceinline__ void step_scale_shift(const StepRaysArgs& a, float& scale, float& shift, bool& scale_live) {
+    shift = a.shifts[a.cam];
+    scale = 1.f;
+    scale_live = false;
+    if (!(a.fix_last_scale && a.cam == a.n_cams - 1)) {       // the gauge: the last view's depth scale is 1
+        const float raw = a.scales[a.cam];
+        scale_live = !(raw < 0.01f);                             // below the floor the scale is the CONSTANT 0.01: no gradient
+        scale = scale_live ? raw : 0.01f;
+    }
+}
+__device__ __forceinline__ void step_matrices(const StepRaysArgs& a, M4& c2w, M4& W, RaySetupArgs& rs) {
+    se3_exp_matrix(a.r_all + 3 * a.cam, a.t_all + 3 * a.cam, c2w.m);
+    W = inv4(c2w);
+    rs.K = a.K; rs.W = W.m; rs.S = a.S;
+}
+__device__ __forceinline__ void step_pixel(const StepRaysArgs& a, int i, float& px, float& py, float& raw) {
+    const int64_t q = a.ray_idx[i];
+    const int y = (int)(q / a.w), x = (int)(q - (int64_t)y * a.w);
+    px = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, (float)x), (float)(a.w - 1)), 1.0f);
+    py = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, (float)y), (float)(a.h - 1)), 1.0f);
+    raw = a.depth_img[(int64_t)nearest_src(y, a.h, a.hd) * a.wd + nearest_src(x, a.w, a.wd)];
+}
+
+__global__ __launch_bounds__(256) void step_rays_fwd_kernel(StepRaysArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    M4 c2w, W, kinv, winv, sinv, m;
+    RaySetupArgs rs{};
+    step_matrices(a, c2w, W, rs);
+    pixel_to_world(rs, kinv, winv, sinv, m);
+    float scale, shift;
+    bool live;
+    step_scale_shift(a, scale, shift, live);
+    if (i == 0) {
+        for (int k = 0; k < 16; ++k) { a.mats[k] = c2w.m[k]; a.mats[16 + k] = W.m[k]; }
+        a.mats[32] = scale;
+        a.mats[33] = shift;
+    }
+    if (i >= a.R) return;
+    float px, py, raw;
+    step_pixel(a, i, px, py, raw);
+    const float dep = a.shift_first ? __fmul_rn(__fadd_rn(raw, shift), scale) : __fadd_rn(__fmul_rn(raw, scale), shift);
+    a.pixels[2 * i] = px;
+    a.pixels[2 * i + 1] = py;
+    if (a.img) {
+        const int64_t q = a.ray_idx[i], hw = (int64_t)a.h * a.w;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.rgb_gt[3 * i + c] = a.img[c * hw + q];
+    }
+    float ray[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ray[c] = m.m[4 * c] * px + m.m[4 * c + 1] * py + m.m[4 * c + 2];   // pixels_world - camera_world
+    const float n = sqrtf(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+    const float q0 = ray[0] * dep, q1 = ray[1] * dep, q2 = ray[2] * dep;
+    float dgt = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);                                              // |points_world - camera_world|
+    if (!a.normalise) dgt = dgt / n;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float d = a.normalise ? ray[c] / n : ray[c];
+        a.pts_o[3 * i + c] = m.m[4 * c + 3];
+        a.dir[3 * i + c] = d;
+        a.view[3 * i + c] = a.use_dir ? -d : 1.f;
+    }
+    a.ray_norm[i] = n;
+    a.d_gt[i] = dgt;
+    a.mask[i] = (isfinite(dgt) && dgt != 0.f) ? 1 : 0;
+}
+
+// The whole way back in one workgroup: the per-ray part of ray_setup_bwd with the depth gradient fed straight into the distortion
+// sums (depth_gather_affine_bwd), both reduced in a FIXED order (strided rays, lane tree, the 8 waves in index order), then the matrix chain rule M = S^-1 W^-1 K^-1, W = c2w^-1 (inv4_bwd), c2w = exp(r, t) (se3_exp_grad) -- and the full
+// (n_cams, .) gradient tables written, zeros outside the frame's row.  Replaces 4 launches + the ~10 tiny ATen kernels of the
+// autograd of `where` / indexing in Learn_Distortion.
+constexpr int kStepBwdThreads = 512;   // 8 waves: 256 registers each (at 1024 threads the matrix chain spills 700 bytes per lane)
+__global__ __launch_bounds__(kStepBwdThreads) void step_rays_bwd_kernel(StepRaysArgs a) {
+    __shared__ float red[14][kStepBwdThreads / 64];
+    __shared__ float park[4][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    float gs = 0.f, gh = 0.f;
+    M4 m;      // only the product survives the ray loop (six live 4x4 matrices per thread spill); thread 0 parks the others in LDS for
+    {          // the chain rule at the end instead of rebuilding them there (the serial tail was two thirds of the kernel)
+        M4 c2w, W, kinv, winv, sinv;
+        RaySetupArgs rs{};
+        step_matrices(a, c2w, W, rs);
+        pixel_to_world(rs, kinv, winv, sinv, m);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { park[0][k] = kinv.m[k]; park[1][k] = winv.m[k]; park[2][k] = sinv.m[k]; park[3][k] = W.m[k]; }
+        }
+    }
+    float scale, shift;
+    bool live;
+    step_scale_shift(a, scale, shift, live);
+    for (int i = threadIdx.x; i < 3 * a.n_cams; i += kStepBwdThreads) { a.d_r[i] = 0.f; a.d_t[i] = 0.f; }
+    for (int i = threadIdx.x; i < a.n_cams; i += kStepBwdThreads) { a.d_scales[i] = 0.f; a.d_shifts[i] = 0.f; }
+    for (int i = threadIdx.x; i < a.R; i += kStepBwdThreads) {
+        float px, py, raw;
+        step_pixel(a, i, px, py, raw);
+        const float dep = a.shift_first ? __fmul_rn(__fadd_rn(raw, shift), scale) : __fadd_rn(__fmul_rn(raw, scale), shift);
+        float ray[3], gdir[3], gray[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ray[c] = m.m[4 * c] * px + m.m[4 * c + 1] * py + m.m[4 * c + 2];
+        const float n = sqrtf(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+        const float rn = 1.f / n;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float g = a.g_dir ? a.g_dir[3 * i + c] : 0.f;
+            if (a.use_dir && a.g_view) g -= a.g_view[3 * i + c];     // view = -dir
+            gdir[c] = g;
+        }
+        float gn = a.g_norm ? a.g_norm[i] : 0.f;                      // dL/d|ray|
+        float gdep = 0.f;
+        const float gd = a.g_dgt ? a.g_dgt[i] : 0.f;
+        const float sgn = dep > 0.f ? 1.f : (dep < 0.f ? -1.f : 0.f);
+        if (a.normalise) {
+            const float dot = (gdir[0] * ray[0] + gdir[1] * ray[1] + gdir[2] * ray[2]) * rn * rn;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gray[c] = (gdir[c] - ray[c] * dot) * rn;   // through ray / |ray|
+            if (gd != 0.f) { gn += gd * fabsf(dep); gdep = gd * n * sgn; }        // d_gt = |depth| |ray|
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gray[c] = gdir[c];
+            if (gd != 0.f) gdep = gd * sgn;                                        // d_gt = |depth| (the |ray| cancels)
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gray[c] += gn * ray[c] * rn;
+        // a non-finite raw depth (masked ray) carries a zero upstream gradient; keep 0 * inf out of the sums
+        if (gdep != 0.f) {
+            gs += a.shift_first ? gdep * (raw + shift) : gdep * raw;
+            gh += a.shift_first ? gdep * scale : gdep;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            acc[4 * c + 0] += gray[c] * px;
+            acc[4 * c + 1] += gray[c] * py;
+            acc[4 * c + 2] += gray[c];
+            acc[4 * c + 3] += a.g_o ? a.g_o[3 * i + c] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+        float v = k < 12 ? acc[k] : (k == 12 ? gs : gh);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0) red[k][wv] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    M4 dm;
+    for (int k = 0; k < 12; ++k) {
+        float t = 0.f;
+        for (int w = 0; w < kStepBwdThreads / 64; ++w) t += red[k][w];
+        dm.m[k] = t;
+    }
+    for (int k = 12; k < 16; ++k) dm.m[k] = 0.f;
+    float tot_s = 0.f, tot_h = 0.f;
+    for (int w = 0; w < kStepBwdThreads / 64; ++w) { tot_s += red[12][w]; tot_h += red[13][w]; }
+    if (live) a.d_scales[a.cam] = tot_s;
+    a.d_shifts[a.cam] = tot_h;
+    // dL/dM (12 sums) -> dL/dW through M = (S^-1 W^-1) K^-1, W^-1 = inv4(W); then W = inv4(c2w); then c2w = exp(r, t)
+    const M4 kinv = load4(park[0]), winv = load4(park[1]), sinv = load4(park[2]), W = load4(park[3]);
+    const M4 d_sw = mul4(dm, transpose4(kinv));
+    const M4 d_winv = mul4(transpose4(sinv), d_sw);
+    const M4 gw = inv_backward(winv, d_winv);                // d loss / d world_mat
+    const M4 gc = inv_backward(W, gw);                       // d loss / d c2w
+    se3_exp_grad(a.r_all + 3 * a.cam, gc.m, a.d_r + 3 * a.cam, a.d_t + 3 * a.cam);
+}
+
 // ------------------------------------------------------------------------------------------------ loss heads
 __device__ __forceinline__ float block_sum(float v, float* sm) {
 #pragma unroll
@@ -471,6 +656,14 @@ hipError_t launch_ray_setup_fwd(const RaySetupArgs& a, hipStream_t st) {
 }
 hipError_t launch_ray_setup_bwd(const RaySetupArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(ray_setup_bwd_kernel, dim3(1), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_step_rays_fwd(const StepRaysArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(step_rays_fwd_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_step_rays_bwd(const StepRaysArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(step_rays_bwd_kernel, dim3(1), dim3(kStepBwdThreads), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_depth_gather_fwd(const float* img, const int64_t* idx, float* out, int R, int h, int w, int hd, int wd, hipStream_t st) {

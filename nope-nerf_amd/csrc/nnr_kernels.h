@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/nnr.h"
 #include "nnr_layout.h"
 
 namespace nnr {
@@ -78,6 +79,7 @@ struct WgradArgs {
     int32_t plane_pitch[48];
     const int32_t* wave_first; // wave w runs jobs [wave_first[w], wave_first[w+1])
     int n_jobs, n_waves;
+    int bias_rows[13];         // elements of gb[l]: the main kernel zeroes them (the reduction adds up to two shares per row)
 };
 
 struct WgradBArgs {            // bf16 training mode (nnr_wgrad_bf16.hip)
@@ -107,6 +109,24 @@ struct RaySetupArgs {
     float *gK, *gW, *gS;         // 16 each
     int R;
     int normalise, use_dir;
+};
+
+// fused front end of a training step (step_rays_fwd / step_rays_bwd, nnr_camera.hip)
+struct StepRaysArgs {
+    const float *r_all, *t_all;      // (n_cams,3) pose tables
+    const float *scales, *shifts;    // (n_cams) depth-distortion tables
+    const float *K, *S;              // 4x4 camera_mat, scale_mat
+    const int64_t* ray_idx;          // (R) flat pixel indices
+    const float* depth_img;          // (hd,wd) raw mono depth
+    const float* img;                // (3,h,w) or null
+    int R, h, w, hd, wd, cam, n_cams;
+    int normalise, use_dir, shift_first, fix_last_scale;
+    // forward outputs
+    float *pts_o, *dir, *view, *ray_norm, *d_gt, *rgb_gt, *pixels, *mats;   // mats: c2w[16], world_mat[16], scale, shift
+    uint8_t* mask;
+    // backward
+    const float *g_o, *g_dir, *g_view, *g_norm, *g_dgt;   // upstream gradients (any may be null)
+    float *d_r, *d_t, *d_scales, *d_shifts;               // full tables, overwritten
 };
 
 struct LossArgs {
@@ -140,6 +160,9 @@ hipError_t launch_depth_gather_affine_bwd(const float* g, const float* img, cons
 hipError_t launch_ndc_rays_fwd(const float* o, const float* d, const float* K, float near_, float* o_ndc, float* d_ndc, int R, hipStream_t st);
 hipError_t launch_ndc_rays_bwd(const float* o, const float* d, const float* K, float near_, const float* g_o_ndc, const float* g_d_ndc,
                                float* g_o, float* g_d, int R, hipStream_t st);
+hipError_t launch_adam_multi(const nnr_adam_table& t, hipStream_t st);
+hipError_t launch_step_rays_fwd(const StepRaysArgs& a, hipStream_t st);
+hipError_t launch_step_rays_bwd(const StepRaysArgs& a, hipStream_t st);
 hipError_t launch_depth_gather_bwd(const float* g, const int64_t* idx, float* g_img, int R, int h, int w, int hd, int wd, hipStream_t st);
 hipError_t launch_render_loss(const LossArgs& a, hipStream_t st);
 hipError_t launch_pixels_from_index(const int64_t* idx, float* out, int R, int h, int w, hipStream_t st);

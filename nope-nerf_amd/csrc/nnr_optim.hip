@@ -1,0 +1,64 @@
+// nnr_optim.hip -- ONE launch for the Adam updates of a training step (reference model/training.py:90-96: up to four
+// torch.optim.Adam.step() calls per iteration).  The trainer already selects torch's single-kernel implementation of that class
+// (fused=True: 2 launches per optimiser -- the step-counter increment and the update -- 6 per step for the network, pose and
+// distortion optimisers, 69 us of GPU time at 595 844 + 128 parameters); this kernel takes the tensors of ALL of them at once.
+//
+// The update is torch's, operation by operation and type by type (aten/src/ATen/native/cuda/fused_adam_utils.cuh, the non-amsgrad,
+// non-capturable ADAM_MODE::ORIGINAL path, weight_decay == 0, maximize == false), because training must not depend on which of the
+// two implementations stepped: lr, betas and eps are DOUBLES, the first / second moment updates are evaluated in double and rounded
+// to float once, the bias corrections are 1 - pow(beta, step) in double rounded to float, the step size lr / bias_correction1 is a
+// double division rounded to float, the denominator adds the double eps to a float quotient.  tests/test_gpu_optim.py compares the
+// parameters and both moments BITWISE with torch.optim.Adam(fused=True) over hundreds of steps.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nnr.h"
+#include "nnr_kernels.h"
+
+namespace nnr {
+
+constexpr int kAdamBlock = 256, kAdamIlp = 4;   // elements per block = 1024
+
+__global__ __launch_bounds__(kAdamBlock) void adam_multi_kernel(nnr_adam_table t) {
+    // which tensor does this block work on?  (block_first is a prefix table: tensor i owns blocks [block_first[i], block_first[i+1]))
+    int i = 0;
+    while (i + 1 < t.n_tensors && (int)blockIdx.x >= t.block_first[i + 1]) ++i;
+    const int64_t n = t.numel[i];
+    const int64_t base = (int64_t)((int)blockIdx.x - t.block_first[i]) * (kAdamBlock * kAdamIlp);
+    float* __restrict__ p = t.param[i];
+    const float* __restrict__ g = t.grad[i];
+    float* __restrict__ m = t.exp_avg[i];
+    float* __restrict__ v = t.exp_avg_sq[i];
+    const double lr = t.lr[i], beta1 = t.beta1[i], beta2 = t.beta2[i], eps = t.eps[i];
+    // torch increments the step counter first (_foreach_add_(state_steps, 1)) and the update reads the incremented value.  Here the
+    // counters ping-pong between two arrays so that no block can read a counter another block has already advanced.
+    const float step = t.step_in[i][0] + 1.0f;
+    if (base == 0 && threadIdx.x == 0) t.step_out[i][0] = step;
+    const float bias_correction1 = (float)(1 - pow(beta1, (double)step));
+    const float bias_correction2_sqrt = (float)sqrt(1 - pow(beta2, (double)step));
+#pragma unroll
+    for (int u = 0; u < kAdamIlp; ++u) {
+        const int64_t e = base + (int64_t)u * kAdamBlock + threadIdx.x;
+        if (e >= n) continue;
+        float param = p[e];
+        const float grad = g[e];
+        float exp_avg = m[e], exp_avg_sq = v[e];
+        exp_avg = beta1 * exp_avg + (1 - beta1) * grad;
+        exp_avg_sq = beta2 * exp_avg_sq + (1 - beta2) * grad * grad;
+        const float step_size = lr / bias_correction1;
+        const float denom = (sqrtf(exp_avg_sq) / bias_correction2_sqrt) + eps;
+        param -= step_size * exp_avg / denom;
+        p[e] = param;
+        m[e] = exp_avg;
+        v[e] = exp_avg_sq;
+    }
+}
+
+hipError_t launch_adam_multi(const nnr_adam_table& t, hipStream_t st) {
+    const int blocks = t.block_first[t.n_tensors];
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(kAdamBlock), 0, st, t);
+    return hipGetLastError();
+}
+
+}  // namespace nnr

@@ -130,6 +130,11 @@ __global__ __launch_bounds__(1024) void randperm_finish_kernel(unsigned int* __r
     }
     __syncthreads();
     for (int i = threadIdx.x; i < r; i += 1024) out[i] = i < m ? (int64_t)(s[i] & idx_mask) : 0;
+    // leave the counters the way this call found them: ZERO.  The scratch buffer is persistent (nnr/sampling.py keeps one per device and
+    // capacity, zero-filled once), so no memset launch precedes the select kernel of the next pick.
+    unsigned int* rank_w = rp_rank(scratch);
+    for (int i = threadIdx.x; i < m; i += 1024) rank_w[i] = 0u;
+    if (threadIdx.x == 0) { scratch[0] = 0u; scratch[1] = 0u; }
 }
 
 // expected candidate count and the buffer that holds it with >= 40 sigma to spare; 0 = r beyond the largest buffer
@@ -149,8 +154,7 @@ hipError_t launch_randperm_prefix(const int64_t* keys, int64_t n, int bits, int 
     const unsigned int cap = randperm_capacity(r);
     const long double frac = randperm_expected(r) / (long double)n;
     const unsigned long long limit = (unsigned long long)((long double)(bits >= 64 ? 18446744073709551615.0L : (long double)(1ull << bits)) * frac);
-    hipError_t e = hipMemsetAsync(scratch, 0, (2 + (size_t)cap) * sizeof(unsigned int), st);   // count, status, ranks
-    if (e != hipSuccess) return e;
+    // (count, status and ranks are zero on entry: the caller zero-fills the buffer ONCE, every call leaves them zeroed)
     const int64_t per_block = 256 * kSelKeys;
     hipLaunchKernelGGL(randperm_select_kernel, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(256), 0, st, keys, n, mask, limit,
                        idx_bits, cap, scratch);

@@ -147,6 +147,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wslot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int j0 = a.wave_first[wslot], j1 = a.wave_first[wslot + 1];
+    // The gradients are OVERWRITTEN, not accumulated into: the weight tiles by the reduction kernel (every weight belongs to exactly one
+    // tile), the bias rows by up to two atomic shares onto the zeros written here -- one workgroup's worth of stores instead of a
+    // zero-fill launch over all 2.4 MB of gradients before this kernel.
+    if (blockIdx.x == 0) {
+        for (int l = 0; l < 13; ++l)
+            for (int r = threadIdx.x; r < a.bias_rows[l]; r += 256) a.gb[l][r] = 0.f;
+    }
 #ifdef NNR_TIMELINE
     if (lane == 0 && wslot < 2048) tl_wgrad_all[2 * wslot] = __builtin_amdgcn_s_memtime();
 #endif
@@ -178,8 +185,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
 #endif
 }
 
-// dW[tile] += sum over the tile's splits of their partial slots; d(bias) likewise.  Every weight belongs to exactly one
-// tile, so plain read-modify-write.  Blocks of jobs that are not split 0 of their tile exit at once; split 0 walks the chain.
+// dW[tile] = sum over the tile's splits of their partial slots (every weight belongs to exactly one tile: a plain store, the caller's
+// buffer needs no zero-fill); d(bias) += its share onto the zeros the main kernel wrote (at most two shares per row: a + b == b + a,
+// the result does not depend on their order).  Blocks of jobs that are not split 0 of their tile exit at once; split 0 walks the chain.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
     const int ji = blockIdx.x >> 4;   // 16 blocks x 256 threads x one float4 = a 128 x 128 tile
     const WgradJob jb = a.jobs[ji];
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
         float* dst = a.gw[jb.layer] + (int64_t)(jb.row0 + row) * jb.ldw + jb.wcol0 + c0;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (c0 + e < jb.x_valid && jb.wcol0 + c0 + e < jb.cols_real) dst[e] += sum[e];
+            if (c0 + e < jb.x_valid && jb.wcol0 + c0 + e < jb.cols_real) dst[e] = sum[e];
     }
     if (jb.bias && (blockIdx.x & 15) == 0 && (int)threadIdx.x < 32 * jb.MI) {
         const int r = threadIdx.x;
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
 }
 
 // Un-merge (nnr_layout.h): from dW' (D/2 x D) and db' of the merged matrix W' = Wg1 Wf, b' = Wg1 bf + bg, with Wg1 = Wg[:, :D]:
-//   dWf += Wg1^T dW'      dWg[:, :D] += dW' Wf^T + db' bf^T      dbf += Wg1^T db'      dbg += db'
+//   dWf = Wg1^T dW'      dWg[:, :D] = dW' Wf^T + db' bf^T      dbf = Wg1^T db'      dbg = db'      (overwritten, like every gradient)
 // Two (D x D/2 x D) products per step, 0.03 % of the MFMA work of the pass: plain VALU dot products, one output per thread.
 template <int D, bool BF16>
 __global__ __launch_bounds__(256) void wgrad_unmerge_kernel(WgradArgs a) {
@@ -223,33 +231,31 @@ __global__ __launch_bounds__(256) void wgrad_unmerge_kernel(WgradArgs a) {
     const float* dWm = a.gw[kMergedLayer];          // [Dh][D]
     const float* dbm = a.gb[kMergedLayer];
     const int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid < D * D) {                               // dWf[j][k] += sum_m Wg1[m][j] dW'[m][k]
+    if (gid < D * D) {                               // dWf[j][k] = sum_m Wg1[m][j] dW'[m][k]
         const int j = gid / D, k = gid - j * D;
         float acc = 0.f;
 #pragma unroll 16   // latency-bound dot products: keep 16 pairs of loads in flight (same fma chain)
         for (int m = 0; m < Dh; ++m) acc = fmaf(Wg1[m * D + j], dWm[m * D + k], acc);
-        a.gw[9][gid] += acc;
-    } else if (gid < D * D + Dh * D) {               // dWg[m][j] += sum_k dW'[m][k] Wf[j][k] + db'[m] bf[j]
+        a.gw[9][gid] = acc;
+    } else if (gid < D * D + Dh * D) {               // dWg[m][j] = sum_k dW'[m][k] Wf[j][k] + db'[m] bf[j]
         const int t = gid - D * D, m = t / D, j = t - m * D;
         float acc = dbm[m] * bf[j];
 #pragma unroll 16
         for (int k = 0; k < D; ++k) acc = fmaf(dWm[m * D + k], Wf[j * D + k], acc);
-        a.gw[10][m * ldg + j] += acc;
-    } else if (gid < D * D + Dh * D + D) {           // dbf[j] += sum_m Wg1[m][j] db'[m]
+        a.gw[10][m * ldg + j] = acc;
+    } else if (gid < D * D + Dh * D + D) {           // dbf[j] = sum_m Wg1[m][j] db'[m]
         const int j = gid - D * D - Dh * D;
         float acc = 0.f;
         for (int m = 0; m < Dh; ++m) acc = fmaf(Wg1[m * D + j], dbm[m], acc);
-        a.gb[9][j] += acc;
-    } else if (gid < D * D + Dh * D + D + Dh) {      // dbg += db'
+        a.gb[9][j] = acc;
+    } else if (gid < D * D + Dh * D + D + Dh) {      // dbg = db'
         const int m = gid - D * D - Dh * D - D;
-        a.gb[10][m] += dbm[m];
+        a.gb[10][m] = dbm[m];
     }
 }
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
-    const size_t merged = ((size_t)(a.D / 2) * a.D + a.D / 2) * sizeof(float);
-    hipError_t e = hipMemsetAsync(a.gw[kMergedLayer], 0, merged, st);   // dW', db' are accumulated into like any gradient
-    if (e != hipSuccess) return e;
+    hipError_t e;
     prof_before(PROF_WGRAD, st);
     hipLaunchKernelGGL(wgrad_kernel, dim3(a.n_waves / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_jobs * 16), dim3(256), 0, st, a);

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void wgrad_b_reduce_kernel(WgradBArgs a) {
             for (int u = 0; u < 8; ++u) sum += v[u];
         }
         for (; s < n; ++s) sum += p[list[s] * stride];
-        a.gw[o.layer][(int64_t)(o.w_row + r) * o.ldw + o.w_col + c] += sum;
+        a.gw[o.layer][(int64_t)(o.w_row + r) * o.ldw + o.w_col + c] = sum;     // every weight belongs to exactly one output rectangle: overwritten
     }
     if (o.bias && blockIdx.x == 0) {
         for (int r = threadIdx.x; r < o.n_rows; r += 256) {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void wgrad_b_reduce_kernel(WgradBArgs a) {
                 const float* q = p + list[s] * stride;
                 sum += q[0] + q[32];
             }
-            a.gb[o.layer][o.w_row + r] += sum;
+            a.gb[o.layer][o.w_row + r] = sum;       // one bias rectangle per layer (bf16_units)
         }
     }
 }
@@ -382,9 +382,7 @@ hipError_t launch_wgrad_bf16(const WgradBArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const size_t merged = ((size_t)(a.D / 2) * a.D + a.D / 2) * sizeof(float);
-    hipError_t e = hipMemsetAsync(a.gw[kMergedLayer], 0, merged, st);   // dW', db' are accumulated into like any gradient
-    if (e != hipSuccess) return e;
+    hipError_t e;
     prof_before(PROF_WGRAD, st);
     hipLaunchKernelGGL(wgrad_b_kernel, dim3(a.n_blocks), dim3(256), kRingBytes, st, a);
     hipLaunchKernelGGL(wgrad_b_reduce_kernel, dim3(64, a.n_outs), dim3(256), 0, st, a);

@@ -22,10 +22,15 @@ class nope_nerf(nn.Module):
         self.device = device
 
     def forward(self, p, ray_idx, camera_mat, world_mat, scale_mat, rendering_technique, it=0, eval_mode=False,
-                depth_img=None, add_noise=True, img_size=None, depth_affine=None):
+                depth_img=None, add_noise=True, img_size=None, depth_affine=None, rays=None):
         """`depth_affine` = (scale, shift, shift_first) is an extension for the trainer: `depth_img` is then the RAW mono-depth
-        map and the frame's distortion is applied to the gathered values only (the same numbers as distorting the map first)."""
+        map and the frame's distortion is applied to the gathered values only (the same numbers as distorting the map first).
+        `rays` (another trainer extension) = the per-ray tensors of nnr.camera.step_rays, which has already gathered the depths
+        and generated the rays in its one launch: nothing is left to do here."""
         depth = None
+        if rays is not None:
+            return self.renderer(p, None, camera_mat, world_mat, scale_mat, rendering_technique, eval_=eval_mode, it=it,
+                                 add_noise=add_noise, rays=rays)
         if rendering_technique == 'nope_nerf':
             # The reference nearest-resizes the whole depth map to the image size every step and then gathers R
             # values (network.py:22-24).  Gather-then-nothing is the same thing: index the source pixel directly.

@@ -71,9 +71,9 @@ class Renderer(nn.Module):
         self.normal_window = None   # (validity of ALL rays of the step, first ray) for the normal term of a shard
 
     def forward(self, pixels, depth, camera_mat, world_mat, scale_mat, rendering_technique, add_noise=True,
-                eval_=False, it=1000000):
+                eval_=False, it=1000000, rays=None):
         if rendering_technique == 'nope_nerf':
-            return self.nope_nerf(pixels, depth, camera_mat, world_mat, scale_mat, it=it, add_noise=add_noise, eval_=eval_)
+            return self.nope_nerf(pixels, depth, camera_mat, world_mat, scale_mat, it=it, add_noise=add_noise, eval_=eval_, rays=rays)
         if rendering_technique == 'phong_renderer':
             return self.phong_renderer(pixels, camera_mat, world_mat, scale_mat, it=it)
         raise ValueError('unknown rendering technique %r' % (rendering_technique,))
@@ -99,7 +99,7 @@ class Renderer(nn.Module):
         return hit
 
     # ------------------------------------------------------------------------------------------------ hot path
-    def nope_nerf(self, pixels, depth, camera_mat, world_mat, scale_mat, add_noise=False, it=100000, eval_=False):
+    def nope_nerf(self, pixels, depth, camera_mat, world_mat, scale_mat, add_noise=False, it=100000, eval_=False, rays=None):
         cfg = self.cfg
         batch_size, n_rays, _ = pixels.shape
         if batch_size != 1:
@@ -108,7 +108,10 @@ class Renderer(nn.Module):
         device = pixels.device
 
         # --- rays (reference :54-87).  inv(S) inv(W) inv(K) stays inside autograd: pose / focal gradients flow here ---
-        if pixels.is_cuda:
+        if rays is not None:
+            # the trainer's fused front end (nnr.camera.step_rays) has generated them together with everything before them
+            origin, ray, view, ray_norm, d_gt, object_mask = rays
+        elif pixels.is_cuda:
             # one HIP launch (nnr_ray_setup_fwd; backward: nnr_ray_setup_bwd) for the three inverses, the unprojection,
             # norms, d_gt and the validity mask
             origin, ray, view, ray_norm, d_gt, object_mask = camera.ray_setup(

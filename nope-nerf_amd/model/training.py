@@ -13,6 +13,7 @@ What is different underneath:
 The per-image losses run as two fused HIP calls (nnr/aux.py); stock torch only for with_ssim / a learnable focal / CPU.
 """
 import logging
+import math
 import os
 
 import numpy as np
@@ -72,6 +73,7 @@ class Trainer(object):
             setattr(self, k, cfg[k])
         self.loss = Loss(cfg)
         self._warned_geo = False
+        self._one = None
         self._nan_flag = None      # (pinned host flag, event) of the previous step's isnan(loss), read one step late
         self._nan_host = None
         # the deferred NaN flag of the newest step is looked at before anything is written to disk (model/checkpoints.py)
@@ -82,9 +84,16 @@ class Trainer(object):
         hook = lambda: (ref() is not None and ref().flush_nan_check())
         hook._trainer = ref
         _ck.PRE_SAVE_HOOKS.append(hook)
+        self.fuse_front_end = bool(cfg.get('fuse_front_end', True))   # training.fuse_front_end: False keeps the separate launches
         if cfg.get('fuse_optimizers', True):   # training.fuse_optimizers: False keeps torch's default multi-kernel Adam
             for opt in (optimizer, optimizer_pose, optimizer_focal, optimizer_distortion):
                 _use_fused_adam(opt)
+        # training.one_launch_adam (default on): ALL of the step's Adam updates in one HIP launch (nnr.optim.MultiAdam: the same
+        # optimizer objects, param_groups and state, bitwise torch's fused arithmetic) instead of two launches per optimiser
+        self._multi_adam = None
+        if cfg.get('fuse_optimizers', True) and cfg.get('one_launch_adam', True):
+            from nnr.optim import MultiAdam
+            self._multi_adam = MultiAdam([optimizer, optimizer_pose, optimizer_focal, optimizer_distortion])
 
     # ------------------------------------------------------------------------------------------------ step
     def _groups(self):
@@ -102,14 +111,21 @@ class Trainer(object):
                 opt.zero_grad()
         loss_dict = self.compute_loss(data, it=it, epoch=epoch, scheduling_start=scheduling_start,
                                       out_render_path=render_path)
-        loss_dict['loss'].backward()
+        loss = loss_dict['loss']
+        if loss.is_cuda:      # the root gradient as a cached constant: loss.backward() would launch a ones_like fill every step
+            if self._one is None or self._one.device != loss.device:
+                self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+            torch.autograd.backward(loss, grad_tensors=self._one if self._one.dtype == loss.dtype else None)
+        else:
+            loss.backward()
         if parallel.world_size() > 1 or parallel.always_reduce():
             nets = [self.model] + [n for n, _ in self._groups() if n]
             parallel.allreduce_gradients([p for n in nets for p in n.parameters()], loss_dict)
-        self.optimizer.step()
-        for net, opt in self._groups():
-            if opt:
-                opt.step()
+        if not (self._multi_adam is not None and loss.is_cuda and self._multi_adam.step()):
+            self.optimizer.step()
+            for net, opt in self._groups():
+                if opt:
+                    opt.step()
         return loss_dict
 
     # ------------------------------------------------------------------------------------------------ data
@@ -151,35 +167,60 @@ class Trainer(object):
         kwargs = {'t_list': self.pose_param_net.get_t(), 'weights': weights, 'rgb_loss_type': rgb_loss_type}
 
         num_cams = self.pose_param_net.num_cams
-        world_mat = self._inverse(self.pose_param_net(img_idx)).unsqueeze(0)
+        n_points = self.n_training_points
+        # The fused front end (nnr.camera.step_rays): pose -> world_mat, the frame's depth distortion, pixel coordinates, gathered
+        # depths, colour targets and rays in ONE launch each way instead of ~9 forward and ~14 backward ones.  Same arithmetic in the
+        # same order; taken whenever nothing needs the intermediate tensors (the per-image losses read the whole distorted map, a
+        # learnable focal rebuilds K inside the graph, an initial pose multiplies onto c2w).
+        fused_front = (img.is_cuda and render_model and not use_ref_imgs and self.distortion_net is not None and not self.optimizer_focal
+                       and getattr(self.pose_param_net, 'init_c2w', None) is None and self.rendering_technique == 'nope_nerf'
+                       and getattr(self.pose_param_net, 'r', None) is not None and self.fuse_front_end)
         scale_input = shift_input = None
         depth_affine = None
-        if self.distortion_net is not None:
-            scale_input, shift_input = self.distortion_net(img_idx)
-            if not use_ref_imgs:
-                # only the R picked pixels of the distorted map are ever used: distort those (model/network.py), not 518 400
-                depth_affine = (scale_input, shift_input, bool(self.shift_first))
-            else:   # the per-image losses read the whole distorted map
-                depth_input = (depth_input + shift_input) * scale_input if self.shift_first \
-                    else depth_input * scale_input + shift_input
-        if self.optimizer_focal:
-            fxfy, camera_mat = self._camera_from_focal(device)
-        else:
+        rays = None
+        if fused_front:
+            ray_idx = sampling.randperm_prefix(h * w, n_points, device)   # == torch.randperm(h * w, device=device)[:n_points]
+            n_total = ray_idx.shape[0]
+            lo, hi = parallel.shard_bounds(n_total, rank, world)
+            ray_loc = ray_idx[lo:hi]
+            rcfg = self.model.renderer.cfg
+            *rays, rgb_gt, p, mats = camera.step_rays(
+                self.pose_param_net.r, self.pose_param_net.t, self.distortion_net.global_scales, self.distortion_net.global_shifts,
+                depth_input, img, ray_loc, camera_mat_gt, scale_mat, cam=int(img_idx), h=h, w=w,
+                fix_last_scale=bool(self.distortion_net.fix_scaleN), shift_first=bool(self.shift_first),
+                normalise=bool(rcfg['normalise_ray']), use_dir=bool(rcfg['use_ray_dir']))
+            rgb_gt = rgb_gt.unsqueeze(0)
+            world_mat = mats[16:32].view(1, 4, 4)
+            scale_input, shift_input = mats[32:33], mats[33:34]
+            depth_affine = (scale_input, shift_input, bool(self.shift_first))
             camera_mat = camera_mat_gt
-
-        # pixel pick: the permutation is drawn exactly as the reference does (training.py:257), so indices are bit-identical
-        n_points = self.n_training_points
-        ray_idx = sampling.randperm_prefix(h * w, n_points, device)   # == torch.randperm(h * w, device=device)[:n_points]
-        n_total = ray_idx.shape[0]
-        lo, hi = parallel.shard_bounds(n_total, rank, world)
-        ray_loc = ray_idx[lo:hi]
-        rgb_gt = img.view(batch_size, 3, h * w).permute(0, 2, 1)[:, ray_loc]
-        if ray_loc.is_cuda:
-            p = camera.pixels_from_index(ray_loc, h, w)                                # == arange_pixels()[1][:, idx], one launch
         else:
-            xs = (ray_loc % w).float()
-            ys = torch.div(ray_loc, w, rounding_mode='floor').float()
-            p = torch.stack([2.0 * xs / (w - 1) - 1.0, 2.0 * ys / (h - 1) - 1.0], dim=-1).unsqueeze(0)
+            world_mat = self._inverse(self.pose_param_net(img_idx)).unsqueeze(0)
+            if self.distortion_net is not None:
+                scale_input, shift_input = self.distortion_net(img_idx)
+                if not use_ref_imgs:
+                    # only the R picked pixels of the distorted map are ever used: distort those (model/network.py), not 518 400
+                    depth_affine = (scale_input, shift_input, bool(self.shift_first))
+                else:   # the per-image losses read the whole distorted map
+                    depth_input = (depth_input + shift_input) * scale_input if self.shift_first \
+                        else depth_input * scale_input + shift_input
+            if self.optimizer_focal:
+                fxfy, camera_mat = self._camera_from_focal(device)
+            else:
+                camera_mat = camera_mat_gt
+
+            # pixel pick: the permutation is drawn exactly as the reference does (training.py:257), so indices are bit-identical
+            ray_idx = sampling.randperm_prefix(h * w, n_points, device)   # == torch.randperm(h * w, device=device)[:n_points]
+            n_total = ray_idx.shape[0]
+            lo, hi = parallel.shard_bounds(n_total, rank, world)
+            ray_loc = ray_idx[lo:hi]
+            rgb_gt = img.view(batch_size, 3, h * w).permute(0, 2, 1)[:, ray_loc]
+            if ray_loc.is_cuda:
+                p = camera.pixels_from_index(ray_loc, h, w)                                # == arange_pixels()[1][:, idx], one launch
+            else:
+                xs = (ray_loc % w).float()
+                ys = torch.div(ray_loc, w, rounding_mode='floor').float()
+                p = torch.stack([2.0 * xs / (w - 1) - 1.0, 2.0 * ys / (h - 1) - 1.0], dim=-1).unsqueeze(0)
 
         rendered_rgb = rendered_depth = gt_depth = None
         if render_model:
@@ -192,7 +233,8 @@ class Trainer(object):
                     d_all = self._gather_depth_all(depth_input, ray_idx, (h, w), depth_affine)
                 renderer.normal_window = (torch.isfinite(d_all) & (d_all != 0), lo)
             out = self.model(p, ray_loc, camera_mat, world_mat, scale_mat, self.rendering_technique, it=it,
-                             eval_mode=eval_mode, depth_img=depth_input, img_size=(h, w), depth_affine=depth_affine)
+                             eval_mode=eval_mode, depth_img=depth_input, img_size=(h, w), depth_affine=depth_affine,
+                             **({'rays': tuple(rays)} if rays is not None else {}))
             renderer.jitter_window = renderer.normal_window = None
             rendered_rgb = out['rgb']
             if not (rendered_rgb.is_cuda and self.loss.depth_loss_type == 'l1'):
@@ -224,7 +266,7 @@ class Trainer(object):
             host, ev = self._nan_flag
             self._nan_flag = None
             ev.synchronize()
-            if bool(host):
+            if math.isnan(float(host)):
                 raise FloatingPointError('NaN loss in the last training step')
 
     def _check_nan(self, loss):
@@ -234,14 +276,14 @@ class Trainer(object):
         if self._nan_flag is not None:
             host, ev = self._nan_flag
             ev.synchronize()
-            if bool(host):
+            if math.isnan(float(host)):
                 raise FloatingPointError('NaN loss in the previous training step')
         if loss.is_cuda:
             if self._nan_host is None:
-                self._nan_host = [torch.empty((), dtype=torch.bool).pin_memory() for _ in range(2)]
+                self._nan_host = [torch.empty((), dtype=torch.float32).pin_memory() for _ in range(2)]
             host = self._nan_host[0]
             self._nan_host.reverse()
-            host.copy_(torch.isnan(loss.detach()), non_blocking=True)
+            host.copy_(loss.detach(), non_blocking=True)      # the loss VALUE; isnan is evaluated on the host (no isnan launch)
             ev = torch.cuda.Event()
             ev.record()
             self._nan_flag = (host, ev)

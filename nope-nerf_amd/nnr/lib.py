@@ -24,8 +24,9 @@ LAYER_NAMES = ("layers0.0", "layers0.2", "layers0.4", "layers0.6", "layers1.0", 
                "layers1.6", "fc_density", "fc_feature", "rgb_layers.0", "fc_rgb")
 
 # = NNR_ABI_VERSION of include/nnr.h; bumped whenever a signature, a struct or a blob layout that crosses the C ABI changes
-# (2: nnr_pc_error_bwd takes n_dst; round-2 layouts of nnr_aux_cfg and the bf16 plan blob)
-ABI_VERSION = 2
+# (2: nnr_pc_error_bwd takes n_dst; round-2 layouts of nnr_aux_cfg and the bf16 plan blob.  3: nnr_step_rays_*; the weight-gradient
+# stage overwrites nnr_param_grads instead of accumulating into it)
+ABI_VERSION = 3
 EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_floats", "nnr_workspace_floats",
            "nnr_plan_bytes", "nnr_plan_counts", "nnr_plan_build", "nnr_pack_weights", "nnr_render_fwd", "nnr_render_bwd", "nnr_ws_plane",
            "nnr_mlp_fwd", "nnr_composite_fwd", "nnr_composite_bwd", "nnr_mlp_dgrad", "nnr_mlp_wgrad", "nnr_ray_reduce",
@@ -33,7 +34,8 @@ EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_
            "nnr_depth_gather_fwd", "nnr_depth_gather_bwd", "nnr_render_loss", "nnr_pixels_from_index", "nnr_pc_nearest",
            "nnr_pc_error_bwd", "nnr_aux_workspace_floats", "nnr_aux_terms_fwd", "nnr_aux_terms_bwd", "nnr_randperm_prefix",
            "nnr_randperm_scratch_bytes", "nnr_ndc_rays_fwd", "nnr_ndc_rays_bwd",
-           "nnr_depth_gather_affine_fwd", "nnr_depth_gather_affine_bwd", "nnr_prof_begin", "nnr_prof_end")
+           "nnr_depth_gather_affine_fwd", "nnr_depth_gather_affine_bwd", "nnr_prof_begin", "nnr_prof_end",
+           "nnr_step_rays_fwd", "nnr_step_rays_bwd", "nnr_adam_step")
 
 
 class Cfg(C.Structure):
@@ -50,6 +52,13 @@ class AuxCfg(C.Structure):
 
 
 AUX_RGBS, AUX_PC, AUX_SCALE_PCS, AUX_DETACH_RGBS = 1, 2, 4, 8
+
+
+class StepCfg(C.Structure):        # nnr_step_cfg: the fused front end of a training step
+    _fields_ = [(n, C.c_int32) for n in ("n_rays", "h", "w", "hd", "wd", "cam", "n_cams")] + [("flags", C.c_uint32)]
+
+
+STEP_NORMALISE, STEP_USE_DIR, STEP_SHIFT_FIRST, STEP_FIX_LAST_SCALE = 1, 2, 4, 8
 
 
 class WgradJobB(C.Structure):      # bf16 training mode: one workgroup job (nnr_layout.h)
@@ -129,6 +138,9 @@ def load():
     lib.nnr_aux_terms_bwd.argtypes = [auxp] + [vp] * 14
     lib.nnr_pc_error_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.nnr_render_loss.argtypes = [vp] * 5 + [i32] + [f32] * 4 + [i32] * 3 + [vp] * 6
+    lib.nnr_step_rays_fwd.argtypes = [C.POINTER(StepCfg)] + [vp] * 19
+    lib.nnr_step_rays_bwd.argtypes = [C.POINTER(StepCfg)] + [vp] * 18
+    lib.nnr_adam_step.argtypes = [vp, vp]
     lib.nnr_prof_begin.argtypes = [i32]
     lib.nnr_prof_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     for n in EXPORTS:

@@ -249,7 +249,7 @@ class _RenderRays(torch.autograd.Function):
         if need_w:
             sizes = [int(np.prod(s)) for s in ctx.shapes]
             offs = np.cumsum([0] + [(n + 3) // 4 * 4 for n in sizes])          # keep every view 16-byte aligned
-            flat = torch.zeros(int(offs[-1]), **f32)
+            flat = torch.empty(int(offs[-1]), **f32)      # the weight-gradient stage overwrites every element (no zero-fill launch)
             views = [flat[offs[i]: offs[i] + sizes[i]].view(ctx.shapes[i]) for i in range(2 * L.N_LAYERS)]
             gs = L.params_struct(views[:L.N_LAYERS], views[L.N_LAYERS:])
             L.check(lib.nnr_mlp_wgrad(C.byref(cfg), L.ptr(ctx.packed), C.byref(gs), L.ptr(_plan_for(cfg, dev)), L.ptr(ws), st), "nnr_mlp_wgrad")

@@ -1,0 +1,110 @@
+"""One HIP launch for all Adam updates of a training step (nnr_adam_step, csrc/nnr_optim.hip).
+
+The reference steps up to four `torch.optim.Adam` instances per iteration (model/training.py:90-96).  `MultiAdam` drives the SAME
+optimizer objects -- their `param_groups` (so LR schedulers keep working) and their `state` (so `state_dict()` / checkpoints keep
+torch's layout: `step`, `exp_avg`, `exp_avg_sq` per parameter) -- but performs the update of all of them in one kernel whose
+arithmetic is torch's fused implementation operation by operation: the results are bitwise those of `Adam(fused=True).step()`
+(tests/test_gpu_optim.py).  Anything it does not cover (other optimizer classes, weight decay, amsgrad, maximize, non-fp32 or CPU
+parameters, more than NNR_ADAM_MAX_TENSORS tensors, non-contiguous gradients) makes `step()` return False and the caller steps the
+optimizers itself."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import torch
+
+from . import lib as L
+
+MAX_TENSORS = 40
+
+
+class AdamTable(C.Structure):       # nnr_adam_table (include/nnr.h)
+    _fields_ = [("param", C.c_void_p * MAX_TENSORS), ("grad", C.c_void_p * MAX_TENSORS), ("exp_avg", C.c_void_p * MAX_TENSORS),
+                ("exp_avg_sq", C.c_void_p * MAX_TENSORS), ("step_in", C.c_void_p * MAX_TENSORS), ("step_out", C.c_void_p * MAX_TENSORS),
+                ("lr", C.c_double * MAX_TENSORS), ("beta1", C.c_double * MAX_TENSORS), ("beta2", C.c_double * MAX_TENSORS),
+                ("eps", C.c_double * MAX_TENSORS), ("numel", C.c_int64 * MAX_TENSORS), ("block_first", C.c_int32 * (MAX_TENSORS + 1)),
+                ("n_tensors", C.c_int32)]
+
+
+def _plain_adam(opt) -> bool:
+    if type(opt) is not torch.optim.Adam:
+        return False
+    for g in opt.param_groups:
+        if g.get('amsgrad') or g.get('maximize') or g.get('capturable') or g.get('differentiable') or g.get('weight_decay', 0) != 0:
+            return False
+        if torch.is_tensor(g['lr']):
+            return False
+        for p in g['params']:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                return False
+    return True
+
+
+class MultiAdam:
+    def __init__(self, optimizers: Sequence[torch.optim.Optimizer]):
+        self.optimizers: List[torch.optim.Optimizer] = [o for o in optimizers if o is not None]
+        self._table = AdamTable()
+        self._steps = None        # two (MAX_TENSORS,) float arrays: the counters ping-pong between them
+        self._flip = 0
+        self._slot = {}           # id(parameter) -> its fixed index into the counter arrays
+
+    def usable(self) -> bool:
+        if not self.optimizers or not all(_plain_adam(o) for o in self.optimizers):
+            return False
+        n = len({id(p) for o in self.optimizers for g in o.param_groups for p in g['params']} | set(self._slot))
+        devs = {p.device for o in self.optimizers for g in o.param_groups for p in g['params']}
+        return 0 < n <= MAX_TENSORS and len(devs) == 1
+
+    def step(self) -> bool:
+        """One launch for every parameter that has a gradient.  False (nothing done) when a precondition does not hold."""
+        if not self.usable():
+            return False
+        t = self._table
+        entries = []
+        for opt in self.optimizers:
+            for g in opt.param_groups:
+                b1, b2 = g['betas']
+                for p in g['params']:
+                    if p.grad is None:
+                        continue
+                    gr = p.grad
+                    if not (gr.is_cuda and gr.dtype == torch.float32 and gr.is_contiguous()) or gr.is_sparse:
+                        return False
+                    entries.append((opt, p, gr, float(g['lr']), float(b1), float(b2), float(g['eps'])))
+        if not entries:
+            return True
+        dev = entries[0][1].device
+        if self._steps is None or self._steps[0].device != dev:
+            self._steps = [torch.zeros(MAX_TENSORS, dtype=torch.float32, device=dev) for _ in range(2)]
+        src, dst = self._steps[self._flip], self._steps[1 - self._flip]
+        blocks = 0
+        for i, (opt, p, gr, lr, b1, b2, eps) in enumerate(entries):
+            k = self._slot.setdefault(id(p), len(self._slot))     # a parameter keeps its counter slot for life (<= MAX_TENSORS: usable())
+            st = opt.state[p]
+            if len(st) == 0:        # torch's lazy state initialisation (Adam._init_group, fused flavour: float32 device counter)
+                st['step'] = torch.zeros((), dtype=torch.float32, device=dev)
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            step = st['step']
+            if not (torch.is_tensor(step) and step.is_cuda and step.dtype == torch.float32):
+                step = torch.as_tensor(float(step), dtype=torch.float32, device=dev)
+            if step.data_ptr() != src[k].data_ptr():      # a counter not in this step's source array yet (first step, restored
+                src[k].copy_(step.reshape(()))            # state, a parameter that sat out the previous step)
+            st['step'] = dst[k]                           # torch's state keeps pointing at the CURRENT counter
+            t.param[i], t.grad[i] = p.data_ptr(), gr.data_ptr()
+            t.exp_avg[i], t.exp_avg_sq[i] = st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
+            t.step_in[i], t.step_out[i] = src[k].data_ptr(), dst[k].data_ptr()
+            t.lr[i], t.beta1[i], t.beta2[i], t.eps[i] = lr, b1, b2, eps
+            t.numel[i] = p.numel()
+            t.block_first[i] = blocks
+            blocks += (p.numel() + 1023) // 1024
+        t.block_first[len(entries)] = blocks
+        t.n_tensors = len(entries)
+        L.check(L.load().nnr_adam_step(C.byref(t), L.stream()), "nnr_adam_step")
+        self._flip = 1 - self._flip
+        for opt in self.optimizers:
+            opt._opt_called = True          # what the LR schedulers' "step() before optimizer.step()" warning looks at
+        from . import ops
+        ops.invalidate_packed_weights()     # the parameters changed behind the optimizers' post-step hooks
+        return True

@@ -15,6 +15,7 @@ from . import lib as L
 
 _CHECKS = 3          # first calls (per process) verified against torch.randperm
 _state = {"checked": 0, "enabled": True}
+_scratch = {}
 
 
 def _key_bits(n: int) -> int:
@@ -39,7 +40,12 @@ def _fast(n: int, r: int, device) -> torch.Tensor:
     seed, offset = gen.initial_seed(), gen.get_offset()
     gen.set_offset(offset + (n + 3) // 4 * 4)        # philox_cuda_state(n) of randperm_handle_duplicate_keys
     out = torch.empty(r, dtype=torch.int64, device=device)
-    scratch = torch.empty(2 + 5 * _capacity(r), dtype=torch.int32, device=device)     # header, ranks, candidates, ordered
+    # header, ranks, candidates, ordered.  Persistent per (device, capacity): zero-filled once -- the kernels leave the counters zeroed,
+    # so no memset launch per pick (the calls of a device are ordered on its current stream)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _capacity(r), torch.cuda.current_stream(device).cuda_stream)
+    scratch = _scratch.get(key)
+    if scratch is None:
+        scratch = _scratch[key] = torch.zeros(2 + 5 * _capacity(r), dtype=torch.int32, device=device)
     L.check(L.load().nnr_randperm_prefix(L.ptr(keys), n, _key_bits(n), r, seed, offset, L.ptr(out), L.ptr(scratch),
                                          L.stream()), "nnr_randperm_prefix")
     return out

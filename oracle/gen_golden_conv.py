@@ -37,7 +37,9 @@ np.savez(sys.argv[3], imgs=f.imgs, dpt=f.dpt_depth, K=f.K, c2ws=np.asarray(f.c2w
 ''' % (FRAMES, SIZE, SEED_SCENE, R, N, D)
 
 
-def main():
+def main(threads=8, replay=None, out_name="conv_llff.npz"):
+    """threads / replay: the chaos envelope (see envelope()) -- the same reference run with another GEMM thread count, fed the frames
+    and pixel permutations the golden run drew (`replay` = the golden blob)."""
     with tempfile.TemporaryDirectory() as tmp:
         # the scene goes through THIS repository's loader (pinned bit-exact against the reference's DataField: tests/test_dataloading.py)
         # in a separate process: `model` / `dataloading` of the reference are imported below under the same names
@@ -50,7 +52,7 @@ def main():
     from utils_poses.align_traj import align_ate_c2b_use_a2b
     from utils_poses.comp_ate import compute_ATE, compute_rpe
     from model.common import mse2psnr
-    torch.set_num_threads(8)
+    torch.set_num_threads(threads)
     cfg = copy.deepcopy(gg.base_cfg(D))
     cfg["training"].update(n_training_points=R, pc_weight=[1.0, 0.0], rgb_s_weight=[1.0, 0.0], vis_reprojection_every=10 ** 9)
     cfg["rendering"].update(num_points=N, sample_option="ndc", dist_alpha=True, depth_range=[0.0, 1.0])
@@ -77,7 +79,10 @@ def main():
     drawn = {}
 
     def randperm(n, *a, **k):
-        drawn["perm"] = real_randperm(n, *a, **k)
+        if replay is not None:      # the recorded pick of this step (the tail of the permutation is never read)
+            drawn["perm"] = torch.cat([torch.from_numpy(replay["ray_idx"][len(order)].astype(np.int64)), torch.zeros(n - R, dtype=torch.int64)])
+        else:
+            drawn["perm"] = real_randperm(n, *a, **k)
         return drawn["perm"]
 
     def pose_errors():
@@ -95,7 +100,8 @@ def main():
         it = 0          # train.py starts at -1 + 1 = 0, where the first step also dumps the re-projection PNGs (it % vis_reprojection_every): start at 1
         for epoch in range(EPOCHS):
             l2 = []
-            for cam in real_randperm(FRAMES).tolist():              # the shuffled DataLoader of train.py:35
+            cams = real_randperm(FRAMES).tolist() if replay is None else [int(c) for c, _ in replay["order"][epoch * FRAMES:(epoch + 1) * FRAMES]]
+            for cam in cams:                                        # the shuffled DataLoader of train.py:35
                 it += 1
                 nb = int(refs[cam])
                 data = {"img": imgs[cam:cam + 1], "img.idx": cam, "img.dpt": dpt[cam:cam + 1], "img.camera_mat": Kt,
@@ -115,10 +121,36 @@ def main():
             "init.pose_r": init_r, "init.pose_t": init_t, "final.pose_r": pose.r.detach().numpy(), "final.pose_t": pose.t.detach().numpy(),
             "final.scales": dist.global_scales.detach().numpy(), "final.shifts": dist.global_shifts.detach().numpy(),
             "cfg": np.array([FRAMES, SIZE[0], SIZE[1], SEED_SCENE, R, N, D, EPOCHS])}
-    out = os.path.join(gg.OUT, "conv_llff.npz")
+    if out_name is None:
+        return blob
+    out = os.path.join(gg.OUT, out_name)
     np.savez_compressed(out, **blob)
     print("wrote", out, os.path.getsize(out), "bytes;", len(order), "steps")
+    return blob
+
+
+def envelope(thread_counts=(1, 2, 3, 4, 5, 6, 7)):
+    """How far apart do two runs of the REFERENCE ITSELF end?  Training is a chaotic map: another summation order inside the CPU GEMMs
+    (another thread count) changes last bits, Adam amplifies them, and after 800 steps the two runs are two samples of the same
+    distribution.  Each variant replays the golden run's frames and pixel picks; recorded per variant: final PSNR / ATE / RPE and the
+    deviation of the loss curve from the golden run, in the very statistics tests/test_conv_reference.py asserts.  The test's
+    statistical tolerances are tied to this spread (tests/golden/conv_llff_envelope.npz)."""
+    gold = dict(np.load(os.path.join(gg.OUT, "conv_llff.npz")))
+    k = list(gold["logged"]).index("loss")
+    smooth = lambda x: np.convolve(x, np.ones(40) / 40, mode="valid")
+    rows = []
+    for t in thread_counts:
+        b = main(threads=t, replay=gold, out_name=None)
+        dev = np.abs(b["losses"] - gold["losses"]) / np.maximum(1.0, np.abs(gold["losses"]))
+        curve = float(np.abs(smooth(b["losses"][:, k]) - smooth(gold["losses"][:, k])).max() / smooth(gold["losses"][:, k]).max())
+        _, psnr, ate, rpe_t, rpe_r = b["curve"][-1]
+        rows.append((t, psnr, ate, rpe_t, rpe_r, float(dev[:20].max()), float(dev[:50].max()), curve))
+        print("threads %d: PSNR %.3f ATE %.4f RPE_r %.3f; first-20 dev %.2e, first-50 %.2e, smoothed curve %.2e" % (t, psnr, ate, rpe_r, rows[-1][5], rows[-1][6], curve))
+    out = os.path.join(gg.OUT, "conv_llff_envelope.npz")
+    np.savez_compressed(out, runs=np.array(rows, dtype=np.float64), golden_final=gold["curve"][-1],
+                        columns=np.array(["threads", "psnr", "ate", "rpe_t", "rpe_r", "dev_first20", "dev_first50", "curve_dev"]))
+    print("wrote", out)
 
 
 if __name__ == "__main__":
-    main()
+    envelope() if "--envelope" in sys.argv else main()

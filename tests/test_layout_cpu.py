@@ -87,7 +87,8 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nnr_abi_version() == 1
+    # the three statements of the ABI version agree: header macro, library, bindings
+    assert lib.nnr_abi_version() == L.ABI_VERSION == int(re.search(r"#define NNR_ABI_VERSION (\d+)", hdr).group(1))
     assert lib.nnr_strerror(-2).decode().startswith("unsupported")
 
 
