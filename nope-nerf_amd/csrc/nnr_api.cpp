@@ -547,6 +547,8 @@ static int mlp_fwd_impl(const nnr_cfg* cfg, const float* pts_o, const float* pts
         if (w.bf16) {
             a.ws_xe16 = ws + plane(w, P_XE16);
             a.ws_xf16 = ws + plane(w, P_XF16);
+            a.ws_pts = ws + plane(w, P_DPTS);      // the input-gradient kernel reads position / view direction here before it
+            a.ws_view = ws + plane(w, P_DVIEW);    // writes their gradients to the same rows
         }
         a.ws_mask = reinterpret_cast<uint32_t*>(ws + plane(w, P_MASK));
     }

@@ -20,6 +20,7 @@ struct MlpFwdArgs {
     float* ws_xf;     // (S_pad,32): direction encoding
     float* ws_xg;     // (S_pad,D/2)
     float *ws_xe16, *ws_xf16;   // bf16 training: tile-major bf16 copies of the encodings (nnr_layout.h)
+    float *ws_pts, *ws_view;    // bf16 training: (S_pad,4) position / view direction of every sample for the input-gradient kernel (= P_DPTS / P_DVIEW)
     uint32_t* ws_mask;
     int64_t S, S_pad;
     int N;

@@ -328,39 +328,56 @@ __device__ __forceinline__ constexpr int stash_tail() {
     return T * last;
 }
 
-// ---- chain rule through the encodings: factors in fragment-register order ---------------------------------------------------
+// ---- chain rule through the encodings --------------------------------------------------------------------------------------
 // d gamma_f / d coordinate = scale_f * partner_f: a sin feature's partner is the cos of the same argument (scale +2^l), a cos feature's
 // the sin (scale -2^l), the identity block has factor 1, padding 0.  The input-gradient kernel needs, per lane and fragment register,
-// exactly that product -- and the forward kernel holds every sin / cos of the sample in the two lanes (half 0 / 1) that own it.  In the
-// bf16 mode the planes P_XE / P_XF therefore store the FACTORS, tile-major in register order (block (chunk, q) = [lane][factors of
-// registers 4q .. 4q+3]): one coalesced 1 KiB store / load per four registers on either side.  Reading the partners out of a row-major
-// (sample, feature) plane instead took 32 single-dword loads per tile whose lanes are 256 bytes apart: a fifth of the
-// input-gradient kernel's time.
-struct EncMeta16 { int coord; float scale; int partner; };
-__device__ __forceinline__ constexpr EncMeta16 enc_meta16(int f, int n_real) {
-    if (f >= n_real) return {0, 0.f, 0};
-    if (f < 3) return {f, 1.f, -1};
-    const int t = f - 3, lvl = t / 6, rem = t - 6 * lvl;
-    const bool is_cos = rem >= 3;
-    const float a = (float)(1 << lvl);
-    return {is_cos ? rem - 3 : rem, is_cos ? -a : a, is_cos ? f - 3 : f + 3};
-}
-// factor of fragment register r for the lane's half, from the lane's own encoding registers and the other half's (own[] swapped
-// across the two 32-lane halves of the wave)
-template <int NR>
-__device__ __forceinline__ float enc_factor(int r, int half, int n_real, const float (&own)[NR], const float (&other)[NR]) {
-    float v[2];
+// exactly that product.  Round 2 had the forward kernel build these factors (48 cross-half shuffles per tile) and store them as fp32
+// planes, 384 bytes per sample written and read -- and every one of the 20 loads of a pass cost the input-gradient kernel a full drain
+// of its store queue (a compiler-visible load next to pending stores is waited for with vmcnt(0): the two kinds may retire out of
+// order as far as hipcc knows).  Now the forward leaves the 12-byte position / view direction (planes P_DPTS / P_DVIEW, which this
+// kernel overwrites with the gradients afterwards) and the factors are RECOMPUTED here: sin / cos of the coordinate by the accurate
+// routine once, the octaves above it by angle doubling (sin 2a = 2 sin a cos a, cos 2a = 1 - 2 sin^2 a: three VALU operations per
+// level instead of ~20).  Doubling multiplies the absolute error by two per level -- 3e-5 at the tenth octave, relative to a factor
+// of 512 -- which only enters the fp32 chain rule d point = sum g_f * factor_f, far below the bf16 rounding of g itself; the
+// FORWARD's encodings, which the bf16 oracle restates, are not touched.
+// d/d(x,y,z) of sum_r g(r) * gamma_{f(r,half)}(x, y, z) for the NR fragment registers of an encoding with NL octaves (3 + 6 NL
+// features), the factors recomputed from the coordinates octave by octave -- a handful of live values, no table.  Feature f sits in
+// register rp(f) of the lanes of half hp(f) (frag_feature^-1); the other half contributes nothing to it, and the two halves' sums are
+// combined by one cross-half shuffle per coordinate at the end.
+template <int NR, int NL, class G>
+__device__ __forceinline__ f32x4 enc_chain(const G& g, float x, float y, float z, int half) {
+    float o[3] = {0.f, 0.f, 0.f};
+    const float xyz[3] = {x, y, z};
+    // which half a feature belongs to enters as a 0 / 1 WEIGHT of its factor, not as a select of the accumulator value: hipcc turns the
+    // selects into whole-vector selects of the 16-register accumulator tuples (two masked copies of each: ~150 spilled registers)
+    const float w1 = half ? 1.f : 0.f, w0 = 1.f - w1;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const EncMeta16 m = enc_meta16(frag_feature(r, h), n_real);
-        if (m.scale == 0.f) v[h] = 0.f;
-        else if (m.partner < 0) v[h] = m.scale;
-        else {
-            const int fp = m.partner, hp = (fp % 8) / 4, rp = 16 * (fp / 32) + (fp % 4) + 4 * ((fp % 32) / 8);   // frag_feature^-1
-            v[h] = m.scale * (hp == h ? own[rp] : other[rp]);
+    for (int c = 0; c < 3; ++c) {
+        auto take = [&](int f, float fac) __attribute__((always_inline)) {     // f is a compile-time constant after unrolling
+            const int hp = (f % 8) / 4, rp = 16 * (f / 32) + (f % 4) + 4 * ((f % 32) / 8);
+            if (rp < NR) {
+                o[c] = fmaf(g(rp), fac * (hp ? w1 : w0), o[c]);
+            }
+        };
+        take(c, 1.f);                                                           // the identity block
+        float sn = sin_or_cos(xyz[c], false), cs = sin_or_cos(xyz[c], true), scale = 1.f;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            take(3 + 6 * l + c, scale * cs);          // d sin(2^l a) / da =  2^l cos(2^l a)
+            take(3 + 6 * l + 3 + c, -scale * sn);     // d cos(2^l a) / da = -2^l sin(2^l a)
+            const float s2 = 2.f * sn * cs;           // the next octave by angle doubling
+            cs = __builtin_fmaf(-2.f * sn, sn, 1.f);
+            sn = s2;
+            scale *= 2.f;
+            // Tie the octave recurrence to the running sum.  Left alone, hipcc runs the recurrence ahead -- all octaves of all
+            // coordinates of both tiles, packed two by two into v_pk_* operations -- and keeps every factor live until the sums
+            // catch up: ~150 spilled registers.  An empty asm that "modifies" both makes octave l + 1 wait for octave l's terms.
+            asm volatile("" : "+v"(sn), "+v"(cs), "+v"(o[c]));
         }
     }
-    return half ? v[1] : v[0];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
+    return f32x4{o[0], o[1], o[2], 0.f};
 }
 
 }  // namespace nnr

@@ -9,38 +9,6 @@
 
 namespace nnr {
 
-// d/d(x,y,z) of sum_r g(r) * gamma(.)_{f(r,half)}: the chain-rule factors (scale * partner value, enc_factor in nnr_mlp_bf16.h) come from
-// the forward kernel's stash in register order, `factors` = this lane's 16 bytes of block (chunk, 0); block q is 256 floats further
-template <int NQ4>
-__device__ __forceinline__ void enc_factors_load(f32x4 (&fac)[NQ4], const float* factors) {
-#pragma unroll
-    for (int q = 0; q < NQ4; ++q) {
-#ifdef NNR_ABLATE_NO_ENCLOAD
-        fac[q] = f32x4{1.f, 1.f, 1.f, 1.f};     // profiling build only
-#else
-        fac[q] = *reinterpret_cast<const f32x4*>(factors + q * 256);
-#endif
-    }
-}
-template <int NR, class G>
-__device__ __forceinline__ f32x4 enc_chain(const G& g, const f32x4 (&fac)[NR / 4], int half) {
-    float g3[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < NR / 4; ++q) {
-        const f32x4 v = fac[q];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f0 = frag_feature(4 * q + i, 0);
-            const int c0 = f0 < 3 ? f0 : (f0 - 3) % 3;     // coordinate of the register in half 0; half 1 is rotated by one (f -> f + 4)
-            g3[c0] = fmaf(g(4 * q + i), v[i], g3[c0]);
-        }
-    }
-    float o[3] = {half ? g3[2] : g3[0], half ? g3[0] : g3[1], half ? g3[1] : g3[2]};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
-    return f32x4{o[0], o[1], o[2], 0.f};
-}
-
 NNR_TL_DECL(tl_dgrad16)
 
 template <int D, int T, int W>
@@ -60,8 +28,11 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     const int lane0 = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
-    // LDS: the panel ring of the transposed weight stream and the fp32 head tables (density row, rgb rows, register order)
-    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + (L::head_floats + 3) / 4];
+    // LDS: the panel ring of the transposed weight stream, the fp32 head tables (density row, rgb rows, register order) and, per wave and
+    // tile, two 1 KiB slots the ReLU gates of a layer are DMA'd into one GEMM before they are needed (below)
+    constexpr bool kMaskLds = L::mask_words == 4;     // D = 256: a lane's gates of a layer (halves A and B) are one 16-byte DMA element
+    constexpr int kTabF4 = (L::head_floats + 3) / 4;
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kTabF4 + (kMaskLds ? W * kTiles * 2 * 64 : 0)];
     float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4);
     for (int i = threadIdx.x; i < L::head_floats; i += 64 * W) ltab[i] = a.packed[L::head_base + i];
     __syncthreads();   // before any DMA is in flight: the only full barrier of the kernel
@@ -75,21 +46,38 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     auto p0 = [&](int part) { return L::bwd_panel0(part); };
 #pragma unroll 1
     for (int pass = 0; pass < n_pass; ++pass) {
-    int lane = lane0;                 // opaque per pass (mlp_fwd_kernel)
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // re-derived and opaque per pass (mlp_fwd_bf16_kernel)
     asm volatile("" : "+v"(lane));
     pipe.lane = lane;
     const int half = lane >> 5;
     const int col = lane & 31;
     const float* const wsig = ltab + half * (16 * DT);   // density row, this half's registers
     const float* const wrgb = ltab + 2 * 16 * DT;        // rgb rows: [(2c + half) * HR + r]
-    const int64_t pair = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * W + wave) * n_pass + pass
-                                               : (int64_t)blockIdx.x * W + wave;
+    const int64_t pair = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * W + wave_u) * n_pass + pass
+                                               : (int64_t)blockIdx.x * W + wave_u;
     int chunk[kTiles];   // chunk index of either tile
-    f32x4 dout[kTiles];
+    f32x4 dout[kTiles], pos[kTiles], vdir[kTiles];
 #pragma unroll
     for (int n = 0; n < kTiles; ++n) chunk[n] = (int)(kTiles * pair + n < last_chunk ? kTiles * pair + n : last_chunk);
     // this lane's sample of tile n; every address is derived from it where it is needed (opaque(), nnr_mlp_bf16.h)
     auto sample = [&](int n) -> int64_t { return (int64_t)opaque(chunk[n]) * kChunk + col; };
+    // ---- ReLU gates through LDS ----
+    // A load into registers that hipcc can see is waited for with vmcnt(0) whenever stores are pending (loads and stores share the
+    // counter and may, as far as the compiler knows, retire out of order) -- and in this kernel stores are ALWAYS pending: each of the
+    // 18 gate loads of a pass drained the whole stash-store queue with the matrix pipe idle (9 % of the kernel).  The gates of a layer
+    // now travel like the weights: one LDS-DMA element per lane and tile (a lane's 16 bytes = halves A and B), issued at the head of
+    // the GEMM BEFORE the one that needs them, covered by that GEMM's counted panel waits (vmcnt retires in issue order, which the
+    // weight ring relies on as well), and read with a hand-waited ds_read_b128.
+    f32x4* const mlds = smem + kNBuf * kPanelF4 + kTabF4 + (kMaskLds ? wave_u * (kTiles * 2 * 64) : 0);
+    auto gates_dma = [&](int layer_idx, int slot) __attribute__((always_inline)) {
+        if constexpr (kMaskLds) {
+#pragma unroll
+            for (int n = 0; n < kTiles; ++n) {
+                const uint32_t* g = a.ws_mask + (((int64_t)opaque(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane) * L::mask_words;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(mlds + (2 * n + slot) * 64), 16, 0, 0);
+            }
+        }
+    };
 #pragma unroll
     for (int n = 0; n < kTiles; ++n) {
         const int64_t sn = sample(n);
@@ -97,6 +85,10 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         // padded samples carry zero gradients so they add nothing to the weight gradients
         if (sn < a.S) dout[n] = *reinterpret_cast<const f32x4*>(a.ws_dout4 + 4 * sn);
         else if (half == 0) *reinterpret_cast<f32x4*>(a.ws_dout4 + 4 * sn) = dout[n];   // padded rows feed the weight-gradient kernel
+        // the forward left the sample's position and view direction where this kernel will put their gradients (nnr_mlp_bf16.h)
+        const int64_t sc = sn < a.S ? sn : a.S - 1;
+        pos[n] = *reinterpret_cast<const f32x4*>(a.ws_dpts + 4 * sc);
+        vdir[n] = *reinterpret_cast<const f32x4*>(a.ws_dview + 4 * sc);
     }
 
     // (the row dimension of the packed arrays is padded by 4: with rows adjacent in memory hipcc forms a 32-byte access across the
@@ -104,12 +96,44 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     uint32_t dq[kTiles][NQ + 4];   // current D-wide gradient, packed (d pre-activation of hidden 8..1), rewritten in place
     f32x16 accA[kTiles][HT], accB[kTiles][HT];   // halves A ([0,D/2)) and B ([D/2,D)) of the gradient being computed
     uint32_t mwA[kTiles][HW], mwB[kTiles][HW];   // ReLU gates of the layer whose gradient sits in accA / accB (gate_append's layout)
-    auto load_mask = [&](uint32_t(&mw)[kTiles][HW], int layer_idx, int hb) __attribute__((always_inline)) {
+    // gates of both halves from LDS slot `slot` (D = 256); the DMA that filled it is older than a counted panel wait this wave has passed
+    auto gates_read = [&](int slot) __attribute__((always_inline)) {
+        static_assert(!kMaskLds || HW == 2, "a lane's 16 bytes are halves A and B");
+        if constexpr (kMaskLds) {
+#pragma unroll
+            for (int n = 0; n < kTiles; ++n) {
+                f32x4 v = frag_read(lds_byte_address(mlds + (2 * n + slot) * 64) + 16u * lane, 0);
+                wait_frag(v, 0);
+                const u32x4 q = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+                for (int w = 0; w < HW; ++w) { mwA[n][w] = q[w]; mwB[n][w] = q[HW + w]; }
+            }
+        }
+    };
+    auto load_mask = [&](uint32_t(&mw)[kTiles][HW], int layer_idx, int hb) __attribute__((always_inline)) {   // D = 128: direct loads
 #pragma unroll
         for (int n = 0; n < kTiles; ++n) {
             const uint32_t* m = a.ws_mask + (((int64_t)opaque(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane) * L::mask_words + hb * HW;
 #pragma unroll
-            for (int w = 0; w < HW; ++w) mw[n][w] = m[w];
+            for (int w = 0; w < HW; ++w) {
+#ifdef NNR_ABLATE_NO_MASKLOAD
+                mw[n][w] = 0xffffffffu ^ (uint32_t)(size_t)m * 0u;     // profiling build only: every gate open, no load
+#else
+                mw[n][w] = m[w];
+#endif
+            }
+        }
+    };
+    // gates of layer `layer_idx`, both halves: requested one GEMM ahead (prefetch), taken into mwA / mwB where the old ones have been used up
+    auto gates_prefetch = [&](int layer_idx) __attribute__((always_inline)) {
+        if constexpr (kMaskLds) gates_dma(layer_idx, layer_idx & 1);
+    };
+    auto gates_fetch = [&](int layer_idx, bool both) __attribute__((always_inline)) {
+        if constexpr (kMaskLds) {
+            gates_read(layer_idx & 1);
+        } else {
+            load_mask(mwA, layer_idx, 0);
+            if (both) load_mask(mwB, layer_idx, 1);
         }
     };
 // one epilogue unit u: tile u % T, packed register u / T of the half -- dq[tile][OFF + u / T] = (relu'(.) ? acc : 0) x 2 as bf16
@@ -132,7 +156,10 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     // ---- colour branch ----
     // d g = relu'(g) .* (Wc^T d rgb_pre): three FMAs per value against the rgb rows in LDS (a 3-deep GEMM is not MFMA work)
     uint32_t dgq[kTiles][NP + 4];
-    load_mask(mwA, 8, 0);
+    gates_prefetch(8);   // colour-hidden gates and hidden 8's: needed at once -- this is the one place a pass waits for them
+    gates_prefetch(7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the loads above are waited for here anyway; nothing else is in flight yet)
+    gates_fetch(8, false);
 #pragma unroll
     for (int q = 0; q < HR / 4; ++q) {
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrgb + (0 + half) * HR + 4 * q);
@@ -161,7 +188,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
                     for (int i = 0; i < 4; ++i) acc[n][t][4 * q + i] = w4[i] * dout[n][3];
             }
     };
-    load_mask(mwA, 7, 0);
+    gates_fetch(7, true);     // mwA for the side units of B_RGBH_FB, mwB for the first trunk layer's pass A
     init_sigma(accA, 0);
     // d g goes to P_DG (tile-major, one more group than D/32: the output gradients themselves -- d rgb_pre[0..2], d sigma_raw, zeros --
     // as bf16, the gradient operand of the two head layers in the weight-gradient kernel)
@@ -177,16 +204,10 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         stash_store(dg_stash[n] + kBlockBf16 * (D / 32), q);
     }
     gemm_wide<HT, HT, true, 0, 1, 0, 0>(accA, dgq, pipe, p0(B_RGBH_FA), dg_stash, NoSide{});
-    load_mask(mwB, 7, 1);
     init_sigma(accB, 1);
     // G = 2 HT rows; unit u writes dq[.][u >> 1] -- not an input of this part
     gemm_wide<HT, HT, false, kPh * NU, kPh * (NU / (2 * HT)), 0, stash_tail<HT, HT, T>()>(accB, dgq, pipe, p0(B_RGBH_FB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
     {
-        // the chain-rule factors are fetched BEFORE the GEMM whose result they multiply: the loads land under it, and the wait for them
-        // does not drain the weight DMA issued meanwhile
-        f32x4 facd[kTiles][4];
-#pragma unroll
-        for (int n = 0; n < kTiles; ++n) enc_factors_load(facd[n], a.ws_xf + ((int64_t)opaque(chunk[n]) * 4) * 256 + lane * 4);
         f32x16 accd[kTiles][1];
         zero_acc2(accd);
         gemm_wide<HT, 1>(accd, dgq, pipe, p0(B_RGBH_D));
@@ -194,7 +215,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         for (int n = 0; n < kTiles; ++n) {
             const int64_t sn = sample(n);
             const bool live = sn < a.S;
-            const f32x4 gv = enc_chain<16>([&](int r) { return accd[n][0][r]; }, facd[n], half);
+            const f32x4 gv = enc_chain<16, 4>([&](int r) { return accd[n][0][r]; }, vdir[n][0], vdir[n][1], vdir[n][2], half);
             if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dview + 4 * sn) = gv;
         }
     }
@@ -208,11 +229,11 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     // below, masked by the ReLU gates of hidden layer `mask_idx`
     auto bwd_layer = [&](int pa, __bf16* const (&st)[kTiles], int mask_idx) __attribute__((always_inline)) {
         zero_acc2(accA);
-        load_mask(mwA, mask_idx, 0);
+        gates_prefetch(mask_idx);      // T DMA elements, younger than the first panel's pieces: PRE = T
         // pass A: rows [0, G/2) only read dq[.][0, NP); the previous gradient's half B is finished meanwhile (unit u at row u / PA, see
         // mlp_fwd_bf16_kernel)
-        gemm_wide<DT, HT, true, kPh * NU, kPh * PA, 0, 0>(accA, dq, pipe, pa, st, NNR_SEL_UNIT(accB, NP, mwB));
-        load_mask(mwB, mask_idx, 1);
+        gemm_wide<DT, HT, true, kPh * NU, kPh * PA, 0, kMaskLds ? T : 0>(accA, dq, pipe, pa, st, NNR_SEL_UNIT(accB, NP, mwB));
+        gates_fetch(mask_idx, true);   // mwB's old contents were used up by the units of pass A
         zero_acc2(accB);
         // pass B: half A of the new gradient replaces dq[.][0, NP) in place behind the reads (unit u at row u / PB + 1)
         gemm_wide<DT, HT, false, kPh * NU, kPh * PB, 1, stash_tail<DT, HT, T>()>(accB, dq, pipe, pa + PP, no_stash, NNR_SEL_UNIT(accA, 0, mwA));
@@ -235,18 +256,15 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         for (int n = 0; n < kTiles; ++n) st[n] = dh(4, n);
         f32x16 acce[kTiles][2];
         zero_acc2(acce);
-        load_mask(mwA, 3, 0);
-        gemm_wide<DT, 2, true, kPh * NU, kPh * PA, 0, 0>(acce, dq, pipe, p0(B_L5E), st, NNR_SEL_UNIT(accB, NP, mwB));
+        gates_prefetch(3);
+        gemm_wide<DT, 2, true, kPh * NU, kPh * PA, 0, kMaskLds ? T : 0>(acce, dq, pipe, p0(B_L5E), st, NNR_SEL_UNIT(accB, NP, mwB));
+        gates_fetch(3, true);
 #pragma unroll
-        for (int n = 0; n < kTiles; ++n) {   // (64 more live registers during the GEMM would spill: the factors are fetched here)
-            f32x4 face[8];
-            enc_factors_load(face, a.ws_xe + ((int64_t)opaque(chunk[n]) * 8) * 256 + lane * 4);
-            gp5[n] = enc_chain<32>([&](int r) { return acce[n][r >> 4][r & 15]; }, face, half);
-        }
+        for (int n = 0; n < kTiles; ++n)
+            gp5[n] = enc_chain<32, 10>([&](int r) { return acce[n][r >> 4][r & 15]; }, pos[n][0], pos[n][1], pos[n][2], half);
     }
-    load_mask(mwB, 3, 1);
     zero_acc2(accA);
-    gemm_wide<DT, HT>(accA, dq, pipe, p0(B_L5HA));   // (the factor loads above were waited for: nothing of B_L5E is in flight)
+    gemm_wide<DT, HT, stash_tail<DT, 2, T>()>(accA, dq, pipe, p0(B_L5HA));   // (B_L5E's last stash stores may stay in flight)
     zero_acc2(accB);
     gemm_wide<DT, HT, false, kPh * NU, kPh * PB, 1, 0>(accB, dq, pipe, p0(B_L5HB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
     NNR_STAMP(tl_dgrad16, 3);
@@ -271,9 +289,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         for (int n = 0; n < kTiles; ++n) {
             const int64_t sn = sample(n);
             const bool live = sn < a.S;
-            f32x4 face[8];
-            enc_factors_load(face, a.ws_xe + ((int64_t)opaque(chunk[n]) * 8) * 256 + lane * 4);
-            const f32x4 gp = enc_chain<32>([&](int r) { return acc2[n][r >> 4][r & 15]; }, face, half);
+            const f32x4 gp = enc_chain<32, 10>([&](int r) { return acc2[n][r >> 4][r & 15]; }, pos[n][0], pos[n][1], pos[n][2], half);
             if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dpts + 4 * sn) = gp + gp5[n];
         }
     }

@@ -76,16 +76,18 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     const bool fuse = !TRAIN && a.fuse_rgb != nullptr;
 #pragma unroll 1
     for (int pass = 0; pass < n_pass; ++pass) {
-    int lane = lane0;                 // opaque per pass: keeps lane-constant addresses from being hoisted and spilled (mlp_fwd_kernel)
+    // the lane index is RE-DERIVED every pass (two instructions, no register carried across the loop) and opaque: keeps lane-constant
+    // addresses from being hoisted out of the pass loop and spilled (mlp_fwd_kernel)
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(lane));
     pipe.lane = lane;
     const int half = lane >> 5;
     const int col = lane & 31;
-    f32x4* const park = smem + kNBuf * kPanelF4 + wave * (6 * T * 64) + lane;
+    f32x4* const park = smem + kNBuf * kPanelF4 + wave_u * (6 * T * 64) + lane;
     const float* bias = ltab - L::bias_base;   // index with L::bias_off(layer)
     const uint32_t* const wsig16 = head16 + half * NQ;
-    const int64_t pair = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * W + wave) * n_pass + pass
-                                               : (int64_t)blockIdx.x * W + wave;
+    const int64_t pair = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * W + wave_u) * n_pass + pass
+                                               : (int64_t)blockIdx.x * W + wave_u;
     int chunk[kTiles];   // chunk index of either tile (< 2^26: S_pad < 2^31)
 #pragma unroll
     for (int n = 0; n < kTiles; ++n) chunk[n] = (int)(kTiles * pair + n < last_chunk ? kTiles * pair + n : last_chunk);
@@ -99,22 +101,71 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     uint32_t eq[kTiles][16 + 4];   // gamma_10(p) packed: 63 -> 64
 
     // ---- sampling (model/rendering.py:184-195; unfused mul/add to round like the reference) and encodings, tile by tile ----
+    // Everything a pass reads from memory is requested HERE, in one batch, before anything is waited for: every s_waitcnt vmcnt of this
+    // phase also waits for the stash stores of the previous pass (vmcnt counts stores, in order), so each separate round trip costs an
+    // HBM write latency -- the tile-by-tile version (ten serialised waits, two 64-bit divisions) was ~15 % of a pass.
+    // Ray mode: the wave walks ONE ray (wave-uniform: its origin / direction / view direction come through the scalar cache) and the
+    // sample index within the ray needs no division; flat mode divides in 32 bits (S_pad < 2^31).
+    float s_z[kTiles], s_p[kTiles][3], s_v[kTiles][3];
+    {
+        int jj[kTiles], rr[kTiles];
+        float zlo[kTiles], zhi[kTiles], jit[kTiles];
+        float ro[kTiles][3], rd[kTiles][3];
+        if (a.chunks_per_ray > 0) {
+            const int ray_u = (int)blockIdx.x * W + wave_u;
+#pragma unroll
+            for (int n = 0; n < kTiles; ++n) {
+                rr[n] = ray_u;
+                jj[n] = (pass * kTiles + n) * kChunk + col;
+            }
+            const float* po = a.pts_o + 3 * (int64_t)ray_u;
+            const float* pd = a.pts_d + 3 * (int64_t)ray_u;
+            const float* pv = a.view_d + 3 * (int64_t)ray_u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float o = po[c], d = pd[c], v = pv[c];     // uniform addresses: scalar loads
+#pragma unroll
+                for (int n = 0; n < kTiles; ++n) { ro[n][c] = o; rd[n][c] = d; s_v[n][c] = v; }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < kTiles; ++n) {
+                const int64_t sn = sample(n);
+                const unsigned sc = (unsigned)(sn < a.S ? sn : a.S - 1);   // padded samples recompute the last one
+                const unsigned nn = (unsigned)opaque(a.N);      // opaque: the reciprocal sequence of the division is not hoisted out of
+                rr[n] = (int)(sc / nn);                           // the pass loop (where it would sit in registers the ray mode needs)
+                jj[n] = (int)(sc - (unsigned)rr[n] * nn);
+            }
+#pragma unroll
+            for (int n = 0; n < kTiles; ++n)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    ro[n][c] = a.pts_o[3 * (int64_t)rr[n] + c];
+                    rd[n][c] = a.pts_d[3 * (int64_t)rr[n] + c];
+                    s_v[n][c] = a.view_d[3 * (int64_t)rr[n] + c];
+                }
+        }
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) {
+            zlo[n] = a.z_lo[jj[n]];
+            zhi[n] = a.z_hi[jj[n]];
+            jit[n] = a.jitter ? a.jitter[(int64_t)rr[n] * a.N + jj[n]] : 0.f;
+        }
+#pragma unroll
+        for (int n = 0; n < kTiles; ++n) {
+            float z = zlo[n];
+            if (a.jitter) z = __fadd_rn(zlo[n], __fmul_rn(__fsub_rn(zhi[n], zlo[n]), jit[n]));
+            s_z[n] = z;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s_p[n][c] = __fadd_rn(ro[n][c], __fmul_rn(rd[n][c], z));
+        }
+    }
 #pragma unroll
     for (int n = 0; n < kTiles; ++n) {
         const int64_t sn = sample(n);
-        const int64_t sc = sn < a.S ? sn : a.S - 1;   // padded samples recompute the last one
-        const int ray = (int)(sc / a.N);
-        const int j = (int)(sc - (int64_t)ray * a.N);
-        const float zlo = a.z_lo[j], zhi = a.z_hi[j];
-        float z = zlo;
-        if (a.jitter) z = __fadd_rn(zlo, __fmul_rn(__fsub_rn(zhi, zlo), a.jitter[sc]));
-        const float* ro = a.pts_o + 3 * (int64_t)ray;
-        const float* rd = a.pts_d + 3 * (int64_t)ray;
-        const float* rv = a.view_d + 3 * (int64_t)ray;
-        const float px = __fadd_rn(ro[0], __fmul_rn(rd[0], z));
-        const float py = __fadd_rn(ro[1], __fmul_rn(rd[1], z));
-        const float pz = __fadd_rn(ro[2], __fmul_rn(rd[2], z));
-        const float vx = rv[0], vy = rv[1], vz = rv[2];
+        const float z = s_z[n];
+        const float px = s_p[n][0], py = s_p[n][1], pz = s_p[n][2];
+        const float vx = s_v[n][0], vy = s_v[n][1], vz = s_v[n][2];
         if (half == 0 && sn < a.S && !fuse) a.ws_z[sn] = z;
         float e[32];
 #pragma unroll
@@ -135,23 +186,13 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         for (int q = 0; q < 2; ++q)
             park[(6 * n + 4 + q) * 64] = __builtin_bit_cast(f32x4, u32x4{dq[4 * q], dq[4 * q + 1], dq[4 * q + 2], dq[4 * q + 3]});
         if constexpr (TRAIN && !kAblateEncStash) {
-            // the chain-rule factors of both encodings in register order for the input-gradient kernel (enc_factor, nnr_mlp_bf16.h),
-            // and tile-major bf16 copies of the encodings = the MFMA operands, for the weight-gradient kernel
-            float es[32], ds[16];
-#pragma unroll
-            for (int r = 0; r < 32; ++r) es[r] = __shfl_xor(e[r], 32, 64);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ds[r] = __shfl_xor(dirv[r], 32, 64);
-            float* pe = a.ws_xe + ((int64_t)opaque(chunk[n]) * 8) * 256 + lane * 4;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                stash_store(pe + q * 256, f32x4{enc_factor(4 * q, half, kPosReal, e, es), enc_factor(4 * q + 1, half, kPosReal, e, es),
-                                                enc_factor(4 * q + 2, half, kPosReal, e, es), enc_factor(4 * q + 3, half, kPosReal, e, es)});
-            float* pf = a.ws_xf + ((int64_t)opaque(chunk[n]) * 4) * 256 + lane * 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                stash_store(pf + q * 256, f32x4{enc_factor(4 * q, half, kDirReal, dirv, ds), enc_factor(4 * q + 1, half, kDirReal, dirv, ds),
-                                                enc_factor(4 * q + 2, half, kDirReal, dirv, ds), enc_factor(4 * q + 3, half, kDirReal, dirv, ds)});
+            // for the input-gradient kernel: the sample's position and view direction (it recomputes the chain-rule factors of the two
+            // encodings from them, nnr_mlp_bf16.h -- 32 bytes per sample instead of 384 of factors), parked in the planes that kernel
+            // overwrites with their gradients; for the weight-gradient kernel: tile-major bf16 copies of the encodings = its MFMA operands
+            if (half == 0 && sn < a.S) {
+                *reinterpret_cast<f32x4*>(a.ws_pts + 4 * sn) = f32x4{px, py, pz, 0.f};
+                *reinterpret_cast<f32x4*>(a.ws_view + 4 * sn) = f32x4{vx, vy, vz, 0.f};
+            }
             __bf16* e16 = tile_row(a.ws_xe16, sn, kPosPad, half);
 #pragma unroll
             for (int b = 0; b < 4; ++b)
@@ -230,11 +271,12 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
 
     // ---- hidden 1: 63 -> D, input = posenc.  Pass A, then pass B with A's epilogue hidden under it. ----
     init_acc(accA, L::bias_off(0));
-    // (training: the 36 stash stores of the encodings above are younger than every piece of the first two panels)
-    gemm_wide<2, HT, TRAIN ? T * 18 : 0>(accA, eq, pipe, p0(F_L1A));
+    // (training: the 16 stash stores of the encodings above -- 6 bf16 blocks + position + view direction per tile -- are younger than
+    // every piece of the first two panels)
+    gemm_wide<2, HT, TRAIN ? T * 8 : 0>(accA, eq, pipe, p0(F_L1A));
     init_acc(accB, L::bias_off(0) + L::Dh);
     clear_mask(mwA);
-    gemm_wide<2, HT, false, kPh * NU, kPh * (NU / 4), 0, TRAIN ? T * 18 : 0>(accB, eq, pipe, p0(F_L1B), no_stash, NNR_RELU_UNIT(accA, 0, mwA));   // (the same stores are younger than panel 1's pieces too)
+    gemm_wide<2, HT, false, kPh * NU, kPh * (NU / 4), 0, TRAIN ? T * 8 : 0>(accB, eq, pipe, p0(F_L1B), no_stash, NNR_RELU_UNIT(accA, 0, mwA));   // (the same stores are younger than panel 1's pieces too)
     store_mask(mwA, 0, 0);
     NNR_STAMP(tl_fwd16, (TRAIN ? 0 : 16) + 2);
     // Invariant from here on: hq[.][0, NP) holds half A of the newest layer, accB holds its half B still to be finished.

@@ -5,8 +5,8 @@
 //
 // The update is torch's, operation by operation and type by type (aten/src/ATen/native/cuda/fused_adam_utils.cuh, the non-amsgrad,
 // non-capturable ADAM_MODE::ORIGINAL path, weight_decay == 0, maximize == false), because training must not depend on which of the
-// two implementations stepped: lr, betas and eps are DOUBLES, the first / second moment updates are evaluated in double and rounded
-// to float once, the bias corrections are 1 - pow(beta, step) in double rounded to float, the step size lr / bias_correction1 is a
+// two implementations stepped: lr, betas and eps are DOUBLES, the first / second moment updates are evaluated in double (one fma on the
+// decayed moment) and rounded to float once, the bias corrections are 1 - pow(beta, step) in double rounded to float, the step size lr / bias_correction1 is a
 // double division rounded to float, the denominator adds the double eps to a float quotient.  tests/test_gpu_optim.py compares the
 // parameters and both moments BITWISE with torch.optim.Adam(fused=True) over hundreds of steps.
 #include <hip/hip_runtime.h>
@@ -43,8 +43,11 @@ __global__ __launch_bounds__(kAdamBlock) void adam_multi_kernel(nnr_adam_table t
         float param = p[e];
         const float grad = g[e];
         float exp_avg = m[e], exp_avg_sq = v[e];
-        exp_avg = beta1 * exp_avg + (1 - beta1) * grad;
-        exp_avg_sq = beta2 * exp_avg_sq + (1 - beta2) * grad * grad;
+        // (torch's `beta1 * exp_avg + (1 - beta1) * grad` is compiled with the first product contracted into an fma -- established
+        // bitwise by tools/adam_variants.py, profiles/r03/f_adam_variants.txt; spelled out here so that it does not depend on this
+        // translation unit's contraction decisions)
+        exp_avg = (float)__fma_rn(beta1, (double)exp_avg, (1 - beta1) * (double)grad);
+        exp_avg_sq = (float)__fma_rn(beta2, (double)exp_avg_sq, (1 - beta2) * (double)grad * (double)grad);
         const float step_size = lr / bias_correction1;
         const float denom = (sqrtf(exp_avg_sq) / bias_correction2_sqrt) + eps;
         param -= step_size * exp_avg / denom;

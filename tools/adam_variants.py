@@ -55,13 +55,32 @@ def main():
         return int((pp != tp).sum()), int((m != tm).sum()), int((v != tv).sum())
 
     print("first moment variants (elements differing from torch, steps 2..4):")
-    for va in range(10):
+    for va in range(20):
         print("  va=%d" % va, [run(k, va, 0, 0)[1] for k in (1, 2, 3)])
+    # a few elements where the closest variants disagree with torch: old moment, gradient, torch's result, the variant's, and the exactly
+    # rounded value of beta1 * m + (1 - beta1) * g in rational arithmetic
+    from fractions import Fraction
+    import struct
+    f2h = lambda x: struct.pack('>f', x).hex()
+    for va in (0, 6):
+        k = 2
+        pp, m, v = (t.clone() for t in traj[k - 1])
+        g = grads(k)
+        lib.adam_variant(pp.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, b1, b2, eps, float(k + 1), va, 0, 0, st_ptr)
+        torch.cuda.synchronize()
+        bad = (m != traj[k][1]).nonzero().reshape(-1)[:6].cpu()
+        m_old = traj[k - 1][1].cpu()
+        for i in bad.tolist():
+            mo, gg, tn, vn = float(m_old[i]), float(g[i].cpu()), float(traj[k][1][i].cpu()), float(m[i].cpu())
+            exact = Fraction(b1) * Fraction(mo) + (1 - Fraction(b1)) * Fraction(gg)
+            exact_w = Fraction(mo) + Fraction(1 - b1) * (Fraction(gg) - Fraction(mo))
+            print("  va=%d i=%d m_old %s (%.9g) g %s (%.9g) torch %s variant %s exact(beta form) %s exact(lerp, w=double(1-b1)) %s"
+                  % (va, i, f2h(mo), mo, f2h(gg), gg, f2h(tn), f2h(vn), f2h(float(exact)), f2h(float(exact_w))))
     print("second moment variants:")
-    for vb in range(8):
+    for vb in range(9):
         print("  vb=%d" % vb, [run(k, 0, vb, 0)[2] for k in (1, 2, 3)])
-    best_a = min(range(10), key=lambda va: sum(run(k, va, 0, 0)[1] for k in (1, 2, 3)))
-    best_b = min(range(8), key=lambda vb: sum(run(k, 0, vb, 0)[2] for k in (1, 2, 3)))
+    best_a = min(range(20), key=lambda va: sum(run(k, va, 0, 0)[1] for k in (1, 2, 3)))
+    best_b = min(range(9), key=lambda vb: sum(run(k, 0, vb, 0)[2] for k in (1, 2, 3)))
     print("best va", best_a, "best vb", best_b)
     print("parameter update variants (with the best moments):")
     for vc in list(range(5)) + [8 + i for i in range(5)]:

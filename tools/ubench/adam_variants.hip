@@ -27,6 +27,20 @@ __global__ void adam_variant_kernel(float* p, const float* g, float* m, float* v
             exp_avg = w < 0.5f ? exp_avg + w * d : grad - d * (1.f - w);
         } break;
         case 9: exp_avg = __fadd_rn(exp_avg, __fmul_rn((float)(1 - beta1), __fsub_rn(grad, exp_avg))); break;   // float lerp, no fma
+        case 10: exp_avg = exp_avg + (1 - beta1) * (grad - exp_avg); break;                               // lerp: float difference, double weight
+        case 11: exp_avg = (float)__dadd_rn((double)exp_avg, __dmul_rn(1 - beta1, (double)(grad - exp_avg))); break;   // the same, no fma
+        case 12: exp_avg = (float)__fma_rn(1 - beta1, (double)(grad - exp_avg), (double)exp_avg); break;   // the same, one fma
+        case 14: exp_avg = __builtin_fmaf((float)(1 - beta1), grad, __builtin_fmaf(-(float)(1 - beta1), exp_avg, exp_avg)); break;   // "faster lerp", float
+        case 15: exp_avg = (float)__fma_rn(1 - beta1, (double)grad, __fma_rn(-(1 - beta1), (double)exp_avg, (double)exp_avg)); break;   // "faster lerp", double
+        case 16: exp_avg = (float)__fma_rn(1 - beta1, (double)grad - (double)exp_avg, (double)exp_avg); break;   // double lerp, one fma
+        case 17: exp_avg = (float)__dadd_rn((double)exp_avg, __dmul_rn(1 - beta1, __dsub_rn((double)grad, (double)exp_avg))); break;   // double lerp, no fma
+        case 18: exp_avg = (float)__fma_rn(beta1, (double)exp_avg, __dmul_rn(1 - beta1, (double)grad)); break;    // beta form, fma on the first product
+        case 19: exp_avg = (float)__fma_rn(1 - beta1, (double)grad, __dmul_rn(beta1, (double)exp_avg)); break;    // beta form, fma on the second product
+        case 13: {   // at::lerp with a double weight: weight < 0.5 branch
+            const double w = 1 - beta1;
+            const float d = grad - exp_avg;
+            exp_avg = w < 0.5 ? (float)(exp_avg + w * d) : (float)(grad - d * (1 - w));
+        } break;
     }
     switch (vb) {
         case 0: exp_avg_sq = beta2 * exp_avg_sq + (1 - beta2) * grad * grad; break;                      // double
@@ -37,6 +51,7 @@ __global__ void adam_variant_kernel(float* p, const float* g, float* m, float* v
         case 5: exp_avg_sq = __builtin_fmaf(b2, exp_avg_sq, (float)(1 - beta2) * grad * grad); break;
         case 6: exp_avg_sq = __builtin_fmaf((float)(1 - beta2) * grad, grad, b2 * exp_avg_sq); break;
         case 7: exp_avg_sq = __fadd_rn(__fmul_rn(b2, exp_avg_sq), __fmul_rn((float)(1 - beta2), __fmul_rn(grad, grad))); break;
+        case 8: exp_avg_sq = (float)__fma_rn(beta2, (double)exp_avg_sq, (1 - beta2) * (double)grad * (double)grad); break;   // double, fma on the decayed moment
     }
     float bc1, bc2s;
     if (vc & 8) {      // bias corrections in float
