@@ -30,9 +30,14 @@ HEADERS = ["nnr_layout.h", "nnr_device.h", "nnr_kernels.h", "nnr_mlp_bf16.h", os
 # warning, kept passing every parity test and ran 8x slower (832 bytes of scratch per lane).  Hence the raised cap AND the check below.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-pragma-unroll-threshold=1048576",
          "-Rpass-analysis=kernel-resource-usage", "-I" + HERE, "-I" + os.path.join(HERE, "..", "..", "include"), "-x", "hip"]
-# scratch bytes per lane a hot kernel may use (spills of lane-constant addresses outside the MFMA streams in the bf16 training kernels)
-SCRATCH_LIMIT = {"mlp_fwd_kernel": 0, "mlp_dgrad_kernel": 0, "wgrad_kernel": 0, "wgrad_b_kernel": 0, "mlp_fwd_bf16_kernel": 256,
-                 "mlp_dgrad_bf16_kernel": 320, "composite_fwd_kernel": 0, "composite_bwd_kernel": 0}
+# Scratch bytes per lane a hot kernel may use, by substring of the MANGLED name (the longest matching substring decides).  In the bf16
+# training kernels a spill reload is not just a slow load: stores are always in flight there, hipcc waits for any load next to pending
+# stores with vmcnt(0), and every reload drains the stash-store queue with the matrix pipe idle -- the TRAINING forward must be free of
+# scratch; the input-gradient kernel keeps a handful of values spilled in its prologue and reloaded at pass start (where the pass waits
+# for its inputs anyway); the inference forward (no stores in flight) may spill its composite carry.
+SCRATCH_LIMIT = {"14mlp_fwd_kernelI": 0, "16mlp_dgrad_kernelI": 0, "12wgrad_kernelE": 0, "14wgrad_b_kernelE": 0,
+                 "19mlp_fwd_bf16_kernelI": 32, "19mlp_fwd_bf16_kernelILi256ELb1E": 0, "19mlp_fwd_bf16_kernelILi128ELb1E": 0,
+                 "21mlp_dgrad_bf16_kernelI": 64, "20composite_fwd_kernelE": 0, "20composite_bwd_kernelE": 0}
 
 
 def check_resources(remarks, what):
@@ -45,9 +50,11 @@ def check_resources(remarks, what):
             name = m.group(1)
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
         if m and name:
-            for key, limit in SCRATCH_LIMIT.items():
-                if ("3nnr%d%sI" % (len(key), key) in name or "3nnr%d%sE" % (len(key), key) in name) and int(m.group(1)) > limit:
-                    bad.append("%s: %s bytes of scratch per lane (limit %d)" % (name, m.group(1), limit))
+            keys = [k for k in SCRATCH_LIMIT if ("3nnr" + k) in name]
+            if keys:
+                key = max(keys, key=len)
+                if int(m.group(1)) > SCRATCH_LIMIT[key]:
+                    bad.append("%s: %s bytes of scratch per lane (limit %d)" % (name, m.group(1), SCRATCH_LIMIT[key]))
     if bad:
         raise RuntimeError("%s: a hot kernel uses scratch memory -- a loop did not unroll or registers spilled:\n  " % what + "\n  ".join(bad))
 

@@ -292,6 +292,12 @@ __device__ __forceinline__ __bf16* tile_row(float* plane, int64_t row, int width
     return reinterpret_cast<__bf16*>(plane) + (row - c) * width + (32 * half + c) * 8;
 }
 
+// The same from the WAVE-UNIFORM first row of the lane's chunk (row0 = plane * S_pad + 32 * chunk, a scalar) and the lane index: a scalar
+// base plus a 32-bit lane offset -- the form the compiler addresses with (SGPR pair + VGPR offset) instead of a 64-bit address per lane
+__device__ __forceinline__ __bf16* tile_lane(float* plane, int64_t row0, int width, int lane) {
+    return reinterpret_cast<__bf16*>(plane) + row0 * width + lane * 8;
+}
+
 template <int N>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N]) {
 #pragma unroll

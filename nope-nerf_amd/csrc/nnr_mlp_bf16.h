@@ -54,6 +54,28 @@ __device__ __forceinline__ int opaque(int x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+// The lane index, re-derived on the spot (two VALU instructions, volatile so that the copies are not merged): the kernels use it for
+// every address and bounds test OUTSIDE the MFMA streams instead of a lane / half / column value kept in a register for the whole pass
+// -- at 512 registers per lane even that one register is spilled, and its reload drains the store queue like any other load.
+__device__ __forceinline__ int lane_id() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+// x of this lane + x of the lane 32 further (the other half-wave, which holds the other half of the features of the same sample):
+// v_permlane32_swap on two copies leaves (lower, lower) in one and (upper, upper) in the other -- their sum is the same number in both
+// halves, bitwise what x + __shfl_xor(x, 32) gives, without the ds_bpermute index register the shuffle keeps alive (and spills).
+__device__ __forceinline__ float sum_halves(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// The same for a WAVE-UNIFORM value, which stays in a scalar register: the chunk index of a tile is one (block and wave index, pass
+// counter), so every plane address is (scalar base + scalar chunk offset) + a 32-bit lane offset and costs no 64-bit vector register --
+// made opaque as a VGPR it turned each use into a 64-bit per-lane address the compiler then kept, and spilled, per pass.
+__device__ __forceinline__ int opaque_uniform(int x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
 
 // The value of a dot2_bf16 chain, safe to use.  gfx950 needs 3 wait states between a DOT instruction's write and a read by any other
 // kind of instruction (and 2 before another instruction overwrites the register); hipcc inserts them for instructions it knows, but an
@@ -376,7 +398,7 @@ __device__ __forceinline__ f32x4 enc_chain(const G& g, float x, float y, float z
         }
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
+    for (int c = 0; c < 3; ++c) o[c] = sum_halves(o[c]);
     return f32x4{o[0], o[1], o[2], 0.f};
 }
 

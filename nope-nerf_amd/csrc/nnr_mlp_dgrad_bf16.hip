@@ -29,10 +29,11 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     const int wave = threadIdx.x >> 6;
 
     // LDS: the panel ring of the transposed weight stream, the fp32 head tables (density row, rgb rows, register order) and, per wave and
-    // tile, two 1 KiB slots the ReLU gates of a layer are DMA'd into one GEMM before they are needed (below)
+    // tile, two 1 KiB slots the ReLU gates of a layer are DMA'd into one GEMM before they are needed, and two more that hold the samples'
+    // positions / view directions for the whole pass (below)
     constexpr bool kMaskLds = L::mask_words == 4;     // D = 256: a lane's gates of a layer (halves A and B) are one 16-byte DMA element
     constexpr int kTabF4 = (L::head_floats + 3) / 4;
-    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kTabF4 + (kMaskLds ? W * kTiles * 2 * 64 : 0)];
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kTabF4 + (kMaskLds ? W * kTiles * 2 * 64 : 0) + W * kTiles * 2 * 64];
     float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4);
     for (int i = threadIdx.x; i < L::head_floats; i += 64 * W) ltab[i] = a.packed[L::head_base + i];
     __syncthreads();   // before any DMA is in flight: the only full barrier of the kernel
@@ -49,18 +50,18 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // re-derived and opaque per pass (mlp_fwd_bf16_kernel)
     asm volatile("" : "+v"(lane));
     pipe.lane = lane;
-    const int half = lane >> 5;
-    const int col = lane & 31;
-    const float* const wsig = ltab + half * (16 * DT);   // density row, this half's registers
+    auto wsig_ = [&]() { return ltab + (lane_id() >> 5) * (16 * DT); };   // density row, this half's registers
     const float* const wrgb = ltab + 2 * 16 * DT;        // rgb rows: [(2c + half) * HR + r]
     const int64_t pair = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * W + wave_u) * n_pass + pass
                                                : (int64_t)blockIdx.x * W + wave_u;
     int chunk[kTiles];   // chunk index of either tile
-    f32x4 dout[kTiles], pos[kTiles], vdir[kTiles];
+    f32x4 dout[kTiles];
 #pragma unroll
-    for (int n = 0; n < kTiles; ++n) chunk[n] = (int)(kTiles * pair + n < last_chunk ? kTiles * pair + n : last_chunk);
+    for (int n = 0; n < kTiles; ++n)      // wave-uniform (block index, wave index, pass counter): lives in scalar registers
+        chunk[n] = __builtin_amdgcn_readfirstlane((int)(kTiles * pair + n < last_chunk ? kTiles * pair + n : last_chunk));
     // this lane's sample of tile n; every address is derived from it where it is needed (opaque(), nnr_mlp_bf16.h)
-    auto sample = [&](int n) -> int64_t { return (int64_t)opaque(chunk[n]) * kChunk + col; };
+    auto row0 = [&](int n) -> int64_t { return (int64_t)opaque_uniform(chunk[n]) * kChunk; };   // first sample of tile n: wave-uniform (scalar)
+    auto sample = [&](int n) -> int64_t { return row0(n) + (lane_id() & 31); };
     // ---- ReLU gates through LDS ----
     // A load into registers that hipcc can see is waited for with vmcnt(0) whenever stores are pending (loads and stores share the
     // counter and may, as far as the compiler knows, retire out of order) -- and in this kernel stores are ALWAYS pending: each of the
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         if constexpr (kMaskLds) {
 #pragma unroll
             for (int n = 0; n < kTiles; ++n) {
-                const uint32_t* g = a.ws_mask + (((int64_t)opaque(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane) * L::mask_words;
+                const uint32_t* g = a.ws_mask + (((int64_t)opaque_uniform(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane_id()) * L::mask_words;
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(mlds + (2 * n + slot) * 64), 16, 0, 0);
             }
         }
@@ -81,15 +82,28 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
 #pragma unroll
     for (int n = 0; n < kTiles; ++n) {
         const int64_t sn = sample(n);
-        dout[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // padded samples carry zero gradients so they add nothing to the weight gradients
-        if (sn < a.S) dout[n] = *reinterpret_cast<const f32x4*>(a.ws_dout4 + 4 * sn);
-        else if (half == 0) *reinterpret_cast<f32x4*>(a.ws_dout4 + 4 * sn) = dout[n];   // padded rows feed the weight-gradient kernel
-        // the forward left the sample's position and view direction where this kernel will put their gradients (nnr_mlp_bf16.h)
-        const int64_t sc = sn < a.S ? sn : a.S - 1;
-        pos[n] = *reinterpret_cast<const f32x4*>(a.ws_dpts + 4 * sc);
-        vdir[n] = *reinterpret_cast<const f32x4*>(a.ws_dview + 4 * sc);
+        // padded samples carry zero gradients so they add nothing to the weight gradients (their rows of the plane, zeroed here, feed the
+        // weight-gradient kernel).  Clamped load times a 0 / 1 weight: no zero vector for the compiler to hoist out of the pass loop.
+        const bool live = sn < a.S;
+        dout[n] = *reinterpret_cast<const f32x4*>(a.ws_dout4 + 4 * (live ? sn : a.S - 1)) * (live ? 1.f : 0.f);
+        if (!live && (lane_id() >> 5) == 0) *reinterpret_cast<f32x4*>(a.ws_dout4 + 4 * sn) = dout[n];
     }
+    // The forward left every sample's position and view direction where this kernel will put their gradients (nnr_mlp_bf16.h).  They are
+    // needed three GEMMs to a whole pass later: held in registers they are the first thing hipcc spills (and a spill reload drains the
+    // store queue like any other load); DMA'd straight into LDS they cost nothing until a hand-waited ds_read fetches them.
+    f32x4* const plds = smem + kNBuf * kPanelF4 + kTabF4 + (kMaskLds ? W * kTiles * 2 * 64 : 0) + wave_u * (kTiles * 2 * 64);
+#pragma unroll
+    for (int n = 0; n < kTiles; ++n) {
+        const int64_t sn = sample(n);
+        const int64_t sc = sn < a.S ? sn : a.S - 1;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(a.ws_dpts + 4 * sc), (lds_ptr_t)(plds + (2 * n) * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(a.ws_dview + 4 * sc), (lds_ptr_t)(plds + (2 * n + 1) * 64), 16, 0, 0);
+    }
+    auto parked = [&](int n, int which) __attribute__((always_inline)) -> f32x4 {     // which: 0 position, 1 view direction
+        f32x4 v = frag_read(lds_byte_address(plds + (2 * n + which) * 64) + 16u * lane_id(), 0);
+        wait_frag(v, 0);
+        return v;
+    };
 
     // (the row dimension of the packed arrays is padded by 4: with rows adjacent in memory hipcc forms a 32-byte access across the
     // row boundary and then leaves those 8 registers in scratch memory)
@@ -102,7 +116,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         if constexpr (kMaskLds) {
 #pragma unroll
             for (int n = 0; n < kTiles; ++n) {
-                f32x4 v = frag_read(lds_byte_address(mlds + (2 * n + slot) * 64) + 16u * lane, 0);
+                f32x4 v = frag_read(lds_byte_address(mlds + (2 * n + slot) * 64) + 16u * lane_id(), 0);
                 wait_frag(v, 0);
                 const u32x4 q = __builtin_bit_cast(u32x4, v);
 #pragma unroll
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     auto load_mask = [&](uint32_t(&mw)[kTiles][HW], int layer_idx, int hb) __attribute__((always_inline)) {   // D = 128: direct loads
 #pragma unroll
         for (int n = 0; n < kTiles; ++n) {
-            const uint32_t* m = a.ws_mask + (((int64_t)opaque(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane) * L::mask_words + hb * HW;
+            const uint32_t* m = a.ws_mask + (((int64_t)opaque_uniform(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane_id()) * L::mask_words + hb * HW;
 #pragma unroll
             for (int w = 0; w < HW; ++w) {
 #ifdef NNR_ABLATE_NO_MASKLOAD
@@ -162,9 +176,9 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     gates_fetch(8, false);
 #pragma unroll
     for (int q = 0; q < HR / 4; ++q) {
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrgb + (0 + half) * HR + 4 * q);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(wrgb + (2 + half) * HR + 4 * q);
-        const f32x4 w2 = *reinterpret_cast<const f32x4*>(wrgb + (4 + half) * HR + 4 * q);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrgb + (0 + (lane_id() >> 5)) * HR + 4 * q);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(wrgb + (2 + (lane_id() >> 5)) * HR + 4 * q);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(wrgb + (4 + (lane_id() >> 5)) * HR + 4 * q);
 #pragma unroll
         for (int n = 0; n < kTiles; ++n) {
             float v[4];
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         for (int t = 0; t < HT; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wsig + hb * HR + 16 * t + 4 * q);
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wsig_() + hb * HR + 16 * t + 4 * q);
 #pragma unroll
                 for (int n = 0; n < kTiles; ++n)
 #pragma unroll
@@ -195,16 +209,16 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
     __bf16* dg_stash[kTiles];
 #pragma unroll
     for (int n = 0; n < kTiles; ++n) {
-        dg_stash[n] = tile_row(a.ws_dg, sample(n), D / 2 + 16, half);
+        dg_stash[n] = tile_lane(a.ws_dg, row0(n), D / 2 + 16, lane_id());
         u32x4 q = {0u, 0u, 0u, 0u};
-        if (half == 0) {
+        if ((lane_id() >> 5) == 0) {
             q[0] = pack_bf16(dout[n][0], dout[n][1]);
             q[1] = pack_bf16(dout[n][2], dout[n][3]);
         }
         stash_store(dg_stash[n] + kBlockBf16 * (D / 32), q);
     }
+    init_sigma(accB, 1);      // (before the GEMM, not after it: the output gradients then die here instead of being spilled across it)
     gemm_wide<HT, HT, true, 0, 1, 0, 0>(accA, dgq, pipe, p0(B_RGBH_FA), dg_stash, NoSide{});
-    init_sigma(accB, 1);
     // G = 2 HT rows; unit u writes dq[.][u >> 1] -- not an input of this part
     gemm_wide<HT, HT, false, kPh * NU, kPh * (NU / (2 * HT)), 0, stash_tail<HT, HT, T>()>(accB, dgq, pipe, p0(B_RGBH_FB), no_stash, NNR_SEL_UNIT(accA, 0, mwA));
     {
@@ -215,14 +229,15 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         for (int n = 0; n < kTiles; ++n) {
             const int64_t sn = sample(n);
             const bool live = sn < a.S;
-            const f32x4 gv = enc_chain<16, 4>([&](int r) { return accd[n][0][r]; }, vdir[n][0], vdir[n][1], vdir[n][2], half);
-            if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dview + 4 * sn) = gv;
+            const f32x4 vd = parked(n, 1);
+            const f32x4 gv = enc_chain<16, 4>([&](int r) { return accd[n][0][r]; }, vd[0], vd[1], vd[2], (lane_id() >> 5));
+            if ((lane_id() >> 5) == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dview + 4 * sn) = gv;
         }
     }
     NNR_STAMP(tl_dgrad16, 1);
 
     // ---- trunk ----
-    auto dh = [&](int hidden_idx /*0..7*/, int n) -> __bf16* { return tile_row(a.ws_dh, (int64_t)hidden_idx * a.S_pad + sample(n), D, half); };
+    auto dh = [&](int hidden_idx /*0..7*/, int n) -> __bf16* { return tile_lane(a.ws_dh, (int64_t)hidden_idx * a.S_pad + row0(n), D, lane_id()); };
     // Invariant from here on: dq[.][0, NP) holds half A of the newest gradient, accB its half B still to be masked (mwB).
 
     // one transposed D x D layer at panel pa: consumes the gradient in dq (stashing it to st[]), produces the gradient of the layer
@@ -260,8 +275,10 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         gemm_wide<DT, 2, true, kPh * NU, kPh * PA, 0, kMaskLds ? T : 0>(acce, dq, pipe, p0(B_L5E), st, NNR_SEL_UNIT(accB, NP, mwB));
         gates_fetch(3, true);
 #pragma unroll
-        for (int n = 0; n < kTiles; ++n)
-            gp5[n] = enc_chain<32, 10>([&](int r) { return acce[n][r >> 4][r & 15]; }, pos[n][0], pos[n][1], pos[n][2], half);
+        for (int n = 0; n < kTiles; ++n) {
+            const f32x4 ps = parked(n, 0);
+            gp5[n] = enc_chain<32, 10>([&](int r) { return acce[n][r >> 4][r & 15]; }, ps[0], ps[1], ps[2], (lane_id() >> 5));
+        }
     }
     zero_acc2(accA);
     gemm_wide<DT, HT, stash_tail<DT, 2, T>()>(accA, dq, pipe, p0(B_L5HA));   // (B_L5E's last stash stores may stay in flight)
@@ -289,8 +306,9 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         for (int n = 0; n < kTiles; ++n) {
             const int64_t sn = sample(n);
             const bool live = sn < a.S;
-            const f32x4 gp = enc_chain<32, 10>([&](int r) { return acc2[n][r >> 4][r & 15]; }, pos[n][0], pos[n][1], pos[n][2], half);
-            if (half == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dpts + 4 * sn) = gp + gp5[n];
+            const f32x4 ps = parked(n, 0);
+            const f32x4 gp = enc_chain<32, 10>([&](int r) { return acc2[n][r >> 4][r & 15]; }, ps[0], ps[1], ps[2], (lane_id() >> 5));
+            if ((lane_id() >> 5) == 0 && live) *reinterpret_cast<f32x4*>(a.ws_dpts + 4 * sn) = gp + gp5[n];
         }
     }
     NNR_STAMP(tl_dgrad16, 5);

@@ -71,6 +71,18 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     const int64_t last_chunk = a.S_pad / kChunk - 1;
     pipe.more = n_pass > 1;
     pipe.start();
+    // Ray mode: the wave walks ONE ray through all its passes -- origin, direction and view direction are fetched once, here (wave-uniform:
+    // they live in scalar registers), not once per pass behind the previous pass's stores
+    const int ray_u = (int)blockIdx.x * W + wave_u;
+    float ray_o[3] = {0.f, 0.f, 0.f}, ray_d[3] = {0.f, 0.f, 0.f}, ray_v[3] = {0.f, 0.f, 0.f};
+    if (TRAIN && a.chunks_per_ray > 0) {     // (the inference kernel keeps its composite carry in the registers these would take)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ray_o[c] = a.pts_o[3 * (int64_t)ray_u + c];
+            ray_d[c] = a.pts_d[3 * (int64_t)ray_u + c];
+            ray_v[c] = a.view_d[3 * (int64_t)ray_u + c];
+        }
+    }
     // fused compositing (inference, ray mode): running transmittance and weighted sums of this wave's ray, carried across its chunks
     float cT = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, cz = 0.f, cw = 0.f;
     const bool fuse = !TRAIN && a.fuse_rgb != nullptr;
@@ -81,17 +93,17 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(lane));
     pipe.lane = lane;
-    const int half = lane >> 5;
-    const int col = lane & 31;
-    f32x4* const park = smem + kNBuf * kPanelF4 + wave_u * (6 * T * 64) + lane;
+    f32x4* const park_w = smem + kNBuf * kPanelF4 + wave_u * (6 * T * 64);      // this wave's parking area (uniform); + lane at use
     const float* bias = ltab - L::bias_base;   // index with L::bias_off(layer)
-    const uint32_t* const wsig16 = head16 + half * NQ;
+    auto wsig16_ = [&]() { return head16 + (lane_id() >> 5) * NQ; };
     const int64_t pair = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * W + wave_u) * n_pass + pass
                                                : (int64_t)blockIdx.x * W + wave_u;
     int chunk[kTiles];   // chunk index of either tile (< 2^26: S_pad < 2^31)
 #pragma unroll
-    for (int n = 0; n < kTiles; ++n) chunk[n] = (int)(kTiles * pair + n < last_chunk ? kTiles * pair + n : last_chunk);
-    auto sample = [&](int n) -> int64_t { return (int64_t)opaque(chunk[n]) * kChunk + col; };   // this lane's sample of tile n
+    for (int n = 0; n < kTiles; ++n)      // wave-uniform (block index, wave index, pass counter): lives in scalar registers
+        chunk[n] = __builtin_amdgcn_readfirstlane((int)(kTiles * pair + n < last_chunk ? kTiles * pair + n : last_chunk));
+    auto row0 = [&](int n) -> int64_t { return (int64_t)opaque_uniform(chunk[n]) * kChunk; };   // first sample of tile n: wave-uniform (scalar)
+    auto sample = [&](int n) -> int64_t { return row0(n) + (lane_id() & 31); };                              // this lane's sample of tile n
 
     // (the row dimension of the packed arrays is padded by 4: with rows adjacent in memory hipcc forms a 32-byte access across the
     // row boundary and then leaves those 8 registers in scratch memory)
@@ -112,20 +124,18 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         float zlo[kTiles], zhi[kTiles], jit[kTiles];
         float ro[kTiles][3], rd[kTiles][3];
         if (a.chunks_per_ray > 0) {
-            const int ray_u = (int)blockIdx.x * W + wave_u;
 #pragma unroll
             for (int n = 0; n < kTiles; ++n) {
                 rr[n] = ray_u;
-                jj[n] = (pass * kTiles + n) * kChunk + col;
-            }
-            const float* po = a.pts_o + 3 * (int64_t)ray_u;
-            const float* pd = a.pts_d + 3 * (int64_t)ray_u;
-            const float* pv = a.view_d + 3 * (int64_t)ray_u;
+                jj[n] = (pass * kTiles + n) * kChunk + (lane_id() & 31);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float o = po[c], d = pd[c], v = pv[c];     // uniform addresses: scalar loads
-#pragma unroll
-                for (int n = 0; n < kTiles; ++n) { ro[n][c] = o; rd[n][c] = d; s_v[n][c] = v; }
+                for (int c = 0; c < 3; ++c) {
+                    if constexpr (TRAIN) {
+                        ro[n][c] = ray_o[c]; rd[n][c] = ray_d[c]; s_v[n][c] = ray_v[c];
+                    } else {
+                        ro[n][c] = a.pts_o[3 * (int64_t)ray_u + c]; rd[n][c] = a.pts_d[3 * (int64_t)ray_u + c]; s_v[n][c] = a.view_d[3 * (int64_t)ray_u + c];
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -166,38 +176,38 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         const float z = s_z[n];
         const float px = s_p[n][0], py = s_p[n][1], pz = s_p[n][2];
         const float vx = s_v[n][0], vy = s_v[n][1], vz = s_v[n][2];
-        if (half == 0 && sn < a.S && !fuse) a.ws_z[sn] = z;
+        if ((lane_id() >> 5) == 0 && sn < a.S && !fuse) a.ws_z[sn] = z;
         float e[32];
 #pragma unroll
-        for (int r = 0; r < 32; ++r) e[r] = enc_register(r, half, kPosReal, px, py, pz);
+        for (int r = 0; r < 32; ++r) e[r] = enc_register(r, (lane_id() >> 5), kPosReal, px, py, pz);
 #pragma unroll
         for (int p = 0; p < 16; ++p) eq[n][p] = pack_bf16(e[2 * p], e[2 * p + 1]);
         float dirv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dirv[r] = enc_register(r, half, kDirReal, vx, vy, vz);
+        for (int r = 0; r < 16; ++r) dirv[r] = enc_register(r, (lane_id() >> 5), kDirReal, vx, vy, vz);
         uint32_t dq[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) dq[p] = pack_bf16(dirv[2 * p], dirv[2 * p + 1]);
         // both encodings wait in LDS: the position encoding for the skip layer, the direction encoding for the colour layer
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            park[(6 * n + q) * 64] = __builtin_bit_cast(f32x4, u32x4{eq[n][4 * q], eq[n][4 * q + 1], eq[n][4 * q + 2], eq[n][4 * q + 3]});
+            (park_w + lane_id())[(6 * n + q) * 64] = __builtin_bit_cast(f32x4, u32x4{eq[n][4 * q], eq[n][4 * q + 1], eq[n][4 * q + 2], eq[n][4 * q + 3]});
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-            park[(6 * n + 4 + q) * 64] = __builtin_bit_cast(f32x4, u32x4{dq[4 * q], dq[4 * q + 1], dq[4 * q + 2], dq[4 * q + 3]});
+            (park_w + lane_id())[(6 * n + 4 + q) * 64] = __builtin_bit_cast(f32x4, u32x4{dq[4 * q], dq[4 * q + 1], dq[4 * q + 2], dq[4 * q + 3]});
         if constexpr (TRAIN && !kAblateEncStash) {
             // for the input-gradient kernel: the sample's position and view direction (it recomputes the chain-rule factors of the two
             // encodings from them, nnr_mlp_bf16.h -- 32 bytes per sample instead of 384 of factors), parked in the planes that kernel
             // overwrites with their gradients; for the weight-gradient kernel: tile-major bf16 copies of the encodings = its MFMA operands
-            if (half == 0 && sn < a.S) {
+            if ((lane_id() >> 5) == 0 && sn < a.S) {
                 *reinterpret_cast<f32x4*>(a.ws_pts + 4 * sn) = f32x4{px, py, pz, 0.f};
                 *reinterpret_cast<f32x4*>(a.ws_view + 4 * sn) = f32x4{vx, vy, vz, 0.f};
             }
-            __bf16* e16 = tile_row(a.ws_xe16, sn, kPosPad, half);
+            __bf16* e16 = tile_lane(a.ws_xe16, row0(n), kPosPad, lane_id());
 #pragma unroll
             for (int b = 0; b < 4; ++b)
                 stash_store(e16 + kBlockBf16 * b, u32x4{eq[n][4 * b], eq[n][4 * b + 1], eq[n][4 * b + 2], eq[n][4 * b + 3]});
-            __bf16* f16 = tile_row(a.ws_xf16, sn, kDirPad, half);
+            __bf16* f16 = tile_lane(a.ws_xf16, row0(n), kDirPad, lane_id());
 #pragma unroll
             for (int b = 0; b < 2; ++b) stash_store(f16 + kBlockBf16 * b, u32x4{dq[4 * b], dq[4 * b + 1], dq[4 * b + 2], dq[4 * b + 3]});
         }
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
 
     // accumulators start at the bias (the same for both tiles), so an epilogue is only ReLU + gate bits + pack
     auto init_acc = [&](f32x16(&acc)[kTiles][HT], int bias_offset) __attribute__((always_inline)) {
-        const float* b = bias + bias_offset + 4 * half;
+        const float* b = bias + bias_offset + 4 * (lane_id() >> 5);
 #pragma unroll
         for (int t = 0; t < HT; ++t)
 #pragma unroll
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
             for (int n = 0; n < kTiles; ++n) {
                 // masks: [chunk][layer][lane][mask_words]; half A of a layer owns the low words, half B the high words.  An ordinary
                 // store: the two halves of a lane's 16 bytes arrive from different passes and rely on L2 to merge them into lines.
-                uint32_t* m = a.ws_mask + (((int64_t)opaque(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane) * L::mask_words + hb * HW;
+                uint32_t* m = a.ws_mask + (((int64_t)opaque_uniform(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane_id()) * L::mask_words + hb * HW;
                 if constexpr (HW == 2) {
                     *reinterpret_cast<u32x2*>(m) = u32x2{mw[n][0], mw[n][1]};
                 } else {
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     auto p0 = [&](int part) { return L::fwd_panel0(part); };
     __bf16* const no_stash[kTiles] = {};
     auto xh = [&](int hidden_idx /*0..7*/, int n) -> __bf16* {
-        return TRAIN ? tile_row(a.ws_xh, (int64_t)hidden_idx * a.S_pad + sample(n), D, half) : nullptr;
+        return TRAIN ? tile_lane(a.ws_xh, (int64_t)hidden_idx * a.S_pad + row0(n), D, lane_id()) : nullptr;
     };
     constexpr int NU = kTiles * NP;   // epilogue units of one half-output pass
     constexpr int TAIL = TRAIN ? stash_tail<DT, HT, T>() : 0;
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         for (int n = 0; n < kTiles; ++n)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const u32x4 v = __builtin_bit_cast(u32x4, park[(6 * n + q) * 64]);
+                const u32x4 v = __builtin_bit_cast(u32x4, (park_w + lane_id())[(6 * n + q) * 64]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) eq[n][4 * q + i] = v[i];
             }
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
                 NNR_RELU_UNIT(accB, NP, mwB)(u);
             } else {   // registers 4v .. 4v+3 of h8, both tiles; every register is final by now: the NU finishing units come first
                 const int v = u - kPh * NU;
-                const u32x4 w4 = *reinterpret_cast<const u32x4*>(wsig16 + 4 * v);
+                const u32x4 w4 = *reinterpret_cast<const u32x4*>(wsig16_() + 4 * v);
 #pragma unroll
                 for (int n = 0; n < kTiles; ++n)
 #pragma unroll
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         for (int n = 0; n < kTiles; ++n)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const u32x4 v = __builtin_bit_cast(u32x4, park[(6 * n + 4 + q) * 64]);
+                const u32x4 v = __builtin_bit_cast(u32x4, (park_w + lane_id())[(6 * n + 4 + q) * 64]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dq[n][4 * q + i] = v[i];
             }
@@ -388,18 +398,18 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
     for (int n = 0; n < kTiles; ++n) {
         const int64_t sn = sample(n);
         if constexpr (TRAIN) {   // tile-major bf16 plane: group gq = packed registers 4 gq .. 4 gq + 3
-            __bf16* xg = tile_row(a.ws_xg, sn, D / 2, half);
+            __bf16* xg = tile_lane(a.ws_xg, row0(n), D / 2, lane_id());
 #pragma unroll
             for (int gq = 0; gq < NP / 4; ++gq)
                 stash_store(xg + kBlockBf16 * gq, u32x4{hq[n][4 * gq], hq[n][4 * gq + 1], hq[n][4 * gq + 2], hq[n][4 * gq + 3]});
         }
         const float sgn = dot2_result(sg[n][0]) + dot2_result(sg[n][1]);
-        const float sigma_raw = sgn + __shfl_xor(sgn, 32, 64) + bias[L::bias_off(8)];
+        const float sigma_raw = sum_halves(sgn) + bias[L::bias_off(8)];
         // rgb head: 3 per-lane dot products over the lane's half of g, halves combined by one shuffle, then sigmoid
         float rgbv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const uint32_t* wc = head16 + 2 * NQ + (2 * c + half) * NP;
+            const uint32_t* wc = head16 + 2 * NQ + (2 * c + (lane_id() >> 5)) * NP;
             float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
             for (int q = 0; q < NP / 4; ++q) {
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
                 dot2_bf16(acc1, hq[n][4 * q + 3], w4[3]);
             }
             const float part = dot2_result(acc0) + dot2_result(acc1);
-            rgbv[c] = part + __shfl_xor(part, 32, 64);
+            rgbv[c] = sum_halves(part);
         }
         const float* bo = bias + L::bias_off(11);
         f32x4 o;
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
         o[2] = sigmoid_ref(rgbv[2] + bo[2]);
         o[3] = sigma_raw;
         if (!fuse) {
-            if (half == 0 && sn < a.S) *reinterpret_cast<f32x4*>(a.ws_out4 + 4 * sn) = o;
+            if ((lane_id() >> 5) == 0 && sn < a.S) *reinterpret_cast<f32x4*>(a.ws_out4 + 4 * sn) = o;
         } else if constexpr (!TRAIN) {
             // compositing of this chunk's 32 samples on top of the ray's carry, as in mlp_fwd_kernel (ray mode: sn < S, whole chunks)
             const int ray = (int)(sn / a.N);
@@ -432,16 +442,16 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
                 zn = a.jitter ? __fadd_rn(lo1, __fmul_rn(__fsub_rn(hi1, lo1), a.jitter[sn + 1])) : lo1;
             }
             float unused;
-            const float alpha = half == 0 ? sample_alpha(o[3], jn < a.N ? zn - z : 1e10f, jn == a.N, a.flags, unused) : 0.f;
-            const float incl = wave_scan_mul(half == 0 ? (1.f - alpha) + kEpsT : 1.f, lane);
+            const float alpha = (lane_id() >> 5) == 0 ? sample_alpha(o[3], jn < a.N ? zn - z : 1e10f, jn == a.N, a.flags, unused) : 0.f;
+            const float incl = wave_scan_mul((lane_id() >> 5) == 0 ? (1.f - alpha) + kEpsT : 1.f, lane_id());
             float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.f;
+            if (lane_id() == 0) excl = 1.f;
             const float w = alpha * cT * excl;
             cT *= __shfl(incl, 31, 64);
             cr += w * o[0]; cg += w * o[1]; cb += w * o[2]; cz += w * z; cw += w;
             if (pass + 1 == n_pass && n == kTiles - 1) {
                 const float sr = wave_sum(cr), sg2 = wave_sum(cg), sb = wave_sum(cb), sz = wave_sum(cz), sw = wave_sum(cw);
-                if (lane == 0) {
+                if (lane_id() == 0) {
                     const float bg = (a.flags & kFlagWhiteBg) ? 1.f - sw : 0.f;
                     float* out = a.fuse_rgb + 3 * (int64_t)ray;
                     out[0] = sr + bg; out[1] = sg2 + bg; out[2] = sb + bg;
