@@ -205,10 +205,24 @@ __global__ __launch_bounds__(64) void aux_finish_kernel(AuxArgs a) {
 // bounded by |g_out[0]| / S and a destination collects at most S of them, so the range (+-2^19) is never approached; the
 // resolution is 6e-14, nine orders of magnitude below a term.
 constexpr double kFixScale = 17592186044416.0;   // 2^44
-__device__ __forceinline__ void fix_add(long long* p, float v) {
+// A term that does not fit -- NaN, inf, or so large that S of them could leave the valid range |sum| < 2^18 (a loss-scaled upstream
+// gradient could do that) -- must not wrap into a finite wrong number: it POISONS the accumulator (atomicMin to the most negative
+// value).  Valid sums stay inside |q| < 2^62; a poisoned accumulator stays outside that range whatever in-range terms are added before
+// or after (at most 2^62 in total, wrapping included), fix_get returns NaN for it, and the trainer's NaN check sees the step.
+constexpr long long kFixPoison = (long long)0x8000000000000000ull;
+constexpr long long kFixValid = 1ll << 62;
+__device__ __forceinline__ void fix_add(long long* p, float v, float term_limit /* 2^18 / S */) {
+    if (!(fabsf(v) <= term_limit)) {        // also true for NaN
+        atomicMin(p, kFixPoison);
+        return;
+    }
     atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * kFixScale));
 }
-__device__ __forceinline__ float fix_get(const long long* p) { return (float)((double)*p * (1.0 / kFixScale)); }
+__device__ __forceinline__ float fix_get(const long long* p) {
+    const long long q = *p;
+    if (q <= -kFixValid || q >= kFixValid) return __builtin_nanf("");
+    return (float)((double)q * (1.0 / kFixScale));
+}
 
 // d mean_s dist[s] * coef for the sources [s_lo, s_hi) of this rank, ACCUMULATED: g_src[s] += w (src_s - dst_j), g_dst[j] -= the same
 __global__ void aux_pc_bwd_kernel(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_out, int S,
@@ -222,8 +236,8 @@ __global__ void aux_pc_bwd_kernel(const float* src, const float* dst, const int6
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = w * (src[3 * s + c] - dst[3 * j + c]);
-        fix_add(g_src + 3 * s + c, v);
-        fix_add(g_dst + 3 * j + c, -v);
+        fix_add(g_src + 3 * s + c, v, 262144.f / (float)S);
+        fix_add(g_dst + 3 * j + c, -v, 262144.f / (float)S);
     }
 }
 

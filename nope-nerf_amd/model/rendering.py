@@ -57,6 +57,14 @@ class RenderOutput(dict):
         return self[key] if key in self else default
 
 
+def _forward_only_samples(pts_o, pts_d, view, z_lo, z_hi, jitter, net, kw):
+    """alpha / z_vals of an evaluation render, fetched late.  Under torch.no_grad() whatever the caller's mode is by then: read after the
+    caller's no_grad block has ended, the operator would otherwise see grad-requiring weights and take the TRAINING path (full
+    activation stash, a multi-GB workspace pinned by an autograd node) for two tensors nobody differentiates."""
+    with torch.no_grad():
+        return nnr.render_rays(pts_o, pts_d, view, z_lo, z_hi, jitter, net.weights(), net.biases(), **kw)[2:]
+
+
 class Renderer(nn.Module):
     def __init__(self, model, cfg, device=None, **kwargs):
         super().__init__()
@@ -170,7 +178,7 @@ class Renderer(nn.Module):
         return RenderOutput({
             'rgb': rgb.reshape(batch_size, -1, 3),
             'normal': diff_norm,
-            **({'_samples': lambda: nnr.render_rays(pts_o, pts_d, view, z_lo, z_hi, jitter, net.weights(), net.biases(), **kw)[2:]}
+            **({'_samples': lambda: _forward_only_samples(pts_o, pts_d, view, z_lo, z_hi, jitter, net, kw)}
                if lazy_samples else {'z_vals': z_val, 'alpha': alpha}),
             # dense per-ray values + validity mask; 'depth_pred' / 'depth_gt' (masked) are derived lazily from these
             'dist_dense': dist_pred,

@@ -37,9 +37,12 @@ np.savez(sys.argv[3], imgs=f.imgs, dpt=f.dpt_depth, K=f.K, c2ws=np.asarray(f.c2w
 ''' % (FRAMES, SIZE, SEED_SCENE, R, N, D)
 
 
-def main(threads=8, replay=None, out_name="conv_llff.npz"):
+def main(threads=8, replay=None, out_name="conv_llff.npz", epochs=EPOCHS, phase=None):
     """threads / replay: the chaos envelope (see envelope()) -- the same reference run with another GEMM thread count, fed the frames
-    and pixel permutations the golden run drew (`replay` = the golden blob)."""
+    and pixel permutations the golden run drew (`replay` = the golden blob).
+    phase = (scheduling_start, annealing_epochs): the TWO-PHASE run -- what train.py's PSNR-plateau scheduler (train.py:309-340) does once
+    it fires at epoch `scheduling_start`: model/training.py:187-217 anneals pc / rgb_s / depth weights to their end values over
+    `annealing_epochs` epochs and switches the rgb term from L1 to L2 afterwards."""
     with tempfile.TemporaryDirectory() as tmp:
         # the scene goes through THIS repository's loader (pinned bit-exact against the reference's DataField: tests/test_dataloading.py)
         # in a separate process: `model` / `dataloading` of the reference are imported below under the same names
@@ -55,6 +58,10 @@ def main(threads=8, replay=None, out_name="conv_llff.npz"):
     torch.set_num_threads(threads)
     cfg = copy.deepcopy(gg.base_cfg(D))
     cfg["training"].update(n_training_points=R, pc_weight=[1.0, 0.0], rgb_s_weight=[1.0, 0.0], vis_reprojection_every=10 ** 9)
+    sched_start = 10 ** 6
+    if phase is not None:
+        sched_start = int(phase[0])
+        cfg["training"]["annealing_epochs"] = int(phase[1])
     cfg["rendering"].update(num_points=N, sample_option="ndc", dist_alpha=True, depth_range=[0.0, 1.0])
     dev = torch.device("cpu")
     np.random.seed(42)
@@ -98,7 +105,7 @@ def main(threads=8, replay=None, out_name="conv_llff.npz"):
     torch.randperm = randperm
     try:
         it = 0          # train.py starts at -1 + 1 = 0, where the first step also dumps the re-projection PNGs (it % vis_reprojection_every): start at 1
-        for epoch in range(EPOCHS):
+        for epoch in range(epochs):
             l2 = []
             cams = real_randperm(FRAMES).tolist() if replay is None else [int(c) for c, _ in replay["order"][epoch * FRAMES:(epoch + 1) * FRAMES]]
             for cam in cams:                                        # the shuffled DataLoader of train.py:35
@@ -106,12 +113,12 @@ def main(threads=8, replay=None, out_name="conv_llff.npz"):
                 nb = int(refs[cam])
                 data = {"img": imgs[cam:cam + 1], "img.idx": cam, "img.dpt": dpt[cam:cam + 1], "img.camera_mat": Kt,
                         "img.scale_mat": eye, "img.ref_imgs": imgs[nb:nb + 1], "img.ref_dpts": dpt[nb:nb + 1], "img.ref_idxs": nb}
-                ld = tr.train_step(data, it, epoch, 10 ** 6, None)
+                ld = tr.train_step(data, it, epoch, sched_start, None)
                 order.append((cam, nb))
                 picks.append(drawn["perm"][:R].numpy().astype(np.int16))
                 losses.append([float(ld[k]) for k in LOGGED])
                 l2.append(float(ld["l2_mean"]))
-            if epoch % 10 == 0 or epoch == EPOCHS - 1:
+            if epoch % 10 == 0 or epoch == epochs - 1:
                 curve.append((epoch, float(mse2psnr(np.mean(l2)))) + pose_errors())
                 print("epoch %3d  PSNR %.2f dB  ATE %.4f  RPE_t %.3f  RPE_r %.3f deg" % curve[-1])
     finally:
@@ -120,7 +127,8 @@ def main(threads=8, replay=None, out_name="conv_llff.npz"):
             "logged": np.array(LOGGED), "curve": np.array(curve, dtype=np.float64),
             "init.pose_r": init_r, "init.pose_t": init_t, "final.pose_r": pose.r.detach().numpy(), "final.pose_t": pose.t.detach().numpy(),
             "final.scales": dist.global_scales.detach().numpy(), "final.shifts": dist.global_shifts.detach().numpy(),
-            "cfg": np.array([FRAMES, SIZE[0], SIZE[1], SEED_SCENE, R, N, D, EPOCHS])}
+            "cfg": np.array([FRAMES, SIZE[0], SIZE[1], SEED_SCENE, R, N, D, epochs]),
+            "phase": np.array([sched_start, cfg["training"]["annealing_epochs"]])}
     if out_name is None:
         return blob
     out = os.path.join(gg.OUT, out_name)
@@ -129,28 +137,36 @@ def main(threads=8, replay=None, out_name="conv_llff.npz"):
     return blob
 
 
-def envelope(thread_counts=(1, 2, 3, 4, 5, 6, 7)):
+def envelope(thread_counts=(1, 2, 3, 4, 5, 6, 7), name="conv_llff", **kw):
     """How far apart do two runs of the REFERENCE ITSELF end?  Training is a chaotic map: another summation order inside the CPU GEMMs
     (another thread count) changes last bits, Adam amplifies them, and after 800 steps the two runs are two samples of the same
     distribution.  Each variant replays the golden run's frames and pixel picks; recorded per variant: final PSNR / ATE / RPE and the
     deviation of the loss curve from the golden run, in the very statistics tests/test_conv_reference.py asserts.  The test's
     statistical tolerances are tied to this spread (tests/golden/conv_llff_envelope.npz)."""
-    gold = dict(np.load(os.path.join(gg.OUT, "conv_llff.npz")))
+    gold = dict(np.load(os.path.join(gg.OUT, name + ".npz")))
     k = list(gold["logged"]).index("loss")
     smooth = lambda x: np.convolve(x, np.ones(40) / 40, mode="valid")
     rows = []
     for t in thread_counts:
-        b = main(threads=t, replay=gold, out_name=None)
+        b = main(threads=t, replay=gold, out_name=None, **kw)
         dev = np.abs(b["losses"] - gold["losses"]) / np.maximum(1.0, np.abs(gold["losses"]))
         curve = float(np.abs(smooth(b["losses"][:, k]) - smooth(gold["losses"][:, k])).max() / smooth(gold["losses"][:, k]).max())
         _, psnr, ate, rpe_t, rpe_r = b["curve"][-1]
         rows.append((t, psnr, ate, rpe_t, rpe_r, float(dev[:20].max()), float(dev[:50].max()), curve))
         print("threads %d: PSNR %.3f ATE %.4f RPE_r %.3f; first-20 dev %.2e, first-50 %.2e, smoothed curve %.2e" % (t, psnr, ate, rpe_r, rows[-1][5], rows[-1][6], curve))
-    out = os.path.join(gg.OUT, "conv_llff_envelope.npz")
+    out = os.path.join(gg.OUT, name + "_envelope.npz")
     np.savez_compressed(out, runs=np.array(rows, dtype=np.float64), golden_final=gold["curve"][-1],
                         columns=np.array(["threads", "psnr", "ate", "rpe_t", "rpe_r", "dev_first20", "dev_first50", "curve_dev"]))
     print("wrote", out)
 
 
+TWO_PHASE = dict(epochs=110, phase=(40, 20))     # switch at epoch 40, annealed by 60, L2 from 60 on, 50 more epochs = 400 steps beyond
+
 if __name__ == "__main__":
-    envelope() if "--envelope" in sys.argv else main()
+    if "--two-phase" in sys.argv:       # tests/golden/conv_llff_2phase.npz + its reference-vs-reference envelope
+        main(out_name="conv_llff_2phase.npz", **TWO_PHASE)
+        envelope((1, 3, 5, 7), name="conv_llff_2phase", **TWO_PHASE)
+    elif "--envelope" in sys.argv:
+        envelope()
+    else:
+        main()

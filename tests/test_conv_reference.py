@@ -28,13 +28,18 @@ FRAMES, H, W, SEED_SCENE, R, N, D, EPOCHS = (int(x) for x in GOLD["cfg"])
 LOGGED = [str(k) for k in GOLD["logged"]]
 
 
-def _replay(tmp_path, dev, monkeypatch, n_steps):
+def _replay(tmp_path, dev, monkeypatch, n_steps, gold=None, sched=10 ** 6, annealing=None, bf16=False):
+    GOLD = gold if gold is not None else globals()["GOLD"]
     import scene_writer
     import train_scene
     import dataloading as dl
     from model.common import mse2psnr
     scene_writer.write_scene(str(tmp_path), scene="toy", frames=FRAMES, size=(H, W), seed=SEED_SCENE)
     cfg = train_scene.scene_cfg(str(tmp_path), "toy", style="llff", n_rays=R, n_samples=N, hidden=D, resident=False, sample_rate=10 ** 6)
+    if annealing is not None:
+        cfg["training"]["annealing_epochs"] = int(annealing)
+    if bf16:
+        cfg["rendering"]["mfma_dtype"] = "bf16"
     _, fields = dl.get_dataloader(cfg, mode="train", shuffle=True)
     f = fields["img"]
     np.random.seed(42)
@@ -55,7 +60,7 @@ def _replay(tmp_path, dev, monkeypatch, n_steps):
         monkeypatch.setattr(torch, "randperm", lambda n, device=None, **kw: torch.cat([ray_idx, torch.zeros(n - R, dtype=torch.int64)]).to(device))
         data = {"img": imgs[cam:cam + 1], "img.idx": cam, "img.dpt": dpt[cam:cam + 1], "img.camera_mat": K, "img.scale_mat": eye,
                 "img.ref_imgs": imgs[nb:nb + 1], "img.ref_dpts": dpt[nb:nb + 1], "img.ref_idxs": nb}
-        ld = trainer.train_step(data, s + 1, s // FRAMES, 10 ** 6, None)
+        ld = trainer.train_step(data, s + 1, s // FRAMES, sched, None)
         losses.append(torch.stack([ld[k].detach().float().reshape(()) for k in LOGGED]))
     trainer.flush_nan_check()
     losses = torch.stack(losses).cpu().numpy().astype(np.float64)
@@ -93,7 +98,7 @@ def test_hip_training_run_tracks_the_reference_run(tmp_path, monkeypatch):
     # thread count (another summation order: last bits).  Between those runs and the golden one: final PSNR 20.20 .. 20.38 dB, ATE
     # 0.0710 .. 0.0758, RPE_r 3.89 .. 4.04 deg, first-50-steps deviation up to 9.1e-3, smoothed curve up to 9.7e-3.  An implementation
     # that IS the reference cannot be asked for more than the reference delivers against itself: the run must land inside that
-    # spread widened by half its width (PSNR: +- 0.1 dB beyond the extremes; errors: +- 5 %), early / curve deviations within 1.5x
+    # spread widened by its own width (PSNR: 20.02 .. 20.56 dB; errors: +- 5 %), early / curve deviations within 1.5x
     # the worst reference-vs-reference value.  The first 20 steps, before chaos sets in, stay at the tight 2e-4.
     env = np.load(os.path.join(HERE, "golden", "conv_llff_envelope.npz"))
     col = {str(c): i for i, c in enumerate(env["columns"])}
@@ -107,7 +112,75 @@ def test_hip_training_run_tracks_the_reference_run(tmp_path, monkeypatch):
     assert first20 <= 2e-4, first20
     assert early <= max(5e-3, 1.5 * runs[:, col["dev_first50"]].max()), early
     assert curve_dev <= max(2e-2, 1.5 * runs[:, col["curve_dev"]].max()), curve_dev
-    half = 0.5 * (psnrs.max() - psnrs.min())
-    assert psnrs.min() - half <= psnr <= psnrs.max() + half, (psnr, psnrs.min(), psnrs.max())
+    width = psnrs.max() - psnrs.min()
+    assert psnrs.min() - width <= psnr <= psnrs.max() + width, (psnr, psnrs.min(), psnrs.max())
     assert 0.95 * ates.min() <= errs["ate"] <= 1.05 * ates.max(), (errs["ate"], ates.min(), ates.max())
     assert 0.95 * rpes.min() <= errs["rpe_rot_deg"] <= 1.05 * rpes.max(), (errs["rpe_rot_deg"], rpes.min(), rpes.max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the TWO-PHASE run: across the schedule switch of train.py:309-340 / model/training.py:187-217
+# ---------------------------------------------------------------------------------------------------------------------------------
+GOLD2_PATH = os.path.join(HERE, "golden", "conv_llff_2phase.npz")
+two_phase = pytest.mark.skipif(not os.path.exists(GOLD2_PATH), reason="tests/golden/conv_llff_2phase.npz not generated")
+
+
+def _two_phase(tmp_path, monkeypatch, dev, bf16=False, steps=None):
+    gold = np.load(GOLD2_PATH)
+    sched, annealing = (int(x) for x in gold["phase"])
+    n = steps or len(gold["order"])
+    losses, psnr, errs, _, _ = _replay(tmp_path, dev, monkeypatch, n, gold=gold, sched=sched, annealing=annealing, bf16=bf16)
+    return gold, losses, psnr, errs, sched, annealing
+
+
+@two_phase
+def test_two_phase_run_first_steps_and_the_switch_on_the_cpu_stand_in(tmp_path, monkeypatch):
+    """The weights the trainer applies, step by step, across the switch: replayed on the CPU stand-in only as far as the first phase
+    stays tight (24 steps), plus the logged weights' effect at the switch itself checked on the HIP run below."""
+    import oracle_backend
+    from model import rendering
+    monkeypatch.setattr(rendering.nnr, "render_rays", oracle_backend.render_rays)
+    gold, losses, _, _, _, _ = _two_phase(tmp_path, monkeypatch, torch.device("cpu"), steps=24)
+    ref = gold["losses"][:24]
+    assert np.abs(losses - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@two_phase
+@pytest.mark.parametrize("bf16", [False, True])
+def test_hip_two_phase_run_tracks_the_reference_across_the_schedule_switch(tmp_path, monkeypatch, bf16):
+    """880 steps: first phase (point-cloud + surface re-projection terms at weight 1, depth 0.04, rgb L1), the annealing window
+    (epochs 40 .. 60: pc / rgb_s / depth weights fall linearly to 0), then 400 steps of the second phase (rgb L2 only -- the per-image
+    block is off, so the trainer takes the fused front end and the headline configuration's kernels).  fp32: the loss curve must track
+    the reference's inside the reference's own run-to-run spread, the terms must vanish exactly where the reference's do, and the run
+    must end at the reference's PSNR / pose error.  bf16 products: the same replay, one-sided (no worse than the reference's spread
+    allows: PSNR above the envelope's lower bound minus its width, pose error below the upper bound plus 10 %)."""
+    gold, losses, psnr, errs, sched, annealing = _two_phase(tmp_path, monkeypatch, torch.device("cuda"), bf16=bf16)
+    ref = gold["losses"]
+    k_loss, k_pc, k_rgbs, k_dep = (LOGGED.index(k) for k in ("loss", "loss_pc", "loss_rgb_s", "loss_depth"))
+    after = (sched + annealing) * FRAMES                     # first step of the second phase
+    # the per-image terms are reported as exact zeros once their weights are 0, exactly where the reference reports zeros
+    assert np.array_equal(losses[:, k_pc] == 0.0, ref[:, k_pc] == 0.0) and np.array_equal(losses[:, k_rgbs] == 0.0, ref[:, k_rgbs] == 0.0)
+    assert np.array_equal(losses[:, k_dep] == 0.0, ref[:, k_dep] == 0.0)
+    assert (ref[after:, k_pc] == 0.0).all() and (ref[:after - annealing * FRAMES, k_pc] != 0.0).all()
+    env = np.load(os.path.join(HERE, "golden", "conv_llff_2phase_envelope.npz"))
+    col = {str(c): i for i, c in enumerate(env["columns"])}
+    runs = env["runs"]
+    _, ref_psnr, ref_ate, _, ref_rpe_r = gold["curve"][-1]
+    psnrs, ates, rpes = np.append(runs[:, col["psnr"]], ref_psnr), np.append(runs[:, col["ate"]], ref_ate), np.append(runs[:, col["rpe_r"]], ref_rpe_r)
+    dev = np.abs(losses - ref) / np.maximum(1.0, np.abs(ref))
+    smooth = lambda x: np.convolve(x, np.ones(40) / 40, mode="valid")
+    curve_dev = float(np.abs(smooth(losses[:, k_loss]) - smooth(ref[:, k_loss])).max() / smooth(ref[:, k_loss]).max())
+    width = psnrs.max() - psnrs.min()
+    print("%s two-phase replay, %d steps (switch at step %d, second phase from %d): first-20 dev %.2e, smoothed curve %.2e (reference vs itself "
+          "<= %.2e); final PSNR %.2f dB (reference runs %.2f .. %.2f), ATE %.4f (%.4f .. %.4f), RPE_r %.2f deg (%.2f .. %.2f)"
+          % ("bf16" if bf16 else "fp32", len(ref), sched * FRAMES, after, dev[:20].max(), curve_dev, runs[:, col["curve_dev"]].max(), psnr,
+             psnrs.min(), psnrs.max(), errs["ate"], ates.min(), ates.max(), errs["rpe_rot_deg"], rpes.min(), rpes.max()))
+    if not bf16:
+        assert dev[:20].max() <= 2e-4
+        assert curve_dev <= max(2e-2, 1.5 * runs[:, col["curve_dev"]].max())
+        assert psnrs.min() - width <= psnr <= psnrs.max() + width
+        assert 0.95 * ates.min() <= errs["ate"] <= 1.05 * ates.max() and 0.95 * rpes.min() <= errs["rpe_rot_deg"] <= 1.05 * rpes.max()
+    else:
+        assert psnr >= psnrs.min() - width
+        assert errs["ate"] <= 1.1 * ates.max() and errs["rpe_rot_deg"] <= 1.1 * rpes.max()
