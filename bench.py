@@ -120,7 +120,8 @@ def build_trainer(device, world, aux=False, bf16=False, rays_per_gpu=None, n_sam
     return trainer, net
 
 
-_TRAFFIC_FILES = ('profiles/r02/hbm_traffic.json', 'profiles/r02/hbm_traffic_bf16_4096x128.json')
+_TRAFFIC_FILES = ('profiles/r03/hbm_traffic.json', 'profiles/r03/hbm_traffic_bf16_4096x128.json',
+                  'profiles/r02/hbm_traffic.json', 'profiles/r02/hbm_traffic_bf16_4096x128.json')
 _KERNEL_KEYS = {
     False: {'mlp_fwd': 'mlp_fwd_kernel<256, true>', 'mlp_dgrad': 'mlp_dgrad_kernel<256>', 'mlp_wgrad': 'nnr::wgrad_kernel('},
     True: {'mlp_fwd': 'mlp_fwd_bf16_kernel<256, true,', 'mlp_dgrad': 'mlp_dgrad_bf16_kernel<256,', 'mlp_wgrad': 'wgrad_b_kernel'},
@@ -230,6 +231,8 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
         dom = max(byts, key=lambda k: times[k])
         for k in byts:
             per[k]['gbytes_per_s'] = round(gbs[k], 1)
+            per[k]['bytes_per_sample'] = byts[k]
+            per[k]['frac_of_hbm_peak'] = round(gbs[k] / PEAK_HBM_GBS, 4)      # every kernel against ITS bound, not only the dominant one
         traffic, src = _hbm_traffic(dom, True, (R, N))
         three['frac_of_bf16_mfma_peak'] = round(three['tflops'] / PEAK_BF16_MFMA_TFLOPS, 4)
         three['gbytes_per_s'] = round(sum(byts.values()) * R * N / (mlp_ms * 1e-3) / 1e9, 1)
@@ -248,9 +251,18 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
 
 
 def bf16_bytes_per_sample(D):
-    act = (8 * D + D // 2) * 2
-    enc, masks, four = (64 + 32) * 4, 9 * 2 * (D // 64) * 4, 16
-    return {'mlp_fwd': act + enc + masks + four + 4, 'mlp_dgrad': act + masks + four + enc + 2 * four, 'mlp_wgrad': 2 * act + enc + four}
+    """Algorithmic HBM bytes per sample of the three bf16-mode kernels = the planes each one writes / reads exactly once (DESIGN.md
+    section 4.2, round 3): hidden activations h1..h8 (8 D) and the colour-hidden layer g (D / 2) as bf16; their gradients likewise, the
+    colour gradient with one extra 16-wide group (the output gradients as bf16); bf16 copies of the two encodings (64 + 32); ReLU gates
+    1 bit per activation (9 layers x D / 8 bytes); (rgb, sigma) 16 B, z 4 B, jitter 4 B; position + view direction 2 x 16 B (what the
+    input-gradient kernel recomputes the chain-rule factors from: the 384 B of fp32 factor planes of round 2 are gone); d point + d
+    view 2 x 16 B."""
+    h, g, dg = 8 * D * 2, (D // 2) * 2, (D // 2 + 16) * 2
+    enc16, gates = (64 + 32) * 2, 9 * D // 8
+    fwd = h + g + enc16 + gates + 16 + 4 + 32 + 4
+    dgrad = h + dg + 32 + gates + 16 + 32
+    wgrad = 2 * h + g + dg + enc16
+    return {'mlp_fwd': fwd, 'mlp_dgrad': dgrad, 'mlp_wgrad': wgrad}
 
 
 def _host_cpu():

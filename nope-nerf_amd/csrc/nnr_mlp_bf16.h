@@ -171,6 +171,56 @@ __device__ __forceinline__ uint32_t pack_gated(float x0, float x1, uint32_t word
     return d;
 }
 
+// ---- PAIRED epilogue units ---------------------------------------------------------------------------------------------------------
+// HYPOTHESIS (round 3): the epilogue of a value pair is a DEPENDENT chain (convert -> relu -> gate bits -> append), and with one wave per
+// SIMD nothing else issues between two links -- the side work of a pass (6 instructions per pair) costs 0.19 ms of the 0.76 ms
+// training forward, ~8 cycles per instruction where an independent instruction issues in 4.  The two tiles of a wave are independent, so the units of
+// the same packed register of tile 0 and tile 1 are issued TOGETHER, link by link -- every instruction then depends on the one two
+// back, not on its predecessor -- and in two phases that go to different MFMA gaps (six instructions each): phase 0 = the four
+// accumulator reads + the two converts, phase 1 = everything else.
+__device__ __forceinline__ void pack2(uint32_t& h0, uint32_t& h1, float x00, float x01, float x10, float x11) {
+    asm("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5" : "=&v"(h0), "=&v"(h1) : "v"(x00), "v"(x01), "v"(x10), "v"(x11));
+}
+__device__ __forceinline__ void relu_gate2(uint32_t& h0, uint32_t& h1, uint32_t& w0, uint32_t& w1) {      // forward, training
+    uint32_t t0, t1;
+    asm("v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\tv_pk_min_u16 %4, %0, %6\n\tv_pk_min_u16 %5, %1, %6\n\t"
+        "v_lshl_or_b32 %2, %2, 1, %4\n\tv_lshl_or_b32 %3, %3, 1, %5"
+        : "+v"(h0), "+v"(h1), "+v"(w0), "+v"(w1), "=&v"(t0), "=&v"(t1)
+        : "s"(0x00010001u));
+}
+__device__ __forceinline__ void relu2(uint32_t& h0, uint32_t& h1) {                                         // forward, inference
+    asm("v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0" : "+v"(h0), "+v"(h1));
+}
+template <int J>
+__device__ __forceinline__ void gate2(uint32_t& d0, uint32_t& d1, uint32_t w0, uint32_t w1) {             // input gradient: AND with pair J's gates
+    uint32_t m0, m1;
+    if constexpr (J == 0)
+        asm("v_pk_ashrrev_i16 %2, %6, %4\n\tv_pk_ashrrev_i16 %3, %6, %5\n\tv_and_b32 %0, %0, %2\n\tv_and_b32 %1, %1, %3"
+            : "+v"(d0), "+v"(d1), "=&v"(m0), "=&v"(m1)
+            : "v"(w0), "v"(w1), "s"(0x000f000fu));
+    else
+        asm("v_lshlrev_b32 %2, %7, %4\n\tv_lshlrev_b32 %3, %7, %5\n\tv_pk_ashrrev_i16 %2, %6, %2\n\tv_pk_ashrrev_i16 %3, %6, %3\n\t"
+            "v_and_b32 %0, %0, %2\n\tv_and_b32 %1, %1, %3"
+            : "+v"(d0), "+v"(d1), "=&v"(m0), "=&v"(m1)
+            : "v"(w0), "v"(w1), "s"(0x000f000fu), "n"(J));
+}
+__device__ __forceinline__ void gate2_at(uint32_t& d0, uint32_t& d1, uint32_t w0, uint32_t w1, int j) {   // j folds after unrolling
+    switch (j) {
+#define NNR_G2_CASE(J) case J: gate2<J>(d0, d1, w0, w1); break;
+        NNR_G2_CASE(0) NNR_G2_CASE(1) NNR_G2_CASE(2) NNR_G2_CASE(3) NNR_G2_CASE(4) NNR_G2_CASE(5) NNR_G2_CASE(6) NNR_G2_CASE(7)
+        NNR_G2_CASE(8) NNR_G2_CASE(9) NNR_G2_CASE(10) NNR_G2_CASE(11) NNR_G2_CASE(12) NNR_G2_CASE(13) NNR_G2_CASE(14)
+#undef NNR_G2_CASE
+        default: gate2<15>(d0, d1, w0, w1); break;
+    }
+}
+// MEASURED (profiles/r03/i_pairs_ab.txt, 4096 x 128): forward 0.771 / 0.775 ms paired vs 0.745 / 0.776 unpaired, input gradient 0.601 /
+// 0.611 vs 0.602 / 0.610 -- no difference beyond the box's run-to-run spread.  The dependent chain is NOT what makes the side work
+// expensive; the product keeps the one-statement-per-pair units and this form stays behind -DNNR_UNIT_PAIRS=1 as a recorded negative.
+#ifndef NNR_UNIT_PAIRS
+#define NNR_UNIT_PAIRS 0
+#endif
+constexpr bool kPairs = NNR_UNIT_PAIRS != 0;
+
 __device__ __forceinline__ uint32_t sel_pair(float x0, float x1, uint32_t word, int j) {   // j folds after unrolling
     switch (j) {
 #define NNR_SEL_CASE(J) case J: return pack_gated<J>(x0, x1, word);

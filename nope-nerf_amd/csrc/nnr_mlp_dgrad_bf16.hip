@@ -154,6 +154,16 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
 // (the gates of a pair as the AND mask of the packed pair: shift, smear, and -- gate_mask, nnr_mlp_bf16.h)
 #define NNR_SEL_UNIT(ACC, OFF, MW)                                                                           \
     [&](int uu) __attribute__((always_inline)) {                                                             \
+        if constexpr (kPairs && T == 2 && kPh == 1 && !kSplitAsm) {                                          \
+            /* paired units (nnr_mlp_bf16.h): call 2 p = phase 0, 2 p + 1 = phase 1 of packed register p of BOTH tiles */ \
+            const int p = uu / 2, ph = uu % 2;                                                               \
+            if (ph == 0) {                                                                                   \
+                pack2(dq[0][(OFF) + p], dq[1][(OFF) + p], ACC[0][(2 * p) >> 4][(2 * p) & 15], ACC[0][(2 * p + 1) >> 4][(2 * p + 1) & 15], \
+                      ACC[1][(2 * p) >> 4][(2 * p) & 15], ACC[1][(2 * p + 1) >> 4][(2 * p + 1) & 15]);      \
+            } else {                                                                                         \
+                gate2_at(dq[0][(OFF) + p], dq[1][(OFF) + p], MW[0][p >> 4], MW[1][p >> 4], p & 15);          \
+            }                                                                                                \
+        } else {                                                                                             \
         const int u = uu / kPh, ph = uu % kPh;                                                               \
         const int n = u % T, p = u / T;                                                                      \
         const float x0 = ACC[n][(2 * p) >> 4][(2 * p) & 15], x1 = ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]; \
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
         } else {                                                                                             \
             if (kPh == 1 || ph == 0) dq[n][(OFF) + p] = pack_bf16(x0, x1);                                   \
             if (kPh == 1 || ph == 1) dq[n][(OFF) + p] &= gate_mask(MW[n][p >> 4], p & 15);                   \
+        }                                                                                                    \
         }                                                                                                    \
     }
     __bf16* const no_stash[kTiles] = {};

@@ -256,6 +256,18 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
 // With kPh = 2 a unit is issued as two half-units (index 2 u: read + pack, 2 u + 1: ReLU + gates) in different gaps between MFMAs.
 #define NNR_RELU_UNIT(ACC, OFF, MW)                                                                          \
     [&](int uu) __attribute__((always_inline)) {                                                             \
+        if constexpr (kPairs && T == 2 && kPh == 1 && !kSplitAsm) {                                          \
+            /* paired units (nnr_mlp_bf16.h): call 2 p = phase 0, 2 p + 1 = phase 1 of packed register p of BOTH tiles */ \
+            const int p = uu / 2, ph = uu % 2;                                                               \
+            if (ph == 0) {                                                                                   \
+                pack2(hq[0][(OFF) + p], hq[1][(OFF) + p], ACC[0][(2 * p) >> 4][(2 * p) & 15], ACC[0][(2 * p + 1) >> 4][(2 * p + 1) & 15], \
+                      ACC[1][(2 * p) >> 4][(2 * p) & 15], ACC[1][(2 * p + 1) >> 4][(2 * p + 1) & 15]);      \
+            } else if (TRAIN && !kAblateMask) {                                                              \
+                relu_gate2(hq[0][(OFF) + p], hq[1][(OFF) + p], MW[0][p >> 4], MW[1][p >> 4]);                \
+            } else {                                                                                         \
+                relu2(hq[0][(OFF) + p], hq[1][(OFF) + p]);                                                   \
+            }                                                                                                \
+        } else {                                                                                             \
         const int u = uu / kPh, ph = uu % kPh;                                                               \
         const int n = u % T, p = u / T;                                                                      \
         const float x0 = ACC[n][(2 * p) >> 4][(2 * p) & 15], x1 = ACC[n][(2 * p + 1) >> 4][(2 * p + 1) & 15]; \
@@ -268,6 +280,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fwd_bf16_kernel(MlpFwdArgs a) {
                 hq[n][(OFF) + p] = relu_bf16x2(hq[n][(OFF) + p]);   /* rounding keeps the sign: relu commutes with it */ \
                 if (TRAIN && !kAblateMask) MW[n][p >> 4] = gate_append(MW[n][p >> 4], hq[n][(OFF) + p]);     \
             }                                                                                                \
+        }                                                                                                    \
         }                                                                                                    \
     }
     auto p0 = [&](int part) { return L::fwd_panel0(part); };

@@ -180,7 +180,8 @@ def test_hip_two_phase_run_tracks_the_reference_across_the_schedule_switch(tmp_p
         assert dev[:20].max() <= 2e-4
         assert curve_dev <= max(2e-2, 1.5 * runs[:, col["curve_dev"]].max())
         assert psnrs.min() - width <= psnr <= psnrs.max() + width
-        assert 0.95 * ates.min() <= errs["ate"] <= 1.05 * ates.max() and 0.95 * rpes.min() <= errs["rpe_rot_deg"] <= 1.05 * rpes.max()
+        # pose errors: no worse than the reference's worst run + 5 %; a LOWER error than the reference's best is not a failure (sanity floor 0.8x)
+        assert 0.8 * ates.min() <= errs["ate"] <= 1.05 * ates.max() and 0.8 * rpes.min() <= errs["rpe_rot_deg"] <= 1.05 * rpes.max()
     else:
         assert psnr >= psnrs.min() - width
         assert errs["ate"] <= 1.1 * ates.max() and errs["rpe_rot_deg"] <= 1.1 * rpes.max()
