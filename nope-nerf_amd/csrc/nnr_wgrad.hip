@@ -188,17 +188,39 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
 // dW[tile] = sum over the tile's splits of their partial slots (every weight belongs to exactly one tile: a plain store, the caller's
 // buffer needs no zero-fill); d(bias) += its share onto the zeros the main kernel wrote (at most two shares per row: a + b == b + a,
 // the result does not depend on their order).  Blocks of jobs that are not split 0 of their tile exit at once; split 0 walks the chain.
+constexpr int kMaxChain = 256;   // splits of one tile (the plan builder cuts a tile's sample range into far fewer)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
     const int ji = blockIdx.x >> 4;   // 16 blocks x 256 threads x one float4 = a 128 x 128 tile
     const WgradJob jb = a.jobs[ji];
     if (jb.split != 0) return;
+    // the tile's chain of splits, walked ONCE per block into LDS: with every thread walking it, each partial slot was fetched behind a
+    // dependent load of the job table (two serialised L2 round trips per split); now the slot loads of all splits are independent
+    // (27.8 -> 24.5 us at 1024 x 192)
+    __shared__ int chain[kMaxChain];
+    __shared__ int n_chain;
+    if (threadIdx.x == 0) {
+        int n = 0, j = ji;
+        for (; j >= 0 && n < kMaxChain; j = a.jobs[j].next_split) chain[n++] = j - ji;
+        if (j >= 0) __builtin_trap();      // a longer chain than the plan builder can produce: never sum a truncated one
+        n_chain = n;
+    }
+    __syncthreads();
+    const int n = n_chain;
     const int t = (blockIdx.x & 15) * 256 + threadIdx.x;
     const int pitch = 32 * jb.NI, f4_per_row = 8 * jb.NI;
     const int row = t / f4_per_row, c0 = 4 * (t - row * f4_per_row);
     if (row < 32 * jb.MI && row < jb.d_valid && jb.row0 + row < jb.rows_real) {
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         const float* src = a.slots + (int64_t)ji * kSlotFloats + row * pitch + c0;
-        for (int j = ji; j >= 0; j = a.jobs[j].next_split) sum += *reinterpret_cast<const f32x4*>(src + (int64_t)(j - ji) * kSlotFloats);
+        int s = 0;
+        for (; s + 4 <= n; s += 4) {      // four slots in flight, added in chain (= sample) order
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)chain[s + u] * kSlotFloats);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sum += v[u];
+        }
+        for (; s < n; ++s) sum += *reinterpret_cast<const f32x4*>(src + (int64_t)chain[s] * kSlotFloats);
         float* dst = a.gw[jb.layer] + (int64_t)(jb.row0 + row) * jb.ldw + jb.wcol0 + c0;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -209,8 +231,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
         if (r < jb.d_valid && jb.row0 + r < jb.rows_real) {
             float sum = 0.f;
             const float* src = a.slots + (int64_t)ji * kSlotFloats + kSlotTile + r;
-            for (int j = ji; j >= 0; j = a.jobs[j].next_split) {
-                const float* p = src + (int64_t)(j - ji) * kSlotFloats;
+            for (int s = 0; s < n; ++s) {
+                const float* p = src + (int64_t)chain[s] * kSlotFloats;
                 sum += p[0] + p[32 * jb.MI];
             }
             atomicAdd(a.gb[jb.layer] + jb.row0 + r, sum);   // two tiles of a row block may each hold a share
