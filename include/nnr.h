@@ -189,8 +189,9 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
                      int32_t n_dst, float* g_src, float* g_dst, void* stream);
 
 /* Per-image losses between a frame ("1") and its neighbour ("2"), fused (SURVEY 8 f1 + f2): the inputs of reference
- * model/training.py:315-358 and the point-cloud / surface re-projection losses of model/losses.py:114-157 (with_ssim off)
- * and their backward.  d1_img/d2_img (hd,wd): the scaled+shifted depth maps; img1r/img2r (3,hr,wr): the images resized
+ * model/training.py:315-358 and the point-cloud / surface re-projection losses of model/losses.py:114-157 (with_ssim
+ * through NNR_AUX_SSIM: the reference's SSIM module, losses.py:222-252, applied as the reference applies it, to the
+ * (1, hr, wr, 3) colour tensors) and their backward.  d1_img/d2_img (hd,wd): the scaled+shifted depth maps; img1r/img2r (3,hr,wr): the images resized
  * (bilinear) to the sampling grid hr = hd/pc_ratio, wr = wd/pc_ratio; K, Kinv, rel: 4x4 row-major camera matrix, its
  * inverse and the relative transform Rt_rel_12; scale2: device scalar.  out[4] = {loss_pc, loss_rgb_s, n_valid, 0}.
  * The backward takes g_out[2] = dL/d{loss_pc, loss_rgb_s} (device) and ACCUMULATES into g_d1_img / g_d2_img (hd,wd;
@@ -202,6 +203,7 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
 #define NNR_AUX_PC 2u           /* pc_weight != 0 */
 #define NNR_AUX_SCALE_PCS 4u    /* training.scale_pcs */
 #define NNR_AUX_DETACH_RGBS 8u  /* training.detach_rgbs_scale */
+#define NNR_AUX_SSIM 16u        /* training.with_ssim: 0.15 clamp|.| + 0.85 SSIM per re-projected colour (12 hr wr more workspace floats) */
 typedef struct nnr_aux_cfg {
     int32_t hd, wd, hr, wr;
     float nearest_limit;

@@ -908,6 +908,10 @@ size_t aux_fill(const nnr_aux_cfg* c, float* ws, nnr::AuxArgs& a) {   // returns
     a.gYq = reinterpret_cast<long long*>(take(6 * S));
     a.X = take(3 * S); a.Y = take(3 * S);
     a.gxy = take(2 * S);
+    if (c->flags & NNR_AUX_SSIM) {
+        a.rgb1 = take(3 * S); a.rgb2 = take(3 * S);
+        a.drgb = take(6 * S);
+    }
     a.dist_xy = take(S); a.dist_yx = take(S);
     a.pflags = reinterpret_cast<uint32_t*>(take(S));
     a.acc = take(8);

@@ -13,6 +13,10 @@
 //   X = rot / scale2, Y = pc2 / scale2                                  (:355-357)  -> point-cloud loss (losses.py:114-148)
 //   rot' = (nl,nl,nl) where -rot.z < nl;  xy = (K [rot';1]).xy / .z;  valid = max|xy| <= 1     (:331-333, common.py:436-457)
 //   rgb_s = mean over valid points and 3 channels of clamp(|img1r(x',y') - img2r(xy)|, 0, 1)     (losses.py:150-157)
+// with_ssim (NNR_AUX_SSIM): the per-point term becomes 0.15 clamp|.| + 0.85 SSIM, where the reference hands the (1, hr, wr, 3) colour
+// tensors to its NCHW SSIM module (losses.py:222-252): the 3x3 reflect-padded average pool therefore runs over (grid x, colour
+// channel) -- the window of (y, x, c) is x-1..x+1 times c-1..c+1, reflected at the row ends and at the channel ends -- and that is
+// what aux_ssim_kernel restates, gradient included.
 #include "../../include/nnr.h"
 #include "nnr_device.h"
 #include "nnr_kernels.h"
@@ -121,23 +125,39 @@ __global__ __launch_bounds__(256) void aux_points_fwd_kernel(AuxArgs a) {
         float gxy0 = 0.f, gxy1 = 0.f;
         uint32_t fl = g.flags;
         if (a.flags & NNR_AUX_RGBS) {
+            const bool ssim = (a.flags & NNR_AUX_SSIM) != 0;
             float q[3], xy[2];
             aux_project(a, g, q, xy);
-            if (fmaxf(fabsf(xy[0]), fabsf(xy[1])) <= 1.f) {
+            const bool valid = fmaxf(fabsf(xy[0]), fabsf(xy[1])) <= 1.f;
+            if (valid) {
                 fl |= kValid;
+                lcnt = 1.f;
+            }
+            if (valid || ssim) {
                 const Bilinear s1 = sample_bilinear(a.img1r, a.hr, a.wr, g.xp, g.yp);
                 const Bilinear s2b = sample_bilinear(a.img2r, a.hr, a.wr, xy[0], xy[1]);
+                if (ssim) {
+                    // the windows of the neighbours need the colours of EVERY point (invalid ones too: their colour is a function of
+                    // their re-projection like any other); the loss and d loss / d colour come from aux_ssim_kernel
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float u = s1.v[c] - s2b.v[c], au = fabsf(u);
-                    if (mine) lsum += fminf(au, 1.f);
-                    // d clamp(|u|,0,1)/d rgb2 = -sign(u) inside (0,1), 0 at the clamps (torch: clamp passes the gradient at the
-                    // bounds, abs gives 0 at 0)
-                    const float gu = (au > 0.f && au <= 1.f) ? (u > 0.f ? -1.f : 1.f) : 0.f;
-                    gxy0 += gu * s2b.dx[c];
-                    gxy1 += gu * s2b.dy[c];
+                    for (int c = 0; c < 3; ++c) {
+                        a.rgb1[3 * i + c] = s1.v[c];
+                        a.rgb2[3 * i + c] = s2b.v[c];
+                        a.drgb[6 * i + c] = s2b.dx[c];
+                        a.drgb[6 * i + 3 + c] = s2b.dy[c];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float u = s1.v[c] - s2b.v[c], au = fabsf(u);
+                        if (mine) lsum += fminf(au, 1.f);
+                        // d clamp(|u|,0,1)/d rgb2 = -sign(u) inside (0,1), 0 at the clamps (torch: clamp passes the gradient at the
+                        // bounds, abs gives 0 at 0)
+                        const float gu = (au > 0.f && au <= 1.f) ? (u > 0.f ? -1.f : 1.f) : 0.f;
+                        gxy0 += gu * s2b.dx[c];
+                        gxy1 += gu * s2b.dy[c];
+                    }
                 }
-                lcnt = 1.f;
             }
             a.gxy[2 * i] = gxy0;
             a.gxy[2 * i + 1] = gxy1;
@@ -150,6 +170,84 @@ __global__ __launch_bounds__(256) void aux_points_fwd_kernel(AuxArgs a) {
         a.part_fwd[4 * blockIdx.x + 0] = bs;
         a.part_fwd[4 * blockIdx.x + 1] = bc;
     }
+}
+
+// with_ssim: loss and d loss / d (re-projected colour) of every point, after aux_points_fwd_kernel has left the colours and the validity
+// of all points.  Point (y, x) owns its three loss terms (if valid and in this rank's shard) and GATHERS the gradient of its own
+// colours from the <= 3 window centres per channel that read them: it re-evaluates the SSIM of the centres x-1, x, x+1 of its row
+// (valid, in the shard) and differentiates each with respect to the taps that land on (y, x) -- no scatter, no atomics.
+__device__ __forceinline__ int reflect1(int k, int n) {   // ReflectionPad2d(1): -1 -> 1, n -> n - 2
+    return k < 0 ? 1 : (k >= n ? n - 2 : k);
+}
+
+__global__ __launch_bounds__(256) void aux_ssim_kernel(AuxArgs a) {
+    __shared__ float scratch[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f, ninth = 1.f / 9.f;
+    float lsum = 0.f;
+    if (i < a.S) {
+        const int y = i / a.wr, x = i - y * a.wr;
+        float g[3] = {0.f, 0.f, 0.f};
+        if ((a.pflags[i] & kValid) && i >= a.s_lo && i < a.s_hi) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float u = a.rgb1[3 * i + c] - a.rgb2[3 * i + c], au = fabsf(u);
+                lsum += 0.15f * fminf(au, 1.f);
+                g[c] += (au > 0.f && au <= 1.f) ? (u > 0.f ? -0.15f : 0.15f) : 0.f;
+            }
+        }
+        for (int dc = -1; dc <= 1; ++dc) {
+            const int xc = x + dc, ic = i + dc;
+            if (xc < 0 || xc >= a.wr || !(a.pflags[ic] & kValid) || ic < a.s_lo || ic >= a.s_hi) continue;
+            int px[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) px[j] = y * a.wr + reflect1(xc + j - 1, a.wr);
+            float xs[3][3], ys[3][3];   // [tap column j][channel]
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    xs[j][c] = a.rgb1[3 * px[j] + c];
+                    ys[j][c] = a.rgb2[3 * px[j] + c];
+                }
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int tc = cc + k - 1 < 0 ? 1 : (cc + k - 1 > 2 ? 1 : cc + k - 1);
+                        const float xv = xs[j][tc], yv = ys[j][tc];
+                        sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
+                    }
+                const float mx = sx * ninth, my = sy * ninth;
+                const float vx = sxx * ninth - mx * mx, vy = syy * ninth - my * my, cv = sxy * ninth - mx * my;
+                const float A1 = 2.f * mx * my + C1, A2 = 2.f * cv + C2, B1 = mx * mx + my * my + C1, B2 = vx + vy + C2;
+                const float n = A1 * A2, d = B1 * B2;
+                const float v = (1.f - n / d) * 0.5f;
+                if (dc == 0) lsum += 0.85f * fminf(fmaxf(v, 0.f), 1.f);
+                if (!(v >= 0.f && v <= 1.f)) continue;   // clamp: gradient only inside [0, 1] (bounds included, like torch)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (px[j] != i) continue;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int tc = cc + k - 1 < 0 ? 1 : (cc + k - 1 > 2 ? 1 : cc + k - 1);
+                        const float xv = xs[j][tc], yv = ys[j][tc];
+                        const float dA1 = 2.f * mx * ninth, dA2 = 2.f * (xv - mx) * ninth;
+                        const float dB1 = 2.f * my * ninth, dB2 = 2.f * (yv - my) * ninth;
+                        const float dn = dA1 * A2 + A1 * dA2, dd = dB1 * B2 + B1 * dB2;
+                        g[tc] += 0.85f * (-0.5f) * (dn * d - n * dd) / (d * d);
+                    }
+                }
+            }
+        }
+        a.gxy[2 * i] = g[0] * a.drgb[6 * i] + g[1] * a.drgb[6 * i + 1] + g[2] * a.drgb[6 * i + 2];
+        a.gxy[2 * i + 1] = g[0] * a.drgb[6 * i + 3] + g[1] * a.drgb[6 * i + 4] + g[2] * a.drgb[6 * i + 5];
+    }
+    const float bs = block_sum(lsum, scratch);
+    if (threadIdx.x == 0) a.part_fwd[4 * blockIdx.x + 0] = bs;
 }
 
 // keys for both directions in one launch
@@ -260,7 +358,10 @@ __device__ __forceinline__ void aux_point_grads(const AuxArgs& a, int i, float& 
             if (ACC && scale) acc[12] -= (gx * a.X[3 * i + r] + gy * a.Y[3 * i + r]) / s2;
         }
     }
-    if ((a.flags & NNR_AUX_RGBS) && (fl & kValid) && !(fl & kBehind) && a.acc[1] > 0.f && i >= a.s_lo && i < a.s_hi) {
+    // (with_ssim: a point's colour also enters its neighbours' windows, so every point -- valid or not, of this shard or not -- may
+    // carry a gradient; aux_ssim_kernel has already restricted the CENTRES to the valid points of the shard)
+    const bool ssim = (a.flags & NNR_AUX_SSIM) != 0;
+    if ((a.flags & NNR_AUX_RGBS) && !(fl & kBehind) && a.acc[1] > 0.f && (ssim || ((fl & kValid) && i >= a.s_lo && i < a.s_hi))) {
         float q[3], xy[2];
         aux_project(a, g, q, xy);
         const float coef = a.g_out[1] / (3.f * a.acc[1]);
@@ -353,6 +454,7 @@ hipError_t launch_aux_fwd(const AuxArgs& a, hipStream_t st) {
     const int S = a.S, nb = (S + 255) / 256;
     const int n = a.s_hi - a.s_lo;   // this rank's source points (all of them without data parallelism)
     hipLaunchKernelGGL(aux_points_fwd_kernel, dim3(nb), dim3(256), 0, st, a);
+    if ((a.flags & NNR_AUX_RGBS) && (a.flags & NNR_AUX_SSIM)) hipLaunchKernelGGL(aux_ssim_kernel, dim3(nb), dim3(256), 0, st, a);
     if (a.flags & NNR_AUX_PC) {
         hipLaunchKernelGGL(aux_fill_keys_kernel, dim3((2 * S + 255) / 256), dim3(256), 0, st, a.keys, 2 * S);
         if (n > 0) {   // the O(S^2 / W) part: only this rank's sources search the whole destination cloud

@@ -179,6 +179,7 @@ struct AuxArgs {
     uint32_t flags;
     // workspace
     float *X, *Y, *gxy;             // (S,3) (S,3) (S,2)
+    float *rgb1, *rgb2, *drgb;      // NNR_AUX_SSIM only: (S,3) colours of both frames at every point, (S,2,3) d rgb2 / d (x, y)
     long long *gXq, *gYq;           // (S,3) each, adjacent: cloud gradients in 2^-44 fixed point (order-independent atomics)
     float *part_fwd, *part_bwd;     // per-block partial sums: [ceil(S/256)][4] and [ceil(S/256)][16]
     uint32_t* pflags;               // (S)

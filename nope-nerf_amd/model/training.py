@@ -10,7 +10,7 @@ What is different underneath:
     losses (training.py:280-365) are means over source points: rank k sums over its shard of the sampling grid with the
     global normalisers (the O(S^2) nearest-neighbour search shrinks by the world size); the O(cameras) trajectory terms
     are replicated and weighted 1/world_size.
-The per-image losses run as two fused HIP calls (nnr/aux.py); stock torch only for with_ssim / a learnable focal / CPU.
+The per-image losses run as two fused HIP calls (nnr/aux.py); stock torch only for a learnable focal / CPU.
 """
 import logging
 import math
@@ -412,7 +412,7 @@ class Trainer(object):
         if shard is not None:
             kwargs['point_shard'] = shard
         dump = (weights['rgb_s_weight'] != 0.0 and (it % self.vis_reprojection_every) == 0 and out_render_path is not None)
-        if d1.is_cuda and not self.optimizer_focal and not self.loss.cfg['with_ssim'] and img.shape[0] == 1 and not dump:
+        if d1.is_cuda and not self.optimizer_focal and img.shape[0] == 1 and not dump:
             # one fused forward / backward pair (nnr/aux.py) instead of ~290 small launches; same inputs, same losses
             from nnr import aux as nnr_aux
             rgb_s = weights['rgb_s_weight'] != 0.0
@@ -420,7 +420,8 @@ class Trainer(object):
             i2 = F.interpolate(img2, res, mode='bilinear') if rgb_s else None
             l_pc, l_rgbs, _ = nnr_aux.aux_terms(d1, d2, rel, scale2, i1, i2, camera_mat, self._inverse(camera_mat), res, nl,
                                                 rgb_s=rgb_s, pc=weights['pc_weight'] != 0.0, scale_pcs=bool(self.scale_pcs),
-                                                detach_rgbs_scale=self.detach_rgbs_scale, shard=shard or (0, 0))
+                                                detach_rgbs_scale=self.detach_rgbs_scale, ssim=self.loss.cfg['with_ssim'] == True,  # noqa: E712 (YAML)
+                                                shard=shard or (0, 0))
             kwargs.update(fused_aux=(l_pc, l_rgbs), sample_resolution=res)
             return
         pixel_locations, p_pc = arange_pixels(resolution=res, device=device)

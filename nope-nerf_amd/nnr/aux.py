@@ -1,7 +1,7 @@
 """The per-image losses between a frame and its neighbour as two fused HIP calls (SURVEY 8 f1 + f2): point-cloud loss and
 surface re-projection loss of reference model/training.py:315-358 + model/losses.py:114-157, forward and backward.
-CUDA tensors only; model/training.py keeps the torch expression for everything this does not cover (CPU, with_ssim,
-a learnable focal length)."""
+CUDA tensors only; model/training.py keeps the torch expression for everything this does not cover (CPU, a learnable
+focal length)."""
 import ctypes as C
 
 import torch
@@ -68,14 +68,15 @@ class _AuxTerms(torch.autograd.Function):
 
 
 def aux_terms(d1_img, d2_img, rel, scale2, img1r, img2r, K, Kinv, res, nearest_limit, *, rgb_s=True, pc=True, scale_pcs=True,
-              detach_rgbs_scale=False, shard=(0, 0)):
+              detach_rgbs_scale=False, ssim=False, shard=(0, 0)):
     """(loss_pc, loss_rgb_s, n_valid) for one frame pair.  d1_img/d2_img: (..., hd, wd) depth maps (scaled + shifted), rel:
     (..., 4, 4) relative transform, scale2: scalar tensor, img1r/img2r: (..., 3, hr, wr), K/Kinv: (..., 4, 4).
+    ssim: training.with_ssim (reference losses.py:153-155).
     shard = (lo, hi): data parallelism -- only the sums over the source points [lo, hi) of the res[0]*res[1] grid, with the global
     normalisers, so that the SUM over ranks is the single-GPU loss / gradient ((0, 0) = all points)."""
     if not d1_img.is_cuda:
         raise RuntimeError("nnr.aux needs CUDA tensors (no CPU fallback)")
     flags = (L.AUX_RGBS if rgb_s else 0) | (L.AUX_PC if pc else 0) | (L.AUX_SCALE_PCS if scale_pcs else 0) | \
-            (L.AUX_DETACH_RGBS if detach_rgbs_scale else 0)
+            (L.AUX_DETACH_RGBS if detach_rgbs_scale else 0) | (L.AUX_SSIM if (ssim and rgb_s) else 0)
     return _AuxTerms.apply(d1_img, d2_img, rel, scale2 if scale_pcs else None, img1r, img2r, K, Kinv, int(res[0]), int(res[1]),
                            float(nearest_limit), flags, tuple(shard))

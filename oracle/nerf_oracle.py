@@ -478,11 +478,26 @@ def project_to_cam(points: torch.Tensor, camera_mat: torch.Tensor):
     return xy, (xy.abs().max(dim=-1)[0] <= 1).unsqueeze(-1).bool()
 
 
+def ssim_dissimilarity(x, y):
+    """model/losses.py:222-252: the SSIM module of the reference, applied the way the reference calls it -- on 4-d tensors whatever
+    their meaning.  losses.py:154 passes (1, hr, wr, 3) colour tensors, so the 3x3 reflect-padded average pool runs over the last two
+    axes: (grid x, colour channel)."""
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    x, y = F.pad(x, (1, 1, 1, 1), mode="reflect"), F.pad(y, (1, 1, 1, 1), mode="reflect")
+    pool = lambda t: F.avg_pool2d(t, 3, 1)
+    mu_x, mu_y = pool(x), pool(y)
+    sigma_x, sigma_y = pool(x ** 2) - mu_x ** 2, pool(y ** 2) - mu_y ** 2
+    sigma_xy = pool(x * y) - mu_x * mu_y
+    n = (2 * mu_x * mu_y + c1) * (2 * sigma_xy + c2)
+    d = (mu_x ** 2 + mu_y ** 2 + c1) * (sigma_x + sigma_y + c2)
+    return torch.clamp((1 - n / d) / 2, 0, 1)
+
+
 def aux_scope(pose_r, pose_t, scales, shifts, cam: int, ref: int, camera_mat, depth_img, depth_ref_img, img, ref_img, *,
               pc_weight=1.0, rgb_s_weight=1.0, pc_ratio=4, nearest_limit=0.01, shift_first=False, detach_ref_img=True,
-              scale_pcs=True, detach_rgbs_scale=False):
+              scale_pcs=True, detach_rgbs_scale=False, with_ssim=False):
     """The per-image terms between a frame and its reference frame -- model/training.py:280-365 (inputs) and
-    model/losses.py:114-157 (point-cloud and surface-reprojection losses; with_ssim off).  depth images (1,1,hd,wd) are the
+    model/losses.py:114-157 (point-cloud and surface-reprojection losses; with_ssim: losses.py:153-155 + 222-252).  depth images (1,1,hd,wd) are the
     raw mono depths; returns (weighted sum, loss_pc, loss_rgb_s)."""
     num_cams = pose_r.shape[0]
     world_mat = torch.inverse(pose_c2w(pose_r[cam], pose_t[cam])).unsqueeze(0)         # :238
@@ -526,7 +541,9 @@ def aux_scope(pose_r, pose_t, scales, shifts, cam: int, ref: int, camera_mat, de
         p_re, valid = project_to_cam(rot, camera_mat)
         rgb_proj = sample(i2, p_re)
         shape = (1, res[0], res[1])
-        diff = (rgb_pc1.view(*shape, 3) - rgb_proj.view(*shape, 3)).abs().clamp(0, 1)   # losses.py:150-157, with_ssim False
+        diff = (rgb_pc1.view(*shape, 3) - rgb_proj.view(*shape, 3)).abs().clamp(0, 1)   # losses.py:150-157
+        if with_ssim:                                                                   # losses.py:153-155
+            diff = 0.15 * diff + 0.85 * ssim_dissimilarity(rgb_pc1.view(*shape, 3), rgb_proj.view(*shape, 3))
         loss_rgb_s = mean_on_mask(diff, valid.view(*shape, 1))
     pc1 = pc1 @ r_rel.transpose(1, 2) + t_rel                                           # :353-358
     if scale_pcs:

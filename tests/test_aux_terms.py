@@ -37,6 +37,26 @@ def test_oracle_aux_scope_matches_reference_golden(name):
         np.testing.assert_allclose(g.numpy(), GOLD[f"{name}.gaux.{k}"], rtol=0, atol=2e-6, err_msg=k)
 
 
+def test_oracle_aux_scope_with_ssim_matches_reference_golden():
+    """with_ssim: the reference's recorded step (mid_ssim.*) differs from the plain one (mid.*) only in the surface re-projection term, so
+    its gradient minus the render part of the plain step (mid.g - mid.gaux: same weights, same draws) is the reference's gradient of the
+    per-image terms with SSIM."""
+    import nerf_oracle as orc
+    inp = _inp("mid")
+    cam, ref = int(GOLD["mid.cam"]), int(GOLD["mid.ref"])
+    leaves = {k: inp[k].clone().requires_grad_(True) for k in ("pose_r", "pose_t", "scales", "shifts")}
+    aux, l_pc, l_rgbs = orc.aux_scope(leaves["pose_r"], leaves["pose_t"], leaves["scales"], leaves["shifts"], cam, ref, inp["K"],
+                                      inp["dpt"].unsqueeze(1), inp["ref_dpt"].unsqueeze(1), inp["img"], inp["ref_img"], with_ssim=True)
+    aux.backward()
+    np.testing.assert_allclose(l_pc.item(), float(GOLD["mid_ssim.out.loss_pc"]), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(l_rgbs.item(), float(GOLD["mid_ssim.out.loss_rgb_s"]), rtol=0, atol=1e-6)
+    assert abs(l_rgbs.item() - float(GOLD["mid.out.loss_rgb_s"])) > 1e-3          # and it is not the plain term
+    for k in leaves:
+        g = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(inp[k])
+        want = GOLD[f"mid_ssim.g.{k}"] - (GOLD[f"mid.g.{k}"] - GOLD[f"mid.gaux.{k}"])
+        np.testing.assert_allclose(g.numpy(), want, rtol=0, atol=5e-6, err_msg=k)
+
+
 def _trainer(inp, dev, adam=False, rendering_overrides=None, **training_overrides):
     import model as mdl
     if True:
@@ -103,6 +123,7 @@ def test_trainer_step_with_per_image_losses_matches_reference_golden(name, monke
 @pytest.mark.parametrize("name,flags", [
     ("mid", dict(scale_pcs=False)), ("mid", dict(detach_rgbs_scale=True)), ("mid", dict(pc_weight=[0.0, 0.0])),
     ("mid", dict(rgb_s_weight=[0.0, 0.0])), ("last", dict(detach_rgbs_scale=True, scale_pcs=False)), ("mid", dict(shift_first=True)),
+    ("mid", dict(with_ssim=True)), ("last", dict(with_ssim=True, detach_rgbs_scale=True)), ("last", dict(with_ssim=True, pc_weight=[0.0, 0.0])),
 ])
 def test_fused_per_image_terms_match_oracle_for_every_flag(name, flags):
     """Only the per-image terms (render weights 0), every configuration switch of reference training.py:325-357, against
@@ -121,7 +142,7 @@ def test_fused_per_image_terms_match_oracle_for_every_flag(name, flags):
     leaves = {k: inp[k].clone().requires_grad_(True) for k in ("pose_r", "pose_t", "scales", "shifts")}
     kw = dict(pc_weight=over.get("pc_weight", [1.0])[0], rgb_s_weight=over.get("rgb_s_weight", [1.0])[0],
               scale_pcs=over.get("scale_pcs", True), detach_rgbs_scale=over.get("detach_rgbs_scale", False),
-              shift_first=over.get("shift_first", False))
+              shift_first=over.get("shift_first", False), with_ssim=over.get("with_ssim", False))
     aux, l_pc, l_rgbs = orc.aux_scope(leaves["pose_r"], leaves["pose_t"], leaves["scales"], leaves["shifts"], cam, ref, inp["K"],
                                       inp["dpt"].unsqueeze(1), inp["ref_dpt"].unsqueeze(1), inp["img"], inp["ref_img"], **kw)
     aux.backward()
@@ -137,15 +158,16 @@ def test_fused_per_image_terms_match_oracle_for_every_flag(name, flags):
 
 
 @pytest.mark.gpu
-def test_fused_path_is_the_one_that_runs(monkeypatch):
-    """The trainer must reach libnnr.so for the per-image terms on the GPU (no silent torch fallback)."""
+@pytest.mark.parametrize("with_ssim", [False, True])
+def test_fused_path_is_the_one_that_runs(monkeypatch, with_ssim):
+    """The trainer must reach libnnr.so for the per-image terms on the GPU (no silent torch fallback), with_ssim included."""
     from nnr import aux as nnr_aux
     calls = []
     real = nnr_aux.aux_terms
     monkeypatch.setattr(nnr_aux, "aux_terms", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     dev = torch.device("cuda")
     inp = _inp("mid")
-    tr, _, _ = _trainer(inp, dev)
+    tr, _, _ = _trainer(inp, dev, with_ssim=with_ssim)
     data = {"img": inp["img"].to(dev), "img.idx": 2, "img.dpt": inp["dpt"].to(dev), "img.camera_mat": inp["K"].to(dev),
             "img.scale_mat": torch.eye(4).unsqueeze(0).to(dev), "img.ref_imgs": inp["ref_img"].to(dev),
             "img.ref_dpts": inp["ref_dpt"].to(dev), "img.ref_idxs": 3}

@@ -92,7 +92,7 @@ def test_rccl_flat_allreduce_world1():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("mid", 2), ("last", 3), ("mid", 8)])
+@pytest.mark.parametrize("name,world", [("mid", 2), ("last", 3), ("mid", 8), ("mid_ssim", 3)])
 def test_virtual_ranks_shard_the_per_image_losses(name, world, monkeypatch):
     """First training phase (pc_weight = rgb_s_weight = 1): each virtual rank runs the fused per-image kernels on its shard of the
     source points (nnr_aux_cfg.shard_lo/hi); the SUM of the ranks' losses and gradients is the reference's single-process step
@@ -101,6 +101,8 @@ def test_virtual_ranks_shard_the_per_image_losses(name, world, monkeypatch):
     import test_aux_terms as ta
     from nnr import parallel
     G = ta.GOLD
+    gold, ssim = name, name.endswith("_ssim")       # with_ssim: a window centre belongs to the rank that owns the point, its taps need not
+    name = name.replace("_ssim", "")
     inp = ta._inp(name)
     cam, ref = int(G[f"{name}.cam"]), int(G[f"{name}.ref"])
     ray_idx, jitter = torch.from_numpy(G[f"{name}.ray_idx"]), torch.from_numpy(G[f"{name}.jitter"])
@@ -116,7 +118,7 @@ def test_virtual_ranks_shard_the_per_image_losses(name, world, monkeypatch):
     tot_l, tot_g = {}, {}
     for r in range(world):
         monkeypatch.setattr(parallel, "rank", lambda r=r: r)
-        tr, pose, distn = ta._trainer(inp, dev)
+        tr, pose, distn = ta._trainer(inp, dev, with_ssim=ssim)
         ld = tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
         for k in ("loss", "loss_pc", "loss_rgb_s", "loss_rgb", "loss_depth"):
             tot_l[k] = tot_l.get(k, 0.0) + float(ld[k])
@@ -124,7 +126,7 @@ def test_virtual_ranks_shard_the_per_image_losses(name, world, monkeypatch):
             g = p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
             tot_g[k] = tot_g.get(k, 0.0) + g
     for k, v in tot_l.items():
-        np.testing.assert_allclose(v, float(G[f"{name}.out.{k}"]), rtol=0, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(v, float(G[f"{gold}.out.{k}"]), rtol=0, atol=2e-5, err_msg=k)
     for k, g in tot_g.items():
-        ref_g = G[f"{name}.g.{k}"]
+        ref_g = G[f"{gold}.g.{k}"]
         assert float(np.abs(g - ref_g).max()) / max(1.0, float(np.abs(ref_g).max())) <= 1e-4, k
