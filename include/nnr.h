@@ -195,7 +195,9 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
  * (bilinear) to the sampling grid hr = hd/pc_ratio, wr = wd/pc_ratio; K, Kinv, rel: 4x4 row-major camera matrix, its
  * inverse and the relative transform Rt_rel_12; scale2: device scalar.  out[4] = {loss_pc, loss_rgb_s, n_valid, 0}.
  * The backward takes g_out[2] = dL/d{loss_pc, loss_rgb_s} (device) and ACCUMULATES into g_d1_img / g_d2_img (hd,wd;
- * zero-fill first; either may be null) and OVERWRITES g_rel_scale[16] = {dL/d rel rows 0..2 (12 floats), dL/d scale2, 0..}.
+ * zero-fill first; either may be null) and OVERWRITES g_rel_scale[16] = {dL/d rel rows 0..2 (12 floats), dL/d scale2, 0..};
+ * with NNR_AUX_GRAD_K g_rel_scale has 40 floats: [16, 28) = dL/dK rows 0..2, [28, 40) = dL/dKinv rows 0..2 (K and Kinv as two
+ * independent inputs, the way autograd sees camera_mat and its inverse in reference model/common.py:112-160, 436-457).
  * Every sum is taken in a fixed order (per-block partials added in block order; shared-destination scatters in 64-bit fixed
  * point), so losses and gradients are bit-reproducible from run to run.
  * Both calls use the same workspace (nnr_aux_workspace_floats) and the same inputs. */
@@ -203,6 +205,7 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
 #define NNR_AUX_PC 2u           /* pc_weight != 0 */
 #define NNR_AUX_SCALE_PCS 4u    /* training.scale_pcs */
 #define NNR_AUX_DETACH_RGBS 8u  /* training.detach_rgbs_scale */
+#define NNR_AUX_GRAD_K 32u      /* a learnable focal length: the backward also returns dL/dK and dL/dKinv (g_rel_scale has 40 floats) */
 #define NNR_AUX_SSIM 16u        /* training.with_ssim: 0.15 clamp|.| + 0.85 SSIM per re-projected colour (12 hr wr more workspace floats) */
 typedef struct nnr_aux_cfg {
     int32_t hd, wd, hr, wr;

@@ -917,7 +917,7 @@ size_t aux_fill(const nnr_aux_cfg* c, float* ws, nnr::AuxArgs& a) {   // returns
     a.acc = take(8);
     const int64_t nb = (S + 255) / 256;
     a.part_fwd = take(4 * nb);
-    a.part_bwd = take(16 * nb);
+    a.part_bwd = take(40 * nb);
     return (size_t)(p - ws);
 }
 }  // namespace

@@ -340,13 +340,17 @@ __global__ void aux_pc_bwd_kernel(const float* src, const float* dst, const int6
 }
 
 // d loss / d (d1, d2) of point i, the chain of gX, gY (point-cloud loss) and of the saved d(point loss)/d(xy) (re-projection loss)
-// back to the two depth values; with ACC also this point's contribution to dL/d rel[r][0..3] (r = 0..2) and dL/d scale2 in acc[13]
+// back to the two depth values; with ACC also this point's contribution to dL/d rel[r][0..3] (r = 0..2), dL/d scale2 in acc[12] and --
+// NNR_AUX_GRAD_K, a learnable focal length -- dL/d K[r][0..3] in acc[13..25) and dL/d Kinv[r][0..3] in acc[25..37)
+constexpr int kAuxCols = 37, kAuxStride = 40;
 template <bool ACC>
-__device__ __forceinline__ void aux_point_grads(const AuxArgs& a, int i, float& gd1, float& gd2, uint32_t& fl, int& src1, float (&acc)[13]) {
+__device__ __forceinline__ void aux_point_grads(const AuxArgs& a, int i, float& gd1, float& gd2, uint32_t& fl, int& src1,
+                                                float (&acc)[kAuxCols]) {
     const AuxGeom g = aux_geometry(a, i);
     fl = a.pflags[i];
     src1 = g.src1;
     const bool scale = (a.flags & NNR_AUX_SCALE_PCS) != 0;
+    const bool grad_k = ACC && (a.flags & NNR_AUX_GRAD_K) != 0;
     const float s2 = scale ? a.scale2[0] : 1.f;
     float g_rot[3] = {0.f, 0.f, 0.f}, g_rot_s[3] = {0.f, 0.f, 0.f}, g_pc2[3] = {0.f, 0.f, 0.f};
     if (a.flags & NNR_AUX_PC) {
@@ -361,14 +365,26 @@ __device__ __forceinline__ void aux_point_grads(const AuxArgs& a, int i, float& 
     // (with_ssim: a point's colour also enters its neighbours' windows, so every point -- valid or not, of this shard or not -- may
     // carry a gradient; aux_ssim_kernel has already restricted the CENTRES to the valid points of the shard)
     const bool ssim = (a.flags & NNR_AUX_SSIM) != 0;
-    if ((a.flags & NNR_AUX_RGBS) && !(fl & kBehind) && a.acc[1] > 0.f && (ssim || ((fl & kValid) && i >= a.s_lo && i < a.s_hi))) {
+    // a point behind the second camera was replaced by the constant (nl, nl, nl): nothing reaches the geometry, but its projection is
+    // still a function of K
+    if ((a.flags & NNR_AUX_RGBS) && (grad_k || !(fl & kBehind)) && a.acc[1] > 0.f && (ssim || ((fl & kValid) && i >= a.s_lo && i < a.s_hi))) {
         float q[3], xy[2];
         aux_project(a, g, q, xy);
         const float coef = a.g_out[1] / (3.f * a.acc[1]);
         const float gx = a.gxy[2 * i] * coef, gy = a.gxy[2 * i + 1] * coef;
         const float gq[3] = {gx / q[2], gy / q[2], -(gx * q[0] + gy * q[1]) / (q[2] * q[2])};
+        if (!(fl & kBehind)) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) g_rot_s[c] = a.K[c] * gq[0] + a.K[4 + c] * gq[1] + a.K[8 + c] * gq[2];
+            for (int c = 0; c < 3; ++c) g_rot_s[c] = a.K[c] * gq[0] + a.K[4 + c] * gq[1] + a.K[8 + c] * gq[2];
+        }
+        if (grad_k) {
+            const bool behind = (fl & kBehind) != 0;
+            const float p[4] = {behind ? a.nl : g.rot[0], behind ? a.nl : g.rot[1], behind ? a.nl : g.rot[2], 1.f};
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[13 + 4 * r + c] = gq[r] * p[c];
+        }
     }
     float g_pc1[3] = {0.f, 0.f, 0.f};
     const bool detach = (a.flags & NNR_AUX_DETACH_RGBS) != 0;
@@ -394,6 +410,12 @@ __device__ __forceinline__ void aux_point_grads(const AuxArgs& a, int i, float& 
         const float dir = k[0] * g.xp + k[1] * g.yp + k[2];
         gd1 += g_pc1[r] * dir;
         gd2 += g_pc2[r] * dir;
+        if (grad_k) {   // d pc[r] / d Kinv[r][:] = (x' d, y' d, d, 1), clamped depths included (the clamp only cuts d L / d depth)
+            acc[25 + 4 * r + 0] = g_pc1[r] * g.xp * g.d1 + g_pc2[r] * g.xp * g.d2;
+            acc[25 + 4 * r + 1] = g_pc1[r] * g.yp * g.d1 + g_pc2[r] * g.yp * g.d2;
+            acc[25 + 4 * r + 2] = g_pc1[r] * g.d1 + g_pc2[r] * g.d2;
+            acc[25 + 4 * r + 3] = g_pc1[r] + g_pc2[r];
+        }
     }
 }
 
@@ -405,9 +427,9 @@ __device__ __forceinline__ void aux_point_grads(const AuxArgs& a, int i, float& 
 __global__ __launch_bounds__(256) void aux_points_bwd_kernel(AuxArgs a) {
     __shared__ float scratch[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    float acc[13];   // dL/d rel[r][0..3] for r = 0..2, dL/d scale2
+    float acc[kAuxCols];   // dL/d rel[r][0..3] for r = 0..2, dL/d scale2, dL/d K rows 0..2, dL/d Kinv rows 0..2
 #pragma unroll
-    for (int k = 0; k < 13; ++k) acc[k] = 0.f;
+    for (int k = 0; k < kAuxCols; ++k) acc[k] = 0.f;
     if (i < a.S) {
         float gd1, gd2;
         uint32_t fl;
@@ -421,7 +443,7 @@ __global__ __launch_bounds__(256) void aux_points_bwd_kernel(AuxArgs a) {
                 float s1 = 0.f, s2 = 0.f;
                 for (int yy = y; yy < a.hr && aux_nearest_src(yy, a.hr, a.hd) == sy; ++yy) {
                     for (int xx = x; xx < a.wr && aux_nearest_src(xx, a.wr, a.wd) == sx; ++xx) {
-                        float e1 = gd1, e2 = gd2, none[13];
+                        float e1 = gd1, e2 = gd2, none[kAuxCols];
                         uint32_t fj = fl;
                         int sj = src1;
                         if (yy != y || xx != x) aux_point_grads<false>(a, yy * a.wr + xx, e1, e2, fj, sj, none);
@@ -434,18 +456,23 @@ __global__ __launch_bounds__(256) void aux_points_bwd_kernel(AuxArgs a) {
             }
         }
     }
+    const int cols = (a.flags & NNR_AUX_GRAD_K) ? kAuxCols : 13;
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
+    for (int k = 0; k < kAuxCols; ++k) {
+        if (k >= cols) break;
         const float bs = block_sum(acc[k], scratch);
-        if (threadIdx.x == 0) a.part_bwd[16 * blockIdx.x + k] = bs;
+        if (threadIdx.x == 0) a.part_bwd[kAuxStride * blockIdx.x + k] = bs;
     }
 }
 
-// g_rel_scale[16] = block partials summed in block order (bit-reproducible)
+// g_rel_scale[16 (40 with NNR_AUX_GRAD_K)] = block partials summed in block order (bit-reproducible): columns 0..12 at [0, 13), the K
+// and Kinv columns 13..36 at [16, 40)
 __global__ __launch_bounds__(64) void aux_bwd_finish_kernel(AuxArgs a, float* g_rel_scale) {
     const int nb = (a.S + 255) / 256;
-    for (int k = 0; k < 16; ++k) {
-        const float t = k < 13 ? ordered_column_sum(a.part_bwd, nb, 16, k) : 0.f;
+    const int n_out = (a.flags & NNR_AUX_GRAD_K) ? 40 : 16;
+    for (int k = 0; k < n_out; ++k) {
+        const int col = k < 13 ? k : (k >= 16 ? k - 3 : -1);
+        const float t = col >= 0 ? ordered_column_sum(a.part_bwd, nb, kAuxStride, col) : 0.f;
         if (threadIdx.x == 0) g_rel_scale[k] = t;
     }
 }

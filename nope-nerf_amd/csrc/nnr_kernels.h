@@ -181,7 +181,7 @@ struct AuxArgs {
     float *X, *Y, *gxy;             // (S,3) (S,3) (S,2)
     float *rgb1, *rgb2, *drgb;      // NNR_AUX_SSIM only: (S,3) colours of both frames at every point, (S,2,3) d rgb2 / d (x, y)
     long long *gXq, *gYq;           // (S,3) each, adjacent: cloud gradients in 2^-44 fixed point (order-independent atomics)
-    float *part_fwd, *part_bwd;     // per-block partial sums: [ceil(S/256)][4] and [ceil(S/256)][16]
+    float *part_fwd, *part_bwd;     // per-block partial sums: [ceil(S/256)][4] and [ceil(S/256)][40]
     uint32_t* pflags;               // (S)
     unsigned long long* keys;       // (2S)
     int64_t *idx_xy, *idx_yx;
@@ -193,7 +193,7 @@ struct AuxArgs {
     float *g_d1_img, *g_d2_img;     // (hd, wd), accumulated into; may be null
 };
 hipError_t launch_aux_fwd(const AuxArgs& a, hipStream_t st);
-hipError_t launch_aux_bwd(const AuxArgs& a, float* g_rel_scale, hipStream_t st);   // g_rel_scale[16]: dL/d rel rows 0..2 (12), dL/d scale2 (1)
+hipError_t launch_aux_bwd(const AuxArgs& a, float* g_rel_scale, hipStream_t st);   // g_rel_scale[16 | 40]: dL/d rel rows 0..2 (12), dL/d scale2 (1); NNR_AUX_GRAD_K: + dL/dK, dL/dKinv rows 0..2 at [16, 40)
 hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int D, unsigned long long* keys, hipStream_t st);
 hipError_t launch_pc_nearest(const float* src, const float* dst, int S, int D, int64_t* idx, float* dist, unsigned long long* keys,
                              hipStream_t st);

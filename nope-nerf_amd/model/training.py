@@ -10,7 +10,7 @@ What is different underneath:
     losses (training.py:280-365) are means over source points: rank k sums over its shard of the sampling grid with the
     global normalisers (the O(S^2) nearest-neighbour search shrinks by the world size); the O(cameras) trajectory terms
     are replicated and weighted 1/world_size.
-The per-image losses run as two fused HIP calls (nnr/aux.py); stock torch only for a learnable focal / CPU.
+The per-image losses run as two fused HIP calls (nnr/aux.py); stock torch only on the CPU and for batches of images.
 """
 import logging
 import math
@@ -412,7 +412,7 @@ class Trainer(object):
         if shard is not None:
             kwargs['point_shard'] = shard
         dump = (weights['rgb_s_weight'] != 0.0 and (it % self.vis_reprojection_every) == 0 and out_render_path is not None)
-        if d1.is_cuda and not self.optimizer_focal and img.shape[0] == 1 and not dump:
+        if d1.is_cuda and img.shape[0] == 1 and not dump:
             # one fused forward / backward pair (nnr/aux.py) instead of ~290 small launches; same inputs, same losses
             from nnr import aux as nnr_aux
             rgb_s = weights['rgb_s_weight'] != 0.0

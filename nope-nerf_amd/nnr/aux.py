@@ -1,7 +1,6 @@
 """The per-image losses between a frame and its neighbour as two fused HIP calls (SURVEY 8 f1 + f2): point-cloud loss and
 surface re-projection loss of reference model/training.py:315-358 + model/losses.py:114-157, forward and backward.
-CUDA tensors only; model/training.py keeps the torch expression for everything this does not cover (CPU, a learnable
-focal length)."""
+CUDA tensors only; model/training.py keeps the torch expression for what this does not cover (CPU, batches of images)."""
 import ctypes as C
 
 import torch
@@ -21,6 +20,8 @@ class _AuxTerms(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         d1, d2 = d1_img.detach().contiguous().float(), d2_img.detach().contiguous().float()
         hd, wd = d1.shape[-2:]
+        if K.requires_grad or Kinv.requires_grad:      # a learnable focal length (reference model/training.py:247-252)
+            flags |= L.AUX_GRAD_K
         cfg = L.AuxCfg(int(hd), int(wd), int(hr), int(wr), float(nl), int(flags), int(shard[0]), int(shard[1]))
         n_ws = lib.nnr_aux_workspace_floats(C.byref(cfg))
         if n_ws == 0:
@@ -37,7 +38,7 @@ class _AuxTerms(torch.autograd.Function):
                                       _st()), "nnr_aux_terms_fwd")
         ctx.cfg, ctx.ws = cfg, ws
         ctx.tensors = (d1, d2, i1, i2, K_c, Kinv_c, rel_c, s2)
-        ctx.shapes = (d1_img.shape, d2_img.shape, rel.shape, None if scale2 is None else scale2.shape)
+        ctx.shapes = (d1_img.shape, d2_img.shape, rel.shape, None if scale2 is None else scale2.shape, K.shape, Kinv.shape)
         ctx.set_materialize_grads(False)
         return out[0], out[1], out[2]
 
@@ -54,17 +55,19 @@ class _AuxTerms(torch.autograd.Function):
             g_out[1] = g_rgbs
         g_d1 = torch.zeros_like(d1) if need_d1 else None
         g_d2 = torch.zeros_like(d2) if need_d2 else None
-        g_rs = torch.empty(16, **f32)
+        g_rs = torch.empty(40, **f32)
         p = lambda t: L.ptr(t) if t is not None else None
         L.check(lib.nnr_aux_terms_bwd(C.byref(ctx.cfg), p(d1), p(d2), p(i1), p(i2), p(K_c), p(Kinv_c), p(rel_c), p(s2), p(g_out),
                                       p(g_d1), p(g_d2), p(g_rs), p(ctx.ws), _st()), "nnr_aux_terms_bwd")
-        sh1, sh2, shr, shs = ctx.shapes
-        g_rel = None
-        if need_rel:
-            g_rel = torch.cat([g_rs[:12], torch.zeros(4, **f32)]).view(shr)
+        sh1, sh2, shr, shs, shk, shki = ctx.shapes
+        rows = lambda lo, shape: torch.cat([g_rs[lo:lo + 12], torch.zeros(4, **f32)]).view(shape)      # the last row is not read
+        g_rel = rows(0, shr) if need_rel else None
         g_s2 = g_rs[12].view(shs) if (need_s2 and shs is not None) else None
+        grad_k = bool(ctx.cfg.flags & L.AUX_GRAD_K)
+        g_k = rows(16, shk) if (grad_k and ctx.needs_input_grad[6]) else None
+        g_kinv = rows(28, shki) if (grad_k and ctx.needs_input_grad[7]) else None
         return (g_d1.view(sh1) if need_d1 else None, g_d2.view(sh2) if need_d2 else None, g_rel, g_s2,
-                None, None, None, None, None, None, None, None, None)
+                None, None, g_k, g_kinv, None, None, None, None, None)
 
 
 def aux_terms(d1_img, d2_img, rel, scale2, img1r, img2r, K, Kinv, res, nearest_limit, *, rgb_s=True, pc=True, scale_pcs=True,

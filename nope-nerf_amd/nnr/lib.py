@@ -51,7 +51,7 @@ class AuxCfg(C.Structure):
                 ("flags", C.c_uint32), ("shard_lo", C.c_int32), ("shard_hi", C.c_int32)]
 
 
-AUX_RGBS, AUX_PC, AUX_SCALE_PCS, AUX_DETACH_RGBS, AUX_SSIM = 1, 2, 4, 8, 16
+AUX_RGBS, AUX_PC, AUX_SCALE_PCS, AUX_DETACH_RGBS, AUX_SSIM, AUX_GRAD_K = 1, 2, 4, 8, 16, 32
 
 
 class StepCfg(C.Structure):        # nnr_step_cfg: the fused front end of a training step

@@ -57,7 +57,7 @@ def test_oracle_aux_scope_with_ssim_matches_reference_golden():
         np.testing.assert_allclose(g.numpy(), want, rtol=0, atol=5e-6, err_msg=k)
 
 
-def _trainer(inp, dev, adam=False, rendering_overrides=None, **training_overrides):
+def _trainer(inp, dev, adam=False, rendering_overrides=None, focal=None, **training_overrides):
     import model as mdl
     if True:
         cfg = {
@@ -87,8 +87,9 @@ def _trainer(inp, dev, adam=False, rendering_overrides=None, **training_override
         dist.global_scales.copy_(inp["scales"]); dist.global_shifts.copy_(inp["shifts"])
     # lr-0 SGD for the single-step gradient checks; the reference's three Adam instances (configs/default.yaml:79-82) otherwise
     opt = (lambda m, lr: torch.optim.Adam(m.parameters(), lr=lr)) if adam else (lambda m, lr: torch.optim.SGD(m.parameters(), lr=0.0))
+    extra = dict(optimizer_focal=opt(focal, 1e-3), focal_net=focal) if focal is not None else {}
     tr = mdl.Trainer(model, opt(model, 1e-3), cfg['training'], device=dev, optimizer_pose=opt(pose, 5e-4), pose_param_net=pose,
-                     optimizer_distortion=opt(dist, 5e-4), distortion_net=dist)
+                     optimizer_distortion=opt(dist, 5e-4), distortion_net=dist, **extra)
     return tr, pose, dist
 
 
@@ -155,6 +156,53 @@ def test_fused_per_image_terms_match_oracle_for_every_flag(name, flags):
         g = g.cpu().numpy() if g is not None else np.zeros_like(ref_g)
         scale = max(1.0, float(np.abs(ref_g).max()))
         assert float(np.abs(g - ref_g).max()) / scale <= 1e-4, (k, flags, float(np.abs(g - ref_g).max()), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,flags", [
+    ("mid", {}), ("mid", dict(with_ssim=True)), ("last", dict(detach_rgbs_scale=True)), ("last", dict(with_ssim=True, scale_pcs=False)),
+    ("mid", dict(pc_weight=[0.0, 0.0], with_ssim=True)), ("mid", dict(rgb_s_weight=[0.0, 0.0])),
+])
+def test_fused_per_image_terms_with_a_learnable_focal_match_oracle(name, flags):
+    """optimizer_focal (reference training.py:247-252): camera_mat is built from the focal parameters, so the per-image terms also
+    return d/dK (the re-projection) and d/dKinv (both back-projections).  fx / fy gradients and everything else against the oracle with
+    the same camera_mat as an autograd leaf chain."""
+    import model as mdl
+    import nerf_oracle as orc
+    dev = torch.device("cuda")
+    inp = _inp(name)
+    cam, ref = int(GOLD[f"{name}.cam"]), int(GOLD[f"{name}.ref"])
+    f0 = [float(inp["K"][0, 0, 0]) * 1.07, float(-inp["K"][0, 1, 1]) * 0.94]      # not the data's intrinsics: a focal mid-optimisation
+    focal = mdl.LearnFocal(True, False, order=2, init_focal=f0).to(dev)
+    over = dict(rgb_weight=[0.0, 0.0], depth_weight=[0.0, 0.0])
+    over.update(flags)
+    tr, pose, dist = _trainer(inp, dev, focal=focal, **over)
+    data = {"img": inp["img"].to(dev), "img.idx": cam, "img.dpt": inp["dpt"].to(dev), "img.camera_mat": inp["K"].to(dev),
+            "img.scale_mat": torch.eye(4).unsqueeze(0).to(dev), "img.ref_imgs": inp["ref_img"].to(dev),
+            "img.ref_dpts": inp["ref_dpt"].to(dev), "img.ref_idxs": ref}
+    ld = tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
+    leaves = {k: inp[k].clone().requires_grad_(True) for k in ("pose_r", "pose_t", "scales", "shifts")}
+    focal_cpu = mdl.LearnFocal(True, False, order=2, init_focal=f0)
+    fxfy = focal_cpu(0)
+    pad = torch.zeros(4)
+    k_mat = torch.cat([fxfy[0:1], pad, -fxfy[1:2], pad, -torch.ones(1), pad, torch.ones(1)]).view(1, 4, 4)     # training.py:248-252
+    kw = dict(pc_weight=over.get("pc_weight", [1.0])[0], rgb_s_weight=over.get("rgb_s_weight", [1.0])[0],
+              scale_pcs=over.get("scale_pcs", True), detach_rgbs_scale=over.get("detach_rgbs_scale", False),
+              with_ssim=over.get("with_ssim", False))
+    aux, l_pc, l_rgbs = orc.aux_scope(leaves["pose_r"], leaves["pose_t"], leaves["scales"], leaves["shifts"], cam, ref, k_mat,
+                                      inp["dpt"].unsqueeze(1), inp["ref_dpt"].unsqueeze(1), inp["img"], inp["ref_img"], **kw)
+    aux.backward()
+    np.testing.assert_allclose(float(ld["loss_pc"]), float(l_pc), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(float(ld["loss_rgb_s"]), float(l_rgbs), rtol=0, atol=1e-5)
+    got = {"fx": focal.fx.grad, "fy": focal.fy.grad, "pose_r": pose.r.grad, "pose_t": pose.t.grad, "scales": dist.global_scales.grad,
+           "shifts": dist.global_shifts.grad}
+    want = dict(leaves, fx=focal_cpu.fx, fy=focal_cpu.fy)
+    assert float(focal_cpu.fx.grad.abs()) > 1e-4 and float(focal_cpu.fy.grad.abs()) > 1e-4      # the case does exercise d/dK
+    for k, g in got.items():
+        ref_g = want[k].grad.numpy() if want[k].grad is not None else np.zeros(tuple(want[k].shape), np.float32)
+        g = g.cpu().numpy() if g is not None else np.zeros_like(ref_g)
+        scale = max(1.0, float(np.abs(ref_g).max()))
+        assert float(np.abs(g - ref_g).max()) / scale <= 1e-4, (k, flags, g, ref_g)
 
 
 @pytest.mark.gpu

@@ -88,7 +88,12 @@ def test_training_step_with_learnable_focal_matches_the_reference(dev, monkeypat
     data = {"img": imgs[cam:cam + 1], "img.idx": cam, "img.dpt": dpts[cam:cam + 1], "img.camera_mat": torch.from_numpy(GOLD["K"]).to(dev),
             "img.scale_mat": torch.eye(4).unsqueeze(0).to(dev), "img.ref_imgs": imgs[nb:nb + 1], "img.ref_dpts": dpts[nb:nb + 1],
             "img.ref_idxs": nb}
+    from nnr import aux as nnr_aux
+    calls, real_aux = [], nnr_aux.aux_terms
+    monkeypatch.setattr(nnr_aux, "aux_terms", lambda *a, **k: (calls.append(1), real_aux(*a, **k))[1])
     ld = tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
+    # on the GPU the per-image terms -- d/dK and d/dKinv of the learnable focal included -- are the fused kernels' (nnr_aux.hip)
+    assert calls == ([1] if dev.type == "cuda" else [])
     for k in ("loss", "loss_rgb", "loss_depth", "loss_pc", "loss_rgb_s", "l2_mean", "focalx", "focaly"):
         assert abs(float(ld[k].detach()) - float(GOLD["focal.out." + k])) <= 1e-5, (k, float(ld[k]), float(GOLD["focal.out." + k]))
     for k, t in (("fx", focal.fx), ("fy", focal.fy), ("pose_r", pose.r), ("pose_t", pose.t), ("scales", dist.global_scales),
