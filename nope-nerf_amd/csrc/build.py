@@ -12,7 +12,11 @@ OUT_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(os.path.dirname(HERE), "nnr", "libnnr.so")
 # (source, defines): the two fp32 MLP kernels are compiled one template instantiation per translation unit -- each is minutes of hipcc
 # time (straight-line code of ~8 000 MFMAs), in one unit the forward alone took 8.5 minutes; the longest unit first
-SOURCES = [("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1")), ("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=0")),
+SOURCES = [("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1", "NNR_FWD_MODE=2")), ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=256", "NNR_DGRAD_MODE=2")),
+           ("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=0", "NNR_FWD_MODE=2")),
+           ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=1", "NNR_FWD_MODE=2")), ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=128", "NNR_DGRAD_MODE=2")),
+           ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=0", "NNR_FWD_MODE=2")),
+           ("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1")), ("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=0")),
            ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=256",)), ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=1")),
            ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=0")), ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=128",)),
            ("nnr_mlp_fwd_bf16.hip", ()), ("nnr_mlp_dgrad_bf16.hip", ()), ("nnr_mlp_fwd.hip", ()), ("nnr_mlp_dgrad.hip", ()),
@@ -23,7 +27,7 @@ SOURCES = [("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1")), ("nnr_mlp_
 def _obj_name(src, defines):
     tag = "".join("_" + d.split("=")[0].lower().replace("nnr_", "") + d.split("=")[1] for d in defines)
     return os.path.splitext(src)[0] + tag + ".o"
-HEADERS = ["nnr_layout.h", "nnr_device.h", "nnr_kernels.h", "nnr_mlp_bf16.h", os.path.join("..", "..", "include", "nnr.h")]
+HEADERS = ["nnr_layout.h", "nnr_device.h", "nnr_kernels.h", "nnr_mlp_bf16.h", "nnr_split.h", os.path.join("..", "..", "include", "nnr.h")]
 # -pragma-unroll-threshold: the MLP kernels are straight-line code by construction (every `#pragma unroll` loop must unroll fully, or
 # the register arrays they index fall back to scratch memory).  LLVM caps `#pragma unroll` at 16 K instructions per loop; one GEMM part
 # of the fp32 input-gradient kernel sat right at that cap, and an unrelated clean-up pushed it over: the kernel compiled without a
@@ -34,7 +38,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-prag
 # training kernels a spill reload is not just a slow load: stores are always in flight there, hipcc waits for any load next to pending
 # stores with vmcnt(0), and every reload drains the stash-store queue with the matrix pipe idle -- the TRAINING kernels may only keep a handful of
 # prologue values in scratch, reloaded at pass start (where the pass waits for its inputs anyway), nothing inside a pass; the inference forward (no stores in flight) may spill its composite carry.
-SCRATCH_LIMIT = {"14mlp_fwd_kernelI": 0, "16mlp_dgrad_kernelI": 0, "12wgrad_kernelE": 0, "14wgrad_b_kernelE": 0,
+SCRATCH_LIMIT = {"14mlp_fwd_kernelI": 0, "14mlp_fwd_kernelILi256ELb1ELi2E": 256, "14mlp_fwd_kernelILi256ELb0ELi2E": 256,
+                 "14mlp_fwd_kernelILi128ELb1ELi2E": 256, "14mlp_fwd_kernelILi128ELb0ELi2E": 256, "16mlp_dgrad_kernelI": 0, "12wgrad_kernelE": 0, "14wgrad_b_kernelE": 0,
                  "19mlp_fwd_bf16_kernelI": 48, "19mlp_fwd_bf16_kernelILi256ELb1E": 16, "19mlp_fwd_bf16_kernelILi128ELb1E": 16,
                  "21mlp_dgrad_bf16_kernelI": 64, "20composite_fwd_kernelE": 0, "20composite_bwd_kernelE": 0}
 
@@ -91,6 +96,28 @@ def build_variant(name, defines):
     return out
 
 
+def build_split_variant(name, defines):
+    """Experiment library: only the D = 256 three-term kernels are recompiled with `defines`, everything else comes from the main build."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.join(os.path.dirname(HERE), "nnr", "libnnr_%s.so" % name)
+    tmp = os.path.join(OUT_DIR, "variant_" + name)
+    os.makedirs(tmp, exist_ok=True)
+    mine = [(src, d) for src, d in SOURCES if any(x.endswith("MODE=2") for x in d) and any(x.endswith("_D=256") for x in d)]
+    jobs = [[hipcc] + FLAGS + ["-D" + d for d in list(defines) + list(d0)] + ["-c", os.path.join(HERE, src), "-o", os.path.join(tmp, _obj_name(src, d0))]
+            for src, d0 in mine]
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=WORKERS) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(tmp if (src, d) in mine else OUT_DIR, _obj_name(src, d)) for src, d in SOURCES]
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -125,7 +152,9 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant nostash NNR_ABLATE_NO_STASH [...]
+    if len(sys.argv) > 2 and sys.argv[1] == "--split-variant":    # build.py --split-variant safesync NNR_SPLIT_SAFE_SYNC
+        print(build_split_variant(sys.argv[2], sys.argv[3:]))
+    elif len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant nostash NNR_ABLATE_NO_STASH [...]
         print(build_variant(sys.argv[2], sys.argv[3:]))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

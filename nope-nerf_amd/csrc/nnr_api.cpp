@@ -47,11 +47,14 @@ int64_t plane(const WsLayout& w, int id) {
     return w.plane(id, &pitch);
 }
 
-size_t packed_floats(int D, bool bf16) {
-    if (bf16) return D == 256 ? (size_t)Layout<256, true>::packed_floats : (size_t)Layout<128, true>::packed_floats;
+size_t packed_floats(int D, int mode) {
+    if (mode == 2) return D == 256 ? (size_t)Layout<256, 2>::packed_floats : (size_t)Layout<128, 2>::packed_floats;
+    if (mode == 1) return D == 256 ? (size_t)Layout<256, 1>::packed_floats : (size_t)Layout<128, 1>::packed_floats;
     return D == 256 ? (size_t)Layout<256>::packed_floats : (size_t)Layout<128>::packed_floats;
 }
 bool is_bf16(const nnr_cfg* c) { return (c->flags & NNR_F_BF16) != 0; }
+bool is_split3(const nnr_cfg* c) { return (c->flags & (NNR_F_BF16 | NNR_F_SPLIT3)) == NNR_F_SPLIT3; }
+int weight_mode(const nnr_cfg* c) { return is_bf16(c) ? 1 : (is_split3(c) ? 2 : 0); }   // Layout<D, MODE>
 
 // Ray mode of the two MLP kernels (nnr_mlp_fwd.hip): a wave walks the N / 32 chunks of ONE ray, a workgroup four rays.  Needs whole
 // chunks per ray and whole workgroups; everything else runs the flat decomposition (same sample numbering, same planes).
@@ -445,7 +448,7 @@ int nnr_prof_end(float* mean_ms4, int32_t* launches4) {
 
 size_t nnr_packed_floats(const nnr_cfg* cfg) {
     if (check_cfg(cfg) != NNR_OK) return 0;
-    return packed_floats(cfg->hidden, is_bf16(cfg));
+    return packed_floats(cfg->hidden, weight_mode(cfg));
 }
 
 size_t nnr_workspace_floats(const nnr_cfg* cfg) {
@@ -521,7 +524,7 @@ int nnr_pack_weights(const nnr_cfg* cfg, const nnr_params* p, float* packed, voi
         a.b[i] = p->bias[i];
     }
     a.packed = packed;
-    hipError_t e = launch_pack(cfg->hidden, a, is_bf16(cfg), (hipStream_t)stream);
+    hipError_t e = launch_pack(cfg->hidden, a, weight_mode(cfg), (hipStream_t)stream);
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
@@ -556,7 +559,7 @@ static int mlp_fwd_impl(const nnr_cfg* cfg, const float* pts_o, const float* pts
     a.chunks_per_ray = chunks_per_ray(cfg);
     a.fuse_rgb = fuse_rgb; a.fuse_dist = fuse_dist; a.flags = cfg->flags;
     hipError_t e = is_bf16(cfg) ? launch_mlp_fwd_bf16(cfg->hidden, a, w.train, (hipStream_t)stream)
-                                : launch_mlp_fwd(cfg->hidden, a, w.train, (hipStream_t)stream);
+                                : launch_mlp_fwd(cfg->hidden, a, w.train, (hipStream_t)stream, is_split3(cfg));
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
@@ -626,7 +629,7 @@ int nnr_mlp_dgrad(const nnr_cfg* cfg, const float* packed, float* ws, void* stre
     a.S = w.S; a.S_pad = w.S_pad;
     a.chunks_per_ray = chunks_per_ray(cfg);
     hipError_t e = is_bf16(cfg) ? launch_mlp_dgrad_bf16(cfg->hidden, a, (hipStream_t)stream)
-                                : launch_mlp_dgrad(cfg->hidden, a, (hipStream_t)stream);
+                                : launch_mlp_dgrad(cfg->hidden, a, (hipStream_t)stream, is_split3(cfg));
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
@@ -682,7 +685,7 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const float* packed, const nnr_param_grads
     a.gb[kMergedLayer] = a.gw[kMergedLayer] + (size_t)(cfg->hidden / 2) * cfg->hidden;
     a.packed = packed;
     a.D = cfg->hidden;
-    a.bf16 = 0;
+    a.bf16 = weight_mode(cfg);   // 0 or 2 here: locates the merge area of the packed buffer for the un-merge step
     {
         const int D = cfg->hidden;
         const int rows[13] = {D, D, D, D, D, D, D, D, 1, D, D / 2, 3, D / 2};   // outputs of the 12 nn.Linear + the merged colour-hidden matrix

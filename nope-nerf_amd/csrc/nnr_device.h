@@ -42,9 +42,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 // W = waves of the workgroup that share the stream; each copies PW = 32 / W of a panel's 32 fragments (8 with the usual 4 waves).
-template <int W>
+// F = fragment slots (KiB) per panel: 32, or 24 in the three-term mode (nnr_layout.h, MODE 2).
+template <int W, int F_ = kPanelFrags>
 struct PanelPipeT {
-    static constexpr int PW = kPanelFrags / W;   // DMA pieces (1 KiB) per wave and panel
+    static constexpr int F = F_, F4 = F_ * 64;   // fragment slots / float4 elements per panel
+    static constexpr int PW = F / W;             // DMA pieces (1 KiB) per wave and panel
+    static_assert(F % W == 0 && PW >= 2 && PW <= 8 && PW % 2 == 0, "piece() addresses the pieces as immediates -PW/2 .. PW/2-1 around the middle one");
     const f32x4* src;  // stream base in global memory offset by this wave's fragment slice (wave-uniform: SGPRs)
     f32x4* lds;        // base of the three panel buffers in LDS
     int wave, lane;    // wave is wave-uniform (readfirstlane'd by the caller)
@@ -76,8 +79,8 @@ struct PanelPipeT {
         // instruction's signed 13-bit immediate, which offsets the global and the LDS address alike -- so a piece costs
         // one VMEM issue and no address arithmetic.
         const int ps = p < n_panels ? p : p - n_panels;
-        const f32x4* g = src + (int64_t)ps * kPanelF4 + (PW / 2) * 64 + lane;
-        f32x4* l = lds + buffer(p) * kPanelF4 + wave * (PW * 64) + (PW / 2) * 64;
+        const f32x4* g = src + (int64_t)ps * F4 + (PW / 2) * 64 + lane;
+        f32x4* l = lds + buffer(p) * F4 + wave * (PW * 64) + (PW / 2) * 64;
         switch (i - PW / 2) {   // the offset operand must be a literal
             case -4: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -4096, 0); break;
             case -3: __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, -3072, 0); break;

@@ -86,13 +86,30 @@ NNR_HD constexpr int part_gp(int MT) { return kPanelFrags / MT; }  // fragment r
 NNR_HD constexpr int part_rows(int KT, bool bf16) { return bf16 ? 2 * KT : 4 * KT; }
 NNR_HD constexpr int part_panels(int KT, int MT, bool bf16 = false) { return (part_rows(KT, bf16) + part_gp(MT) - 1) / part_gp(MT); }
 
-// BF16 = true: the packed weights of the bf16-MFMA mode (NNR_F_BF16).  A fragment is still 64 lanes x 16 bytes, but holds
+// ---- MODE 2: fp32 operands as THREE bf16 terms (NNR_F_SPLIT3; the kernels: nnr_split.h) -------------------------------------------------
+// CDNA4's matrix pipe multiplies bf16 sixteen times faster than fp32 (v_mfma_f32_32x32x16_bf16: 16 384 MACs in 32 cycles;
+// v_mfma_f32_32x32x2_f32: 2 048 in 64).  An fp32 number is the exact sum of three bf16 numbers -- h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m), 8 + 8 + 8 significand bits, the same exponent range -- so a product w x = sum over the nine term pairs, of which
+// the three smallest (w_m x_l, w_l x_m, w_l x_l: below 2^-24 |w x|, less than fp32's own rounding of the product) are dropped: SIX bf16
+// MFMAs, accumulated in fp32, replace the eight fp32 MFMAs of the same 16 k-values -- 2.7 times fewer matrix-pipe cycles for a result
+// that is as close to the exact product as the fp32 instruction's (measured against fp64: tests/test_gpu_split3.py).
+// The packed weights of this mode: fragment rows as in the bf16 mode (one per 16 k-values), but each row holds 3 * MT fragments -- the
+// l, m and h terms of the row, in that order (the order the kernels consume them in) -- and a panel is 24 fragment slots (24 KiB):
+// GP = 8 / MT whole rows.  Fragment (b, term t, mt) lives in panel b / GP, slot ((b % GP) * 3 + t) * MT + mt.
+constexpr int kSplitPanelFrags = 24;
+NNR_HD constexpr int mode_panel_frags(int mode) { return mode == 2 ? kSplitPanelFrags : kPanelFrags; }
+NNR_HD constexpr int mode_rows(int KT, int mode) { return mode ? 2 * KT : 4 * KT; }
+NNR_HD constexpr int mode_gp(int MT, int mode) { return mode == 2 ? kSplitPanelFrags / (3 * MT) : kPanelFrags / MT; }
+NNR_HD constexpr int mode_panels(int KT, int MT, int mode) { return (mode_rows(KT, mode) + mode_gp(MT, mode) - 1) / mode_gp(MT, mode); }
+
+// MODE = 1 (BF16): the packed weights of the bf16-MFMA mode (NNR_F_BF16).  A fragment is still 64 lanes x 16 bytes, but holds
 // 8 bf16 per lane: lane l of fragment (b, mt) has A[32*mt + (l&31)][16b + 4h + i] (i = 0..3), then [16b + 8 + 4h + i] with
 // h = l>>5 -- the two k-groups 2b, 2b+1 of the fp32 layout, which is exactly the order in which 8 consecutive activation
 // registers of a lane hold them, so one v_mfma_f32_32x32x16_bf16 consumes 8 registers (packed to bf16) against one fragment
 // (the k labelling inside an MFMA is arbitrary as long as A and B agree).  Biases, head tables and the merge area stay fp32.
-template <int D, bool BF16 = false>
+template <int D, int MODE = 0>   // 0: fp32 MFMA, 1: bf16 MFMA, 2: fp32 as three bf16 terms
 struct Layout {
+    static constexpr int panel_floats = mode_panel_frags(MODE) * 256;
     static constexpr int DT = D / 32;
     static constexpr int HT = D / 64;  // tiles of half a layer's outputs == tiles of the colour-hidden layer (D/2 wide)
     static_assert(D == 128 || D == 256, "hidden width must be 128 or 256");
@@ -122,19 +139,19 @@ struct Layout {
     // first panel of a part; the forward stream occupies panels [0, fwd_panels), the backward stream follows
     NNR_HD static constexpr int fwd_panel0(int p) {
         int o = 0;
-        for (int i = 0; i < p; ++i) o += part_panels(fwd(i).KT, fwd(i).MT, BF16);
+        for (int i = 0; i < p; ++i) o += mode_panels(fwd(i).KT, fwd(i).MT, MODE);
         return o;
     }
     static constexpr int fwd_panels = fwd_panel0(F_NPARTS);
     NNR_HD static constexpr int bwd_panel0(int p) {  // relative to the start of the backward stream
         int o = 0;
-        for (int i = 0; i < p; ++i) o += part_panels(bwd(i).KT, bwd(i).MT, BF16);
+        for (int i = 0; i < p; ++i) o += mode_panels(bwd(i).KT, bwd(i).MT, MODE);
         return o;
     }
     static constexpr int bwd_panels = bwd_panel0(B_NPARTS);
-    static constexpr int bwd_base = fwd_panels * kPanelFloats;  // float offset of the backward stream
+    static constexpr int bwd_base = fwd_panels * panel_floats;  // float offset of the backward stream
     // biases, each padded to a multiple of 32 floats: hidden 1..8, sigma, feature, colour hidden, rgb
-    static constexpr int bias_base = (fwd_panels + bwd_panels) * kPanelFloats;
+    static constexpr int bias_base = (fwd_panels + bwd_panels) * panel_floats;
     NNR_HD static constexpr int bias_off(int layer) {  // layer in state_dict order
         int o = bias_base;
         for (int i = 0; i < layer; ++i) o += bias_pad(i);

@@ -4,8 +4,10 @@
 // pre-activation gradient in the workspace for the weight-gradient kernel.  Same structure as the forward: one wave =
 // 32 samples, gradients stay in VGPRs between layers as MFMA B operands, A fragments are the transposed packed weights.
 // ReLU masks come from the 1-bit-per-activation stash written by the forward (32x less traffic than re-reading h).
+// MODE 2 (NNR_F_SPLIT3): every GEMM part's products as six bf16 MFMA terms (nnr_split.h), everything else unchanged.
 #include "nnr_device.h"
 #include "nnr_kernels.h"
+#include "nnr_split.h"
 
 namespace nnr {
 
@@ -50,27 +52,29 @@ __device__ __forceinline__ f32x4 enc_backward(const G& g, const float (&pv)[NR],
 
 NNR_TL_DECL(tl_dgrad)
 
-template <int D>
+template <int D, int MODE>
 __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     NNR_STAMP(tl_dgrad, 0);
-    using L = Layout<D>;
+    using L = Layout<D, MODE>;
+    using Pipe = PanelPipeT<kWavesPerBlock, mode_panel_frags(MODE)>;
+    constexpr int kRingF4 = kNBuf * Pipe::F4;
     constexpr int DT = L::DT, HT = L::HT;
     constexpr int HR = 16 * HT;              // registers of half a layer's outputs
     constexpr int NP = HR / 2;               // register pairs per half (the unit of hidden epilogue work)
     constexpr int HW = (HR + 31) / 32;       // mask words per half
-    constexpr int PP = part_panels(DT, HT);  // panels of one D x D/2 pass
+    constexpr int PP = mode_panels(DT, HT, MODE);  // panels of one D x D/2 pass
     const int lane0 = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
     // LDS: the panel ring of the transposed (backward) weight stream, a parking area for d(posenc) of the skip layer and
     // the head tables (density row, rgb rows, register order) -- one array, see PanelPipe in nnr_device.h
     constexpr int kPark = kWavesPerBlock * 8 * 64;
-    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kPark + (L::head_floats + 3) / 4];
-    float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4 + kPark);
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kRingF4 + kPark + (L::head_floats + 3) / 4];
+    float* const ltab = reinterpret_cast<float*>(smem + kRingF4 + kPark);
     for (int i = threadIdx.x; i < L::head_floats; i += 256) ltab[i] = a.packed[L::head_base + i];
     __syncthreads();   // before any DMA is in flight: the only full barrier of the kernel
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed + L::bwd_base) + wave_u * (8 * 64), smem, wave_u, lane0, L::bwd_panels};
+    Pipe pipe{reinterpret_cast<const f32x4*>(a.packed + L::bwd_base) + wave_u * (Pipe::PW * 64), smem, wave_u, lane0, L::bwd_panels};
     // flat or ray-mode decomposition, exactly as in mlp_fwd_kernel: in ray mode a wave walks the chunks of one ray and the transposed
     // weight stream wraps around from pass to pass
     const int n_pass = a.chunks_per_ray > 0 ? a.chunks_per_ray : 1;
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     pipe.lane = lane;
     const int half = lane >> 5;
     const int col = lane & 31;
-    f32x4* const de_lds = smem + kNBuf * kPanelF4 + wave * (8 * 64) + lane;
+    f32x4* const de_lds = smem + kRingF4 + wave * (8 * 64) + lane;
     const float* const wsig = ltab + half * (16 * DT);   // density row, this half's registers
     const float* const wrgb = ltab + 2 * 16 * DT;        // rgb rows: [(2c + half) * HR + r]
     const int64_t chunk = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * kWavesPerBlock + wave) * n_pass + pass
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     }   // pass
 }
 
-#if defined(NNR_TIMELINE) && defined(NNR_DGRAD_D) && NNR_DGRAD_D == 256
+#if defined(NNR_TIMELINE) && defined(NNR_DGRAD_D) && NNR_DGRAD_D == 256 && !defined(NNR_DGRAD_MODE)
 extern "C" int nnr_timeline_dgrad(unsigned long long* host32) {
     return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_dgrad), 32 * sizeof(unsigned long long));
 }
@@ -245,16 +249,20 @@ extern "C" int nnr_timeline_dgrad(unsigned long long* host32) {
 
 // one D per translation unit, see nnr_mlp_fwd.hip
 #ifdef NNR_DGRAD_D
+#ifndef NNR_DGRAD_MODE
+#define NNR_DGRAD_MODE 0
+#endif
 template <>
-hipError_t launch_mlp_dgrad_variant<NNR_DGRAD_D>(const MlpDgradArgs& a, hipStream_t st) {
+hipError_t launch_mlp_dgrad_variant<NNR_DGRAD_D, NNR_DGRAD_MODE>(const MlpDgradArgs& a, hipStream_t st) {
     dim3 grid((unsigned)(a.chunks_per_ray > 0 ? a.S_pad / kBlockSamples / a.chunks_per_ray : a.S_pad / kBlockSamples)), block(256);
     prof_before(PROF_DGRAD, st);
-    hipLaunchKernelGGL((mlp_dgrad_kernel<NNR_DGRAD_D>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((mlp_dgrad_kernel<NNR_DGRAD_D, NNR_DGRAD_MODE>), grid, block, 0, st, a);
     prof_after(PROF_DGRAD, st);
     return hipGetLastError();
 }
 #else
-hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st) {
+hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st, bool split3) {
+    if (split3) return D == 256 ? launch_mlp_dgrad_variant<256, 2>(a, st) : launch_mlp_dgrad_variant<128, 2>(a, st);
     return D == 256 ? launch_mlp_dgrad_variant<256>(a, st) : launch_mlp_dgrad_variant<128>(a, st);
 }
 #endif

@@ -9,8 +9,11 @@
 // Every D-wide layer runs as two half-output passes so that epilogues execute inside the MFMA stream (nnr_device.h).
 // HBM per sample: 4 B jitter in, 20 B out (+ the 9.4 KB activation stash when training, written once, never re-read here).
 // (fp32 products; the bf16-MFMA mode has its own kernel, nnr_mlp_fwd_bf16.hip)
+// MODE 2 (NNR_F_SPLIT3): the same kernel with every GEMM part's products taken as six bf16 MFMA terms -- only the weight stream (24 KiB
+// panels of pre-split fragments) and gemm_part (nnr_split.h) differ; 2.7 times fewer matrix-pipe cycles, fp32-equivalent results.
 #include "nnr_device.h"
 #include "nnr_kernels.h"
+#include "nnr_split.h"
 
 namespace nnr {
 
@@ -22,22 +25,24 @@ constexpr bool kAblateNoMask = false;
 
 NNR_TL_DECL(tl_fwd)
 
-template <int D, bool TRAIN>
+template <int D, bool TRAIN, int MODE>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 0);
-    using L = Layout<D>;
+    using L = Layout<D, MODE>;
+    using Pipe = PanelPipeT<kWavesPerBlock, mode_panel_frags(MODE)>;
+    constexpr int kRingF4 = kNBuf * Pipe::F4;
     constexpr int DT = L::DT, HT = L::HT;
     const int lane0 = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
     // ---- weight panels (LDS ring, DMA two panels ahead) and the bias / head tables, all in ONE __shared__ array. ----
     constexpr int kPark = kWavesPerBlock * 12 * 64;   // per wave 12 float4 slots per lane: posenc (8) + direnc (4)
-    __shared__ __attribute__((aligned(16))) f32x4 smem[kNBuf * kPanelF4 + kPark + (L::table_floats + 3) / 4];
-    float* const ltab = reinterpret_cast<float*>(smem + kNBuf * kPanelF4 + kPark);
+    __shared__ __attribute__((aligned(16))) f32x4 smem[kRingF4 + kPark + (L::table_floats + 3) / 4];
+    float* const ltab = reinterpret_cast<float*>(smem + kRingF4 + kPark);
     for (int i = threadIdx.x; i < L::table_floats; i += 256) ltab[i] = a.packed[L::bias_base + i];
     __syncthreads();   // before any DMA is in flight: this is the only full barrier of the kernel
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    PanelPipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave_u * (8 * 64), smem, wave_u, lane0, L::fwd_panels};
+    Pipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave_u * (Pipe::PW * 64), smem, wave_u, lane0, L::fwd_panels};
     // Work decomposition.  Flat (a.chunks_per_ray == 0): workgroup b takes the samples [128 b, 128 b + 128), wave w the 32 from
     // 32 w on -- one pass over the weight stream per workgroup.  Ray mode (N a multiple of 32, R a multiple of 4): workgroup b takes
     // the rays 4 b .. 4 b + 3, wave w ray 4 b + w, and walks its N / 32 chunks one after the other; the weight stream wraps around
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     pipe.lane = lane;
     const int half = lane >> 5;
     const int col = lane & 31;
-    f32x4* const park = smem + kNBuf * kPanelF4 + wave * (12 * 64) + lane;
+    f32x4* const park = smem + kRingF4 + wave * (12 * 64) + lane;
     const int64_t chunk_id = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * kWavesPerBlock + wave) * n_pass + pass
                                                    : (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const int64_t s = chunk_id * kChunk + col;                                     // this lane's sample
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     constexpr int HR = 16 * HT;              // registers of half a layer's outputs
     constexpr int NP = HR / 2;               // register pairs per half (the unit of hidden epilogue work)
     constexpr int HW = (HR + 31) / 32;       // mask words per half
-    constexpr int PP = part_panels(DT, HT);  // panels of one D x D/2 pass
+    constexpr int PP = mode_panels(DT, HT, MODE);  // panels of one D x D/2 pass
 
     float h[16 * DT];    // current layer input (activations of the previous layer), rewritten in place
     f32x16 accA[HT], accB[HT];   // halves A ([0,D/2)) and B ([D/2,D)) of the layer being computed
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     }   // pass
 }
 
-#if defined(NNR_TIMELINE) && defined(NNR_FWD_D) && NNR_FWD_D == 256 && NNR_FWD_TRAIN
+#if defined(NNR_TIMELINE) && defined(NNR_FWD_D) && NNR_FWD_D == 256 && NNR_FWD_TRAIN && !defined(NNR_FWD_MODE)
 extern "C" int nnr_timeline_fwd(unsigned long long* host32) {
     return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_fwd), 32 * sizeof(unsigned long long));
 }
@@ -329,18 +334,25 @@ extern "C" int nnr_timeline_fwd(unsigned long long* host32) {
 // csrc/build.py compiles this file once per variant (-DNNR_FWD_D=.. -DNNR_FWD_TRAIN=..) in parallel and once without the macros
 // for the dispatcher below.
 #ifdef NNR_FWD_D
+#ifndef NNR_FWD_MODE
+#define NNR_FWD_MODE 0
+#endif
 template <>
-hipError_t launch_mlp_fwd_variant<NNR_FWD_D, (NNR_FWD_TRAIN != 0)>(const MlpFwdArgs& a, hipStream_t st) {
+hipError_t launch_mlp_fwd_variant<NNR_FWD_D, (NNR_FWD_TRAIN != 0), NNR_FWD_MODE>(const MlpFwdArgs& a, hipStream_t st) {
     // ray mode: one workgroup per 4 rays, chunks_per_ray passes each; flat mode: one workgroup per 128 samples
     dim3 grid((unsigned)(a.chunks_per_ray > 0 ? a.S_pad / kBlockSamples / a.chunks_per_ray : a.S_pad / kBlockSamples)), block(256);
     constexpr bool train = NNR_FWD_TRAIN != 0;
     prof_before(train ? PROF_FWD_TRAIN : PROF_FWD_INFER, st);
-    hipLaunchKernelGGL((mlp_fwd_kernel<NNR_FWD_D, train>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((mlp_fwd_kernel<NNR_FWD_D, train, NNR_FWD_MODE>), grid, block, 0, st, a);
     prof_after(train ? PROF_FWD_TRAIN : PROF_FWD_INFER, st);
     return hipGetLastError();
 }
 #else
-hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st) {
+hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st, bool split3) {
+    if (split3) {
+        if (D == 256) return train ? launch_mlp_fwd_variant<256, true, 2>(a, st) : launch_mlp_fwd_variant<256, false, 2>(a, st);
+        return train ? launch_mlp_fwd_variant<128, true, 2>(a, st) : launch_mlp_fwd_variant<128, false, 2>(a, st);
+    }
     if (D == 256) return train ? launch_mlp_fwd_variant<256, true>(a, st) : launch_mlp_fwd_variant<256, false>(a, st);
     return train ? launch_mlp_fwd_variant<128, true>(a, st) : launch_mlp_fwd_variant<128, false>(a, st);
 }

@@ -9,7 +9,7 @@ namespace nnr {
 
 // W' = Wg[:, :D] Wf and b' = Wg[:, :D] bf + bg (nnr_layout.h), plus the copies the un-merge step of the weight-gradient pass
 // reads.  One thread per element of W'; products accumulated in index order with fma.
-template <int D, bool BF16>
+template <int D, int BF16>
 __global__ __launch_bounds__(256) void merge_kernel(PackArgs a) {
     using L = Layout<D, BF16>;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -34,14 +34,16 @@ __global__ __launch_bounds__(256) void merge_kernel(PackArgs a) {
     for (int i = gid; i < D * D; i += gridDim.x * blockDim.x) a.packed[L::copy_wf_off + i] = Wf[i];
 }
 
-template <int D, bool BF16>
+// MODE (= BF16 below): Layout<D, MODE> -- 0 fp32 fragments, 1 bf16 fragments, 2 three bf16 TERMS per weight (l, m, h fragments per row)
+template <int D, int BF16>
 __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     using L = Layout<D, BF16>;
+    constexpr int kFrags = mode_panel_frags(BF16);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per packed float4
     const int64_t n_frag4 = L::bias_base / 4;
     if (gid < n_frag4) {
-        const int panel = (int)(gid / (kPanelFrags * 64));   // global panel index (forward stream, then backward stream)
-        const int slot = (int)((gid / 64) % kPanelFrags);
+        const int panel = (int)(gid / (kFrags * 64));   // global panel index (forward stream, then backward stream)
+        const int slot = (int)((gid / 64) % kFrags);
         const int lane = (int)(gid & 63);
         // locate the part that owns this panel
         PartDesc pd{};
@@ -50,21 +52,23 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
 #pragma unroll
         for (int p = 0; p < F_NPARTS; ++p) {
             const PartDesc d = L::fwd(p);
-            const int np = part_panels(d.KT, d.MT, BF16);
+            const int np = mode_panels(d.KT, d.MT, BF16);
             if (!found && panel < base + np) { pd = d; found = true; }
             if (!found) base += np;
         }
 #pragma unroll
         for (int p = 0; p < B_NPARTS; ++p) {
             const PartDesc d = L::bwd(p);
-            const int np = part_panels(d.KT, d.MT, BF16);
+            const int np = mode_panels(d.KT, d.MT, BF16);
             if (!found && panel < base + np) { pd = d; found = true; }
             if (!found) base += np;
         }
-        const int gp = part_gp(pd.MT);
-        const int g = (panel - base) * gp + slot / pd.MT;   // fragment row: k-group (fp32) or double k-group (bf16)
+        const int gp = mode_gp(pd.MT, BF16);
+        constexpr int kTerms = BF16 == 2 ? 3 : 1;           // fragments per row and m-tile
+        const int g = (panel - base) * gp + slot / (kTerms * pd.MT);   // fragment row: k-group (fp32) or double k-group (bf16 modes)
+        const int term = (slot / pd.MT) % kTerms;          // MODE 2: 0 = l, 1 = m, 2 = h (the order the kernels consume them in)
         const int mt = slot % pd.MT;
-        const bool live = slot < gp * pd.MT && g < part_rows(pd.KT, BF16);
+        const bool live = slot < gp * kTerms * pd.MT && g < mode_rows(pd.KT, BF16);
         const int m = 32 * mt + (lane & 31);
         const float* W = a.w[pd.layer];
         auto elem = [&](int k) -> float {
@@ -72,7 +76,19 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
                 return pd.transpose ? W[(int64_t)(pd.koff + k) * pd.ld + pd.moff + m] : W[(int64_t)(pd.moff + m) * pd.ld + pd.koff + k];
             return 0.f;
         };
-        if constexpr (BF16) {   // 8 bf16: k = 16g + 4h + i, then 16g + 8 + 4h + i (nnr_layout.h)
+        if constexpr (BF16 == 2) {   // the fragment of ONE term: h = rn(w), m = rn(w - h), l = rn(w - h - m), differences exact in fp32
+            bf16x8 q;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float w = elem(16 * g + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3));
+                const __bf16 h = (__bf16)w;
+                const float r1 = w - (float)h;
+                const __bf16 m = (__bf16)r1;
+                const __bf16 l = (__bf16)(r1 - (float)m);
+                q[i] = term == 2 ? h : (term == 1 ? m : l);
+            }
+            reinterpret_cast<bf16x8*>(a.packed)[gid] = q;
+        } else if constexpr (BF16 == 1) {   // 8 bf16: k = 16g + 4h + i, then 16g + 8 + 4h + i (nnr_layout.h)
             bf16x8 q;
 #pragma unroll
             for (int i = 0; i < 8; ++i) q[i] = (__bf16)elem(16 * g + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3));
@@ -113,7 +129,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     }
 }
 
-template <int D, bool BF16>
+template <int D, int BF16>
 static hipError_t launch(const PackArgs& a0, hipStream_t st) {
     using L = Layout<D, BF16>;
     PackArgs a = a0;
@@ -126,9 +142,10 @@ static hipError_t launch(const PackArgs& a0, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_pack(int D, const PackArgs& a, bool bf16, hipStream_t st) {
-    if (bf16) return D == 256 ? launch<256, true>(a, st) : launch<128, true>(a, st);
-    return D == 256 ? launch<256, false>(a, st) : launch<128, false>(a, st);
+hipError_t launch_pack(int D, const PackArgs& a, int mode, hipStream_t st) {
+    if (mode == 2) return D == 256 ? launch<256, 2>(a, st) : launch<128, 2>(a, st);
+    if (mode == 1) return D == 256 ? launch<256, 1>(a, st) : launch<128, 1>(a, st);
+    return D == 256 ? launch<256, 0>(a, st) : launch<128, 0>(a, st);
 }
 
 }  // namespace nnr

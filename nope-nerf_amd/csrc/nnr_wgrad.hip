@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
 // Un-merge (nnr_layout.h): from dW' (D/2 x D) and db' of the merged matrix W' = Wg1 Wf, b' = Wg1 bf + bg, with Wg1 = Wg[:, :D]:
 //   dWf = Wg1^T dW'      dWg[:, :D] = dW' Wf^T + db' bf^T      dbf = Wg1^T db'      dbg = db'      (overwritten, like every gradient)
 // Two (D x D/2 x D) products per step, 0.03 % of the MFMA work of the pass: plain VALU dot products, one output per thread.
-template <int D, bool BF16>
+template <int D, int BF16>   // BF16 = the MODE of Layout<D, MODE>: where the merge area of the packed buffer sits
 __global__ __launch_bounds__(256) void wgrad_unmerge_kernel(WgradArgs a) {
     using L = Layout<D, BF16>;
     constexpr int Dh = L::Dh, ldg = D + kDirReal;
@@ -290,10 +290,15 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
 hipError_t launch_wgrad_unmerge(const WgradArgs& a, hipStream_t st) {
     const int threads = a.D * a.D + (a.D / 2) * a.D + a.D + a.D / 2;
     const dim3 grid((threads + 255) / 256), block(256);
-    if (a.D == 256 && a.bf16) hipLaunchKernelGGL((wgrad_unmerge_kernel<256, true>), grid, block, 0, st, a);
-    else if (a.D == 256) hipLaunchKernelGGL((wgrad_unmerge_kernel<256, false>), grid, block, 0, st, a);
-    else if (a.bf16) hipLaunchKernelGGL((wgrad_unmerge_kernel<128, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((wgrad_unmerge_kernel<128, false>), grid, block, 0, st, a);
+    if (a.D == 256) {
+        if (a.bf16 == 2) hipLaunchKernelGGL((wgrad_unmerge_kernel<256, 2>), grid, block, 0, st, a);
+        else if (a.bf16 == 1) hipLaunchKernelGGL((wgrad_unmerge_kernel<256, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wgrad_unmerge_kernel<256, 0>), grid, block, 0, st, a);
+    } else {
+        if (a.bf16 == 2) hipLaunchKernelGGL((wgrad_unmerge_kernel<128, 2>), grid, block, 0, st, a);
+        else if (a.bf16 == 1) hipLaunchKernelGGL((wgrad_unmerge_kernel<128, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wgrad_unmerge_kernel<128, 0>), grid, block, 0, st, a);
+    }
     return hipGetLastError();
 }
 

@@ -17,6 +17,24 @@ NNR_F_WHITE_BG = 2
 NNR_F_RELU_SIGMA = 4
 NNR_F_TRAIN = 8
 NNR_F_BF16 = 16
+NNR_F_SPLIT3 = 32
+
+# How the fp32 mode multiplies (include/nnr.h, NNR_F_SPLIT3): "split3" = every operand as three bf16 terms, six bf16 MFMAs per product
+# with fp32 accumulation -- fp32-equivalent results (tests/test_gpu_split3.py) at 2.7x fewer matrix-pipe cycles; "mfma" = fp32 MFMAs.
+_fp32_products = os.environ.get("NNR_FP32_PRODUCTS", "mfma")
+
+
+def set_fp32_products(kind: str) -> str:
+    """Select "split3" or "mfma" for every fp32-mode call made from now on; returns the previous setting."""
+    global _fp32_products
+    if kind not in ("split3", "mfma"):
+        raise ValueError(kind)
+    prev, _fp32_products = _fp32_products, kind
+    return prev
+
+
+def fp32_products() -> str:
+    return _fp32_products
 N_LAYERS = 12
 
 #: state_dict order of the 12 nn.Linear layers (reference model/official_nerf.py:20-37)
@@ -166,6 +184,8 @@ def make_cfg(n_rays: int, n_samples: int, hidden: int, *, dist_alpha=False, whit
              train=False, bf16=False) -> Cfg:
     flags = (NNR_F_DIST_ALPHA if dist_alpha else 0) | (NNR_F_WHITE_BG if white_bg else 0) | \
             (NNR_F_RELU_SIGMA if relu_sigma else 0) | (NNR_F_TRAIN if train else 0) | (NNR_F_BF16 if bf16 else 0)
+    if not bf16 and _fp32_products == "split3":
+        flags |= NNR_F_SPLIT3
     return Cfg(int(n_rays), int(n_samples), int(hidden), flags)
 
 

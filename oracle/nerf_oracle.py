@@ -119,7 +119,7 @@ def pixel_grid(h: int, w: int) -> torch.Tensor:
     p = torch.stack([xs, ys], dim=-1).reshape(1, -1, 2).float()
     p[..., 0] = 2.0 * p[..., 0] / (w - 1) - 1.0
     p[..., 1] = 2.0 * p[..., 1] / (h - 1) - 1.0
-    return p
+    return p.to(torch.get_default_dtype())      # the fp32 values, whatever dtype the caller evaluates the rest in (fp64 ground truths)
 
 
 def unproject(pixels: torch.Tensor, depth: torch.Tensor, camera_mat, world_mat, scale_mat) -> torch.Tensor:
