@@ -53,6 +53,9 @@ EXECUTED_MACS_PER_SAMPLE = {D: 64 * D + 3 * D * D + (D + 64) * D + 3 * D * D + D
 PEAK_FP32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0               # dense bf16 MFMA (not the 2:1-sparsity headline figure)
 PEAK_HBM_GBS = 8000.0                        # HBM3E
+FP32_HOW = {'mfma': 'fp32 (fp32 MFMAs)',
+            'split3': 'fp32 results: forward / input-gradient products as six bf16 MFMA terms of three-term operands, fp32 accumulate '
+                      '(as close to fp64 as fp32 MFMAs: tests/test_gpu_split3.py); weight gradient on fp32 MFMAs'}
 
 
 def full_cfg(rays_total, aux=False, bf16=False, n_samples=None, hidden=None):
@@ -242,7 +245,17 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
                 'bytes_per_launch': byts[dom] * R * N, 'kernels': per, 'fused_mlp_all_three': three}
     traffic, src = _hbm_traffic(dom, False, (R, N))
     three['frac'] = round(three['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4)
+    products = L.fp32_products()
+    if products == 'split3':
+        # forward / input gradient: every fp32 product as six bf16 MFMA terms (csrc/nnr_split.h) -- their bound is the bf16 matrix pipe,
+        # and the work they issue is 6 x the executed MACs; the weight gradient still runs on fp32 MFMAs
+        for k in ('mlp_fwd', 'mlp_dgrad', 'mlp_fwd_infer'):
+            issued = 6 * executed / (times[k] * 1e-3) / 1e12
+            per[k].update(mfma='bf16, 6 terms per fp32 product', issued_bf16_tflops=round(issued, 1),
+                          frac_of_bf16_mfma_peak=round(issued / PEAK_BF16_MFMA_TFLOPS, 4))
+        per['mlp_wgrad']['mfma'] = 'fp32'
     return {
+        'fp32_products': products,
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': src, 'timing': how,
         'flop_per_launch': flops, 'executed_flop_per_launch': executed, 'executed_tflops': round(executed / (times[dom] * 1e-3) / 1e12, 2),
@@ -420,15 +433,28 @@ def _timed_steps(trainer, data, warmup, steps, use_dist):
     return elapsed, float(ld['loss'].detach()), in_step
 
 
-def extra_config(device, name, rays, n_samples, bf16, steps=10, warmup=3):
-    """One more BASELINE configuration measured in the same run on one GPU: full Trainer.train_step + the kernels' roofline."""
+def extra_config(device, name, rays, n_samples, bf16, steps=10, warmup=3, products=None):
+    """One more BASELINE configuration measured in the same run on one GPU: full Trainer.train_step + the kernels' roofline.
+    products: 'mfma' / 'split3' for this block only (nnr.lib.set_fp32_products)."""
+    from nnr import lib as L
+    prev = L.set_fp32_products(products) if products else None
+    try:
+        return _extra_config(device, name, rays, n_samples, bf16, steps, warmup)
+    finally:
+        if prev:
+            L.set_fp32_products(prev)
+
+
+def _extra_config(device, name, rays, n_samples, bf16, steps, warmup):
+    from nnr import lib as L
     trainer, net = build_trainer(device, 1, False, bf16, rays, n_samples)
     data = synthetic_batch(device)
     elapsed, loss, in_step = _timed_steps(trainer, data, warmup, steps, False)
     ms = elapsed / steps * 1e3
     roof = kernel_roofline(net, device, reps=3, bf16=bf16, rays=rays, n_samples=n_samples, in_step=in_step)
     out = {'workload': name, 'rays_per_gpu': rays, 'n_samples': n_samples, 'hidden': HIDDEN,
-           'dtype': 'bf16 products / f32 accumulate' if bf16 else 'f32', 'steps': steps, 'warmup': warmup,
+           'dtype': 'bf16 products / f32 accumulate' if bf16 else 'f32', 'fp32_products': None if bf16 else L.fp32_products(),
+           'steps': steps, 'warmup': warmup,
            'ms_per_step': round(ms, 4), 'value': round(rays / (ms * 1e-3), 1), 'unit': 'rays/s', 'final_loss': round(loss, 6),
            'roofline': {k: roof[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'timing')},
            'kernels_ms': {k: v['ms'] for k, v in roof['kernels'].items()},
@@ -547,6 +573,8 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         rays = R * world
+        from nnr import lib as nnr_lib
+        fp32_products = nnr_lib.fp32_products()
         headline = (R, N) == (R_PER_GPU, N_SAMPLES) and not args.bf16
         what = ('BASELINE configs[1]: 1024 rays/GPU x 192 samples (64 coarse + 128 fine pinned as one 192-sample stratified pass)'
                 if headline else f'{R} rays/GPU x {N} samples')
@@ -554,8 +582,9 @@ def main():
             'metric': 'training rays/sec', 'value': round(rays / (ms * 1e-3), 1), 'unit': 'rays/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 products / f32 accumulate' if args.bf16 else 'f32', 'data': 'synthetic',
-            'config': {'workload': what + ', 8-layer-256 MLP, pose + distortion learnable, ' + ('bf16 MFMA' if args.bf16 else 'fp32') +
+            'config': {'workload': what + ', 8-layer-256 MLP, pose + distortion learnable, ' + ('bf16 MFMA' if args.bf16 else FP32_HOW[fp32_products]) +
                                    '; full Trainer.train_step incl. 3 Adam steps; aux per-image losses ' + ('ON (pc + rgb_s)' if args.aux else 'off'),
+                       'fp32_products': None if args.bf16 else fp32_products,
                        'rays_per_gpu': R, 'n_samples': N, 'hidden': HIDDEN, 'image': [IMG_H, IMG_W],
                        'parallelism': f'dp{world} (ray-sharded, one flat all-reduce)'},
             'final_loss': round(loss_val, 6),
@@ -573,6 +602,9 @@ def main():
                                               4096, 128, True),
                 'fp32_1024x128': extra_config(device, "the reference's stock default: 1024 rays x 128 samples (configs/default.yaml:37,76), fp32",
                                               1024, 128, False),
+                # the headline shape with v_mfma_f32_32x32x2_f32 products in all three kernels (the fp32 path of rounds 1-2)
+                'fp32_mfma_1024x192': extra_config(device, 'BASELINE configs[1] with fp32-MFMA products (NNR_FP32_PRODUCTS=mfma)',
+                                                   R_PER_GPU, N_SAMPLES, False, products='mfma') if fp32_products != 'mfma' else None,
                 'cpu_32x64_d128': None if args.no_cpu_baseline else cpu_config0(),
             }
         print(json.dumps(out), flush=True)

@@ -58,6 +58,9 @@ struct PanelPipeT {
     // next pass; `phase` = (panels of the earlier passes) % kNBuf keeps the ring position running across passes.
     int phase = 0;
     bool more = false;   // another pass follows this one
+    // three-term kernels (nnr_split.h): stash stores the part BEFORE the next one certainly issued after the last DMA piece of that
+    // part's first panel (set by the kernel right before the call: a literal, folded after inlining; see enter<EXTRA>)
+    int part_pre = 0;
 
     __device__ __forceinline__ int buffer(int p) const {   // ring slot of panel p of the current pass (p compile-time in the callers)
         const int b = p % kNBuf + phase;

@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     [&](int u) __attribute__((always_inline)) {                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
             const int r = 2 * u + i;                                                                         \
-            d[(OFF) + r] = ((MW[r >> 5] >> (r & 31)) & 1u) ? ACC[r >> 4][r & 15] : 0.f;                      \
+            /* the gate bit as an all-ones / zero AND mask (one signed bit-field extract), not compare + select */ \
+            d[(OFF) + r] = __uint_as_float(__float_as_uint(ACC[r >> 4][r & 15]) &                             \
+                                           (uint32_t)((int32_t)(MW[r >> 5] << (31 - (r & 31))) >> 31));       \
         }                                                                                                    \
     }
 #define NNR_MOVE_PAIR(ACC, OFF)                                                                              \
@@ -190,7 +192,9 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
         load_mask(mwB, mask_idx, 1);
         zero_acc(accB);
         // pass B: half A of the new gradient replaces d[0,HR) in place, one k-group behind the reads
+        pipe.part_pre = MODE == 2 && PP >= 2 ? 6 : 0;   // pass A's last rows stashed (nnr_split.h)
         gemm_part<DT, HT, false, NP, 2, 1>(accB, d, pipe, pa + PP, nullptr, NNR_SEL_PAIR(accA, 0, mwA));
+        pipe.part_pre = 0;
     };
     // hidden 8,7,6 -> d pre-activation of 7,6,5
 #pragma unroll 1

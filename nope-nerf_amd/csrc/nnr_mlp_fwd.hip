@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
             const int r = 2 * u + i;                                                                         \
             const float x = ACC[r >> 4][r & 15];                                                             \
             h[(OFF) + r] = relu1(x);                                                                         \
-            if (TRAIN && !kAblateNoMask) MW[r >> 5] |= x > 0.f ? (1u << (r & 31)) : 0u;                      \
+            /* (x > 0) == (relu(x) != 0): as integers, min(bits, 1) shifted into place -- two instructions  */ \
+            if (TRAIN && !kAblateNoMask) MW[r >> 5] |= min(__float_as_uint(h[(OFF) + r]), 1u) << (r & 31);    \
         }                                                                                                    \
     }
 #define NNR_MOVE_PAIR(ACC, OFF)                                                                              \
@@ -184,7 +185,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         init_acc(accB, L::bias_off(li) + L::Dh);
         clear_mask(mwA);
         // pass B: half A of the new layer replaces h[0,HR) in place, one k-group behind the reads
+        pipe.part_pre = TRAIN && MODE == 2 && PP >= 2 ? 6 : 0;   // pass A's last rows stashed (nnr_split.h)
         gemm_part<DT, HT, false, NP, 2, 1>(accB, h, pipe, pa + PP, nullptr, NNR_RELU_PAIR(accA, 0, mwA));
+        pipe.part_pre = 0;
         store_mask(mwA, li, 0);
     };
     // hidden 2..4

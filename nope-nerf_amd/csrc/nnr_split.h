@@ -46,6 +46,82 @@ __device__ __forceinline__ void wait_lgkm_n(f32x4& frag, int n) {
     }
 }
 
+// the same for all MT fragments of a class at once (one wait, one compiler-inserted s_nop)
+template <int MT>
+__device__ __forceinline__ void wait_class(f32x4 (&f)[MT], int n) {
+#ifdef NNR_SPLIT_SAFE_SYNC
+    n = 0;
+#endif
+    switch (n) {
+#define NNR_WC(k)                                                                                                                 \
+    case k:                                                                                                                       \
+        if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(" #k ")" : "+v"(f[0]));                                            \
+        else if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(" #k ")" : "+v"(f[0]), "+v"(f[1]));                           \
+        else asm volatile("s_waitcnt lgkmcnt(" #k ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));                          \
+        break;
+        NNR_WC(0) NNR_WC(1) NNR_WC(2) NNR_WC(4)
+#undef NNR_WC
+        default:
+            if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[0]));
+            else if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[0]), "+v"(f[1]));
+            else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+            break;
+    }
+}
+
+// ---- where the work of a row goes ----------------------------------------------------------------------------------------------------
+// One wave per SIMD hides about five 4-cycle instructions under each 32-cycle MFMA and pays for every further one
+// (tools/ubench/mfma_valu_overlap.hip), so what matters is not how much a row carries besides its 6 MT MFMAs but how EVENLY it is spread
+// over the 6 MT gaps.  The work is cut into small operations -- the three dependent stages of a pair's split (5, 5 and 1 instructions),
+// the stash stores, the DMA burst, the side units -- listed in an order that interleaves the kinds, and a compile-time pass assigns each to
+// the first gap whose instruction budget it still fits in (the fragment refills are fixed: one ds_read in each gap after a term-0 / 2 /
+// 5 MFMA, a counted wait in front of the first MFMA of each fragment class).
+struct RowOp { int kind, idx, cost; };      // kind 0: split stage A of pair idx, 1: stage B, 2: stage C, 3: stash store idx, 4: DMA, 5: side unit idx
+template <int NOPS, int NM>
+struct RowSched { RowOp op[NOPS]; int gap[NOPS]; };
+
+template <int MT, bool STASH, int NUNITS, int UCOST>
+constexpr auto make_row_sched() {
+    constexpr int NM = 6 * MT, NOPS = 12 + (STASH ? 2 : 0) + 1 + NUNITS;
+    RowSched<NOPS, NM> r{};
+    // the split stages in order A0..A3, B0..B3, C0..C3 (stage k + 1 of a pair well after stage k), everything else merged in between
+    RowOp x[12] = {}, y[3 + NUNITS + 1] = {};
+    for (int i = 0; i < 12; ++i) x[i] = RowOp{i / 4, i % 4, i < 8 ? 5 : 1};
+    int ny = 0;
+    for (int u = 0; u < NUNITS; ++u) {
+        y[ny++] = RowOp{5, u, UCOST};
+        if (STASH && (u == NUNITS / 4 || u == (3 * NUNITS) / 4)) y[ny] = RowOp{3, u == NUNITS / 4 ? 0 : 1, 2}, ++ny;
+        if (u == NUNITS / 2) y[ny++] = RowOp{4, 0, 4};
+    }
+    if (NUNITS == 0) {
+        if (STASH) y[ny++] = RowOp{3, 0, 2};
+        y[ny++] = RowOp{4, 0, 4};
+        if (STASH) y[ny++] = RowOp{3, 1, 2};
+    }
+    int n = 0, ix = 0, iy = 0;
+    while (ix < 12 || iy < ny) {      // merge by fractional position
+        const bool take_x = iy >= ny || (ix < 12 && (2 * ix + 1) * ny <= (2 * iy + 1) * 12);
+        r.op[n++] = take_x ? x[ix++] : y[iy++];
+    }
+    int total = 0, fixed[NM] = {};
+    for (int j = 0; j < NM; ++j) {
+        const int t = j / MT;
+        fixed[j] = (t == 0 || t == 2 || t == 5) ? 1 : 0;      // the refill read
+        if (j % MT == 0 && (t == 0 || t == 1 || t == 3)) fixed[j > 0 ? j - 1 : 0] += 2;   // the counted wait (+ s_nop) in front of MFMA j
+        total += fixed[j];
+    }
+    for (int i = 0; i < NOPS; ++i) total += r.op[i].cost;
+    const int cap = (total + NM - 1) / NM;
+    // the DMA burst must come after the panel switch in gap 0: start filling at gap 1
+    int j = 1, load = fixed[1 < NM ? 1 : 0];
+    for (int i = 0; i < NOPS; ++i) {
+        while (j < NM - 1 && load > 0 && load + r.op[i].cost > cap + 1) { ++j; load = fixed[j]; }
+        r.gap[i] = j;
+        load += r.op[i].cost;
+    }
+    return r;
+}
+
 // acc[mt] += A_part[32 mt .., :] * in, the products as six bf16 terms.  Same contract as gemm_part (nnr_device.h) -- `in` in fragment
 // layout, the optional row-major fp32 stash of `in`, NSIDE side units at PPG per k-group of 8 (so 2 PPG per row here) starting at
 // k-group SHIFT -- with one difference the callers already respect: a row's eight registers are READ (split) while the row before it
@@ -55,8 +131,7 @@ __device__ __forceinline__ void wait_lgkm_n(f32x4& frag, int n) {
 //     t0 (l, h)   t1 (m, m)   t2 (m, h)   t3 (h, l)   t4 (h, m)   t5 (h, h)
 // so the l fragments are free after t0, the m fragments after t2, the h fragments after t5: each is refilled IN PLACE for the next row
 // right after its last MFMA (reads in the order l, m, h -- the order of first use), which gives every read at least 3 MT MFMAs to land.
-// The other work of a row -- the split of the next row (4 pairs), two stash stores, the DMA pieces, 2 PPG side units -- is spread over
-// the 3 MT gaps that hold no refill.
+// UCOST: instructions of one side unit, for the balance of the gaps (see above).
 template <int KT, int MT, bool STASH, int NSIDE_, int PPG, int SHIFT, class Side, int NACC, int NIN>
 __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const SplitPipe& pipe, int p0, float* stash,
                                           const Side& side) {
@@ -67,13 +142,19 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
 #endif
     static_assert(MT <= NACC && 16 * KT <= NIN, "tile counts exceed the register arrays");
     static_assert(!(STASH && SHIFT != 0), "a part that stashes its input must not rewrite it");
+    static_assert(MT == 1 || MT == 2 || MT == 4, "m-tiles per part");
     constexpr int G = 2 * KT, GP = mode_gp(MT, 2), NM = 6 * MT, PW = SplitPipe::PW;
     auto wcls = [](int t) { return t == 0 ? 0 : (t < 3 ? 1 : 2); };             // term -> class (0 = l, 1 = m, 2 = h) of the weights ...
     auto xcls = [](int t) { return t == 0 ? 2 : (t == 1 ? 1 : (t == 2 ? 2 : t - 3)); };   // ... and of the activations
     auto rows_in = [](int pi) { return (G - pi * GP) < GP ? (G - pi * GP) : GP; };
     auto ppk_of = [&](int pi) { return (PW + rows_in(pi) - 1) / rows_in(pi); };
-    constexpr int NFREE = 3 * MT;                                              // gaps without a refill: terms 1, 3, 4
-    constexpr int NWORK = 4 + (STASH ? 2 : 0) + 1 + (NSIDE > 0 ? 2 * PPG : 0);  // split pairs, stash stores, DMA, side units
+    constexpr int ppk_full = (PW + GP - 1) / GP;      // pieces per row of a full panel
+    constexpr int NUNITS = NSIDE > 0 ? 2 * PPG : 0;
+#ifndef NNR_SPLIT_UCOST
+#define NNR_SPLIT_UCOST 7
+#endif
+    constexpr auto sched = make_row_sched<MT, STASH, NUNITS, NNR_SPLIT_UCOST>();
+    constexpr int NOPS = 12 + (STASH ? 2 : 0) + 1 + NUNITS;
 
     // the stash address as (wave-uniform base in scalar registers) + (32-bit lane offset): a 64-bit per-lane pointer kept across the
     // part is spilled at this register pressure, and its reload is a VMEM load that drains the store / DMA queues
@@ -87,7 +168,14 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
         stash_base = reinterpret_cast<const char*>(b);
         stash_off = (int)(p - b);
     }
-    pipe.enter(p0);
+    // Entering the part's first panel.  Its pieces were issued while the previous part consumed its second-to-last panel; if that part
+    // stashed, the stores of its last rows (pipe.part_pre of them, told by the kernel) are younger and may stay in flight -- without
+    // this, every pass that follows a stashing pass starts with a full drain of the store queue (an HBM write latency, matrix pipe idle).
+#ifndef NNR_SPLIT_SAFE_SYNC
+    if (pipe.part_pre == 6) pipe.enter<6>(p0);
+    else
+#endif
+        pipe.enter(p0);
     pipe.pieces(p0 + 2, 0, ppk_of(0));
     const unsigned lane_base = lds_byte_address(pipe.lds) + 16u * pipe.lane;
     unsigned panel_addr = lane_base + pipe.buffer(p0) * (SplitPipe::F4 * 16);
@@ -97,6 +185,7 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) fr[c][mt] = frag_read(panel_addr, c * MT + mt);
     uint32_t xs[3][4], xn[3][4];   // [class][pair]: the packed B operands of the current / next row
+    float r0[4], r1[4];            // the residuals of the next row's pairs between the split stages
 #pragma unroll
     for (int q = 0; q < 4; ++q) split_pair(in[2 * q], in[2 * q + 1], xs[2][q], xs[1][q], xs[0][q]);
 
@@ -107,11 +196,12 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
         for (int j = 0; j < NM; ++j) {
             const int t = j / MT, mt = j % MT, wc = wcls(t), xc = xcls(t);
             __builtin_amdgcn_sched_barrier(0);
-            // first use of a fragment in this row: it has landed when at most the reads issued after it are outstanding -- the rest of
-            // the previous row's refills (order l, m, h) plus this row's refills so far (none in the last row)
-            if (t == 0) wait_lgkm_n(fr[0][mt], last ? 3 * MT - 1 - mt : 3 * MT - 1);
-            else if (t == 1) wait_lgkm_n(fr[1][mt], (last ? 2 * MT : 3 * MT) - 1 - mt);
-            else if (t == 3) wait_lgkm_n(fr[2][mt], (last ? MT : 3 * MT) - 1 - mt);
+            // first MFMA of a fragment class in this row: ALL its fragments have landed when at most the reads issued after the class's
+            // last one are outstanding -- the later classes of the previous row's refills (order l, m, h) plus this row's refills so far
+            // (none in the last row).  One wait per class, not per fragment: 3 instead of 3 MT (each drags an s_nop along).
+            if (mt == 0 && t == 0) wait_class<MT>(fr[0], 2 * MT);
+            else if (mt == 0 && t == 1) wait_class<MT>(fr[1], last ? MT : 2 * MT);
+            else if (mt == 0 && t == 3) wait_class<MT>(fr[2], last ? 0 : 2 * MT);
             if (NNR_SPLIT_TERMS == 6 || (NNR_SPLIT_TERMS == 3 && (t == 2 || t >= 4)) || (NNR_SPLIT_TERMS == 1 && t == 5))
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[wc][mt]),
                                                               __builtin_bit_cast(bf16x8, u32x4{xs[xc][0], xs[xc][1], xs[xc][2], xs[xc][3]}),
@@ -125,44 +215,67 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
 #ifdef NNR_SPLIT_SAFE_SYNC
                     pipe.enter<0>(pn);
 #else
-                    pipe.enter<STASH ? 2 * (GP - 1) : 0>(pn);
-#endif   // this panel's earlier rows' stash stores are younger than the pieces waited for
+                    // Stash stores younger than the pieces waited for may stay in flight: those of this panel's earlier rows -- and, from
+                    // the part's third panel on, those the panel BEFORE issued after the last burst of pn's pieces (pn's pieces go out
+                    // while the panel two back is consumed: first burst in the row before it, then ppk per row).  Every store that must
+                    // be waited for is then at least GP + 1 rows old instead of 1: the switch no longer waits out HBM write latency.
+                    constexpr int kLastBurstRow = (PW + ppk_full - 1) / ppk_full - 2;
+                    constexpr int kExtraNear = 2 * (GP - 1), kExtraFar = kExtraNear + 2 * (GP - 1 - kLastBurstRow);
+                    if ((g + 1) / GP >= 2) pipe.enter<STASH ? kExtraFar : 0>(pn);
+                    else pipe.enter<STASH ? kExtraNear : 0>(pn);
+#endif
                     panel_addr = lane_base + pipe.buffer(pn) * (SplitPipe::F4 * 16);
                 }
                 fr[wc][mt] = frag_read(panel_addr, (((g + 1) % GP) * 3 + wc) * MT + mt);
             }
-            // everything else, in the gaps without a refill
-            const int fj = t == 1 ? mt : (t == 3 ? MT + mt : (t == 4 ? 2 * MT + mt : -1));
-            if (fj >= 0) {
+            // everything else, where the row's schedule puts it
 #pragma unroll
-                for (int i = 0; i < NWORK; ++i) {
-                    if ((i * NFREE) / NWORK != fj) continue;
-                    int k = i;
-                    if (k < 4) {                       // split of pair k of the next row
-                        if (!last) split_pair(in[8 * (g + 1) + 2 * k], in[8 * (g + 1) + 2 * k + 1], xn[2][k], xn[1][k], xn[0][k]);
-                        continue;
+            for (int i = 0; i < NOPS; ++i) {
+                if (sched.gap[i] != j) continue;
+                const int kind = sched.op[i].kind, k = sched.op[i].idx;
+                if (kind == 0) {            // split of pair k of the next row, stage A: h, and what it leaves
+#ifdef NNR_ABLATE_NO_SPLIT
+                    if (!last) { xn[2][k] = xs[2][k]; xn[1][k] = xs[1][k]; xn[0][k] = xs[0][k]; }   // profiling build only
+#else
+                    if (!last) {
+                        const float x0 = in[8 * (g + 1) + 2 * k], x1 = in[8 * (g + 1) + 2 * k + 1];
+                        xn[2][k] = pack_bf16(x0, x1);
+                        r0[k] = x0 - __uint_as_float(xn[2][k] << 16);
+                        r1[k] = x1 - __uint_as_float(xn[2][k] & 0xffff0000u);
                     }
-                    k -= 4;
-                    if (STASH) {
-                        if (k < 2) {
-#ifndef NNR_ABLATE_NO_STASH
-                            *reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + stash_off + 32 * (2 * g + k)) =
-                                f32x4{in[8 * g + 4 * k], in[8 * g + 4 * k + 1], in[8 * g + 4 * k + 2], in[8 * g + 4 * k + 3]};
+                } else if (kind == 1) {     // stage B: m, and what it leaves
+                    if (!last) {
+                        xn[1][k] = pack_bf16(r0[k], r1[k]);
+                        r0[k] = r0[k] - __uint_as_float(xn[1][k] << 16);
+                        r1[k] = r1[k] - __uint_as_float(xn[1][k] & 0xffff0000u);
+                    }
+                } else if (kind == 2) {     // stage C: l
+                    if (!last) xn[0][k] = pack_bf16(r0[k], r1[k]);
 #endif
-                            continue;
-                        }
-                        k -= 2;
+                } else if (kind == 3) {
+                    if constexpr (STASH) {
+#ifndef NNR_ABLATE_NO_STASH
+#ifdef NNR_SPLIT_TILE_STASH     // experiment (WRONG layout, timing only): one contiguous 1 KiB block per store
+                        f32x4* const dst = reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + 1024 * (2 * g + k) + 16 * pipe.lane);
+#else
+                        f32x4* const dst = reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + stash_off + 32 * (2 * g + k));
+#endif
+                        const f32x4 val = f32x4{in[8 * g + 4 * k], in[8 * g + 4 * k + 1], in[8 * g + 4 * k + 2], in[8 * g + 4 * k + 3]};
+#ifdef NNR_SPLIT_NT_STASH
+                        __builtin_nontemporal_store(val, dst);   // experiment: keep the 1.9 GB of stash out of the L2's way
+#else
+                        *dst = val;
+#endif
+#endif
                     }
-                    if (k == 0) {                      // DMA pieces of the panel two ahead, spread over the rows of the current panel
-                        const int pi = g / GP, gi = g % GP;
-                        if (gi == rows_in(pi) - 1) {
-                            if (!last) pipe.pieces(p0 + pi + 3, 0, ppk_of(pi + 1));   // this row entered panel pi + 1 above
-                        } else {
-                            pipe.pieces(p0 + pi + 2, (gi + 1) * ppk_of(pi), ppk_of(pi));
-                        }
-                        continue;
+                } else if (kind == 4) {     // DMA pieces of the panel two ahead, spread over the rows of the current panel
+                    const int pi = g / GP, gi = g % GP;
+                    if (gi == rows_in(pi) - 1) {
+                        if (!last) pipe.pieces(p0 + pi + 3, 0, ppk_of(pi + 1));   // this row entered panel pi + 1 above
+                    } else {
+                        pipe.pieces(p0 + pi + 2, (gi + 1) * ppk_of(pi), ppk_of(pi));
                     }
-                    k -= 1;
+                } else {
                     if constexpr (NSIDE > 0) {
                         const int u = (2 * g - SHIFT) * PPG + k;
                         if (u >= 0 && u < NSIDE) side(u);

@@ -19,9 +19,10 @@ NNR_F_TRAIN = 8
 NNR_F_BF16 = 16
 NNR_F_SPLIT3 = 32
 
-# How the fp32 mode multiplies (include/nnr.h, NNR_F_SPLIT3): "split3" = every operand as three bf16 terms, six bf16 MFMAs per product
-# with fp32 accumulation -- fp32-equivalent results (tests/test_gpu_split3.py) at 2.7x fewer matrix-pipe cycles; "mfma" = fp32 MFMAs.
-_fp32_products = os.environ.get("NNR_FP32_PRODUCTS", "mfma")
+# How the fp32 mode multiplies in the forward and input-gradient kernels (include/nnr.h, NNR_F_SPLIT3): "split3" = every operand as three
+# bf16 terms, six bf16 MFMAs per product with fp32 accumulation -- as close to the exact result as the fp32 instruction
+# (tests/test_gpu_split3.py, against fp64) at 2.7x fewer matrix-pipe cycles; "mfma" = v_mfma_f32_32x32x2_f32 (NNR_FP32_PRODUCTS=mfma).
+_fp32_products = os.environ.get("NNR_FP32_PRODUCTS", "split3")
 
 
 def set_fp32_products(kind: str) -> str:

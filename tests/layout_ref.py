@@ -79,6 +79,80 @@ def pack_part(A, KT, MT):
     return out.reshape(-1)
 
 
+# ---- MODE 2 of nnr_layout.h: every weight as three bf16 terms (NNR_F_SPLIT3) ----------------------------------------------------------
+SPLIT_PANEL_FRAGS = 24
+
+
+def bf16_rn(x):
+    """fp32 -> the nearest bf16 (ties to even), returned as fp32 (low 16 bits zero)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)
+    return r.view(np.float32)
+
+
+def split3(x):
+    """(l, m, h): h = rn(x), m = rn(x - h), l = rn(x - h - m); the differences are exact in fp32 (csrc/nnr_split.h, nnr_pack.hip)."""
+    x = np.asarray(x, dtype=np.float32)
+    h = bf16_rn(x)
+    r1 = (x - h).astype(np.float32)
+    m = bf16_rn(r1)
+    l = bf16_rn((r1 - m).astype(np.float32))
+    return l, m, h
+
+
+def pack_part_split(A, KT, MT):
+    """Panelised fragments of one part in MODE 2, as the fp32 words the pack kernel writes: [n_panels][24 slots][64 lanes][4 words];
+    fragment row b = 16 k-values lives in panel b // GP (GP = 8 // MT), term t (0 = l, 1 = m, 2 = h) and m-tile mt in slot
+    ((b % GP) * 3 + t) * MT + mt; lane l holds 8 bf16: A[32 mt + (l & 31)][16 b + 8 (i >> 2) + 4 (l >> 5) + (i & 3)], i = 0..7, two per
+    word (even i in the low half)."""
+    gp = SPLIT_PANEL_FRAGS // (3 * MT)
+    rows = 2 * KT
+    n_panels = (rows + gp - 1) // gp
+    out = np.zeros((n_panels, SPLIT_PANEL_FRAGS, 64, 4), dtype=np.uint32)
+    lane = np.arange(64)
+    terms = split3(A)
+    for b in range(rows):
+        for t in range(3):
+            for mt in range(MT):
+                r = 32 * mt + (lane & 31)
+                for i in range(8):
+                    v = terms[t][r, 16 * b + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)]
+                    bits = (v.view(np.uint32) >> 16).astype(np.uint32)
+                    out[b // gp, ((b % gp) * 3 + t) * MT + mt, :, i // 2] |= bits << (16 * (i & 1))
+    return out.reshape(-1).view(np.float32)
+
+
+def gemm_part_split_emulated(packed_part, in_regs, KT, MT):
+    """What nnr_split.h's gemm_part computes from a MODE 2 packed part and the fp32 activation registers [16 KT][64 lanes]: per row of 16
+    k-values the six term products (l,h) (m,m) (m,h) (h,l) (h,m) (h,h) of v_mfma_f32_32x32x16_bf16 -- lane l supplies A[l & 31][k = 8 (l >> 5)
+    + i] and B[k][l & 31]; D register rho of lane l is D[(rho & 3) + 8 (rho >> 2) + 4 (l >> 5)][l & 31] -- accumulated in fp32.
+    Returns [MT][16][64] accumulator registers."""
+    gp = SPLIT_PANEL_FRAGS // (3 * MT)
+    pan = packed_part.view(np.uint32).reshape(-1, SPLIT_PANEL_FRAGS, 64, 4)
+    lane = np.arange(64)
+    acc = np.zeros((MT, 16, 64), dtype=np.float32)
+
+    def unpack(words):       # [64][4] uint32 -> [64][8] fp32
+        o = np.zeros((64, 8), dtype=np.float32)
+        for i in range(8):
+            o[:, i] = (((words[:, i // 2] >> (16 * (i & 1))) & 0xffff) << 16).astype(np.uint32).view(np.float32)
+        return o
+    for b in range(2 * KT):
+        xs = split3(in_regs[8 * b:8 * b + 8].T)      # each [64][8]: the lane's 8 k-values of the row, as three terms
+        for wt, xt in ((0, 2), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2)):
+            for mt in range(MT):
+                a = unpack(pan[b // gp, ((b % gp) * 3 + wt) * MT + mt])       # lane -> A[l & 31][8 (l >> 5) + i]
+                A = np.zeros((32, 16), dtype=np.float64)
+                B = np.zeros((16, 32), dtype=np.float64)
+                for i in range(8):
+                    A[lane & 31, 8 * (lane >> 5) + i] = a[:, i]
+                    B[8 * (lane >> 5) + i, lane & 31] = xs[xt][:, i]
+                Dm = A @ B
+                for rho in range(16):
+                    acc[mt, rho] = (acc[mt, rho] + Dm[(rho & 3) + 8 * (rho >> 2) + 4 * (lane >> 5), lane & 31]).astype(np.float32)
+    return acc
+
+
 def part_frags(packed_part, KT, MT):
     """Inverse view of pack_part: [4*KT][MT][64][4]."""
     gp = PANEL_FRAGS // MT
@@ -101,8 +175,9 @@ def head_tables(weights, D):
     return np.concatenate(out)
 
 
-def pack_all(weights, biases, D, with_exact_mask=False):
-    """weights/biases: lists of 12 numpy arrays in state_dict order -> the packed buffer nnr_pack_weights produces.
+def pack_all(weights, biases, D, with_exact_mask=False, mode=0):
+    """weights/biases: lists of 12 numpy arrays in state_dict order -> the packed buffer nnr_pack_weights produces (mode 0: fp32
+    fragments, mode 2: three bf16 terms per weight, NNR_F_SPLIT3).
     with_exact_mask: also a bool array, False where the value derives from the merged matrix (compare with a tolerance)."""
     wm, bm = merged(weights, biases, D)
     w13 = list(weights) + [wm]
@@ -111,7 +186,7 @@ def pack_all(weights, biases, D, with_exact_mask=False):
         chunks.append(v)
         exact.append(np.full(v.size, is_exact))
     for part in fwd_parts(D) + bwd_parts(D):
-        put(pack_part(part_matrix(w13[part[0]], part), part[2], part[3]), part[0] != MERGED)
+        put((pack_part_split if mode == 2 else pack_part)(part_matrix(w13[part[0]], part), part[2], part[3]), part[0] != MERGED)
     for l, (b, pad) in enumerate(zip(biases, bias_pads(D))):
         v = np.zeros(pad, dtype=np.float32)
         src = bm if l == 10 else b          # the colour-hidden slot holds the merged bias

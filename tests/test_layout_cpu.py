@@ -31,6 +31,33 @@ def _layer(W_l, parts, idxs, x_regs):
     return np.concatenate(outs)
 
 
+def test_three_term_parts_reproduce_the_fp32_products():
+    """MODE 2 (NNR_F_SPLIT3): a part packed as three bf16 terms per weight, multiplied by the emulated six-term row of nnr_split.h
+    against activations in the register layout, gives the plain matmul to fp32 rounding -- for every (KT, MT) shape the kernels use
+    (forward and transposed parts, edge tiles with zero padding), i.e. the slot algebra (rows of 16 k, 3 MT fragments per row, 24-slot
+    panels) closes; and the terms themselves add up to the weights exactly."""
+    D = 128
+    W, _ = rand_weights(D, seed=3)
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(8).astype(np.float32) * np.float32(10.0) ** rng.integers(-6, 6, 8).astype(np.float32)
+    l, m, h = lr.split3(x)
+    assert np.array_equal((h.astype(np.float64) + m + l).astype(np.float32), x) and np.all(np.abs(m) <= np.abs(h) * 2.0 ** -8)
+    for parts, idx in ((lr.fwd_parts(D), (0, 2, 9, 19)), (lr.bwd_parts(D), (2, 3, 9, 18))):
+        for i in idx:
+            part = parts[i]
+            layer, tr, KT, MT, m_real, k_real = part[:6]
+            A = lr.part_matrix(W[layer] if layer != lr.MERGED else rng.standard_normal((D // 2, D)).astype(np.float32), part)
+            X = np.zeros((32 * KT, 32), dtype=np.float32)
+            X[:k_real] = rng.standard_normal((k_real, 32)).astype(np.float32)
+            pk = lr.pack_part_split(A, KT, MT)
+            assert pk.size == (-(-2 * KT // (8 // MT))) * 24 * 256
+            acc = lr.gemm_part_split_emulated(pk, lr.to_regs(X), KT, MT)
+            got = lr.from_regs(acc.reshape(-1, 64))
+            want = A.astype(np.float64) @ X.astype(np.float64)
+            scale = np.abs(A).astype(np.float64) @ np.abs(X).astype(np.float64) + 1e-30
+            assert float((np.abs(got - want) / scale).max()) <= 3e-7, (part, float((np.abs(got - want) / scale).max()))
+
+
 def test_chained_layers_in_register_layout():
     """Two chained layers, each as its two half-output passes, computed with emulated MFMAs on packed fragments == plain
     matmuls; the output registers of one layer are directly the B operands of the next (no transpose)."""
@@ -98,7 +125,11 @@ def test_sizes_and_error_codes(D):
     lib = L.load()
     W, B = rand_weights(D)
     cfg = L.make_cfg(16, 64, D, train=True)
+    cfg = L.Cfg(16, 64, D, cfg.flags & ~L.NNR_F_SPLIT3)               # fp32-MFMA products
     assert lib.nnr_packed_floats(C.byref(cfg)) == lr.pack_all(W, B, D).size
+    split_cfg = L.Cfg(16, 64, D, cfg.flags | L.NNR_F_SPLIT3)          # three-term products: only the packed weights differ
+    assert lib.nnr_packed_floats(C.byref(split_cfg)) == lr.pack_all(W, B, D, mode=2).size
+    assert lib.nnr_workspace_floats(C.byref(split_cfg)) == lib.nnr_workspace_floats(C.byref(cfg))
     S_pad = 16 * 64
     x_width = 64 + 8 * D + 32 + D // 2      # posenc, h1..h8, direction encoding, colour hidden (no feature vector: merged)
     d_width = 8 * D + D // 2
