@@ -32,4 +32,4 @@ print('bench line of the traced run: %.3f ms/step' % d['ms_per_step'])
 PY
   head -4 gpurun_out/step_$name/breakdown.txt
 done
-timeout 600 python bench.py > gpurun_out/r03/j_bench_untraced.json.txt 2> gpurun_out/r03/j_bench.err; echo "bench exit $?"
+mkdir -p gpurun_out/r03; timeout 900 python bench.py > gpurun_out/r03/j_bench_untraced.json.txt 2> gpurun_out/r03/j_bench.err; echo "bench exit $?"
