@@ -39,7 +39,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-prag
 # stores with vmcnt(0), and every reload drains the stash-store queue with the matrix pipe idle -- the TRAINING kernels may only keep a handful of
 # prologue values in scratch, reloaded at pass start (where the pass waits for its inputs anyway), nothing inside a pass; the inference forward (no stores in flight) may spill its composite carry.
 SCRATCH_LIMIT = {"14mlp_fwd_kernelI": 0, "14mlp_fwd_kernelILi256ELb1ELi2E": 256, "14mlp_fwd_kernelILi256ELb0ELi2E": 256,
-                 "14mlp_fwd_kernelILi128ELb1ELi2E": 256, "14mlp_fwd_kernelILi128ELb0ELi2E": 256, "16mlp_dgrad_kernelI": 0, "12wgrad_kernelE": 0, "14wgrad_b_kernelE": 0,
+                 "14mlp_fwd_kernelILi128ELb1ELi2E": 256, "14mlp_fwd_kernelILi128ELb0ELi2E": 256, "16mlp_dgrad_kernelI": 0, "12wgrad_kernelI": 0, "14wgrad_b_kernelE": 0,
                  "19mlp_fwd_bf16_kernelI": 48, "19mlp_fwd_bf16_kernelILi256ELb1E": 16, "19mlp_fwd_bf16_kernelILi128ELb1E": 16,
                  "21mlp_dgrad_bf16_kernelI": 64, "20composite_fwd_kernelE": 0, "20composite_bwd_kernelE": 0}
 
@@ -103,6 +103,8 @@ def build_split_variant(name, defines):
     tmp = os.path.join(OUT_DIR, "variant_" + name)
     os.makedirs(tmp, exist_ok=True)
     mine = [(src, d) for src, d in SOURCES if any(x.endswith("MODE=2") for x in d) and any(x.endswith("_D=256") for x in d)]
+    if any(x.startswith("NNR_ABLATE_WGRAD") for x in defines):
+        mine = [(src, d) for src, d in SOURCES if src == "nnr_wgrad.hip"]
     jobs = [[hipcc] + FLAGS + ["-D" + d for d in list(defines) + list(d0)] + ["-c", os.path.join(HERE, src), "-o", os.path.join(tmp, _obj_name(src, d0))]
             for src, d0 in mine]
 

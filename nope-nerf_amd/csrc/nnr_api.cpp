@@ -158,9 +158,16 @@ Plan build_plan(const nnr_cfg* c) {
     }
     // Measured cycles per cost-granule relative to a 4x4 tile (tools/timeline.py, MI355X): narrow tiles issue the same
     // loads for fewer MFMAs.  Weights in 1/1000.
-    auto weight = [](const WgradJob& j) -> int64_t {
+    // Three-term mode (nnr_wgrad.hip, wgrad_job_split): the 4 x 4 tiles run on the bf16 matrix pipe, the narrow ones still on fp32 MFMAs --
+    // per MFMA-equivalent a 4 x 4 tile costs `split_w` / 1000 of what it costs in fp32 (measured: NNR_WGRAD_SPLIT_WEIGHT sweeps).
+    static const int split_w = [] {
+        const char* e = std::getenv("NNR_WGRAD_SPLIT_WEIGHT");
+        return e ? std::max(50, std::atoi(e)) : 560;
+    }();
+    const bool split = is_split3(c) && std::getenv("NNR_WGRAD_FP32") == nullptr;
+    auto weight = [split](const WgradJob& j) -> int64_t {
         const int mn = j.MI * j.NI;
-        int w = mn == 16 ? 1000 : mn == 8 ? 1035 : mn == 4 ? 1145 : 1250;
+        int w = mn == 16 ? (split ? split_w : 1000) : mn == 8 ? 1035 : mn == 4 ? 1145 : 1250;
         if (j.bias == 1) w += mn == 16 ? 20 : mn == 8 ? 42 : 20;
         return (int64_t)mn * w;
     };

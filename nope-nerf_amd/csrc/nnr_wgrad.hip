@@ -14,6 +14,8 @@
 // first D columns of the colour-hidden layer get their gradients from the merged matrix W' (wgrad_unmerge_kernel).
 #include "nnr_device.h"
 #include "nnr_kernels.h"
+#include "nnr_split.h"
+#include <cstdlib>
 
 namespace nnr {
 
@@ -137,13 +139,179 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
     NNR_STAMP(tl_wgrad, 2);
 }
 
+// ---- the 4 x 4 tile with every product as six bf16 MFMA terms (NNR_F_SPLIT3; the idea: nnr_split.h) -----------------------------------
+// Same job, same slot, same flush.  The reduction index (samples) is the k of v_mfma_f32_32x32x16_bf16, so a lane supplies EIGHT samples
+// per operand and MFMA -- lane (h, m) the samples k + 8 h + s, s = 0..7, of feature columns MI m .. MI m + 3 (the four interleaved
+// sub-tiles) -- and a step is 16 samples: 8 rows of 16 bytes per lane and operand, the fp32 kernel's bytes.  The 256 accumulators fill
+// the AGPR file, and a register-resident pipeline of the loaded rows does not fit beside the term registers (thousands of
+// spills), so the rows are STAGED IN LDS: each wave owns two 16 KiB buffers, filled by global_load_lds (no VGPR round trip, no barrier --
+// the area is private to the wave) one step ahead, and the values come back two at a time, one gap before they are split.
+//   Xc / Xn    the activation operand's terms of this step and the next (2 x 48 registers: every block needs all four sub-tiles)
+//   Dq[2]      the terms of ONE gradient sub-tile, made one block ahead (2 x 12)
+// Block i of a step = 24 MFMAs (gradient sub-tile i against the four activation sub-tiles, six terms each); under them
+//   block 0: DMA of the next step's 16 rows; terms of gradient sub-tile 1        block 1: terms of gradient sub-tile 2
+//   block 2: terms of gradient sub-tile 3 + activation sub-tiles 0, 1 of the NEXT step (its rows have landed: vmcnt(0) at the block start)
+//   block 3: terms of gradient sub-tile 0 of the next step + activation sub-tiles 2, 3 of the next step
+constexpr int kStageF4 = 2 * 16 * 64;      // f32x4 per wave: 2 buffers x (8 gradient + 8 activation rows) x 64 lanes
+
+__device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradArgs& a, int lane, int ji, f32x4* stage) {
+    constexpr int MI = 4, NI = 4;
+    const int half = lane >> 5, m = lane & 31;
+    const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
+    const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
+    const char* const dg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane] + jb.d_col0 + (dok ? MI * m : 0) + (int64_t)(8 * half) * dp);
+    const char* const xg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane] + jb.x_col0 + (xok ? NI * m : 0) + (int64_t)(8 * half) * xp);
+    // d(bias): which of a pair's two samples this tile sums (WgradJob::bias: 1 all, 2 even, 3 odd sample pairs of the fp32 kernel = here s parity)
+    const float bw0 = (jb.bias == 1 || jb.bias == 2) ? 1.f : 0.f, bw1 = (jb.bias == 1 || jb.bias == 3) ? 1.f : 0.f;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[MI] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t Xc[NI][3][4], Xn[NI][3][4], Dq[2][3][4];   // current / next step's activation terms; [..][term: 0 = l, 1 = m, 2 = h][pair of samples]
+    float f0[2][4], f1[2][4];     // a pair's two values between its fetch and its split, then the residuals between the stages
+    const float* const lrow = reinterpret_cast<const float*>(stage) + 4 * lane;   // this lane's 4 floats of staged row r: lrow[256 r + c]
+
+// row S (0..7) of operand G (pitch P floats) of the step at sample KK -> staged row ROW of this wave
+#define NNR_WDMA(G, P, KK, S, DST, ROW) \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(G + ((KK) + (S)) * (int64_t)(P) * 4), (lds_ptr_t)((DST) + (ROW) * 64), 16, 0, 0)
+#ifdef NNR_ABLATE_WGRAD_NO_FETCH      /* profiling builds only (results NOT valid) */
+#define NNR_WFETCH(W, P, LR, ROW0, C) (f0[W][P] = bw0 + (float)(P), f1[W][P] = bw1 + (float)(C))
+#else
+#define NNR_WFETCH(W, P, LR, ROW0, C) (f0[W][P] = (LR)[256 * ((ROW0) + 2 * (P)) + (C)], f1[W][P] = (LR)[256 * ((ROW0) + 2 * (P) + 1) + (C)])
+#endif
+// the split of pair P of component C of the rows [ROW0, ROW0 + 8), stage ST: 0 fetch, 1 h, 2 m, 3 l; W = residual set, BI >= 0: d(bias) slot
+#define NNR_WSPLIT(LR, ROW0, C, P, ST, Q, W, BI, BWT)                                        \
+    do {                                                                                     \
+        if ((ST) == 0) {                                                                     \
+            NNR_WFETCH(W, P, LR, ROW0, C);                                                   \
+        } else if ((ST) == 1) {                                                              \
+            if ((BI) >= 0) bsum[(BI) >= 0 ? (BI) : 0] += (BWT) * (bw0 * f0[W][P] + bw1 * f1[W][P]); \
+            Q[2][P] = pack_bf16(f0[W][P], f1[W][P]);                                         \
+            f0[W][P] = f0[W][P] - __uint_as_float(Q[2][P] << 16);                            \
+            f1[W][P] = f1[W][P] - __uint_as_float(Q[2][P] & 0xffff0000u);                    \
+        } else if ((ST) == 2) {                                                              \
+            Q[1][P] = pack_bf16(f0[W][P], f1[W][P]);                                         \
+            f0[W][P] = f0[W][P] - __uint_as_float(Q[1][P] << 16);                            \
+            f1[W][P] = f1[W][P] - __uint_as_float(Q[1][P] & 0xffff0000u);                    \
+        } else {                                                                             \
+            Q[0][P] = pack_bf16(f0[W][P], f1[W][P]);                                         \
+        }                                                                                    \
+    } while (0)
+#define NNR_WSPLIT_ALL(ROW0, C, Q, W, BI)                                                    \
+    _Pragma("unroll") for (int st_ = 0; st_ < 4; ++st_)                                      \
+        _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_) NNR_WSPLIT(lrow, ROW0, C, p_, st_, Q, W, BI, 1.f)
+
+    // prologue: the first step's rows, all terms of the activation operand, the first gradient sub-tile
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        NNR_WDMA(dg, dp, jb.k0, s, stage, s);
+        NNR_WDMA(xg, xp, jb.k0, s, stage, 8 + s);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NNR_WSPLIT_ALL(8, 0, Xc[0], 1, -1);
+    NNR_WSPLIT_ALL(8, 1, Xc[1], 1, -1);
+    NNR_WSPLIT_ALL(8, 2, Xc[2], 1, -1);
+    NNR_WSPLIT_ALL(8, 3, Xc[3], 1, -1);
+    NNR_WSPLIT_ALL(0, 0, Dq[0], 0, 0);
+
+    // One 16-sample step per iteration of ONE loop body (two textual copies for the two buffer parities made hipcc assign the 256
+    // accumulators to different registers in the copies and shuffle them in between: hundreds of moves and spills per step); the staging
+    // buffers alternate by address, and the next step's activation terms are copied over the current ones at the end of the step (48 moves).
+    // kn = the step to prefetch: the last step re-reads its own rows -- no branch around the DMA -- and nf = 0 keeps them out of d(bias).
+    for (int64_t k = jb.k0; k < jb.k1; k += 16) {
+        const int par = (int)(((k - jb.k0) >> 4) & 1);
+        const bool more = k + 16 < jb.k1;
+        const int64_t kn = more ? k + 16 : k;
+        const float nf = more ? 1.f : 0.f;
+        const float* const lc = lrow + 4096 * par;            // this step's staged rows, the next step's
+        const float* const ln = lrow + 4096 * (1 - par);
+        f32x4* const dst = stage + 1024 * (1 - par);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (i == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the next step's rows have landed
+            const int n_ops = 16 + (i >= 2 ? 32 : 0);
+#pragma unroll
+            for (int g = 0; g < 24; ++g) {
+                const int j = g / 6, t = g % 6;
+                const int wc = t == 0 ? 0 : (t < 3 ? 1 : 2), xc = t == 0 ? 2 : (t == 1 ? 1 : (t == 2 ? 2 : t - 3));
+                __builtin_amdgcn_sched_barrier(0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, u32x4{Dq[i & 1][wc][0], Dq[i & 1][wc][1], Dq[i & 1][wc][2], Dq[i & 1][wc][3]}),
+                    __builtin_bit_cast(bf16x8, u32x4{Xc[j][xc][0], Xc[j][xc][1], Xc[j][xc][2], Xc[j][xc][3]}),
+                    acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef NNR_ABLATE_WGRAD_NO_DMA
+                if (i == 0 && g < 16) {
+                    if (g < 8) NNR_WDMA(dg, dp, kn, g, dst, g);
+                    else NNR_WDMA(xg, xp, kn, g - 8, dst, g);
+                }
+#endif
+#pragma unroll
+                for (int o = 0; o < 48; ++o) {
+                    if (o >= n_ops || (o * 24) / n_ops != g) continue;
+                    const bool is_d = n_ops == 16 || o % 3 == 0;                // with 48 operations every third is the gradient's
+                    const int od = n_ops == 16 ? o : o / 3, ox = o - o / 3 - 1;  // index within the operand's own 16 / 32 operations
+#ifdef NNR_ABLATE_WGRAD_NO_SPLIT
+                    continue;
+#endif
+                    if (is_d) {
+                        const int st = od / 4, p = od % 4;                       // all pairs' fetch, then stages 1, 2, 3
+                        if (i == 0) NNR_WSPLIT(lc, 0, 1, p, st, Dq[1], 0, 1, 1.f);
+                        else if (i == 1) NNR_WSPLIT(lc, 0, 2, p, st, Dq[0], 0, 2, 1.f);
+                        else if (i == 2) NNR_WSPLIT(lc, 0, 3, p, st, Dq[1], 0, 3, 1.f);
+                        else NNR_WSPLIT(ln, 0, 0, p, st, Dq[0], 0, 0, nf);       // the NEXT step's sub-tile 0
+                    } else {
+                        const int cc = 2 * (i - 2) + ox / 16, r = ox % 16, st = r / 4, p = r % 4;
+                        NNR_WSPLIT(ln, 8, cc, p, st, Xn[cc], 1, -1, 0.f);
+                    }
+                }
+            }
+            // every tile stays in the accumulation registers, always: with any of them in VGPRs nothing else fits
+            asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Xc[j][t][q] = Xn[j][t][q];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last step's prefetch writes LDS: let it finish before the next job reuses the area
+#undef NNR_WDMA
+#undef NNR_WSPLIT
+#undef NNR_WFETCH
+#undef NNR_WSPLIT_ALL
+
+    float* slot = a.slots + (int64_t)ji * kSlotFloats;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* dst = slot + (MI * mr + i) * (32 * NI) + NI * m;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        }
+    if (jb.bias != 0) {
+        float* dst = slot + kSlotTile + half * (32 * MI) + MI * m;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) dst[i] = bsum[i];
+    }
+}
+
 #ifdef NNR_TIMELINE
 extern "C" int nnr_timeline_wgrad(unsigned long long* host32) {
     return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_wgrad), 32 * sizeof(unsigned long long));
 }
 #endif
 
+template <bool SPLIT>     // SPLIT: the 4 x 4 tiles with three-term products (wgrad_job_split); the narrow tiles stay on fp32 MFMAs
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) f32x4 stage_all[SPLIT ? kWavesPerBlock * kStageF4 : 1];
     const int lane = threadIdx.x & 63;
     const int wslot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int j0 = a.wave_first[wslot], j1 = a.wave_first[wslot + 1];
@@ -165,6 +333,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
 #define NNR_WGRAD_CASE(MI_, NI_)                                 \
     case MI_ * 8 + NI_: NNR_WGRAD_RUN(MI_, NI_, 0); break;        \
     case MI_ * 8 + NI_ + 64: NNR_WGRAD_RUN(MI_, NI_, 1); break;
+        if constexpr (SPLIT) {
+            if (__builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI) == 4 * 8 + 4) {
+                wgrad_job_split(jb, a, lane, ji, stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kStageF4);
+                continue;
+            }
+        }
         switch (key) {
             case 4 * 8 + 4 + 128: NNR_WGRAD_RUN(4, 4, 2); break;
             case 4 * 8 + 4 + 192: NNR_WGRAD_RUN(4, 4, 3); break;
@@ -279,7 +453,9 @@ __global__ __launch_bounds__(256) void wgrad_unmerge_kernel(WgradArgs a) {
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
     hipError_t e;
     prof_before(PROF_WGRAD, st);
-    hipLaunchKernelGGL(wgrad_kernel, dim3(a.n_waves / 4), dim3(256), 0, st, a);
+    static const bool split_off = std::getenv("NNR_WGRAD_FP32") != nullptr;      // experiments: fp32 MFMAs in the weight gradient of the three-term mode
+    if (a.bf16 == 2 && !split_off) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_jobs * 16), dim3(256), 0, st, a);
     e = hipGetLastError();
     if (e == hipSuccess) e = launch_wgrad_unmerge(a, st);

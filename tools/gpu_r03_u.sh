@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 3, call U: the weight gradient's 4 x 4 tiles with three-term products (LDS-staged rows): parity, determinism, timing
+mkdir -p gpurun_out/r03
+timeout 1500 python -m pytest tests/test_gpu_split3.py tests/test_gpu_layer_local.py tests/test_gpu_parity.py tests/test_gpu_determinism.py tests/test_gpu_bench_shape_parity.py -q -m gpu -x -s 2>&1 | grep -v Warning | tail -14 > gpurun_out/r03/u_tests.txt
+echo "pytest exit $?"; tail -8 gpurun_out/r03/u_tests.txt
+SHAPE="1024 192 f32" bash tools/gpu_variants.sh > gpurun_out/r03/u_time.txt 2>&1; cat gpurun_out/r03/u_time.txt
+NNR_WGRAD_FP32=1 SHAPE="1024 192 f32" bash tools/gpu_variants.sh 2>&1 | tail -1
+timeout 600 python bench.py --no-extra --no-cpu-baseline > gpurun_out/r03/u_bench.json.txt 2>/dev/null
+python - <<'PY'
+import json
+for l in open('gpurun_out/r03/u_bench.json.txt'):
+    if l.startswith('{'):
+        d=json.loads(l); print(d['value'], d['ms_per_step'], d['final_loss'], {k:v['ms'] for k,v in d['roofline']['kernels'].items()})
+PY
