@@ -162,7 +162,7 @@ Plan build_plan(const nnr_cfg* c) {
     // per MFMA-equivalent a 4 x 4 tile costs `split_w` / 1000 of what it costs in fp32 (measured: NNR_WGRAD_SPLIT_WEIGHT sweeps).
     static const int split_w = [] {
         const char* e = std::getenv("NNR_WGRAD_SPLIT_WEIGHT");
-        return e ? std::max(50, std::atoi(e)) : 560;
+        return e ? std::max(50, std::atoi(e)) : 520;
     }();
     const bool split = is_split3(c) && std::getenv("NNR_WGRAD_FP32") == nullptr;
     auto weight = [split](const WgradJob& j) -> int64_t {

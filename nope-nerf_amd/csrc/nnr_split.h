@@ -20,12 +20,16 @@ using SplitPipe = PanelPipeT<kWavesPerBlock, kSplitPanelFrags>;
 
 // the three bf16 terms of two fp32 values, packed (x0 in the low halves): h = rn(x), m = rn(x - h), l = rn(x - h - m); both differences
 // are exact in fp32.  (An infinite or NaN input gives NaN terms -- as good as the inf the fp32 path would produce: the trainer stops.)
+// (the conversion as the compiler's own v_cvt_pk_bf16_f32, round to nearest even: written as inline asm -- pack_bf16 -- hipcc puts an
+// s_nop behind every use, and the two subtractions of a pair as one packed instruction)
+__device__ __forceinline__ uint32_t pack_pair(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = pack_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = pack_bf16(r0, r1);
-    const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);
-    l = pack_bf16(q0, q1);
+    f32x2 r = {x0, x1};
+    h = pack_pair(r);
+    r = r - f32x2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    m = pack_pair(r);
+    r = r - f32x2{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    l = pack_pair(r);
 }
 
 // experiments only (tools/gpu_r03_*.sh): NNR_SPLIT_SAFE_SYNC = every counted wait as a full one; NNR_SPLIT_TERMS = 1 / 3 / 6 of the terms
@@ -185,7 +189,7 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) fr[c][mt] = frag_read(panel_addr, c * MT + mt);
     uint32_t xs[3][4], xn[3][4];   // [class][pair]: the packed B operands of the current / next row
-    float r0[4], r1[4];            // the residuals of the next row's pairs between the split stages
+    f32x2 rr[4];                   // the residuals of the next row's pairs between the split stages (adjacent registers: packed subtracts)
 #pragma unroll
     for (int q = 0; q < 4; ++q) split_pair(in[2 * q], in[2 * q + 1], xs[2][q], xs[1][q], xs[0][q]);
 
@@ -238,19 +242,17 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                     if (!last) { xn[2][k] = xs[2][k]; xn[1][k] = xs[1][k]; xn[0][k] = xs[0][k]; }   // profiling build only
 #else
                     if (!last) {
-                        const float x0 = in[8 * (g + 1) + 2 * k], x1 = in[8 * (g + 1) + 2 * k + 1];
-                        xn[2][k] = pack_bf16(x0, x1);
-                        r0[k] = x0 - __uint_as_float(xn[2][k] << 16);
-                        r1[k] = x1 - __uint_as_float(xn[2][k] & 0xffff0000u);
+                        rr[k] = f32x2{in[8 * (g + 1) + 2 * k], in[8 * (g + 1) + 2 * k + 1]};
+                        xn[2][k] = pack_pair(rr[k]);
+                        rr[k] = rr[k] - f32x2{__uint_as_float(xn[2][k] << 16), __uint_as_float(xn[2][k] & 0xffff0000u)};
                     }
                 } else if (kind == 1) {     // stage B: m, and what it leaves
                     if (!last) {
-                        xn[1][k] = pack_bf16(r0[k], r1[k]);
-                        r0[k] = r0[k] - __uint_as_float(xn[1][k] << 16);
-                        r1[k] = r1[k] - __uint_as_float(xn[1][k] & 0xffff0000u);
+                        xn[1][k] = pack_pair(rr[k]);
+                        rr[k] = rr[k] - f32x2{__uint_as_float(xn[1][k] << 16), __uint_as_float(xn[1][k] & 0xffff0000u)};
                     }
                 } else if (kind == 2) {     // stage C: l
-                    if (!last) xn[0][k] = pack_bf16(r0[k], r1[k]);
+                    if (!last) xn[0][k] = pack_pair(rr[k]);
 #endif
                 } else if (kind == 3) {
                     if constexpr (STASH) {

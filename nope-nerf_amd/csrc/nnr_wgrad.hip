@@ -154,15 +154,18 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
 //   block 3: terms of gradient sub-tile 0 of the next step + activation sub-tiles 2, 3 of the next step
 constexpr int kStageF4 = 2 * 16 * 64;      // f32x4 per wave: 2 buffers x (8 gradient + 8 activation rows) x 64 lanes
 
+template <int BIAS>      // WgradJob::bias (compile-time: the d(bias) sums are one add per sample pair in the tiles that carry them)
 __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradArgs& a, int lane, int ji, f32x4* stage) {
     constexpr int MI = 4, NI = 4;
     const int half = lane >> 5, m = lane & 31;
     const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
     const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
-    const char* const dg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane] + jb.d_col0 + (dok ? MI * m : 0) + (int64_t)(8 * half) * dp);
-    const char* const xg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane] + jb.x_col0 + (xok ? NI * m : 0) + (int64_t)(8 * half) * xp);
-    // d(bias): which of a pair's two samples this tile sums (WgradJob::bias: 1 all, 2 even, 3 odd sample pairs of the fp32 kernel = here s parity)
-    const float bw0 = (jb.bias == 1 || jb.bias == 2) ? 1.f : 0.f, bw1 = (jb.bias == 1 || jb.bias == 3) ? 1.f : 0.f;
+    // (wave-uniform row base in scalar registers) + (32-bit lane offset): no vector address arithmetic per DMA
+    const char* const dg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane] + jb.d_col0);
+    const char* const xg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane] + jb.x_col0);
+    const int dlane = 4 * ((dok ? MI * m : 0) + 8 * half * dp), xlane = 4 * ((xok ? NI * m : 0) + 8 * half * xp);
+    // d(bias): which of a pair's two samples this tile sums (WgradJob::bias: 1 all, 2 / 3: the two tiles of a row block share the samples
+    // -- here by the parity of s)
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -173,16 +176,18 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float bsum[MI] = {0.f, 0.f, 0.f, 0.f};
     uint32_t Xc[NI][3][4], Xn[NI][3][4], Dq[2][3][4];   // current / next step's activation terms; [..][term: 0 = l, 1 = m, 2 = h][pair of samples]
-    float f0[2][4], f1[2][4];     // a pair's two values between its fetch and its split, then the residuals between the stages
+    f32x2 fp[2][4];               // a pair's two values between its fetch and its split, then the residuals between the stages (adjacent: packed subtracts)
     const float* const lrow = reinterpret_cast<const float*>(stage) + 4 * lane;   // this lane's 4 floats of staged row r: lrow[256 r + c]
 
 // row S (0..7) of operand G (pitch P floats) of the step at sample KK -> staged row ROW of this wave
-#define NNR_WDMA(G, P, KK, S, DST, ROW) \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(G + ((KK) + (S)) * (int64_t)(P) * 4), (lds_ptr_t)((DST) + (ROW) * 64), 16, 0, 0)
+#define NNR_WDMA(G, LANE, P, KK, S, DST, ROW) \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)((G) + ((KK) + (S)) * (int64_t)(P) * 4 + (LANE)), (lds_ptr_t)((DST) + (ROW) * 64), 16, 0, 0)
+// (the conversion as the compiler's own: as inline asm -- pack_bf16 -- every use drags an s_nop along, 55 per step)
+#define NNR_WPACK(V) __builtin_bit_cast(uint32_t, __builtin_convertvector(V, bf16x2))
 #ifdef NNR_ABLATE_WGRAD_NO_FETCH      /* profiling builds only (results NOT valid) */
-#define NNR_WFETCH(W, P, LR, ROW0, C) (f0[W][P] = bw0 + (float)(P), f1[W][P] = bw1 + (float)(C))
+#define NNR_WFETCH(W, P, LR, ROW0, C) (fp[W][P] = f32x2{1.f + (float)(P), 2.f + (float)(C)})
 #else
-#define NNR_WFETCH(W, P, LR, ROW0, C) (f0[W][P] = (LR)[256 * ((ROW0) + 2 * (P)) + (C)], f1[W][P] = (LR)[256 * ((ROW0) + 2 * (P) + 1) + (C)])
+#define NNR_WFETCH(W, P, LR, ROW0, C) (fp[W][P] = f32x2{(LR)[256 * ((ROW0) + 2 * (P)) + (C)], (LR)[256 * ((ROW0) + 2 * (P) + 1) + (C)]})
 #endif
 // the split of pair P of component C of the rows [ROW0, ROW0 + 8), stage ST: 0 fetch, 1 h, 2 m, 3 l; W = residual set, BI >= 0: d(bias) slot
 #define NNR_WSPLIT(LR, ROW0, C, P, ST, Q, W, BI, BWT)                                        \
@@ -190,16 +195,15 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
         if ((ST) == 0) {                                                                     \
             NNR_WFETCH(W, P, LR, ROW0, C);                                                   \
         } else if ((ST) == 1) {                                                              \
-            if ((BI) >= 0) bsum[(BI) >= 0 ? (BI) : 0] += (BWT) * (bw0 * f0[W][P] + bw1 * f1[W][P]); \
-            Q[2][P] = pack_bf16(f0[W][P], f1[W][P]);                                         \
-            f0[W][P] = f0[W][P] - __uint_as_float(Q[2][P] << 16);                            \
-            f1[W][P] = f1[W][P] - __uint_as_float(Q[2][P] & 0xffff0000u);                    \
+            if ((BI) >= 0 && BIAS != 0)                                                      \
+                bsum[(BI) >= 0 ? (BI) : 0] += (BWT) * (BIAS == 1 ? fp[W][P][0] + fp[W][P][1] : (BIAS == 2 ? fp[W][P][0] : fp[W][P][1])); \
+            Q[2][P] = NNR_WPACK(fp[W][P]);                                   \
+            fp[W][P] = fp[W][P] - f32x2{__uint_as_float(Q[2][P] << 16), __uint_as_float(Q[2][P] & 0xffff0000u)}; \
         } else if ((ST) == 2) {                                                              \
-            Q[1][P] = pack_bf16(f0[W][P], f1[W][P]);                                         \
-            f0[W][P] = f0[W][P] - __uint_as_float(Q[1][P] << 16);                            \
-            f1[W][P] = f1[W][P] - __uint_as_float(Q[1][P] & 0xffff0000u);                    \
+            Q[1][P] = NNR_WPACK(fp[W][P]);                                   \
+            fp[W][P] = fp[W][P] - f32x2{__uint_as_float(Q[1][P] << 16), __uint_as_float(Q[1][P] & 0xffff0000u)}; \
         } else {                                                                             \
-            Q[0][P] = pack_bf16(f0[W][P], f1[W][P]);                                         \
+            Q[0][P] = NNR_WPACK(fp[W][P]);                                   \
         }                                                                                    \
     } while (0)
 #define NNR_WSPLIT_ALL(ROW0, C, Q, W, BI)                                                    \
@@ -209,8 +213,8 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     // prologue: the first step's rows, all terms of the activation operand, the first gradient sub-tile
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        NNR_WDMA(dg, dp, jb.k0, s, stage, s);
-        NNR_WDMA(xg, xp, jb.k0, s, stage, 8 + s);
+        NNR_WDMA(dg, dlane, dp, jb.k0, s, stage, s);
+        NNR_WDMA(xg, xlane, xp, jb.k0, s, stage, 8 + s);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     NNR_WSPLIT_ALL(8, 0, Xc[0], 1, -1);
@@ -247,8 +251,8 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef NNR_ABLATE_WGRAD_NO_DMA
                 if (i == 0 && g < 16) {
-                    if (g < 8) NNR_WDMA(dg, dp, kn, g, dst, g);
-                    else NNR_WDMA(xg, xp, kn, g - 8, dst, g);
+                    if (g < 8) NNR_WDMA(dg, dlane, dp, kn, g, dst, g);
+                    else NNR_WDMA(xg, xlane, xp, kn, g - 8, dst, g);
                 }
 #endif
 #pragma unroll
@@ -285,6 +289,7 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
 #undef NNR_WDMA
 #undef NNR_WSPLIT
 #undef NNR_WFETCH
+#undef NNR_WPACK
 #undef NNR_WSPLIT_ALL
 
     float* slot = a.slots + (int64_t)ji * kSlotFloats;
@@ -296,7 +301,7 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
             float* dst = slot + (MI * mr + i) * (32 * NI) + NI * m;
             *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
         }
-    if (jb.bias != 0) {
+    if constexpr (BIAS != 0) {
         float* dst = slot + kSlotTile + half * (32 * MI) + MI * m;
 #pragma unroll
         for (int i = 0; i < MI; ++i) dst[i] = bsum[i];
@@ -335,7 +340,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     case MI_ * 8 + NI_ + 64: NNR_WGRAD_RUN(MI_, NI_, 1); break;
         if constexpr (SPLIT) {
             if (__builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI) == 4 * 8 + 4) {
-                wgrad_job_split(jb, a, lane, ji, stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kStageF4);
+                f32x4* const stage = stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kStageF4;
+                switch (__builtin_amdgcn_readfirstlane(jb.bias)) {
+                    case 0: wgrad_job_split<0>(jb, a, lane, ji, stage); break;
+                    case 1: wgrad_job_split<1>(jb, a, lane, ji, stage); break;
+                    case 2: wgrad_job_split<2>(jb, a, lane, ji, stage); break;
+                    default: wgrad_job_split<3>(jb, a, lane, ji, stage); break;
+                }
                 continue;
             }
         }
