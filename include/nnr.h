@@ -52,9 +52,10 @@ extern "C" {
 #define NNR_F_SPLIT3 32u    /* fp32 results from the bf16 matrix pipe: every operand of every nn.Linear product as the EXACT sum of three
                              * bf16 terms (8 + 8 + 8 significand bits), six of the nine term products as bf16 MFMAs with fp32
                              * accumulation, the three below 2^-24 of the product dropped (nnr_split.h).  As close to the exact result
-                             * as the fp32 MFMA path (verified against fp64), 2.7 times fewer matrix-pipe cycles.  Planes and workspace
-                             * are those of the fp32 mode; only the packed-weight buffer differs (nnr_packed_floats).  Ignored with
-                             * NNR_F_BF16. */
+                             * as the fp32 MFMA path (verified against fp64), 2.7 times fewer matrix-pipe cycles.  The planes are those
+                             * of the fp32 mode; the packed-weight buffer has another size and layout (nnr_packed_floats) and the
+                             * weight-gradient plan another cut (nnr_plan_bytes, nnr_workspace_floats: query with the same flags).
+                             * Ignored with NNR_F_BF16. */
 
 /* Problem description.  POD, passed by pointer, read on the host only. */
 typedef struct nnr_cfg {
