@@ -198,6 +198,11 @@ class Renderer(nn.Module):
         if self.normal_window is None:
             noise = torch.rand_like(surface)
         else:
+            # data parallel: the rank draws the whole step's perturbations and keeps its rows, so that every rank's generator ends where
+            # the single-process run's does (the reference draws rand_like(surface) over ALL valid rays).  The two int(...) below are
+            # blocking device-to-host reads -- the only ones in a training step, taken only with rendering.normal_loss on AND more than
+            # one rank; the surface[mask] boolean indexing above synchronises in the single-process path as well (it is the reference's
+            # own expression).  Everything else in the step stays on the device (deferred NaN flag, device-side counts).
             valid_all, lo = self.normal_window
             first = int(valid_all[:lo].sum())
             noise = torch.rand(int(valid_all.sum()), 3, dtype=surface.dtype, device=surface.device)[first:first + n]
