@@ -154,16 +154,22 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
 //   block 3: terms of gradient sub-tile 0 of the next step + activation sub-tiles 2, 3 of the next step
 constexpr int kStageF4 = 2 * 16 * 64;      // f32x4 per wave: 2 buffers x (8 gradient + 8 activation rows) x 64 lanes
 
-template <int BIAS>      // WgradJob::bias (compile-time: the d(bias) sums are one add per sample pair in the tiles that carry them)
+// NI = 2: the 128 x 64 tiles against the position encoding (the bulk of the narrow tiles).  The activation rows are still fetched 16 bytes
+// per lane -- by the lanes' (m & 15): 16 lanes cover the 64 columns -- and lane n finds its two interleaved columns 2 n, 2 n + 1 in the
+// slot of lane n / 2; one activation sub-tile is made per block (in blocks 2 and 3), a block is 12 MFMAs.
+template <int BIAS, int NI>      // BIAS: WgradJob::bias (compile-time: the d(bias) sums are one add per sample pair in the tiles that carry them)
 __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradArgs& a, int lane, int ji, f32x4* stage) {
-    constexpr int MI = 4, NI = 4;
+    constexpr int MI = 4;
+    static_assert(NI == 4 || NI == 2, "activation sub-tiles per job");
+    constexpr int G = 6 * NI;                  // MFMAs (= gaps) per block
     const int half = lane >> 5, m = lane & 31;
     const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
     const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
     // (wave-uniform row base in scalar registers) + (32-bit lane offset): no vector address arithmetic per DMA
     const char* const dg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane] + jb.d_col0);
     const char* const xg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane] + jb.x_col0);
-    const int dlane = 4 * ((dok ? MI * m : 0) + 8 * half * dp), xlane = 4 * ((xok ? NI * m : 0) + 8 * half * xp);
+    const int dlane = 4 * ((dok ? MI * m : 0) + 8 * half * dp);
+    const int xlane = NI == 4 ? 4 * ((xok ? NI * m : 0) + 8 * half * xp) : 4 * (4 * (m & 15) + 8 * half * xp);
     // d(bias): which of a pair's two samples this tile sums (WgradJob::bias: 1 all, 2 / 3: the two tiles of a row block share the samples
     // -- here by the parity of s)
 
@@ -178,6 +184,8 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     uint32_t Xc[NI][3][4], Xn[NI][3][4], Dq[2][3][4];   // current / next step's activation terms; [..][term: 0 = l, 1 = m, 2 = h][pair of samples]
     f32x2 fp[2][4];               // a pair's two values between its fetch and its split, then the residuals between the stages (adjacent: packed subtracts)
     const float* const lrow = reinterpret_cast<const float*>(stage) + 4 * lane;   // this lane's 4 floats of staged row r: lrow[256 r + c]
+    // the activation operand's columns of this lane in a staged row: its own slot (NI = 4), or half of the slot of lane m / 2 (NI = 2)
+    const float* const lrowx = NI == 4 ? lrow : reinterpret_cast<const float*>(stage) + 4 * (32 * half + (m >> 1)) + 2 * (m & 1);
 
 // row S (0..7) of operand G (pitch P floats) of the step at sample KK -> staged row ROW of this wave
 #define NNR_WDMA(G, LANE, P, KK, S, DST, ROW) \
@@ -206,9 +214,9 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
             Q[0][P] = NNR_WPACK(fp[W][P]);                                   \
         }                                                                                    \
     } while (0)
-#define NNR_WSPLIT_ALL(ROW0, C, Q, W, BI)                                                    \
+#define NNR_WSPLIT_ALL(LR, ROW0, C, Q, W, BI)                                                \
     _Pragma("unroll") for (int st_ = 0; st_ < 4; ++st_)                                      \
-        _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_) NNR_WSPLIT(lrow, ROW0, C, p_, st_, Q, W, BI, 1.f)
+        _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_) NNR_WSPLIT(LR, ROW0, C, p_, st_, Q, W, BI, 1.f)
 
     // prologue: the first step's rows, all terms of the activation operand, the first gradient sub-tile
 #pragma unroll
@@ -217,11 +225,9 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
         NNR_WDMA(xg, xlane, xp, jb.k0, s, stage, 8 + s);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    NNR_WSPLIT_ALL(8, 0, Xc[0], 1, -1);
-    NNR_WSPLIT_ALL(8, 1, Xc[1], 1, -1);
-    NNR_WSPLIT_ALL(8, 2, Xc[2], 1, -1);
-    NNR_WSPLIT_ALL(8, 3, Xc[3], 1, -1);
-    NNR_WSPLIT_ALL(0, 0, Dq[0], 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) NNR_WSPLIT_ALL(lrowx, 8, j, Xc[j], 1, -1);
+    NNR_WSPLIT_ALL(lrow, 0, 0, Dq[0], 0, 0);
 
     // One 16-sample step per iteration of ONE loop body (two textual copies for the two buffer parities made hipcc assign the 256
     // accumulators to different registers in the copies and shuffle them in between: hundreds of moves and spills per step); the staging
@@ -234,13 +240,16 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
         const float nf = more ? 1.f : 0.f;
         const float* const lc = lrow + 4096 * par;            // this step's staged rows, the next step's
         const float* const ln = lrow + 4096 * (1 - par);
+        const float* const lnx = lrowx + 4096 * (1 - par);
         f32x4* const dst = stage + 1024 * (1 - par);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             if (i == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the next step's rows have landed
-            const int n_ops = 16 + (i >= 2 ? 32 : 0);
+            constexpr int kXOps = 16 * (NI / 2);                                  // activation operations of a block that makes NI / 2 sub-tiles
+            const int n_ops = 16 + (i >= 2 ? kXOps : 0);
+            const int stride = n_ops / 16;                                        // every stride-th operation is the gradient's
 #pragma unroll
-            for (int g = 0; g < 24; ++g) {
+            for (int g = 0; g < G; ++g) {
                 const int j = g / 6, t = g % 6;
                 const int wc = t == 0 ? 0 : (t < 3 ? 1 : 2), xc = t == 0 ? 2 : (t == 1 ? 1 : (t == 2 ? 2 : t - 3));
                 __builtin_amdgcn_sched_barrier(0);
@@ -250,19 +259,20 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
                     acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef NNR_ABLATE_WGRAD_NO_DMA
-                if (i == 0 && g < 16) {
-                    if (g < 8) NNR_WDMA(dg, dlane, dp, kn, g, dst, g);
-                    else NNR_WDMA(xg, xlane, xp, kn, g - 8, dst, g);
+                {
+                    const int q = i * G + g;                                      // the 16 rows of the next step, one per gap from the step's start
+                    if (q < 8) NNR_WDMA(dg, dlane, dp, kn, q, dst, q);
+                    else if (q < 16) NNR_WDMA(xg, xlane, xp, kn, q - 8, dst, q);
                 }
 #endif
 #pragma unroll
                 for (int o = 0; o < 48; ++o) {
-                    if (o >= n_ops || (o * 24) / n_ops != g) continue;
-                    const bool is_d = n_ops == 16 || o % 3 == 0;                // with 48 operations every third is the gradient's
-                    const int od = n_ops == 16 ? o : o / 3, ox = o - o / 3 - 1;  // index within the operand's own 16 / 32 operations
+                    if (o >= n_ops || (o * G) / n_ops != g) continue;
 #ifdef NNR_ABLATE_WGRAD_NO_SPLIT
                     continue;
 #endif
+                    const bool is_d = stride == 1 || o % stride == 0;
+                    const int od = stride == 1 ? o : o / stride, ox = o - o / stride - 1;   // index within the operand's own operations
                     if (is_d) {
                         const int st = od / 4, p = od % 4;                       // all pairs' fetch, then stages 1, 2, 3
                         if (i == 0) NNR_WSPLIT(lc, 0, 1, p, st, Dq[1], 0, 1, 1.f);
@@ -270,13 +280,14 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
                         else if (i == 2) NNR_WSPLIT(lc, 0, 3, p, st, Dq[1], 0, 3, 1.f);
                         else NNR_WSPLIT(ln, 0, 0, p, st, Dq[0], 0, 0, nf);       // the NEXT step's sub-tile 0
                     } else {
-                        const int cc = 2 * (i - 2) + ox / 16, r = ox % 16, st = r / 4, p = r % 4;
-                        NNR_WSPLIT(ln, 8, cc, p, st, Xn[cc], 1, -1, 0.f);
+                        const int cc = (NI / 2) * (i - 2) + ox / 16, r = ox % 16, st = r / 4, p = r % 4;
+                        NNR_WSPLIT(lnx, 8, cc, p, st, Xn[cc], 1, -1, 0.f);
                     }
                 }
             }
             // every tile stays in the accumulation registers, always: with any of them in VGPRs nothing else fits
-            asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]));
+            if constexpr (NI == 4) asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]));
+            else asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]));
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j)
@@ -299,9 +310,10 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
         for (int r = 0; r < 16; ++r) {
             const int mr = (r & 3) + 8 * (r >> 2) + 4 * half;
             float* dst = slot + (MI * mr + i) * (32 * NI) + NI * m;
-            *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+            if constexpr (NI == 4) *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+            else *reinterpret_cast<f32x2*>(dst) = f32x2{acc[i][0][r], acc[i][1][r]};
         }
-    if constexpr (BIAS != 0) {
+    if (jb.bias != 0) {      // (jobs without d(bias) run the BIAS = 1 instance and drop the sums: one instantiation less per shape)
         float* dst = slot + kSlotTile + half * (32 * MI) + MI * m;
 #pragma unroll
         for (int i = 0; i < MI; ++i) dst[i] = bsum[i];
@@ -339,13 +351,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     case MI_ * 8 + NI_: NNR_WGRAD_RUN(MI_, NI_, 0); break;        \
     case MI_ * 8 + NI_ + 64: NNR_WGRAD_RUN(MI_, NI_, 1); break;
         if constexpr (SPLIT) {
+            // (the 128 x 64 tiles against the position encoding -- wgrad_job_split<.., 2> -- were measured on this path too: their VALU work
+            // per MFMA is 1.6 times the 4 x 4 tile's and the kernel got SLOWER, 1.15 -> 1.29 ms at the best plan weight; they stay on fp32 MFMAs)
             if (__builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI) == 4 * 8 + 4) {
                 f32x4* const stage = stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kStageF4;
                 switch (__builtin_amdgcn_readfirstlane(jb.bias)) {
-                    case 0: wgrad_job_split<0>(jb, a, lane, ji, stage); break;
-                    case 1: wgrad_job_split<1>(jb, a, lane, ji, stage); break;
-                    case 2: wgrad_job_split<2>(jb, a, lane, ji, stage); break;
-                    default: wgrad_job_split<3>(jb, a, lane, ji, stage); break;
+                    case 2: wgrad_job_split<2, 4>(jb, a, lane, ji, stage); break;
+                    case 3: wgrad_job_split<3, 4>(jb, a, lane, ji, stage); break;
+                    default: wgrad_job_split<1, 4>(jb, a, lane, ji, stage); break;     // 1, and 0 (sums dropped)
                 }
                 continue;
             }
