@@ -61,6 +61,10 @@ struct PanelPipeT {
     // three-term kernels (nnr_split.h): stash stores the part BEFORE the next one certainly issued after the last DMA piece of that
     // part's first panel (set by the kernel right before the call: a literal, folded after inlining; see enter<EXTRA>)
     int part_pre = 0;
+    // three-term training forward (nnr_split.h): while gates_on, the part that splits a hidden vector into its bf16 terms also leaves that
+    // vector's ReLU gate bits (register r -> bit r & 31 of gw[r >> 5]) -- the packed h term is zero exactly where the activation is
+    bool gates_on = false;
+    mutable uint32_t gw[4] = {0, 0, 0, 0};
 
     __device__ __forceinline__ int buffer(int p) const {   // ring slot of panel p of the current pass (p compile-time in the callers)
         const int b = p % kNBuf + phase;

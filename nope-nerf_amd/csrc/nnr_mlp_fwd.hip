@@ -134,22 +134,34 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int w = 0; w < HW; ++w) mw[w] = 0;
     };
+    constexpr bool kGateSplit = MODE == 2 && TRAIN && !kAblateNoMask;     // see NNR_RELU_PAIR below
+    auto store_gates = [&](int layer_idx) __attribute__((always_inline)) {      // both halves of a hidden layer's gates, from the pipe
+        if constexpr (kGateSplit) {
+            uint32_t* m = mask_base + (int64_t)layer_idx * 64 * L::mask_words;
+#pragma unroll
+            for (int w = 0; w < L::mask_words; ++w) m[w] = pipe.gw[w];
+        }
+    };
     auto store_mask = [&](const uint32_t(&mw)[HW], int layer_idx, int hb) __attribute__((always_inline)) {
-        if (TRAIN) {
+        if (TRAIN && !(kGateSplit && layer_idx < 8)) {
             uint32_t* m = mask_base + (int64_t)layer_idx * 64 * L::mask_words + hb * HW;
 #pragma unroll
             for (int w = 0; w < HW; ++w) m[w] = mw[w];
         }
     };
 // one epilogue unit u (registers 2u, 2u+1 of the half): h[off + 2u + i] = relu(acc) (+ sign bit) or plain move.  Mask bit r = (x > 0).
-#define NNR_RELU_PAIR(ACC, OFF, MW)                                                                          \
+    // Three-term training mode: the gates of the hidden layers come out of the NEXT layer's split (gate_pair, nnr_split.h) -- two
+    // instructions per value less in the epilogue units, and the units' mask words no longer live across the passes.  GATE: this call site
+    // still makes its own (the colour-hidden layer, whose output no GEMM part splits).
+#define NNR_RELU_PAIR(ACC, OFF, MW) NNR_RELU_PAIR_(ACC, OFF, MW, !kGateSplit)
+#define NNR_RELU_PAIR_(ACC, OFF, MW, GATE)                                                                   \
     [&](int u) __attribute__((always_inline)) {                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
             const int r = 2 * u + i;                                                                         \
             const float x = ACC[r >> 4][r & 15];                                                             \
             h[(OFF) + r] = relu1(x);                                                                         \
             /* (x > 0) == (relu(x) != 0): as integers, min(bits, 1) shifted into place -- two instructions  */ \
-            if (TRAIN && !kAblateNoMask) MW[r >> 5] |= min(__float_as_uint(h[(OFF) + r]), 1u) << (r & 31);    \
+            if (TRAIN && !kAblateNoMask && (GATE)) MW[r >> 5] |= min(__float_as_uint(h[(OFF) + r]), 1u) << (r & 31); \
         }                                                                                                    \
     }
 #define NNR_MOVE_PAIR(ACC, OFF)                                                                              \
@@ -180,7 +192,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         init_acc(accA, L::bias_off(li));
         clear_mask(mwB);
         // pass A: the first half of the k-groups only needs h[0,HR); the previous layer's half B is finished meanwhile
+        pipe.gates_on = kGateSplit;
         gemm_part<DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, pa, stash, NNR_RELU_PAIR(accB, HR, mwB));
+        pipe.gates_on = false;
+        store_gates(li - 1);
         store_mask(mwB, li - 1, 1);
         init_acc(accB, L::bias_off(li) + L::Dh);
         clear_mask(mwA);
@@ -197,7 +212,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // hidden 5: [h4 ; e] -> D   (skip connection, input order [h, posenc]: model/official_nerf.py:63)
     init_acc(accA, L::bias_off(4));
     clear_mask(mwB);
+    pipe.gates_on = kGateSplit;
     gemm_part<DT, HT, TRAIN, NP, 2, 0>(accA, h, pipe, p0(F_L5HA), xh(3), NNR_RELU_PAIR(accB, HR, mwB));
+    pipe.gates_on = false;
+    store_gates(3);
     store_mask(mwB, 3, 1);
     float e5[32];
 #pragma unroll
@@ -240,8 +258,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         };
         // 4 units per k-group: the NP finishing units occupy k-groups [0, NP/4) -- long before k-group 2*DT first reads
         // h[HR..] -- and the 2*NP density units k-groups [NP/4, 3*NP/4) <= 4*DT
+        pipe.gates_on = kGateSplit;
         gemm_part<DT, HT, TRAIN, 3 * NP, 4, 0>(accA, h, pipe, p0(F_RGBH_F), xh(7), finish_then_sigma);
+        pipe.gates_on = false;
     }
+    store_gates(7);
     store_mask(mwB, 7, 1);
     const float sg = sg0 + sg1;
     const float sigma_raw = sg + __shfl_xor(sg, 32, 64) + bias[L::bias_off(8)];
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 8);
     clear_mask(mwA);
 #pragma unroll
-    for (int u = 0; u < NP; ++u) NNR_RELU_PAIR(accA, 0, mwA)(u);   // g = h[0, HR)
+    for (int u = 0; u < NP; ++u) NNR_RELU_PAIR_(accA, 0, mwA, true)(u);   // g = h[0, HR)
     store_mask(mwA, 8, 0);
     if (TRAIN) {
         float* xg = a.ws_xg + ss * (D / 2) + 4 * half;
@@ -322,6 +343,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     }
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 9);
 #undef NNR_RELU_PAIR
+#undef NNR_RELU_PAIR_
 #undef NNR_MOVE_PAIR
     pipe.next_pass(pass + 2 < n_pass);
     }   // pass

@@ -36,6 +36,15 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint
 #ifndef NNR_SPLIT_TERMS
 #define NNR_SPLIT_TERMS 6
 #endif
+// bits 0, 1 = (low half != 0), (high half != 0) of a packed bf16 pair: the ReLU gates of the two activations it holds (an activation is
+// >= 0 after the ReLU, and its h term is zero exactly when it is: bf16 has fp32's exponent range).  Two gates in four instructions where
+// the epilogue's compare / select / or took three per value.
+__device__ __forceinline__ uint32_t gate_pair(uint32_t hpk) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, hpk), u16x2{1, 1}));
+    return (u & 1u) | (u >> 15);
+}
+
 // at most n LDS reads outstanding (n folds after unrolling; lgkmcnt is a 4-bit field); tied to the fragment like wait_frag
 __device__ __forceinline__ void wait_lgkm_n(f32x4& frag, int n) {
 #ifdef NNR_SPLIT_SAFE_SYNC
@@ -190,8 +199,16 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
         for (int mt = 0; mt < MT; ++mt) fr[c][mt] = frag_read(panel_addr, c * MT + mt);
     uint32_t xs[3][4], xn[3][4];   // [class][pair]: the packed B operands of the current / next row
     f32x2 rr[4];                   // the residuals of the next row's pairs between the split stages (adjacent registers: packed subtracts)
+    const bool gates = STASH && pipe.gates_on;      // (set by the kernel right before the call: folded)
+    if (gates) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) split_pair(in[2 * q], in[2 * q + 1], xs[2][q], xs[1][q], xs[0][q]);
+        for (int w = 0; w < 4; ++w) pipe.gw[w] = 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        split_pair(in[2 * q], in[2 * q + 1], xs[2][q], xs[1][q], xs[0][q]);
+        if (gates) pipe.gw[0] |= gate_pair(xs[2][q]) << (2 * q);
+    }
 
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -245,6 +262,7 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                         rr[k] = f32x2{in[8 * (g + 1) + 2 * k], in[8 * (g + 1) + 2 * k + 1]};
                         xn[2][k] = pack_pair(rr[k]);
                         rr[k] = rr[k] - f32x2{__uint_as_float(xn[2][k] << 16), __uint_as_float(xn[2][k] & 0xffff0000u)};
+                        if (gates) pipe.gw[(8 * (g + 1) + 2 * k) >> 5] |= gate_pair(xn[2][k]) << ((8 * (g + 1) + 2 * k) & 31);
                     }
                 } else if (kind == 1) {     // stage B: m, and what it leaves
                     if (!last) {
