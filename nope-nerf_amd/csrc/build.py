@@ -38,8 +38,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-prag
 # training kernels a spill reload is not just a slow load: stores are always in flight there, hipcc waits for any load next to pending
 # stores with vmcnt(0), and every reload drains the stash-store queue with the matrix pipe idle -- the TRAINING kernels may only keep a handful of
 # prologue values in scratch, reloaded at pass start (where the pass waits for its inputs anyway), nothing inside a pass; the inference forward (no stores in flight) may spill its composite carry.
-# (three-term kernels: only the D = 256 training forward keeps its mask words' worth of scratch, 184 bytes -- DESIGN 4.3)
-SCRATCH_LIMIT = {"14mlp_fwd_kernelI": 0, "14mlp_fwd_kernelILi256ELb1ELi2E": 192, "16mlp_dgrad_kernelI": 0, "12wgrad_kernelI": 0, "14wgrad_b_kernelE": 0,
+# (three-term kernels: only the D = 256 training forward keeps a few pass-start values in scratch, 32 bytes)
+SCRATCH_LIMIT = {"14mlp_fwd_kernelI": 0, "14mlp_fwd_kernelILi256ELb1ELi2E": 48, "16mlp_dgrad_kernelI": 0, "12wgrad_kernelI": 0, "14wgrad_b_kernelE": 0,
                  "19mlp_fwd_bf16_kernelI": 48, "19mlp_fwd_bf16_kernelILi256ELb1E": 16, "19mlp_fwd_bf16_kernelILi128ELb1E": 16,
                  "21mlp_dgrad_bf16_kernelI": 64, "20composite_fwd_kernelE": 0, "20composite_bwd_kernelE": 0}
 
