@@ -240,12 +240,21 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
         three['frac_of_bf16_mfma_peak'] = round(three['tflops'] / PEAK_BF16_MFMA_TFLOPS, 4)
         three['gbytes_per_s'] = round(sum(byts.values()) * R * N / (mlp_ms * 1e-3) / 1e9, 1)
         three['frac_of_hbm_peak'] = round(three['gbytes_per_s'] / PEAK_HBM_GBS, 4)
-        return {'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs[dom], 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                'frac': round(gbs[dom] / PEAK_HBM_GBS, 4), 'traffic': traffic, 'traffic_source': src, 'timing': how,
-                'bytes_per_launch': byts[dom] * R * N, 'kernels': per, 'fused_mlp_all_three': three}
+        for k in byts:
+            per[k]['frac_of_bf16_mfma_peak'] = round(per[k]['executed_tflops'] / PEAK_BF16_MFMA_TFLOPS, 4)
+        # SURVEY 8(d) prices this mode against the dense bf16 MFMA peak; the HBM figure of the same kernel stands beside it (the stash the
+        # kernels' own layout defines is what they actually wait on: DESIGN 4.2)
+        return {'bound': 'mfma', 'kernel': dom, 'achieved': per[dom]['executed_tflops'], 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(per[dom]['executed_tflops'] / PEAK_BF16_MFMA_TFLOPS, 4),
+                'what': 'bf16 MFMA work executed by the dominant kernel (executed MACs x 2 / its in-step duration) against the dense bf16 peak',
+                'hbm': {'achieved': round(gbs[dom], 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs[dom] / PEAK_HBM_GBS, 4),
+                        'bytes_per_launch': byts[dom] * R * N, 'what': 'algorithmic stash bytes of the same kernel / its duration'},
+                'traffic': traffic, 'traffic_source': src, 'timing': how, 'flop_per_launch': flops, 'executed_flop_per_launch': executed,
+                'kernels': per, 'fused_mlp_all_three': three}
     traffic, src = _hbm_traffic(dom, False, (R, N))
-    three['frac'] = round(three['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4)
     products = L.fp32_products()
+    if products != 'split3':      # (three-term products run on the bf16 pipe: an "fp32 MFMA fraction" of them would read above 1)
+        three['frac'] = round(three['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4)
     if products == 'split3':
         # Every fp32 product as six bf16 MFMA terms (csrc/nnr_split.h): the kernels' bound is the bf16 matrix pipe, and the work they issue
         # is 6 x the executed MACs.  Forward / input gradient: all of it; weight gradient: the 4 x 4 tiles (480 of the 528 tile-units of
@@ -378,14 +387,37 @@ def cpu_baseline_port(sample_rays=192, warmup=2, steps=5):
 
 
 def cpu_config0(warmup=1, steps=3):
-    """BASELINE configs[0] -- the reference's own CPU-runnable case: configs/Tanks/Ignatius.yaml settings, 32 rays x 64 samples,
-    hidden_dim 128 (the reference architecture at D=128; `model.num_layers` is unused there), FULL training step
-    with the first-phase per-image losses on (point cloud + surface re-projection, on 216x384 mono-depth maps -> a 54x96 sampling
-    grid), forward + backward, on the host cores through the oracle."""
+    """BASELINE configs[0] -- the reference's own CPU-runnable case -- on the REFERENCE ITSELF when it is staged (`kind: "reference"`):
+    tools/cpu_reference_baseline.py --train-step runs the staged, unmodified /root/reference/model package's `Trainer.train_step`
+    (model/training.py:67-97) with configs/Tanks/Ignatius.yaml over configs/default.yaml, 32 rays x 64 samples, hidden_dim 128, the
+    first-phase per-image losses on, three Adam steps, for a small sweep of thread counts (2 k samples per step do not feed 32 threads) and
+    reports the best; otherwise the oracle port (`kind: "port"`, with the reason)."""
+    stage = os.path.join(ROOT, 'gpurun_stage', 'reference_cpu')
+    why = 'no staged reference (gpurun_stage/reference_cpu/model missing)'
+    if os.path.isfile(os.path.join(stage, 'model', 'training.py')) and os.path.isfile(os.path.join(stage, 'configs', 'Tanks', 'Ignatius.yaml')):
+        cmd = [sys.executable, os.path.join(ROOT, 'tools', 'cpu_reference_baseline.py'), '--train-step', '--rays', '32', '--samples', '64',
+               '--hidden', '128', '--warmup', str(warmup), '--steps', str(steps)]
+        env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'PYTHONPATH')}
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+            lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            if r.returncode == 0 and lines:
+                return json.loads(lines[-1])
+            why = 'reference worker failed: ' + (r.stderr.strip().splitlines() or ['?'])[-1][:300]
+        except Exception as e:        # noqa: BLE001 -- a baseline must never take the benchmark down
+            why = 'reference worker failed: %r' % (e,)
+    out = cpu_config0_port(warmup, steps)
+    out['fallback_reason'] = why
+    return out
+
+
+def cpu_config0_port(warmup=1, steps=3):
+    """The same case through the oracle port (fallback when no reference is staged): forward + backward of the render slice and the
+    per-image terms on 108 x 192 mono-depth maps (a 27 x 48 grid); 8 threads at most."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as orc
     host_cores, cpu_model = _host_cpu()
-    threads = min(host_cores, 32)
+    threads = min(host_cores, 8)
     torch.set_num_threads(threads)
     R, N, D, dh, dw = 32, 64, 128, 108, 192
     g = torch.Generator().manual_seed(0)
@@ -428,9 +460,12 @@ def _timed_steps(trainer, data, warmup, steps, use_dist):
     from nnr import lib as L
     lib = L.load()
     L.check(lib.nnr_prof_begin(steps), 'nnr_prof_begin')      # two event records per MLP kernel launch: microseconds of host time per step
-    t0 = time.perf_counter()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # one record per step on the step's stream, no sync:
+    t0 = time.perf_counter()                                                      # the spread of the timed steps (the region is ~70 ms)
+    marks[0].record()
     for i in range(steps):
         ld = step(warmup + i)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -439,6 +474,10 @@ def _timed_steps(trainer, data, warmup, steps, use_dist):
     ms4, n4 = (C.c_float * 4)(), (C.c_int32 * 4)()
     L.check(lib.nnr_prof_end(ms4, n4), 'nnr_prof_end')
     in_step = {'mlp_fwd': float(ms4[0]), 'mlp_dgrad': float(ms4[1]), 'mlp_wgrad': float(ms4[2]), 'launches': int(n4[0])}
+    per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)], dtype=np.float64)
+    in_step['step_ms'] = {'mean': round(float(per_step.mean()), 4), 'std': round(float(per_step.std()), 4), 'min': round(float(per_step.min()), 4),
+                          'max': round(float(per_step.max()), 4), 'median': round(float(np.median(per_step)), 4),
+                          'how': 'GPU time between event records at the end of consecutive timed steps (this rank)'}
     if use_dist:
         t = torch.tensor([elapsed], device=data['img'].device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -447,32 +486,38 @@ def _timed_steps(trainer, data, warmup, steps, use_dist):
     return elapsed, float(ld['loss'].detach()), in_step
 
 
-def extra_config(device, name, rays, n_samples, bf16, steps=10, warmup=3, products=None):
+def extra_config(device, name, rays, n_samples, bf16, steps=10, warmup=3, products=None, aux=False):
     """One more BASELINE configuration measured in the same run on one GPU: full Trainer.train_step + the kernels' roofline.
     products: 'mfma' / 'split3' for this block only (nnr.lib.set_fp32_products)."""
     from nnr import lib as L
     prev = L.set_fp32_products(products) if products else None
     try:
-        return _extra_config(device, name, rays, n_samples, bf16, steps, warmup)
+        return _extra_config(device, name, rays, n_samples, bf16, steps, warmup, aux)
     finally:
         if prev:
             L.set_fp32_products(prev)
 
 
-def _extra_config(device, name, rays, n_samples, bf16, steps, warmup):
+def _extra_config(device, name, rays, n_samples, bf16, steps, warmup, aux=False):
     from nnr import lib as L
-    trainer, net = build_trainer(device, 1, False, bf16, rays, n_samples)
+    trainer, net = build_trainer(device, 1, aux, bf16, rays, n_samples)
     data = synthetic_batch(device)
     elapsed, loss, in_step = _timed_steps(trainer, data, warmup, steps, False)
     ms = elapsed / steps * 1e3
     roof = kernel_roofline(net, device, reps=3, bf16=bf16, rays=rays, n_samples=n_samples, in_step=in_step)
     out = {'workload': name, 'rays_per_gpu': rays, 'n_samples': n_samples, 'hidden': HIDDEN,
            'dtype': 'bf16 products / f32 accumulate' if bf16 else 'f32', 'fp32_products': None if bf16 else L.fp32_products(),
-           'steps': steps, 'warmup': warmup,
-           'ms_per_step': round(ms, 4), 'value': round(rays / (ms * 1e-3), 1), 'unit': 'rays/s', 'final_loss': round(loss, 6),
+           'steps': steps, 'warmup': warmup, 'aux_per_image_losses': bool(aux),
+           'ms_per_step': round(ms, 4), 'step_ms': in_step['step_ms'], 'value': round(rays / (ms * 1e-3), 1), 'unit': 'rays/s',
+           'final_loss': round(loss, 6),
            'roofline': {k: roof[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'timing')},
            'kernels_ms': {k: v['ms'] for k, v in roof['kernels'].items()},
            'kernels_isolated_ms': {k: v['isolated_ms'] for k, v in roof['kernels'].items()}, 'fused_mlp_all_three': roof['fused_mlp_all_three']}
+    if 'hbm' in roof:
+        out['roofline']['hbm'] = roof['hbm']
+    if aux:     # everything of the step that is not one of the three MLP kernels: the per-image block + the small launches
+        mlp = sum(out['kernels_ms'][k] for k in ('mlp_fwd', 'mlp_dgrad', 'mlp_wgrad'))
+        out['outside_the_three_mlp_kernels_ms'] = round(ms - mlp, 4)
     del trainer, net, data
     torch.cuda.empty_cache()
     return out
@@ -519,6 +564,9 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--rays-per-gpu', type=int, default=R_PER_GPU, help='rays each rank renders per step (BASELINE configs[3]: 4096)')
+    ap.add_argument('--total-rays', type=int, default=0,
+                    help='STRONG scaling: the step is this many rays in total, every rank renders total / N of them (the default is weak scaling: '
+                         '--rays-per-gpu on every rank); e.g. --total-rays 32768 --gpus 8 = BASELINE configs[3]')
     ap.add_argument('--samples', type=int, default=N_SAMPLES, help='samples per ray (headline 192 = 64 + 128; stock default 128)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the extra `configs` blocks (bf16 4096x128, fp32 N=128, CPU configs[0])')
@@ -576,6 +624,10 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
 
     R, N = args.rays_per_gpu, args.samples
+    if args.total_rays:
+        if args.total_rays % (4 * world):
+            raise SystemExit(f"--total-rays {args.total_rays} must be a multiple of 4 x the number of ranks ({world})")
+        R = args.total_rays // world
     trainer, net = build_trainer(device, world, args.aux, args.bf16, R, N)
     data = synthetic_batch(device)
     elapsed, loss_val, in_step = _timed_steps(trainer, data, args.warmup, args.steps, use_dist)
@@ -589,17 +641,17 @@ def main():
         rays = R * world
         from nnr import lib as nnr_lib
         fp32_products = nnr_lib.fp32_products()
-        headline = (R, N) == (R_PER_GPU, N_SAMPLES) and not args.bf16
+        headline = (R, N) == (R_PER_GPU, N_SAMPLES) and not args.bf16 and not args.total_rays
         what = ('BASELINE configs[1]: 1024 rays/GPU x 192 samples (64 coarse + 128 fine pinned as one 192-sample stratified pass)'
                 if headline else f'{R} rays/GPU x {N} samples')
         out = {
             'metric': 'training rays/sec', 'value': round(rays / (ms * 1e-3), 1), 'unit': 'rays/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 products / f32 accumulate' if args.bf16 else 'f32', 'data': 'synthetic',
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'step_ms': in_step['step_ms'], 'higher_is_better': True,
+            'scaling': 'strong' if args.total_rays else 'weak', 'vs_baseline': None, 'dtype': 'bf16 products / f32 accumulate' if args.bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': what + ', 8-layer-256 MLP, pose + distortion learnable, ' + ('bf16 MFMA' if args.bf16 else FP32_HOW[fp32_products]) +
                                    '; full Trainer.train_step incl. 3 Adam steps; aux per-image losses ' + ('ON (pc + rgb_s)' if args.aux else 'off'),
                        'fp32_products': None if args.bf16 else fp32_products,
-                       'rays_per_gpu': R, 'n_samples': N, 'hidden': HIDDEN, 'image': [IMG_H, IMG_W],
+                       'rays_per_gpu': R, 'total_rays': rays, 'n_samples': N, 'hidden': HIDDEN, 'image': [IMG_H, IMG_W],
                        'parallelism': f'dp{world} (ray-sharded, one flat all-reduce)'},
             'final_loss': round(loss_val, 6),
         }
@@ -619,6 +671,10 @@ def main():
                 # the headline shape with v_mfma_f32_32x32x2_f32 products in all three kernels (the fp32 path of rounds 1-2)
                 'fp32_mfma_1024x192': extra_config(device, 'BASELINE configs[1] with fp32-MFMA products (NNR_FP32_PRODUCTS=mfma)',
                                                    R_PER_GPU, N_SAMPLES, False, products='mfma') if fp32_products != 'mfma' else None,
+                # what the reference runs for its first 10 000 epochs (configs/default.yaml:99-100,118): the headline step with the per-image
+                # point-cloud + surface re-projection losses ON
+                'fp32_1024x192_aux': extra_config(device, 'BASELINE configs[1] in the first training phase: per-image losses (pc + rgb_s) on',
+                                                  R_PER_GPU, N_SAMPLES, False, aux=True),
                 'cpu_32x64_d128': None if args.no_cpu_baseline else cpu_config0(),
             }
         print(json.dumps(out), flush=True)

@@ -23,6 +23,8 @@ NNR_F_SPLIT3 = 32
 # bf16 terms, six bf16 MFMAs per product with fp32 accumulation -- as close to the exact result as the fp32 instruction
 # (tests/test_gpu_split3.py, against fp64) at 2.7x fewer matrix-pipe cycles; "mfma" = v_mfma_f32_32x32x2_f32 (NNR_FP32_PRODUCTS=mfma).
 _fp32_products = os.environ.get("NNR_FP32_PRODUCTS", "split3")
+if _fp32_products not in ("split3", "mfma"):      # a typo must not silently select the other arithmetic (packed layout, plan and kernels differ)
+    raise ValueError("NNR_FP32_PRODUCTS=%r: expected 'split3' or 'mfma'" % _fp32_products)
 
 
 def set_fp32_products(kind: str) -> str:

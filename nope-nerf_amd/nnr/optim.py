@@ -10,6 +10,7 @@ optimizers itself."""
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Sequence
 
 import torch
@@ -48,10 +49,15 @@ class MultiAdam:
         self._steps = None        # two (MAX_TENSORS,) float arrays: the counters ping-pong between them
         self._flip = 0
         self._slot = {}           # id(parameter) -> its fixed index into the counter arrays
+        self._free = []           # counter slots of parameters that no longer exist
+        self._alive = {}          # id(parameter) -> weak reference: a recycled id must not inherit a dead parameter's counter slot
 
     def usable(self) -> bool:
         if not self.optimizers or not all(_plain_adam(o) for o in self.optimizers):
             return False
+        for k in [k for k, r in self._alive.items() if r() is None]:      # parameters that were re-created: free their slots
+            self._free.append(self._slot.pop(k))
+            del self._alive[k]
         n = len({id(p) for o in self.optimizers for g in o.param_groups for p in g['params']} | set(self._slot))
         devs = {p.device for o in self.optimizers for g in o.param_groups for p in g['params']}
         return 0 < n <= MAX_TENSORS and len(devs) == 1
@@ -79,8 +85,12 @@ class MultiAdam:
             self._steps = [torch.zeros(MAX_TENSORS, dtype=torch.float32, device=dev) for _ in range(2)]
         src, dst = self._steps[self._flip], self._steps[1 - self._flip]
         blocks = 0
+        rebind = []
         for i, (opt, p, gr, lr, b1, b2, eps) in enumerate(entries):
-            k = self._slot.setdefault(id(p), len(self._slot))     # a parameter keeps its counter slot for life (<= MAX_TENSORS: usable())
+            if id(p) not in self._slot:      # a parameter keeps its counter slot for life (<= MAX_TENSORS: usable())
+                self._slot[id(p)] = self._free.pop() if self._free else len(self._slot)
+                self._alive[id(p)] = weakref.ref(p)
+            k = self._slot[id(p)]
             st = opt.state[p]
             if len(st) == 0:        # torch's lazy state initialisation (Adam._init_group, fused flavour: float32 device counter)
                 st['step'] = torch.zeros((), dtype=torch.float32, device=dev)
@@ -91,7 +101,7 @@ class MultiAdam:
                 step = torch.as_tensor(float(step), dtype=torch.float32, device=dev)
             if step.data_ptr() != src[k].data_ptr():      # a counter not in this step's source array yet (first step, restored
                 src[k].copy_(step.reshape(()))            # state, a parameter that sat out the previous step)
-            st['step'] = dst[k]                           # torch's state keeps pointing at the CURRENT counter
+            rebind.append((st, dst[k]))
             t.param[i], t.grad[i] = p.data_ptr(), gr.data_ptr()
             t.exp_avg[i], t.exp_avg_sq[i] = st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
             t.step_in[i], t.step_out[i] = src[k].data_ptr(), dst[k].data_ptr()
@@ -102,6 +112,8 @@ class MultiAdam:
         t.block_first[len(entries)] = blocks
         t.n_tensors = len(entries)
         L.check(L.load().nnr_adam_step(C.byref(t), L.stream()), "nnr_adam_step")
+        for st, counter in rebind:          # only after a successful launch: torch's state keeps pointing at the CURRENT counter
+            st['step'] = counter
         self._flip = 1 - self._flip
         for opt in self.optimizers:
             opt._opt_called = True          # what the LR schedulers' "step() before optimizer.step()" warning looks at

@@ -1,7 +1,8 @@
 """GPU (-m gpu): coarse performance guards.  Parity tests cannot see a kernel that computes the right numbers ten times too slowly --
 it has happened twice: a launch sized for one workgroup (D = 128 weight gradient) and a `#pragma unroll` loop that
 silently stopped unrolling, putting the fp32 input-gradient kernel's register arrays into scratch memory (8x slower, every parity test
-green; csrc/build.py now checks the compiler's scratch report as well).  Bounds are ~2x the measured durations on an MI355X."""
+green; csrc/build.py now checks the compiler's scratch report as well).  Bounds are 1.5x the durations measured on an MI355X (isolated
+launches, tools/time_kernels.py), per arithmetic mode: a 3x regression of one kernel used to pass the round-2 bounds."""
 import os
 import sys
 
@@ -12,26 +13,38 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-# ms per launch: (R, N, bf16) -> kernel -> bound
+# ms per launch, isolated launches: (R, N, mode) -> kernel -> bound = 1.5 x measured (round 3/4 boxes, the slower of the runs on record)
 BOUNDS = {
-    (1024, 192, False): {"mlp_fwd": 3.6, "mlp_dgrad": 3.3, "mlp_wgrad": 3.2, "mlp_fwd_infer": 3.0},      # measured 1.82 / 1.62 / 1.58 / 1.46
-    (4096, 128, True): {"mlp_fwd": 1.7, "mlp_dgrad": 1.7, "mlp_wgrad": 1.5, "mlp_fwd_infer": 1.0},       # measured 0.78 / 0.75 / 0.87-0.94 / 0.45
-    (1000, 100, False): {"mlp_fwd": 2.6, "mlp_dgrad": 2.4, "mlp_wgrad": 2.4, "mlp_fwd_infer": 2.2},      # flat decomposition (N % 32 != 0)
+    # three-term products (the default fp32 arithmetic): measured 1.13-1.22 / 0.99-1.02 / 1.03-1.15 / 0.80-0.85
+    (1024, 192, "split3"): {"mlp_fwd": 1.85, "mlp_dgrad": 1.55, "mlp_wgrad": 1.75, "mlp_fwd_infer": 1.3},
+    # fp32 MFMAs (NNR_FP32_PRODUCTS=mfma): measured 1.82 / 1.62 / 1.58 / 1.46
+    (1024, 192, "mfma"): {"mlp_fwd": 2.75, "mlp_dgrad": 2.45, "mlp_wgrad": 2.4, "mlp_fwd_infer": 2.2},
+    # bf16 products: measured 0.76-0.78 / 0.67-0.75 / 0.87-0.94 / 0.45-0.50
+    (4096, 128, "bf16"): {"mlp_fwd": 1.17, "mlp_dgrad": 1.13, "mlp_wgrad": 1.41, "mlp_fwd_infer": 0.75},
+    # flat decomposition (N % 32 != 0), three-term: no measurement on record beyond "under the ray-mode time x R N ratio": 2x of that
+    (1000, 100, "split3"): {"mlp_fwd": 1.3, "mlp_dgrad": 1.1, "mlp_wgrad": 1.3, "mlp_fwd_infer": 0.95},
 }
 
 
 @pytest.mark.parametrize("shape", sorted(BOUNDS))
-def test_mlp_kernels_are_not_an_order_of_magnitude_off(shape):
+def test_mlp_kernels_stay_within_one_and_a_half_times_their_measured_durations(shape):
     import bench
     import model as mdl
-    R, N, bf16 = shape
+    from nnr import lib as L
+    R, N, mode = shape
+    bf16 = mode == "bf16"
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    net = mdl.OfficialStaticNerf(bench.full_cfg(R, bf16=bf16, n_samples=N)).to(dev)
-    out = bench.kernel_roofline(net, dev, reps=4, bf16=bf16, rays=R, n_samples=N)
+    prev = L.set_fp32_products("mfma" if mode == "mfma" else "split3")
+    try:
+        net = mdl.OfficialStaticNerf(bench.full_cfg(R, bf16=bf16, n_samples=N)).to(dev)
+        out = bench.kernel_roofline(net, dev, reps=6, bf16=bf16, rays=R, n_samples=N)
+    finally:
+        L.set_fp32_products(prev)
+    got = {k: round(out["kernels"][k]["ms"], 3) for k in BOUNDS[shape]}
+    print("perf guard", shape, got)
     for k, bound in BOUNDS[shape].items():
-        ms = out["kernels"][k]["ms"]
-        assert ms <= bound, (shape, k, ms, bound)
+        assert got[k] <= bound, (shape, k, got[k], bound)
 
 
 def test_in_step_kernel_timing_hooks():

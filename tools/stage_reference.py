@@ -25,6 +25,9 @@ def stage(ref=None):
         if name.endswith(".py"):
             shutil.copyfile(os.path.join(ref, "model", name), os.path.join(STAGE, "model", name))
     shutil.copyfile(os.path.join(ref, "configs", "default.yaml"), os.path.join(STAGE, "configs", "default.yaml"))
+    # BASELINE configs[0] names configs/Tanks/Ignatius.yaml: bench.py's `cpu_32x64_d128` block runs the reference's Trainer.train_step on it
+    os.makedirs(os.path.join(STAGE, "configs", "Tanks"), exist_ok=True)
+    shutil.copyfile(os.path.join(ref, "configs", "Tanks", "Ignatius.yaml"), os.path.join(STAGE, "configs", "Tanks", "Ignatius.yaml"))
     return STAGE
 
 
