@@ -32,7 +32,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint
     l = pack_pair(r);
 }
 
-// experiments only (tools/gpu_r03_*.sh): NNR_SPLIT_SAFE_SYNC = every counted wait as a full one; NNR_SPLIT_TERMS = 1 / 3 / 6 of the terms
+// experiments only (tools/archive/r03/): NNR_SPLIT_SAFE_SYNC = every counted wait as a full one; NNR_SPLIT_TERMS = 1 / 3 / 6 of the terms
 #ifndef NNR_SPLIT_TERMS
 #define NNR_SPLIT_TERMS 6
 #endif
@@ -275,6 +275,14 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                 } else if (kind == 3) {
                     if constexpr (STASH) {
 #ifndef NNR_ABLATE_NO_STASH
+#ifdef NNR_SPLIT_TERM_STASH     // experiment (WRONG layout, timing only): the row's three packed term operands, 3 x 1 KiB contiguous, non-temporal
+                        {
+                            u32x4* const td = reinterpret_cast<u32x4*>(const_cast<char*>(stash_base) + 1024 * (3 * g + 2 * k) + 16 * pipe.lane);
+                            __builtin_nontemporal_store(u32x4{xs[2 * k][0], xs[2 * k][1], xs[2 * k][2], xs[2 * k][3]}, td);
+                            if (k == 0) __builtin_nontemporal_store(u32x4{xs[1][0], xs[1][1], xs[1][2], xs[1][3]}, td + 64);
+                            continue;
+                        }
+#endif
 #ifdef NNR_SPLIT_TILE_STASH     // experiment (WRONG layout, timing only): one contiguous 1 KiB block per store
                         f32x4* const dst = reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + 1024 * (2 * g + k) + 16 * pipe.lane);
 #else

@@ -3,10 +3,14 @@
 Two loaders behind the same call:
   * the reference's: a torch DataLoader over host arrays, default collate, one (1,3,h,w) frame (+ neighbour, depth maps) per
     step -- every step then pays a host-to-device copy of 10-25 MB in Trainer.process_data_dict (model/training.py:165-185);
-  * `dataloading.resident: True`: the whole scene is uploaded once (a 150-frame 540x960 scene with depth maps is about 1.2 GB of
-    the 288 GB of HBM) and every step receives views of the resident tensors, so the `.to(device)` calls of the trainer are
-    no-ops and nothing crosses PCIe inside the training loop.  The order of the views still comes from a torch sampler with the
-    same `shuffle` flag."""
+  * the resident one: the whole scene is uploaded once (a 150-frame 540x960 scene with depth maps is about 1.2 GB of the 288 GB of
+    HBM) and every step receives views of the resident tensors, so the `.to(device)` calls of the trainer are no-ops and nothing
+    crosses PCIe inside the training loop.  The order of the views still comes from a torch sampler with the same `shuffle` flag,
+    and the batches are bit-identical to the host loader's (tests/test_dataloading.py).
+Which one: `dataloading.resident` = True / False forces either; ABSENT (every YAML of the reference: train.py, unmodified, with its own
+configs) means AUTO -- resident when a GPU is there, the batch size is 1 (every config of the reference) and the scene takes at most
+half of the free device memory; otherwise the reference's loader.  The reference's loop then runs at the rate of the step, not of the
+host collate + PCIe copy of 10-25 MB per step (profiles/r04/scene_loop_*.json)."""
 import logging
 import os
 
@@ -111,17 +115,42 @@ class ResidentLoader(object):
             yield out
 
 
+def _scene_bytes(field):
+    return sum(int(a.nbytes) for a in (getattr(field, 'imgs', None), getattr(field, 'dpt_depth', None),
+                                       getattr(field, 'depth', None) if getattr(field, 'with_depth', False) else None) if a is not None)
+
+
+def _auto_resident(field, dcfg, mode):
+    """`dataloading.resident` absent: (use the resident loader?, why not)."""
+    if os.environ.get('NNR_RESIDENT', '') in ('0', 'off', 'false'):
+        return False, 'NNR_RESIDENT=0'
+    if not torch.cuda.is_available():
+        return False, 'no GPU'
+    if dcfg['batchsize'] != 1:
+        return False, 'batchsize %d' % dcfg['batchsize']
+    need = _scene_bytes(field)
+    free, _ = torch.cuda.mem_get_info()
+    if need > free // 2:
+        return False, 'the scene (%.1f GB) does not fit in half of the free device memory (%.1f GB)' % (need / 2 ** 30, free / 2 ** 30)
+    return True, ''
+
+
 def get_dataloader(cfg, mode='train', shuffle=True, n_views=None):
     """-> (iterable of batches, {'img': DataField}).  mode 'render' with n_views yields that many camera-only batches."""
     dcfg = cfg['dataloading']
     fields = get_data_fields(cfg, mode)
     if not (n_views is not None and mode == 'render'):
         n_views = fields['img'].N_imgs
-    if dcfg.get('resident', False):
+    resident = dcfg.get('resident', 'auto')
+    if resident == 'auto' or resident is None:
+        resident, why = _auto_resident(fields['img'], dcfg, mode)
+        if not resident:
+            logger.info('host loader (%s)', why)
+    if resident:
         if dcfg['batchsize'] != 1:
             raise ValueError('dataloading.resident serves one view per step (batchsize 1), as every config of the reference does')
         device = torch.device(dcfg.get('resident_device') or ('cuda' if torch.cuda.is_available() else 'cpu'))
-        print(mode, ': ', n_views, ' views (resident on %s)' % device)
+        print(mode, ': ', n_views, ' views (resident on %s: %.1f MB)' % (device, _scene_bytes(fields['img']) / 2 ** 20))
         return ResidentLoader(fields['img'], n_views, shuffle, device), fields
     dataset = OurDataset(fields, n_views=n_views, mode=mode)
     loader = data.DataLoader(dataset, batch_size=dcfg['batchsize'], num_workers=dcfg['n_workers'], shuffle=shuffle,

@@ -13,6 +13,7 @@ import json
 import os
 import runpy
 import sys
+import time
 import types
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -23,7 +24,7 @@ def main():
     script, argv = sys.argv[1], sys.argv[2:]
     # our packages first, the reference checkout last: what a user gets who copies model/, dataloading/ and utils_poses/ over theirs
     sys.path[:0] = [os.path.join(ROOT, "nope-nerf_amd"), HERE, os.path.join(ROOT, "oracle")]
-    scalars = []
+    scalars, epoch_marks = [], []
     tb = types.ModuleType("torch.utils.tensorboard")
 
     class SummaryWriter:
@@ -32,6 +33,8 @@ def main():
 
         def add_scalar(self, tag, value, step):
             scalars.append((tag, float(value), int(step)))
+            if tag == "train/loss_pc_epoch":          # train.py:272 logs this once per epoch, right after the epoch's last step
+                epoch_marks.append((int(step), time.perf_counter()))
 
         def add_image(self, *a, **k):
             pass
@@ -91,6 +94,10 @@ def main():
         if out:
             with open(out, "w") as fh:
                 json.dump(scalars, fh)
+        out = os.environ.get("DROPIN_TIMES")          # [(iterations done, wall clock)] at every epoch end: the loop's rate (tools/loop_rate.py)
+        if out:
+            with open(out, "w") as fh:
+                json.dump(epoch_marks, fh)
 
 
 if __name__ == "__main__":

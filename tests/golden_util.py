@@ -81,18 +81,44 @@ def golden_grads(case):
     return out
 
 
-def compare_grad(name, got, kind, ref, norm, tol):
-    """Max-abs comparison after normalising by the golden tensor's max-abs when that exceeds 1
-    (SURVEY.md section 8d parity thresholds)."""
+def rel_l2(got, ref):
+    """|got - ref|_2 / |ref|_2 in float64: insensitive to the tensor's scale (unlike max-abs / max(1, |ref|max), which compares
+    ABSOLUTELY whenever the reference tensor stays below 1 -- every one of the 28 golden gradient tensors does) and to a single flipped
+    ReLU gate (unlike max-abs / |ref|max)."""
+    got, ref = np.asarray(got, dtype=np.float64).reshape(-1), np.asarray(ref, dtype=np.float64).reshape(-1)
+    den = float(np.linalg.norm(ref))
+    return float(np.linalg.norm(got - ref)) / den if den > 0 else float(np.linalg.norm(got - ref))
+
+
+def parity_log(line):
+    """Measured parity figures, one line per tensor, appended to $NNR_PARITY_LOG when it is set (the GPU scripts copy it to profiles/)."""
+    path = os.environ.get("NNR_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(line.rstrip() + "\n")
+
+
+REL_L2_TOL = 1e-3      # per gradient tensor, HIP fp32 path against the fp32 oracle / golden (VERDICT r03 item 2; measured values: parity_log)
+
+
+def compare_grad(name, got, kind, ref, norm, tol, rel_tol=REL_L2_TOL):
+    """Two bars per tensor: (i) max-abs after normalising by the golden tensor's max-abs when that exceeds 1 (SURVEY.md section 8d parity
+    thresholds -- an ABSOLUTE bar for every gradient tensor on record, all of which stay below 1); (ii) relative L2 <= rel_tol, which is
+    what catches a wrong tensor whose entries are all tiny (an all-zero first-layer gradient passes (i))."""
     got = got.detach().cpu().double().numpy()
     if kind == "sub":
         stride = got.size // SUBSAMPLE          # same rule as oracle/gen_golden.py
         got_cmp = got.reshape(-1)[::stride]
         assert abs(np.linalg.norm(got) - norm) <= tol * max(1.0, norm) * 10, name
+        assert abs(np.linalg.norm(got) - norm) <= rel_tol * norm, (name, float(np.linalg.norm(got)), norm)
     else:
         got_cmp = got
     ref = ref.astype(np.float64)
     scale = max(1.0, np.abs(ref).max())
     err = np.abs(got_cmp.reshape(ref.shape) - ref).max() / scale
     assert err <= tol, f"{name}: {err:.3e} > {tol}"
+    rl2 = rel_l2(got_cmp, ref)
+    parity_log("%s max-abs %.3e rel-L2 %.3e ref-max %.3e" % (name, err, rl2, float(np.abs(ref).max())))
+    if float(np.abs(ref).max()) > 0:
+        assert rl2 <= rel_tol, f"{name}: relative L2 {rl2:.3e} > {rel_tol}"
     return err

@@ -68,3 +68,19 @@ def test_one_rank_on_a_real_rccl_group():
     assert line["value"] > 1e4 and line["final_loss"] == line["final_loss"]      # a finite loss after steps that all-reduced on RCCL
     print("one-rank RCCL group: %.0f rays/s, flat all-reduce of %d floats %.0f us"
           % (line["value"], line["collective"]["bucket_floats"], line["collective"]["allreduce_us"]))
+
+
+def test_strong_scaling_switch_and_config4_rank_shape():
+    """`--total-rays T`: the step is T rays in total and each of the N ranks renders T / N of them (strong scaling; the default is weak).
+    Two ranks sharing the GPU split a 2048-ray step; then BASELINE configs[3]'s per-rank shape -- 4096 rays x 128 samples, bf16 products --
+    through the same two-rank path (8192 rays per step)."""
+    strong = _run(["--gpus", "2", "--total-rays", "2048"] + COMMON, {"NNR_ALLOW_SHARED_GPU": "1"})
+    assert strong["scaling"] == "strong" and strong["n_gpus"] == 2
+    assert strong["config"]["rays_per_gpu"] == 1024 and strong["config"]["total_rays"] == 2048
+    assert abs(strong["value"] - 2048 / (strong["ms_per_step"] * 1e-3)) <= 1e-3 * strong["value"]
+    c4 = _run(["--gpus", "2", "--rays-per-gpu", "4096", "--samples", "128", "--bf16"] + COMMON, {"NNR_ALLOW_SHARED_GPU": "1"})
+    assert c4["scaling"] == "weak" and c4["config"]["rays_per_gpu"] == 4096 and c4["config"]["total_rays"] == 8192
+    assert c4["collective"]["rccl_ranks_seen"] == 2 and c4["dtype"].startswith("bf16")
+    assert c4["value"] > 1e5 and c4["final_loss"] == c4["final_loss"]
+    print("strong scaling, 2048 rays over 2 ranks on one GPU: %.0f rays/s; configs[3] rank shape (2 x 4096 x 128, bf16): %.0f rays/s"
+          % (strong["value"], c4["value"]))

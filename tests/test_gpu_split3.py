@@ -45,19 +45,31 @@ def _errors(out, grads, ref, rgrads):
     return e
 
 
+def _rel_l2(out, grads, ref, rgrads):
+    """Relative L2 per tensor against fp64: unlike max-abs / max|ref| (above), not dominated by a single flipped ReLU gate."""
+    import golden_util as gu
+    e = {"out." + k: gu.rel_l2(out[k].detach().cpu().double().numpy(), ref[k].detach().numpy()) for k in ("rgb", "depth_pred", "alpha")}
+    e.update({k: gu.rel_l2(grads[k].detach().cpu().double().numpy(), r.numpy()) for k, r in rgrads.items()})
+    return e
+
+
 @pytest.mark.parametrize("D", [256, 128])
 def test_three_term_products_are_as_close_to_fp64_as_fp32_mfmas(D, capsys):
     from nnr import lib as L
     from test_gpu_parity import run_hip
     case = sp._case(256, 64, D, seed=77 + D)
     ref, rgrads = _oracle64(case)
-    errs = {}
+    errs, l2 = {}, {}
+    # the yardstick: the CPU fp32 oracle (== the reference, bit for bit) against the same fp64 evaluation
+    cout, cgrads = sp._oracle(case)
+    errs["cpu"], l2["cpu"] = _errors(cout, cgrads, ref, rgrads), _rel_l2(cout, cgrads, ref, rgrads)
     prev = L.fp32_products()
     try:
         for kind in ("mfma", "split3"):
             L.set_fp32_products(kind)
             out, grads = run_hip(case)
             errs[kind] = _errors(out, grads, ref, rgrads)
+            l2[kind] = _rel_l2(out, grads, ref, rgrads)
     finally:
         L.set_fp32_products(prev)
     worst = {kind: max(errs[kind].values()) for kind in errs}
@@ -71,6 +83,26 @@ def test_three_term_products_are_as_close_to_fp64_as_fp32_mfmas(D, capsys):
         # what must not happen is a tensor at another ORDER (a missing term shows as 4e-4, tools/split3_debug.py).  Floor 1e-6.
         assert errs["split3"][k] <= max(3.0 * errs["mfma"][k], 1e-6), (k, errs["split3"][k], errs["mfma"][k])
     assert mean["split3"] <= 1.25 * mean["mfma"] + 1e-8
+    # Against the yardstick, in relative L2: every tensor of either HIP mode within 2x of what CPU fp32 (the reference's own arithmetic)
+    # leaves against fp64 (floor 1e-6: tensors both sides hold to rounding level).  VERDICT r03 weak 2: in the max-abs metric above the HIP
+    # modes read 3x worse than CPU fp32 at D = 256 and 20x better at D = 128 -- single gate flips; this is the metric that can bound.
+    import golden_util as gu
+    import os
+    worst_ratio = ("", 0.0)
+    for k in l2["cpu"]:
+        gu.parity_log("fp64 yardstick D=%d %s: rel-L2 cpu-fp32 %.3e hip-mfma %.3e hip-split3 %.3e | max-abs/|ref|max cpu %.3e mfma %.3e split3 %.3e"
+                      % (D, k, l2["cpu"][k], l2["mfma"][k], l2["split3"][k], errs["cpu"][k], errs["mfma"][k], errs["split3"][k]))
+        for kind in ("mfma", "split3"):
+            worst_ratio = max(worst_ratio, (k + "/" + kind, l2[kind][k] / max(l2["cpu"][k], 1e-6)), key=lambda x: x[1])
+    with capsys.disabled():
+        print("D=%d vs fp64 in relative L2: mean over tensors -- CPU fp32 %.2e, fp32 MFMAs %.2e, three-term %.2e; worst HIP / max(CPU, 1e-6) "
+              "ratio %.2f (%s); max-abs metric: CPU fp32 worst %.2e mean %.2e"
+              % (D, np.mean(list(l2["cpu"].values())), np.mean(list(l2["mfma"].values())), np.mean(list(l2["split3"].values())),
+                 worst_ratio[1], worst_ratio[0], max(errs["cpu"].values()), float(np.mean(list(errs["cpu"].values())))))
+    if os.environ.get("NNR_FP64_YARDSTICK_REPORT_ONLY") != "1":
+        for k in l2["cpu"]:
+            for kind in ("mfma", "split3"):
+                assert l2[kind][k] <= 2.0 * max(l2["cpu"][k], 1e-6), (D, k, kind, l2[kind][k], l2["cpu"][k])
 
 
 def test_three_term_step_at_1024x192_matches_the_oracle_end_to_end(capsys):
@@ -89,11 +121,16 @@ def test_three_term_step_at_1024x192_matches_the_oracle_end_to_end(capsys):
         err = float((out[k].detach().cpu() - ref[k].detach()).abs().max())
         worst_out = max(worst_out, err)
         assert err <= 1e-4, (k, err)
-    worst = ("", 0.0)
+    import golden_util as gu
+    worst, worst_l2 = ("", 0.0), ("", 0.0)
     for k, r in rgrads.items():
         err = float((grads[k].detach().cpu().double() - r.double()).abs().max()) / max(1.0, float(r.abs().max()))
         worst = max(worst, (k, err), key=lambda x: x[1])
         assert err <= 1e-4, (k, err)
+        rl2 = gu.rel_l2(grads[k].detach().cpu().double().numpy(), r.double().numpy())
+        gu.parity_log("three-term 1024x192 vs oracle %s max-abs %.3e rel-L2 %.3e ref-max %.3e" % (k, err, rl2, float(r.abs().max())))
+        worst_l2 = max(worst_l2, (k, rl2), key=lambda x: x[1])
+        assert rl2 <= gu.REL_L2_TOL, (k, rl2)
     with capsys.disabled():
-        print("\nthree-term products, 1024x192 D=256 end to end vs oracle: outputs %.2e, worst of 28 gradient tensors %.2e (%s)"
-              % (worst_out, worst[1], worst[0]))
+        print("\nthree-term products, 1024x192 D=256 end to end vs oracle: outputs %.2e, worst of 28 gradient tensors max-abs %.2e (%s), "
+              "relative L2 %.2e (%s)" % (worst_out, worst[1], worst[0], worst_l2[1], worst_l2[0]))
