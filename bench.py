@@ -153,7 +153,7 @@ def _hbm_traffic(kernel, bf16=False, shape=None):
     return None, None
 
 
-def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, in_step=None):
+def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, in_step=None, sequence_reps=0):
     """Roofline block of the three fused-MLP kernels.  `in_step` = their mean durations INSIDE the timed training steps (HIP events
     on the launch stream around every launch, nnr_prof_begin / nnr_prof_end: _timed_steps): the basis of `achieved` when given.
     Each kernel is also timed in isolation (`reps` back-to-back launches between two events; reported as `isolated_ms`): that
@@ -211,6 +211,20 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
         torch.cuda.synchronize()
         times[name] = e0.elapsed_time(e1) / reps   # ms per launch
     isolated = dict(times)
+    sequence = None
+    if sequence_reps:      # the five stages in the order of a training step, `sequence_reps` times, an event pair around every launch: what a
+                           # kernel costs BETWEEN the others (clock, L2 and HBM state of a step) without a Trainer -- for experiment libraries
+        order = ['mlp_fwd', 'composite_fwd', 'composite_bwd', 'mlp_dgrad', 'mlp_wgrad']
+        marks = {k: [] for k in order}
+        for _ in range(sequence_reps + 2):
+            for k in order:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                L.check(stages[k](), k)
+                e1.record()
+                marks[k].append((e0, e1))
+        torch.cuda.synchronize()
+        sequence = {k: round(float(np.mean([a.elapsed_time(b) for a, b in v[2:]])), 4) for k, v in marks.items()}
     if in_step:
         times.update({k: in_step[k] for k in ('mlp_fwd', 'mlp_dgrad', 'mlp_wgrad')})
     how = ('HIP events on the launch stream around every launch of the kernel inside the %d timed training steps' % in_step['launches']
@@ -220,6 +234,9 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
     per = {k: {'ms': round(v, 4), 'tflops': round(flops / (v * 1e-3) / 1e12, 2) if k.startswith('mlp_') else None,
                'executed_tflops': round(executed / (v * 1e-3) / 1e12, 2) if k.startswith('mlp_') else None,
                'isolated_ms': round(isolated[k], 4)} for k, v in times.items()}
+    if sequence:
+        for k, v in sequence.items():
+            per[k]['sequence_ms'] = v
     dom = max(('mlp_fwd', 'mlp_dgrad', 'mlp_wgrad'), key=lambda k: times[k])
     achieved = flops / (times[dom] * 1e-3) / 1e12
     mlp_ms = times['mlp_fwd'] + times['mlp_dgrad'] + times['mlp_wgrad']

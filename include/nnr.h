@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNR_ABI_VERSION 3
+#define NNR_ABI_VERSION 4
 
 /* error codes */
 #define NNR_OK 0
@@ -134,6 +134,11 @@ int nnr_render_bwd(const nnr_cfg* cfg, const float* packed, const float* d_rgb, 
  * (the feature vector of model/official_nerf.py:87 and its gradient are never formed: that layer is folded into the
  * colour-hidden layer, see nnr_layout.h) */
 int64_t nnr_ws_plane(const nnr_cfg* cfg, int plane, int32_t* pitch_out);
+/* How the plane's elements are ordered (ABI 4): 0 = row-major fp32 [sample][pitch]; 1 = tile-major bf16 (NNR_F_BF16 training, above);
+ * 2 = tile-major fp32 -- NNR_F_SPLIT3 training, planes 31..38 and 40: 1 KiB blocks [chunk of 32 samples][octet j of features], a block
+ * is [lane = 32 h + c][4 floats] = features 8 j + 4 h + {0..3} of sample 32 chunk + c (nnr_layout.h: tile32_index); offset and pitch
+ * (= floats per sample) are those nnr_ws_plane reports.  <0 for an unknown plane. */
+int nnr_ws_plane_layout(const nnr_cfg* cfg, int plane);
 
 /* Individual stages, exported for profiling and bench.py's per-kernel roofline timing.  Same arguments
  * and workspace contract as the fused entry points above. */

@@ -39,6 +39,7 @@ WsLayout ws_layout(const nnr_cfg* c) {
     w.D = c->hidden;
     w.train = (c->flags & NNR_F_TRAIN) != 0;
     w.bf16 = w.train && (c->flags & NNR_F_BF16) != 0;
+    w.tile32 = w.train && (c->flags & (NNR_F_BF16 | NNR_F_SPLIT3)) == NNR_F_SPLIT3;   // the three-term training mode's gradient planes (nnr_layout.h)
     return w;
 }
 
@@ -477,6 +478,16 @@ int64_t nnr_ws_plane(const nnr_cfg* cfg, int pl, int32_t* pitch_out) {
     return pl < 0 ? -1 : o;
 }
 
+int nnr_ws_plane_layout(const nnr_cfg* cfg, int pl) {
+    if (check_cfg(cfg) != NNR_OK) return -1;
+    const WsLayout w = ws_layout(cfg);
+    int pitch = 0;
+    if (pl < 0 || w.plane(pl, &pitch) < 0) return -1;
+    if (w.tiled(pl)) return 2;
+    if (w.bf16 && ((pl >= P_XH1 && pl < P_XH1 + 8) || pl == P_XG || pl == P_XE16 || pl == P_XF16 || (pl >= P_DH1 && pl < P_DH1 + 8) || pl == P_DG)) return 1;
+    return 0;
+}
+
 size_t nnr_plan_bytes(const nnr_cfg* cfg) {
     if (check_cfg(cfg) != NNR_OK) return 0;
     if (is_bf16(cfg)) return plan_bytes(build_plan_bf16(cfg));
@@ -680,6 +691,7 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const float* packed, const nnr_param_grads
         int pitch = 0;
         a.plane_off[p] = w.plane(p, &pitch);
         a.plane_pitch[p] = pitch;
+        a.plane_tile[p] = w.tiled(p) ? 1 : 0;
     }
     {
         const Plan p = build_plan(cfg);   // host-only arithmetic, microseconds

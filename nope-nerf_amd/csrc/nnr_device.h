@@ -65,6 +65,10 @@ struct PanelPipeT {
     // vector's ReLU gate bits (register r -> bit r & 31 of gw[r >> 5]) -- the packed h term is zero exactly where the activation is
     bool gates_on = false;
     mutable uint32_t gw[4] = {0, 0, 0, 0};
+    // three-term input-gradient kernel (nnr_split.h): the stash planes are tile-major fp32 (nnr_layout.h, tile32_index) -- the part's
+    // `stash` argument is then the block of (this wave's chunk, first octet of the part's input) + 16 bytes per lane, every store one
+    // contiguous non-temporal 1 KiB block.  Set once by the kernel: a literal, folded after inlining.
+    bool stash_tile = false;
 
     __device__ __forceinline__ int buffer(int p) const {   // ring slot of panel p of the current pass (p compile-time in the callers)
         const int b = p % kNBuf + phase;

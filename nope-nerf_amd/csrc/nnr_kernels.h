@@ -78,6 +78,7 @@ struct WgradArgs {
     float* slots;              // n_jobs partial slots of kSlotFloats (see nnr_layout.h)
     int64_t plane_off[48];     // offset (floats) of each plane id, -1 if absent
     int32_t plane_pitch[48];
+    int32_t plane_tile[48];    // 1: the plane is tile-major fp32 (WsLayout::tiled, nnr_layout.h)
     const int32_t* wave_first; // wave w runs jobs [wave_first[w], wave_first[w+1])
     int n_jobs, n_waves;
     int bias_rows[13];         // elements of gb[l]: the main kernel zeroes them (the reduction adds up to two shares per row)

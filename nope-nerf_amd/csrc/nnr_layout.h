@@ -211,10 +211,24 @@ NNR_HD constexpr int64_t tile_major_index(int64_t s, int f, int G) {
     return ((((s >> 5) * G + (f >> 4)) * 64 + 32 * ((f & 7) >> 2) + (s & 31)) << 3) + 4 * ((f & 15) >> 3) + (f & 3);
 }
 
+// ---- tile-major fp32 planes (three-term training mode, round 4) ---------------------------------------------------------------------
+// The pre-activation gradients P_DH1.., P_DG of the NNR_F_SPLIT3 training workspace are stored in the order the producing wave holds
+// them, like the bf16 planes above but 4 bytes per value: a plane of W floats per sample is an array of 1 KiB BLOCKS [chunk of 32
+// samples][octet j of features], a block is [lane = 32 h + c][4 floats] with lane (h, c) holding, for sample 32 chunk + c, the features
+// 8 j + 4 h + {0..3} -- the four registers one stash store of gemm_part (nnr_split.h) writes.  Every stash store of the input-gradient
+// kernel is then ONE contiguous, non-temporal 1 KiB wave-store (8 whole cache lines that go past the L2 instead of evicting the weight
+// stream from it) where the row-major plane took 16 bytes into each of 64 lines: 1.07 -> 0.88 ms for that kernel
+// (profiles/r04/a_stash_variants.txt).  The weight-gradient kernel fetches 64-byte runs of such blocks by LDS-DMA (nnr_wgrad.hip).
+NNR_HD constexpr int64_t tile32_index(int64_t s, int f, int W) {
+    return (((s >> 5) * (W >> 3) + (f >> 3)) << 8) + ((((f >> 2) & 1) * 32 + (s & 31)) << 2) + (f & 3);
+}
+
 struct WsLayout {
     int64_t S, S_pad;
     int D;
     bool train;
+    bool tile32 = false; // NNR_F_SPLIT3 training: the gradient planes are tile-major fp32 (tiled(), above); offsets and sizes are unchanged
+    NNR_HD bool tiled(int p) const { return tile32 && train && ((p >= P_DH1 && p < P_DH1 + 8) || p == P_DG); }
     bool bf16 = false;   // NNR_F_BF16 training: the operands of the weight-gradient products -- hidden activations (P_XH1.., P_XG),
                          // the encodings' copies (P_XE16, P_XF16) and the pre-activation gradients (P_DH1.., P_DG) -- are tile-major
                          // bf16 planes (see above; pitch below = floats per sample = elements / 2); P_XE / P_XF hold the fp32

@@ -4,7 +4,8 @@
 // pre-activation gradient in the workspace for the weight-gradient kernel.  Same structure as the forward: one wave =
 // 32 samples, gradients stay in VGPRs between layers as MFMA B operands, A fragments are the transposed packed weights.
 // ReLU masks come from the 1-bit-per-activation stash written by the forward (32x less traffic than re-reading h).
-// MODE 2 (NNR_F_SPLIT3): every GEMM part's products as six bf16 MFMA terms (nnr_split.h), everything else unchanged.
+// MODE 2 (NNR_F_SPLIT3): every GEMM part's products as six bf16 MFMA terms (nnr_split.h); the gradient planes it leaves for the weight-
+// gradient kernel are tile-major fp32, one contiguous non-temporal 1 KiB wave-store per stash store (nnr_layout.h: tile32_index); everything else unchanged.
 #include "nnr_device.h"
 #include "nnr_kernels.h"
 #include "nnr_split.h"
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     // weight stream wraps around from pass to pass
     const int n_pass = a.chunks_per_ray > 0 ? a.chunks_per_ray : 1;
     pipe.more = n_pass > 1;
+    pipe.stash_tile = MODE == 2;     // three-term mode: the gradient planes are tile-major fp32, written past the L2 (nnr_layout.h)
     pipe.start();
     NNR_STAMP(tl_dgrad, 1);
     auto p0 = [&](int part) { return L::bwd_panel0(part); };
@@ -161,7 +163,8 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     };
     load_mask(mwA, 7, 0);
     init_sigma(accA, 0);
-    float* const dg_stash = a.ws_dg + ss * (D / 2) + 4 * half;   // d g goes to P_DG
+    // d g goes to P_DG.  Row-major: this lane's row + its half's four columns; tile-major (MODE 2): block (chunk, octet 0) + 16 bytes per lane
+    float* const dg_stash = MODE == 2 ? a.ws_dg + chunk * (int64_t)((D / 16) * 256) + 4 * lane : a.ws_dg + ss * (D / 2) + 4 * half;
     gemm_part<HT, HT, true>(accA, dg, pipe, p0(B_RGBH_FA), dg_stash);
     load_mask(mwB, 7, 1);
     init_sigma(accB, 1);
@@ -179,7 +182,10 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     NNR_STAMP(tl_dgrad, 3);
 
     // ---- trunk ----
-    auto dh = [&](int hidden_idx /*0..7*/) -> float* { return a.ws_dh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half; };
+    auto dh = [&](int hidden_idx /*0..7*/) -> float* {
+        if constexpr (MODE == 2) return a.ws_dh + (int64_t)hidden_idx * a.S_pad * D + chunk * (int64_t)((D / 8) * 256) + 4 * lane;
+        else return a.ws_dh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half;
+    };
     // Invariant from here on: d[0, HR) holds half A of the newest gradient, accB its half B still to be masked (mwB).
 
     // one transposed D x D layer at panel pa: consumes the gradient in d (stashing it to `stash`), produces the gradient of

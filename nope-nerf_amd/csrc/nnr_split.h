@@ -283,17 +283,23 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                             continue;
                         }
 #endif
-#ifdef NNR_SPLIT_TILE_STASH     // experiment (WRONG layout, timing only): one contiguous 1 KiB block per store
-                        f32x4* const dst = reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + 1024 * (2 * g + k) + 16 * pipe.lane);
-#else
-                        f32x4* const dst = reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + stash_off + 32 * (2 * g + k));
-#endif
                         const f32x4 val = f32x4{in[8 * g + 4 * k], in[8 * g + 4 * k + 1], in[8 * g + 4 * k + 2], in[8 * g + 4 * k + 3]};
-#ifdef NNR_SPLIT_NT_STASH
-                        __builtin_nontemporal_store(val, dst);   // experiment: keep the 1.9 GB of stash out of the L2's way
+                        if (pipe.stash_tile) {
+                            // tile-major plane (nnr_layout.h): store 2 g + k of the part is octet 2 g + k of its input -- one contiguous 1 KiB block
+                            // per wave, written past the L2 (whole lines: nothing for the L2 to merge, and the weight stream stays resident)
+                            __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + stash_off + 1024 * (2 * g + k)));
+                        } else {
+#ifdef NNR_SPLIT_TILE_STASH     // experiment (WRONG layout, timing only): one contiguous 1 KiB block per store
+                            f32x4* const dst = reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + 1024 * (2 * g + k) + 16 * pipe.lane);
 #else
-                        *dst = val;
+                            f32x4* const dst = reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + stash_off + 32 * (2 * g + k));
 #endif
+#ifdef NNR_SPLIT_NT_STASH
+                            __builtin_nontemporal_store(val, dst);   // experiment: keep the 1.9 GB of stash out of the L2's way
+#else
+                            *dst = val;
+#endif
+                        }
 #endif
                     }
                 } else if (kind == 4) {     // DMA pieces of the panel two ahead, spread over the rows of the current panel

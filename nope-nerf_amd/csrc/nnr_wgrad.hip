@@ -57,8 +57,16 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
     const int half = lane >> 5, m = lane & 31;
     const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
     const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
-    const float* dptr = a.ws + a.plane_off[jb.d_plane] + jb.d_col0 + (dok ? MI * m : 0) + (int64_t)half * dp;
-    const float* xptr = a.ws + a.plane_off[jb.x_plane] + jb.x_col0 + (xok ? NI * m : 0) + (int64_t)half * xp;
+    // Row of sample s of an operand = base + (s >> 5) * A + (s & 31) * B floats, for both plane layouts (nnr_layout.h): row-major
+    // A = 32 pitch, B = pitch; tile-major fp32 (the gradient planes of the three-term mode) A = one chunk of blocks = 32 pitch, B = 4,
+    // and the lane's columns c .. c + W - 1 (W <= 4, c a multiple of W) sit at (c >> 3) * 256 + ((c >> 2) & 1) * 128 + (c & 3) of the chunk.
+    // The samples of a stage are k + 2 u + half with k a multiple of 16: (s & 31) = (k & 31) + 2 u + half never carries.
+    const bool dt = a.plane_tile[jb.d_plane] != 0, xt = a.plane_tile[jb.x_plane] != 0;
+    const int dc = jb.d_col0 + (dok ? MI * m : 0), xc = jb.x_col0 + (xok ? NI * m : 0);
+    const int d_row = dt ? 4 : dp, x_row = xt ? 4 : xp;                         // B
+    const int64_t d_chunk = 32 * (int64_t)dp, x_chunk = 32 * (int64_t)xp;      // A
+    const float* dptr = a.ws + a.plane_off[jb.d_plane] + (dt ? (dc >> 3) * 256 + ((dc >> 2) & 1) * 128 + (dc & 3) : dc) + half * d_row;
+    const float* xptr = a.ws + a.plane_off[jb.x_plane] + (xt ? (xc >> 3) * 256 + ((xc >> 2) & 1) * 128 + (xc & 3) : xc) + half * x_row;
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -78,10 +86,12 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
     Vec<MI> dA[kU], dB[kU];
     Vec<NI> xA[kU], xB[kU];
     auto load_stage = [&](Vec<MI>(&d)[kU], Vec<NI>(&x)[kU], int64_t kk) {
+        const float* const dk = dptr + (kk >> 5) * d_chunk + (kk & 31) * d_row;      // (the wave-uniform part of the address)
+        const float* const xk = xptr + (kk >> 5) * x_chunk + (kk & 31) * x_row;
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-            d[u] = load_vec<MI>(dptr + (kk + 2 * u) * dp);
-            x[u] = load_vec<NI>(xptr + (kk + 2 * u) * xp);
+            d[u] = load_vec<MI>(dk + 2 * u * d_row);
+            x[u] = load_vec<NI>(xk + 2 * u * x_row);
         }
     };
     auto compute = [&](const Vec<MI>(&d)[kU], const Vec<NI>(&x)[kU]) {
@@ -157,7 +167,13 @@ constexpr int kStageF4 = 2 * 16 * 64;      // f32x4 per wave: 2 buffers x (8 gra
 // NI = 2: the 128 x 64 tiles against the position encoding (the bulk of the narrow tiles).  The activation rows are still fetched 16 bytes
 // per lane -- by the lanes' (m & 15): 16 lanes cover the 64 columns -- and lane n finds its two interleaved columns 2 n, 2 n + 1 in the
 // slot of lane n / 2; one activation sub-tile is made per block (in blocks 2 and 3), a block is 12 MFMAs.
-template <int BIAS, int NI>      // BIAS: WgradJob::bias (compile-time: the d(bias) sums are one add per sample pair in the tiles that carry them)
+// DTILE: the gradient operand's plane is tile-major fp32 (nnr_layout.h: tile32_index; the three-term input-gradient kernel writes it that way).
+// Its eight DMA instructions of a step then fetch 64-byte runs -- instruction j, lane i: feature quad 16 (j & 1) + (i & 15), samples
+// 4 (j >> 1) + (i >> 4) of the step, four consecutive samples of a quad being 64 contiguous bytes of a block -- into LDS slot 64 j + i, an
+// image in which lane (h, m)'s two samples of pair P sit 16 slots apart (one ds_read2st64_b32) and the 16 lanes a read services together hit
+// 16 different bank groups, exactly as in the row-major image.  Which samples a lane supplies to the MFMAs is unchanged.  All 128 columns
+// of a 4 x 4 tile's gradient operand are valid in every unit (wgrad_units), so this path has no clamped lanes.
+template <int BIAS, int NI, bool DTILE>      // BIAS: WgradJob::bias (compile-time: the d(bias) sums are one add per sample pair in the tiles that carry them)
 __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradArgs& a, int lane, int ji, f32x4* stage) {
     constexpr int MI = 4;
     static_assert(NI == 4 || NI == 2, "activation sub-tiles per job");
@@ -166,9 +182,10 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
     const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
     // (wave-uniform row base in scalar registers) + (32-bit lane offset): no vector address arithmetic per DMA
-    const char* const dg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane] + jb.d_col0);
+    const char* const dg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane] + (DTILE ? (jb.d_col0 >> 3) * 256 : jb.d_col0));
     const char* const xg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane] + jb.x_col0);
-    const int dlane = 4 * ((dok ? MI * m : 0) + 8 * half * dp);
+    const int dlane = DTILE ? ((lane & 15) >> 1) * 1024 + (lane & 1) * 512 + (lane >> 4) * 16 : 4 * ((dok ? MI * m : 0) + 8 * half * dp);
+    const int64_t d_chunk_bytes = 128 * (int64_t)dp;       // tile-major: bytes per 32-sample chunk of the plane
     const int xlane = NI == 4 ? 4 * ((xok ? NI * m : 0) + 8 * half * xp) : 4 * (4 * (m & 15) + 8 * half * xp);
     // d(bias): which of a pair's two samples this tile sums (WgradJob::bias: 1 all, 2 / 3: the two tiles of a row block share the samples
     // -- here by the parity of s)
@@ -184,6 +201,8 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     uint32_t Xc[NI][3][4], Xn[NI][3][4], Dq[2][3][4];   // current / next step's activation terms; [..][term: 0 = l, 1 = m, 2 = h][pair of samples]
     f32x2 fp[2][4];               // a pair's two values between its fetch and its split, then the residuals between the stages (adjacent: packed subtracts)
     const float* const lrow = reinterpret_cast<const float*>(stage) + 4 * lane;   // this lane's 4 floats of staged row r: lrow[256 r + c]
+    // tile-major gradient image: sample 8 h + 2 P (+ 1) of quad m at float 4 (256 h + 64 (m >> 4) + (m & 15)) + 512 (P >> 1) + 128 (P & 1) (+ 64)
+    const float* const lrowd = DTILE ? reinterpret_cast<const float*>(stage) + 4 * (256 * half + 64 * (m >> 4) + (m & 15)) : lrow;
     // the activation operand's columns of this lane in a staged row: its own slot (NI = 4), or half of the slot of lane m / 2 (NI = 2)
     const float* const lrowx = NI == 4 ? lrow : reinterpret_cast<const float*>(stage) + 4 * (32 * half + (m >> 1)) + 2 * (m & 1);
 
@@ -195,8 +214,17 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
 #ifdef NNR_ABLATE_WGRAD_NO_FETCH      /* profiling builds only (results NOT valid) */
 #define NNR_WFETCH(W, P, LR, ROW0, C) (fp[W][P] = f32x2{1.f + (float)(P), 2.f + (float)(C)})
 #else
-#define NNR_WFETCH(W, P, LR, ROW0, C) (fp[W][P] = f32x2{(LR)[256 * ((ROW0) + 2 * (P)) + (C)], (LR)[256 * ((ROW0) + 2 * (P) + 1) + (C)]})
+#define NNR_WOFF(ROW0, P, C, SECOND) (((ROW0) == 0 && DTILE) ? 512 * ((P) >> 1) + 128 * ((P) & 1) + (C) + 64 * (SECOND) : 256 * ((ROW0) + 2 * (P) + (SECOND)) + (C))
+#define NNR_WFETCH(W, P, LR, ROW0, C) (fp[W][P] = f32x2{(LR)[NNR_WOFF(ROW0, P, C, 0)], (LR)[NNR_WOFF(ROW0, P, C, 1)]})
 #endif
+// the gradient operand's DMA instruction S (0..7) of the step at sample KK: a staged row of the row-major plane, or 64-byte runs of the tile-major one
+#define NNR_WDMA_D(KK, S, DST, ROW)                                                                                                      \
+    do {                                                                                                                                 \
+        if constexpr (DTILE)                                                                                                             \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(dg + ((KK) >> 5) * d_chunk_bytes + ((KK) & 31) * 16 + ((S) & 1) * 8192 + ((S) >> 1) * 64 + dlane), \
+                                             (lds_ptr_t)((DST) + (ROW) * 64), 16, 0, 0);                                                 \
+        else NNR_WDMA(dg, dlane, dp, KK, S, DST, ROW);                                                                                    \
+    } while (0)
 // the split of pair P of component C of the rows [ROW0, ROW0 + 8), stage ST: 0 fetch, 1 h, 2 m, 3 l; W = residual set, BI >= 0: d(bias) slot
 #define NNR_WSPLIT(LR, ROW0, C, P, ST, Q, W, BI, BWT)                                        \
     do {                                                                                     \
@@ -221,13 +249,13 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     // prologue: the first step's rows, all terms of the activation operand, the first gradient sub-tile
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        NNR_WDMA(dg, dlane, dp, jb.k0, s, stage, s);
+        NNR_WDMA_D((int64_t)jb.k0, s, stage, s);
         NNR_WDMA(xg, xlane, xp, jb.k0, s, stage, 8 + s);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int j = 0; j < NI; ++j) NNR_WSPLIT_ALL(lrowx, 8, j, Xc[j], 1, -1);
-    NNR_WSPLIT_ALL(lrow, 0, 0, Dq[0], 0, 0);
+    NNR_WSPLIT_ALL(lrowd, 0, 0, Dq[0], 0, 0);
 
     // One 16-sample step per iteration of ONE loop body (two textual copies for the two buffer parities made hipcc assign the 256
     // accumulators to different registers in the copies and shuffle them in between: hundreds of moves and spills per step); the staging
@@ -238,8 +266,8 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
         const bool more = k + 16 < jb.k1;
         const int64_t kn = more ? k + 16 : k;
         const float nf = more ? 1.f : 0.f;
-        const float* const lc = lrow + 4096 * par;            // this step's staged rows, the next step's
-        const float* const ln = lrow + 4096 * (1 - par);
+        const float* const lc = lrowd + 4096 * par;           // this step's staged gradient rows, the next step's
+        const float* const ln = lrowd + 4096 * (1 - par);
         const float* const lnx = lrowx + 4096 * (1 - par);
         f32x4* const dst = stage + 1024 * (1 - par);
 #pragma unroll
@@ -261,7 +289,7 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
 #ifndef NNR_ABLATE_WGRAD_NO_DMA
                 {
                     const int q = i * G + g;                                      // the 16 rows of the next step, one per gap from the step's start
-                    if (q < 8) NNR_WDMA(dg, dlane, dp, kn, q, dst, q);
+                    if (q < 8) NNR_WDMA_D(kn, q, dst, q);
                     else if (q < 16) NNR_WDMA(xg, xlane, xp, kn, q - 8, dst, q);
                 }
 #endif
@@ -298,6 +326,8 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last step's prefetch writes LDS: let it finish before the next job reuses the area
 #undef NNR_WDMA
+#undef NNR_WDMA_D
+#undef NNR_WOFF
 #undef NNR_WSPLIT
 #undef NNR_WFETCH
 #undef NNR_WPACK
@@ -355,10 +385,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
             // per MFMA is 1.6 times the 4 x 4 tile's and the kernel got SLOWER, 1.15 -> 1.29 ms at the best plan weight; they stay on fp32 MFMAs)
             if (__builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI) == 4 * 8 + 4) {
                 f32x4* const stage = stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kStageF4;
+                // (every gradient plane of the three-term mode is tile-major: WsLayout::tiled -- the row-major instantiation is not built)
                 switch (__builtin_amdgcn_readfirstlane(jb.bias)) {
-                    case 2: wgrad_job_split<2, 4>(jb, a, lane, ji, stage); break;
-                    case 3: wgrad_job_split<3, 4>(jb, a, lane, ji, stage); break;
-                    default: wgrad_job_split<1, 4>(jb, a, lane, ji, stage); break;     // 1, and 0 (sums dropped)
+                    case 2: wgrad_job_split<2, 4, true>(jb, a, lane, ji, stage); break;
+                    case 3: wgrad_job_split<3, 4, true>(jb, a, lane, ji, stage); break;
+                    default: wgrad_job_split<1, 4, true>(jb, a, lane, ji, stage); break;     // 1, and 0 (sums dropped)
                 }
                 continue;
             }

@@ -59,6 +59,29 @@ def _use_fused_adam(opt):
     return True
 
 
+class _EarlyScalar(torch.Tensor):
+    """A logged loss scalar whose VALUE is already on its way to the host.
+
+    The reference's loop reads three scalars of every step with `.item()` (train.py:211-214) -- on a device tensor that is a blocking
+    copy on the step's stream, i.e. it waits for the step's backward and optimizer kernels too, and the next step's host work (config
+    annealing, a dozen launches of the front end) then runs with the GPU idle: 0.4 ms of a 3.5 ms step, 1.3 ms with the first-phase
+    per-image losses (profiles/r04/b_scene_loop.json).  The values exist as soon as the FORWARD is done: train_step copies them into
+    pinned host memory right behind the loss kernel (one stack launch + one asynchronous copy, enqueued before the backward) and returns
+    these tensors -- device tensors in every respect (same data, `.detach().cpu()`, formatting, arithmetic), except that `.item()` waits
+    for that copy's event only and answers from the host copy.  Same value, no drain of the launch queue."""
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def item(self):
+        early = getattr(self, '_early', None)
+        if early is None:
+            return torch.Tensor.item(self)
+        slot, generation, index, event = early
+        if slot['generation'] != generation:      # a scalar of an older step whose host buffer has been reused since: the device copy is the value
+            return torch.Tensor.item(self)
+        event.synchronize()
+        return slot['host'][index].item()
+
+
 class Trainer(object):
     def __init__(self, model, optimizer, cfg, device=None, optimizer_pose=None, pose_param_net=None,
                  optimizer_focal=None, focal_net=None, optimizer_distortion=None, distortion_net=None, **kwargs):
@@ -76,6 +99,8 @@ class Trainer(object):
         self._one = None
         self._nan_flag = None      # (pinned host flag, event) of the previous step's isnan(loss), read one step late
         self._nan_host = None
+        self._early_host = None    # four pinned buffers for the step's logged scalars (_EarlyScalar), used in turn
+        self.early_scalars = bool(cfg.get('early_scalars', True))   # training.early_scalars: False returns plain device tensors
         # the deferred NaN flag of the newest step is looked at before anything is written to disk (model/checkpoints.py)
         import weakref
         from model import checkpoints as _ck
@@ -112,6 +137,7 @@ class Trainer(object):
         loss_dict = self.compute_loss(data, it=it, epoch=epoch, scheduling_start=scheduling_start,
                                       out_render_path=render_path)
         loss = loss_dict['loss']
+        early = self._copy_scalars_early(loss_dict) if (loss.is_cuda and self.early_scalars) else None
         if loss.is_cuda:      # the root gradient as a cached constant: loss.backward() would launch a ones_like fill every step
             if self._one is None or self._one.device != loss.device:
                 self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
@@ -126,7 +152,32 @@ class Trainer(object):
             for net, opt in self._groups():
                 if opt:
                     opt.step()
+        if early is not None:
+            keys, slot, event = early
+            for i, k in enumerate(keys):
+                t = torch.Tensor._make_subclass(_EarlyScalar, loss_dict[k].detach())
+                t._early = (slot, slot['generation'], i, event)
+                loss_dict[k] = t
         return loss_dict
+
+    def _copy_scalars_early(self, loss_dict):
+        """Enqueue, BEFORE the backward, the copy of the step's 0-dim logged scalars to pinned host memory (see _EarlyScalar).  Not under
+        data parallelism: there the logged scalars are summed over the ranks after the backward (parallel.allreduce_gradients)."""
+        if parallel.world_size() > 1 or parallel.always_reduce():
+            return None
+        keys = [k for k, v in loss_dict.items() if torch.is_tensor(v) and v.is_cuda and v.dim() == 0 and v.dtype == torch.float32]
+        if not keys:
+            return None
+        if self._early_host is None or self._early_host[0]['host'].numel() < len(keys):
+            self._early_host = [{'host': torch.empty(max(16, len(keys)), dtype=torch.float32).pin_memory(), 'generation': 0} for _ in range(4)]
+        slot = self._early_host[0]
+        self._early_host.append(self._early_host.pop(0))      # the buffers of the last three steps stay valid for their readers
+        slot['generation'] += 1
+        with torch.no_grad():
+            slot['host'][:len(keys)].copy_(torch.stack([loss_dict[k].detach() for k in keys]), non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        return keys, slot, event
 
     # ------------------------------------------------------------------------------------------------ data
     def process_data_dict(self, data):

@@ -46,10 +46,12 @@ LAYER_NAMES = ("layers0.0", "layers0.2", "layers0.4", "layers0.6", "layers1.0", 
 
 # = NNR_ABI_VERSION of include/nnr.h; bumped whenever a signature, a struct or a blob layout that crosses the C ABI changes
 # (2: nnr_pc_error_bwd takes n_dst; round-2 layouts of nnr_aux_cfg and the bf16 plan blob.  3: nnr_step_rays_*; the weight-gradient
-# stage overwrites nnr_param_grads instead of accumulating into it)
-ABI_VERSION = 3
+# stage overwrites nnr_param_grads instead of accumulating into it.  4: nnr_ws_plane_layout; the gradient planes of a three-term training workspace
+# are tile-major fp32)
+ABI_VERSION = 4
 EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_floats", "nnr_workspace_floats",
            "nnr_plan_bytes", "nnr_plan_counts", "nnr_plan_build", "nnr_pack_weights", "nnr_render_fwd", "nnr_render_bwd", "nnr_ws_plane",
+           "nnr_ws_plane_layout",
            "nnr_mlp_fwd", "nnr_composite_fwd", "nnr_composite_bwd", "nnr_mlp_dgrad", "nnr_mlp_wgrad", "nnr_ray_reduce",
            "nnr_se3_exp_fwd", "nnr_se3_exp_bwd", "nnr_inv4_fwd", "nnr_inv4_bwd", "nnr_ray_setup_fwd", "nnr_ray_setup_bwd",
            "nnr_depth_gather_fwd", "nnr_depth_gather_bwd", "nnr_render_loss", "nnr_pixels_from_index", "nnr_pc_nearest",
@@ -128,6 +130,7 @@ def load():
     lib.nnr_render_bwd.argtypes = [cfgp, vp, vp, vp, C.POINTER(Params), vp, vp, vp, vp, vp, vp]
     lib.nnr_ws_plane.restype = i64
     lib.nnr_ws_plane.argtypes = [cfgp, C.c_int, C.POINTER(C.c_int32)]
+    lib.nnr_ws_plane_layout.argtypes = [cfgp, C.c_int]
     lib.nnr_mlp_fwd.argtypes = [cfgp] + [vp] * 9
     lib.nnr_composite_fwd.argtypes = [cfgp] + [vp] * 6
     lib.nnr_composite_bwd.argtypes = [cfgp] + [vp] * 4

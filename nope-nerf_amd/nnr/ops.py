@@ -179,6 +179,13 @@ def workspace_plane(cfg: L.Cfg, ws: torch.Tensor, plane: int, n_rows: Optional[i
         raise KeyError(plane)
     S = cfg.n_rays * cfg.n_samples
     rows = n_rows if n_rows is not None else S
+    if L.load().nnr_ws_plane_layout(C.byref(cfg), plane) == 2:
+        # tile-major fp32 (the gradient planes of a three-term training workspace): [chunk of 32 samples][octet j][half h][sample c][i],
+        # feature = 8 j + 4 h + i  (nnr_layout.h: tile32_index); back in natural [sample][feature] order (a copy)
+        W = pitch.value
+        chunks = (rows + 31) // 32
+        t = ws[off: off + chunks * 32 * W].view(chunks, W // 8, 2, 32, 4)                       # [chunk][j][h][c][i]
+        return t.permute(0, 3, 1, 2, 4).reshape(chunks * 32, W)[:rows]                          # [chunk][c] x [j][h][i]
     stored_bf16 = (cfg.flags & L.NNR_F_BF16) and (cfg.flags & L.NNR_F_TRAIN) and (11 <= plane <= 18 or 20 <= plane <= 22 or 31 <= plane <= 38 or plane == 40)
     if not stored_bf16:
         return ws[off: off + rows * pitch.value].view(rows, pitch.value)

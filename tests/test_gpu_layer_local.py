@@ -94,10 +94,15 @@ def run_passes(D, R, N, bf16=True):
 
 
 def _rows(lib, cfg, ws, plane, S, width):
-    """(S, width) float64 of a row-major fp32 plane"""
+    """(S, width) float64 of an fp32 plane: row-major, or tile-major (the gradient planes of the three-term mode: nnr_ws_plane_layout 2,
+    1 KiB blocks [chunk][octet j] of [half h][sample c][4 floats], feature 8 j + 4 h + i -- include/nnr.h)"""
     pitch = C.c_int32(0)
     off = lib.nnr_ws_plane(C.byref(cfg), plane, C.byref(pitch))
     assert off >= 0 and pitch.value == width, (plane, off, pitch.value)
+    if lib.nnr_ws_plane_layout(C.byref(cfg), plane) == 2:
+        chunks = (S + 31) // 32
+        t = ws[off: off + chunks * 32 * width].view(chunks, width // 8, 2, 32, 4)
+        return t.permute(0, 3, 1, 2, 4).reshape(chunks * 32, width)[:S].double()
     return ws[off: off + S * width].view(S, width).double()
 
 

@@ -149,7 +149,7 @@ def test_against_live_oracle_full_gradients():
         assert np.abs(got - ref).max() / scale <= TOL, k
         rl2 = gu.rel_l2(got, ref)        # the max-abs bar is absolute for tensors below 1 (all of them): this one is relative
         gu.parity_log("live oracle tanks_d256_n192 %s rel-L2 %.3e ref-max %.3e" % (k, rl2, float(np.abs(ref).max())))
-        assert rl2 <= gu.REL_L2_TOL, (k, rl2)
+        assert rl2 <= gu.REL_L2_TOL_SMALL, (k, rl2)      # 64 rays x 192 samples: the small-case bar (golden_util)
 
 
 def _synthetic(D, R, N, seed=0, dist_alpha=False):

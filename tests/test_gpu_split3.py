@@ -83,26 +83,54 @@ def test_three_term_products_are_as_close_to_fp64_as_fp32_mfmas(D, capsys):
         # what must not happen is a tensor at another ORDER (a missing term shows as 4e-4, tools/split3_debug.py).  Floor 1e-6.
         assert errs["split3"][k] <= max(3.0 * errs["mfma"][k], 1e-6), (k, errs["split3"][k], errs["mfma"][k])
     assert mean["split3"] <= 1.25 * mean["mfma"] + 1e-8
-    # Against the yardstick, in relative L2: every tensor of either HIP mode within 2x of what CPU fp32 (the reference's own arithmetic)
-    # leaves against fp64 (floor 1e-6: tensors both sides hold to rounding level).  VERDICT r03 weak 2: in the max-abs metric above the HIP
-    # modes read 3x worse than CPU fp32 at D = 256 and 20x better at D = 128 -- single gate flips; this is the metric that can bound.
+    # Against the yardstick, in relative L2.  What the measurements say (profiles/r04/a_parity_rel_l2.txt,
+    # a_fp64_bisect_d256.txt): stage by stage every forward plane of the HIP kernels is as close to fp64 as the CPU oracle's or closer
+    # (position encoding 1.6e-5 against 1.9e-5, hidden layers 1.1-1.6e-5 against 1.3-1.9e-5), and the backward planes agree to 1e-6 ..
+    # 1e-5 -- UNTIL a ReLU gate that sits within rounding of zero falls on the other side than fp64's; from that layer down the whole
+    # gradient of either fp32 evaluation is 1e-4 .. 1e-3 off in relative L2.  Every case has 10-25 such gates per layer in 16 k samples,
+    # on the CPU and on the GPU alike; WHICH evaluation catches the heavier ones differs from case to case (seed 333 of the bisect: CPU
+    # 7e-4, HIP 1.3e-5 on the first layers' gradients; this test's first seed: CPU 1e-3, HIP 5.5e-3).  So a per-tensor bound on ONE case
+    # bounds nothing; over several cases the two are the same: the geometric mean over seeds of HIP / CPU per tensor, and over all
+    # tensors, is what is asserted.
     import golden_util as gu
     import os
-    worst_ratio = ("", 0.0)
+    ratios = {kind: {k: [l2[kind][k] / max(l2["cpu"][k], 1e-6)] for k in l2["cpu"]} for kind in ("mfma", "split3")}
     for k in l2["cpu"]:
-        gu.parity_log("fp64 yardstick D=%d %s: rel-L2 cpu-fp32 %.3e hip-mfma %.3e hip-split3 %.3e | max-abs/|ref|max cpu %.3e mfma %.3e split3 %.3e"
-                      % (D, k, l2["cpu"][k], l2["mfma"][k], l2["split3"][k], errs["cpu"][k], errs["mfma"][k], errs["split3"][k]))
-        for kind in ("mfma", "split3"):
-            worst_ratio = max(worst_ratio, (k + "/" + kind, l2[kind][k] / max(l2["cpu"][k], 1e-6)), key=lambda x: x[1])
-    with capsys.disabled():
-        print("D=%d vs fp64 in relative L2: mean over tensors -- CPU fp32 %.2e, fp32 MFMAs %.2e, three-term %.2e; worst HIP / max(CPU, 1e-6) "
-              "ratio %.2f (%s); max-abs metric: CPU fp32 worst %.2e mean %.2e"
-              % (D, np.mean(list(l2["cpu"].values())), np.mean(list(l2["mfma"].values())), np.mean(list(l2["split3"].values())),
-                 worst_ratio[1], worst_ratio[0], max(errs["cpu"].values()), float(np.mean(list(errs["cpu"].values())))))
-    if os.environ.get("NNR_FP64_YARDSTICK_REPORT_ONLY") != "1":
-        for k in l2["cpu"]:
+        gu.parity_log("fp64 yardstick D=%d seed %d %s: rel-L2 cpu-fp32 %.3e hip-mfma %.3e hip-split3 %.3e | max-abs/|ref|max cpu %.3e mfma %.3e split3 %.3e"
+                      % (D, 77 + D, k, l2["cpu"][k], l2["mfma"][k], l2["split3"][k], errs["cpu"][k], errs["mfma"][k], errs["split3"][k]))
+    for seed in (177 + D, 277 + D, 377 + D):
+        case_s = sp._case(256, 64, D, seed=seed)
+        ref_s, rgrads_s = _oracle64(case_s)
+        cout_s, cgrads_s = sp._oracle(case_s)
+        l2c = _rel_l2(cout_s, cgrads_s, ref_s, rgrads_s)
+        prev = L.fp32_products()
+        try:
             for kind in ("mfma", "split3"):
-                assert l2[kind][k] <= 2.0 * max(l2["cpu"][k], 1e-6), (D, k, kind, l2[kind][k], l2["cpu"][k])
+                L.set_fp32_products(kind)
+                out_s, grads_s = run_hip(case_s)
+                l2k = _rel_l2(out_s, grads_s, ref_s, rgrads_s)
+                for k in l2c:
+                    ratios[kind][k].append(l2k[k] / max(l2c[k], 1e-6))
+                    gu.parity_log("fp64 yardstick D=%d seed %d %s: rel-L2 cpu-fp32 %.3e hip-%s %.3e" % (D, seed, k, l2c[k], kind, l2k[k]))
+        finally:
+            L.set_fp32_products(prev)
+    gm = lambda v: float(np.exp(np.mean(np.log(np.maximum(np.asarray(v, dtype=np.float64), 1e-12)))))
+    per_tensor = {kind: {k: gm(v) for k, v in ratios[kind].items()} for kind in ratios}
+    overall = {kind: gm([x for v in ratios[kind].values() for x in v]) for kind in ratios}
+    worst = {kind: max(per_tensor[kind].items(), key=lambda kv: kv[1]) for kind in ratios}
+    with capsys.disabled():
+        print("D=%d vs fp64 in relative L2 over 4 seeds: geometric mean of HIP / CPU-fp32 over all tensors -- fp32 MFMAs %.2f, three-term %.2f; "
+              "worst tensor (geometric mean over seeds) %.2f (%s) / %.2f (%s); first seed alone: CPU fp32 mean %.2e, fp32 MFMAs %.2e, three-term %.2e"
+              % (D, overall["mfma"], overall["split3"], worst["mfma"][1], worst["mfma"][0], worst["split3"][1], worst["split3"][0],
+                 np.mean(list(l2["cpu"].values())), np.mean(list(l2["mfma"].values())), np.mean(list(l2["split3"].values()))))
+    gu.parity_log("fp64 yardstick D=%d summary: overall geometric-mean ratio mfma %.3f split3 %.3f; worst tensor mfma %.3f (%s) split3 %.3f (%s)"
+                  % (D, overall["mfma"], overall["split3"], worst["mfma"][1], worst["mfma"][0], worst["split3"][1], worst["split3"][0]))
+    if os.environ.get("NNR_FP64_YARDSTICK_REPORT_ONLY") != "1":
+        for kind in ratios:
+            # measured (profiles/r04/b_gpu_tests.txt): overall 0.58 / 0.60 at D = 256, 0.50 / 0.49 at D = 128 -- the HIP kernels are on average CLOSER
+            # to fp64 than the CPU oracle --; worst single tensor over the four seeds 4.2 - 4.8 (heavy-tailed: one gate decides a tensor)
+            assert overall[kind] <= 1.5, (D, kind, overall[kind])
+            assert worst[kind][1] <= 10.0, (D, kind, worst[kind])
 
 
 def test_three_term_step_at_1024x192_matches_the_oracle_end_to_end(capsys):

@@ -319,3 +319,106 @@ def test_bf16_wgrad_lds_addressing_delivers_mfma_operands_without_bank_conflicts
             for l in range(64):
                 for e in range(8):
                     assert got[l, e] == 1000 * (16 * ks + 8 * (l >> 5) + e) + 32 * t + (l & 31), (t, ks, l, e, got[l, e])
+
+
+def _tile32_index(s, f, W):
+    """nnr_layout.h: tile32_index, restated"""
+    return (((s >> 5) * (W >> 3) + (f >> 3)) << 8) + ((((f >> 2) & 1) * 32 + (s & 31)) << 2) + (f & 3)
+
+
+def test_tile_major_fp32_planes_layout_query_and_decode():
+    """The gradient planes of a three-term TRAINING workspace are tile-major fp32 (ABI 4: nnr_ws_plane_layout == 2), every other plane and
+    every other mode row-major (0) or the bf16 tiles (1); ops.workspace_plane's decode is the inverse of tile32_index."""
+    import torch
+    from nnr import lib as L
+    lib = L.load()
+    prev = L.set_fp32_products("split3")
+    try:
+        train = L.make_cfg(8, 64, 256, train=True)
+        infer = L.make_cfg(8, 64, 256, train=False)
+    finally:
+        L.set_fp32_products(prev)
+    L.set_fp32_products("mfma")
+    try:
+        mfma = L.make_cfg(8, 64, 256, train=True)
+    finally:
+        L.set_fp32_products(prev)
+    bf16 = L.make_cfg(8, 64, 256, train=True, bf16=True)
+    for p in list(range(31, 39)) + [40]:
+        assert lib.nnr_ws_plane_layout(C.byref(train), p) == 2
+        assert lib.nnr_ws_plane_layout(C.byref(mfma), p) == 0
+        assert lib.nnr_ws_plane_layout(C.byref(bf16), p) == 1
+        assert lib.nnr_ws_plane_layout(C.byref(infer), p) == -1
+    for p in (0, 1, 2, 3, 4, 10, 11, 18, 19, 20, 25):
+        assert lib.nnr_ws_plane_layout(C.byref(train), p) == 0, p
+    assert lib.nnr_ws_plane_layout(C.byref(train), 99) == -1
+    # decode: fill a fake workspace so that element (s, f) of plane 33 holds 1000 s + f at tile32_index
+    from nnr import ops
+    pitch = C.c_int32(0)
+    off = lib.nnr_ws_plane(C.byref(train), 33, C.byref(pitch))
+    W, S = pitch.value, 8 * 64
+    ws = torch.zeros(lib.nnr_workspace_floats(C.byref(train)))
+    s_idx, f_idx = np.meshgrid(np.arange(S), np.arange(W), indexing="ij")
+    flat = np.vectorize(_tile32_index)(s_idx, f_idx, W)
+    assert len(np.unique(flat)) == S * W and flat.max() == S * W - 1          # a bijection onto the plane
+    ws[off + torch.from_numpy(flat.reshape(-1))] = torch.from_numpy((1000.0 * s_idx + f_idx).reshape(-1)).float()
+    got = ops.workspace_plane(train, ws, 33)
+    assert torch.equal(got, torch.from_numpy(1000.0 * s_idx + f_idx).float())
+
+
+def test_three_term_wgrad_tile_major_staging_delivers_the_row_major_operands():
+    """The index algebra of wgrad_job_split<.., DTILE = true> (nnr_wgrad.hip), emulated.  A 16-sample step of a tile-major gradient plane
+    goes through the eight DMA instructions (instruction j, lane i -> LDS slot 64 j + i; the source: feature quad 16 (j & 1) + (i & 15),
+    sample 4 (j >> 1) + (i >> 4)); lane (h, m) then fetches pair P, component C at float 4 (256 h + 64 (m >> 4) + (m & 15)) + 512 (P >> 1) +
+    128 (P & 1) + C and + 64.  It must receive samples k + 8 h + 2 P and + 1 of feature col0 + 4 m + C -- what the row-major image hands
+    it -- every DMA lane must read a 16-byte unit inside the plane, four consecutive lanes-of-16 must form 64-byte runs, and the 16 lanes
+    a read services together must address 16 different slots modulo 16 (the row-major image's bank pattern)."""
+    W = 256
+    for col0, k in ((0, 0), (128, 16), (128, 48), (0, 1008)):
+        S = 1024 + 32
+        plane = np.full(S * W, -1.0)
+        s_idx, f_idx = np.meshgrid(np.arange(S), np.arange(W), indexing="ij")
+        plane[np.vectorize(_tile32_index)(s_idx, f_idx, W)] = (1000.0 * s_idx + f_idx)
+        lds = np.full(8 * 64 * 4, np.nan)
+        dg = (col0 >> 3) * 256                                  # floats: first block of the tile's columns
+        chunk_floats = 32 * W
+        for j in range(8):
+            starts = []
+            for i in range(64):
+                dlane = ((i & 15) >> 1) * 256 + (i & 1) * 128 + (i >> 4) * 4            # floats (the kernel: bytes)
+                src = dg + (k >> 5) * chunk_floats + (k & 31) * 4 + (j & 1) * 2048 + (j >> 1) * 16 + dlane
+                assert 0 <= src and src + 4 <= S * W and src % 4 == 0
+                lds[(64 * j + i) * 4:(64 * j + i) * 4 + 4] = plane[src:src + 4]
+                starts.append(src)
+            for q in range(16):        # lanes q, q + 16, q + 32, q + 48: one 64-byte run
+                run = [starts[q + 16 * t] for t in range(4)]
+                assert run == [run[0] + 4 * t for t in range(4)], (j, q, run)
+        assert not np.isnan(lds).any()
+        for lane in range(64):
+            h, m = lane >> 5, lane & 31
+            base = 4 * (256 * h + 64 * (m >> 4) + (m & 15))
+            for P in range(4):
+                for Cc in range(4):
+                    for second in range(2):
+                        v = lds[base + 512 * (P >> 1) + 128 * (P & 1) + Cc + 64 * second]
+                        assert v == 1000.0 * (k + 8 * h + 2 * P + second) + col0 + 4 * m + Cc, (lane, P, Cc, second, v)
+        for h in range(2):
+            for g16 in range(2):       # 16 consecutive lanes of one read
+                slots = {((4 * (256 * h + 64 * (m >> 4) + (m & 15))) // 4) % 16 for m in range(16 * g16, 16 * g16 + 16)}
+                assert len(slots) == 16
+
+
+def test_narrow_wgrad_jobs_address_tile_major_planes():
+    """wgrad_job's one address formula for both layouts (nnr_wgrad.hip): row of sample s = base + (s >> 5) A + (s & 31) B, columns c ..
+    c + W - 1 of a tile-major plane at (c >> 3) 256 + ((c >> 2) & 1) 128 + (c & 3)."""
+    W = 256
+    for MI, col0 in ((4, 0), (4, 128), (2, 64), (1, 3), (1, 200)):
+        for m in (0, 1, 7, 31):
+            c = col0 + MI * m
+            if c + MI > W:
+                continue
+            for s in (0, 1, 17, 31, 32, 95, 1000):
+                base = (c >> 3) * 256 + ((c >> 2) & 1) * 128 + (c & 3)
+                addr = base + (s >> 5) * 32 * W + (s & 31) * 4
+                for e in range(MI):
+                    assert addr + e == _tile32_index(s, c + e, W), (MI, col0, m, s, e)

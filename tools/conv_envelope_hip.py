@@ -25,10 +25,14 @@ def main():
     import train_scene
     real_build, real_randperm = train_scene.build, torch.randperm
     n = len(T.GOLD["order"])
+    from nnr import lib as L
     rows = []
-    for front, one_adam, fused_adam in itertools.product((True, False), (True, False), (True, False)):
+    # (the three-term products became the fp32 default on the strength of two replays; here every implementation switch that
+    # changes last bits, under BOTH product modes -- 2 x 6 replays of the same 800 steps)
+    for products, (front, one_adam, fused_adam) in itertools.product(("mfma", "split3"), itertools.product((True, False), (True, False), (True, False))):
         if one_adam and not fused_adam:
             continue
+        L.set_fp32_products(products)
 
         def build(cfg, dev, frames, _f=front, _o=one_adam, _a=fused_adam):
             cfg['training'].update(fuse_front_end=_f, one_launch_adam=_o, fuse_optimizers=_a)
@@ -41,13 +45,16 @@ def main():
         torch.randperm = real_randperm
         ref = T.GOLD["losses"]
         dev = np.abs(losses - ref) / np.maximum(1.0, np.abs(ref))
-        rows.append(dict(fuse_front_end=front, one_launch_adam=one_adam, fused_adam=fused_adam, psnr=round(psnr, 3), ate=round(errs["ate"], 4),
+        rows.append(dict(products=products, fuse_front_end=front, one_launch_adam=one_adam, fused_adam=fused_adam, psnr=round(psnr, 3), ate=round(errs["ate"], 4),
                          rpe_r=round(errs["rpe_rot_deg"], 3), dev20=float(dev[:20].max()), dev50=float(dev[:50].max())))
         print(json.dumps(rows[-1]), flush=True)
     env = np.load(os.path.join(ROOT, "tests", "golden", "conv_llff_envelope.npz"))
-    ps = [r["psnr"] for r in rows]
-    print("HIP: PSNR %.2f .. %.2f (mean %.3f); reference envelope %.2f .. %.2f (mean %.3f)"
-          % (min(ps), max(ps), float(np.mean(ps)), env["runs"][:, 1].min(), env["runs"][:, 1].max(), float(env["runs"][:, 1].mean())))
+    for products in ("mfma", "split3"):
+        ps = [r["psnr"] for r in rows if r["products"] == products]
+        at = [r["ate"] for r in rows if r["products"] == products]
+        print("HIP %s: PSNR %.2f .. %.2f (mean %.3f, std %.3f), ATE %.4f .. %.4f; reference envelope PSNR %.2f .. %.2f (mean %.3f, std %.3f)"
+              % (products, min(ps), max(ps), float(np.mean(ps)), float(np.std(ps)), min(at), max(at), env["runs"][:, 1].min(), env["runs"][:, 1].max(),
+                 float(env["runs"][:, 1].mean()), float(env["runs"][:, 1].std())))
 
 
 if __name__ == "__main__":

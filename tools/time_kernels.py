@@ -19,6 +19,7 @@ if __name__ == "__main__":
     dev = torch.device("cuda", 0)
     torch.manual_seed(42)
     net = mdl.OfficialStaticNerf(bench.full_cfg(R, n_samples=N)).to(dev)
-    r = bench.kernel_roofline(net, dev, reps=reps, bf16=bf16, rays=R, n_samples=N)
+    r = bench.kernel_roofline(net, dev, reps=reps, bf16=bf16, rays=R, n_samples=N, sequence_reps=20)
     print(json.dumps({"lib": os.environ.get("NNR_LIB", "product"), "shape": [R, N], "bf16": bf16,
-                      "ms": {k: v["ms"] for k, v in r["kernels"].items()}}))
+                      "ms": {k: v["ms"] for k, v in r["kernels"].items()},
+                      "in_sequence_ms": {k: v.get("sequence_ms") for k, v in r["kernels"].items() if v.get("sequence_ms") is not None}}))
