@@ -43,7 +43,8 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 // W = waves of the workgroup that share the stream; each copies PW = 32 / W of a panel's 32 fragments (8 with the usual 4 waves).
 // F = fragment slots (KiB) per panel: 32, or 24 in the three-term mode (nnr_layout.h, MODE 2).
-template <int W, int F_ = kPanelFrags>
+// STASH_TILE_: see kStashTile below.
+template <int W, int F_ = kPanelFrags, bool STASH_TILE_ = false>
 struct PanelPipeT {
     static constexpr int F = F_, F4 = F_ * 64;   // fragment slots / float4 elements per panel
     static constexpr int PW = F / W;             // DMA pieces (1 KiB) per wave and panel
@@ -67,8 +68,9 @@ struct PanelPipeT {
     mutable uint32_t gw[4] = {0, 0, 0, 0};
     // three-term input-gradient kernel (nnr_split.h): the stash planes are tile-major fp32 (nnr_layout.h, tile32_index) -- the part's
     // `stash` argument is then the block of (this wave's chunk, first octet of the part's input) + 16 bytes per lane, every store one
-    // contiguous non-temporal 1 KiB block.  Set once by the kernel: a literal, folded after inlining.
-    bool stash_tile = false;
+    // contiguous non-temporal 1 KiB block.  A property of the pipe's TYPE: as a run-time member the two store flavours sat in the two arms
+    // of a branch, the branch folded -- and the arms were merged first, which dropped the non-temporal hint from the surviving store.
+    static constexpr bool kStashTile = STASH_TILE_;
 
     __device__ __forceinline__ int buffer(int p) const {   // ring slot of panel p of the current pass (p compile-time in the callers)
         const int b = p % kNBuf + phase;

@@ -219,6 +219,11 @@ NNR_HD constexpr int64_t tile_major_index(int64_t s, int f, int G) {
 // kernel is then ONE contiguous, non-temporal 1 KiB wave-store (8 whole cache lines that go past the L2 instead of evicting the weight
 // stream from it) where the row-major plane took 16 bytes into each of 64 lines: 1.07 -> 0.88 ms for that kernel
 // (profiles/r04/a_stash_variants.txt).  The weight-gradient kernel fetches 64-byte runs of such blocks by LDS-DMA (nnr_wgrad.hip).
+#ifdef NNR_ROWMAJOR_DPLANES      // A/B builds (csrc/build.py --variant): the round-3 layout, row-major gradient planes
+constexpr bool kTileGradPlanes = false;
+#else
+constexpr bool kTileGradPlanes = true;
+#endif
 NNR_HD constexpr int64_t tile32_index(int64_t s, int f, int W) {
     return (((s >> 5) * (W >> 3) + (f >> 3)) << 8) + ((((f >> 2) & 1) * 32 + (s & 31)) << 2) + (f & 3);
 }
@@ -228,7 +233,7 @@ struct WsLayout {
     int D;
     bool train;
     bool tile32 = false; // NNR_F_SPLIT3 training: the gradient planes are tile-major fp32 (tiled(), above); offsets and sizes are unchanged
-    NNR_HD bool tiled(int p) const { return tile32 && train && ((p >= P_DH1 && p < P_DH1 + 8) || p == P_DG); }
+    NNR_HD bool tiled(int p) const { return kTileGradPlanes && tile32 && train && ((p >= P_DH1 && p < P_DH1 + 8) || p == P_DG); }
     bool bf16 = false;   // NNR_F_BF16 training: the operands of the weight-gradient products -- hidden activations (P_XH1.., P_XG),
                          // the encodings' copies (P_XE16, P_XF16) and the pre-activation gradients (P_DH1.., P_DG) -- are tile-major
                          // bf16 planes (see above; pitch below = floats per sample = elements / 2); P_XE / P_XF hold the fp32

@@ -57,7 +57,8 @@ template <int D, int MODE>
 __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     NNR_STAMP(tl_dgrad, 0);
     using L = Layout<D, MODE>;
-    using Pipe = PanelPipeT<kWavesPerBlock, mode_panel_frags(MODE)>;
+    constexpr bool kTile = MODE == 2 && kTileGradPlanes;      // tile-major gradient planes (nnr_layout.h)
+    using Pipe = PanelPipeT<kWavesPerBlock, mode_panel_frags(MODE), kTile>;
     constexpr int kRingF4 = kNBuf * Pipe::F4;
     constexpr int DT = L::DT, HT = L::HT;
     constexpr int HR = 16 * HT;              // registers of half a layer's outputs
@@ -80,7 +81,6 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     // weight stream wraps around from pass to pass
     const int n_pass = a.chunks_per_ray > 0 ? a.chunks_per_ray : 1;
     pipe.more = n_pass > 1;
-    pipe.stash_tile = MODE == 2;     // three-term mode: the gradient planes are tile-major fp32, written past the L2 (nnr_layout.h)
     pipe.start();
     NNR_STAMP(tl_dgrad, 1);
     auto p0 = [&](int part) { return L::bwd_panel0(part); };
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     load_mask(mwA, 7, 0);
     init_sigma(accA, 0);
     // d g goes to P_DG.  Row-major: this lane's row + its half's four columns; tile-major (MODE 2): block (chunk, octet 0) + 16 bytes per lane
-    float* const dg_stash = MODE == 2 ? a.ws_dg + chunk * (int64_t)((D / 16) * 256) + 4 * lane : a.ws_dg + ss * (D / 2) + 4 * half;
+    float* const dg_stash = kTile ? a.ws_dg + chunk * (int64_t)((D / 16) * 256) + 4 * lane : a.ws_dg + ss * (D / 2) + 4 * half;
     gemm_part<HT, HT, true>(accA, dg, pipe, p0(B_RGBH_FA), dg_stash);
     load_mask(mwB, 7, 1);
     init_sigma(accB, 1);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
 
     // ---- trunk ----
     auto dh = [&](int hidden_idx /*0..7*/) -> float* {
-        if constexpr (MODE == 2) return a.ws_dh + (int64_t)hidden_idx * a.S_pad * D + chunk * (int64_t)((D / 8) * 256) + 4 * lane;
+        if constexpr (kTile) return a.ws_dh + (int64_t)hidden_idx * a.S_pad * D + chunk * (int64_t)((D / 8) * 256) + 4 * lane;
         else return a.ws_dh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half;
     };
     // Invariant from here on: d[0, HR) holds half A of the newest gradient, accB its half B still to be masked (mwB).

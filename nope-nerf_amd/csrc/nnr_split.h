@@ -16,7 +16,9 @@
 
 namespace nnr {
 
-using SplitPipe = PanelPipeT<kWavesPerBlock, kSplitPanelFrags>;
+template <bool TILE>
+using SplitPipeT = PanelPipeT<kWavesPerBlock, kSplitPanelFrags, TILE>;
+using SplitPipe = SplitPipeT<false>;
 
 // the three bf16 terms of two fp32 values, packed (x0 in the low halves): h = rn(x), m = rn(x - h), l = rn(x - h - m); both differences
 // are exact in fp32.  (An infinite or NaN input gives NaN terms -- as good as the inf the fp32 path would produce: the trainer stops.)
@@ -145,8 +147,8 @@ constexpr auto make_row_sched() {
 // so the l fragments are free after t0, the m fragments after t2, the h fragments after t5: each is refilled IN PLACE for the next row
 // right after its last MFMA (reads in the order l, m, h -- the order of first use), which gives every read at least 3 MT MFMAs to land.
 // UCOST: instructions of one side unit, for the balance of the gaps (see above).
-template <int KT, int MT, bool STASH, int NSIDE_, int PPG, int SHIFT, class Side, int NACC, int NIN>
-__device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const SplitPipe& pipe, int p0, float* stash,
+template <int KT, int MT, bool STASH, int NSIDE_, int PPG, int SHIFT, class Side, int NACC, int NIN, bool TILE>
+__device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const SplitPipeT<TILE>& pipe, int p0, float* stash,
                                           const Side& side) {
 #ifdef NNR_ABLATE_NO_SIDE
     constexpr int NSIDE = 0;   // profiling build only
@@ -156,7 +158,7 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
     static_assert(MT <= NACC && 16 * KT <= NIN, "tile counts exceed the register arrays");
     static_assert(!(STASH && SHIFT != 0), "a part that stashes its input must not rewrite it");
     static_assert(MT == 1 || MT == 2 || MT == 4, "m-tiles per part");
-    constexpr int G = 2 * KT, GP = mode_gp(MT, 2), NM = 6 * MT, PW = SplitPipe::PW;
+    constexpr int G = 2 * KT, GP = mode_gp(MT, 2), NM = 6 * MT, PW = SplitPipeT<TILE>::PW;
     auto wcls = [](int t) { return t == 0 ? 0 : (t < 3 ? 1 : 2); };             // term -> class (0 = l, 1 = m, 2 = h) of the weights ...
     auto xcls = [](int t) { return t == 0 ? 2 : (t == 1 ? 1 : (t == 2 ? 2 : t - 3)); };   // ... and of the activations
     auto rows_in = [](int pi) { return (G - pi * GP) < GP ? (G - pi * GP) : GP; };
@@ -185,13 +187,13 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
     // stashed, the stores of its last rows (pipe.part_pre of them, told by the kernel) are younger and may stay in flight -- without
     // this, every pass that follows a stashing pass starts with a full drain of the store queue (an HBM write latency, matrix pipe idle).
 #ifndef NNR_SPLIT_SAFE_SYNC
-    if (pipe.part_pre == 6) pipe.enter<6>(p0);
+    if (pipe.part_pre == 6) pipe.template enter<6>(p0);
     else
 #endif
         pipe.enter(p0);
     pipe.pieces(p0 + 2, 0, ppk_of(0));
     const unsigned lane_base = lds_byte_address(pipe.lds) + 16u * pipe.lane;
-    unsigned panel_addr = lane_base + pipe.buffer(p0) * (SplitPipe::F4 * 16);
+    unsigned panel_addr = lane_base + pipe.buffer(p0) * (SplitPipeT<TILE>::F4 * 16);
     f32x4 fr[3][MT];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -234,7 +236,7 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                 const int pn = p0 + (g + 1) / GP;
                 if (t == 0 && mt == 0 && (g + 1) % GP == 0) {
 #ifdef NNR_SPLIT_SAFE_SYNC
-                    pipe.enter<0>(pn);
+                    pipe.template enter<0>(pn);
 #else
                     // Stash stores younger than the pieces waited for may stay in flight: those of this panel's earlier rows -- and, from
                     // the part's third panel on, those the panel BEFORE issued after the last burst of pn's pieces (pn's pieces go out
@@ -242,10 +244,10 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                     // be waited for is then at least GP + 1 rows old instead of 1: the switch no longer waits out HBM write latency.
                     constexpr int kLastBurstRow = (PW + ppk_full - 1) / ppk_full - 2;
                     constexpr int kExtraNear = 2 * (GP - 1), kExtraFar = kExtraNear + 2 * (GP - 1 - kLastBurstRow);
-                    if ((g + 1) / GP >= 2) pipe.enter<STASH ? kExtraFar : 0>(pn);
-                    else pipe.enter<STASH ? kExtraNear : 0>(pn);
+                    if ((g + 1) / GP >= 2) pipe.template enter<STASH ? kExtraFar : 0>(pn);
+                    else pipe.template enter<STASH ? kExtraNear : 0>(pn);
 #endif
-                    panel_addr = lane_base + pipe.buffer(pn) * (SplitPipe::F4 * 16);
+                    panel_addr = lane_base + pipe.buffer(pn) * (SplitPipeT<TILE>::F4 * 16);
                 }
                 fr[wc][mt] = frag_read(panel_addr, (((g + 1) % GP) * 3 + wc) * MT + mt);
             }
@@ -284,10 +286,20 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                         }
 #endif
                         const f32x4 val = f32x4{in[8 * g + 4 * k], in[8 * g + 4 * k + 1], in[8 * g + 4 * k + 2], in[8 * g + 4 * k + 3]};
-                        if (pipe.stash_tile) {
+                        if constexpr (TILE) {
                             // tile-major plane (nnr_layout.h): store 2 g + k of the part is octet 2 g + k of its input -- one contiguous 1 KiB block
-                            // per wave, written past the L2 (whole lines: nothing for the L2 to merge, and the weight stream stays resident)
-                            __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + stash_off + 1024 * (2 * g + k)));
+                            // per wave, written past the L2 (whole lines: nothing for the L2 to merge, and the weight stream stays resident).
+                            // Written as the instruction itself: (scalar base, bumped by 4 KiB every fourth block) + (32-bit lane offset) +
+                            // immediate.  Through a pointer hipcc made it a FLAT store without the hint at first (the two arms of a run-time
+                            // branch merged), then a global store whose 64-bit VECTOR address it re-based with two VALU adds per store.
+                            // hipcc does not count asm memory operations: its own waits only get more conservative, and the counted
+                            // vmcnt waits of the panel switches (PanelPipeT::enter<EXTRA>) are the ones written for these stores.
+                            const uint64_t sb = reinterpret_cast<uint64_t>(stash_base) + 4096u * ((2 * g + k) >> 2);
+#ifdef NNR_TILE_STASH_PLAIN      // experiment: the same store without the non-temporal hint
+                            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" : : "v"(stash_off), "v"(val), "s"(sb), "n"(1024 * ((2 * g + k) & 3)) : "memory");
+#else
+                            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" : : "v"(stash_off), "v"(val), "s"(sb), "n"(1024 * ((2 * g + k) & 3)) : "memory");
+#endif
                         } else {
 #ifdef NNR_SPLIT_TILE_STASH     // experiment (WRONG layout, timing only): one contiguous 1 KiB block per store
                             f32x4* const dst = reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + 1024 * (2 * g + k) + 16 * pipe.lane);
@@ -333,8 +345,8 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
     }
 }
 
-template <int KT, int MT, bool STASH = false, int NACC, int NIN>
-__device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const SplitPipe& pipe, int p0,
+template <int KT, int MT, bool STASH = false, int NACC, int NIN, bool TILE>
+__device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const SplitPipeT<TILE>& pipe, int p0,
                                           float* stash = nullptr) {
     gemm_part<KT, MT, STASH, 0, 1, 0>(acc, in, pipe, p0, stash, NoSide{});
 }

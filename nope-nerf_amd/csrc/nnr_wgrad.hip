@@ -178,6 +178,7 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     constexpr int MI = 4;
     static_assert(NI == 4 || NI == 2, "activation sub-tiles per job");
     constexpr int G = 6 * NI;                  // MFMAs (= gaps) per block
+    static_assert(G >= 16, "block 3 issues the 16 DMA rows of the step after next, one per gap");
     const int half = lane >> 5, m = lane & 31;
     const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
     const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
@@ -253,6 +254,14 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
         NNR_WDMA(xg, xlane, xp, jb.k0, s, stage, 8 + s);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {   // the SECOND step's rows into the other buffer (round 4: the fetch runs two steps ahead, see the loop)
+        const int64_t k1st = jb.k0 + 16 < jb.k1 ? jb.k0 + 16 : jb.k0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            NNR_WDMA_D(k1st, s, stage + 1024, s);
+            NNR_WDMA(xg, xlane, xp, k1st, s, stage + 1024, 8 + s);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NI; ++j) NNR_WSPLIT_ALL(lrowx, 8, j, Xc[j], 1, -1);
     NNR_WSPLIT_ALL(lrowd, 0, 0, Dq[0], 0, 0);
@@ -260,16 +269,21 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     // One 16-sample step per iteration of ONE loop body (two textual copies for the two buffer parities made hipcc assign the 256
     // accumulators to different registers in the copies and shuffle them in between: hundreds of moves and spills per step); the staging
     // buffers alternate by address, and the next step's activation terms are copied over the current ones at the end of the step (48 moves).
-    // kn = the step to prefetch: the last step re-reads its own rows -- no branch around the DMA -- and nf = 0 keeps them out of d(bias).
+    // Fetch distance (round 4): the rows of step k + 32 are requested in block 3 of step k, into the buffer step k itself used -- its last read
+    // is the fetch of gradient sub-tile 3 in block 2 -- and are first needed in block 2 of step k + 16: THREE blocks (72 MFMAs, ~1.2 us) in
+    // flight.  Round 3 requested step k + 16 in block 0 of step k for block 2 of the same step: two blocks, 0.8 us -- enough for rows that sit
+    // in the L2 or the memory-side cache, not for HBM under load, which is where rows written with non-temporal stores come from.
+    // kn = the step to prefetch: past the end a wave re-reads rows of its own range (valid data, no branch around the DMA); nf = 0 keeps
+    // the step after the last one out of d(bias).
     for (int64_t k = jb.k0; k < jb.k1; k += 16) {
         const int par = (int)(((k - jb.k0) >> 4) & 1);
         const bool more = k + 16 < jb.k1;
-        const int64_t kn = more ? k + 16 : k;
+        const int64_t kn = k + 32 < jb.k1 ? k + 32 : k;
         const float nf = more ? 1.f : 0.f;
         const float* const lc = lrowd + 4096 * par;           // this step's staged gradient rows, the next step's
         const float* const ln = lrowd + 4096 * (1 - par);
         const float* const lnx = lrowx + 4096 * (1 - par);
-        f32x4* const dst = stage + 1024 * (1 - par);
+        f32x4* const dst = stage + 1024 * par;                // (free from block 3 on)
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             if (i == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the next step's rows have landed
@@ -288,7 +302,7 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef NNR_ABLATE_WGRAD_NO_DMA
                 {
-                    const int q = i * G + g;                                      // the 16 rows of the next step, one per gap from the step's start
+                    const int q = i == 3 ? g : 16;                                // the 16 rows of step k + 32, one per gap from the start of block 3
                     if (q < 8) NNR_WDMA_D(kn, q, dst, q);
                     else if (q < 16) NNR_WDMA(xg, xlane, xp, kn, q - 8, dst, q);
                 }
@@ -387,9 +401,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
                 f32x4* const stage = stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kStageF4;
                 // (every gradient plane of the three-term mode is tile-major: WsLayout::tiled -- the row-major instantiation is not built)
                 switch (__builtin_amdgcn_readfirstlane(jb.bias)) {
-                    case 2: wgrad_job_split<2, 4, true>(jb, a, lane, ji, stage); break;
-                    case 3: wgrad_job_split<3, 4, true>(jb, a, lane, ji, stage); break;
-                    default: wgrad_job_split<1, 4, true>(jb, a, lane, ji, stage); break;     // 1, and 0 (sums dropped)
+                    case 2: wgrad_job_split<2, 4, kTileGradPlanes>(jb, a, lane, ji, stage); break;
+                    case 3: wgrad_job_split<3, 4, kTileGradPlanes>(jb, a, lane, ji, stage); break;
+                    default: wgrad_job_split<1, 4, kTileGradPlanes>(jb, a, lane, ji, stage); break;     // 1, and 0 (sums dropped)
                 }
                 continue;
             }

@@ -165,7 +165,8 @@ class Trainer(object):
         data parallelism: there the logged scalars are summed over the ranks after the backward (parallel.allreduce_gradients)."""
         if parallel.world_size() > 1 or parallel.always_reduce():
             return None
-        keys = [k for k, v in loss_dict.items() if torch.is_tensor(v) and v.is_cuda and v.dim() == 0 and v.dtype == torch.float32]
+        keys = [k for k, v in loss_dict.items() if torch.is_tensor(v) and v.is_cuda and v.numel() == 1 and v.dtype == torch.float32
+                and k not in ('scale', 'shift')]       # (the two distortion entries are (1,) views train.py only stores)
         if not keys:
             return None
         if self._early_host is None or self._early_host[0]['host'].numel() < len(keys):
@@ -174,20 +175,30 @@ class Trainer(object):
         self._early_host.append(self._early_host.pop(0))      # the buffers of the last three steps stay valid for their readers
         slot['generation'] += 1
         with torch.no_grad():
-            slot['host'][:len(keys)].copy_(torch.stack([loss_dict[k].detach() for k in keys]), non_blocking=True)
+            slot['host'][:len(keys)].copy_(torch.stack([loss_dict[k].detach().reshape(()) for k in keys]), non_blocking=True)
         event = torch.cuda.Event()
         event.record()
         return keys, slot, event
 
     # ------------------------------------------------------------------------------------------------ data
+    @staticmethod
+    def _host_index(idx):
+        """The loaders hand the view index over as a one-element HOST tensor (default collate).  Used as it is -- `table[idx]` on a device
+        table -- it is copied to the device by a blocking pageable copy that first waits for everything queued on the stream: with the
+        per-image block on, four such lookups per step drained the launch queue behind the render kernels (the unmodified train.py ran at
+        0.75 of the step's rate in its first phase, profiles/r04/e_*).  A Python int indexes without any copy."""
+        if torch.is_tensor(idx) and not idx.is_cuda and idx.numel() == 1:
+            return int(idx)
+        return idx
+
     def process_data_dict(self, data):
         dev = self.device
         return (data.get('img').to(dev), data.get('img.dpt').to(dev).unsqueeze(1), data.get('img.camera_mat').to(dev),
-                data.get('img.scale_mat').to(dev), data.get('img.idx'))
+                data.get('img.scale_mat').to(dev), self._host_index(data.get('img.idx')))
 
     def process_data_reference(self, data):
         dev = self.device
-        return (data.get('img.ref_imgs').to(dev), data.get('img.ref_dpts').to(dev).unsqueeze(1), data.get('img.ref_idxs'))
+        return (data.get('img.ref_imgs').to(dev), data.get('img.ref_dpts').to(dev).unsqueeze(1), self._host_index(data.get('img.ref_idxs')))
 
     def anneal(self, start_weight, end_weight, anneal_start_epoch, anneal_epoches, current):
         if current <= anneal_start_epoch:
