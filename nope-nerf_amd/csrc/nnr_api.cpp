@@ -163,7 +163,7 @@ Plan build_plan(const nnr_cfg* c) {
     // per MFMA-equivalent a 4 x 4 tile costs `split_w` / 1000 of what it costs in fp32 (measured: NNR_WGRAD_SPLIT_WEIGHT sweeps).
     static const int split_w = [] {
         const char* e = std::getenv("NNR_WGRAD_SPLIT_WEIGHT");
-        return e ? std::max(50, std::atoi(e)) : 520;
+        return e ? std::max(50, std::atoi(e)) : 480;      // (round 4, shared split: 1.18 / 1.16 / 1.14 / 1.11 / 1.12 ms at 360 / 400 / 440 / 480 / 520)
     }();
     const bool split = is_split3(c) && std::getenv("NNR_WGRAD_FP32") == nullptr;
     auto weight = [split](const WgradJob& j) -> int64_t {
@@ -207,6 +207,12 @@ Plan build_plan(const nnr_cfg* c) {
             for (int t = 0; t < 4; ++t) emit(4 * b + t, groups[g][t], lo, hi);
         }
     }
+    // Three-term mode: the four tiles of a class-A segment sit in one workgroup over ONE sample range -- the kernel runs them as a workgroup
+    // job in which every operand value is split once (wgrad_group_split, nnr_wgrad.hip: barriers inside, so all four waves must be there)
+    static const bool coop = std::getenv("NNR_WGRAD_NO_COOP") == nullptr;
+    if (split && coop)
+        for (int wv = 0; wv < 4 * nb_a; ++wv)
+            for (auto& j : per_wave[wv]) j.reserved = 1;
     // class B: tile u occupies [off_u, off_u + cost_u * granules) of the tape; a cut inside a tile is rounded to a granule
     const int nw_b = nb_b * 4;
     const int64_t tape_b = cost_b * granules;

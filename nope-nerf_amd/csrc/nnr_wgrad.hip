@@ -364,6 +364,216 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     }
 }
 
+// ---- the four 4 x 4 tiles of a D x D layer as ONE workgroup job (round 4): every operand value is split ONCE per workgroup ---------
+// wgrad_job_split makes the terms of its two operand halves on its own: in a workgroup that owns the four tiles (a, b) of one layer over
+// one sample range -- what the host plan gives every class-A workgroup -- each half is split twice, and the split is what these waves
+// wait for (4.8 non-MFMA instructions per MFMA, one wave per SIMD hides about five).  Here wave (a, b) splits only HALF of each of its
+// operands -- of the step's 16 samples the pairs 2 b, 2 b + 1 of gradient half a and the pairs 2 a, 2 a + 1 of activation half b, all four
+// interleaved sub-tiles -- and the halves are exchanged through LDS:
+//   staging   per wave 2 x 8 KiB: the 4 + 4 rows (of 2 x 4 samples) it splits, by LDS-DMA two steps ahead          64 KiB
+//   exchange  2 buffers x 4 regions (gradient half 0 / 1, activation half 0 / 1) x [sub-tile 4][term 3][lane 64][16 B]   96 KiB
+//             a lane's 16 bytes = its packed pairs 0 .. 3 of that sub-tile and term = the MFMA operand; the owner of pairs 2 q, 2 q + 1
+//             writes bytes [8 q, 8 q + 8)
+// Step k (16 samples), exchange buffer e = step parity: blocks 0 - 2 (72 MFMAs on the terms of step k read from buffer e) carry the split of
+// step k + 1's rows and the writes of its terms into buffer 1 - e; ONE barrier; block 3 carries the reads of step k + 1's activation terms.
+// Buffer 1 - e was last read (terms of step k - 1) before the previous step's barrier.  Per step and wave: 16 pair splits instead of 32,
+// 24 + 24 LDS exchanges, 8 DMA rows instead of 16: ~2.3 non-MFMA instructions per MFMA.  The products, their order and the accumulators are
+// those of wgrad_job_split (the weight gradients are bit-identical); d(bias) is summed by each wave over the samples it splits (the two
+// tiles of a row block still hold one share each).  Every wave of the workgroup must run the same steps: the plan marks these jobs
+// (WgradJob::reserved = 1) and gives the four waves of a class-A workgroup the same sample ranges.
+constexpr int kCoopStageF4 = 2 * 8 * 64;                 // f32x4 per wave: 2 buffers x (4 gradient + 4 activation rows) x 64 lanes
+constexpr int kCoopRegionF4 = 4 * 3 * 64;                // f32x4 per exchange region
+constexpr int kCoopXchF4 = kWavesPerBlock * kCoopStageF4;   // the exchange buffers start behind the four staging areas
+constexpr int kCoopF4 = kCoopXchF4 + 2 * 4 * kCoopRegionF4; // 160 KiB
+
+template <bool DTILE>
+__device__ __forceinline__ void wgrad_group_split(const WgradJob& jb, const WgradArgs& a, int lane, int ji, f32x4* lds_all, int wave) {
+    constexpr int MI = 4, NI = 4;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const int half = lane >> 5, m = lane & 31;
+    const int ta = __builtin_amdgcn_readfirstlane(jb.d_col0 >> 7), tb = __builtin_amdgcn_readfirstlane(jb.x_col0 >> 7);   // this wave's tile
+    const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
+    f32x4* const stage = lds_all + wave * kCoopStageF4;
+    // ---- DMA sources (all 128 columns of either half are valid in these units: wgrad_units) ----
+    const char* const dg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane] + (DTILE ? (jb.d_col0 >> 3) * 256 : jb.d_col0));
+    const char* const xg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane] + jb.x_col0);
+    const int dlane = DTILE ? ((lane & 15) >> 1) * 1024 + (lane & 1) * 512 + (lane >> 4) * 16 : 4 * (MI * m + 8 * half * dp);
+    const int xlane = 4 * (NI * m + 8 * half * xp);
+    const int64_t d_chunk_bytes = 128 * (int64_t)dp;
+    // gradient row r (0..3) of the step at sample KK -> staged row r; tile-major: the four DMA instructions that hold the samples 4 tb + 0..3 and
+    // 8 + 4 tb + 0..3 of the step (instruction 2 (tb + 2 (r >> 1)) + (r & 1) of wgrad_job_split's eight); row-major: samples KK + 8 h + 4 tb + r
+    auto dma_d = [&](int64_t KK, int r, f32x4* dst) __attribute__((always_inline)) {
+        if constexpr (DTILE)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(dg + (KK >> 5) * d_chunk_bytes + (KK & 31) * 16 + (r & 1) * 8192 + (tb + 2 * (r >> 1)) * 64 + dlane),
+                                             (lds_ptr_t)(dst + r * 64), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(dg + (KK + 4 * tb + r) * (int64_t)dp * 4 + dlane), (lds_ptr_t)(dst + r * 64), 16, 0, 0);
+    };
+    auto dma_x = [&](int64_t KK, int r, f32x4* dst) __attribute__((always_inline)) {      // samples KK + 8 h + 4 ta + r -> staged row 4 + r
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(xg + (KK + 4 * ta + r) * (int64_t)xp * 4 + xlane), (lds_ptr_t)(dst + (4 + r) * 64), 16, 0, 0);
+    };
+    // ---- staged values of this lane: pair pl (0, 1) of the wave's four samples per half, component C ----
+    const float* const sf = reinterpret_cast<const float*>(stage);
+    const float* const lrd = DTILE ? sf + 4 * (128 * half + 64 * (m >> 4) + (m & 15)) : sf + 4 * lane;
+    const float* const lrx = sf + 4 * lane;
+    auto off_d = [](int pl, int C, int second) { return DTILE ? 128 * pl + C + 64 * second : 256 * (2 * pl + second) + C; };
+    auto off_x = [](int pl, int C, int second) { return 256 * (4 + 2 * pl + second) + C; };
+    // ---- exchange addresses (bytes from lds_all) ----
+    char* const xch = reinterpret_cast<char*>(lds_all + kCoopXchF4);
+    constexpr int kBufBytes = 4 * kCoopRegionF4 * 16, kRegBytes = kCoopRegionF4 * 16;
+    char* const rd_d = xch + ta * kRegBytes + lane * 16;                 // + buffer * kBufBytes + ((sub-tile * 3 + term) * 64) * 16
+    char* const rd_x = xch + (2 + tb) * kRegBytes + lane * 16;
+    char* const wr_d = rd_d + 8 * tb;                                      // this wave's pairs 2 tb, 2 tb + 1 of the gradient half
+    char* const wr_x = rd_x + 8 * ta;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[MI] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t Xc[NI][3][4], Xn[NI][3][4], Dq[2][3][4];     // [sub-tile][term: 0 = l, 1 = m, 2 = h][pair]
+    uint32_t T[4][3];                                     // the terms of the batch of four pairs being split: [pair in batch][term]
+    f32x2 rr[4];
+
+    auto pack = [](f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); };
+    auto unp = [](uint32_t h) { return f32x2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)}; };
+    // pair q (0..15) = operand q >> 3 (0 gradient, 1 activation), component (q >> 1) & 3, local pair q & 1; stage 0 fetch, 1 h (+ d(bias)), 2 m, 3 l
+    auto split_op = [&](int q, int st, const float* bd, const float* bx, float nf) __attribute__((always_inline)) {
+        const int op = q >> 3, C = (q >> 1) & 3, pl = q & 1, s = q & 3;
+        if (st == 0) {
+            rr[s] = op == 0 ? f32x2{bd[off_d(pl, C, 0)], bd[off_d(pl, C, 1)]} : f32x2{bx[off_x(pl, C, 0)], bx[off_x(pl, C, 1)]};
+        } else if (st == 1) {
+            if (op == 0) bsum[C] += nf * (rr[s][0] + rr[s][1]);
+            T[s][2] = pack(rr[s]);
+            rr[s] = rr[s] - unp(T[s][2]);
+        } else if (st == 2) {
+            T[s][1] = pack(rr[s]);
+            rr[s] = rr[s] - unp(T[s][1]);
+        } else {
+            T[s][0] = pack(rr[s]);
+        }
+    };
+    // the three terms of component C of operand op (pairs (op, C, 0), (op, C, 1) = batch slots 2 (C & 1), 2 (C & 1) + 1) into exchange buffer eb
+    auto write_op = [&](int op, int C, int t, int eb) __attribute__((always_inline)) {
+        char* const p = (op == 0 ? wr_d : wr_x) + eb * kBufBytes + ((C * 3 + t) * 64) * 16;
+        *reinterpret_cast<u32x2*>(p) = u32x2{T[2 * (C & 1)][t], T[2 * (C & 1) + 1][t]};
+    };
+    auto read_terms = [&](uint32_t (&dst)[3][4], const char* base, int sub, int eb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(base + eb * kBufBytes + ((sub * 3 + t) * 64) * 16);
+            dst[t][0] = v[0]; dst[t][1] = v[1]; dst[t][2] = v[2]; dst[t][3] = v[3];
+        }
+    };
+    // the 88 split / write operations of a step in issue order: per batch of four pairs (two components of one operand) 4 fetches, 4 x h,
+    // 4 x m, 4 x l, then the six writes of the two components
+    auto coop_op = [&](int n, const float* bd, const float* bx, float nf, int eb) __attribute__((always_inline)) {
+        const int B = n / 22, o = n % 22;
+        if (o < 16) split_op(4 * B + (o & 3), o >> 2, bd, bx, nf);
+        else write_op(B >> 1, 2 * (B & 1) + (o - 16) / 3, (o - 16) % 3, eb);
+    };
+
+    // ---- prologue: nobody may still read what this job is about to overwrite (the previous job's last exchange buffer, its staging) ----
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        dma_d(jb.k0, r, stage);
+        dma_x(jb.k0, r, stage);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        const int64_t k1st = jb.k0 + 16 < jb.k1 ? jb.k0 + 16 : jb.k0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dma_d(k1st, r, stage + 512);
+            dma_x(k1st, r, stage + 512);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 88; ++n) coop_op(n, lrd, lrx, 1.f, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) read_terms(Xc[j], rd_x, j, 0);
+    read_terms(Dq[0], rd_d, 0, 0);
+
+    for (int64_t k = jb.k0; k < jb.k1; k += 16) {
+        const int e = (int)(((k - jb.k0) >> 4) & 1);              // exchange buffer of this step's terms = staging buffer of this step's rows
+        const bool more = k + 16 < jb.k1;
+        const int64_t kn = k + 32 < jb.k1 ? k + 32 : k;           // rows to request (past the end: rows of the own range again, never used)
+        const float nf = more ? 1.f : 0.f;
+        const float* const bd = lrd + 2048 * (1 - e);             // the NEXT step's staged rows (requested a whole step ago)
+        const float* const bx = lrx + 2048 * (1 - e);
+        f32x4* const dst = stage + 512 * e;                       // this step's rows were split during the previous step: free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next step's rows have landed
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (i == 3) {       // every wave's terms of the next step are in buffer 1 - e, every wave's reads of this step's gradient terms are done
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+#pragma unroll
+            for (int g = 0; g < 24; ++g) {
+                const int j = g / 6, t = g % 6;
+                const int wc = t == 0 ? 0 : (t < 3 ? 1 : 2), xc = t == 0 ? 2 : (t == 1 ? 1 : (t == 2 ? 2 : t - 3));
+                __builtin_amdgcn_sched_barrier(0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, u32x4{Dq[i & 1][wc][0], Dq[i & 1][wc][1], Dq[i & 1][wc][2], Dq[i & 1][wc][3]}),
+                    __builtin_bit_cast(bf16x8, u32x4{Xc[j][xc][0], Xc[j][xc][1], Xc[j][xc][2], Xc[j][xc][3]}),
+                    acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < 3) {
+                    const int gg = 24 * i + g;                     // gap 0..71 of the step's first three blocks
+                    if (g == 1) read_terms(Dq[(i + 1) & 1], rd_d, i + 1, e);      // the gradient terms of the next block
+                    if (i == 0 && g >= 4 && g < 12) {              // the rows of the step after next
+                        if (g < 8) dma_d(kn, g - 4, dst);
+                        else dma_x(kn, g - 8, dst);
+                    }
+#pragma unroll
+                    for (int n = 0; n < 88; ++n)
+                        if ((n * 72) / 88 == gg) coop_op(n, bd, bx, nf, 1 - e);
+                } else {
+                    // block 3: the next step's activation terms (after the barrier), one read per gap; its first gradient sub-tile last
+                    if (g < 12) {
+                        const int sub = g / 3, tt = g % 3;
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(rd_x + (1 - e) * kBufBytes + ((sub * 3 + tt) * 64) * 16);
+                        Xn[sub][tt][0] = v[0]; Xn[sub][tt][1] = v[1]; Xn[sub][tt][2] = v[2]; Xn[sub][tt][3] = v[3];
+                    } else if (g == 20) {
+                        read_terms(Dq[0], rd_d, 0, 1 - e);         // (Dq[0] was last used by block 2)
+                    }
+                }
+            }
+            asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Xc[j][t][q] = Xn[j][t][q];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the last prefetch writes LDS: let it finish before the area is reused
+
+    float* slot = a.slots + (int64_t)ji * kSlotFloats;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* dst = slot + (MI * mr + i) * (32 * NI) + NI * m;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        }
+    if (jb.bias != 0) {
+        float* dst = slot + kSlotTile + half * (32 * MI) + MI * m;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) dst[i] = bsum[i];
+    }
+}
+
 #ifdef NNR_TIMELINE
 extern "C" int nnr_timeline_wgrad(unsigned long long* host32) {
     return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_wgrad), 32 * sizeof(unsigned long long));
@@ -372,7 +582,7 @@ extern "C" int nnr_timeline_wgrad(unsigned long long* host32) {
 
 template <bool SPLIT>     // SPLIT: the 4 x 4 tiles with three-term products (wgrad_job_split); the narrow tiles stay on fp32 MFMAs
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) f32x4 stage_all[SPLIT ? kWavesPerBlock * kStageF4 : 1];
+    __shared__ __attribute__((aligned(16))) f32x4 stage_all[SPLIT ? (kCoopF4 > kWavesPerBlock * kStageF4 ? kCoopF4 : kWavesPerBlock * kStageF4) : 1];
     const int lane = threadIdx.x & 63;
     const int wslot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int j0 = a.wave_first[wslot], j1 = a.wave_first[wslot + 1];
@@ -397,6 +607,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
         if constexpr (SPLIT) {
             // (the 128 x 64 tiles against the position encoding -- wgrad_job_split<.., 2> -- were measured on this path too: their VALU work
             // per MFMA is 1.6 times the 4 x 4 tile's and the kernel got SLOWER, 1.15 -> 1.29 ms at the best plan weight; they stay on fp32 MFMAs)
+            if (__builtin_amdgcn_readfirstlane(jb.reserved) == 1) {      // a class-A workgroup: the layer's four tiles share the split (all four waves are here)
+                wgrad_group_split<kTileGradPlanes>(jb, a, lane, ji, stage_all, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
+                continue;
+            }
             if (__builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI) == 4 * 8 + 4) {
                 f32x4* const stage = stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kStageF4;
                 // (every gradient plane of the three-term mode is tile-major: WsLayout::tiled -- the row-major instantiation is not built)
