@@ -88,7 +88,8 @@ size_t nnr_packed_floats(const nnr_cfg* cfg);
 /* floats of scratch the forward(+backward, if NNR_F_TRAIN) needs; contents are opaque except via nnr_ws_plane */
 size_t nnr_workspace_floats(const nnr_cfg* cfg);
 /* The weight-gradient work plan: a static, balanced schedule of wave jobs (which tile of which dW, which sample range),
- * WgradJob[n_jobs] grouped by wave followed by int32 wave_first[n_waves + 1].  Build on the host, upload once per cfg.
+ * WgradJob[n_jobs] grouped by wave followed by int32 wave_first[n_waves + 1], int32 n_heads, int32 heads[n_heads] (the job that holds
+ * split 0 of every tile: ABI 4).  Build on the host, upload once per cfg.
  * nnr_plan_counts reports n_jobs / n_waves (either pointer may be null). */
 size_t nnr_plan_bytes(const nnr_cfg* cfg);
 int nnr_plan_counts(const nnr_cfg* cfg, int32_t* n_jobs, int32_t* n_waves);

@@ -133,6 +133,7 @@ constexpr int kMinGranulesPerBlock = 16;  // small problems use fewer workgroups
 struct Plan {
     std::vector<WgradJob> jobs;        // grouped by wave: wave w runs jobs [wave_first[w], wave_first[w+1])
     std::vector<int32_t> wave_first;   // n_waves + 1 entries, n_waves a multiple of 4
+    std::vector<int32_t> heads;        // job index of split 0 of every tile: the reduction kernel launches 16 workgroups per HEAD, not per job
 };
 
 // Balanced static schedule.  Work is measured in cost-granules (MI*NI MFMAs-per-sample-pair x 16 samples).  The D x D
@@ -245,11 +246,13 @@ Plan build_plan(const nnr_cfg* c) {
             p.jobs[v[s]].split = (int32_t)s;
             p.jobs[v[s]].next_split = s + 1 < v.size() ? v[s + 1] : -1;
         }
+        if (!v.empty()) p.heads.push_back(v[0]);
     }
     return p;
 }
 
-size_t plan_bytes(const Plan& p) { return p.jobs.size() * sizeof(WgradJob) + p.wave_first.size() * sizeof(int32_t); }
+// blob: WgradJob[n_jobs], int32 wave_first[n_waves + 1], int32 n_heads, int32 heads[n_heads]
+size_t plan_bytes(const Plan& p) { return p.jobs.size() * sizeof(WgradJob) + (p.wave_first.size() + 1 + p.heads.size()) * sizeof(int32_t); }
 
 // ---- weight-gradient plan of the bf16 training mode (nnr_wgrad_bf16.hip) ------------------------------------------------------
 // Units = the products dW = Dlt^T X of the 12 layers (the feature layer merged into the colour-hidden one, the density head riding
@@ -531,8 +534,12 @@ int nnr_plan_build(const nnr_cfg* cfg, void* plan_host) {
     }
     const Plan p = build_plan(cfg);   // layout: WgradJob[n_jobs], then int32 wave_first[n_waves + 1]
     std::memcpy(plan_host, p.jobs.data(), p.jobs.size() * sizeof(WgradJob));
-    std::memcpy(static_cast<char*>(plan_host) + p.jobs.size() * sizeof(WgradJob), p.wave_first.data(),
-                p.wave_first.size() * sizeof(int32_t));
+    char* tail = static_cast<char*>(plan_host) + p.jobs.size() * sizeof(WgradJob);
+    std::memcpy(tail, p.wave_first.data(), p.wave_first.size() * sizeof(int32_t));
+    tail += p.wave_first.size() * sizeof(int32_t);
+    const int32_t n_heads = (int32_t)p.heads.size();
+    std::memcpy(tail, &n_heads, sizeof(int32_t));
+    std::memcpy(tail + sizeof(int32_t), p.heads.data(), p.heads.size() * sizeof(int32_t));
     return NNR_OK;
 }
 
@@ -703,8 +710,10 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const float* packed, const nnr_param_grads
         const Plan p = build_plan(cfg);   // host-only arithmetic, microseconds
         a.n_jobs = (int)p.jobs.size();
         a.n_waves = (int)p.wave_first.size() - 1;
+        a.n_heads = (int)p.heads.size();
     }
     a.wave_first = reinterpret_cast<const int32_t*>(a.jobs + a.n_jobs);
+    a.heads = a.wave_first + a.n_waves + 2;      // behind the wave table and the count
     a.slots = ws + w.total();
     a.gw[kMergedLayer] = a.slots + (size_t)a.n_jobs * kSlotFloats;
     a.gb[kMergedLayer] = a.gw[kMergedLayer] + (size_t)(cfg->hidden / 2) * cfg->hidden;

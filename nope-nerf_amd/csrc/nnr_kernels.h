@@ -80,7 +80,8 @@ struct WgradArgs {
     int32_t plane_pitch[48];
     int32_t plane_tile[48];    // 1: the plane is tile-major fp32 (WsLayout::tiled, nnr_layout.h)
     const int32_t* wave_first; // wave w runs jobs [wave_first[w], wave_first[w+1])
-    int n_jobs, n_waves;
+    const int32_t* heads;      // job index of split 0 of every tile (the reduction kernel's workgroups)
+    int n_jobs, n_waves, n_heads;
     int bias_rows[13];         // elements of gb[l]: the main kernel zeroes them (the reduction adds up to two shares per row)
 };
 

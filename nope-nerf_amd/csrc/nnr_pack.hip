@@ -8,22 +8,36 @@
 namespace nnr {
 
 // W' = Wg[:, :D] Wf and b' = Wg[:, :D] bf + bg (nnr_layout.h), plus the copies the un-merge step of the weight-gradient pass
-// reads.  One thread per element of W'; products accumulated in index order with fma.
+// reads.  Products accumulated in index order with fma (one chain per element: the value is defined by that order and pinned bit for
+// bit by tests/layout_ref.py).  Round 4: a workgroup computes a 16 x 16 tile of W' from LDS copies of its 16 rows of Wg and 16 columns of
+// Wf -- the same chains, but every operand is fetched from memory once per tile instead of once per element (one thread per element with
+// both operands from L2 was 16 us of latency); the copies and b' run in the workgroups behind the tiles.
 template <int D, int BF16>
 __global__ __launch_bounds__(256) void merge_kernel(PackArgs a) {
     using L = Layout<D, BF16>;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const float* Wf = a.w[9];
     const float* Wg = a.w[10];
     constexpr int ldg = D + kDirReal;
-    if (gid < L::Dh * D) {
-        const int m = gid / D, k = gid - m * D;
+    constexpr int kTiles = (L::Dh / 16) * (D / 16);
+    __shared__ float wg_s[16][D + 1];      // rows m0 .. m0 + 15 of Wg[:, :D] (+1: the 16 rows a wave reads sit in different banks)
+    __shared__ float wf_s[D][16];          // columns k0 .. k0 + 15 of Wf
+    if ((int)blockIdx.x < kTiles) {
+        const int m0 = 16 * ((int)blockIdx.x / (D / 16)), k0 = 16 * ((int)blockIdx.x % (D / 16));
+        for (int i = threadIdx.x; i < 16 * D; i += 256) {
+            wg_s[i / D][i % D] = Wg[(m0 + i / D) * ldg + i % D];
+            wf_s[i / 16][i % 16] = Wf[(i / 16) * D + k0 + i % 16];
+        }
+        __syncthreads();
+        const int mi = threadIdx.x >> 4, ki = threadIdx.x & 15;
         float acc = 0.f;
-#pragma unroll 16   // same fma chain, but 16 pairs of loads in flight: the loop is latency-bound (one wave per SIMD at best)
-        for (int j = 0; j < D; ++j) acc = fmaf(Wg[m * ldg + j], Wf[j * D + k], acc);
+#pragma unroll 16
+        for (int j = 0; j < D; ++j) acc = fmaf(wg_s[mi][j], wf_s[j][ki], acc);
+        const int gid = (m0 + mi) * D + k0 + ki;
         a.packed[L::merged_w_off + gid] = acc;
-        a.packed[L::copy_wg_off + gid] = Wg[m * ldg + k];
+        a.packed[L::copy_wg_off + gid] = wg_s[mi][k0 + ki];
+        return;
     }
+    const int gid = ((int)blockIdx.x - kTiles) * 256 + threadIdx.x, n_rest = ((int)gridDim.x - kTiles) * 256;
     if (gid < L::Dh) {
         float acc = a.b[10][gid];
 #pragma unroll 16
@@ -31,7 +45,7 @@ __global__ __launch_bounds__(256) void merge_kernel(PackArgs a) {
         a.packed[L::merged_b_off + gid] = acc;
     }
     if (gid < D) a.packed[L::copy_bf_off + gid] = a.b[9][gid];
-    for (int i = gid; i < D * D; i += gridDim.x * blockDim.x) a.packed[L::copy_wf_off + i] = Wf[i];
+    for (int i = gid; i < D * D; i += n_rest) a.packed[L::copy_wf_off + i] = Wf[i];
 }
 
 // MODE (= BF16 below): Layout<D, MODE> -- 0 fp32 fragments, 1 bf16 fragments, 2 three bf16 TERMS per weight (l, m, h fragments per row)
@@ -135,7 +149,7 @@ static hipError_t launch(const PackArgs& a0, hipStream_t st) {
     PackArgs a = a0;
     a.w[kMergedLayer] = a.packed + L::merged_w_off;
     a.b[kMergedLayer] = a.packed + L::merged_b_off;
-    hipLaunchKernelGGL((merge_kernel<D, BF16>), dim3((L::Dh * D + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((merge_kernel<D, BF16>), dim3((L::Dh / 16) * (D / 16) + 32), dim3(256), 0, st, a);      // tiles of W', then 32 workgroups of copies
     const int64_t threads = L::bias_base / 4 + L::table_floats;
     dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     hipLaunchKernelGGL((pack_kernel<D, BF16>), grid, block, 0, st, a);

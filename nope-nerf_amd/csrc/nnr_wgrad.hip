@@ -647,9 +647,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
 // the result does not depend on their order).  Blocks of jobs that are not split 0 of their tile exit at once; split 0 walks the chain.
 constexpr int kMaxChain = 256;   // splits of one tile (the plan builder cuts a tile's sample range into far fewer)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
-    const int ji = blockIdx.x >> 4;   // 16 blocks x 256 threads x one float4 = a 128 x 128 tile
+    const int ji = a.heads[blockIdx.x >> 4];   // 16 blocks x 256 threads x one float4 = a 128 x 128 tile; one group of 16 per TILE (round 4:
+                                               // launched per job -- 17 000 workgroups of which 16 in 17 returned at once -- this took 24 us)
     const WgradJob jb = a.jobs[ji];
-    if (jb.split != 0) return;
     // the tile's chain of splits, walked ONCE per block into LDS: with every thread walking it, each partial slot was fetched behind a
     // dependent load of the job table (two serialised L2 round trips per split); now the slot loads of all splits are independent
     // (27.8 -> 24.5 us at 1024 x 192)
@@ -670,12 +670,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         const float* src = a.slots + (int64_t)ji * kSlotFloats + row * pitch + c0;
         int s = 0;
-        for (; s + 4 <= n; s += 4) {      // four slots in flight, added in chain (= sample) order
-            f32x4 v[4];
+        for (; s + 8 <= n; s += 8) {      // eight slots in flight, added in chain (= sample) order
+            f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)chain[s + u] * kSlotFloats);
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)chain[s + u] * kSlotFloats);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sum += v[u];
+            for (int u = 0; u < 8; ++u) sum += v[u];
         }
         for (; s < n; ++s) sum += *reinterpret_cast<const f32x4*>(src + (int64_t)chain[s] * kSlotFloats);
         float* dst = a.gw[jb.layer] + (int64_t)(jb.row0 + row) * jb.ldw + jb.wcol0 + c0;
@@ -739,7 +739,7 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
     static const bool split_off = std::getenv("NNR_WGRAD_FP32") != nullptr;      // experiments: fp32 MFMAs in the weight gradient of the three-term mode
     if (a.bf16 == 2 && !split_off) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_jobs * 16), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_heads * 16), dim3(256), 0, st, a);
     e = hipGetLastError();
     if (e == hipSuccess) e = launch_wgrad_unmerge(a, st);
     prof_after(PROF_WGRAD, st);      // the bracket covers the whole stage: main kernel + slot reduction + un-merge
