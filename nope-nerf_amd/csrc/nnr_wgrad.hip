@@ -434,7 +434,7 @@ __device__ __forceinline__ void wgrad_group_split(const WgradJob& jb, const Wgra
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float bsum[MI] = {0.f, 0.f, 0.f, 0.f};
-    uint32_t Xc[NI][3][4], Xn[NI][3][4], Dq[2][3][4];     // [sub-tile][term: 0 = l, 1 = m, 2 = h][pair]
+    uint32_t Xc[NI][3][4], Dq[2][3][4];     // [sub-tile][term: 0 = l, 1 = m, 2 = h][pair]
     uint32_t T[4][3];                                     // the terms of the batch of four pairs being split: [pair in batch][term]
     f32x2 rr[4];
 
@@ -537,24 +537,14 @@ __device__ __forceinline__ void wgrad_group_split(const WgradJob& jb, const Wgra
                     for (int n = 0; n < 88; ++n)
                         if ((n * 72) / 88 == gg) coop_op(n, bd, bx, nf, 1 - e);
                 } else {
-                    // block 3: the next step's activation terms (after the barrier), one read per gap; its first gradient sub-tile last
-                    if (g < 12) {
-                        const int sub = g / 3, tt = g % 3;
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(rd_x + (1 - e) * kBufBytes + ((sub * 3 + tt) * 64) * 16);
-                        Xn[sub][tt][0] = v[0]; Xn[sub][tt][1] = v[1]; Xn[sub][tt][2] = v[2]; Xn[sub][tt][3] = v[3];
-                    } else if (g == 20) {
-                        read_terms(Dq[0], rd_d, 0, 1 - e);         // (Dq[0] was last used by block 2)
-                    }
+                    // block 3 (behind the barrier): activation sub-tile j's last MFMA of the step is gap 6 j + 5 -- its registers take the
+                    // next step's terms right behind it (no second register set, no 48 moves per step); the first gradient sub-tile last
+                    if (t == 5) read_terms(Xc[j], rd_x, j, 1 - e);
+                    if (g == 20) read_terms(Dq[0], rd_d, 0, 1 - e);         // (Dq[0] was last used by block 2)
                 }
             }
             asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]));
         }
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) Xc[j][t][q] = Xn[j][t][q];
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the last prefetch writes LDS: let it finish before the area is reused
 

@@ -15,14 +15,14 @@ sys.path.insert(0, ROOT)
 
 # ms per launch, isolated launches: (R, N, mode) -> kernel -> bound = 1.5 x measured (round 3/4 boxes, the slower of the runs on record)
 BOUNDS = {
-    # three-term products (the default fp32 arithmetic): measured 1.13-1.22 / 0.99-1.02 / 1.03-1.15 / 0.80-0.85
-    (1024, 192, "split3"): {"mlp_fwd": 1.85, "mlp_dgrad": 1.55, "mlp_wgrad": 1.75, "mlp_fwd_infer": 1.3},
-    # fp32 MFMAs (NNR_FP32_PRODUCTS=mfma): measured 1.82 / 1.62 / 1.58 / 1.46
-    (1024, 192, "mfma"): {"mlp_fwd": 2.75, "mlp_dgrad": 2.45, "mlp_wgrad": 2.4, "mlp_fwd_infer": 2.2},
-    # bf16 products: measured 0.76-0.78 / 0.67-0.75 / 0.87-0.94 / 0.45-0.50
-    (4096, 128, "bf16"): {"mlp_fwd": 1.17, "mlp_dgrad": 1.13, "mlp_wgrad": 1.41, "mlp_fwd_infer": 0.75},
-    # flat decomposition (N % 32 != 0), three-term: no measurement on record beyond "under the ray-mode time x R N ratio": 2x of that
-    (1000, 100, "split3"): {"mlp_fwd": 1.3, "mlp_dgrad": 1.1, "mlp_wgrad": 1.3, "mlp_fwd_infer": 0.95},
+    # three-term products (the default fp32 arithmetic), round 4: measured 1.19-1.24 / 0.85-0.89 / 1.13-1.17 / 0.80-0.84
+    (1024, 192, "split3"): {"mlp_fwd": 1.85, "mlp_dgrad": 1.35, "mlp_wgrad": 1.75, "mlp_fwd_infer": 1.26},
+    # fp32 MFMAs (NNR_FP32_PRODUCTS=mfma): measured 1.69 / 1.54 / 1.56 / 1.46
+    (1024, 192, "mfma"): {"mlp_fwd": 2.55, "mlp_dgrad": 2.3, "mlp_wgrad": 2.35, "mlp_fwd_infer": 2.2},
+    # bf16 products: measured 0.71 / 0.61 / 0.91 / 0.49
+    (4096, 128, "bf16"): {"mlp_fwd": 1.07, "mlp_dgrad": 0.92, "mlp_wgrad": 1.36, "mlp_fwd_infer": 0.74},
+    # flat decomposition (N % 32 != 0), three-term: measured 0.74 / 0.66 / 0.67 / 0.55
+    (1000, 100, "split3"): {"mlp_fwd": 1.11, "mlp_dgrad": 1.0, "mlp_wgrad": 1.0, "mlp_fwd_infer": 0.83},
 }
 
 
