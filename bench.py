@@ -123,7 +123,8 @@ def build_trainer(device, world, aux=False, bf16=False, rays_per_gpu=None, n_sam
     return trainer, net
 
 
-_TRAFFIC_FILES = ('profiles/r03/hbm_traffic.json', 'profiles/r03/hbm_traffic_bf16_4096x128.json',
+_TRAFFIC_FILES = ('profiles/r04/hbm_traffic.json', 'profiles/r04/hbm_traffic_bf16_4096x128.json',
+                  'profiles/r03/hbm_traffic.json', 'profiles/r03/hbm_traffic_bf16_4096x128.json',
                   'profiles/r02/hbm_traffic.json', 'profiles/r02/hbm_traffic_bf16_4096x128.json')
 _KERNEL_KEYS = {
     False: {'mlp_fwd': 'mlp_fwd_kernel<256, true', 'mlp_dgrad': 'mlp_dgrad_kernel<256', 'mlp_wgrad': 'nnr::wgrad_kernel'},

@@ -100,6 +100,7 @@ class Trainer(object):
         self._nan_flag = None      # (pinned host flag, event) of the previous step's isnan(loss), read one step late
         self._nan_host = None
         self._early_host = None    # four pinned buffers for the step's logged scalars (_EarlyScalar), used in turn
+        self._nan_with_early = False
         self.early_scalars = bool(cfg.get('early_scalars', True))   # training.early_scalars: False returns plain device tensors
         # the deferred NaN flag of the newest step is looked at before anything is written to disk (model/checkpoints.py)
         import weakref
@@ -134,10 +135,17 @@ class Trainer(object):
                 if not net.training:
                     net.train()
                 opt.zero_grad()
-        loss_dict = self.compute_loss(data, it=it, epoch=epoch, scheduling_start=scheduling_start,
-                                      out_render_path=render_path)
+        self._nan_with_early = bool(self.early_scalars and self.device is not None and torch.device(self.device).type == 'cuda'
+                                    and not (parallel.world_size() > 1 or parallel.always_reduce()))
+        try:
+            loss_dict = self.compute_loss(data, it=it, epoch=epoch, scheduling_start=scheduling_start,
+                                          out_render_path=render_path)
+        finally:
+            deferred, self._nan_with_early = self._nan_with_early, False
         loss = loss_dict['loss']
         early = self._copy_scalars_early(loss_dict) if (loss.is_cuda and self.early_scalars) else None
+        if deferred and (early is None or self._nan_flag is None):      # (the early copy did not take the loss along: copy it now)
+            self._check_nan(loss)
         if loss.is_cuda:      # the root gradient as a cached constant: loss.backward() would launch a ones_like fill every step
             if self._one is None or self._one.device != loss.device:
                 self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
@@ -154,7 +162,7 @@ class Trainer(object):
                     opt.step()
         if early is not None:
             keys, slot, event = early
-            for i, k in enumerate(keys):
+            for k, i in keys:
                 t = torch.Tensor._make_subclass(_EarlyScalar, loss_dict[k].detach())
                 t._early = (slot, slot['generation'], i, event)
                 loss_dict[k] = t
@@ -162,23 +170,48 @@ class Trainer(object):
 
     def _copy_scalars_early(self, loss_dict):
         """Enqueue, BEFORE the backward, the copy of the step's 0-dim logged scalars to pinned host memory (see _EarlyScalar).  Not under
-        data parallelism: there the logged scalars are summed over the ranks after the backward (parallel.allreduce_gradients)."""
+        data parallelism: there the logged scalars are summed over the ranks after the backward (parallel.allreduce_gradients).
+        One asynchronous copy, no launch, when every scalar that is not the cached zero is a view of ONE small device buffer (the fused
+        loss kernel's output: loss, loss_rgb, loss_depth, l2_mean -- the step without per-image losses); otherwise one stack launch + one
+        copy.  The deferred NaN check reads the loss from the same host buffer (no second copy)."""
         if parallel.world_size() > 1 or parallel.always_reduce():
             return None
         keys = [k for k, v in loss_dict.items() if torch.is_tensor(v) and v.is_cuda and v.numel() == 1 and v.dtype == torch.float32
                 and k not in ('scale', 'shift')]       # (the two distortion entries are (1,) views train.py only stores)
         if not keys:
             return None
-        if self._early_host is None or self._early_host[0]['host'].numel() < len(keys):
-            self._early_host = [{'host': torch.empty(max(16, len(keys)), dtype=torch.float32).pin_memory(), 'generation': 0} for _ in range(4)]
+        if self._early_host is None or self._early_host[0]['host'].numel() < max(16, len(keys)) + 1:
+            self._early_host = [{'host': torch.zeros(max(16, len(keys)) + 17, dtype=torch.float32).pin_memory(), 'generation': 0} for _ in range(4)]
         slot = self._early_host[0]
         self._early_host.append(self._early_host.pop(0))      # the buffers of the last three steps stay valid for their readers
         slot['generation'] += 1
+        host = slot['host']
+        zero = _zero(loss_dict[keys[0]])
+        live = [k for k in keys if loss_dict[k] is not zero]
+        index = {}
+        base = None
+        if live:
+            st = loss_dict[live[0]].untyped_storage()
+            if all(loss_dict[k].untyped_storage().data_ptr() == st.data_ptr() for k in live) and st.nbytes() <= 64:
+                base = torch.empty(0, dtype=torch.float32, device=loss_dict[live[0]].device).set_(st)      # the whole buffer, as it lies
         with torch.no_grad():
-            slot['host'][:len(keys)].copy_(torch.stack([loss_dict[k].detach().reshape(()) for k in keys]), non_blocking=True)
+            if base is not None:
+                n = base.numel()
+                host[:n].copy_(base, non_blocking=True)
+                for k in live:
+                    index[k] = loss_dict[k].storage_offset()
+                host[16] = 0.0                                 # (a host write: the slot the cached zeros answer from)
+                for k in keys:
+                    if k not in index:
+                        index[k] = 16
+            else:
+                host[:len(keys)].copy_(torch.stack([loss_dict[k].detach().reshape(()) for k in keys]), non_blocking=True)
+                index = {k: i for i, k in enumerate(keys)}
         event = torch.cuda.Event()
         event.record()
-        return keys, slot, event
+        if 'loss' in index:                                    # the deferred NaN check of this step looks at the same copy
+            self._nan_flag = (host[index['loss']:index['loss'] + 1], event)
+        return [(k, index[k]) for k in keys], slot, event
 
     # ------------------------------------------------------------------------------------------------ data
     @staticmethod
@@ -337,9 +370,12 @@ class Trainer(object):
         memory, with an event -- right behind its loss kernel and only looked at during step i+1."""
         if self._nan_flag is not None:
             host, ev = self._nan_flag
+            self._nan_flag = None
             ev.synchronize()
             if math.isnan(float(host)):
                 raise FloatingPointError('NaN loss in the previous training step')
+        if getattr(self, '_nan_with_early', False) and loss.is_cuda:
+            return      # train_step copies the step's logged scalars to the host in one go (_copy_scalars_early) and points the flag at it
         if loss.is_cuda:
             if self._nan_host is None:
                 self._nan_host = [torch.empty((), dtype=torch.float32).pin_memory() for _ in range(2)]

@@ -15,3 +15,11 @@ if __name__ == "__main__":
         ld = trainer.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
         print("aux", aux, {k: (type(v).__name__, tuple(v.shape), str(v.dtype), str(v.device)) if torch.is_tensor(v) else type(v).__name__ for k, v in ld.items()})
         print("   item():", {k: round(v.item(), 6) for k, v in ld.items() if torch.is_tensor(v) and v.numel() == 1})
+        for k, v in ld.items():      # the early host copy answers exactly what the device tensor holds
+            if torch.is_tensor(v) and v.numel() == 1:
+                assert v.item() == torch.Tensor.item(v), (k, v.item(), torch.Tensor.item(v))
+        for i in range(3):           # and keeps doing so over further steps (slot rotation)
+            ld2 = trainer.train_step(data, it=2 + i, epoch=0, scheduling_start=10000, render_path=None)
+            assert all(v.item() == torch.Tensor.item(v) for v in ld2.values() if torch.is_tensor(v) and v.numel() == 1)
+        trainer.flush_nan_check()
+        print("   early host copies == device values over 4 steps; NaN flag clean")
