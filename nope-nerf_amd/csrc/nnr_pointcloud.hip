@@ -12,21 +12,28 @@
 // index of the minimum.  The kernel forms the same fp32 value and orders candidates by (sqrt bits, index).
 #include "nnr_device.h"
 #include "nnr_kernels.h"
+#include <cstdlib>
 
 namespace nnr {
 
 constexpr int kPcBlock = 256;   // lanes per workgroup
-constexpr int kPcPer = 4;       // source points per lane: one LDS read feeds four pairs, held as two float2 so that the
-                                // subtract / square / fma chain issues as packed fp32 (v_pk_*: two pairs per instruction)
 constexpr int kPcTile = 1024;   // destination points staged in LDS at a time (16 KB as float4)
-
+// PER = source points per lane, held as float2 pairs so that the subtract / square / fma chain issues as packed fp32 (v_pk_*: two
+// pairs per instruction); one LDS read feeds PER pairs.  Round 4 measured what bounds the kernel (profiles/r04/k_pc_nearest_sweep.txt,
+// 32 400 x 32 400 points, the first training phase's clouds at 540 x 960): NOT the instruction count -- the time falls linearly with the
+// number of workgroups up to ~2048 (8 waves per SIMD: 6.0 / 3.2 / 1.7 / 0.85 / 0.46 / 0.34 ms at 32 / 64 / 128 / 256 / 512 / 1024
+// workgroups), i.e. it is the latency of the dependent chain LDS read -> subtract -> multiply -> fma -> fma -> compare -> branch that
+// more waves hide, and longer destination ranges per workgroup (fewer takes of the bookkeeping branch) do not pay for the waves they
+// cost.  PER = 2 with 2048 workgroups: 316 us against 343 for PER = 4 / 1024 (rounds 1-3).
 // keys[s] = min over this block's destination range of (sqrt(d2) bits << 32 | index): distances are >= 0, so their bit
 // patterns order like the values, and equal distances order by index (= first occurrence).
+template <int kPcPer>
 __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __restrict__ src, const float* __restrict__ dst, int S,
                                                               int D, int d_per_block, unsigned long long* __restrict__ keys) {
     __shared__ f32x4 tile[kPcTile];
     const int s0 = (blockIdx.x * kPcBlock + threadIdx.x) * kPcPer;
-    f32x2 x[2], y[2], z[2];
+    constexpr int kPairs = kPcPer / 2;
+    f32x2 x[kPairs], y[kPairs], z[kPairs];
 #pragma unroll
     for (int u = 0; u < kPcPer; ++u) {
         const int sc = s0 + u < S ? s0 + u : S - 1;
@@ -35,7 +42,7 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __res
         z[u >> 1][u & 1] = src[3 * sc + 2];
     }
     const int d0 = blockIdx.y * d_per_block, d1 = min(D, d0 + d_per_block);
-    f32x2 best_d2[2];
+    f32x2 best_d2[kPairs];
     float best_s[kPcPer];
     int best_i[kPcPer];
 #pragma unroll
@@ -52,18 +59,21 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __res
             tile[i] = f32x4{p[0], p[1], p[2], 0.f};
         }
         __syncthreads();
-#pragma unroll 2
+#pragma unroll 4
         for (int i = 0; i < n; ++i) {
             const f32x4 q = tile[i];   // same address in every lane: an LDS broadcast
-            f32x2 d2[2];
+            f32x2 d2[kPairs];
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
+            for (int v = 0; v < kPairs; ++v) {
                 const f32x2 dx = x[v] - q[0], dy = y[v] - q[1], dz = z[v] - q[2];
                 // torch.linalg.norm's sum of squares: fma(dz,dz, fma(dy,dy, dx*dx)), every step rounded to fp32
                 d2[v] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
             }
             // rare after the first few points: the sqrt and the bookkeeping stay out of the steady-state loop
-            if ((d2[0][0] < best_d2[0][0]) | (d2[0][1] < best_d2[0][1]) | (d2[1][0] < best_d2[1][0]) | (d2[1][1] < best_d2[1][1])) {
+            bool any = false;
+#pragma unroll
+            for (int v = 0; v < kPairs; ++v) any = any | (d2[v][0] < best_d2[v][0]) | (d2[v][1] < best_d2[v][1]);
+            if (any) {
 #pragma unroll
                 for (int u = 0; u < kPcPer; ++u) {
                     const float v = d2[u >> 1][u & 1];
@@ -146,14 +156,18 @@ __global__ __launch_bounds__(256) void pc_error_bwd_kernel(const float* __restri
 
 // keys must hold ~0 (or earlier candidates): the search only lowers them
 hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int D, unsigned long long* keys, hipStream_t st) {
-    // enough workgroups to fill the chip: split the destination range until there are ~4 per CU
-    const int bx = (S + kPcBlock * kPcPer - 1) / (kPcBlock * kPcPer);
-    int split = (1024 + bx - 1) / bx;
-    const int max_split = (D + 255) / 256;   // at least 256 destination points per workgroup
+    // PER sources per lane and the number of workgroups to aim for (the destination range is split until there are about that many;
+    // at least 256 destination points per workgroup): knobs for experiments, defaults from the round-4 sweep (profiles/r04/)
+    static const int per = [] { const char* e = std::getenv("NNR_PC_PER"); const int v = e ? std::atoi(e) : 2; return v == 4 ? 4 : 2; }();
+    static const int wgs = [] { const char* e = std::getenv("NNR_PC_WGS"); const int v = e ? std::atoi(e) : 2048; return v < 1 ? 1 : v; }();
+    const int bx = (S + kPcBlock * per - 1) / (kPcBlock * per);
+    int split = (wgs + bx - 1) / bx;
+    const int max_split = (D + 255) / 256;
     split = split < 1 ? 1 : (split > max_split ? max_split : split);
     const int d_per_block = ((D + split - 1) / split + 255) / 256 * 256;
     const int by = (D + d_per_block - 1) / d_per_block;
-    hipLaunchKernelGGL(pc_nearest_kernel, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
+    if (per == 4) hipLaunchKernelGGL(pc_nearest_kernel<4>, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
+    else hipLaunchKernelGGL(pc_nearest_kernel<2>, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
     return hipGetLastError();
 }
 
