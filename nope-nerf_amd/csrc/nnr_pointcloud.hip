@@ -54,35 +54,42 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __res
     for (int t0 = d0; t0 < d1; t0 += kPcTile) {
         const int n = min(kPcTile, d1 - t0);
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += kPcBlock) {
-            const float* p = dst + 3 * (int64_t)(t0 + i);
-            tile[i] = f32x4{p[0], p[1], p[2], 0.f};
+        const int n4 = (n + 3) & ~3;      // four destination points per trip: pad with points at infinity (their d2 is +inf: never a minimum)
+        for (int i = threadIdx.x; i < n4; i += kPcBlock) {
+            const float* p = dst + 3 * (int64_t)(t0 + (i < n ? i : 0));
+            tile[i] = i < n ? f32x4{p[0], p[1], p[2], 0.f} : f32x4{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f};
         }
         __syncthreads();
-#pragma unroll 4
-        for (int i = 0; i < n; ++i) {
-            const f32x4 q = tile[i];   // same address in every lane: an LDS broadcast
-            f32x2 d2[kPairs];
-#pragma unroll
-            for (int v = 0; v < kPairs; ++v) {
-                const f32x2 dx = x[v] - q[0], dy = y[v] - q[1], dz = z[v] - q[2];
-                // torch.linalg.norm's sum of squares: fma(dz,dz, fma(dy,dy, dx*dx)), every step rounded to fp32
-                d2[v] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-            }
-            // rare after the first few points: the sqrt and the bookkeeping stay out of the steady-state loop
+        // Four points per trip, ONE branch for the four (round 4): the chain LDS read -> subtract -> multiply -> fma -> fma -> compare ->
+        // branch is what this kernel waits for (see above); four independent chains per source pair and a quarter of the branches.
+#pragma unroll 1
+        for (int i = 0; i < n4; i += 4) {
+            f32x2 d2[4][kPairs];
             bool any = false;
 #pragma unroll
-            for (int v = 0; v < kPairs; ++v) any = any | (d2[v][0] < best_d2[v][0]) | (d2[v][1] < best_d2[v][1]);
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 q = tile[i + k];   // same address in every lane: an LDS broadcast
+#pragma unroll
+                for (int v = 0; v < kPairs; ++v) {
+                    const f32x2 dx = x[v] - q[0], dy = y[v] - q[1], dz = z[v] - q[2];
+                    // torch.linalg.norm's sum of squares: fma(dz,dz, fma(dy,dy, dx*dx)), every step rounded to fp32
+                    d2[k][v] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                    any = any | (d2[k][v][0] < best_d2[v][0]) | (d2[k][v][1] < best_d2[v][1]);
+                }
+            }
+            // rare after the first few points: the sqrt and the bookkeeping stay out of the steady-state loop; the four points in index order
             if (any) {
 #pragma unroll
-                for (int u = 0; u < kPcPer; ++u) {
-                    const float v = d2[u >> 1][u & 1];
-                    if (v < best_d2[u >> 1][u & 1]) {
-                        const float sq = __fsqrt_rn(v);
-                        if (sq < best_s[u]) { best_s[u] = sq; best_i[u] = t0 + i; }   // equal sqrt: the earlier index stays
-                        best_d2[u >> 1][u & 1] = v;
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int u = 0; u < kPcPer; ++u) {
+                        const float v = d2[k][u >> 1][u & 1];
+                        if (v < best_d2[u >> 1][u & 1]) {
+                            const float sq = __fsqrt_rn(v);
+                            if (sq < best_s[u]) { best_s[u] = sq; best_i[u] = t0 + i + k; }   // equal sqrt: the earlier index stays
+                            best_d2[u >> 1][u & 1] = v;
+                        }
                     }
-                }
             }
         }
     }
