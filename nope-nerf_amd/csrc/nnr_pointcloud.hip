@@ -99,126 +99,6 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __res
             atomicMin(keys + s0 + u, ((unsigned long long)__float_as_uint(best_s[u]) << 32) | (unsigned int)best_i[u]);
 }
 
-// ---- the same search with exact pruning (round 4) ------------------------------------------------------------------------------------
-// The brute-force kernel above evaluates S x D pairs; in the trainer both clouds are back-projected depth maps in raster order (32 400
-// points each at 540 x 960), where 64 consecutive destination points are a short curve in space and almost all of them are far from any
-// given source.  A workgroup takes 512 consecutive sources (two per lane) and a PART of the destination's 64-point chunks; it first forms
-// the axis-aligned box of every chunk of its part (LDS), then visits a chunk only if some source of the wave could still find its
-// minimum there:  lb2 (1 - 1e-5) <= best_d2,  lb2 = the squared distance from the source to the box, best_d2 the smallest d2 the
-// source has seen.  Exactness: every point of a skipped chunk has d2 >= lb2 > best_d2 (1 + 1e-5) -- five orders above the rounding of
-// either side and of the sqrt bucket in which two d2 give the same distance -- so neither the minimum nor a tie for it can sit there;
-// visited points are evaluated with the brute-force kernel's arithmetic (the fma chain of torch.linalg.norm, then sqrt) and merged by
-// (sqrt bits, index) lexicographically -- the order of visits does not matter, the first index of the minimum wins as in torch.argmin.
-// The chunk nearest to the wave's middle source is visited first (a good bound at once, whatever the order of the points); parts
-// are merged through the same 64-bit atomicMin as the brute-force kernel's destination ranges.  A chunk's points are not staged:
-// lane k holds point k and v_readlane hands its coordinates to the whole wave as scalars.
-constexpr int kPcChunk = 64;
-constexpr int kPcMaxPartChunks = 128;      // boxes of a part in LDS: 4 KB
-
-__global__ __launch_bounds__(256) void pc_nearest_pruned_kernel(const float* __restrict__ src, const float* __restrict__ dst, int S, int D,
-                                                                int chunks_per_part, unsigned long long* __restrict__ keys) {
-    __shared__ float box[kPcMaxPartChunks][8];      // lo.xyz, hi.xyz of every chunk of this part (empty chunk: lo = +inf, hi = -inf)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n_chunks = (D + kPcChunk - 1) / kPcChunk;
-    const int c0 = blockIdx.y * chunks_per_part, c1 = min(n_chunks, c0 + chunks_per_part);
-    const float inf = __builtin_inff();
-    // ---- boxes: wave w takes the chunks c0 + w, c0 + w + 4, ... ----
-    for (int c = c0 + wave; c < c1; c += 4) {
-        const int j = c * kPcChunk + lane;
-        float lo[3], hi[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float v = j < D ? dst[3 * (int64_t)j + a] : __builtin_nanf("");
-            lo[a] = v == v ? v : inf;            // a NaN coordinate never wins a comparison in the search either: keep it out of the box
-            hi[a] = v == v ? v : -inf;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1)
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, 64));
-                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, 64));
-            }
-        if (lane == 0) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) { box[c - c0][a] = lo[a]; box[c - c0][4 + a] = hi[a]; }
-        }
-    }
-    __syncthreads();
-    // ---- this lane's two sources ----
-    const int s0 = (blockIdx.x * 256 + threadIdx.x) * 2;
-    float x[2], y[2], z[2], best_d2[2], best_thr[2], best_s[2];      // best_thr = best_d2 (1 + 4e-7): see visit()
-    int best_i[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int sc = s0 + u < S ? s0 + u : S - 1;
-        x[u] = src[3 * (int64_t)sc]; y[u] = src[3 * (int64_t)sc + 1]; z[u] = src[3 * (int64_t)sc + 2];
-        best_d2[u] = inf; best_thr[u] = inf; best_s[u] = inf; best_i[u] = 0x7fffffff;
-    }
-    // squared distance of source u to the box of part-chunk c (0 inside; NaN-free for finite sources: an empty box gives +inf)
-    auto lb2 = [&](int c, int u) __attribute__((always_inline)) {
-        const float ex = fmaxf(fmaxf(box[c][0] - x[u], x[u] - box[c][4]), 0.f);
-        const float ey = fmaxf(fmaxf(box[c][1] - y[u], y[u] - box[c][5]), 0.f);
-        const float ez = fmaxf(fmaxf(box[c][2] - z[u], z[u] - box[c][6]), 0.f);
-        return fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-    };
-    auto visit = [&](int c) __attribute__((always_inline)) {      // all 64 points of chunk c0 + c against this lane's two sources
-        const int j = (c0 + c) * kPcChunk + lane;
-        const float px = j < D ? dst[3 * (int64_t)j] : inf, py = j < D ? dst[3 * (int64_t)j + 1] : inf, pz = j < D ? dst[3 * (int64_t)j + 2] : inf;
-#pragma unroll 8
-        for (int k = 0; k < kPcChunk; ++k) {
-            const float qx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px), k));
-            const float qy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py), k));
-            const float qz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz), k));
-            float d2[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float dx = x[u] - qx, dy = y[u] - qy, dz = z[u] - qz;
-                d2[u] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));      // torch.linalg.norm's sum of squares, as in the brute-force kernel
-            }
-            // A candidate is anything whose DISTANCE could equal the best one: two d2 up to 1.2e-7 apart (relative) round to the same sqrt,
-            // and of those the smaller INDEX wins (the brute-force kernel meets it first) even if its d2 is the larger one -- hence the
-            // threshold a hair above the smallest d2 seen, and the lexicographic (sqrt, index) comparison.  d2 = +inf is never a match.
-            if (((d2[0] <= best_thr[0]) & (d2[0] < inf)) | ((d2[1] <= best_thr[1]) & (d2[1] < inf))) {
-                const int idx = (c0 + c) * kPcChunk + k;
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if ((d2[u] <= best_thr[u]) & (d2[u] < inf)) {
-                        const float sq = __fsqrt_rn(d2[u]);
-                        if (sq < best_s[u] || (sq == best_s[u] && idx < best_i[u])) { best_s[u] = sq; best_i[u] = idx; }
-                        if (d2[u] < best_d2[u]) { best_d2[u] = d2[u]; best_thr[u] = d2[u] * 1.0000004f; }
-                    }
-            }
-        }
-    };
-    // ---- the chunk nearest to the wave's middle source first ----
-    const int n_part = c1 - c0;
-    int seed = 0;
-    if (n_part > 0) {
-        const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[0]), 32));
-        const float my = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y[0]), 32));
-        const float mz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[0]), 32));
-        float best = inf;
-        for (int c = 0; c < n_part; ++c) {
-            const float ex = fmaxf(fmaxf(box[c][0] - mx, mx - box[c][4]), 0.f), ey = fmaxf(fmaxf(box[c][1] - my, my - box[c][5]), 0.f);
-            const float ez = fmaxf(fmaxf(box[c][2] - mz, mz - box[c][6]), 0.f);
-            const float l = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-            if (l < best) { best = l; seed = c; }
-        }
-        seed = __builtin_amdgcn_readfirstlane(seed);
-        visit(seed);
-    }
-    for (int c = 0; c < n_part; ++c) {
-        if (c == seed) continue;
-        const bool need = (lb2(c, 0) * 0.99999f <= best_d2[0]) | (lb2(c, 1) * 0.99999f <= best_d2[1]);
-        if (__builtin_amdgcn_ballot_w64(need) != 0) visit(c);      // wave-uniform: readlane needs every lane's point
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-        if (s0 + u < S && best_i[u] != 0x7fffffff)
-            atomicMin(keys + s0 + u, ((unsigned long long)__float_as_uint(best_s[u]) << 32) | (unsigned int)best_i[u]);
-}
-
 __global__ void pc_fill_keys_kernel(unsigned long long* keys, int S) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < S) keys[s] = ~0ull;
@@ -285,21 +165,6 @@ __global__ __launch_bounds__(256) void pc_error_bwd_kernel(const float* __restri
 hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int D, unsigned long long* keys, hipStream_t st) {
     // PER sources per lane and the number of workgroups to aim for (the destination range is split until there are about that many;
     // at least 256 destination points per workgroup): knobs for experiments, defaults from the round-4 sweep (profiles/r04/)
-    // NNR_PC_PRUNED=1: the pruned search instead of the brute-force kernel -- the same indices bit for bit (tests/test_gpu_pc_pruned.py).
-    // NOT the default: measured (profiles/r04/m_pc_nearest_pruned.txt, n_*) it is 1.3 - 2x SLOWER than brute force on clouds whose depth is
-    // white noise per pixel (bench.py's synthetic batch: the boxes of 64 consecutive pixels span the whole depth range and prune little)
-    // and it is bound by the latency of its v_readlane -> subtract -> fma -> compare chain like the brute-force kernel is by its own;
-    // on smooth depth maps see the same file.
-    static const bool pruned = std::getenv("NNR_PC_PRUNED") != nullptr && std::getenv("NNR_PC_BRUTE") == nullptr;
-    if (pruned) {
-        static const int parts_target = [] { const char* e = std::getenv("NNR_PC_PARTS"); const int v = e ? std::atoi(e) : 8; return v < 1 ? 1 : v; }();
-        const int n_chunks = (D + kPcChunk - 1) / kPcChunk;
-        int cpp = (n_chunks + parts_target - 1) / parts_target;
-        cpp = cpp > kPcMaxPartChunks ? kPcMaxPartChunks : (cpp < 1 ? 1 : cpp);
-        const int by = (n_chunks + cpp - 1) / cpp;
-        hipLaunchKernelGGL(pc_nearest_pruned_kernel, dim3((S + 511) / 512, by), dim3(256), 0, st, src, dst, S, D, cpp, keys);
-        return hipGetLastError();
-    }
     static const int per = [] { const char* e = std::getenv("NNR_PC_PER"); const int v = e ? std::atoi(e) : 2; return v == 4 ? 4 : 2; }();
     static const int wgs = [] { const char* e = std::getenv("NNR_PC_WGS"); const int v = e ? std::atoi(e) : 2048; return v < 1 ? 1 : v; }();
     const int bx = (S + kPcBlock * per - 1) / (kPcBlock * per);
