@@ -136,7 +136,7 @@ int nnr_render_bwd(const nnr_cfg* cfg, const float* packed, const float* d_rgb, 
  * colour-hidden layer, see nnr_layout.h) */
 int64_t nnr_ws_plane(const nnr_cfg* cfg, int plane, int32_t* pitch_out);
 /* How the plane's elements are ordered (ABI 4): 0 = row-major fp32 [sample][pitch]; 1 = tile-major bf16 (NNR_F_BF16 training, above);
- * 2 = tile-major fp32 -- NNR_F_SPLIT3 training, planes 31..38 and 40: 1 KiB blocks [chunk of 32 samples][octet j of features], a block
+ * 2 = tile-major fp32 -- NNR_F_SPLIT3 training, planes 10..20 (activations) and 31..38, 40 (gradients): 1 KiB blocks [chunk of 32 samples][octet j of features], a block
  * is [lane = 32 h + c][4 floats] = features 8 j + 4 h + {0..3} of sample 32 chunk + c (nnr_layout.h: tile32_index); offset and pitch
  * (= floats per sample) are those nnr_ws_plane reports.  <0 for an unknown plane. */
 int nnr_ws_plane_layout(const nnr_cfg* cfg, int plane);

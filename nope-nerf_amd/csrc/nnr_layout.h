@@ -224,6 +224,16 @@ constexpr bool kTileGradPlanes = false;
 #else
 constexpr bool kTileGradPlanes = true;
 #endif
+// The ACTIVATION planes (P_XE, P_XH1.., P_XF, P_XG) of the three-term training workspace are tile-major too (same blocks, written by the
+// forward's stash stores).  The first measurement said the forward does not gain from it (1.185 against 1.108 ms): that experiment
+// library had compiled its forward with 183 scratch reloads, every one a full drain of the store queue (an extra address register per
+// store) -- found only at the end of round 4, when a build WITHOUT the weight DMA ran the training forward at the inference forward's
+// time (0.85 ms): what the row-major stores cost is the 64 cache lines each of them touches in the address path the weight DMA shares.
+#ifdef NNR_ROWMAJOR_XPLANES
+constexpr bool kTileActPlanes = false;
+#else
+constexpr bool kTileActPlanes = true;
+#endif
 NNR_HD constexpr int64_t tile32_index(int64_t s, int f, int W) {
     return (((s >> 5) * (W >> 3) + (f >> 3)) << 8) + ((((f >> 2) & 1) * 32 + (s & 31)) << 2) + (f & 3);
 }
@@ -232,8 +242,13 @@ struct WsLayout {
     int64_t S, S_pad;
     int D;
     bool train;
-    bool tile32 = false; // NNR_F_SPLIT3 training: the gradient planes are tile-major fp32 (tiled(), above); offsets and sizes are unchanged
-    NNR_HD bool tiled(int p) const { return kTileGradPlanes && tile32 && train && ((p >= P_DH1 && p < P_DH1 + 8) || p == P_DG); }
+    bool tile32 = false; // NNR_F_SPLIT3 training: the stash planes (activations and gradients) are tile-major fp32 (tiled(), above); offsets and sizes are unchanged
+    NNR_HD bool tiled(int p) const {
+        if (!(tile32 && train)) return false;
+        if ((p >= P_DH1 && p < P_DH1 + 8) || p == P_DG) return kTileGradPlanes;
+        if (p == P_XE || (p >= P_XH1 && p < P_XH1 + 8) || p == P_XF || p == P_XG) return kTileActPlanes;
+        return false;
+    }
     bool bf16 = false;   // NNR_F_BF16 training: the operands of the weight-gradient products -- hidden activations (P_XH1.., P_XG),
                          // the encodings' copies (P_XE16, P_XF16) and the pre-activation gradients (P_DH1.., P_DG) -- are tile-major
                          // bf16 planes (see above; pitch below = floats per sample = elements / 2); P_XE / P_XF hold the fp32

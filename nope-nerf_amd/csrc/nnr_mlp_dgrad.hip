@@ -26,14 +26,18 @@ __device__ __forceinline__ constexpr EncMeta enc_meta(int f, int n_real) {
 // Chain rule through gamma_L for the NR registers of one lane: returns d/d(x,y,z) of sum_r g[r] * gamma(.)_{f(r,half)}.
 // `pv[r]` = scale * partner value (cos for a sin feature, -sin for a cos feature, 1 for the identity block), prepared by
 // enc_partners.  The coordinate of register r is compile-time for half 0 and rotates by one for half 1 (f -> f+4, blocks of 3).
-template <int NR>
+// TILE: `enc` is this sample's place in a tile-major plane (nnr_layout.h: chunk base + 4 (s & 31)) and feature f sits at
+// (f >> 3) 256 + ((f >> 2) & 1) 128 + (f & 3) from there; otherwise the sample's row.
+template <int NR, bool TILE = false>
 __device__ __forceinline__ void enc_partners(float (&pv)[NR], const float* enc, int n_real, int half) {
+    auto at = [](int f) { return TILE ? (f >> 3) * 256 + ((f >> 2) & 1) * 128 + (f & 3) : f; };
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const EncMeta m0 = enc_meta(frag_feature(r, 0), n_real), m1 = enc_meta(frag_feature(r, 1), n_real);
-        const int partner = half ? m1.partner : m0.partner;
+        const int partner = half ? at(m1.partner >= 0 ? m1.partner : 0) : at(m0.partner >= 0 ? m0.partner : 0);
+        const bool has = half ? m1.partner >= 0 : m0.partner >= 0;
         const float sc = half ? m1.scale : m0.scale;
-        pv[r] = sc * (partner >= 0 ? enc[partner] : 1.f);
+        pv[r] = sc * (has ? enc[partner] : 1.f);
     }
 }
 template <int NR, class G>
@@ -58,6 +62,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     NNR_STAMP(tl_dgrad, 0);
     using L = Layout<D, MODE>;
     constexpr bool kTile = MODE == 2 && kTileGradPlanes;      // tile-major gradient planes (nnr_layout.h)
+    constexpr bool kTileXr = MODE == 2 && kTileActPlanes;    // the forward's encoding planes are tile-major too (read here for the chain rule)
     using Pipe = PanelPipeT<kWavesPerBlock, mode_panel_frags(MODE), kTile>;
     constexpr int kRingF4 = kNBuf * Pipe::F4;
     constexpr int DT = L::DT, HT = L::HT;
@@ -171,7 +176,11 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     gemm_part<HT, HT, false, NP, 2, 0>(accB, dg, pipe, p0(B_RGBH_FB), nullptr, NNR_SEL_PAIR(accA, 0, mwA));
     {
         float pvd[16];   // stored direction encoding (sin<->cos partners): the loads land under this short pass
-        enc_partners(pvd, a.ws_xf + (live ? s : 0) * kDirPad, kDirReal, half);
+        {
+            const int64_t sl = live ? s : 0;
+            if constexpr (kTileXr) enc_partners<16, true>(pvd, a.ws_xf + (sl >> 5) * (int64_t)((kDirPad / 8) * 256) + (sl & 31) * 4, kDirReal, half);
+            else enc_partners(pvd, a.ws_xf + sl * kDirPad, kDirReal, half);
+        }
         f32x16 accd[1];
         zero_acc(accd);
         gemm_part<HT, 1>(accd, dg, pipe, p0(B_RGBH_D));
@@ -230,7 +239,11 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     // hidden 1: d posenc = W1^T d1 + (skip-layer part parked in LDS), then the chain rule through gamma_10 -> d point
     {
         float pve[32];   // stored position encoding (sin<->cos partners): the loads land under the last pass
-        enc_partners(pve, a.ws_xe + (live ? s : 0) * kPosPad, kPosReal, half);
+        {
+            const int64_t sl = live ? s : 0;
+            if constexpr (kTileXr) enc_partners<32, true>(pve, a.ws_xe + (sl >> 5) * (int64_t)((kPosPad / 8) * 256) + (sl & 31) * 4, kPosReal, half);
+            else enc_partners(pve, a.ws_xe + sl * kPosPad, kPosReal, half);
+        }
         f32x16 acc2[2];
         zero_acc(acc2);
         gemm_part<DT, 2, true, NP, 2, 0>(acc2, d, pipe, p0(B_L1), dh(0), NNR_SEL_PAIR(accB, HR, mwB));

@@ -29,7 +29,8 @@ template <int D, bool TRAIN, int MODE>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     NNR_STAMP(tl_fwd, (TRAIN ? 0 : 16) + 0);
     using L = Layout<D, MODE>;
-    using Pipe = PanelPipeT<kWavesPerBlock, mode_panel_frags(MODE)>;
+    constexpr bool kTileX = MODE == 2 && TRAIN && kTileActPlanes;      // tile-major activation planes, non-temporal whole-block stores (nnr_layout.h)
+    using Pipe = PanelPipeT<kWavesPerBlock, mode_panel_frags(MODE), kTileX>;
     constexpr int kRingF4 = kNBuf * Pipe::F4;
     constexpr int DT = L::DT, HT = L::HT;
     const int lane0 = threadIdx.x & 63;
@@ -169,9 +170,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         _Pragma("unroll") for (int i = 0; i < 2; ++i) h[(OFF) + 2 * u + i] = ACC[(2 * u + i) >> 4][(2 * u + i) & 15]; \
     }
     auto p0 = [&](int part) { return L::fwd_panel0(part); };
-    float* const xe = TRAIN ? a.ws_xe + ss * kPosPad + 4 * half : nullptr;
+    // stash destinations.  Row-major: this lane's row + its half's four columns; tile-major (kTileX): block (chunk, octet 0) of the plane +
+    // 16 bytes per lane -- gemm_part adds 1 KiB per stash store
+    float* const xe = !TRAIN ? nullptr : kTileX ? a.ws_xe + chunk_id * (int64_t)((kPosPad / 8) * 256) + 4 * lane : a.ws_xe + ss * kPosPad + 4 * half;
     auto xh = [&](int hidden_idx /*0..7*/) -> float* {
-        return TRAIN ? a.ws_xh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half : nullptr;
+        if constexpr (!TRAIN) return nullptr;
+        else if constexpr (kTileX) return a.ws_xh + (int64_t)hidden_idx * a.S_pad * D + chunk_id * (int64_t)((D / 8) * 256) + 4 * lane;
+        else return a.ws_xh + ((int64_t)hidden_idx * a.S_pad + ss) * D + 4 * half;
     };
 
     // ---- hidden 1: 63 -> D, input = posenc.  Pass A, then pass B with A's epilogue hidden under it. ----
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // model/official_nerf.py:87-89) is folded into this one by the pack kernel, see nnr_layout.h.  One pass (D/2 outputs).
     // Its side work first finishes hidden 8 (half B), then evaluates the density head -- a per-lane dot product of h8 with
     // the density row (a 1-row GEMM is not MFMA work).
-    float* const xf = TRAIN ? a.ws_xf + ss * kDirPad + 4 * half : nullptr;
+    float* const xf = !TRAIN ? nullptr : kTileX ? a.ws_xf + chunk_id * (int64_t)((kDirPad / 8) * 256) + 4 * lane : a.ws_xf + ss * kDirPad + 4 * half;
     init_acc(accA, L::bias_off(10));
     clear_mask(mwB);
     float sg0 = 0.f, sg1 = 0.f;
@@ -281,10 +286,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     for (int u = 0; u < NP; ++u) NNR_RELU_PAIR_(accA, 0, mwA, true)(u);   // g = h[0, HR)
     store_mask(mwA, 8, 0);
     if (TRAIN) {
-        float* xg = a.ws_xg + ss * (D / 2) + 4 * half;
+        if constexpr (kTileX) {      // registers 4 q .. 4 q + 3 = features 8 q + 4 half + {0..3}: octet q of the plane, one whole block per store
+            typedef __attribute__((address_space(1))) f32x4 glb_f32x4;
+            glb_f32x4* const xg = (glb_f32x4*)(a.ws_xg + chunk_id * (int64_t)((D / 16) * 256) + 4 * lane);
 #pragma unroll
-        for (int q = 0; q < HR / 4; ++q)
-            *reinterpret_cast<f32x4*>(xg + 8 * q) = f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
+            for (int q = 0; q < HR / 4; ++q) __builtin_nontemporal_store(f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]}, xg + 64 * q);
+        } else {
+            float* xg = a.ws_xg + ss * (D / 2) + 4 * half;
+#pragma unroll
+            for (int q = 0; q < HR / 4; ++q)
+                *reinterpret_cast<f32x4*>(xg + 8 * q) = f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
+        }
     }
     // rgb head: 3 per-lane dot products over the lane's half of g, halves combined by one shuffle, then sigmoid
     float rgbv[3];

@@ -173,10 +173,11 @@ constexpr int kStageF4 = 2 * 16 * 64;      // f32x4 per wave: 2 buffers x (8 gra
 // image in which lane (h, m)'s two samples of pair P sit 16 slots apart (one ds_read2st64_b32) and the 16 lanes a read services together hit
 // 16 different bank groups, exactly as in the row-major image.  Which samples a lane supplies to the MFMAs is unchanged.  All 128 columns
 // of a 4 x 4 tile's gradient operand are valid in every unit (wgrad_units), so this path has no clamped lanes.
-template <int BIAS, int NI, bool DTILE>      // BIAS: WgradJob::bias (compile-time: the d(bias) sums are one add per sample pair in the tiles that carry them)
+template <int BIAS, int NI, bool DTILE, bool XTILE>      // BIAS: WgradJob::bias (compile-time: the d(bias) sums are one add per sample pair in the tiles that carry them)
 __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradArgs& a, int lane, int ji, f32x4* stage) {
     constexpr int MI = 4;
     static_assert(NI == 4 || NI == 2, "activation sub-tiles per job");
+    static_assert(!XTILE || NI == 4, "the tile-major activation image is laid out for whole 128-column tiles");
     constexpr int G = 6 * NI;                  // MFMAs (= gaps) per block
     static_assert(G >= 16, "block 3 issues the 16 DMA rows of the step after next, one per gap");
     const int half = lane >> 5, m = lane & 31;
@@ -184,10 +185,11 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     const bool dok = MI * m < jb.d_valid, xok = NI * m < jb.x_valid;
     // (wave-uniform row base in scalar registers) + (32-bit lane offset): no vector address arithmetic per DMA
     const char* const dg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane] + (DTILE ? (jb.d_col0 >> 3) * 256 : jb.d_col0));
-    const char* const xg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane] + jb.x_col0);
-    const int dlane = DTILE ? ((lane & 15) >> 1) * 1024 + (lane & 1) * 512 + (lane >> 4) * 16 : 4 * ((dok ? MI * m : 0) + 8 * half * dp);
-    const int64_t d_chunk_bytes = 128 * (int64_t)dp;       // tile-major: bytes per 32-sample chunk of the plane
-    const int xlane = NI == 4 ? 4 * ((xok ? NI * m : 0) + 8 * half * xp) : 4 * (4 * (m & 15) + 8 * half * xp);
+    const char* const xg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane] + (XTILE ? (jb.x_col0 >> 3) * 256 : jb.x_col0));
+    const int tlane = ((lane & 15) >> 1) * 1024 + (lane & 1) * 512 + (lane >> 4) * 16;      // tile-major: this lane's 16 bytes of a DMA instruction
+    const int dlane = DTILE ? tlane : 4 * ((dok ? MI * m : 0) + 8 * half * dp);
+    const int64_t d_chunk_bytes = 128 * (int64_t)dp, x_chunk_bytes = 128 * (int64_t)xp;       // tile-major: bytes per 32-sample chunk of the plane
+    const int xlane = XTILE ? tlane : NI == 4 ? 4 * ((xok ? NI * m : 0) + 8 * half * xp) : 4 * (4 * (m & 15) + 8 * half * xp);
     // d(bias): which of a pair's two samples this tile sums (WgradJob::bias: 1 all, 2 / 3: the two tiles of a row block share the samples
     // -- here by the parity of s)
 
@@ -205,7 +207,9 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     // tile-major gradient image: sample 8 h + 2 P (+ 1) of quad m at float 4 (256 h + 64 (m >> 4) + (m & 15)) + 512 (P >> 1) + 128 (P & 1) (+ 64)
     const float* const lrowd = DTILE ? reinterpret_cast<const float*>(stage) + 4 * (256 * half + 64 * (m >> 4) + (m & 15)) : lrow;
     // the activation operand's columns of this lane in a staged row: its own slot (NI = 4), or half of the slot of lane m / 2 (NI = 2)
-    const float* const lrowx = NI == 4 ? lrow : reinterpret_cast<const float*>(stage) + 4 * (32 * half + (m >> 1)) + 2 * (m & 1);
+    // (tile-major: the same image as the gradient's, behind the eight gradient rows)
+    const float* const lrowx = XTILE ? reinterpret_cast<const float*>(stage) + 4 * (256 * half + 64 * (m >> 4) + (m & 15)) + 2048
+                             : NI == 4 ? lrow : reinterpret_cast<const float*>(stage) + 4 * (32 * half + (m >> 1)) + 2 * (m & 1);
 
 // row S (0..7) of operand G (pitch P floats) of the step at sample KK -> staged row ROW of this wave
 #define NNR_WDMA(G, LANE, P, KK, S, DST, ROW) \
@@ -215,7 +219,7 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
 #ifdef NNR_ABLATE_WGRAD_NO_FETCH      /* profiling builds only (results NOT valid) */
 #define NNR_WFETCH(W, P, LR, ROW0, C) (fp[W][P] = f32x2{1.f + (float)(P), 2.f + (float)(C)})
 #else
-#define NNR_WOFF(ROW0, P, C, SECOND) (((ROW0) == 0 && DTILE) ? 512 * ((P) >> 1) + 128 * ((P) & 1) + (C) + 64 * (SECOND) : 256 * ((ROW0) + 2 * (P) + (SECOND)) + (C))
+#define NNR_WOFF(ROW0, P, C, SECOND) (((ROW0) == 0 ? DTILE : XTILE) ? 512 * ((P) >> 1) + 128 * ((P) & 1) + (C) + 64 * (SECOND) : 256 * ((ROW0) + 2 * (P) + (SECOND)) + (C))
 #define NNR_WFETCH(W, P, LR, ROW0, C) (fp[W][P] = f32x2{(LR)[NNR_WOFF(ROW0, P, C, 0)], (LR)[NNR_WOFF(ROW0, P, C, 1)]})
 #endif
 // the gradient operand's DMA instruction S (0..7) of the step at sample KK: a staged row of the row-major plane, or 64-byte runs of the tile-major one
@@ -225,6 +229,13 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(dg + ((KK) >> 5) * d_chunk_bytes + ((KK) & 31) * 16 + ((S) & 1) * 8192 + ((S) >> 1) * 64 + dlane), \
                                              (lds_ptr_t)((DST) + (ROW) * 64), 16, 0, 0);                                                 \
         else NNR_WDMA(dg, dlane, dp, KK, S, DST, ROW);                                                                                    \
+    } while (0)
+#define NNR_WDMA_X(KK, S, DST, ROW)                                                                                                      \
+    do {                                                                                                                                 \
+        if constexpr (XTILE)                                                                                                             \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(xg + ((KK) >> 5) * x_chunk_bytes + ((KK) & 31) * 16 + ((S) & 1) * 8192 + ((S) >> 1) * 64 + xlane), \
+                                             (lds_ptr_t)((DST) + (ROW) * 64), 16, 0, 0);                                                 \
+        else NNR_WDMA(xg, xlane, xp, KK, S, DST, ROW);                                                                                    \
     } while (0)
 // the split of pair P of component C of the rows [ROW0, ROW0 + 8), stage ST: 0 fetch, 1 h, 2 m, 3 l; W = residual set, BI >= 0: d(bias) slot
 #define NNR_WSPLIT(LR, ROW0, C, P, ST, Q, W, BI, BWT)                                        \
@@ -251,7 +262,7 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         NNR_WDMA_D((int64_t)jb.k0, s, stage, s);
-        NNR_WDMA(xg, xlane, xp, jb.k0, s, stage, 8 + s);
+        NNR_WDMA_X((int64_t)jb.k0, s, stage, 8 + s);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {   // the SECOND step's rows into the other buffer (round 4: the fetch runs two steps ahead, see the loop)
@@ -259,7 +270,7 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             NNR_WDMA_D(k1st, s, stage + 1024, s);
-            NNR_WDMA(xg, xlane, xp, k1st, s, stage + 1024, 8 + s);
+            NNR_WDMA_X(k1st, s, stage + 1024, 8 + s);
         }
     }
 #pragma unroll
@@ -304,7 +315,7 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
                 {
                     const int q = i == 3 ? g : 16;                                // the 16 rows of step k + 32, one per gap from the start of block 3
                     if (q < 8) NNR_WDMA_D(kn, q, dst, q);
-                    else if (q < 16) NNR_WDMA(xg, xlane, xp, kn, q - 8, dst, q);
+                    else if (q < 16) NNR_WDMA_X(kn, q - 8, dst, q);
                 }
 #endif
 #pragma unroll
@@ -341,6 +352,7 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last step's prefetch writes LDS: let it finish before the next job reuses the area
 #undef NNR_WDMA
 #undef NNR_WDMA_D
+#undef NNR_WDMA_X
 #undef NNR_WOFF
 #undef NNR_WSPLIT
 #undef NNR_WFETCH
@@ -386,7 +398,7 @@ constexpr int kCoopRegionF4 = 4 * 3 * 64;                // f32x4 per exchange r
 constexpr int kCoopXchF4 = kWavesPerBlock * kCoopStageF4;   // the exchange buffers start behind the four staging areas
 constexpr int kCoopF4 = kCoopXchF4 + 2 * 4 * kCoopRegionF4; // 160 KiB
 
-template <bool DTILE>
+template <bool DTILE, bool XTILE>
 __device__ __forceinline__ void wgrad_group_split(const WgradJob& jb, const WgradArgs& a, int lane, int ji, f32x4* lds_all, int wave) {
     constexpr int MI = 4, NI = 4;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -396,10 +408,11 @@ __device__ __forceinline__ void wgrad_group_split(const WgradJob& jb, const Wgra
     f32x4* const stage = lds_all + wave * kCoopStageF4;
     // ---- DMA sources (all 128 columns of either half are valid in these units: wgrad_units) ----
     const char* const dg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane] + (DTILE ? (jb.d_col0 >> 3) * 256 : jb.d_col0));
-    const char* const xg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane] + jb.x_col0);
-    const int dlane = DTILE ? ((lane & 15) >> 1) * 1024 + (lane & 1) * 512 + (lane >> 4) * 16 : 4 * (MI * m + 8 * half * dp);
-    const int xlane = 4 * (NI * m + 8 * half * xp);
-    const int64_t d_chunk_bytes = 128 * (int64_t)dp;
+    const char* const xg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane] + (XTILE ? (jb.x_col0 >> 3) * 256 : jb.x_col0));
+    const int tlane = ((lane & 15) >> 1) * 1024 + (lane & 1) * 512 + (lane >> 4) * 16;
+    const int dlane = DTILE ? tlane : 4 * (MI * m + 8 * half * dp);
+    const int xlane = XTILE ? tlane : 4 * (NI * m + 8 * half * xp);
+    const int64_t d_chunk_bytes = 128 * (int64_t)dp, x_chunk_bytes = 128 * (int64_t)xp;
     // gradient row r (0..3) of the step at sample KK -> staged row r; tile-major: the four DMA instructions that hold the samples 4 tb + 0..3 and
     // 8 + 4 tb + 0..3 of the step (instruction 2 (tb + 2 (r >> 1)) + (r & 1) of wgrad_job_split's eight); row-major: samples KK + 8 h + 4 tb + r
     auto dma_d = [&](int64_t KK, int r, f32x4* dst) __attribute__((always_inline)) {
@@ -410,14 +423,18 @@ __device__ __forceinline__ void wgrad_group_split(const WgradJob& jb, const Wgra
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(dg + (KK + 4 * tb + r) * (int64_t)dp * 4 + dlane), (lds_ptr_t)(dst + r * 64), 16, 0, 0);
     };
     auto dma_x = [&](int64_t KK, int r, f32x4* dst) __attribute__((always_inline)) {      // samples KK + 8 h + 4 ta + r -> staged row 4 + r
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(xg + (KK + 4 * ta + r) * (int64_t)xp * 4 + xlane), (lds_ptr_t)(dst + (4 + r) * 64), 16, 0, 0);
+        if constexpr (XTILE)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(xg + (KK >> 5) * x_chunk_bytes + (KK & 31) * 16 + (r & 1) * 8192 + (ta + 2 * (r >> 1)) * 64 + xlane),
+                                             (lds_ptr_t)(dst + (4 + r) * 64), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(xg + (KK + 4 * ta + r) * (int64_t)xp * 4 + xlane), (lds_ptr_t)(dst + (4 + r) * 64), 16, 0, 0);
     };
     // ---- staged values of this lane: pair pl (0, 1) of the wave's four samples per half, component C ----
     const float* const sf = reinterpret_cast<const float*>(stage);
     const float* const lrd = DTILE ? sf + 4 * (128 * half + 64 * (m >> 4) + (m & 15)) : sf + 4 * lane;
-    const float* const lrx = sf + 4 * lane;
+    const float* const lrx = XTILE ? sf + 4 * (128 * half + 64 * (m >> 4) + (m & 15)) + 1024 : sf + 4 * lane;
     auto off_d = [](int pl, int C, int second) { return DTILE ? 128 * pl + C + 64 * second : 256 * (2 * pl + second) + C; };
-    auto off_x = [](int pl, int C, int second) { return 256 * (4 + 2 * pl + second) + C; };
+    auto off_x = [](int pl, int C, int second) { return XTILE ? 128 * pl + C + 64 * second : 256 * (4 + 2 * pl + second) + C; };
     // ---- exchange addresses (bytes from lds_all) ----
     char* const xch = reinterpret_cast<char*>(lds_all + kCoopXchF4);
     constexpr int kBufBytes = 4 * kCoopRegionF4 * 16, kRegBytes = kCoopRegionF4 * 16;
@@ -598,16 +615,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
             // (the 128 x 64 tiles against the position encoding -- wgrad_job_split<.., 2> -- were measured on this path too: their VALU work
             // per MFMA is 1.6 times the 4 x 4 tile's and the kernel got SLOWER, 1.15 -> 1.29 ms at the best plan weight; they stay on fp32 MFMAs)
             if (__builtin_amdgcn_readfirstlane(jb.reserved) == 1) {      // a class-A workgroup: the layer's four tiles share the split (all four waves are here)
-                wgrad_group_split<kTileGradPlanes>(jb, a, lane, ji, stage_all, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
+                wgrad_group_split<kTileGradPlanes, kTileActPlanes>(jb, a, lane, ji, stage_all, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
                 continue;
             }
             if (__builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI) == 4 * 8 + 4) {
                 f32x4* const stage = stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kStageF4;
                 // (every gradient plane of the three-term mode is tile-major: WsLayout::tiled -- the row-major instantiation is not built)
                 switch (__builtin_amdgcn_readfirstlane(jb.bias)) {
-                    case 2: wgrad_job_split<2, 4, kTileGradPlanes>(jb, a, lane, ji, stage); break;
-                    case 3: wgrad_job_split<3, 4, kTileGradPlanes>(jb, a, lane, ji, stage); break;
-                    default: wgrad_job_split<1, 4, kTileGradPlanes>(jb, a, lane, ji, stage); break;     // 1, and 0 (sums dropped)
+                    case 2: wgrad_job_split<2, 4, kTileGradPlanes, kTileActPlanes>(jb, a, lane, ji, stage); break;
+                    case 3: wgrad_job_split<3, 4, kTileGradPlanes, kTileActPlanes>(jb, a, lane, ji, stage); break;
+                    default: wgrad_job_split<1, 4, kTileGradPlanes, kTileActPlanes>(jb, a, lane, ji, stage); break;     // 1, and 0 (sums dropped)
                 }
                 continue;
             }

@@ -327,7 +327,7 @@ def _tile32_index(s, f, W):
 
 
 def test_tile_major_fp32_planes_layout_query_and_decode():
-    """The gradient planes of a three-term TRAINING workspace are tile-major fp32 (ABI 4: nnr_ws_plane_layout == 2), every other plane and
+    """The stash planes (activations and gradients) of a three-term TRAINING workspace are tile-major fp32 (ABI 4: nnr_ws_plane_layout == 2), every other plane and
     every other mode row-major (0) or the bf16 tiles (1); ops.workspace_plane's decode is the inverse of tile32_index."""
     import torch
     from nnr import lib as L
@@ -349,7 +349,10 @@ def test_tile_major_fp32_planes_layout_query_and_decode():
         assert lib.nnr_ws_plane_layout(C.byref(mfma), p) == 0
         assert lib.nnr_ws_plane_layout(C.byref(bf16), p) == 1
         assert lib.nnr_ws_plane_layout(C.byref(infer), p) == -1
-    for p in (0, 1, 2, 3, 4, 10, 11, 18, 19, 20, 25):
+    for p in [10] + list(range(11, 19)) + [19, 20]:      # the activation planes: position encoding, h1..h8, direction encoding, colour hidden
+        assert lib.nnr_ws_plane_layout(C.byref(train), p) == 2, p
+        assert lib.nnr_ws_plane_layout(C.byref(mfma), p) == 0, p
+    for p in (0, 1, 2, 3, 4, 25):
         assert lib.nnr_ws_plane_layout(C.byref(train), p) == 0, p
     assert lib.nnr_ws_plane_layout(C.byref(train), 99) == -1
     # decode: fill a fake workspace so that element (s, f) of plane 33 holds 1000 s + f at tile32_index
