@@ -164,7 +164,9 @@ Plan build_plan(const nnr_cfg* c) {
     // per MFMA-equivalent a 4 x 4 tile costs `split_w` / 1000 of what it costs in fp32 (measured: NNR_WGRAD_SPLIT_WEIGHT sweeps).
     static const int split_w = [] {
         const char* e = std::getenv("NNR_WGRAD_SPLIT_WEIGHT");
-        return e ? std::max(50, std::atoi(e)) : 480;      // (round 4, shared split: 1.18 / 1.16 / 1.14 / 1.11 / 1.12 ms at 360 / 400 / 440 / 480 / 520)
+        return e ? std::max(50, std::atoi(e)) : 440;      // (round 4, shared split, row-major activations: 1.18 / 1.16 / 1.14 / 1.11 / 1.12 ms at 360 /
+                                                         // 400 / 440 / 480 / 520; both operands tile-major: 1.12 / 1.11 / 1.10 / 1.11 at 380 / 420 / 440 / 460, 1.14 at 480 on
+                                                         // another box where 440 gave 1.11 -- profiles/r04/r*_wgrad_weight_sweep_tile_x.txt)
     }();
     const bool split = is_split3(c) && std::getenv("NNR_WGRAD_FP32") == nullptr;
     auto weight = [split](const WgradJob& j) -> int64_t {
