@@ -25,12 +25,34 @@ using SplitPipe = SplitPipeT<false>;
 // (the conversion as the compiler's own v_cvt_pk_bf16_f32, round to nearest even: written as inline asm -- pack_bf16 -- hipcc puts an
 // s_nop behind every use, and the two subtractions of a pair as one packed instruction)
 __device__ __forceinline__ uint32_t pack_pair(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
+// What a pair leaves behind its packed rounding, r - float(bf16(r)): shift, mask, one packed subtract.
+// Tried at the end of round 4 (NNR_SPLIT_DOT2 builds): one v_dot2c_f32_bf16 per value (D += A.x B.x + A.y B.y with B = {-1, 0} resp. {0, -1}
+// from scalar registers) -- 7 instructions per split pair instead of 9, bit-identical for every finite input, denormals included, and the
+// same issue rate in isolation (tools/micro/dot2_residual.hip; profiles/r04/s_dot2_residual.txt).  Inside these kernels it is SLOWER
+// (forward 0.817 -> 0.862 ms in inference, input gradient 0.890 -> 0.912, weight gradient 1.126 -> 1.171; profiles/r04/t_*): the dot
+// unit does not overlap with the matrix pipe the way the plain VALU does; and the D = 128 layer-local test failed with it.  Not used.
+// (Beware of the selectors as compile-time constants: hipcc folds {-1, 0} into the inline constant -1.0, which the instruction reads as
+// the 32-bit pattern 0xbf800000 = {0, -1}.)
+#ifdef NNR_SPLIT_DOT2
+__device__ __forceinline__ f32x2 pair_residual(f32x2 r, uint32_t packed) {
+    uint32_t lo, hi;
+    asm("s_mov_b32 %0, 0xbf80" : "=s"(lo));
+    asm("s_mov_b32 %0, 0xbf800000" : "=s"(hi));
+    const bf16x2 p = __builtin_bit_cast(bf16x2, packed);
+    return f32x2{__builtin_amdgcn_fdot2_f32_bf16(p, __builtin_bit_cast(bf16x2, lo), r[0], false),
+                 __builtin_amdgcn_fdot2_f32_bf16(p, __builtin_bit_cast(bf16x2, hi), r[1], false)};
+}
+#else
+__device__ __forceinline__ f32x2 pair_residual(f32x2 r, uint32_t packed) {
+    return r - f32x2{__uint_as_float(packed << 16), __uint_as_float(packed & 0xffff0000u)};
+}
+#endif
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
     f32x2 r = {x0, x1};
     h = pack_pair(r);
-    r = r - f32x2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    r = pair_residual(r, h);
     m = pack_pair(r);
-    r = r - f32x2{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    r = pair_residual(r, m);
     l = pack_pair(r);
 }
 
@@ -263,13 +285,13 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                     if (!last) {
                         rr[k] = f32x2{in[8 * (g + 1) + 2 * k], in[8 * (g + 1) + 2 * k + 1]};
                         xn[2][k] = pack_pair(rr[k]);
-                        rr[k] = rr[k] - f32x2{__uint_as_float(xn[2][k] << 16), __uint_as_float(xn[2][k] & 0xffff0000u)};
+                        rr[k] = pair_residual(rr[k], xn[2][k]);
                         if (gates) pipe.gw[(8 * (g + 1) + 2 * k) >> 5] |= gate_pair(xn[2][k]) << ((8 * (g + 1) + 2 * k) & 31);
                     }
                 } else if (kind == 1) {     // stage B: m, and what it leaves
                     if (!last) {
                         xn[1][k] = pack_pair(rr[k]);
-                        rr[k] = rr[k] - f32x2{__uint_as_float(xn[1][k] << 16), __uint_as_float(xn[1][k] & 0xffff0000u)};
+                        rr[k] = pair_residual(rr[k], xn[1][k]);
                     }
                 } else if (kind == 2) {     // stage C: l
                     if (!last) xn[0][k] = pack_pair(rr[k]);

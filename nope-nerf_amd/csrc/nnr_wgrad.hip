@@ -246,10 +246,10 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
             if ((BI) >= 0 && BIAS != 0)                                                      \
                 bsum[(BI) >= 0 ? (BI) : 0] += (BWT) * (BIAS == 1 ? fp[W][P][0] + fp[W][P][1] : (BIAS == 2 ? fp[W][P][0] : fp[W][P][1])); \
             Q[2][P] = NNR_WPACK(fp[W][P]);                                   \
-            fp[W][P] = fp[W][P] - f32x2{__uint_as_float(Q[2][P] << 16), __uint_as_float(Q[2][P] & 0xffff0000u)}; \
+            fp[W][P] = pair_residual(fp[W][P], Q[2][P]);                                      \
         } else if ((ST) == 2) {                                                              \
             Q[1][P] = NNR_WPACK(fp[W][P]);                                   \
-            fp[W][P] = fp[W][P] - f32x2{__uint_as_float(Q[1][P] << 16), __uint_as_float(Q[1][P] & 0xffff0000u)}; \
+            fp[W][P] = pair_residual(fp[W][P], Q[1][P]);                                      \
         } else {                                                                             \
             Q[0][P] = NNR_WPACK(fp[W][P]);                                   \
         }                                                                                    \
@@ -456,7 +456,6 @@ __device__ __forceinline__ void wgrad_group_split(const WgradJob& jb, const Wgra
     f32x2 rr[4];
 
     auto pack = [](f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); };
-    auto unp = [](uint32_t h) { return f32x2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)}; };
     // pair q (0..15) = operand q >> 3 (0 gradient, 1 activation), component (q >> 1) & 3, local pair q & 1; stage 0 fetch, 1 h (+ d(bias)), 2 m, 3 l
     auto split_op = [&](int q, int st, const float* bd, const float* bx, float nf) __attribute__((always_inline)) {
         const int op = q >> 3, C = (q >> 1) & 3, pl = q & 1, s = q & 3;
@@ -465,10 +464,10 @@ __device__ __forceinline__ void wgrad_group_split(const WgradJob& jb, const Wgra
         } else if (st == 1) {
             if (op == 0) bsum[C] += nf * (rr[s][0] + rr[s][1]);
             T[s][2] = pack(rr[s]);
-            rr[s] = rr[s] - unp(T[s][2]);
+            rr[s] = pair_residual(rr[s], T[s][2]);
         } else if (st == 2) {
             T[s][1] = pack(rr[s]);
-            rr[s] = rr[s] - unp(T[s][1]);
+            rr[s] = pair_residual(rr[s], T[s][1]);
         } else {
             T[s][0] = pack(rr[s]);
         }
