@@ -425,3 +425,41 @@ def test_narrow_wgrad_jobs_address_tile_major_planes():
                 addr = base + (s >> 5) * 32 * W + (s & 31) * 4
                 for e in range(MI):
                     assert addr + e == _tile32_index(s, c + e, W), (MI, col0, m, s, e)
+
+
+def test_shared_split_stages_its_quarter_of_both_tile_major_operands():
+    """wgrad_group_split<DTILE, XTILE> (nnr_wgrad.hip), emulated for wave (ta, tb) of a class-A workgroup: of a 16-sample step it stages the
+    samples 8 h + 4 tb + {0..3} of gradient half ta (staged rows 0..3) and the samples 8 h + 4 ta + {0..3} of activation half tb (rows 4..7),
+    each as four DMA instructions r (source: quad 16 (r & 1) + (i & 15), sample 4 (t + 2 (r >> 1)) + (i >> 4) with t = tb resp. ta), and
+    lane (h, m) reads local pair pl, component C at float 4 (128 h + 64 (m >> 4) + (m & 15)) + 128 pl + C (+ 64; + 1024 for the activation
+    rows).  Both operands use the same mapping with the roles of ta and tb exchanged; the planes have different widths (the merged layer)."""
+    for Wd, Wx, dcol0, xcol0, k in ((256, 256, 0, 128, 32), (256, 256, 128, 0, 1008), (128, 256, 0, 128, 48)):
+        S = 1024 + 32
+        planes = {}
+        for name, W in (("d", Wd), ("x", Wx)):
+            pl = np.full(S * W, -1.0)
+            s_idx, f_idx = np.meshgrid(np.arange(S), np.arange(W), indexing="ij")
+            pl[np.vectorize(_tile32_index)(s_idx, f_idx, W)] = 1000.0 * s_idx + f_idx
+            planes[name] = pl
+        ta, tb = dcol0 >> 7, xcol0 >> 7
+        lds = np.full(8 * 64 * 4, np.nan)
+        for name, W, col0, t, row0 in (("d", Wd, dcol0, tb, 0), ("x", Wx, xcol0, ta, 4)):
+            base = (col0 >> 3) * 256
+            for r in range(4):
+                for i in range(64):
+                    tlane = ((i & 15) >> 1) * 256 + (i & 1) * 128 + (i >> 4) * 4          # floats (the kernel: bytes)
+                    src = base + (k >> 5) * 32 * W + (k & 31) * 4 + (r & 1) * 2048 + (t + 2 * (r >> 1)) * 16 + tlane
+                    assert 0 <= src and src + 4 <= S * W
+                    slot = 64 * (row0 + r) + i
+                    lds[4 * slot:4 * slot + 4] = planes[name][src:src + 4]
+        assert not np.isnan(lds).any()
+        for lane in range(64):
+            h, m = lane >> 5, lane & 31
+            lane_base = 4 * (128 * h + 64 * (m >> 4) + (m & 15))
+            for name, col0, t, extra in (("d", dcol0, tb, 0), ("x", xcol0, ta, 1024)):
+                for pl in range(2):
+                    for Cc in range(4):
+                        for second in range(2):
+                            v = lds[lane_base + extra + 128 * pl + Cc + 64 * second]
+                            want = 1000.0 * (k + 8 * h + 4 * t + 2 * pl + second) + col0 + 4 * m + Cc
+                            assert v == want, (name, lane, pl, Cc, second, v, want)
