@@ -24,4 +24,6 @@ class Learn_Distortion(nn.Module):
             return torch.ones_like(shift), shift                      # the gauge: the last view's depth scale is 1
         raw = self.global_scales[cam_id]
         # value AND gradient of the reference's `if scale < 0.01: scale = tensor(0.01)` without its device->host sync
+        # (below the floor the parameter receives a ZERO gradient and Adam keeps moving it by momentum -- what the reference does under the torch it
+        # pins, 1.7, whose zero_grad() zero-fills; under torch >= 2.0 its gradient would be None and Adam would skip the tensor for that step)
         return torch.where(raw < _SCALE_FLOOR, torch.full_like(raw, _SCALE_FLOOR), raw), shift
