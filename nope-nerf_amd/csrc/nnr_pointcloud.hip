@@ -27,10 +27,17 @@ constexpr int kPcTile = 1024;   // destination points staged in LDS at a time (1
 // cost.  PER = 2 with 2048 workgroups: 316 us against 343 for PER = 4 / 1024 (rounds 1-3).
 // keys[s] = min over this block's destination range of (sqrt(d2) bits << 32 | index): distances are >= 0, so their bit
 // patterns order like the values, and equal distances order by index (= first occurrence).
-template <int kPcPer>
+// SCALAR (end of round 4, an experiment: NNR_PC_SCALAR=1): the destination points through the SCALAR cache instead of an LDS tile -- every lane of
+// a wave needs the same point at the same time, and as an LDS broadcast that is still 64 lanes x 16 bytes over the LDS return path.  With
+// wave-uniform global addresses hipcc emits s_load_dwordx8 / x4 (12 floats = four points per trip, the next trip's loads issued before this
+// trip's arithmetic) and the coordinates enter the packed instructions as scalar operands; no LDS, no barriers.  Same indices -- and SLOWER:
+// 169 against 152 us at 20 736 points, 345 against 304 at 32 400 (profiles/r04/w_pc_nearest_scalar_vs_lds.txt): the LDS pipe is not what
+// bounds this kernel.  (What does, most likely: with ~50 destination ranges per source block a range is ~400 points, in which a lane still
+// improves its minimum ~6 times -- nearly every trip of a wave takes the bookkeeping branch for some lane.)
+template <int kPcPer, bool SCALAR>
 __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __restrict__ src, const float* __restrict__ dst, int S,
                                                               int D, int d_per_block, unsigned long long* __restrict__ keys) {
-    __shared__ f32x4 tile[kPcTile];
+    __shared__ f32x4 tile[SCALAR ? 1 : kPcTile];
     const int s0 = (blockIdx.x * kPcBlock + threadIdx.x) * kPcPer;
     constexpr int kPairs = kPcPer / 2;
     f32x2 x[kPairs], y[kPairs], z[kPairs];
@@ -51,45 +58,83 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __res
         best_s[u] = __builtin_inff();
         best_i[u] = 0x7fffffff;
     }
-    for (int t0 = d0; t0 < d1; t0 += kPcTile) {
-        const int n = min(kPcTile, d1 - t0);
-        __syncthreads();
-        const int n4 = (n + 3) & ~3;      // four destination points per trip: pad with points at infinity (their d2 is +inf: never a minimum)
-        for (int i = threadIdx.x; i < n4; i += kPcBlock) {
-            const float* p = dst + 3 * (int64_t)(t0 + (i < n ? i : 0));
-            tile[i] = i < n ? f32x4{p[0], p[1], p[2], 0.f} : f32x4{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f};
+    // four destination points (q: 12 floats) against this lane's sources; the four in index order, first index wins among equals
+    auto trip = [&](const float (&q)[12], int i0) __attribute__((always_inline)) {
+        f32x2 d2[4][kPairs];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int v = 0; v < kPairs; ++v) {
+                const f32x2 dx = x[v] - q[3 * k], dy = y[v] - q[3 * k + 1], dz = z[v] - q[3 * k + 2];
+                // torch.linalg.norm's sum of squares: fma(dz,dz, fma(dy,dy, dx*dx)), every step rounded to fp32
+                d2[k][v] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                any = any | (d2[k][v][0] < best_d2[v][0]) | (d2[k][v][1] < best_d2[v][1]);
+            }
         }
-        __syncthreads();
-        // Four points per trip, ONE branch for the four (round 4): the chain LDS read -> subtract -> multiply -> fma -> fma -> compare ->
-        // branch is what this kernel waits for (see above); four independent chains per source pair and a quarter of the branches.
-#pragma unroll 1
-        for (int i = 0; i < n4; i += 4) {
-            f32x2 d2[4][kPairs];
-            bool any = false;
+        // rare after the first few points: the sqrt and the bookkeeping stay out of the steady-state loop
+        if (any) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x4 q = tile[i + k];   // same address in every lane: an LDS broadcast
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int v = 0; v < kPairs; ++v) {
-                    const f32x2 dx = x[v] - q[0], dy = y[v] - q[1], dz = z[v] - q[2];
-                    // torch.linalg.norm's sum of squares: fma(dz,dz, fma(dy,dy, dx*dx)), every step rounded to fp32
-                    d2[k][v] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-                    any = any | (d2[k][v][0] < best_d2[v][0]) | (d2[k][v][1] < best_d2[v][1]);
+                for (int u = 0; u < kPcPer; ++u) {
+                    const float v = d2[k][u >> 1][u & 1];
+                    if (v < best_d2[u >> 1][u & 1]) {
+                        const float sq = __fsqrt_rn(v);
+                        if (sq < best_s[u]) { best_s[u] = sq; best_i[u] = i0 + k; }   // equal sqrt: the earlier index stays
+                        best_d2[u >> 1][u & 1] = v;
+                    }
+                }
+        }
+    };
+    if constexpr (SCALAR) {
+        const int n = d1 - d0;
+        const float* __restrict__ const p = dst + 3 * (int64_t)d0;
+        // points i .. i + 3 of the range; past its end the LAST point again (an equal distance never replaces the earlier index)
+        auto fetch = [&](int i, float (&q)[12]) __attribute__((always_inline)) {
+            if (i + 4 <= n) {
+#pragma unroll
+                for (int j = 0; j < 12; ++j) q[j] = p[3 * i + j];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ik = i + k < n ? i + k : n - 1;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) q[3 * k + c] = p[3 * ik + c];
                 }
             }
-            // rare after the first few points: the sqrt and the bookkeeping stay out of the steady-state loop; the four points in index order
-            if (any) {
+        };
+        if (n > 0) {
+            float q[12], qn[12];
+            fetch(0, q);
+#pragma unroll 1
+            for (int i = 0; i < n; i += 4) {
+                fetch(i + 4 < n ? i + 4 : i, qn);      // the next trip's points (the last trip: its own again)
+                trip(q, d0 + i);
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int j = 0; j < 12; ++j) q[j] = qn[j];
+            }
+        }
+    } else {
+        for (int t0 = d0; t0 < d1; t0 += kPcTile) {
+            const int n = min(kPcTile, d1 - t0);
+            __syncthreads();
+            const int n4 = (n + 3) & ~3;      // four destination points per trip: pad with points at infinity (their d2 is +inf: never a minimum)
+            for (int i = threadIdx.x; i < n4; i += kPcBlock) {
+                const float* p = dst + 3 * (int64_t)(t0 + (i < n ? i : 0));
+                tile[i] = i < n ? f32x4{p[0], p[1], p[2], 0.f} : f32x4{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f};
+            }
+            __syncthreads();
+            // Four points per trip, ONE branch for the four (round 4): four independent chains per source pair and a quarter of the branches.
+#pragma unroll 1
+            for (int i = 0; i < n4; i += 4) {
+                float q[12];
 #pragma unroll
-                    for (int u = 0; u < kPcPer; ++u) {
-                        const float v = d2[k][u >> 1][u & 1];
-                        if (v < best_d2[u >> 1][u & 1]) {
-                            const float sq = __fsqrt_rn(v);
-                            if (sq < best_s[u]) { best_s[u] = sq; best_i[u] = t0 + i + k; }   // equal sqrt: the earlier index stays
-                            best_d2[u >> 1][u & 1] = v;
-                        }
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 t = tile[i + k];   // same address in every lane: an LDS broadcast
+                    q[3 * k] = t[0]; q[3 * k + 1] = t[1]; q[3 * k + 2] = t[2];
+                }
+                trip(q, t0 + i);
             }
         }
     }
@@ -173,8 +218,14 @@ hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int
     split = split < 1 ? 1 : (split > max_split ? max_split : split);
     const int d_per_block = ((D + split - 1) / split + 255) / 256 * 256;
     const int by = (D + d_per_block - 1) / d_per_block;
-    if (per == 4) hipLaunchKernelGGL(pc_nearest_kernel<4>, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
-    else hipLaunchKernelGGL(pc_nearest_kernel<2>, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
+    static const bool lds = std::getenv("NNR_PC_SCALAR") == nullptr;   // (experiment: the destination points through the scalar cache, see the kernel)
+    if (lds) {
+        if (per == 4) hipLaunchKernelGGL((pc_nearest_kernel<4, false>), dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
+        else hipLaunchKernelGGL((pc_nearest_kernel<2, false>), dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
+    } else {
+        if (per == 4) hipLaunchKernelGGL((pc_nearest_kernel<4, true>), dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
+        else hipLaunchKernelGGL((pc_nearest_kernel<2, true>), dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
+    }
     return hipGetLastError();
 }
 
