@@ -144,6 +144,68 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __res
             atomicMin(keys + s0 + u, ((unsigned long long)__float_as_uint(best_s[u]) << 32) | (unsigned int)best_i[u]);
 }
 
+// ONE source per lane, the packed instructions over PAIRS OF DESTINATION points (end of round 4).  With two sources per lane and the destination
+// range cut ~50 ways for occupancy, a wave's 128 running minima improve somewhere in nearly every trip of a ~500-point range (a minimum over n
+// points improves ~ln n times, most of them early): the bookkeeping branch -- eight conditional blocks with a sqrt each -- was the steady state,
+// not the exception.  Here a wave carries 64 minima (half the chance per trip, half the blocks when it happens), the same number of waves needs
+// a quarter of the range cuts (four times longer ranges: the early phase is a smaller share), and the arithmetic per pair is unchanged: the
+// tile holds the points as pairs [x0 x1 y0 y1 z0 z1], three 16-byte LDS broadcasts deliver four points as packed operands.
+template <int GROUPS>      // groups of four destination points per trip (one branch per trip)
+__global__ __launch_bounds__(kPcBlock) void pc_nearest_one_kernel(const float* __restrict__ src, const float* __restrict__ dst, int S, int D,
+                                                                  int d_per_block, unsigned long long* __restrict__ keys) {
+    __shared__ f32x4 tile[3 * kPcTile / 4];      // 12 floats per four points
+    const int s = blockIdx.x * kPcBlock + threadIdx.x;
+    const int sc = s < S ? s : S - 1;
+    const float sx = src[3 * sc], sy = src[3 * sc + 1], sz = src[3 * sc + 2];
+    const f32x2 x{sx, sx}, y{sy, sy}, z{sz, sz};
+    const int d0 = blockIdx.y * d_per_block, d1 = min(D, d0 + d_per_block);
+    float best_d2 = __builtin_inff(), best_s = __builtin_inff();
+    int best_i = 0x7fffffff;
+    for (int t0 = d0; t0 < d1; t0 += kPcTile) {
+        const int n = min(kPcTile, d1 - t0);
+        __syncthreads();
+        constexpr int kTrip = 4 * GROUPS;
+        const int n4 = (n + kTrip - 1) / kTrip * kTrip;      // pad with points at infinity (their d2 is +inf: never a minimum)
+        float* const tf = reinterpret_cast<float*>(tile);
+        for (int i = threadIdx.x; i < n4; i += kPcBlock) {
+            const float* p = dst + 3 * (int64_t)(t0 + (i < n ? i : 0));
+            const float inf = __builtin_inff();
+            const int o = 6 * (i >> 1) + (i & 1);          // pair i / 2: [x0 x1 y0 y1 z0 z1]
+            tf[o] = i < n ? p[0] : inf;
+            tf[o + 2] = i < n ? p[1] : inf;
+            tf[o + 4] = i < n ? p[2] : inf;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < n4; i += kTrip) {
+            float d2[kTrip];
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) {
+                const int t = 3 * ((i >> 2) + g);
+                const f32x4 a = tile[t], b = tile[t + 1], c = tile[t + 2];   // x0 x1 y0 y1 | z0 z1 x2 x3 | y2 y3 z2 z3
+                const f32x2 dx0 = x - f32x2{a[0], a[1]}, dy0 = y - f32x2{a[2], a[3]}, dz0 = z - f32x2{b[0], b[1]};
+                const f32x2 dx1 = x - f32x2{b[2], b[3]}, dy1 = y - f32x2{c[0], c[1]}, dz1 = z - f32x2{c[2], c[3]};
+                // torch.linalg.norm's sum of squares: fma(dz,dz, fma(dy,dy, dx*dx)), every step rounded to fp32
+                const f32x2 e0 = __builtin_elementwise_fma(dz0, dz0, __builtin_elementwise_fma(dy0, dy0, dx0 * dx0));
+                const f32x2 e1 = __builtin_elementwise_fma(dz1, dz1, __builtin_elementwise_fma(dy1, dy1, dx1 * dx1));
+                d2[4 * g] = e0[0]; d2[4 * g + 1] = e0[1]; d2[4 * g + 2] = e1[0]; d2[4 * g + 3] = e1[1];
+                any = any | (e0[0] < best_d2) | (e0[1] < best_d2) | (e1[0] < best_d2) | (e1[1] < best_d2);
+            }
+            if (any) {
+#pragma unroll
+                for (int k = 0; k < kTrip; ++k)
+                    if (d2[k] < best_d2) {
+                        const float sq = __fsqrt_rn(d2[k]);
+                        if (sq < best_s) { best_s = sq; best_i = t0 + i + k; }   // equal sqrt: the earlier index stays
+                        best_d2 = d2[k];
+                    }
+            }
+        }
+    }
+    if (s < S && best_i != 0x7fffffff) atomicMin(keys + s, ((unsigned long long)__float_as_uint(best_s) << 32) | (unsigned int)best_i);
+}
+
 __global__ void pc_fill_keys_kernel(unsigned long long* keys, int S) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < S) keys[s] = ~0ull;
@@ -210,14 +272,23 @@ __global__ __launch_bounds__(256) void pc_error_bwd_kernel(const float* __restri
 hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int D, unsigned long long* keys, hipStream_t st) {
     // PER sources per lane and the number of workgroups to aim for (the destination range is split until there are about that many;
     // at least 256 destination points per workgroup): knobs for experiments, defaults from the round-4 sweep (profiles/r04/)
-    static const int per = [] { const char* e = std::getenv("NNR_PC_PER"); const int v = e ? std::atoi(e) : 2; return v == 4 ? 4 : 2; }();
-    static const int wgs = [] { const char* e = std::getenv("NNR_PC_WGS"); const int v = e ? std::atoi(e) : 2048; return v < 1 ? 1 : v; }();
-    const int bx = (S + kPcBlock * per - 1) / (kPcBlock * per);
+    // (end of round 4: ONE source per lane, eight points per trip, ~4096 workgroups: 117 / 233 us at 20 736 / 32 400 points against 145 / 297 for
+    // two sources per lane and 2048 workgroups -- profiles/r04/x2_pc_nearest_one_per_lane.txt)
+    static const int per = [] { const char* e = std::getenv("NNR_PC_PER"); const int v = e ? std::atoi(e) : 1; return v == 4 ? 4 : (v == 2 ? 2 : 1); }();
+    static const int wgs = [] { const char* e = std::getenv("NNR_PC_WGS"); const int v = e ? std::atoi(e) : (per == 1 ? 4096 : 2048); return v < 1 ? 1 : v; }();
+    const int bx = (S + kPcBlock * per - 1) / (kPcBlock * per);      // (per = 1: pc_nearest_one_kernel)
     int split = (wgs + bx - 1) / bx;
     const int max_split = (D + 255) / 256;
     split = split < 1 ? 1 : (split > max_split ? max_split : split);
     const int d_per_block = ((D + split - 1) / split + 255) / 256 * 256;
     const int by = (D + d_per_block - 1) / d_per_block;
+    if (per == 1) {
+        static const int groups = [] { const char* e = std::getenv("NNR_PC_GROUPS"); return e ? std::atoi(e) : 2; }();
+        if (groups == 2) hipLaunchKernelGGL(pc_nearest_one_kernel<2>, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
+        else if (groups == 4) hipLaunchKernelGGL(pc_nearest_one_kernel<4>, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
+        else hipLaunchKernelGGL(pc_nearest_one_kernel<1>, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
+        return hipGetLastError();
+    }
     static const bool lds = std::getenv("NNR_PC_SCALAR") == nullptr;   // (experiment: the destination points through the scalar cache, see the kernel)
     if (lds) {
         if (per == 4) hipLaunchKernelGGL((pc_nearest_kernel<4, false>), dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);

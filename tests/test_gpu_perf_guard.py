@@ -36,13 +36,21 @@ def test_mlp_kernels_stay_within_one_and_a_half_times_their_measured_durations(s
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     prev = L.set_fp32_products("mfma" if mode == "mfma" else "split3")
+    # A guard against REGRESSIONS must not fail on a noisy box: isolated launches of the kernels that write gigabytes scatter (a bf16 training
+    # forward was once timed at 1.19 ms on a box whose other three kernels were at their usual 0.52-0.89: profiles/r04/y_pc_tests.txt), so a
+    # kernel above its bound is measured again -- up to three rounds, the minimum per kernel counts; a real regression fails all of them.
+    got = {}
     try:
         net = mdl.OfficialStaticNerf(bench.full_cfg(R, bf16=bf16, n_samples=N)).to(dev)
-        out = bench.kernel_roofline(net, dev, reps=6, bf16=bf16, rays=R, n_samples=N)
+        for attempt in range(3):
+            out = bench.kernel_roofline(net, dev, reps=6, bf16=bf16, rays=R, n_samples=N)
+            for k in BOUNDS[shape]:
+                got[k] = min(got.get(k, float("inf")), round(out["kernels"][k]["ms"], 3))
+            print("perf guard", shape, "attempt", attempt, {k: round(out["kernels"][k]["ms"], 3) for k in BOUNDS[shape]})
+            if all(got[k] <= b for k, b in BOUNDS[shape].items()):
+                break
     finally:
         L.set_fp32_products(prev)
-    got = {k: round(out["kernels"][k]["ms"], 3) for k in BOUNDS[shape]}
-    print("perf guard", shape, got)
     for k, bound in BOUNDS[shape].items():
         assert got[k] <= bound, (shape, k, got[k], bound)
 
