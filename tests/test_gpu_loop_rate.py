@@ -26,7 +26,9 @@ def test_unmodified_train_script_runs_at_the_rate_of_the_step(mode, tmp_path):
     aux = not mode.endswith("noaux")
     ref = loop_rate.bench_rate(rays, samples, aux, steps=30, warmup=8)
     for attempt in range(2):      # a shared host can stall a 30-epoch run of a script once; a loop that IS slower stays slower
-        res = loop_rate.run_mode(mode, os.path.join(work, "scenes"), "loop", rays, samples, 30, work)
+        run_dir = os.path.join(work, "run%d" % attempt)      # (a fresh out_dir: train.py resumes from a checkpoint it finds)
+        os.makedirs(run_dir, exist_ok=True)
+        res = loop_rate.run_mode(mode, os.path.join(work, "scenes"), "loop", rays, samples, 30, run_dir)
         frac = res["rays_per_s"] / ref["rays_per_s"]
         print("train.py (%s, %s loader): %.0f rays/s = %.2f of the bench rate %.0f rays/s (%.3f vs %.3f ms per iteration)"
               % (mode, res["loader"], res["rays_per_s"], frac, ref["rays_per_s"], res["ms_per_iteration"], ref["ms_per_step"]))
