@@ -113,6 +113,9 @@ __device__ __forceinline__ void wait_class(f32x4 (&f)[MT], int n) {
 // the stash stores, the DMA burst, the side units -- listed in an order that interleaves the kinds, and a compile-time pass assigns each to
 // the first gap whose instruction budget it still fits in (the fragment refills are fixed: one ds_read in each gap after a term-0 / 2 /
 // 5 MFMA, a counted wait in front of the first MFMA of each fragment class).
+#ifndef NNR_SPLIT_STASH_COST      // instructions a stash store counts for in the balance of the gaps (experiments: 1 -- a tile-major store is one instruction)
+#define NNR_SPLIT_STASH_COST 2
+#endif
 struct RowOp { int kind, idx, cost; };      // kind 0: split stage A of pair idx, 1: stage B, 2: stage C, 3: stash store idx, 4: DMA, 5: side unit idx
 template <int NOPS, int NM>
 struct RowSched { RowOp op[NOPS]; int gap[NOPS]; };
@@ -127,13 +130,13 @@ constexpr auto make_row_sched() {
     int ny = 0;
     for (int u = 0; u < NUNITS; ++u) {
         y[ny++] = RowOp{5, u, UCOST};
-        if (STASH && (u == NUNITS / 4 || u == (3 * NUNITS) / 4)) y[ny] = RowOp{3, u == NUNITS / 4 ? 0 : 1, 2}, ++ny;
+        if (STASH && (u == NUNITS / 4 || u == (3 * NUNITS) / 4)) y[ny] = RowOp{3, u == NUNITS / 4 ? 0 : 1, NNR_SPLIT_STASH_COST}, ++ny;
         if (u == NUNITS / 2) y[ny++] = RowOp{4, 0, 4};
     }
     if (NUNITS == 0) {
-        if (STASH) y[ny++] = RowOp{3, 0, 2};
+        if (STASH) y[ny++] = RowOp{3, 0, NNR_SPLIT_STASH_COST};
         y[ny++] = RowOp{4, 0, 4};
-        if (STASH) y[ny++] = RowOp{3, 1, 2};
+        if (STASH) y[ny++] = RowOp{3, 1, NNR_SPLIT_STASH_COST};
     }
     int n = 0, ix = 0, iy = 0;
     while (ix < 12 || iy < ny) {      // merge by fractional position
