@@ -150,29 +150,37 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __res
 // not the exception.  Here a wave carries 64 minima (half the chance per trip, half the blocks when it happens), the same number of waves needs
 // a quarter of the range cuts (four times longer ranges: the early phase is a smaller share), and the arithmetic per pair is unchanged: the
 // tile holds the points as pairs [x0 x1 y0 y1 z0 z1], three 16-byte LDS broadcasts deliver four points as packed operands.
-template <int GROUPS>      // groups of four destination points per trip (one branch per trip)
+template <int GROUPS, int SRC>      // groups of four destination points per trip (one branch per trip); sources per lane (s, s + 256, ..: each with its own minimum)
 __global__ __launch_bounds__(kPcBlock) void pc_nearest_one_kernel(const float* __restrict__ src, const float* __restrict__ dst, int S, int D,
                                                                   int d_per_block, unsigned long long* keys, int seed) {
     __shared__ f32x4 tile[3 * kPcTile / 4];      // 12 floats per four points
-    const int s = blockIdx.x * kPcBlock + threadIdx.x;
-    const int sc = s < S ? s : S - 1;
-    const float sx = src[3 * sc], sy = src[3 * sc + 1], sz = src[3 * sc + 2];
-    const f32x2 x{sx, sx}, y{sy, sy}, z{sz, sz};
+    int s[SRC], sc[SRC];
+    float sx[SRC], sy[SRC], sz[SRC];
+    f32x2 x[SRC], y[SRC], z[SRC];
+#pragma unroll
+    for (int u = 0; u < SRC; ++u) {
+        s[u] = (blockIdx.x * SRC + u) * kPcBlock + threadIdx.x;
+        sc[u] = s[u] < S ? s[u] : S - 1;
+        sx[u] = src[3 * sc[u]]; sy[u] = src[3 * sc[u] + 1]; sz[u] = src[3 * sc[u] + 2];
+        x[u] = f32x2{sx[u], sx[u]}; y[u] = f32x2{sy[u], sy[u]}; z[u] = f32x2{sz[u], sz[u]};
+    }
     const int d0 = blockIdx.y * d_per_block, d1 = min(D, d0 + d_per_block);
     // The running minimum as the key it will be merged with: (sqrt bits, index), lexicographic -- candidates may arrive in ANY order (seeds
     // from other ranges, below), the smaller index wins among equal rounded distances as in the reference.  The steady-state test is one
     // compare of d2 against `thr`, an upper bound of every d2 whose rounded square root is <= best_s (s^2 (1 + 4 ulp): sqrt_rn(v) <= s implies
     // v <= s^2 (1 + 2^-23) up to the rounding of s^2 itself); what passes is decided exactly.
-    float best_s = __builtin_inff(), thr = __builtin_inff();
-    int best_i = 0x7fffffff;
-    auto consider = [&](float v, int idx) __attribute__((always_inline)) {
-        if (v <= thr && v < __builtin_inff()) {      // (padding points and infinite distances never match)
+    float best_s[SRC], thr[SRC];
+    int best_i[SRC];
+#pragma unroll
+    for (int u = 0; u < SRC; ++u) { best_s[u] = __builtin_inff(); thr[u] = __builtin_inff(); best_i[u] = 0x7fffffff; }
+    auto consider = [&](int u, float v, int idx) __attribute__((always_inline)) {
+        if (v <= thr[u] && v < __builtin_inff()) {      // (padding points and infinite distances never match)
             const float sq = __fsqrt_rn(v);
-            if (sq < best_s || (sq == best_s && idx < best_i)) {
-                best_s = sq;
-                best_i = idx;
+            if (sq < best_s[u] || (sq == best_s[u] && idx < best_i[u])) {
+                best_s[u] = sq;
+                best_i[u] = idx;
                 const float t = sq * sq;
-                thr = __builtin_fmaf(t, 4.8e-7f, t);
+                thr[u] = __builtin_fmaf(t, 4.8e-7f, t);
             }
         }
     };
@@ -182,25 +190,31 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_one_kernel(const float* _
     // exists: the eight destination points around the source's own index, wherever they lie (the two clouds of the trainer are depth maps of
     // neighbouring frames on the same pixel grid: the point at the same pixel is a good first guess).  The result is the same minimum over a
     // superset of the range's candidates: indices bit-identical (tests/test_pointcloud.py).
-    unsigned long long k0 = ~0ull;
-    if (seed) {
-        k0 = s < S ? __atomic_load_n(keys + s, __ATOMIC_RELAXED) : ~0ull;
-        if (k0 != ~0ull) {
-            best_s = __uint_as_float((unsigned int)(k0 >> 32));
-            best_i = (int)(unsigned int)(k0 & 0xffffffffu);
-            const float t = best_s * best_s;
-            thr = __builtin_fmaf(t, 4.8e-7f, t);
-        } else if (seed > 1) {
+    unsigned long long k0[SRC];
+    float seed_s[SRC];
+    int seed_i[SRC];
 #pragma unroll
-            for (int j = -4; j < 4; ++j) {
-                const int q = min(max(sc + j, 0), D - 1);
-                const float ex = sx - dst[3 * q], ey = sy - dst[3 * q + 1], ez = sz - dst[3 * q + 2];
-                consider(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)), q);
+    for (int u = 0; u < SRC; ++u) {
+        k0[u] = ~0ull;
+        if (seed) {
+            k0[u] = s[u] < S ? __atomic_load_n(keys + s[u], __ATOMIC_RELAXED) : ~0ull;
+            if (k0[u] != ~0ull) {
+                best_s[u] = __uint_as_float((unsigned int)(k0[u] >> 32));
+                best_i[u] = (int)(unsigned int)(k0[u] & 0xffffffffu);
+                const float t = best_s[u] * best_s[u];
+                thr[u] = __builtin_fmaf(t, 4.8e-7f, t);
+            } else if (seed > 1) {
+#pragma unroll
+                for (int j = -4; j < 4; ++j) {
+                    const int q = min(max(sc[u] + j, 0), D - 1);
+                    const float ex = sx[u] - dst[3 * q], ey = sy[u] - dst[3 * q + 1], ez = sz[u] - dst[3 * q + 2];
+                    consider(u, __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)), q);
+                }
             }
         }
+        seed_s[u] = best_s[u];
+        seed_i[u] = best_i[u];
     }
-    const float seed_s = best_s;
-    const int seed_i = best_i;
     for (int t0 = d0; t0 < d1; t0 += kPcTile) {
         const int n = min(kPcTile, d1 - t0);
         __syncthreads();
@@ -218,28 +232,35 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_one_kernel(const float* _
         __syncthreads();
 #pragma unroll 1
         for (int i = 0; i < n4; i += kTrip) {
-            float d2[kTrip];
+            float d2[SRC][kTrip];
             bool any = false;
 #pragma unroll
             for (int g = 0; g < GROUPS; ++g) {
                 const int t = 3 * ((i >> 2) + g);
                 const f32x4 a = tile[t], b = tile[t + 1], c = tile[t + 2];   // x0 x1 y0 y1 | z0 z1 x2 x3 | y2 y3 z2 z3
-                const f32x2 dx0 = x - f32x2{a[0], a[1]}, dy0 = y - f32x2{a[2], a[3]}, dz0 = z - f32x2{b[0], b[1]};
-                const f32x2 dx1 = x - f32x2{b[2], b[3]}, dy1 = y - f32x2{c[0], c[1]}, dz1 = z - f32x2{c[2], c[3]};
-                // torch.linalg.norm's sum of squares: fma(dz,dz, fma(dy,dy, dx*dx)), every step rounded to fp32
-                const f32x2 e0 = __builtin_elementwise_fma(dz0, dz0, __builtin_elementwise_fma(dy0, dy0, dx0 * dx0));
-                const f32x2 e1 = __builtin_elementwise_fma(dz1, dz1, __builtin_elementwise_fma(dy1, dy1, dx1 * dx1));
-                d2[4 * g] = e0[0]; d2[4 * g + 1] = e0[1]; d2[4 * g + 2] = e1[0]; d2[4 * g + 3] = e1[1];
-                any = any | (e0[0] <= thr) | (e0[1] <= thr) | (e1[0] <= thr) | (e1[1] <= thr);
+#pragma unroll
+                for (int u = 0; u < SRC; ++u) {
+                    const f32x2 dx0 = x[u] - f32x2{a[0], a[1]}, dy0 = y[u] - f32x2{a[2], a[3]}, dz0 = z[u] - f32x2{b[0], b[1]};
+                    const f32x2 dx1 = x[u] - f32x2{b[2], b[3]}, dy1 = y[u] - f32x2{c[0], c[1]}, dz1 = z[u] - f32x2{c[2], c[3]};
+                    // torch.linalg.norm's sum of squares: fma(dz,dz, fma(dy,dy, dx*dx)), every step rounded to fp32
+                    const f32x2 e0 = __builtin_elementwise_fma(dz0, dz0, __builtin_elementwise_fma(dy0, dy0, dx0 * dx0));
+                    const f32x2 e1 = __builtin_elementwise_fma(dz1, dz1, __builtin_elementwise_fma(dy1, dy1, dx1 * dx1));
+                    d2[u][4 * g] = e0[0]; d2[u][4 * g + 1] = e0[1]; d2[u][4 * g + 2] = e1[0]; d2[u][4 * g + 3] = e1[1];
+                    any = any | (e0[0] <= thr[u]) | (e0[1] <= thr[u]) | (e1[0] <= thr[u]) | (e1[1] <= thr[u]);
+                }
             }
             if (any) {
 #pragma unroll
-                for (int k = 0; k < kTrip; ++k) consider(d2[k], t0 + i + k);
+                for (int u = 0; u < SRC; ++u)
+#pragma unroll
+                    for (int k = 0; k < kTrip; ++k) consider(u, d2[u][k], t0 + i + k);
             }
         }
     }
-    if (s < S && best_i != 0x7fffffff && (best_s != seed_s || best_i != seed_i || k0 == ~0ull))
-        atomicMin(keys + s, ((unsigned long long)__float_as_uint(best_s) << 32) | (unsigned int)best_i);
+#pragma unroll
+    for (int u = 0; u < SRC; ++u)
+        if (s[u] < S && best_i[u] != 0x7fffffff && (best_s[u] != seed_s[u] || best_i[u] != seed_i[u] || k0[u] == ~0ull))
+            atomicMin(keys + s[u], ((unsigned long long)__float_as_uint(best_s[u]) << 32) | (unsigned int)best_i[u]);
 }
 
 __global__ void pc_fill_keys_kernel(unsigned long long* keys, int S) {
@@ -305,13 +326,15 @@ __global__ __launch_bounds__(256) void pc_error_bwd_kernel(const float* __restri
 }
 
 // keys must hold ~0 (or earlier candidates): the search only lowers them
+static inline int max_split_of(int D) { return (D + 255) / 256; }
 hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int D, unsigned long long* keys, hipStream_t st) {
     // PER sources per lane and the number of workgroups to aim for (the destination range is split until there are about that many;
     // at least 256 destination points per workgroup): knobs for experiments, defaults from the round-4 sweep (profiles/r04/)
-    // (end of round 4: ONE source per lane, eight points per trip, ~4096 workgroups: 117 / 233 us at 20 736 / 32 400 points against 145 / 297 for
-    // two sources per lane and 2048 workgroups -- profiles/r04/x2_pc_nearest_one_per_lane.txt)
+    // (end of round 4: ONE source per lane, eight points per trip: 117 / 233 us at 20 736 / 32 400 points against 145 / 297 for two sources per
+    // lane and 2048 workgroups -- profiles/r04/x2_pc_nearest_one_per_lane.txt; with seeded ranges 88 / 189 us at 8192 workgroups, i.e. ranges of 256
+    // points, y3_pc_nearest_src.txt; two sources per lane of the seeded kernel, NNR_PC_SRC=2: 104 / 198)
     static const int per = [] { const char* e = std::getenv("NNR_PC_PER"); const int v = e ? std::atoi(e) : 1; return v == 4 ? 4 : (v == 2 ? 2 : 1); }();
-    static const int wgs = [] { const char* e = std::getenv("NNR_PC_WGS"); const int v = e ? std::atoi(e) : (per == 1 ? 4096 : 2048); return v < 1 ? 1 : v; }();
+    static const int wgs = [] { const char* e = std::getenv("NNR_PC_WGS"); const int v = e ? std::atoi(e) : (per == 1 ? 8192 : 2048); return v < 1 ? 1 : v; }();
     const int bx = (S + kPcBlock * per - 1) / (kPcBlock * per);      // (per = 1: pc_nearest_one_kernel)
     int split = (wgs + bx - 1) / bx;
     const int max_split = (D + 255) / 256;
@@ -319,12 +342,19 @@ hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int
     const int d_per_block = ((D + split - 1) / split + 255) / 256 * 256;
     const int by = (D + d_per_block - 1) / d_per_block;
     if (per == 1) {
-        static const int groups = [] { const char* e = std::getenv("NNR_PC_GROUPS"); return e ? std::atoi(e) : 2; }();
         // NNR_PC_SEED: 0 = every range starts from +infinity, 1 = from the key already there, 2 (default) = + the points around the own index
         static const int seed = [] { const char* e = std::getenv("NNR_PC_SEED"); return e ? std::atoi(e) : 2; }();
-        if (groups == 2) hipLaunchKernelGGL(pc_nearest_one_kernel<2>, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys, seed);
-        else if (groups == 4) hipLaunchKernelGGL(pc_nearest_one_kernel<4>, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys, seed);
-        else hipLaunchKernelGGL(pc_nearest_one_kernel<1>, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys, seed);
+        static const int groups = [] { const char* e = std::getenv("NNR_PC_GROUPS"); return e ? std::atoi(e) : 2; }();
+        static const int nsrc = [] { const char* e = std::getenv("NNR_PC_SRC"); return e && std::atoi(e) == 2 ? 2 : 1; }();      // sources per lane
+        const int bxs = (S + kPcBlock * nsrc - 1) / (kPcBlock * nsrc);
+        int sp = (wgs + bxs - 1) / bxs;
+        sp = sp < 1 ? 1 : (sp > max_split_of(D) ? max_split_of(D) : sp);
+        const int dpb = ((D + sp - 1) / sp + 255) / 256 * 256;
+        const dim3 grid(bxs, (D + dpb - 1) / dpb);
+#define NNR_PC_ONE(G_, S_) hipLaunchKernelGGL((pc_nearest_one_kernel<G_, S_>), grid, dim3(kPcBlock), 0, st, src, dst, S, D, dpb, keys, seed)
+        if (nsrc == 2) { if (groups == 1) NNR_PC_ONE(1, 2); else if (groups == 4) NNR_PC_ONE(4, 2); else NNR_PC_ONE(2, 2); }
+        else { if (groups == 1) NNR_PC_ONE(1, 1); else if (groups == 4) NNR_PC_ONE(4, 1); else NNR_PC_ONE(2, 1); }
+#undef NNR_PC_ONE
         return hipGetLastError();
     }
     static const bool lds = std::getenv("NNR_PC_SCALAR") == nullptr;   // (experiment: the destination points through the scalar cache, see the kernel)
