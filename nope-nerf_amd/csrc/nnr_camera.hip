@@ -294,36 +294,50 @@ __global__ void depth_gather_fwd_kernel(const float* img, const int64_t* ray_idx
 }
 // Several rays share a depth pixel whenever the mono-depth map is coarser than the image (the DPT default), and float atomics would
 // make that pixel's sum depend on arrival order.  Instead ONE ray owns each hit pixel -- the lowest-numbered ray that maps to it -- and
-// adds the gradients of all rays of that pixel in ray order: every ray compares its target with every other ray's (LDS tiles of 256;
+// adds the gradients of all rays of that pixel in a fixed order (four interleaved quarter-walks, see the kernel): every ray compares its target with every other ray's (LDS tiles of 256;
 // R^2 integer compares, 1 M at 1024 rays), no atomics, bit-reproducible.  g_img must hold zeros (or whatever is to be accumulated into).
 __global__ __launch_bounds__(256) void depth_gather_bwd_kernel(const float* g, const int64_t* ray_idx, float* g_img, int R, int h, int w,
                                                                int hd, int wd) {
-    __shared__ int tgt[256];
-    __shared__ float gv[256];
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) int tgt[256];
+    __shared__ __attribute__((aligned(16))) float gv[256];
     auto target = [&](int k) {
         const int64_t q = ray_idx[k];
         const int y = (int)(q / w), x = (int)(q - (int64_t)y * w);
         return nearest_src(y, h, hd) * wd + nearest_src(x, w, wd);
     };
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // 64 rays per workgroup, FOUR lanes per ray (end of round 4): lane `part` of a ray's quad walks entries [64 part, 64 part + 64) of every tile
+    // of 256 rays, four entries per LDS read; the four partial sums are added in the fixed order ((p0 + p1) + (p2 + p3)).  With one lane per
+    // ray and one entry per read this 4-workgroup kernel was 67 us of dependent LDS latency, the longest small launch of the first phase.
+    const int part = threadIdx.x & 3;
+    const int i = blockIdx.x * 64 + (threadIdx.x >> 2);
     const int ti = i < R ? target(i) : -1;
     bool owner = i < R;
     float sum = 0.f;
     for (int base = 0; base < R; base += 256) {
         const int j = base + threadIdx.x;
         __syncthreads();
-        tgt[threadIdx.x] = j < R ? target(j) : -2;
+        tgt[threadIdx.x] = j < R ? target(j) : -2;      // (entries past R: a target no ray has)
         gv[threadIdx.x] = j < R ? g[j] : 0.f;
         __syncthreads();
-        const int n = R - base < 256 ? R - base : 256;
-        for (int k = 0; k < n; ++k) {
-            if (tgt[k] == ti) {
-                sum += gv[k];
-                if (base + k < i) owner = false;
-            }
+#pragma unroll 4
+        for (int k = 64 * part; k < 64 * part + 64; k += 4) {
+            const i32x4 t4 = *reinterpret_cast<const i32x4*>(tgt + k);
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gv + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (t4[e] == ti) {
+                    sum += g4[e];
+                    if (base + k + e < i) owner = false;
+                }
         }
     }
-    if (owner) g_img[ti] += sum;     // the only writer of this pixel
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    int own = owner ? 1 : 0;
+    own &= __shfl_xor(own, 1);
+    own &= __shfl_xor(own, 2);
+    if (own && part == 0) g_img[ti] += sum;     // the only writer of this pixel
 }
 
 // The same gather with the per-image affine depth distortion applied to the R gathered values instead of the whole map
@@ -673,7 +687,7 @@ hipError_t launch_depth_gather_fwd(const float* img, const int64_t* idx, float* 
 hipError_t launch_depth_gather_bwd(const float* g, const int64_t* idx, float* g_img, int R, int h, int w, int hd, int wd, hipStream_t st) {
     hipError_t e = hipMemsetAsync(g_img, 0, (size_t)hd * wd * sizeof(float), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(depth_gather_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, st, g, idx, g_img, R, h, w, hd, wd);
+    hipLaunchKernelGGL(depth_gather_bwd_kernel, dim3((R + 63) / 64), dim3(256), 0, st, g, idx, g_img, R, h, w, hd, wd);
     return hipGetLastError();
 }
 // ---- NDC rays for forward-facing scenes (model/common.py:632-675, called from Renderer.sample_ndc, rendering.py:168-180) ----
