@@ -27,17 +27,15 @@ constexpr int kPcTile = 1024;   // destination points staged in LDS at a time (1
 // cost.  PER = 2 with 2048 workgroups: 316 us against 343 for PER = 4 / 1024 (rounds 1-3).
 // keys[s] = min over this block's destination range of (sqrt(d2) bits << 32 | index): distances are >= 0, so their bit
 // patterns order like the values, and equal distances order by index (= first occurrence).
-// SCALAR (end of round 4, an experiment: NNR_PC_SCALAR=1): the destination points through the SCALAR cache instead of an LDS tile -- every lane of
-// a wave needs the same point at the same time, and as an LDS broadcast that is still 64 lanes x 16 bytes over the LDS return path.  With
-// wave-uniform global addresses hipcc emits s_load_dwordx8 / x4 (12 floats = four points per trip, the next trip's loads issued before this
-// trip's arithmetic) and the coordinates enter the packed instructions as scalar operands; no LDS, no barriers.  Same indices -- and SLOWER:
-// 169 against 152 us at 20 736 points, 345 against 304 at 32 400 (profiles/r04/w_pc_nearest_scalar_vs_lds.txt): the LDS pipe is not what
-// bounds this kernel.  (What does, most likely: with ~50 destination ranges per source block a range is ~400 points, in which a lane still
-// improves its minimum ~6 times -- nearly every trip of a wave takes the bookkeeping branch for some lane.)
-template <int kPcPer, bool SCALAR>
+// (Measured at the end of round 4 and removed again: the destination points through the SCALAR cache instead of the LDS tile -- wave-uniform
+// global addresses, s_load_dwordx8 / x4 for four points per trip, the coordinates as scalar operands of the packed instructions, no LDS and no
+// barrier: the same indices, 12 % SLOWER (profiles/r04/w_pc_nearest_scalar_vs_lds.txt; commit 122ab07).  The LDS pipe is not what bounds the
+// search; the bookkeeping branch was, see pc_nearest_one_kernel.)
+// This kernel -- two sources per lane -- is the search of rounds 1-4, kept behind NNR_PC_PER=2 as the A/B baseline of the product kernel below.
+template <int kPcPer>
 __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __restrict__ src, const float* __restrict__ dst, int S,
                                                               int D, int d_per_block, unsigned long long* __restrict__ keys) {
-    __shared__ f32x4 tile[SCALAR ? 1 : kPcTile];
+    __shared__ f32x4 tile[kPcTile];
     const int s0 = (blockIdx.x * kPcBlock + threadIdx.x) * kPcPer;
     constexpr int kPairs = kPcPer / 2;
     f32x2 x[kPairs], y[kPairs], z[kPairs];
@@ -87,35 +85,7 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __res
                 }
         }
     };
-    if constexpr (SCALAR) {
-        const int n = d1 - d0;
-        const float* __restrict__ const p = dst + 3 * (int64_t)d0;
-        // points i .. i + 3 of the range; past its end the LAST point again (an equal distance never replaces the earlier index)
-        auto fetch = [&](int i, float (&q)[12]) __attribute__((always_inline)) {
-            if (i + 4 <= n) {
-#pragma unroll
-                for (int j = 0; j < 12; ++j) q[j] = p[3 * i + j];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int ik = i + k < n ? i + k : n - 1;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) q[3 * k + c] = p[3 * ik + c];
-                }
-            }
-        };
-        if (n > 0) {
-            float q[12], qn[12];
-            fetch(0, q);
-#pragma unroll 1
-            for (int i = 0; i < n; i += 4) {
-                fetch(i + 4 < n ? i + 4 : i, qn);      // the next trip's points (the last trip: its own again)
-                trip(q, d0 + i);
-#pragma unroll
-                for (int j = 0; j < 12; ++j) q[j] = qn[j];
-            }
-        }
-    } else {
+    {
         for (int t0 = d0; t0 < d1; t0 += kPcTile) {
             const int n = min(kPcTile, d1 - t0);
             __syncthreads();
@@ -326,45 +296,24 @@ __global__ __launch_bounds__(256) void pc_error_bwd_kernel(const float* __restri
 }
 
 // keys must hold ~0 (or earlier candidates): the search only lowers them
-static inline int max_split_of(int D) { return (D + 255) / 256; }
 hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int D, unsigned long long* keys, hipStream_t st) {
-    // PER sources per lane and the number of workgroups to aim for (the destination range is split until there are about that many;
-    // at least 256 destination points per workgroup): knobs for experiments, defaults from the round-4 sweep (profiles/r04/)
-    // (end of round 4: ONE source per lane, eight points per trip: 117 / 233 us at 20 736 / 32 400 points against 145 / 297 for two sources per
-    // lane and 2048 workgroups -- profiles/r04/x2_pc_nearest_one_per_lane.txt; with seeded ranges 88 / 189 us at 8192 workgroups, i.e. ranges of 256
-    // points, y3_pc_nearest_src.txt; two sources per lane of the seeded kernel, NNR_PC_SRC=2: 104 / 198)
-    static const int per = [] { const char* e = std::getenv("NNR_PC_PER"); const int v = e ? std::atoi(e) : 1; return v == 4 ? 4 : (v == 2 ? 2 : 1); }();
+    // The product search: pc_nearest_one_kernel, one source per lane, eight points per trip, seeded ranges, the destination range cut until
+    // there are ~8192 workgroups (>= 256 points per range).  End of round 4, at 20 736 / 32 400 points: 88 / 189 us against 145 / 297 for
+    // the search of rounds 1-4 (two sources per lane, 2048 workgroups: NNR_PC_PER=2).  Sweeps: profiles/r04/x2_*, y2_*, y3_* (workgroups 256 ..
+    // 16 384; 4 / 8 / 16 points per trip; two sources per lane of the seeded kernel: 104 / 198 us).
+    // NNR_PC_WGS: workgroups to aim for; NNR_PC_SEED: 0 = every range starts from +infinity, 1 = from the key already there, 2 (default) = and,
+    // before a key exists, from the points around the source's own index.
+    static const int per = [] { const char* e = std::getenv("NNR_PC_PER"); return e && std::atoi(e) == 2 ? 2 : 1; }();
     static const int wgs = [] { const char* e = std::getenv("NNR_PC_WGS"); const int v = e ? std::atoi(e) : (per == 1 ? 8192 : 2048); return v < 1 ? 1 : v; }();
-    const int bx = (S + kPcBlock * per - 1) / (kPcBlock * per);      // (per = 1: pc_nearest_one_kernel)
+    static const int seed = [] { const char* e = std::getenv("NNR_PC_SEED"); return e ? std::atoi(e) : 2; }();
+    const int bx = (S + kPcBlock * per - 1) / (kPcBlock * per);
     int split = (wgs + bx - 1) / bx;
     const int max_split = (D + 255) / 256;
     split = split < 1 ? 1 : (split > max_split ? max_split : split);
     const int d_per_block = ((D + split - 1) / split + 255) / 256 * 256;
     const int by = (D + d_per_block - 1) / d_per_block;
-    if (per == 1) {
-        // NNR_PC_SEED: 0 = every range starts from +infinity, 1 = from the key already there, 2 (default) = + the points around the own index
-        static const int seed = [] { const char* e = std::getenv("NNR_PC_SEED"); return e ? std::atoi(e) : 2; }();
-        static const int groups = [] { const char* e = std::getenv("NNR_PC_GROUPS"); return e ? std::atoi(e) : 2; }();
-        static const int nsrc = [] { const char* e = std::getenv("NNR_PC_SRC"); return e && std::atoi(e) == 2 ? 2 : 1; }();      // sources per lane
-        const int bxs = (S + kPcBlock * nsrc - 1) / (kPcBlock * nsrc);
-        int sp = (wgs + bxs - 1) / bxs;
-        sp = sp < 1 ? 1 : (sp > max_split_of(D) ? max_split_of(D) : sp);
-        const int dpb = ((D + sp - 1) / sp + 255) / 256 * 256;
-        const dim3 grid(bxs, (D + dpb - 1) / dpb);
-#define NNR_PC_ONE(G_, S_) hipLaunchKernelGGL((pc_nearest_one_kernel<G_, S_>), grid, dim3(kPcBlock), 0, st, src, dst, S, D, dpb, keys, seed)
-        if (nsrc == 2) { if (groups == 1) NNR_PC_ONE(1, 2); else if (groups == 4) NNR_PC_ONE(4, 2); else NNR_PC_ONE(2, 2); }
-        else { if (groups == 1) NNR_PC_ONE(1, 1); else if (groups == 4) NNR_PC_ONE(4, 1); else NNR_PC_ONE(2, 1); }
-#undef NNR_PC_ONE
-        return hipGetLastError();
-    }
-    static const bool lds = std::getenv("NNR_PC_SCALAR") == nullptr;   // (experiment: the destination points through the scalar cache, see the kernel)
-    if (lds) {
-        if (per == 4) hipLaunchKernelGGL((pc_nearest_kernel<4, false>), dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
-        else hipLaunchKernelGGL((pc_nearest_kernel<2, false>), dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
-    } else {
-        if (per == 4) hipLaunchKernelGGL((pc_nearest_kernel<4, true>), dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
-        else hipLaunchKernelGGL((pc_nearest_kernel<2, true>), dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
-    }
+    if (per == 1) hipLaunchKernelGGL((pc_nearest_one_kernel<2, 1>), dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys, seed);
+    else hipLaunchKernelGGL(pc_nearest_kernel<2>, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
     return hipGetLastError();
 }
 
