@@ -488,6 +488,21 @@ __device__ __forceinline__ void wgrad_group_split(const WgradJob& jb, const Wgra
     // 4 x m, 4 x l, then the six writes of the two components
     auto coop_op = [&](int n, const float* bd, const float* bx, float nf, int eb) __attribute__((always_inline)) {
         const int B = n / 22, o = n % 22;
+#ifdef NNR_ABLATE_WGRAD_COOP      /* profiling builds only (results NOT valid): what the kernel would cost if its operands arrived as terms --
+                                     1: fetches and exchange writes stay, the split arithmetic is replaced by three moves per pair; 2: neither */
+        if (o < 16) {
+            const int q = 4 * B + (o & 3), st = o >> 2, sq = q & 3;
+            if (st == 0) {
+                if (NNR_ABLATE_WGRAD_COOP == 1) split_op(q, 0, bd, bx, nf);
+                else rr[sq] = f32x2{1.f + (float)q, 2.f};
+            } else {
+                T[sq][3 - st] = __float_as_uint(rr[sq][st & 1]) + st;
+            }
+        } else if (NNR_ABLATE_WGRAD_COOP == 1) {
+            write_op(B >> 1, 2 * (B & 1) + (o - 16) / 3, (o - 16) % 3, eb);
+        }
+        return;
+#endif
         if (o < 16) split_op(4 * B + (o & 3), o >> 2, bd, bx, nf);
         else write_op(B >> 1, 2 * (B & 1) + (o - 16) / 3, (o - 16) % 3, eb);
     };
