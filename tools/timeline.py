@@ -67,6 +67,13 @@ if __name__ == "__main__":
             bytype[key].append(dur[wv] / max(cost, 1))
         for k, x in sorted(bytype.items()):
             print("class B/A wave types", k, "n", len(x), "cycles per cost-granule min/mean/max %.1f %.1f %.1f" % (min(x), sum(x) / len(x), max(x)))
+        # the slowest and the fastest workgroups: which jobs their four waves ran, and how long each wave took
+        for b in list(order[-8:]) + list(order[:4]):
+            desc = []
+            for wv in range(4 * b, 4 * b + 4):
+                js = jobs[first[wv]:first[wv + 1]]
+                desc.append("%d:" % dur[wv] + "+".join("(%d,%d,b%d,L%d,%d)" % (j.MI, j.NI, j.bias, j.layer, (j.k1 - j.k0) // 16) for j in js))
+            print("block", int(b), int(per_blk[b]), " | ".join(desc))
     if hasattr(handle, "nnr_timeline_fwd16_all") and bf16:
         import numpy as np
         buf = (ctypes.c_ulonglong * (3 * 4096))()
