@@ -19,7 +19,7 @@ SOURCES = [("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1", "NNR_FWD_MOD
            ("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1")), ("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=0")),
            ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=256",)), ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=1")),
            ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=0")), ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=128",)),
-           ("nnr_mlp_fwd_bf16.hip", ()), ("nnr_mlp_dgrad_bf16.hip", ()), ("nnr_mlp_fwd.hip", ()), ("nnr_mlp_dgrad.hip", ()),
+           ("nnr_mlp_fwd_bf16.hip", ()), ("nnr_mlp_dgrad_bf16.hip", ()), ("nnr_mlp_fwd_ws.hip", ()), ("nnr_mlp_fwd.hip", ()), ("nnr_mlp_dgrad.hip", ()),
            ("nnr_api.cpp", ()), ("nnr_pack.hip", ()), ("nnr_wgrad.hip", ()), ("nnr_wgrad_bf16.hip", ()), ("nnr_composite.hip", ()),
            ("nnr_camera.hip", ()), ("nnr_pointcloud.hip", ()), ("nnr_aux.hip", ()), ("nnr_randperm.hip", ()), ("nnr_optim.hip", ())]
 

@@ -14,6 +14,11 @@
 
 using namespace nnr;
 
+namespace nnr {
+hipError_t launch_mlp_fwd_ws(const MlpFwdArgs& a, hipStream_t st);      // nnr_mlp_fwd_ws.hip (declared here: nnr_kernels.h is a dependency of every kernel)
+}
+constexpr bool kFwdWsDefault = false;      // prototype: opt in with NNR_FWD_WS=1
+
 namespace {
 
 thread_local int g_last_hip = 0;
@@ -561,6 +566,12 @@ int nnr_pack_weights(const nnr_cfg* cfg, const nnr_params* p, float* packed, voi
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
+// NNR_FWD_WS=0 / 1 selects the one-wave-per-SIMD / wave-specialised inference forward (read at every call: A/B runs in one process)
+static bool fwd_ws_enabled() {
+    const char* e = std::getenv("NNR_FWD_WS");
+    return e ? (e[0] != '0') : kFwdWsDefault;
+}
+
 // the forward MLP launch; fuse_rgb / fuse_dist != null: inference with the compositing in the kernel's epilogue (ray mode only)
 static int mlp_fwd_impl(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, const float* view_d, const float* z_lo,
                         const float* z_hi, const float* jitter, const float* packed, float* ws, float* fuse_rgb, float* fuse_dist,
@@ -591,6 +602,11 @@ static int mlp_fwd_impl(const nnr_cfg* cfg, const float* pts_o, const float* pts
     a.S = w.S; a.S_pad = w.S_pad; a.N = cfg->n_samples;
     a.chunks_per_ray = chunks_per_ray(cfg);
     a.fuse_rgb = fuse_rgb; a.fuse_dist = fuse_dist; a.flags = cfg->flags;
+    // the wave-specialised forward (nnr_mlp_fwd_ws.hip): three-term inference at D = 256
+    if (fwd_ws_enabled() && is_split3(cfg) && cfg->hidden == 256 && !w.train) {
+        hipError_t ews = launch_mlp_fwd_ws(a, (hipStream_t)stream);
+        return ews == hipSuccess ? NNR_OK : hip_fail(ews);
+    }
     hipError_t e = is_bf16(cfg) ? launch_mlp_fwd_bf16(cfg->hidden, a, w.train, (hipStream_t)stream)
                                 : launch_mlp_fwd(cfg->hidden, a, w.train, (hipStream_t)stream, is_split3(cfg));
     return e == hipSuccess ? NNR_OK : hip_fail(e);
