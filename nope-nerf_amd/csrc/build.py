@@ -120,6 +120,23 @@ def build_split_variant(name, defines):
     return out
 
 
+def build_ws_variant(name, defines):
+    """Experiment library: only nnr_mlp_fwd_ws.hip is recompiled with `defines` (profiling switches: results not valid)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.join(os.path.dirname(HERE), "nnr", "libnnr_%s.so" % name)
+    tmp = os.path.join(OUT_DIR, "variant_" + name)
+    os.makedirs(tmp, exist_ok=True)
+    obj = os.path.join(tmp, "nnr_mlp_fwd_ws.o")
+    r = subprocess.run([hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(HERE, "nnr_mlp_fwd_ws.hip"), "-o", obj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    objs = [obj if src == "nnr_mlp_fwd_ws.hip" else os.path.join(OUT_DIR, _obj_name(src, d)) for src, d in SOURCES]
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return out
+
+
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -154,7 +171,9 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--split-variant":    # build.py --split-variant safesync NNR_SPLIT_SAFE_SYNC
+    if len(sys.argv) > 2 and sys.argv[1] == "--ws-variant":         # build.py --ws-variant nobar NNR_WS_NO_BARRIER
+        print(build_ws_variant(sys.argv[2], sys.argv[3:]))
+    elif len(sys.argv) > 2 and sys.argv[1] == "--split-variant":    # build.py --split-variant safesync NNR_SPLIT_SAFE_SYNC
         print(build_split_variant(sys.argv[2], sys.argv[3:]))
     elif len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant nostash NNR_ABLATE_NO_STASH [...]
         print(build_variant(sys.argv[2], sys.argv[3:]))

@@ -85,8 +85,12 @@ __device__ __forceinline__ void wait_lgkm() {
     static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit field");
     asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory");
 }
+// Profiling builds only (results NOT valid): NNR_WS_NO_BARRIER, NNR_WS_NO_DMAWAIT, NNR_WS_NO_DMA, NNR_WS_NO_INTAKE, NNR_WS_NO_TERMS, NNR_WS_NO_DRAIN,
+// NNR_WS_HELPER_IDLE (the helper only keeps the barriers), NNR_WS_MFMA_IDLE (the MFMA wave only keeps the barriers)
 __device__ __forceinline__ void row_barrier() {
+#ifndef NNR_WS_NO_BARRIER
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
 }
 
@@ -127,8 +131,17 @@ struct MfmaRole {
     // nnr_split.h: (weights term, activation term) = (l,h) (m,m) (m,h) (h,l) (h,m) (h,h).  PR = the row's place in its panel (0 / 1) =
     // the parity of the row number.  ND accumulator pieces W0 .. W0 + ND - 1 of the OTHER set (piece w = tile w / 4, registers 4 (w % 4) ..
     // + 3) go to the drain slots of this row.
-    template <int SET, bool ZERO, int PR, int ND, int W0>
+    template <int SET, bool ZERO, int PR, int ND_, int W0>
     __device__ __forceinline__ void row() {
+#ifdef NNR_WS_NO_DRAIN
+        constexpr int ND = 0;
+#else
+        constexpr int ND = ND_;
+#endif
+#ifdef NNR_WS_MFMA_IDLE
+        row_barrier();
+        return;
+#endif
         static_assert(ND >= 0 && ND <= 4 && W0 + ND <= 4 * MT, "drain pieces");
         // fragments of row j + 1: the other row of this panel, or the first row of the next panel (in the ring)
         unsigned nxt = panel_addr;
@@ -304,6 +317,9 @@ struct HelperRole {
     // terms of row j + 2 from SRC (row SROW of that vector), into term slot PR = j & 1
     template <int PR, int SRC, int SROW>
     __device__ __forceinline__ void make_terms() {
+#if defined(NNR_WS_NO_TERMS) || defined(NNR_WS_HELPER_IDLE)
+        return;
+#endif
         float v[8];
         if constexpr (SRC == SRC_E) {
             static_for<8>([&](auto I) __attribute__((always_inline)) { v[I] = e[8 * SROW + I]; });
@@ -326,6 +342,9 @@ struct HelperRole {
     // bias_addr: LDS byte address of the group's bias row (+ 16 half); SIGMA: the density head runs along (hidden 8 arriving)
     template <int PR, int KIND, int NI, int IW0, bool SIGMA>
     __device__ __forceinline__ void intake(unsigned bias_addr) {
+#if defined(NNR_WS_NO_INTAKE) || defined(NNR_WS_HELPER_IDLE)
+        return;
+#endif
         if constexpr (KIND != IN_NONE && NI > 0) {
             static_for<NI>([&](auto I) __attribute__((always_inline)) {
                 constexpr int w = IW0 + I, t = w / 4, q = w % 4;
@@ -383,8 +402,15 @@ struct HelperRole {
     // weight DMA: every even period one panel -- panel (j + 4) / 2 of this chunk -- then wait for the panel issued one even period
     // earlier (the six pieces just issued may stay in flight)
     __device__ __forceinline__ void dma() {
+#if defined(NNR_WS_NO_DMA) || defined(NNR_WS_HELPER_IDLE)
+        ++dp;
+        return;
+#endif
         const bool issued = issue_panel(dp);
         ++dp;
+#ifdef NNR_WS_NO_DMAWAIT
+        return;
+#endif
         if (issued) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     }
@@ -393,7 +419,9 @@ struct HelperRole {
         intake<PR, KIND, NI, IW0, SIGMA>(bias_addr);
         make_terms<PR, SRC, SROW>();
         if constexpr (PR == 0) dma();
+#ifndef NNR_WS_HELPER_IDLE
         extra();
+#endif
         wait_lgkm<0>();
         row_barrier();
     }
