@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNR_ABI_VERSION 4
+#define NNR_ABI_VERSION 5
 
 /* error codes */
 #define NNR_OK 0
@@ -278,7 +278,15 @@ int nnr_ndc_rays_bwd(const float* rays_o, const float* rays_d, const float* came
  * moments as torch.optim.Adam(fused=True).  The table is passed BY VALUE (host struct, <= NNR_ADAM_MAX_TENSORS tensors, all fp32,
  * contiguous).  step_in[i] / step_out[i]: one-element float counters; the kernel reads step_in, uses step_in + 1 and writes it to
  * step_out (distinct buffers: no block may see a counter another block has advanced).  block_first: prefix table in units of 1024
- * elements, block_first[i+1] - block_first[i] = ceil(numel[i] / 1024). */
+ * elements, block_first[i+1] - block_first[i] = ceil(numel[i] / 1024).
+ * flavour (ABI 5) selects WHICH of torch's two Adam arithmetics is reproduced: NNR_ADAM_FUSED = the above; NNR_ADAM_SINGLE = torch's
+ * single-tensor implementation (torch/optim/adam.py::_single_tensor_adam -- what the plain `optim.Adam(...)` objects of the reference's
+ * train.py:58,99,117,140 run): float moments by one fma each (lerp_; mul_ + addcmul_), the bias corrections and the step size computed by
+ * the CALLER as host doubles exactly as that function does -- lr[i] then carries -(lr / (1 - beta1^step)) (the table is a kernel argument:
+ * 4 KiB at most), bc2_sqrt[i] = (1 - beta2^step)^0.5, step = the incremented counter --, denominator = sqrt(v) * float(1 / bc2_sqrt) + float(eps) (ATen divides by a host scalar through its
+ * reciprocal), update = one fma.  Bitwise torch.optim.Adam(foreach=False, fused=False) (tests/test_gpu_optim.py). */
+#define NNR_ADAM_FUSED 0
+#define NNR_ADAM_SINGLE 1
 #define NNR_ADAM_MAX_TENSORS 40
 typedef struct nnr_adam_table {
     float* param[NNR_ADAM_MAX_TENSORS];
@@ -291,6 +299,8 @@ typedef struct nnr_adam_table {
     int64_t numel[NNR_ADAM_MAX_TENSORS];
     int32_t block_first[NNR_ADAM_MAX_TENSORS + 1];
     int32_t n_tensors;
+    int32_t flavour, reserved;
+    double bc2_sqrt[NNR_ADAM_MAX_TENSORS];      /* NNR_ADAM_SINGLE only */
 } nnr_adam_table;
 int nnr_adam_step(const nnr_adam_table* table, void* stream);
 

@@ -817,11 +817,12 @@ int nnr_ray_setup_bwd(const float* pixels, const float* depth, const float* K, c
 }
 int nnr_adam_step(const nnr_adam_table* t, void* stream) {
     if (!t || t->n_tensors < 0 || t->n_tensors > NNR_ADAM_MAX_TENSORS) return NNR_E_BADCFG;
-    if (t->block_first[0] != 0) return NNR_E_BADCFG;
+    if (t->block_first[0] != 0 || (t->flavour != NNR_ADAM_FUSED && t->flavour != NNR_ADAM_SINGLE)) return NNR_E_BADCFG;
     for (int i = 0; i < t->n_tensors; ++i) {
         if (!t->param[i] || !t->grad[i] || !t->exp_avg[i] || !t->exp_avg_sq[i] || !t->step_in[i] || !t->step_out[i] || t->numel[i] <= 0 ||
             t->step_in[i] == t->step_out[i])
             return NNR_E_BADCFG;
+        if (t->flavour == NNR_ADAM_SINGLE && !(t->bc2_sqrt[i] > 0.0)) return NNR_E_BADCFG;
         if (t->block_first[i + 1] - t->block_first[i] != (int32_t)((t->numel[i] + 1023) / 1024)) return NNR_E_BADCFG;
     }
     NNR_LAUNCH(launch_adam_multi(*t, (hipStream_t)stream));

@@ -18,6 +18,7 @@
 namespace nnr {
 
 constexpr int kAdamBlock = 256, kAdamIlp = 4;   // elements per block = 1024
+static_assert(sizeof(nnr_adam_table) <= 4096, "the table is passed by value: a kernel argument block holds 4 KiB");
 
 __global__ __launch_bounds__(kAdamBlock) void adam_multi_kernel(nnr_adam_table t) {
     // which tensor does this block work on?  (block_first is a prefix table: tensor i owns blocks [block_first[i], block_first[i+1]))
@@ -34,6 +35,36 @@ __global__ __launch_bounds__(kAdamBlock) void adam_multi_kernel(nnr_adam_table t
     // counters ping-pong between two arrays so that no block can read a counter another block has already advanced.
     const float step = t.step_in[i][0] + 1.0f;
     if (base == 0 && threadIdx.x == 0) t.step_out[i][0] = step;
+    if (t.flavour == NNR_ADAM_SINGLE) {
+        // torch/optim/adam.py::_single_tensor_adam on this build, link by link (tools/adam_single_variants.py compares every candidate
+        // expression bitwise with torch's kernels, profiles/r05/b_adam_single_variants.txt): exp_avg.lerp_(grad, 1 - beta1) = one float fma
+        // on the difference; exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2) = a float product and one fma; the denominator
+        // divides by the HOST scalar bias_correction2 ** 0.5 through its reciprocal (taken in double, rounded to float), then adds float(eps)
+        // -- two kernels in torch, so the product and the sum must NOT contract --; param.addcdiv_(exp_avg, denom, value = -step_size) = one
+        // fma on the quotient.  The host scalars come from the caller as python computes them.
+        const float w1 = (float)(1 - beta1), b2f = (float)beta2, w2 = (float)(1 - beta2), epsf = (float)eps;
+        const float inv_bc2 = (float)(1.0 / t.bc2_sqrt[i]), nss = (float)lr;      // (this flavour's lr[i] = -(lr / bias_correction1), see nnr.h)
+#pragma unroll
+        for (int u = 0; u < kAdamIlp; ++u) {
+            const int64_t e = base + (int64_t)u * kAdamBlock + threadIdx.x;
+            if (e >= n) continue;
+            const float grad = g[e];
+            float exp_avg = m[e], exp_avg_sq = v[e];
+            exp_avg = __builtin_fmaf(w1, grad - exp_avg, exp_avg);
+            float decayed = exp_avg_sq * b2f, gg = grad * grad;
+            asm volatile("" : "+v"(decayed), "+v"(gg));          // (products of their own kernels: rounded before the fma)
+            exp_avg_sq = __builtin_fmaf(w2, gg, decayed);
+            float scaled = sqrtf(exp_avg_sq) * inv_bc2;
+            asm volatile("" : "+v"(scaled));
+            const float denom = scaled + epsf;
+            float quot = exp_avg / denom;
+            asm volatile("" : "+v"(quot));
+            p[e] = __builtin_fmaf(nss, quot, p[e]);
+            m[e] = exp_avg;
+            v[e] = exp_avg_sq;
+        }
+        return;
+    }
     const float bias_correction1 = (float)(1 - pow(beta1, (double)step));
     const float bias_correction2_sqrt = (float)sqrt(1 - pow(beta2, (double)step));
 #pragma unroll

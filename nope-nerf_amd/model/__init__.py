@@ -3,6 +3,10 @@ MI355X-native render path in `nnr` (libnnr.so).  The names are resolved from one
 and checked at import time."""
 import importlib
 
+from nnr import parallel as _parallel
+
+_parallel.auto_init()      # under torchrun: bind the GPU of this rank, join the process group (nnr/parallel.py) -- train.py itself never does
+
 _EXPORTS = {
     'CheckpointIO': 'checkpoints', 'nope_nerf': 'network', 'Trainer': 'training', 'Renderer': 'rendering',
     'get_model': 'config', 'OfficialStaticNerf': 'official_nerf', 'LearnPose': 'poses', 'LearnFocal': 'intrinsics',

@@ -35,11 +35,17 @@ class CheckpointIO(object):
     def save(self, filename, **kwargs):
         for hook in list(PRE_SAVE_HOOKS):
             hook()
+        from nnr import parallel
+        if not parallel.is_writer():      # data parallel: every rank holds the same parameters and optimiser state; rank 0 writes them
+            return
         blob = dict(kwargs)
         blob.update({name: mod.state_dict() for name, mod in self.module_dict.items()})
         torch.save(blob, self._path(filename))
 
     def backup_model_best(self, filename, **kwargs):
+        from nnr import parallel
+        if not parallel.is_writer():
+            return
         src = self._path(filename)
         if os.path.exists(src):
             dst = os.path.join(self.checkpoint_dir, 'backup_model_best')

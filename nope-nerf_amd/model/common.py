@@ -180,7 +180,10 @@ def mse2psnr(mse):
 
 def backup(out_dir, config):
     """Snapshot the run's config and sources under <out_dir>/backup (reference model/common.py:492-506: config,
-    train.py, configs/default.yaml and the top-level files of ./model and ./dataloading).  Missing files are skipped."""
+    train.py, configs/default.yaml and the top-level files of ./model and ./dataloading).  Missing files are skipped.  Data parallel: rank 0 only."""
+    from nnr import parallel
+    if not parallel.is_writer():
+        return
     dst = os.path.join(out_dir, 'backup')
     os.makedirs(dst, exist_ok=True)
     shutil.copyfile(config, os.path.join(dst, 'config.yaml'))

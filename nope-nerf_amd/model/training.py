@@ -111,15 +111,22 @@ class Trainer(object):
         hook._trainer = ref
         _ck.PRE_SAVE_HOOKS.append(hook)
         self.fuse_front_end = bool(cfg.get('fuse_front_end', True))   # training.fuse_front_end: False keeps the separate launches
-        if cfg.get('fuse_optimizers', True):   # training.fuse_optimizers: False keeps torch's default multi-kernel Adam
+        # training.adam_arithmetic: WHICH of torch's two Adam arithmetics the step's updates carry out (nnr/optim.py).  "single" (default) =
+        # torch's single-tensor implementation, i.e. what the plain optim.Adam objects of the reference's train.py:58,99,117,140 do (host
+        # step counters, float moments); "fused" = torch's fused=True flavour (double-precision moments rounded once), the default of
+        # rounds 2-4.  The two differ in last bits only -- and 800 steps of the convergence replay turn that into 0.15 dB (profiles/r05/).
+        self.adam_arithmetic = str(cfg.get('adam_arithmetic', 'single'))
+        if self.adam_arithmetic not in ('single', 'fused'):
+            raise ValueError("training.adam_arithmetic: %r (expected 'single' or 'fused')" % self.adam_arithmetic)
+        if cfg.get('fuse_optimizers', True) and self.adam_arithmetic == 'fused':   # training.fuse_optimizers: False keeps torch's default multi-kernel Adam
             for opt in (optimizer, optimizer_pose, optimizer_focal, optimizer_distortion):
                 _use_fused_adam(opt)
         # training.one_launch_adam (default on): ALL of the step's Adam updates in one HIP launch (nnr.optim.MultiAdam: the same
-        # optimizer objects, param_groups and state, bitwise torch's fused arithmetic) instead of two launches per optimiser
+        # optimizer objects, param_groups and state, bitwise the selected torch arithmetic) instead of 2-7 launches per optimiser
         self._multi_adam = None
         if cfg.get('fuse_optimizers', True) and cfg.get('one_launch_adam', True):
             from nnr.optim import MultiAdam
-            self._multi_adam = MultiAdam([optimizer, optimizer_pose, optimizer_focal, optimizer_distortion])
+            self._multi_adam = MultiAdam([optimizer, optimizer_pose, optimizer_focal, optimizer_distortion], self.adam_arithmetic)
 
     # ------------------------------------------------------------------------------------------------ step
     def _groups(self):
@@ -574,6 +581,8 @@ class Trainer(object):
             rgb = torch.cat(rgb, dim=1).view(h, w, 3).cpu().numpy()
             depth = torch.cat(depth, dim=0).view(h, w).cpu().numpy()
         img_out = (rgb * 255).astype(np.uint8)
+        if not parallel.is_writer():      # data parallel: the frames are identical on every rank, rank 0 writes them
+            return img_out
         depth_u8 = np.clip(255.0 / depth.max() * (depth - depth.min()), 0, 255).astype(np.uint8)
         _save_png(depth_u8, os.path.join(out_render_path, '%04d_depth.png' % img_idx))
         Image.fromarray(img_out).convert("RGB").save(os.path.join(out_render_path, '%04d_img.png' % img_idx))

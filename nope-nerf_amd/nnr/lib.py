@@ -47,8 +47,8 @@ LAYER_NAMES = ("layers0.0", "layers0.2", "layers0.4", "layers0.6", "layers1.0", 
 # = NNR_ABI_VERSION of include/nnr.h; bumped whenever a signature, a struct or a blob layout that crosses the C ABI changes
 # (2: nnr_pc_error_bwd takes n_dst; round-2 layouts of nnr_aux_cfg and the bf16 plan blob.  3: nnr_step_rays_*; the weight-gradient
 # stage overwrites nnr_param_grads instead of accumulating into it.  4: nnr_ws_plane_layout; the gradient planes of a three-term training workspace
-# are tile-major fp32)
-ABI_VERSION = 4
+# are tile-major fp32.  5: nnr_adam_table.flavour / bc2_sqrt -- torch's single-tensor Adam arithmetic beside the fused one)
+ABI_VERSION = 5
 EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_floats", "nnr_workspace_floats",
            "nnr_plan_bytes", "nnr_plan_counts", "nnr_plan_build", "nnr_pack_weights", "nnr_render_fwd", "nnr_render_bwd", "nnr_ws_plane",
            "nnr_ws_plane_layout",

@@ -3,8 +3,13 @@
 The reference steps up to four `torch.optim.Adam` instances per iteration (model/training.py:90-96).  `MultiAdam` drives the SAME
 optimizer objects -- their `param_groups` (so LR schedulers keep working) and their `state` (so `state_dict()` / checkpoints keep
 torch's layout: `step`, `exp_avg`, `exp_avg_sq` per parameter) -- but performs the update of all of them in one kernel whose
-arithmetic is torch's fused implementation operation by operation: the results are bitwise those of `Adam(fused=True).step()`
-(tests/test_gpu_optim.py).  Anything it does not cover (other optimizer classes, weight decay, amsgrad, maximize, non-fp32 or CPU
+arithmetic is, operation by operation, one of torch's own two (tests/test_gpu_optim.py holds both bitwise):
+  "single" (the default)  torch's single-tensor implementation, `Adam(foreach=False, fused=False).step()` -- what the plain
+                          `optim.Adam(...)` objects of the reference's train.py:58,99,117,140 run; the step counters stay host tensors as there,
+                          bias corrections and step size are computed on the host in python doubles exactly as torch/optim/adam.py does;
+  "fused"                 `Adam(fused=True).step()`: double-precision moments rounded once, device step counters.
+The two differ in the last bits of every update; over 800 steps of the convergence replay that was the difference between landing inside
+and 0.15 dB below the reference's own run-to-run spread (profiles/r04/b_conv_envelope_hip.txt, profiles/r05/).  Anything it does not cover (other optimizer classes, weight decay, amsgrad, maximize, non-fp32 or CPU
 parameters, more than NNR_ADAM_MAX_TENSORS tensors, non-contiguous gradients) makes `step()` return False and the caller steps the
 optimizers itself."""
 from __future__ import annotations
@@ -25,7 +30,10 @@ class AdamTable(C.Structure):       # nnr_adam_table (include/nnr.h)
                 ("exp_avg_sq", C.c_void_p * MAX_TENSORS), ("step_in", C.c_void_p * MAX_TENSORS), ("step_out", C.c_void_p * MAX_TENSORS),
                 ("lr", C.c_double * MAX_TENSORS), ("beta1", C.c_double * MAX_TENSORS), ("beta2", C.c_double * MAX_TENSORS),
                 ("eps", C.c_double * MAX_TENSORS), ("numel", C.c_int64 * MAX_TENSORS), ("block_first", C.c_int32 * (MAX_TENSORS + 1)),
-                ("n_tensors", C.c_int32)]
+                ("n_tensors", C.c_int32), ("flavour", C.c_int32), ("reserved", C.c_int32), ("bc2_sqrt", C.c_double * MAX_TENSORS)]
+
+
+FLAVOURS = {"fused": 0, "single": 1}      # NNR_ADAM_FUSED / NNR_ADAM_SINGLE (include/nnr.h)
 
 
 def _plain_adam(opt) -> bool:
@@ -43,7 +51,10 @@ def _plain_adam(opt) -> bool:
 
 
 class MultiAdam:
-    def __init__(self, optimizers: Sequence[torch.optim.Optimizer]):
+    def __init__(self, optimizers: Sequence[torch.optim.Optimizer], arithmetic: str = "single"):
+        if arithmetic not in FLAVOURS:
+            raise ValueError("adam arithmetic %r: expected 'single' or 'fused'" % (arithmetic,))
+        self.arithmetic = arithmetic
         self.optimizers: List[torch.optim.Optimizer] = [o for o in optimizers if o is not None]
         self._table = AdamTable()
         self._steps = None        # two (MAX_TENSORS,) float arrays: the counters ping-pong between them
@@ -92,16 +103,30 @@ class MultiAdam:
                 self._alive[id(p)] = weakref.ref(p)
             k = self._slot[id(p)]
             st = opt.state[p]
-            if len(st) == 0:        # torch's lazy state initialisation (Adam._init_group, fused flavour: float32 device counter)
-                st['step'] = torch.zeros((), dtype=torch.float32, device=dev)
+            single = self.arithmetic == "single"
+            if len(st) == 0:        # torch's lazy state initialisation (Adam._init_group): a float32 counter, on the host for the
+                                    # single-tensor implementation, beside the parameter for the fused one
+                st['step'] = torch.zeros((), dtype=torch.float32, device="cpu" if single else dev)
                 st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
             step = st['step']
-            if not (torch.is_tensor(step) and step.is_cuda and step.dtype == torch.float32):
-                step = torch.as_tensor(float(step), dtype=torch.float32, device=dev)
-            if step.data_ptr() != src[k].data_ptr():      # a counter not in this step's source array yet (first step, restored
-                src[k].copy_(step.reshape(()))            # state, a parameter that sat out the previous step)
-            rebind.append((st, dst[k]))
+            if single:
+                # torch/optim/adam.py::_single_tensor_adam: step_t += 1; step = _get_value(step_t); bias_correction1 = 1 - beta1 ** step;
+                # bias_correction2 = 1 - beta2 ** step; step_size = lr / bias_correction1; bias_correction2_sqrt = bias_correction2 ** 0.5
+                if not (torch.is_tensor(step) and not step.is_cuda):      # restored from / handed over by the fused flavour: one host read
+                    step = torch.as_tensor(float(step), dtype=torch.float32)
+                    st['step'] = step
+                step += 1
+                sv = step.item()
+                lr = -(lr / (1 - b1 ** sv))
+                t.bc2_sqrt[i] = (1 - b2 ** sv) ** 0.5
+            else:
+                if not (torch.is_tensor(step) and step.is_cuda and step.dtype == torch.float32):
+                    step = torch.as_tensor(float(step), dtype=torch.float32, device=dev)
+                if step.data_ptr() != src[k].data_ptr():      # a counter not in this step's source array yet (first step, restored
+                    src[k].copy_(step.reshape(()))            # state, a parameter that sat out the previous step)
+                rebind.append((st, dst[k]))
+                t.bc2_sqrt[i] = 1.0
             t.param[i], t.grad[i] = p.data_ptr(), gr.data_ptr()
             t.exp_avg[i], t.exp_avg_sq[i] = st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
             t.step_in[i], t.step_out[i] = src[k].data_ptr(), dst[k].data_ptr()
@@ -111,6 +136,7 @@ class MultiAdam:
             blocks += (p.numel() + 1023) // 1024
         t.block_first[len(entries)] = blocks
         t.n_tensors = len(entries)
+        t.flavour = FLAVOURS[self.arithmetic]
         L.check(L.load().nnr_adam_step(C.byref(t), L.stream()), "nnr_adam_step")
         for st, counter in rebind:          # only after a successful launch: torch's state keeps pointing at the CURRENT counter
             st['step'] = counter

@@ -11,6 +11,75 @@ import torch
 import torch.distributed as dist
 
 
+_auto = {"done": False, "made_group": False}
+
+
+def auto_init() -> bool:
+    """Called by `import model`: under a multi-process launcher -- `torchrun --nproc-per-node N train.py cfg.yaml` sets RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR, MASTER_PORT -- bind this process to its GPU and join the process group, so that the reference's UNMODIFIED
+    train.py (which never calls init_process_group and asks for the device "cuda": /root/reference/train.py:18-60) trains data-parallel:
+      * torch.cuda.set_device(LOCAL_RANK): train.py's torch.device("cuda") then means this rank's GPU;
+      * init_process_group: 'nccl' (= RCCL) with the device bound when there is a GPU per rank, 'gloo' otherwise (CPU runs, or several ranks
+        sharing one GPU: NNR_DIST_BACKEND=gloo); nothing happens when a group already exists or WORLD_SIZE is 1 / unset;
+      * os.makedirs tolerates a directory that another rank created between train.py's os.path.exists() and os.makedirs()
+        (train.py:176-177, 234-235: every rank runs those lines at the same moment).
+    File outputs are rank 0's: CheckpointIO.save / backup_model_best, model.common.backup and Trainer.render_visdata write nothing elsewhere.
+    Returns True when this call created the group."""
+    import os
+    if _auto["done"]:
+        return _auto["made_group"]
+    _auto["done"] = True
+    try:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+    except ValueError:
+        world = 1
+    if world <= 1 or "RANK" not in os.environ or not dist.is_available() or dist.is_initialized():
+        return False
+    if os.environ.get("NNR_NO_AUTO_DIST") == "1":
+        return False
+    rank_, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    backend = os.environ.get("NNR_DIST_BACKEND")
+    have_gpu = torch.cuda.is_available()
+    if have_gpu:
+        n = torch.cuda.device_count()
+        if backend is None:      # one GPU per local rank: RCCL; fewer (ranks sharing a GPU, as the one-GPU tests do): gloo
+            backend = "nccl" if n >= int(os.environ.get("LOCAL_WORLD_SIZE", world)) else "gloo"
+        torch.cuda.set_device(local % n)
+    elif backend is None:
+        backend = "gloo"
+    kw = {}
+    if backend == "nccl":
+        kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+    dist.init_process_group(backend, rank=rank_, world_size=world, **kw)
+    _auto["made_group"] = True
+    import atexit
+
+    def _bye():
+        if dist.is_initialized():
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+    atexit.register(_bye)
+    real_makedirs = os.makedirs
+
+    def makedirs(name, mode=0o777, exist_ok=False):      # every rank: whoever loses the race between exists() and makedirs() carries on
+        try:
+            return real_makedirs(name, mode, exist_ok)
+        except FileExistsError:
+            if not os.path.isdir(name):
+                raise
+    os.makedirs = makedirs
+    return True
+
+
+def is_writer() -> bool:
+    """Whether this process writes the run's files (checkpoints, visualisations, config backups): rank 0, or the only process."""
+    return rank() == 0
+
+
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -58,15 +127,20 @@ _LOGGED = ('loss', 'loss_rgb', 'loss_depth', 'l2_mean', 'loss_dist_1st', 'loss_d
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], loss_dict: Optional[Dict[str, torch.Tensor]] = None):
     """SUM-reduce every .grad (and the logged loss scalars) across ranks through ONE flat fp32 bucket.
-    Parameters whose grad is None on this rank (e.g. an unused pose row) contribute zeros so that bucket layouts
-    agree on every rank."""
+    A parameter whose grad is None on this rank (an unused table) contributes zeros so that bucket layouts agree on every rank; one flag
+    per parameter rides along in the same bucket ("this rank has a gradient"), and a parameter that NO rank has a gradient for keeps
+    grad = None afterwards -- exactly the single-process state.  That matters: Adam skips a parameter without a gradient (no momentum
+    step, no step-counter increment), and the reference leaves the distortion scales without one whenever the step's frame is the gauge
+    camera (model/distortions.py:23-24); handing Adam a zero-filled gradient instead moved the scales by their momentum in those steps
+    and a two-rank run of train.py drifted from the single-process run (tests/test_dropin_torchrun.py)."""
     params = [p for p in params if p.requires_grad]
     if not params:
         return
-    dev = params[0].device
     pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]
     keys = [k for k in _LOGGED if loss_dict is not None and torch.is_tensor(loss_dict.get(k))]
     pieces += [loss_dict[k].detach().reshape(1).float() for k in keys]
+    dev = pieces[0].device
+    pieces.append(torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32).to(dev, non_blocking=True))
     flat = torch.cat(pieces)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     views, off = [], 0
@@ -77,9 +151,13 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], loss_dict: Optiona
     have = [i for i, p in enumerate(params) if p.grad is not None]
     if have:
         torch._foreach_copy_([params[i].grad for i in have], [views[i] for i in have])   # one multi-tensor launch
-    for i, p in enumerate(params):
-        if p.grad is None:
-            p.grad = views[i].clone()
+    missing = [i for i, p in enumerate(params) if p.grad is None]
+    n_keys = len(keys)
+    if missing:      # rare (a rank without a gradient for a table): did any other rank have one?  One small host read, only then.
+        flags = flat[off + n_keys:].cpu()
+        for i in missing:
+            if float(flags[i]) > 0.0:
+                params[i].grad = views[i].clone()
     for k in keys:
         # the autograd-free logged value ('loss' is no longer needed for backward at this point); a view of the private
         # bucket, not a copy -- each copy would be one more launch per step

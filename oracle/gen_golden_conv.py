@@ -37,12 +37,14 @@ np.savez(sys.argv[3], imgs=f.imgs, dpt=f.dpt_depth, K=f.K, c2ws=np.asarray(f.c2w
 ''' % (FRAMES, SIZE, SEED_SCENE, R, N, D)
 
 
-def main(threads=8, replay=None, out_name="conv_llff.npz", epochs=EPOCHS, phase=None):
+def main(threads=8, replay=None, out_name="conv_llff.npz", epochs=EPOCHS, phase=None, seed=None):
     """threads / replay: the chaos envelope (see envelope()) -- the same reference run with another GEMM thread count, fed the frames
     and pixel permutations the golden run drew (`replay` = the golden blob).
     phase = (scheduling_start, annealing_epochs): the TWO-PHASE run -- what train.py's PSNR-plateau scheduler (train.py:309-340) does once
     it fires at epoch `scheduling_start`: model/training.py:187-217 anneals pc / rgb_s / depth weights to their end values over
-    `annealing_epochs` epochs and switches the rgb term from L1 to L2 afterwards."""
+    `annealing_epochs` epochs and switches the rgb term from L1 to L2 afterwards.
+    seed: another DRAW of the run -- the same scene, network and initial poses, but the order of the frames and every step's pixel pick come
+    from torch.manual_seed(1000 + seed) (see seeds())."""
     with tempfile.TemporaryDirectory() as tmp:
         # the scene goes through THIS repository's loader (pinned bit-exact against the reference's DataField: tests/test_dataloading.py)
         # in a separate process: `model` / `dataloading` of the reference are imported below under the same names
@@ -99,6 +101,8 @@ def main(threads=8, replay=None, out_name="conv_llff.npz", epochs=EPOCHS, phase=
         rpe_t, rpe_r = compute_rpe(gt.numpy(), aligned)
         return float(compute_ATE(gt.numpy(), aligned)), float(rpe_t * 100), float(np.degrees(rpe_r))
 
+    if seed is not None:
+        torch.manual_seed(1000 + int(seed))
     Kt = K.unsqueeze(0) if K.dim() == 2 else K
     eye = torch.eye(4).unsqueeze(0)
     order, picks, losses, curve = [], [], [], [(-1, float("nan")) + pose_errors()]
@@ -160,6 +164,26 @@ def envelope(thread_counts=(1, 2, 3, 4, 5, 6, 7), name="conv_llff", **kw):
     print("wrote", out)
 
 
+def seeds(n=8, threads=8):
+    """the envelope above varies only the summation order; a statistic needs independent SAMPLES.  n more runs of the
+    reference, each with its own frame order and pixel picks (seed 1 .. n), recorded so that tests / tools can replay every one of them on
+    the HIP kernels: a PAIRED comparison (same draws, reference arithmetic against ours), in which the batch noise cancels.
+    tests/golden/conv_llff_seeds.npz: per seed the draws (order, ray_idx), the first 20 steps' logged losses, the final PSNR / ATE / RPE."""
+    out = dict(order=[], ray_idx=[], losses20=[], final=[], psnr_curve=[])
+    for s in range(1, n + 1):
+        b = main(threads=threads, out_name=None, seed=s)
+        out["order"].append(b["order"]); out["ray_idx"].append(b["ray_idx"]); out["losses20"].append(b["losses"][:20])
+        out["final"].append(b["curve"][-1][1:]); out["psnr_curve"].append(b["curve"][:, 1])
+        print("seed %d: final PSNR %.3f ATE %.4f RPE_r %.3f" % ((s,) + tuple(b["curve"][-1][[1, 2, 4]])), flush=True)
+    gold = np.load(os.path.join(gg.OUT, "conv_llff.npz"))
+    path = os.path.join(gg.OUT, "conv_llff_seeds.npz")
+    np.savez_compressed(path, seeds=np.arange(1, n + 1), order=np.stack(out["order"]), ray_idx=np.stack(out["ray_idx"]),
+                        losses20=np.stack(out["losses20"]), final=np.array(out["final"], dtype=np.float64), psnr_curve=np.array(out["psnr_curve"]),
+                        columns=np.array(["psnr", "ate", "rpe_t", "rpe_r"]), logged=np.array(LOGGED), cfg=gold["cfg"],
+                        **{k: gold[k] for k in ("init.pose_r", "init.pose_t")})
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 TWO_PHASE = dict(epochs=110, phase=(40, 20))     # switch at epoch 40, annealed by 60, L2 from 60 on, 50 more epochs = 400 steps beyond
 
 if __name__ == "__main__":
@@ -168,5 +192,7 @@ if __name__ == "__main__":
         envelope((1, 3, 5, 7), name="conv_llff_2phase", **TWO_PHASE)
     elif "--envelope" in sys.argv:
         envelope()
+    elif "--seeds" in sys.argv:         # tests/golden/conv_llff_seeds.npz: eight independent draws of the reference run
+        seeds(int(sys.argv[sys.argv.index("--seeds") + 1]) if len(sys.argv) > sys.argv.index("--seeds") + 1 else 8)
     else:
         main()

@@ -1,4 +1,6 @@
-"""GPU (-m gpu): nnr.optim.MultiAdam -- one launch for the step's three Adam optimisers -- against torch.optim.Adam(fused=True), BITWISE.
+"""GPU (-m gpu): nnr.optim.MultiAdam -- one launch for the step's three Adam optimisers -- against torch.optim.Adam, BITWISE, in both of
+torch's arithmetics: "single" = Adam(foreach=False, fused=False), the single-tensor implementation the reference's plain optim.Adam objects
+run (train.py:58,99,117,140; the default of this repository since round 5), and "fused" = Adam(fused=True).
 
 Training must not depend on which implementation stepped (the 800-step replay of the reference run, tests/test_conv_reference.py, sits
 on top of this): parameters, first and second moments and step counters are compared with torch.equal after every block of steps, on
@@ -24,7 +26,8 @@ def _params(dev, seed):
 
 def _opts(groups, fused):
     lrs = (1e-3, 5e-4, 5e-4)
-    return [torch.optim.Adam(ps, lr=lr, fused=fused) for ps, lr in zip(groups, lrs)]
+    kw = dict(fused=True) if fused else dict(fused=False, foreach=False)
+    return [torch.optim.Adam(ps, lr=lr, **kw) for ps, lr in zip(groups, lrs)]
 
 
 def _grads(groups, step, gen, skip_last):
@@ -58,13 +61,15 @@ def _assert_same(a, b, what):
                     (what, i, ("param", "exp_avg", "exp_avg_sq", "step")[j], float((u.float().cpu().reshape(-1) - v.float().cpu().reshape(-1)).abs().max()))
 
 
+@pytest.mark.parametrize("arithmetic", ["single", "fused"])
 @pytest.mark.parametrize("skip_last", [False, True])
-def test_one_launch_adam_is_bitwise_torch_fused_adam(skip_last, capsys):
+def test_one_launch_adam_is_bitwise_torch_adam(skip_last, arithmetic, capsys):
     from nnr.optim import MultiAdam
     dev = torch.device("cuda")
     ga, gb = _params(dev, 5), _params(dev, 5)
-    oa, ob = _opts(ga, True), _opts(gb, True)
-    multi = MultiAdam(ob)
+    fused = arithmetic == "fused"
+    oa, ob = _opts(ga, fused), _opts(gb, fused)
+    multi = MultiAdam(ob, arithmetic)
     assert multi.usable()
     gen = torch.Generator().manual_seed(11)
     n_steps = 240
@@ -99,7 +104,49 @@ def test_one_launch_adam_is_bitwise_torch_fused_adam(skip_last, capsys):
         assert multi.step()
     _assert_same(oa, ob, "after the state_dict swap")
     with capsys.disabled():
-        print("\nMultiAdam == torch fused Adam bitwise over %d steps (28 tensors, lr change at 100%s)" % (n_steps + 5, ", a parameter skipping steps" if skip_last else ""))
+        print("\nMultiAdam(%s) == torch.optim.Adam(%s) bitwise over %d steps (28 tensors, lr change at 100%s)"
+              % (arithmetic, "fused=True" if fused else "foreach=False, fused=False", n_steps + 5, ", a parameter skipping steps" if skip_last else ""))
+
+
+def test_the_two_arithmetics_differ_and_hand_over():
+    """The flavours are not the same numbers (else the switch would be moot), and either continues from the other's state."""
+    from nnr.optim import MultiAdam
+    dev = torch.device("cuda")
+    ga, gb = _params(dev, 7), _params(dev, 7)
+    oa, ob = _opts(ga, False), _opts(gb, True)
+    ma, mb = MultiAdam(oa, "single"), MultiAdam(ob, "fused")
+    gen = torch.Generator().manual_seed(13)
+    for step in range(20):
+        grads = _grads(ga, step, gen, False)
+        for p, q, g in zip([p for ps in ga for p in ps], [p for ps in gb for p in ps], grads):
+            p.grad, q.grad = g.to(dev), g.to(dev).clone()
+        assert ma.step() and mb.step()
+    differ = sum(int((x[0] != y[0]).sum()) for x, y in zip(_state(oa), _state(ob)))
+    assert differ > 0
+    worst = max(float(((x[0] - y[0]).abs() / x[0].abs().clamp_min(1e-3)).max()) for x, y in zip(_state(oa), _state(ob)))
+    assert worst < 1e-4, worst                      # last bits, not another optimiser
+    # hand-over: the single flavour continues from the fused flavour's state (device counters become host counters) exactly like torch would
+    sd = [copy.deepcopy(o.state_dict()) for o in ob]
+    gc = _params(dev, 7)
+    oc = _opts(gc, False)
+    for p_c, p_b in zip([p for ps in gc for p in ps], [p for ps in gb for p in ps]):
+        p_c.data.copy_(p_b.data)
+    for o, s_ in zip(oc, sd):
+        o.load_state_dict(s_)
+    mc = MultiAdam(oc, "single")
+    od = _opts([[p.detach().clone().requires_grad_(True) for p in ps] for ps in gb], False)
+    for o, s_ in zip(od, sd):
+        o.load_state_dict(s_)
+    for o in oc + od:       # (a state_dict carries the param_groups' implementation switches too: back to the single-tensor implementation)
+        for grp in o.param_groups:
+            grp['fused'], grp['foreach'] = False, False
+    grads = _grads(ga, 20, gen, False)
+    for p, q, g in zip([p for o in oc for grp in o.param_groups for p in grp['params']], [p for o in od for grp in o.param_groups for p in grp['params']], grads):
+        p.grad, q.grad = g.to(dev), g.to(dev).clone()
+    assert mc.step()
+    for o in od:
+        o.step()
+    _assert_same(od, oc, "hand-over from the fused flavour")
 
 
 def test_multi_adam_declines_what_it_does_not_cover():
