@@ -87,7 +87,7 @@ def test_rccl_flat_allreduce_world1():
         ld = {'loss': torch.tensor(2.5, device=DEV)}
         parallel.allreduce_gradients([a, b], ld)
         torch.cuda.synchronize()
-        assert float(a.grad.sum()) == 3000.0 and float(b.grad.abs().sum()) == 0.0 and float(ld['loss']) == 2.5
+        assert float(a.grad.sum()) == 3000.0 and b.grad is None and float(ld['loss']) == 2.5      # no rank has a gradient for b: it stays without one (Adam skips it, as in a single process)
     finally:
         dist.destroy_process_group()
 

@@ -36,3 +36,56 @@ def test_reference_train_script_on_the_hip_kernels_tracks_its_cpu_run():
           % (res["scalars_logged"], res["steps"], res["train/loss"]["first_10_max_dev"], res["train/loss"]["max_dev"],
              res["train/psnr"]["gpu_last"], res["train/psnr"]["cpu_last"]))
     assert res["train/loss"]["first_10_max_dev"] <= 1e-3
+
+
+def test_reference_train_script_under_two_ranks_sharing_the_gpu():
+    """`torchrun --nproc-per-node 2 train.py cfg` by hand, HIP kernels: two processes with the launcher's environment, the UNMODIFIED script.
+    `import model` binds the device and joins the group (nnr.parallel.auto_init; NNR_DIST_BACKEND=gloo because RCCL refuses two ranks on one
+    device), each rank renders half of the step's rays, one flat all-reduce, rank 0 writes.  Against the single-process run of the same
+    configuration on the same GPU: the logged losses of the first epoch to 1e-4 (same draws: both ranks and the single process draw the
+    step's whole permutation and jitter), PSNR / ATE at the end inside the chaos envelope of 2 dB / 30 %."""
+    import socket
+    ref = os.path.join(STAGE, "ref")
+    out = os.path.join(ROOT, "gpurun_out", "dropin")
+    os.makedirs(out, exist_ok=True)
+    import shutil
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(STAGE, "dropin_gpu.yaml")))
+    results = {}
+    for world in (1, 2):
+        out_dir = os.path.join(STAGE, "out_gpu_w%d" % world)
+        shutil.rmtree(out_dir, ignore_errors=True)
+        cfg["training"]["out_dir"] = out_dir
+        cfg_path = os.path.join(STAGE, "dropin_gpu_w%d.yaml" % world)
+        with open(cfg_path, "w") as fh:
+            yaml.safe_dump(cfg, fh)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ, DROPIN_BACKEND="hip", DROPIN_SCALARS=os.path.join(out, "scalars_gpu_w%d_r%d.json" % (world, rank)), NNR_REFERENCE=ref,
+                       PYTHONPATH="")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE"):
+                env.pop(k, None)
+            if world > 1:
+                env.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                           NNR_DIST_BACKEND="gloo")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dropin_runner.py"), "train.py", cfg_path], cwd=ref, env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        logs = [p.communicate(timeout=900)[0] for p in procs]
+        for p, log in zip(procs, logs):
+            assert p.returncode == 0, log[-4000:]
+        by = {}
+        for tag, value, step in json.load(open(os.path.join(out, "scalars_gpu_w%d_r0.json" % world))):
+            by.setdefault(tag, []).append(value)
+        results[world] = by
+        assert os.path.isfile(os.path.join(out_dir, "model.pt"))
+    a, b = results[1], results[2]
+    n = min(len(a["train/loss"]), len(b["train/loss"]))
+    first = max(abs(x - y) / max(1.0, abs(x)) for x, y in zip(a["train/loss"][:3], b["train/loss"][:3]))
+    print("train.py, 2 ranks on one GPU vs 1: %d logged steps, first-3 loss deviation %.2e, final PSNR %.2f / %.2f, ATE %.4f / %.4f"
+          % (n, first, a["train/psnr"][-1], b["train/psnr"][-1], a["eval/ate_trans"][-1], b["eval/ate_trans"][-1]))
+    assert first <= 1e-4, first
+    assert abs(a["train/psnr"][-1] - b["train/psnr"][-1]) <= 2.0
+    assert abs(a["eval/ate_trans"][-1] - b["eval/ate_trans"][-1]) <= 0.3 * max(a["eval/ate_trans"][-1], 1e-3)

@@ -132,11 +132,11 @@ def test_the_two_arithmetics_differ_and_hand_over():
     for p_c, p_b in zip([p for ps in gc for p in ps], [p for ps in gb for p in ps]):
         p_c.data.copy_(p_b.data)
     for o, s_ in zip(oc, sd):
-        o.load_state_dict(s_)
+        o.load_state_dict(copy.deepcopy(s_))      # (load_state_dict adopts tensors that already sit on the right device: two optimizers must not share them)
     mc = MultiAdam(oc, "single")
     od = _opts([[p.detach().clone().requires_grad_(True) for p in ps] for ps in gb], False)
     for o, s_ in zip(od, sd):
-        o.load_state_dict(s_)
+        o.load_state_dict(copy.deepcopy(s_))
     for o in oc + od:       # (a state_dict carries the param_groups' implementation switches too: back to the single-tensor implementation)
         for grp in o.param_groups:
             grp['fused'], grp['foreach'] = False, False

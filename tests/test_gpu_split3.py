@@ -98,7 +98,7 @@ def test_three_term_products_are_as_close_to_fp64_as_fp32_mfmas(D, capsys):
     for k in l2["cpu"]:
         gu.parity_log("fp64 yardstick D=%d seed %d %s: rel-L2 cpu-fp32 %.3e hip-mfma %.3e hip-split3 %.3e | max-abs/|ref|max cpu %.3e mfma %.3e split3 %.3e"
                       % (D, 77 + D, k, l2["cpu"][k], l2["mfma"][k], l2["split3"][k], errs["cpu"][k], errs["mfma"][k], errs["split3"][k]))
-    for seed in (177 + D, 277 + D, 377 + D):
+    for seed in [177 + D + 100 * i for i in range(11)]:      # 12 cases with the first one (four were thin for a heavy-tailed statistic)
         case_s = sp._case(256, 64, D, seed=seed)
         ref_s, rgrads_s = _oracle64(case_s)
         cout_s, cgrads_s = sp._oracle(case_s)
@@ -118,8 +118,12 @@ def test_three_term_products_are_as_close_to_fp64_as_fp32_mfmas(D, capsys):
     per_tensor = {kind: {k: gm(v) for k, v in ratios[kind].items()} for kind in ratios}
     overall = {kind: gm([x for v in ratios[kind].values() for x in v]) for kind in ratios}
     worst = {kind: max(per_tensor[kind].items(), key=lambda kv: kv[1]) for kind in ratios}
+    median = {kind: {k: float(np.median(v)) for k, v in ratios[kind].items()} for kind in ratios}
+    worst_med = {kind: max(median[kind].items(), key=lambda kv: kv[1]) for kind in ratios}
     with capsys.disabled():
-        print("D=%d vs fp64 in relative L2 over 4 seeds: geometric mean of HIP / CPU-fp32 over all tensors -- fp32 MFMAs %.2f, three-term %.2f; "
+        print("D=%d: worst per-tensor MEDIAN over the 12 seeds of HIP / CPU-fp32 -- fp32 MFMAs %.2f (%s), three-term %.2f (%s)"
+              % (D, worst_med["mfma"][1], worst_med["mfma"][0], worst_med["split3"][1], worst_med["split3"][0]))
+        print("D=%d vs fp64 in relative L2 over 12 seeds: geometric mean of HIP / CPU-fp32 over all tensors -- fp32 MFMAs %.2f, three-term %.2f; "
               "worst tensor (geometric mean over seeds) %.2f (%s) / %.2f (%s); first seed alone: CPU fp32 mean %.2e, fp32 MFMAs %.2e, three-term %.2e"
               % (D, overall["mfma"], overall["split3"], worst["mfma"][1], worst["mfma"][0], worst["split3"][1], worst["split3"][0],
                  np.mean(list(l2["cpu"].values())), np.mean(list(l2["mfma"].values())), np.mean(list(l2["split3"].values()))))
@@ -130,7 +134,11 @@ def test_three_term_products_are_as_close_to_fp64_as_fp32_mfmas(D, capsys):
             # measured (profiles/r04/b_gpu_tests.txt): overall 0.58 / 0.60 at D = 256, 0.50 / 0.49 at D = 128 -- the HIP kernels are on average CLOSER
             # to fp64 than the CPU oracle --; worst single tensor over the four seeds 4.2 - 4.8 (heavy-tailed: one gate decides a tensor)
             assert overall[kind] <= 1.5, (D, kind, overall[kind])
-            assert worst[kind][1] <= 10.0, (D, kind, worst[kind])
+            # (12 seeds, profiles/r05/d_gpu_tests.txt: overall 0.49 / 0.44 at D = 256, 0.43 / 0.44 at D = 128; worst tensor 2.0 / 1.6 and 2.6 / 2.65)
+            assert worst[kind][1] <= 5.0, (D, kind, worst[kind])
+            # the median over the seeds is what one gate cannot move: measured 1.95 / 2.04 (the pose gradients, D = 256) and 1.14 / 1.18 -- every
+            # tensor's typical distance to fp64 within 2.5x of the CPU oracle's own
+            assert worst_med[kind][1] <= 2.5, (D, kind, worst_med[kind])
 
 
 def test_three_term_step_at_1024x192_matches_the_oracle_end_to_end(capsys):

@@ -97,6 +97,40 @@ def test_two_rank_step_equals_single_process(name, n_rays, depth_loss_type):
         assert err <= 1e-5 * max(1.0, float(g.abs().max())), (k, err)
 
 
+def _missing_worker(rank, world, port, q):
+    from nnr import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, b, c = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2)), torch.nn.Parameter(torch.ones(4))
+        a.grad = torch.full((3,), 2.0 + rank)
+        if rank == 1:
+            b.grad = torch.full((2,), 5.0)          # only rank 1 has a gradient for b; nobody has one for c
+        ld = {'loss': torch.tensor(1.5)}
+        parallel.allreduce_gradients([a, b, c], ld)
+        q.put((rank, a.grad.tolist(), None if b.grad is None else b.grad.tolist(), c.grad is None, float(ld['loss'])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_keeps_a_gradient_none_only_when_no_rank_has_one():
+    """Adam skips a parameter without a gradient (no momentum step, no counter increment): under data parallelism a table that no rank has
+    a gradient for -- the distortion scales in a gauge-camera step, model/distortions.py:23-24 -- must stay without one, while a table only
+    SOME rank has a gradient for gets the sum everywhere (the bucket layout is the same on every rank either way)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_missing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ga, gb, c_none, loss in got:
+        assert ga == [5.0, 5.0, 5.0] and gb == [5.0, 5.0] and c_none and loss == 3.0, got
+
+
 def test_allreduce_handles_missing_grads():
     """A parameter without a gradient on this rank still occupies its slot in the flat bucket."""
     from nnr import parallel
@@ -107,7 +141,7 @@ def test_allreduce_handles_missing_grads():
         a.grad = torch.full((3,), 2.0)
         ld = {'loss': torch.tensor(1.5)}
         parallel.allreduce_gradients([a, b], ld)
-        assert torch.equal(a.grad, torch.full((3,), 2.0)) and torch.equal(b.grad, torch.zeros(2)) and float(ld['loss']) == 1.5
+        assert torch.equal(a.grad, torch.full((3,), 2.0)) and b.grad is None and float(ld['loss']) == 1.5
     finally:
         dist.destroy_process_group()
 
@@ -186,7 +220,8 @@ def _aux_step(name, monkeypatch_like=None):
     losses = {k: float(ld[k]) for k in ("loss", "loss_pc", "loss_rgb_s", "loss_rgb", "loss_depth")}
     zeros = lambda p: torch.zeros_like(p)
     grads = {"pose_r": pose.r.grad if pose.r.grad is not None else zeros(pose.r), "pose_t": pose.t.grad if pose.t.grad is not None else zeros(pose.t),
-             "scales": distn.global_scales.grad, "shifts": distn.global_shifts.grad}
+             "scales": distn.global_scales.grad if distn.global_scales.grad is not None else zeros(distn.global_scales),      # (the gauge camera's step leaves the scales without a gradient, on every rank)
+             "shifts": distn.global_shifts.grad if distn.global_shifts.grad is not None else zeros(distn.global_shifts)}
     return losses, {k: v.detach().numpy().copy() for k, v in grads.items()}
 
 
