@@ -137,6 +137,9 @@ def build_ws_variant(name, defines):
     return out
 
 
+LAST_BUILD = {"compiled": [], "reused": [], "linked": False}      # what the newest build() call did (printed by __graft_entry__.build())
+
+
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -165,8 +168,11 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(WORKERS, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OUT_DIR, _obj_name(src, defines)) for src, defines in SOURCES]
-    if force or jobs or _stale(LIB, objs):
+    relink = bool(force or jobs or _stale(LIB, objs))
+    if relink:
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    compiled = [os.path.basename(j[-1]) for j in jobs]
+    LAST_BUILD.update(compiled=compiled, reused=[os.path.basename(o) for o in objs if os.path.basename(o) not in compiled], linked=relink)
     return LIB
 
 

@@ -173,7 +173,9 @@ Plan build_plan(const nnr_cfg* c) {
                                                          // 400 / 440 / 480 / 520; both operands tile-major: 1.12 / 1.11 / 1.10 / 1.11 at 380 / 420 / 440 / 460, 1.14 at 480 on
                                                          // another box where 440 gave 1.11 -- profiles/r04/r*_wgrad_weight_sweep_tile_x.txt)
     }();
-    const bool split = is_split3(c) && std::getenv("NNR_WGRAD_FP32") == nullptr;
+    static const bool env_fp32 = std::getenv("NNR_WGRAD_FP32") != nullptr;      // (every knob of the plan is read ONCE per process, here: a plan built
+                                                                                // under one setting never meets a launch that assumes another)
+    const bool split = is_split3(c) && !env_fp32;
     auto weight = [split](const WgradJob& j) -> int64_t {
         const int mn = j.MI * j.NI;
         int w = mn == 16 ? (split ? split_w : 1000) : mn == 8 ? 1035 : mn == 4 ? 1145 : 1250;
@@ -259,7 +261,8 @@ Plan build_plan(const nnr_cfg* c) {
 }
 
 // blob: WgradJob[n_jobs], int32 wave_first[n_waves + 1], int32 n_heads, int32 heads[n_heads]
-size_t plan_bytes(const Plan& p) { return p.jobs.size() * sizeof(WgradJob) + (p.wave_first.size() + 1 + p.heads.size()) * sizeof(int32_t); }
+constexpr int32_t kPlanMagic = 0x4e4e5235;      // 'NNR5': the trailer of the fp32 / three-term plan blob (= nnr_wgrad.hip's)
+size_t plan_bytes(const Plan& p) { return p.jobs.size() * sizeof(WgradJob) + (p.wave_first.size() + 1 + p.heads.size() + 4) * sizeof(int32_t); }
 
 // ---- weight-gradient plan of the bf16 training mode (nnr_wgrad_bf16.hip) ------------------------------------------------------
 // Units = the products dW = Dlt^T X of the 12 layers (the feature layer merged into the colour-hidden one, the density head riding
@@ -547,6 +550,10 @@ int nnr_plan_build(const nnr_cfg* cfg, void* plan_host) {
     const int32_t n_heads = (int32_t)p.heads.size();
     std::memcpy(tail, &n_heads, sizeof(int32_t));
     std::memcpy(tail + sizeof(int32_t), p.heads.data(), p.heads.size() * sizeof(int32_t));
+    // trailer: what the weight-gradient kernel checks before it trusts the blob (a blob of another ABI, shape or plan setting makes it trap
+    // instead of indexing the job table with garbage)
+    const int32_t trailer[4] = {kPlanMagic, (int32_t)p.jobs.size(), (int32_t)p.wave_first.size() - 1, n_heads};
+    std::memcpy(tail + sizeof(int32_t) * (1 + p.heads.size()), trailer, sizeof(trailer));
     return NNR_OK;
 }
 

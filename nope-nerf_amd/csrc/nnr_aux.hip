@@ -23,6 +23,8 @@
 
 namespace nnr {
 
+hipError_t launch_pc_nearest_keys_at(const float* src, const float* dst, int S, int D, unsigned long long* keys, int s_off, hipStream_t st);   // nnr_pointcloud.hip
+
 __device__ __forceinline__ int aux_nearest_src(int dst, int dst_size, int src_size) {   // F.interpolate(mode='nearest')
     const float scale = (float)src_size / (float)dst_size;
     const int s = (int)floorf((float)dst * scale);
@@ -485,9 +487,9 @@ hipError_t launch_aux_fwd(const AuxArgs& a, hipStream_t st) {
     if (a.flags & NNR_AUX_PC) {
         hipLaunchKernelGGL(aux_fill_keys_kernel, dim3((2 * S + 255) / 256), dim3(256), 0, st, a.keys, 2 * S);
         if (n > 0) {   // the O(S^2 / W) part: only this rank's sources search the whole destination cloud
-            hipError_t e = launch_pc_nearest_keys(a.X + 3 * a.s_lo, a.Y, n, S, a.keys + a.s_lo, st);
+            hipError_t e = launch_pc_nearest_keys_at(a.X + 3 * a.s_lo, a.Y, n, S, a.keys + a.s_lo, a.s_lo, st);
             if (e != hipSuccess) return e;
-            e = launch_pc_nearest_keys(a.Y + 3 * a.s_lo, a.X, n, S, a.keys + S + a.s_lo, st);
+            e = launch_pc_nearest_keys_at(a.Y + 3 * a.s_lo, a.X, n, S, a.keys + S + a.s_lo, a.s_lo, st);
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(aux_decode_kernel, dim3(nb), dim3(256), 0, st, a.keys, S, a.s_lo, a.s_hi, a.idx_xy, a.dist_xy, a.part_fwd, 2);

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_kernel(const float* __res
 // tile holds the points as pairs [x0 x1 y0 y1 z0 z1], three 16-byte LDS broadcasts deliver four points as packed operands.
 template <int GROUPS, int SRC>      // groups of four destination points per trip (one branch per trip); sources per lane (s, s + 256, ..: each with its own minimum)
 __global__ __launch_bounds__(kPcBlock) void pc_nearest_one_kernel(const float* __restrict__ src, const float* __restrict__ dst, int S, int D,
-                                                                  int d_per_block, unsigned long long* keys, int seed) {
+                                                                  int d_per_block, unsigned long long* keys, int seed, int s_off) {
     __shared__ f32x4 tile[3 * kPcTile / 4];      // 12 floats per four points
     int s[SRC], sc[SRC];
     float sx[SRC], sy[SRC], sz[SRC];
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_one_kernel(const float* _
                 best_s[u] = sq;
                 best_i[u] = idx;
                 const float t = sq * sq;
-                thr[u] = __builtin_fmaf(t, 4.8e-7f, t);
+                thr[u] = __builtin_fmaf(t, 4.8e-7f, t) + 1.2e-38f;      // (+ the smallest normal: the relative margin vanishes when t is subnormal)
             }
         }
     };
@@ -172,11 +172,11 @@ __global__ __launch_bounds__(kPcBlock) void pc_nearest_one_kernel(const float* _
                 best_s[u] = __uint_as_float((unsigned int)(k0[u] >> 32));
                 best_i[u] = (int)(unsigned int)(k0[u] & 0xffffffffu);
                 const float t = best_s[u] * best_s[u];
-                thr[u] = __builtin_fmaf(t, 4.8e-7f, t);
+                thr[u] = __builtin_fmaf(t, 4.8e-7f, t) + 1.2e-38f;      // (+ the smallest normal: the relative margin vanishes when t is subnormal)
             } else if (seed > 1) {
 #pragma unroll
                 for (int j = -4; j < 4; ++j) {
-                    const int q = min(max(sc[u] + j, 0), D - 1);
+                    const int q = min(max(sc[u] + s_off + j, 0), D - 1);      // s_off: the source range's place in its cloud (data parallel shards)
                     const float ex = sx[u] - dst[3 * q], ey = sy[u] - dst[3 * q + 1], ez = sz[u] - dst[3 * q + 2];
                     consider(u, __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)), q);
                 }
@@ -296,7 +296,12 @@ __global__ __launch_bounds__(256) void pc_error_bwd_kernel(const float* __restri
 }
 
 // keys must hold ~0 (or earlier candidates): the search only lowers them
+hipError_t launch_pc_nearest_keys_at(const float* src, const float* dst, int S, int D, unsigned long long* keys, int s_off, hipStream_t st);
 hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int D, unsigned long long* keys, hipStream_t st) {
+    return launch_pc_nearest_keys_at(src, dst, S, D, keys, 0, st);
+}
+// s_off: index of src[0] in the cloud the S sources are a range of (the "same pixel" seed looks around s_off + s in dst)
+hipError_t launch_pc_nearest_keys_at(const float* src, const float* dst, int S, int D, unsigned long long* keys, int s_off, hipStream_t st) {
     // The product search: pc_nearest_one_kernel, one source per lane, eight points per trip, seeded ranges, the destination range cut until
     // there are ~8192 workgroups (>= 256 points per range).  End of round 4, at 20 736 / 32 400 points: 88 / 189 us against 145 / 297 for
     // the search of rounds 1-4 (two sources per lane, 2048 workgroups: NNR_PC_PER=2).  Sweeps: profiles/r04/x2_*, y2_*, y3_* (workgroups 256 ..
@@ -312,7 +317,7 @@ hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int
     split = split < 1 ? 1 : (split > max_split ? max_split : split);
     const int d_per_block = ((D + split - 1) / split + 255) / 256 * 256;
     const int by = (D + d_per_block - 1) / d_per_block;
-    if (per == 1) hipLaunchKernelGGL((pc_nearest_one_kernel<2, 1>), dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys, seed);
+    if (per == 1) hipLaunchKernelGGL((pc_nearest_one_kernel<2, 1>), dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys, seed, s_off);
     else hipLaunchKernelGGL(pc_nearest_kernel<2>, dim3(bx, by), dim3(kPcBlock), 0, st, src, dst, S, D, d_per_block, keys);
     return hipGetLastError();
 }

@@ -51,6 +51,7 @@ __device__ __forceinline__ Vec<W> load_vec(const float* p) {
 }
 
 constexpr int kU = 4;  // k-steps (pairs of samples) per pipeline stage
+constexpr int32_t kPlanMagic = 0x4e4e5235;      // 'NNR5' (nnr_api.cpp: nnr_plan_build writes the trailer)
 
 template <int MI, int NI, int BIAS>   // BIAS: WgradJob::bias
 __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a, int lane, int ji) {
@@ -606,6 +607,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) f32x4 stage_all[SPLIT ? (kCoopF4 > kWavesPerBlock * kStageF4 ? kCoopF4 : kWavesPerBlock * kStageF4) : 1];
     const int lane = threadIdx.x & 63;
     const int wslot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    // The plan blob is the caller's (a device buffer built by nnr_plan_build); the launch's counts come from a fresh host plan of the same
+    // configuration.  The blob's trailer -- magic, jobs, waves, tiles -- must say the same, or the blob belongs to another ABI version, shape
+    // or plan setting: trap (the launch fails loudly) instead of walking the job table with foreign indices.
+    {
+        const int32_t* const tr = a.heads + a.n_heads;
+        if (tr[0] != kPlanMagic || tr[1] != a.n_jobs || tr[2] != a.n_waves || tr[3] != a.n_heads) __builtin_trap();
+    }
     const int j0 = a.wave_first[wslot], j1 = a.wave_first[wslot + 1];
     // The gradients are OVERWRITTEN, not accumulated into: the weight tiles by the reduction kernel (every weight belongs to exactly one
     // tile), the bias rows by up to two atomic shares onto the zeros written here -- one workgroup's worth of stores instead of a

@@ -75,10 +75,23 @@ class _ViewIndices(data.Dataset):
 class ResidentLoader(object):
     """Iterates like the reference loader at batchsize 1, but the frames / depth maps live on `device` for the whole run."""
 
+    _uploaded = {}      # (device, content key) -> device tensor: train.py builds two loaders of the same scene (train.py:35-36), one upload serves both
+
     def __init__(self, field, n_views, shuffle, device):
         self.field, self.n_views, self.device = field, n_views, device
         self.order = data.DataLoader(_ViewIndices(n_views), batch_size=1, shuffle=shuffle, num_workers=0)
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+        def up(a):
+            a = np.ascontiguousarray(a)
+            if a.nbytes < (1 << 20):
+                return torch.from_numpy(a).to(device)
+            import hashlib
+            key = (str(device), a.shape, str(a.dtype), hashlib.blake2b(a.view(np.uint8).reshape(-1), digest_size=16).hexdigest())   # the whole content (~1 GB/s, once)
+            t = ResidentLoader._uploaded.get(key)
+            if t is None:
+                t = torch.from_numpy(a).to(device)
+                ResidentLoader._uploaded[key] = t
+            return t
         self.imgs = up(field.imgs) if field.mode != 'render' else None
         self.dpt = up(field.dpt_depth) if (field.dpt_depth is not None and field.mode != 'render') else None
         self.depth = up(field.depth) if (field.with_depth and field.mode != 'render') else None
@@ -129,9 +142,11 @@ def _auto_resident(field, dcfg, mode):
     if dcfg['batchsize'] != 1:
         return False, 'batchsize %d' % dcfg['batchsize']
     need = _scene_bytes(field)
-    free, _ = torch.cuda.mem_get_info()
-    if need > free // 2:
-        return False, 'the scene (%.1f GB) does not fit in half of the free device memory (%.1f GB)' % (need / 2 ** 30, free / 2 ** 30)
+    # (the device's TOTAL memory from its properties: torch.cuda.mem_get_info() would create a CUDA context in this process, and when the
+    # answer is "host loader" that process goes on to fork DataLoader workers -- ADVICE r04)
+    total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
+    if need > total // 4:
+        return False, 'the scene (%.1f GB) does not fit in a quarter of the device memory (%.1f GB)' % (need / 2 ** 30, total / 2 ** 30)
     return True, ''
 
 
@@ -149,7 +164,9 @@ def get_dataloader(cfg, mode='train', shuffle=True, n_views=None):
     if resident:
         if dcfg['batchsize'] != 1:
             raise ValueError('dataloading.resident serves one view per step (batchsize 1), as every config of the reference does')
-        device = torch.device(dcfg.get('resident_device') or ('cuda' if torch.cuda.is_available() else 'cpu'))
+        # dataloading.resident_device names the device (the one the Trainer runs on, if not the current one); default: the CURRENT device --
+        # under torchrun `import model` has made that this rank's GPU (nnr.parallel.auto_init)
+        device = torch.device(dcfg.get('resident_device') or (('cuda:%d' % torch.cuda.current_device()) if torch.cuda.is_available() else 'cpu'))
         print(mode, ': ', n_views, ' views (resident on %s: %.1f MB)' % (device, _scene_bytes(fields['img']) / 2 ** 20))
         return ResidentLoader(fields['img'], n_views, shuffle, device), fields
     dataset = OurDataset(fields, n_views=n_views, mode=mode)

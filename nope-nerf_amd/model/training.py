@@ -81,6 +81,14 @@ class _EarlyScalar(torch.Tensor):
         event.synchronize()
         return slot['host'][index].item()
 
+    # copies and pickles are PLAIN tensors with the same data: the host slot and its event stay with the step that made them
+    # (copy.deepcopy / torch.save of a logged scalar must not try to copy a torch.cuda.Event -- ADVICE r04)
+    def __deepcopy__(self, memo):
+        return self.as_subclass(torch.Tensor).detach().clone()
+
+    def __reduce_ex__(self, proto):
+        return self.as_subclass(torch.Tensor).detach().clone().__reduce_ex__(proto)
+
 
 class Trainer(object):
     def __init__(self, model, optimizer, cfg, device=None, optimizer_pose=None, pose_param_net=None,

@@ -1,8 +1,9 @@
 """GPU (-m gpu): coarse performance guards.  Parity tests cannot see a kernel that computes the right numbers ten times too slowly --
 it has happened twice: a launch sized for one workgroup (D = 128 weight gradient) and a `#pragma unroll` loop that
 silently stopped unrolling, putting the fp32 input-gradient kernel's register arrays into scratch memory (8x slower, every parity test
-green; csrc/build.py now checks the compiler's scratch report as well).  Bounds are 1.5x the durations measured on an MI355X (isolated
-launches, tools/time_kernels.py), per arithmetic mode: a 3x regression of one kernel used to pass the round-2 bounds."""
+green; csrc/build.py now checks the compiler's scratch report as well).  Bounds are 2x the durations measured on MI355X boxes (isolated
+launches, tools/time_kernels.py; the round's boxes differ by 10 % among themselves), per arithmetic mode -- the failures this guards against were
+8x and 170x; 1.5x of one box's best run (round 4) was a flake waiting for a slow box."""
 import os
 import sys
 
@@ -13,21 +14,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-# ms per launch, isolated launches: (R, N, mode) -> kernel -> bound = 1.5 x measured (round 3/4 boxes, the slower of the runs on record)
+# ms per launch, isolated launches: (R, N, mode) -> kernel -> bound = 2 x measured (round 3/4 boxes, the slower of the runs on record)
 BOUNDS = {
     # three-term products (the default fp32 arithmetic), round 4: measured 1.19-1.24 / 0.85-0.89 / 1.13-1.17 / 0.80-0.84
-    (1024, 192, "split3"): {"mlp_fwd": 1.85, "mlp_dgrad": 1.35, "mlp_wgrad": 1.75, "mlp_fwd_infer": 1.26},
+    (1024, 192, "split3"): {"mlp_fwd": 2.45, "mlp_dgrad": 1.8, "mlp_wgrad": 2.35, "mlp_fwd_infer": 1.7},
     # fp32 MFMAs (NNR_FP32_PRODUCTS=mfma): measured 1.69 / 1.54 / 1.56 / 1.46
-    (1024, 192, "mfma"): {"mlp_fwd": 2.55, "mlp_dgrad": 2.3, "mlp_wgrad": 2.35, "mlp_fwd_infer": 2.2},
+    (1024, 192, "mfma"): {"mlp_fwd": 3.4, "mlp_dgrad": 3.1, "mlp_wgrad": 3.1, "mlp_fwd_infer": 2.9},
     # bf16 products: measured 0.71 / 0.61 / 0.91 / 0.49
-    (4096, 128, "bf16"): {"mlp_fwd": 1.07, "mlp_dgrad": 0.92, "mlp_wgrad": 1.36, "mlp_fwd_infer": 0.74},
+    (4096, 128, "bf16"): {"mlp_fwd": 1.42, "mlp_dgrad": 1.22, "mlp_wgrad": 1.82, "mlp_fwd_infer": 0.98},
     # flat decomposition (N % 32 != 0), three-term: measured 0.74 / 0.66 / 0.67 / 0.55
-    (1000, 100, "split3"): {"mlp_fwd": 1.11, "mlp_dgrad": 1.0, "mlp_wgrad": 1.0, "mlp_fwd_infer": 0.83},
+    (1000, 100, "split3"): {"mlp_fwd": 1.48, "mlp_dgrad": 1.32, "mlp_wgrad": 1.34, "mlp_fwd_infer": 1.1},
 }
 
 
 @pytest.mark.parametrize("shape", sorted(BOUNDS))
-def test_mlp_kernels_stay_within_one_and_a_half_times_their_measured_durations(shape):
+def test_mlp_kernels_stay_within_twice_their_measured_durations(shape):
     import bench
     import model as mdl
     from nnr import lib as L
