@@ -89,14 +89,21 @@ def synthetic_batch(device, seed=42, depth_hw=None):
     f = 0.7 * IMG_W
     K = torch.diag(torch.tensor([2 * f / IMG_W, -2 * f / IMG_H, -1.0, 1.0])).unsqueeze(0)
     dh, dw = depth_hw or (IMG_H, IMG_W)
+    # the batch of a scene that is RESIDENT in HBM, as dataloading.ResidentLoader serves it (section 5 of DESIGN.md: inputs are device-resident):
+    # frame and neighbour are views of one scene tensor, the camera matrix is the scene's own tensor -- both flagged the way the loader flags
+    # them, so that the trainer may keep per-frame constants (the resized frames of the per-image losses, the inverse camera matrix)
+    frames = torch.rand(2, 3, IMG_H, IMG_W, generator=g).to(device)
+    frames._nnr_resident = True
+    Kd = K.to(device)
+    Kd._nnr_resident = True
     return {
-        'img': torch.rand(1, 3, IMG_H, IMG_W, generator=g).to(device),
+        'img': frames[0:1],
         'img.idx': 3,
         'img.dpt': (1 + 2 * torch.rand(1, dh, dw, generator=g)).to(device),
-        'img.camera_mat': K.to(device),
+        'img.camera_mat': Kd,
         'img.scale_mat': torch.eye(4).unsqueeze(0).to(device),
         # the neighbouring frame the per-image losses compare against (dataloading: ref_imgs / ref_dpts / ref_idxs)
-        'img.ref_imgs': torch.rand(1, 3, IMG_H, IMG_W, generator=g).to(device),
+        'img.ref_imgs': frames[1:2],
         'img.ref_dpts': (1 + 2 * torch.rand(1, dh, dw, generator=g)).to(device),
         'img.ref_idxs': 4,
     }

@@ -213,12 +213,18 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
  * independent inputs, the way autograd sees camera_mat and its inverse in reference model/common.py:112-160, 436-457).
  * Every sum is taken in a fixed order (per-block partials added in block order; shared-destination scatters in 64-bit fixed
  * point), so losses and gradients are bit-reproducible from run to run.
- * Both calls use the same workspace (nnr_aux_workspace_floats) and the same inputs. */
+ * Both calls use the same workspace (nnr_aux_workspace_floats) and the same inputs.
+ * NNR_AUX_AFFINE (ABI 5): d1_img / d2_img are the RAW mono-depth maps and `aff` = device (scale1, shift1, scale2, shift2) -- the per-image
+ * distortion of model/training.py:240-245, 294-296 ((depth + shift) * scale with NNR_AUX_SHIFT_FIRST) -- is applied to the sampled values
+ * inside the kernels; the backward then returns dL/d aff at g_rel_scale[40, 44) (44 floats) and needs no g_d*_img (pass NULL).  Without the
+ * flag `aff` must be NULL. */
 #define NNR_AUX_RGBS 1u         /* rgb_s_weight != 0 */
 #define NNR_AUX_PC 2u           /* pc_weight != 0 */
 #define NNR_AUX_SCALE_PCS 4u    /* training.scale_pcs */
 #define NNR_AUX_DETACH_RGBS 8u  /* training.detach_rgbs_scale */
 #define NNR_AUX_GRAD_K 32u      /* a learnable focal length: the backward also returns dL/dK and dL/dKinv (g_rel_scale has 40 floats) */
+#define NNR_AUX_AFFINE 64u      /* the depth distortion is applied in the kernels (aff) */
+#define NNR_AUX_SHIFT_FIRST 128u /* training.shift_first */
 #define NNR_AUX_SSIM 16u        /* training.with_ssim: 0.15 clamp|.| + 0.85 SSIM per re-projected colour (12 hr wr more workspace floats) */
 typedef struct nnr_aux_cfg {
     int32_t hd, wd, hr, wr;
@@ -233,10 +239,10 @@ typedef struct nnr_aux_cfg {
 } nnr_aux_cfg;
 size_t nnr_aux_workspace_floats(const nnr_aux_cfg* cfg);
 int nnr_aux_terms_fwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* d2_img, const float* img1r, const float* img2r,
-                      const float* K, const float* Kinv, const float* rel, const float* scale2, float* out, float* workspace,
-                      void* stream);
+                      const float* K, const float* Kinv, const float* rel, const float* scale2, const float* aff, float* out,
+                      float* workspace, void* stream);
 int nnr_aux_terms_bwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* d2_img, const float* img1r, const float* img2r,
-                      const float* K, const float* Kinv, const float* rel, const float* scale2, const float* g_out,
+                      const float* K, const float* Kinv, const float* rel, const float* scale2, const float* aff, const float* g_out,
                       float* g_d1_img, float* g_d2_img, float* g_rel_scale, float* workspace, void* stream);
 
 /* out[0..r) = torch.randperm(n, device=cuda)[:r] (the pixel pick of model/training.py:257) from the n int64 keys torch's
@@ -313,15 +319,23 @@ int nnr_adam_step(const nnr_adam_table* table, void* stream);
  * r_all, t_all (n_cams,3); scales, shifts (n_cams); K, S 4x4 row-major; ray_idx (n_rays) int64; depth_img (hd,wd) RAW mono depth;
  * img (3,h,w) or null.  Outputs as nnr_ray_setup_fwd, plus rgb_gt (n_rays,3) [if img], pixels (n_rays,2) and mats[34] = c2w (16),
  * world_mat (16), effective scale, shift.  Backward: d_r, d_t (n_cams,3), d_scales, d_shifts (n_cams) are OVERWRITTEN (zeros outside
- * row cam). */
+ * row cam).
+ * cfg->ref >= 0 (ABI 5): the step also carries the frame PAIR of the per-image losses (model/training.py:280-313): mats then holds 56
+ * floats -- [34, 50) rel = inverse(c2w_ref) inverse(world_mat) (the last camera: world_mat inverse(inverse(c2w_ref)), the roles swap),
+ * [50, 54) the two clouds' depth distortions (scale1, shift1, scale2, shift2) in the order nnr_aux_terms_* takes them, [54] the second
+ * cloud's scale -- what ~30 launches of se3_exp / inverse / matmul / indexing and their autograd made; the backward takes the upstream
+ * gradient of mats (g_mats, 56 floats, or NULL) and chains it into the same tables (NNR_STEP_DETACH_REF = training.detach_ref_img: nothing
+ * flows into the reference camera's rows). */
 #define NNR_STEP_NORMALISE 1u       /* rendering.normalise_ray */
 #define NNR_STEP_USE_DIR 2u         /* rendering.use_ray_dir */
 #define NNR_STEP_SHIFT_FIRST 4u     /* training.shift_first: (depth + shift) * scale */
 #define NNR_STEP_FIX_LAST_SCALE 8u  /* distortion.fix_scaleN */
+#define NNR_STEP_DETACH_REF 16u     /* training.detach_ref_img (with ref >= 0) */
 typedef struct nnr_step_cfg {
     int32_t n_rays, h, w, hd, wd; /* image size, mono-depth map size */
     int32_t cam, n_cams;
     uint32_t flags;
+    int32_t ref;                  /* the reference camera of the per-image losses, -1 = none */
 } nnr_step_cfg;
 int nnr_step_rays_fwd(const nnr_step_cfg* cfg, const float* r_all, const float* t_all, const float* scales, const float* shifts,
                       const float* K, const float* S, const int64_t* ray_idx, const float* depth_img, const float* img, float* pts_o,
@@ -329,8 +343,8 @@ int nnr_step_rays_fwd(const nnr_step_cfg* cfg, const float* r_all, const float* 
                       void* stream);
 int nnr_step_rays_bwd(const nnr_step_cfg* cfg, const float* r_all, const float* t_all, const float* scales, const float* shifts,
                       const float* K, const float* S, const int64_t* ray_idx, const float* depth_img, const float* g_pts_o,
-                      const float* g_dir, const float* g_view, const float* g_ray_norm, const float* g_d_gt, float* d_r, float* d_t,
-                      float* d_scales, float* d_shifts, void* stream);
+                      const float* g_dir, const float* g_view, const float* g_ray_norm, const float* g_d_gt, const float* g_mats,
+                      float* d_r, float* d_t, float* d_scales, float* d_shifts, void* stream);
 
 /* depth = nearest-resize(depth_img (hd,wd) -> (h,w)).flatten()[ray_idx]  (model/network.py:22-24) without materialising
  * the resized image; backward scatter-adds into a zero-filled (hd,wd) gradient image. */

@@ -840,6 +840,10 @@ static bool step_fill(const nnr_step_cfg* c, nnr::StepRaysArgs& a) {
     a.R = c->n_rays; a.h = c->h; a.w = c->w; a.hd = c->hd; a.wd = c->wd; a.cam = c->cam; a.n_cams = c->n_cams;
     a.normalise = (c->flags & NNR_STEP_NORMALISE) != 0; a.use_dir = (c->flags & NNR_STEP_USE_DIR) != 0;
     a.shift_first = (c->flags & NNR_STEP_SHIFT_FIRST) != 0; a.fix_last_scale = (c->flags & NNR_STEP_FIX_LAST_SCALE) != 0;
+    if (c->ref >= c->n_cams || c->ref == c->cam) return false;
+    a.ref = c->ref < 0 ? -1 : c->ref;
+    a.detach_ref = (c->flags & NNR_STEP_DETACH_REF) != 0;
+    a.g_mats = nullptr;
     return true;
 }
 int nnr_step_rays_fwd(const nnr_step_cfg* cfg, const float* r_all, const float* t_all, const float* scales, const float* shifts,
@@ -858,10 +862,11 @@ int nnr_step_rays_fwd(const nnr_step_cfg* cfg, const float* r_all, const float* 
 }
 int nnr_step_rays_bwd(const nnr_step_cfg* cfg, const float* r_all, const float* t_all, const float* scales, const float* shifts,
                       const float* K, const float* S, const int64_t* ray_idx, const float* depth_img, const float* g_pts_o,
-                      const float* g_dir, const float* g_view, const float* g_ray_norm, const float* g_d_gt, float* d_r, float* d_t,
-                      float* d_scales, float* d_shifts, void* stream) {
+                      const float* g_dir, const float* g_view, const float* g_ray_norm, const float* g_d_gt, const float* g_mats,
+                      float* d_r, float* d_t, float* d_scales, float* d_shifts, void* stream) {
     nnr::StepRaysArgs a{};
     if (!step_fill(cfg, a)) return NNR_E_BADCFG;
+    a.g_mats = g_mats;
     if (!r_all || !t_all || !scales || !shifts || !K || !S || !ray_idx || !depth_img || !d_r || !d_t || !d_scales || !d_shifts)
         return NNR_E_BADCFG;
     a.r_all = r_all; a.t_all = t_all; a.scales = scales; a.shifts = shifts; a.K = K; a.S = S; a.ray_idx = ray_idx;
@@ -980,7 +985,7 @@ size_t aux_fill(const nnr_aux_cfg* c, float* ws, nnr::AuxArgs& a) {   // returns
     a.acc = take(8);
     const int64_t nb = (S + 255) / 256;
     a.part_fwd = take(4 * nb);
-    a.part_bwd = take(40 * nb);
+    a.part_bwd = take(44 * nb);
     return (size_t)(p - ws);
 }
 }  // namespace
@@ -992,10 +997,13 @@ size_t nnr_aux_workspace_floats(const nnr_aux_cfg* cfg) {
 }
 
 int nnr_aux_terms_fwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* d2_img, const float* img1r, const float* img2r,
-                      const float* K, const float* Kinv, const float* rel, const float* scale2, float* out, float* ws, void* stream) {
+                      const float* K, const float* Kinv, const float* rel, const float* scale2, const float* aff, float* out, float* ws,
+                      void* stream) {
     nnr::AuxArgs a{};
     if (!ws || !aux_fill(cfg, ws, a)) return NNR_E_BADCFG;
     if (!d1_img || !d2_img || !K || !Kinv || !rel || !out) return NNR_E_BADCFG;
+    if (((cfg->flags & NNR_AUX_AFFINE) != 0) != (aff != nullptr)) return NNR_E_BADCFG;
+    a.aff = aff; a.shift_first = (cfg->flags & NNR_AUX_SHIFT_FIRST) != 0;
     if ((cfg->flags & NNR_AUX_RGBS) && (!img1r || !img2r)) return NNR_E_BADCFG;
     if ((cfg->flags & NNR_AUX_SCALE_PCS) && !scale2) return NNR_E_BADCFG;
     if (((uintptr_t)ws & 7) != 0) return NNR_E_ALIGN;
@@ -1005,11 +1013,13 @@ int nnr_aux_terms_fwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* 
 }
 
 int nnr_aux_terms_bwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* d2_img, const float* img1r, const float* img2r,
-                      const float* K, const float* Kinv, const float* rel, const float* scale2, const float* g_out, float* g_d1_img,
-                      float* g_d2_img, float* g_rel_scale, float* ws, void* stream) {
+                      const float* K, const float* Kinv, const float* rel, const float* scale2, const float* aff, const float* g_out,
+                      float* g_d1_img, float* g_d2_img, float* g_rel_scale, float* ws, void* stream) {
     nnr::AuxArgs a{};
     if (!ws || !aux_fill(cfg, ws, a)) return NNR_E_BADCFG;
     if (!d1_img || !d2_img || !K || !Kinv || !rel || !g_out || !g_rel_scale) return NNR_E_BADCFG;
+    if (((cfg->flags & NNR_AUX_AFFINE) != 0) != (aff != nullptr)) return NNR_E_BADCFG;
+    a.aff = aff; a.shift_first = (cfg->flags & NNR_AUX_SHIFT_FIRST) != 0;
     if ((cfg->flags & NNR_AUX_SCALE_PCS) && !scale2) return NNR_E_BADCFG;
     if (((uintptr_t)ws & 7) != 0) return NNR_E_ALIGN;
     a.d1_img = d1_img; a.d2_img = d2_img; a.img1r = img1r; a.img2r = img2r; a.K = K; a.Kinv = Kinv; a.rel = rel; a.scale2 = scale2;

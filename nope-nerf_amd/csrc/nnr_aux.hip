@@ -73,6 +73,12 @@ __device__ __forceinline__ AuxGeom aux_geometry(const AuxArgs& a, int i) {
     g.src1 = aux_nearest_src(y, a.hr, a.hd) * a.wd + aux_nearest_src(x, a.wr, a.wd);
     g.d1 = a.d1_img[g.src1];
     g.d2 = a.d2_img[g.src1];
+    if (a.aff) {      // NNR_AUX_AFFINE: the maps are the RAW mono depths, the per-image distortion is applied here (to the S sampled values
+                      // instead of hd x wd, and without the two launches + their autograd per map): model/training.py:240-245, 294-296
+        const float s1 = a.aff[0], t1 = a.aff[1], s2 = a.aff[2], t2 = a.aff[3];
+        g.d1 = a.shift_first ? __fmul_rn(__fadd_rn(g.d1, t1), s1) : __fadd_rn(__fmul_rn(g.d1, s1), t1);
+        g.d2 = a.shift_first ? __fmul_rn(__fadd_rn(g.d2, t2), s2) : __fadd_rn(__fmul_rn(g.d2, s2), t2);
+    }
     g.flags = 0;
     if (g.d1 < a.nl) { g.d1 = a.nl; g.flags |= kClamp1; }
     if (g.d2 < a.nl) { g.d2 = a.nl; g.flags |= kClamp2; }
@@ -344,7 +350,7 @@ __global__ void aux_pc_bwd_kernel(const float* src, const float* dst, const int6
 // d loss / d (d1, d2) of point i, the chain of gX, gY (point-cloud loss) and of the saved d(point loss)/d(xy) (re-projection loss)
 // back to the two depth values; with ACC also this point's contribution to dL/d rel[r][0..3] (r = 0..2), dL/d scale2 in acc[12] and --
 // NNR_AUX_GRAD_K, a learnable focal length -- dL/d K[r][0..3] in acc[13..25) and dL/d Kinv[r][0..3] in acc[25..37)
-constexpr int kAuxCols = 37, kAuxStride = 40;
+constexpr int kAuxCols = 41, kAuxStride = 44;      // [37, 41): dL/d (scale1, shift1, scale2, shift2) of NNR_AUX_AFFINE
 template <bool ACC>
 __device__ __forceinline__ void aux_point_grads(const AuxArgs& a, int i, float& gd1, float& gd2, uint32_t& fl, int& src1,
                                                 float (&acc)[kAuxCols]) {
@@ -437,6 +443,11 @@ __global__ __launch_bounds__(256) void aux_points_bwd_kernel(AuxArgs a) {
         uint32_t fl;
         int src1;
         aux_point_grads<true>(a, i, gd1, gd2, fl, src1, acc);
+        if (a.aff) {      // d depth / d (scale, shift) = (raw, 1), or (raw + shift, scale) with shift_first; a clamped depth passes nothing
+            const float r1 = a.d1_img[src1], r2 = a.d2_img[src1];
+            if (!(fl & kClamp1)) { acc[37] = gd1 * (a.shift_first ? r1 + a.aff[1] : r1); acc[38] = gd1 * (a.shift_first ? a.aff[0] : 1.f); }
+            if (!(fl & kClamp2)) { acc[39] = gd2 * (a.shift_first ? r2 + a.aff[3] : r2); acc[40] = gd2 * (a.shift_first ? a.aff[2] : 1.f); }
+        }
         if (a.g_d1_img || a.g_d2_img) {
             const int y = i / a.wr, x = i - y * a.wr;
             const int sy = aux_nearest_src(y, a.hr, a.hd), sx = aux_nearest_src(x, a.wr, a.wd);
@@ -458,17 +469,17 @@ __global__ __launch_bounds__(256) void aux_points_bwd_kernel(AuxArgs a) {
             }
         }
     }
-    const int cols = (a.flags & NNR_AUX_GRAD_K) ? kAuxCols : 13;
+    const bool grad_k = (a.flags & NNR_AUX_GRAD_K) != 0;
 #pragma unroll
     for (int k = 0; k < kAuxCols; ++k) {
-        if (k >= cols) break;
+        if ((k >= 13 && k < 37 && !grad_k) || (k >= 37 && !a.aff)) continue;      // (wave-uniform: the barrier inside block_sum is safe)
         const float bs = block_sum(acc[k], scratch);
         if (threadIdx.x == 0) a.part_bwd[kAuxStride * blockIdx.x + k] = bs;
     }
 }
 
-// g_rel_scale[16 (40 with NNR_AUX_GRAD_K)] = block partials summed in block order (bit-reproducible): columns 0..12 at [0, 13), the K
-// and Kinv columns 13..36 at [16, 40)
+// g_rel_scale[16 (40 with NNR_AUX_GRAD_K, 44 with NNR_AUX_AFFINE)] = block partials summed in block order (bit-reproducible): columns 0..12
+// at [0, 13), the K and Kinv columns 13..36 at [16, 40), the distortion columns 37..40 at [40, 44)
 __global__ __launch_bounds__(64) void aux_bwd_finish_kernel(AuxArgs a, float* g_rel_scale) {
     const int nb = (a.S + 255) / 256;
     const int n_out = (a.flags & NNR_AUX_GRAD_K) ? 40 : 16;
@@ -476,6 +487,12 @@ __global__ __launch_bounds__(64) void aux_bwd_finish_kernel(AuxArgs a, float* g_
         const int col = k < 13 ? k : (k >= 16 ? k - 3 : -1);
         const float t = col >= 0 ? ordered_column_sum(a.part_bwd, nb, kAuxStride, col) : 0.f;
         if (threadIdx.x == 0) g_rel_scale[k] = t;
+    }
+    if (a.aff) {      // NNR_AUX_AFFINE: dL/d (scale1, shift1, scale2, shift2) at [40, 44)
+        for (int k = 0; k < 4; ++k) {
+            const float t = ordered_column_sum(a.part_bwd, nb, kAuxStride, 37 + k);
+            if (threadIdx.x == 0) g_rel_scale[40 + k] = t;
+        }
     }
 }
 

@@ -417,6 +417,29 @@ __device__ __forceinline__ void step_scale_shift(const StepRaysArgs& a, float& s
         scale = scale_live ? raw : 0.01f;
     }
 }
+// the reference camera of the per-image losses: its pose, the relative transform of the pair, its depth distortion
+struct PairGeom { M4 c2w_ref, ref_rt, other_inv, rel; float scale_ref, shift_ref; bool ref_live; };
+__device__ __forceinline__ PairGeom pair_geometry(const StepRaysArgs& a, const M4& W) {
+    PairGeom g;
+    se3_exp_matrix(a.r_all + 3 * a.ref, a.t_all + 3 * a.ref, g.c2w_ref.m);
+    g.ref_rt = inv4(g.c2w_ref);
+    if (a.cam < a.n_cams - 1) {
+        g.other_inv = inv4(W);                       // inverse(world_mat): the trainer inverts numerically, so does this
+        g.rel = mul4(g.ref_rt, g.other_inv);
+    } else {
+        g.other_inv = inv4(g.ref_rt);
+        g.rel = mul4(W, g.other_inv);
+    }
+    g.shift_ref = a.shifts[a.ref];
+    g.scale_ref = 1.f;
+    g.ref_live = false;
+    if (!(a.fix_last_scale && a.ref == a.n_cams - 1)) {
+        const float raw = a.scales[a.ref];
+        g.ref_live = !(raw < 0.01f);
+        g.scale_ref = g.ref_live ? raw : 0.01f;
+    }
+    return g;
+}
 __device__ __forceinline__ void step_matrices(const StepRaysArgs& a, M4& c2w, M4& W, RaySetupArgs& rs) {
     se3_exp_matrix(a.r_all + 3 * a.cam, a.t_all + 3 * a.cam, c2w.m);
     W = inv4(c2w);
@@ -443,6 +466,18 @@ __global__ __launch_bounds__(256) void step_rays_fwd_kernel(StepRaysArgs a) {
         for (int k = 0; k < 16; ++k) { a.mats[k] = c2w.m[k]; a.mats[16 + k] = W.m[k]; }
         a.mats[32] = scale;
         a.mats[33] = shift;
+        if (a.ref >= 0) {
+            // The frame pair of the per-image losses (model/training.py:280-313): rel = ref_rt inverse(world_mat), or -- the last camera
+            // takes the roles the other way round -- world_mat inverse(ref_rt), with ref_rt = inverse(c2w_ref); the two distortions in the
+            // order (first cloud, second cloud) of nnr_aux_terms_*; scale2 = the second cloud's scale.
+            PairGeom pg = pair_geometry(a, W);
+            for (int k = 0; k < 16; ++k) a.mats[34 + k] = pg.rel.m[k];
+            const bool swap = a.cam == a.n_cams - 1;
+            a.mats[50] = swap ? pg.scale_ref : scale;  a.mats[51] = swap ? pg.shift_ref : shift;
+            a.mats[52] = swap ? scale : pg.scale_ref;  a.mats[53] = swap ? shift : pg.shift_ref;
+            a.mats[54] = swap ? scale : pg.scale_ref;
+            a.mats[55] = 0.f;
+        }
     }
     if (i >= a.R) return;
     float px, py, raw;
@@ -565,13 +600,45 @@ __global__ __launch_bounds__(kStepBwdThreads) void step_rays_bwd_kernel(StepRays
     for (int k = 12; k < 16; ++k) dm.m[k] = 0.f;
     float tot_s = 0.f, tot_h = 0.f;
     for (int w = 0; w < kStepBwdThreads / 64; ++w) { tot_s += red[12][w]; tot_h += red[13][w]; }
-    if (live) a.d_scales[a.cam] = tot_s;
-    a.d_shifts[a.cam] = tot_h;
     // dL/dM (12 sums) -> dL/dW through M = (S^-1 W^-1) K^-1, W^-1 = inv4(W); then W = inv4(c2w); then c2w = exp(r, t)
     const M4 kinv = load4(park[0]), winv = load4(park[1]), sinv = load4(park[2]), W = load4(park[3]);
     const M4 d_sw = mul4(dm, transpose4(kinv));
     const M4 d_winv = mul4(transpose4(sinv), d_sw);
-    const M4 gw = inv_backward(winv, d_winv);                // d loss / d world_mat
+    M4 gw = inv_backward(winv, d_winv);                      // d loss / d world_mat
+    if (a.ref >= 0 && a.g_mats) {
+        // the per-image losses' share (upstream gradient of mats[34, 55)): the relative transform chains into world_mat (and, unless the
+        // reference side is detached -- training.detach_ref_img, the default -- into the reference pose), the pair's distortion entries
+        // into the two cameras' rows
+        const PairGeom pg = pair_geometry(a, W);
+        M4 g_rel;
+        for (int k = 0; k < 12; ++k) g_rel.m[k] = a.g_mats[34 + k];
+        for (int k = 12; k < 16; ++k) g_rel.m[k] = 0.f;
+        const bool swap = a.cam == a.n_cams - 1;
+        M4 g_ref_rt;
+        if (!swap) {      // rel = ref_rt inv(W)
+            g_ref_rt = mul4(g_rel, transpose4(pg.other_inv));
+            const M4 g_winv = mul4(transpose4(pg.ref_rt), g_rel);
+            const M4 add = inv_backward(pg.other_inv, g_winv);
+            for (int k = 0; k < 16; ++k) gw.m[k] += add.m[k];
+        } else {          // rel = W inv(ref_rt)
+            const M4 add = mul4(g_rel, transpose4(pg.other_inv));
+            for (int k = 0; k < 16; ++k) gw.m[k] += add.m[k];
+            const M4 g_inv = mul4(transpose4(W), g_rel);
+            g_ref_rt = inv_backward(pg.other_inv, g_inv);
+        }
+        const float g_s_in = a.g_mats[swap ? 52 : 50] + (swap ? a.g_mats[54] : 0.f), g_h_in = a.g_mats[swap ? 53 : 51];
+        const float g_s_ref = a.g_mats[swap ? 50 : 52] + (swap ? 0.f : a.g_mats[54]), g_h_ref = a.g_mats[swap ? 51 : 53];
+        tot_s += g_s_in;
+        tot_h += g_h_in;
+        if (!a.detach_ref) {
+            const M4 g_c2w_ref = inv_backward(pg.ref_rt, g_ref_rt);
+            se3_exp_grad(a.r_all + 3 * a.ref, g_c2w_ref.m, a.d_r + 3 * a.ref, a.d_t + 3 * a.ref);
+            if (pg.ref_live) a.d_scales[a.ref] = g_s_ref;
+            a.d_shifts[a.ref] = g_h_ref;
+        }
+    }
+    if (live) a.d_scales[a.cam] = tot_s;
+    a.d_shifts[a.cam] = tot_h;
     const M4 gc = inv_backward(W, gw);                       // d loss / d c2w
     se3_exp_grad(a.r_all + 3 * a.cam, gc.m, a.d_r + 3 * a.cam, a.d_t + 3 * a.cam);
 }

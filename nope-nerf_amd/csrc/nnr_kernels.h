@@ -130,6 +130,10 @@ struct StepRaysArgs {
     // backward
     const float *g_o, *g_dir, *g_view, *g_norm, *g_dgt;   // upstream gradients (any may be null)
     float *d_r, *d_t, *d_scales, *d_shifts;               // full tables, overwritten
+    // the frame pair of the per-image losses (ref >= 0): mats[34, 56) = rel (16), the pair's distortions (s1, t1, s2, t2), scale2, 0;
+    // backward: g_mats = the upstream gradient of mats (may be null), detach_ref = training.detach_ref_img
+    int ref, detach_ref;
+    const float* g_mats;
 };
 
 struct LossArgs {
@@ -175,6 +179,8 @@ struct AuxArgs {
     const float *img1r, *img2r;     // (3, hr, wr) images resized to the sampling grid
     const float *K, *Kinv, *rel;    // 4x4 row-major
     const float* scale2;            // device scalar (read only with NNR_AUX_SCALE_PCS)
+    const float* aff;               // NNR_AUX_AFFINE: device (scale1, shift1, scale2, shift2) applied to the RAW maps d1_img / d2_img here; else null
+    int shift_first;                // NNR_AUX_SHIFT_FIRST: (depth + shift) * scale
     int hd, wd, hr, wr, S;
     int s_lo, s_hi;                 // this rank's shard of the source points (data parallelism): [0, S) on one GPU
     float nl;

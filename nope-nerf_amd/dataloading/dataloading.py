@@ -93,9 +93,12 @@ class ResidentLoader(object):
                 ResidentLoader._uploaded[key] = t
             return t
         self.imgs = up(field.imgs) if field.mode != 'render' else None
+        if self.imgs is not None:
+            self.imgs._nnr_resident = True      # views of it may be cached per frame by their consumers (model.Trainer._resized)
         self.dpt = up(field.dpt_depth) if (field.dpt_depth is not None and field.mode != 'render') else None
         self.depth = up(field.depth) if (field.with_depth and field.mode != 'render') else None
         self.K = up(field.K).unsqueeze(0)
+        self.K._nnr_resident = True
         self.eye = torch.eye(4, device=device).unsqueeze(0)
         self.dataset = self.order.dataset
 

@@ -119,6 +119,8 @@ class Trainer(object):
         hook._trainer = ref
         _ck.PRE_SAVE_HOOKS.append(hook)
         self.fuse_front_end = bool(cfg.get('fuse_front_end', True))   # training.fuse_front_end: False keeps the separate launches
+        self.fuse_pair = bool(cfg.get('fuse_pair', True))             # training.fuse_pair: False keeps the first phase on the separate launches
+        self._resize_cache, self._kinv_cache = {}, None
         # training.adam_arithmetic: WHICH of torch's two Adam arithmetics the step's updates carry out (nnr/optim.py).  "single" (default) =
         # torch's single-tensor implementation, i.e. what the plain optim.Adam objects of the reference's train.py:58,99,117,140 do (host
         # step counters, float moments); "fused" = torch's fused=True flavour (double-precision moments rounded once), the default of
@@ -282,13 +284,23 @@ class Trainer(object):
         # depths, colour targets and rays in ONE launch each way instead of ~9 forward and ~14 backward ones.  Same arithmetic in the
         # same order; taken whenever nothing needs the intermediate tensors (the per-image losses read the whole distorted map, a
         # learnable focal rebuilds K inside the graph, an initial pose multiplies onto c2w).
-        fused_front = (img.is_cuda and render_model and not use_ref_imgs and self.distortion_net is not None and not self.optimizer_focal
-                       and getattr(self.pose_param_net, 'init_c2w', None) is None and self.rendering_technique == 'nope_nerf'
-                       and getattr(self.pose_param_net, 'r', None) is not None and self.fuse_front_end)
+        fusable = (img.is_cuda and render_model and self.distortion_net is not None and not self.optimizer_focal
+                   and getattr(self.pose_param_net, 'init_c2w', None) is None and self.rendering_technique == 'nope_nerf'
+                   and getattr(self.pose_param_net, 'r', None) is not None and self.fuse_front_end)
+        # Round 5: the first training phase takes it too.  The frame PAIR of the per-image losses rides along in the same two launches
+        # (reference pose, inverses, relative transform, the reference frame's distortion: mats[34:55]) and the per-image block applies the
+        # distortions to its sampled depths itself (nnr.aux, `aff`) -- no distorted full-size depth map, no se3_exp / inverse / matmul /
+        # indexing launches and none of their autograd.  Not for the steps that dump the re-projection images (they want the intermediates).
+        dump_reproj = (use_ref_imgs and weights['rgb_s_weight'] != 0.0 and (it % self.vis_reprojection_every) == 0 and out_render_path is not None)
+        fused_pair = bool(fusable and use_ref_imgs and batch_size == 1 and not dump_reproj and self.fuse_pair)
+        fused_front = bool(fusable and (not use_ref_imgs or fused_pair))
         scale_input = shift_input = None
         depth_affine = None
         rays = None
+        pair = None
         if fused_front:
+            if fused_pair:
+                ref_img, depth_ref_raw, ref_idx = self.process_data_reference(data)
             ray_idx = sampling.randperm_prefix(h * w, n_points, device)   # == torch.randperm(h * w, device=device)[:n_points]
             n_total = ray_idx.shape[0]
             lo, hi = parallel.shard_bounds(n_total, rank, world)
@@ -298,7 +310,10 @@ class Trainer(object):
                 self.pose_param_net.r, self.pose_param_net.t, self.distortion_net.global_scales, self.distortion_net.global_shifts,
                 depth_input, img, ray_loc, camera_mat_gt, scale_mat, cam=int(img_idx), h=h, w=w,
                 fix_last_scale=bool(self.distortion_net.fix_scaleN), shift_first=bool(self.shift_first),
-                normalise=bool(rcfg['normalise_ray']), use_dir=bool(rcfg['use_ray_dir']))
+                normalise=bool(rcfg['normalise_ray']), use_dir=bool(rcfg['use_ray_dir']),
+                ref=int(ref_idx) if fused_pair else -1, detach_ref=bool(self.detach_ref_img))
+            if fused_pair:
+                pair = (mats, ref_img, depth_ref_raw, int(ref_idx))
             rgb_gt = rgb_gt.unsqueeze(0)
             world_mat = mats[16:32].view(1, 4, 4)
             scale_input, shift_input = mats[32:33], mats[33:34]
@@ -352,7 +367,9 @@ class Trainer(object):
                 if self.detach_gt_depth:
                     gt_depth = gt_depth.detach()
 
-        if use_ref_imgs:
+        if use_ref_imgs and pair is not None:
+            self._pair_terms(kwargs, pair, img, depth_input, camera_mat, img_idx, num_cams, h_depth, w_depth, weights)
+        elif use_ref_imgs:
             self._reference_terms(kwargs, data, img, depth_input, camera_mat, world_mat, scale_input, img_idx, num_cams,
                                   h_depth, w_depth, weights, it, out_render_path)
 
@@ -490,6 +507,54 @@ class Trainer(object):
         if depth_affine is not None:
             d_all = (d_all + depth_affine[1]) * depth_affine[0] if depth_affine[2] else d_all * depth_affine[0] + depth_affine[1]
         return d_all.reshape(-1)
+
+    def _pair_terms(self, kwargs, pair, img, depth_raw, camera_mat, img_idx, num_cams, h_depth, w_depth, weights):
+        """The per-image block behind the fused front end (round 5): everything it needs beyond the frames themselves -- relative transform,
+        the two distortions in cloud order, scale2 -- is in `mats` (nnr.camera.step_rays with ref >= 0); the depth maps stay RAW.
+        Same losses as _reference_terms (reference training.py:280-365; pinned by the reference goldens of tests/test_aux_terms.py)."""
+        from nnr import aux as nnr_aux
+        mats, ref_img, depth_ref_raw, ref_idx = pair
+        swap = not (img_idx < (num_cams - 1))               # the last camera takes the roles the other way round (training.py:301-311)
+        raw1, raw2 = (depth_ref_raw, depth_raw) if swap else (depth_raw, depth_ref_raw)
+        img1, img2 = (ref_img, img) if swap else (img, ref_img)
+        res = (int(h_depth / self.pc_ratio), int(w_depth / self.pc_ratio))
+        world = parallel.world_size()
+        shard = parallel.shard_bounds(res[0] * res[1], parallel.rank(), world) if world > 1 else None
+        if shard is not None:
+            kwargs['point_shard'] = shard
+        rgb_s = weights['rgb_s_weight'] != 0.0
+        i1 = self._resized(img1, res) if rgb_s else None
+        i2 = self._resized(img2, res) if rgb_s else None
+        l_pc, l_rgbs, _ = nnr_aux.aux_terms(raw1, raw2, mats[34:50].view(1, 4, 4), mats[54:55], i1, i2, camera_mat, self._constant_inverse(camera_mat),
+                                            res, self.nearest_limit, rgb_s=rgb_s, pc=weights['pc_weight'] != 0.0, scale_pcs=bool(self.scale_pcs),
+                                            detach_rgbs_scale=self.detach_rgbs_scale, ssim=self.loss.cfg['with_ssim'] == True,  # noqa: E712 (YAML)
+                                            shard=shard or (0, 0), aff=mats[50:54], shift_first=bool(self.shift_first))
+        kwargs.update(fused_aux=(l_pc, l_rgbs), sample_resolution=res)
+
+    def _resized(self, frame, res):
+        """F.interpolate(frame, res, mode='bilinear') -- for a frame that is a view of a RESIDENT scene tensor (dataloading.ResidentLoader: the
+        storage lives for the whole run and is never rewritten) the result is computed once per (frame, resolution) and kept: two launches
+        per step less.  Any other frame is resized every time."""
+        base = getattr(frame, '_base', None)
+        if base is None or not getattr(base, '_nnr_resident', False):
+            return F.interpolate(frame, res, mode='bilinear')
+        key = (frame.data_ptr(), tuple(frame.shape), tuple(res))
+        hit = self._resize_cache.get(key)
+        if hit is None:
+            if len(self._resize_cache) >= 4096:
+                self._resize_cache.clear()
+            hit = self._resize_cache[key] = F.interpolate(frame, res, mode='bilinear').detach()
+        return hit
+
+    def _constant_inverse(self, m):
+        """inverse of the camera matrix: for the matrix of a RESIDENT scene (dataloading.ResidentLoader hands the same tensor over every step,
+        and nothing writes to it) computed once; any other tensor is inverted every time (one launch)."""
+        if m.requires_grad or not getattr(m, '_nnr_resident', False):
+            return self._inverse(m)
+        key = (m.data_ptr(), m._version)
+        if self._kinv_cache is None or self._kinv_cache[0] != key:
+            self._kinv_cache = (key, self._inverse(m).detach())
+        return self._kinv_cache[1]
 
     def _reference_terms(self, kwargs, data, img, depth_input, camera_mat, world_mat, scale_input, img_idx, num_cams,
                          h_depth, w_depth, weights, it, out_render_path):

@@ -14,7 +14,7 @@ def _st():
 
 class _AuxTerms(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, d1_img, d2_img, rel, scale2, img1r, img2r, K, Kinv, hr, wr, nl, flags, shard):
+    def forward(ctx, d1_img, d2_img, rel, scale2, img1r, img2r, K, Kinv, hr, wr, nl, flags, shard, aff=None):
         lib = L.load()
         dev = d1_img.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -22,6 +22,8 @@ class _AuxTerms(torch.autograd.Function):
         hd, wd = d1.shape[-2:]
         if K.requires_grad or Kinv.requires_grad:      # a learnable focal length (reference model/training.py:247-252)
             flags |= L.AUX_GRAD_K
+        if aff is not None:                            # the maps are RAW; (scale1, shift1, scale2, shift2) is applied in the kernels
+            flags |= L.AUX_AFFINE
         cfg = L.AuxCfg(int(hd), int(wd), int(hr), int(wr), float(nl), int(flags), int(shard[0]), int(shard[1]))
         n_ws = lib.nnr_aux_workspace_floats(C.byref(cfg))
         if n_ws == 0:
@@ -33,31 +35,36 @@ class _AuxTerms(torch.autograd.Function):
         i1 = img1r.detach().contiguous().float() if img1r is not None else None
         i2 = img2r.detach().contiguous().float() if img2r is not None else None
         out = torch.empty(4, **f32)
+        af = aff.detach().reshape(4).contiguous().float() if aff is not None else None
         p = lambda t: L.ptr(t) if t is not None else None
-        L.check(lib.nnr_aux_terms_fwd(C.byref(cfg), p(d1), p(d2), p(i1), p(i2), p(K_c), p(Kinv_c), p(rel_c), p(s2), p(out), p(ws),
+        L.check(lib.nnr_aux_terms_fwd(C.byref(cfg), p(d1), p(d2), p(i1), p(i2), p(K_c), p(Kinv_c), p(rel_c), p(s2), p(af), p(out), p(ws),
                                       _st()), "nnr_aux_terms_fwd")
         ctx.cfg, ctx.ws = cfg, ws
-        ctx.tensors = (d1, d2, i1, i2, K_c, Kinv_c, rel_c, s2)
+        ctx.tensors = (d1, d2, i1, i2, K_c, Kinv_c, rel_c, s2, af)
         ctx.shapes = (d1_img.shape, d2_img.shape, rel.shape, None if scale2 is None else scale2.shape, K.shape, Kinv.shape)
+        ctx.aff_shape = None if aff is None else aff.shape
         ctx.set_materialize_grads(False)
         return out[0], out[1], out[2]
 
     @staticmethod
     def backward(ctx, g_pc, g_rgbs, _g_count):
         lib = L.load()
-        d1, d2, i1, i2, K_c, Kinv_c, rel_c, s2 = ctx.tensors
+        d1, d2, i1, i2, K_c, Kinv_c, rel_c, s2, af = ctx.tensors
         need_d1, need_d2, need_rel, need_s2 = ctx.needs_input_grad[:4]
         f32 = dict(dtype=torch.float32, device=d1.device)
-        g_out = torch.zeros(2, **f32)
-        if g_pc is not None:
-            g_out[0] = g_pc
-        if g_rgbs is not None:
-            g_out[1] = g_rgbs
-        g_d1 = torch.zeros_like(d1) if need_d1 else None
-        g_d2 = torch.zeros_like(d2) if need_d2 else None
-        g_rs = torch.empty(40, **f32)
+        if g_pc is not None and g_rgbs is not None:      # (the usual case: one launch instead of a fill and two copies)
+            g_out = torch.stack([g_pc.reshape(()).float(), g_rgbs.reshape(()).float()])
+        else:
+            g_out = torch.zeros(2, **f32)
+            if g_pc is not None:
+                g_out[0] = g_pc
+            if g_rgbs is not None:
+                g_out[1] = g_rgbs
+        g_d1 = torch.zeros_like(d1) if (need_d1 and af is None) else None
+        g_d2 = torch.zeros_like(d2) if (need_d2 and af is None) else None
+        g_rs = torch.empty(44, **f32)
         p = lambda t: L.ptr(t) if t is not None else None
-        L.check(lib.nnr_aux_terms_bwd(C.byref(ctx.cfg), p(d1), p(d2), p(i1), p(i2), p(K_c), p(Kinv_c), p(rel_c), p(s2), p(g_out),
+        L.check(lib.nnr_aux_terms_bwd(C.byref(ctx.cfg), p(d1), p(d2), p(i1), p(i2), p(K_c), p(Kinv_c), p(rel_c), p(s2), p(af), p(g_out),
                                       p(g_d1), p(g_d2), p(g_rs), p(ctx.ws), _st()), "nnr_aux_terms_bwd")
         sh1, sh2, shr, shs, shk, shki = ctx.shapes
         rows = lambda lo, shape: torch.cat([g_rs[lo:lo + 12], torch.zeros(4, **f32)]).view(shape)      # the last row is not read
@@ -66,20 +73,25 @@ class _AuxTerms(torch.autograd.Function):
         grad_k = bool(ctx.cfg.flags & L.AUX_GRAD_K)
         g_k = rows(16, shk) if (grad_k and ctx.needs_input_grad[6]) else None
         g_kinv = rows(28, shki) if (grad_k and ctx.needs_input_grad[7]) else None
-        return (g_d1.view(sh1) if need_d1 else None, g_d2.view(sh2) if need_d2 else None, g_rel, g_s2,
-                None, None, g_k, g_kinv, None, None, None, None, None)
+        g_aff = g_rs[40:44].view(ctx.aff_shape) if (af is not None and ctx.needs_input_grad[13]) else None
+        return (g_d1.view(sh1) if g_d1 is not None else None, g_d2.view(sh2) if g_d2 is not None else None, g_rel, g_s2,
+                None, None, g_k, g_kinv, None, None, None, None, None, g_aff)
 
 
 def aux_terms(d1_img, d2_img, rel, scale2, img1r, img2r, K, Kinv, res, nearest_limit, *, rgb_s=True, pc=True, scale_pcs=True,
-              detach_rgbs_scale=False, ssim=False, shard=(0, 0)):
+              detach_rgbs_scale=False, ssim=False, shard=(0, 0), aff=None, shift_first=False):
     """(loss_pc, loss_rgb_s, n_valid) for one frame pair.  d1_img/d2_img: (..., hd, wd) depth maps (scaled + shifted), rel:
     (..., 4, 4) relative transform, scale2: scalar tensor, img1r/img2r: (..., 3, hr, wr), K/Kinv: (..., 4, 4).
     ssim: training.with_ssim (reference losses.py:153-155).
     shard = (lo, hi): data parallelism -- only the sums over the source points [lo, hi) of the res[0]*res[1] grid, with the global
-    normalisers, so that the SUM over ranks is the single-GPU loss / gradient ((0, 0) = all points)."""
+    normalisers, so that the SUM over ranks is the single-GPU loss / gradient ((0, 0) = all points).
+    aff = (4,) tensor (scale1, shift1, scale2, shift2): d1_img / d2_img are then the RAW mono-depth maps and the per-image distortion
+    (shift_first: (depth + shift) * scale) is applied to the sampled values inside the kernels; its gradient comes back as one (4,) tensor
+    instead of two depth-map-sized gradient images and their reductions."""
     if not d1_img.is_cuda:
         raise RuntimeError("nnr.aux needs CUDA tensors (no CPU fallback)")
     flags = (L.AUX_RGBS if rgb_s else 0) | (L.AUX_PC if pc else 0) | (L.AUX_SCALE_PCS if scale_pcs else 0) | \
-            (L.AUX_DETACH_RGBS if detach_rgbs_scale else 0) | (L.AUX_SSIM if (ssim and rgb_s) else 0)
+            (L.AUX_DETACH_RGBS if detach_rgbs_scale else 0) | (L.AUX_SSIM if (ssim and rgb_s) else 0) | \
+            (L.AUX_SHIFT_FIRST if (shift_first and aff is not None) else 0)
     return _AuxTerms.apply(d1_img, d2_img, rel, scale2 if scale_pcs else None, img1r, img2r, K, Kinv, int(res[0]), int(res[1]),
-                           float(nearest_limit), flags, tuple(shard))
+                           float(nearest_limit), flags, tuple(shard), aff)

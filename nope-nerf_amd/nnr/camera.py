@@ -91,7 +91,7 @@ class _RaySetup(torch.autograd.Function):
         pix, dep, k, w, s = ctx.saved_tensors
         R, dev = pix.shape[0], pix.device
         opt = lambda g: _f32(g) if g is not None else None
-        g_o, g_dir, g_view, g_norm, g_dgt = (opt(g) for g in (g_o, g_dir, g_view, g_norm, g_dgt))
+        g_o, g_dir, g_view, g_norm, g_dgt, g_mats = (opt(g) for g in (g_o, g_dir, g_view, g_norm, g_dgt, _gmat))
         f = dict(dtype=torch.float32, device=dev)
         d_depth = torch.empty(R, **f) if dep is not None else None
         out = torch.empty(3 * 16 + 12, **f)
@@ -254,7 +254,7 @@ class _StepRays(torch.autograd.Function):
     @staticmethod
     def forward(ctx, r_all, t_all, scales, shifts, depth_img, img, ray_idx, K, S, meta):
         import ctypes as C
-        cam, h, w, fix_last, shift_first, normalise, use_dir = meta
+        cam, h, w, fix_last, shift_first, normalise, use_dir, ref, detach_ref = meta
         r, t, sc, sh = _f32(r_all), _f32(t_all), _f32(scales).reshape(-1), _f32(shifts).reshape(-1)
         dimg = _f32(depth_img)
         hd, wd = dimg.shape[-2:]
@@ -264,7 +264,8 @@ class _StepRays(torch.autograd.Function):
         im = _f32(img).reshape(3, h * w) if img is not None else None
         cfg = L.StepCfg(R, int(h), int(w), int(hd), int(wd), int(cam), int(r.shape[0]),
                         (L.STEP_NORMALISE if normalise else 0) | (L.STEP_USE_DIR if use_dir else 0) |
-                        (L.STEP_SHIFT_FIRST if shift_first else 0) | (L.STEP_FIX_LAST_SCALE if fix_last else 0))
+                        (L.STEP_SHIFT_FIRST if shift_first else 0) | (L.STEP_FIX_LAST_SCALE if fix_last else 0) |
+                        (L.STEP_DETACH_REF if detach_ref else 0), int(ref))
         f = dict(dtype=torch.float32, device=dev)
         # one allocation for the per-ray float outputs: pts_o, dir, view, rgb_gt (3 each), pixels (2), ray_norm, d_gt (1 each)
         flat = torch.empty(R * 16, **f)
@@ -272,7 +273,7 @@ class _StepRays(torch.autograd.Function):
         pixels = flat[12 * R: 14 * R].view(1, R, 2)
         norm, d_gt = flat[14 * R: 15 * R], flat[15 * R: 16 * R]
         mask = torch.empty(R, dtype=torch.bool, device=dev)
-        mats = torch.empty(34, **f)
+        mats = torch.empty(56 if ref >= 0 else 34, **f)
         L.check(L.load().nnr_step_rays_fwd(C.byref(cfg), L.ptr(r), L.ptr(t), L.ptr(sc), L.ptr(sh), L.ptr(k), L.ptr(s), L.ptr(idx),
                                            L.ptr(dimg), L.ptr(im), L.ptr(pts_o), L.ptr(dirs), L.ptr(view), L.ptr(norm), L.ptr(d_gt),
                                            L.ptr(mask), L.ptr(rgb_gt) if im is not None else None, L.ptr(pixels), L.ptr(mats), _st()),
@@ -282,8 +283,12 @@ class _StepRays(torch.autograd.Function):
         ctx.shapes = (tuple(r_all.shape), tuple(t_all.shape), tuple(scales.shape), tuple(shifts.shape))
         # the gauge (model/distortions.py: the last camera's scale is torch.ones_like): the scale table is not part of that step's
         # graph, its .grad stays None and Adam skips it -- a zero-filled gradient would still move it by momentum
-        ctx.gauge = bool(fix_last) and int(cam) == int(r.shape[0]) - 1 and int(sc.shape[0]) == int(r.shape[0])
-        ctx.mark_non_differentiable(mask, rgb_gt, pixels, mats)
+        ctx.gauge = (bool(fix_last) and int(cam) == int(r.shape[0]) - 1 and int(sc.shape[0]) == int(r.shape[0])
+                     and (ref < 0 or detach_ref))      # (a live reference camera keeps the scale table in the graph through its own row)
+        if ref >= 0:      # the pair entries of mats (rel, the two distortions, scale2) carry the per-image losses' gradients back
+            ctx.mark_non_differentiable(mask, rgb_gt, pixels)
+        else:
+            ctx.mark_non_differentiable(mask, rgb_gt, pixels, mats)
         ctx.set_materialize_grads(False)
         return pts_o, dirs, view, norm, d_gt, mask, rgb_gt, pixels, mats
 
@@ -292,22 +297,27 @@ class _StepRays(torch.autograd.Function):
         import ctypes as C
         r, t, sc, sh, k, s, idx, dimg = ctx.saved_tensors
         opt = lambda g: _f32(g) if g is not None else None
-        g_o, g_dir, g_view, g_norm, g_dgt = (opt(g) for g in (g_o, g_dir, g_view, g_norm, g_dgt))
+        g_o, g_dir, g_view, g_norm, g_dgt, g_mats = (opt(g) for g in (g_o, g_dir, g_view, g_norm, g_dgt, _gmat))
         n = r.shape[0]
         out = torch.empty(8 * n, dtype=torch.float32, device=r.device)
         d_r, d_t, d_sc, d_sh = out[:3 * n], out[3 * n:6 * n], out[6 * n:7 * n], out[7 * n:]
         L.check(L.load().nnr_step_rays_bwd(C.byref(ctx.cfg), L.ptr(r), L.ptr(t), L.ptr(sc), L.ptr(sh), L.ptr(k), L.ptr(s), L.ptr(idx),
                                            L.ptr(dimg), L.ptr(g_o), L.ptr(g_dir), L.ptr(g_view), L.ptr(g_norm), L.ptr(g_dgt),
+                                           L.ptr(g_mats) if ctx.cfg.ref >= 0 else None,
                                            L.ptr(d_r), L.ptr(d_t), L.ptr(d_sc), L.ptr(d_sh), _st()), "nnr_step_rays_bwd")
         rs, ts, ss, hs = ctx.shapes
         return d_r.view(rs), d_t.view(ts), (None if ctx.gauge else d_sc.view(ss)), d_sh.view(hs), None, None, None, None, None, None
 
 
 def step_rays(r_all, t_all, scales, shifts, depth_img, img, ray_idx, camera_mat, scale_mat, *, cam: int, h: int, w: int,
-              fix_last_scale: bool, shift_first: bool, normalise: bool, use_dir: bool):
+              fix_last_scale: bool, shift_first: bool, normalise: bool, use_dir: bool, ref: int = -1, detach_ref: bool = True):
     """Fused front end of a training step, one launch each way.  (n_cams,3) pose tables, (n_cams,1) distortion tables, the RAW
     (1,1,hd,wd) mono-depth map, the (1,3,h,w) frame (or None), (R,) pixel indices, (1,4,4) camera / scale matrices (constants)
     -> pts_o, dir, view (R,3), ray_norm, d_gt (R), mask (R) bool, rgb_gt (R,3), pixels (1,R,2), mats (34: c2w, world_mat, scale,
-    shift).  Differentiable with respect to the four tables."""
+    shift).  Differentiable with respect to the four tables.
+    ref >= 0: the frame pair of the per-image losses rides along -- mats has 56 entries, [34:50] the relative transform, [50:54] the two
+    clouds' distortions (scale1, shift1, scale2, shift2), [54] scale2 -- and gradients arriving at those entries are chained into the
+    tables by the same backward launch (detach_ref = training.detach_ref_img: none into the reference camera's rows)."""
     return _StepRays.apply(r_all, t_all, scales, shifts, depth_img, img, ray_idx, camera_mat, scale_mat,
-                           (int(cam), int(h), int(w), bool(fix_last_scale), bool(shift_first), bool(normalise), bool(use_dir)))
+                           (int(cam), int(h), int(w), bool(fix_last_scale), bool(shift_first), bool(normalise), bool(use_dir), int(ref),
+                            bool(detach_ref)))

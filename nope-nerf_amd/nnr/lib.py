@@ -47,7 +47,8 @@ LAYER_NAMES = ("layers0.0", "layers0.2", "layers0.4", "layers0.6", "layers1.0", 
 # = NNR_ABI_VERSION of include/nnr.h; bumped whenever a signature, a struct or a blob layout that crosses the C ABI changes
 # (2: nnr_pc_error_bwd takes n_dst; round-2 layouts of nnr_aux_cfg and the bf16 plan blob.  3: nnr_step_rays_*; the weight-gradient
 # stage overwrites nnr_param_grads instead of accumulating into it.  4: nnr_ws_plane_layout; the gradient planes of a three-term training workspace
-# are tile-major fp32.  5: nnr_adam_table.flavour / bc2_sqrt -- torch's single-tensor Adam arithmetic beside the fused one)
+# are tile-major fp32.  5: nnr_adam_table.flavour / bc2_sqrt -- torch's single-tensor Adam arithmetic beside the fused one; nnr_step_cfg.ref + g_mats: the frame pair of the
+# per-image losses in the fused front end; nnr_aux_terms_*: `aff`, the depth distortion applied in the kernels)
 ABI_VERSION = 5
 EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_floats", "nnr_workspace_floats",
            "nnr_plan_bytes", "nnr_plan_counts", "nnr_plan_build", "nnr_pack_weights", "nnr_render_fwd", "nnr_render_bwd", "nnr_ws_plane",
@@ -74,14 +75,14 @@ class AuxCfg(C.Structure):
                 ("flags", C.c_uint32), ("shard_lo", C.c_int32), ("shard_hi", C.c_int32)]
 
 
-AUX_RGBS, AUX_PC, AUX_SCALE_PCS, AUX_DETACH_RGBS, AUX_SSIM, AUX_GRAD_K = 1, 2, 4, 8, 16, 32
+AUX_RGBS, AUX_PC, AUX_SCALE_PCS, AUX_DETACH_RGBS, AUX_SSIM, AUX_GRAD_K, AUX_AFFINE, AUX_SHIFT_FIRST = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class StepCfg(C.Structure):        # nnr_step_cfg: the fused front end of a training step
-    _fields_ = [(n, C.c_int32) for n in ("n_rays", "h", "w", "hd", "wd", "cam", "n_cams")] + [("flags", C.c_uint32)]
+    _fields_ = [(n, C.c_int32) for n in ("n_rays", "h", "w", "hd", "wd", "cam", "n_cams")] + [("flags", C.c_uint32), ("ref", C.c_int32)]
 
 
-STEP_NORMALISE, STEP_USE_DIR, STEP_SHIFT_FIRST, STEP_FIX_LAST_SCALE = 1, 2, 4, 8
+STEP_NORMALISE, STEP_USE_DIR, STEP_SHIFT_FIRST, STEP_FIX_LAST_SCALE, STEP_DETACH_REF = 1, 2, 4, 8, 16
 
 
 class WgradJobB(C.Structure):      # bf16 training mode: one workgroup job (nnr_layout.h)
@@ -158,12 +159,12 @@ def load():
     auxp = C.POINTER(AuxCfg)
     lib.nnr_aux_workspace_floats.restype = C.c_size_t
     lib.nnr_aux_workspace_floats.argtypes = [auxp]
-    lib.nnr_aux_terms_fwd.argtypes = [auxp] + [vp] * 11
-    lib.nnr_aux_terms_bwd.argtypes = [auxp] + [vp] * 14
+    lib.nnr_aux_terms_fwd.argtypes = [auxp] + [vp] * 12
+    lib.nnr_aux_terms_bwd.argtypes = [auxp] + [vp] * 15
     lib.nnr_pc_error_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.nnr_render_loss.argtypes = [vp] * 5 + [i32] + [f32] * 4 + [i32] * 3 + [vp] * 6
     lib.nnr_step_rays_fwd.argtypes = [C.POINTER(StepCfg)] + [vp] * 19
-    lib.nnr_step_rays_bwd.argtypes = [C.POINTER(StepCfg)] + [vp] * 18
+    lib.nnr_step_rays_bwd.argtypes = [C.POINTER(StepCfg)] + [vp] * 19
     lib.nnr_adam_step.argtypes = [vp, vp]
     lib.nnr_prof_begin.argtypes = [i32]
     lib.nnr_prof_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]

@@ -255,3 +255,55 @@ def test_step_with_ssim_term_matches_reference_on_the_cpu_stand_in(monkeypatch):
 @pytest.mark.gpu
 def test_step_with_ssim_term_matches_reference_on_the_hip_kernels(monkeypatch):
     _ssim_step(torch.device("cuda"), monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cam_ref,flags", [
+    ("mid", None, {}), ("last", None, {}),
+    ("mid", None, dict(detach_ref_img=False)),                          # gradients into the reference camera's pose and distortion rows
+    ("last", None, dict(detach_ref_img=False, shift_first=True)),       # the roles swapped, (depth + shift) * scale
+    ("mid", (2, 3), dict(detach_ref_img=False)),                        # the reference camera is the gauge (its scale is the constant 1)
+    ("mid", None, dict(scale_pcs=False, detach_rgbs_scale=True)), ("mid", None, dict(with_ssim=True, detach_ref_img=False)),
+    ("mid", None, dict(pc_weight=[0.0, 0.0])), ("last", None, dict(rgb_s_weight=[0.0, 0.0], detach_ref_img=False)),
+])
+def test_first_phase_step_on_the_fused_front_end_equals_the_separate_launches(name, cam_ref, flags, monkeypatch):
+    """Round 5: the first-phase step takes the fused front end too -- the frame pair (reference pose, inverses, relative transform, the
+    reference's distortion) rides along in nnr_step_rays_fwd / _bwd and the per-image kernels distort their own sampled depths
+    (nnr_aux_terms_*, `aff`).  Against the same step on the separate launches (training.fuse_pair: False): the same losses, the same
+    gradients of poses, distortions and network, also where the reference side is not detached, for the last camera (roles swapped), for
+    a reference camera that is the gauge, and under every per-image switch."""
+    dev = torch.device("cuda")
+    inp = _inp(name)
+    cam, ref = cam_ref if cam_ref is not None else (int(GOLD[f"{name}.cam"]), int(GOLD[f"{name}.ref"]))
+    ray_idx, jitter = torch.from_numpy(GOLD[f"{name}.ray_idx"]), torch.from_numpy(GOLD[f"{name}.jitter"])
+    monkeypatch.setattr(torch, "randperm", lambda n, device=None, **kw: torch.cat([ray_idx, torch.zeros(n - R, dtype=torch.int64)]).to(device))
+    real_rand = torch.rand
+    monkeypatch.setattr(torch, "rand", lambda *s, device=None, **kw: jitter.to(device) if tuple(s) == (1, R, N) else real_rand(*s, device=device, **kw))
+    from nnr import camera
+    out = {}
+    for fused in (False, True):
+        calls = []
+        real_step = camera.step_rays
+        monkeypatch.setattr(camera, "step_rays", lambda *a, **k: (calls.append(k.get("ref", -1)), real_step(*a, **k))[1])
+        tr, pose, dist = _trainer(inp, dev, fuse_pair=fused, **flags)
+        data = {"img": inp["img"].to(dev), "img.idx": cam, "img.dpt": inp["dpt"].to(dev), "img.camera_mat": inp["K"].to(dev),
+                "img.scale_mat": torch.eye(4).unsqueeze(0).to(dev), "img.ref_imgs": inp["ref_img"].to(dev),
+                "img.ref_dpts": inp["ref_dpt"].to(dev), "img.ref_idxs": ref}
+        ld = tr.train_step(data, it=1, epoch=0, scheduling_start=10000, render_path=None)
+        monkeypatch.setattr(camera, "step_rays", real_step)
+        assert calls == ([ref] if fused else []), calls            # the fused step went through the pair front end, the other one did not
+        grads = {"pose_r": pose.r.grad, "pose_t": pose.t.grad, "scales": dist.global_scales.grad, "shifts": dist.global_shifts.grad}
+        grads.update({"net." + k: p.grad for k, p in tr.model.named_parameters()})
+        out[fused] = ({k: float(ld[k]) for k in ("loss", "loss_pc", "loss_rgb_s", "loss_rgb", "loss_depth")},
+                      {k: (None if g is None else g.detach().clone()) for k, g in grads.items()})
+    (l0, g0), (l1, g1) = out[False], out[True]
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 2e-6 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    for k in g0:
+        assert (g0[k] is None) == (g1[k] is None), k
+        if g0[k] is None:
+            continue
+        scale = max(1e-6, float(g0[k].abs().max()))
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * scale, (k, float((g0[k] - g1[k]).abs().max()) / scale)
+    if flags.get("detach_ref_img") is False and flags.get("pc_weight", [1.0])[0] != 0.0:
+        assert float(g1["pose_r"][ref].abs().max()) > 0.0           # the reference camera's pose row is live
