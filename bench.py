@@ -299,7 +299,7 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
             'frac': round(issued_dom / PEAK_BF16_MFMA_TFLOPS, 4),
             'what': 'issued bf16 MFMA work (6 terms x executed MACs x 2) / in-step time vs the dense bf16 peak',
             'notes': 'peak at the nominal 2.4 GHz; the chip holds ~1.8 GHz under these kernels (DESIGN 4.3).  frac_algorithmic = 6 terms x ALGORITHMIC '
-                     'MACs x 2 / time / peak (SURVEY 8d counts algorithmic work; the kernels execute 89 % of it: feature layer folded).  '
+                     'MACs x 2 / time / peak (SURVEY 8d counts algorithmic work; the kernels execute 89 %% of it: feature layer folded).  '
                      'fp32_equivalent_tflops = algorithmic FLOPs / time, which exceeds the fp32 MFMA peak of %.1f by construction' % PEAK_FP32_MFMA_TFLOPS,
             'frac_algorithmic': round(6 * share[dom] * flops / (times[dom] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
             'fp32_equivalent_tflops': round(achieved, 2), 'traffic': traffic, 'traffic_source': src, 'timing': how,

@@ -217,7 +217,11 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
  * NNR_AUX_AFFINE (ABI 5): d1_img / d2_img are the RAW mono-depth maps and `aff` = device (scale1, shift1, scale2, shift2) -- the per-image
  * distortion of model/training.py:240-245, 294-296 ((depth + shift) * scale with NNR_AUX_SHIFT_FIRST) -- is applied to the sampled values
  * inside the kernels; the backward then returns dL/d aff at g_rel_scale[40, 44) (44 floats) and needs no g_d*_img (pass NULL).  Without the
- * flag `aff` must be NULL. */
+ * flag `aff` must be NULL.
+ * The nearest-neighbour search walks the destination depth map's pixel grid around each source's projection and prunes by the distance to
+ * the destination RAYS (nnr_aux.hip: aux_pc_search_kernel; the same indices as the exhaustive nnr_pc_nearest, ~7x faster at 135 x 240);
+ * NNR_PC_SEARCH=brute in the environment selects the exhaustive search.  The forward zeroes the backward's accumulators: ONE backward per
+ * forward. */
 #define NNR_AUX_RGBS 1u         /* rgb_s_weight != 0 */
 #define NNR_AUX_PC 2u           /* pc_weight != 0 */
 #define NNR_AUX_SCALE_PCS 4u    /* training.scale_pcs */
@@ -225,6 +229,10 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
 #define NNR_AUX_GRAD_K 32u      /* a learnable focal length: the backward also returns dL/dK and dL/dKinv (g_rel_scale has 40 floats) */
 #define NNR_AUX_AFFINE 64u      /* the depth distortion is applied in the kernels (aff) */
 #define NNR_AUX_SHIFT_FIRST 128u /* training.shift_first */
+#define NNR_AUX_WEIGHTED 256u    /* out[3] = w_pc loss_pc + w_rgbs loss_rgb_s (the active terms; each product and the sum rounded to fp32, the torch
+                                 * expression of model/losses.py:196-203); the backward's g_out is then ONE float, dL/d out[3] */
+#define NNR_AUX_MATS_GRAD 512u   /* with NNR_AUX_AFFINE, without NNR_AUX_GRAD_K: rel, aff and scale2 are slices of nnr_step_rays_fwd's 56-float mats block
+                                 * ([34, 50), [50, 54), [54]) and the backward writes g_rel_scale[56] in THAT layout (zeros elsewhere) */
 #define NNR_AUX_SSIM 16u        /* training.with_ssim: 0.15 clamp|.| + 0.85 SSIM per re-projected colour (12 hr wr more workspace floats) */
 typedef struct nnr_aux_cfg {
     int32_t hd, wd, hr, wr;
@@ -236,6 +244,7 @@ typedef struct nnr_aux_cfg {
      * normalisers (S, the number of valid re-projections): the SUM over ranks of the losses and of every gradient equals the
      * single-GPU value.  0, 0 = all points. */
     int32_t shard_lo, shard_hi;
+    float w_pc, w_rgbs;      /* NNR_AUX_WEIGHTED: training.pc_weight / rgb_s_weight of the step */
 } nnr_aux_cfg;
 size_t nnr_aux_workspace_floats(const nnr_aux_cfg* cfg);
 int nnr_aux_terms_fwd(const nnr_aux_cfg* cfg, const float* d1_img, const float* d2_img, const float* img1r, const float* img2r,

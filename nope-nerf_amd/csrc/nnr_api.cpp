@@ -967,6 +967,8 @@ size_t aux_fill(const nnr_aux_cfg* c, float* ws, nnr::AuxArgs& a) {   // returns
     a.s_hi = (c->shard_lo == 0 && c->shard_hi == 0) ? (int)S : c->shard_hi;   // 0, 0 = every point (one GPU)
     a.nl = c->nearest_limit;
     a.flags = c->flags;
+    a.w_pc = c->w_pc; a.w_rgbs = c->w_rgbs;
+    if ((c->flags & NNR_AUX_MATS_GRAD) && (!(c->flags & NNR_AUX_AFFINE) || (c->flags & NNR_AUX_GRAD_K))) return 0;
     float* p = ws;
     auto take = [&](int64_t n) { float* r = p; p += n; return r; };
     a.keys = reinterpret_cast<unsigned long long*>(take(4 * S));

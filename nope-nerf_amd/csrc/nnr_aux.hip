@@ -20,6 +20,8 @@
 #include "../../include/nnr.h"
 #include "nnr_device.h"
 #include "nnr_kernels.h"
+#include <cstdlib>
+#include <string>
 
 namespace nnr {
 
@@ -129,7 +131,9 @@ __global__ __launch_bounds__(256) void aux_points_fwd_kernel(AuxArgs a) {
         for (int r = 0; r < 3; ++r) {
             a.X[3 * i + r] = g.rot[r] / s2;
             a.Y[3 * i + r] = g.pc2[r] / s2;
+            if (a.flags & NNR_AUX_PC) { a.gXq[3 * i + r] = 0; a.gYq[3 * i + r] = 0; }      // the backward's accumulators (was a memset launch there)
         }
+        if (i == 0) *reinterpret_cast<unsigned int*>(a.acc + 7) = 0u;      // the ticket counter of aux_dist_sum_kernel
         float gxy0 = 0.f, gxy1 = 0.f;
         uint32_t fl = g.flags;
         if (a.flags & NNR_AUX_RGBS) {
@@ -280,6 +284,210 @@ __global__ __launch_bounds__(256) void aux_decode_kernel(const unsigned long lon
     if (threadIdx.x == 0) part[4 * blockIdx.x + slot] = bs;
 }
 
+// ---- nearest neighbours between the two clouds: the search that knows where the destination points can be -------------------------------
+// Both clouds are depth maps lifted along the rays of a pixel grid: Y_j = c + t_j M b_j with b_j = (x'_j, y'_j, 1) the grid point of index j,
+// t_j = depth / scale2 and, for the direction X -> Y,  M = Kinv[:3,:3], c = Kinv[:3,3] / scale2;  for Y -> X,  M = R Kinv[:3,:3],
+// c = (R Kinv[:3,3] + t) / scale2  (aux_geometry above).  A destination point lies on the LINE c + t M b_j whatever its depth, so a source
+// P = c + w with w = p_z M a, a = (u, v, 1), is at least
+//        dist(P, line_j) = |w x M b_j| / |M b_j| = |p_z| |cof(M) (a x b_j)| / |M b_j|  >=  |p_z| sqrt(q(a - b_j)) / B
+// away from it, where a x b = (dv, -du, k), q(du, dv) is the quadratic form of cof(M) on the first two components with the cof(M) e_3
+// direction projected out (whatever k is), and B = max |M b| over the grid (a corner).  Grid points outside the ellipse
+// q(du, dv) <= (rho B / p_z)^2 cannot hold a point within rho of P: the brute-force search over S destinations (nnr_pointcloud.hip: 1.05 G
+// pairs per direction at 135 x 240, 176 us at the VALU floor of its instruction mix) becomes a walk over the grid rows around P's own
+// projection, the ellipse shrinking with the running minimum.  The candidates that ARE visited are evaluated exactly as the brute-force
+// kernel evaluates them (torch.linalg.norm's fma chain, keys (sqrt bits, index): the first index among equal rounded distances), and the
+// pruning only ever skips grid points whose line is farther than the running minimum plus margins for every rounding involved (the stored
+// points are within a few ulp of their lines; u, v and q carry relative errors of 1e-6: rho is inflated by 1e-3 and by 1e-5 of the
+// magnitudes involved, the pixel ranges by one pixel) -- the indices are those of the exhaustive search, tests/test_aux_terms.py and
+// tests/test_pointcloud.py compare them.  A source behind / beside the destination camera (p_z ~ 0), a singular M or a degenerate grid
+// disable the pruning for that source: it scans everything.
+// G lanes share one source: rows round-robin, the running minimum shared after every row.  One launch, blockIdx.y = direction; idx / dist are
+// written directly (no key table, no fill, no decode).
+constexpr int kPcLanes = 8;      // lanes per source
+
+struct PcRays {      // per direction, wave-uniform
+    float c[3], Minv[9];
+    float guu, guv, gvv, det, B;      // q(du, dv) = guu du^2 + 2 guv du dv + gvv dv^2;  det = guu gvv - guv^2
+    bool ok;
+};
+
+__device__ __forceinline__ PcRays pc_rays(const AuxArgs& a, int dir) {
+    PcRays r;
+    const float s2 = (a.flags & NNR_AUX_SCALE_PCS) ? a.scale2[0] : 1.f;
+    float M[9], k3[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        k3[i] = a.Kinv[4 * i + 3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M[3 * i + j] = a.Kinv[4 * i + j];
+    }
+    if (dir == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r.c[i] = k3[i] / s2;
+    } else {
+        float RM[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            r.c[i] = (a.rel[4 * i] * k3[0] + a.rel[4 * i + 1] * k3[1] + a.rel[4 * i + 2] * k3[2] + a.rel[4 * i + 3]) / s2;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) RM[3 * i + j] = a.rel[4 * i] * M[j] + a.rel[4 * i + 1] * M[3 + j] + a.rel[4 * i + 2] * M[6 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) M[i] = RM[i];
+    }
+    // cof(M): row i = cross product of the other two rows (cyclic); M^-1 = cof(M)^T / det
+    float N[9];
+    N[0] = M[4] * M[8] - M[5] * M[7]; N[1] = M[5] * M[6] - M[3] * M[8]; N[2] = M[3] * M[7] - M[4] * M[6];
+    N[3] = M[7] * M[2] - M[8] * M[1]; N[4] = M[8] * M[0] - M[6] * M[2]; N[5] = M[6] * M[1] - M[7] * M[0];
+    N[6] = M[1] * M[5] - M[2] * M[4]; N[7] = M[2] * M[3] - M[0] * M[5]; N[8] = M[0] * M[4] - M[1] * M[3];
+    const float dm = M[0] * N[0] + M[1] * N[1] + M[2] * N[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.Minv[3 * i + j] = N[3 * j + i] / dm;
+    // columns of cof(M): n1 (times dv), n2 (times -du), n3 (times k: projected out)
+    float n1[3] = {N[0], N[3], N[6]}, n2[3] = {N[1], N[4], N[7]};
+    const float n3[3] = {N[2], N[5], N[8]};
+    const float l3 = n3[0] * n3[0] + n3[1] * n3[1] + n3[2] * n3[2];
+    const float p1 = (n1[0] * n3[0] + n1[1] * n3[1] + n1[2] * n3[2]) / l3, p2 = (n2[0] * n3[0] + n2[1] * n3[1] + n2[2] * n3[2]) / l3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { n1[i] -= p1 * n3[i]; n2[i] -= p2 * n3[i]; }
+    r.gvv = n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2];
+    r.guu = n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2];
+    r.guv = -(n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2]);
+    r.det = r.guu * r.gvv - r.guv * r.guv;
+    float B2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {      // |M b|^2 is convex in b: its maximum over the grid is at a corner
+        const float bx = (k & 1) ? 1.f : -1.f, by = (k & 2) ? 1.f : -1.f;
+        float l = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const float t = M[3 * i] * bx + M[3 * i + 1] * by + M[3 * i + 2]; l += t * t; }
+        B2 = fmaxf(B2, l);
+    }
+    r.B = sqrtf(B2) * 1.0001f;
+    const float big = 1e30f;
+    r.ok = a.wr > 1 && a.hr > 1 && fabsf(dm) > 1e-30f && fabsf(dm) < big && l3 > 1e-30f && r.det > 1e-12f * r.guu * r.gvv && r.guu > 0.f && r.gvv > 0.f
+           && B2 < big && s2 == s2 && fabsf(s2) > 1e-30f;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void aux_pc_search_kernel(AuxArgs a) {
+    constexpr int G = kPcLanes;
+    const int dir = blockIdx.y;
+    const float* __restrict__ src = dir == 0 ? a.X : a.Y;
+    const float* __restrict__ dst = dir == 0 ? a.Y : a.X;
+    const int sub = threadIdx.x % G;
+    const int s = a.s_lo + blockIdx.x * (256 / G) + threadIdx.x / G;
+    if (s >= a.s_hi) return;      // (whole groups leave together: the shuffles below stay inside a group)
+    const PcRays R = pc_rays(a, dir);
+    const int wr = a.wr, hr = a.hr;
+    const float sx = src[3 * s], sy = src[3 * s + 1], sz = src[3 * s + 2];
+    const float wx = sx - R.c[0], wy = sy - R.c[1], wz = sz - R.c[2];
+    const float px = R.Minv[0] * wx + R.Minv[1] * wy + R.Minv[2] * wz, py = R.Minv[3] * wx + R.Minv[4] * wy + R.Minv[5] * wz,
+                pz = R.Minv[6] * wx + R.Minv[7] * wy + R.Minv[8] * wz;
+    const float wl = sqrtf(wx * wx + wy * wy + wz * wz), cl = fabsf(R.c[0]) + fabsf(R.c[1]) + fabsf(R.c[2]);
+    // prune only where the projection means something: in front of / behind the camera by more than a sliver of |p|
+    const bool prune = R.ok && fabsf(pz) > 1e-4f * (fabsf(px) + fabsf(py)) && fabsf(pz) > 1e-30f && wl < 1e30f;
+    const float u = prune ? px / pz : 0.f, v = prune ? py / pz : 0.f;
+    const float hw = 0.5f * (float)(wr - 1), hh = 0.5f * (float)(hr - 1);
+    const float fx = (u + 1.f) * hw, fy = (v + 1.f) * hh;      // P's projection in grid units
+    const int x0 = (int)fminf(fmaxf(rintf(fx), 0.f), (float)(wr - 1)), y0 = (int)fminf(fmaxf(rintf(fy), 0.f), (float)(hr - 1));
+    const float bz = prune ? R.B / fabsf(pz) : 0.f;
+
+    float best_s = __builtin_inff(), thr = __builtin_inff();
+    int best_i = 0x7fffffff;
+    auto consider = [&](float d2, int idx) __attribute__((always_inline)) {
+        if (d2 <= thr && d2 < __builtin_inff()) {
+            const float sq = __fsqrt_rn(d2);
+            if (sq < best_s || (sq == best_s && idx < best_i)) {
+                best_s = sq;
+                best_i = idx;
+                const float t = sq * sq;
+                thr = __builtin_fmaf(t, 4.8e-7f, t) + 1.2e-38f;      // every d2 whose rounded root is <= best_s lies below this (nnr_pointcloud.hip)
+            }
+        }
+    };
+    auto dist2 = [&](int j) __attribute__((always_inline)) {
+        const float ex = sx - dst[3 * j], ey = sy - dst[3 * j + 1], ez = sz - dst[3 * j + 2];
+        return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));      // torch.linalg.norm's sum of squares
+    };
+    auto share = [&]() __attribute__((always_inline)) {      // the group's running minimum in every lane of the group
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) {
+            const float os = __shfl_xor(best_s, o, 64);
+            const int oi = __shfl_xor(best_i, o, 64);
+            if (os < best_s || (os == best_s && oi < best_i)) { best_s = os; best_i = oi; }
+        }
+        const float t = best_s * best_s;
+        thr = best_s < __builtin_inff() ? __builtin_fmaf(t, 4.8e-7f, t) + 1.2e-38f : __builtin_inff();
+    };
+    // first guesses: the 5 x 5 grid points around the projection (clamped into the grid)
+    for (int k = sub; k < 25; k += G) {
+        const int yy = min(max(y0 + k / 5 - 2, 0), hr - 1), xx = min(max(x0 + k % 5 - 2, 0), wr - 1);
+        consider(dist2(yy * wr + xx), yy * wr + xx);
+    }
+    share();
+    // rows outwards from the projection: offsets 0, +1, -1, +2, -2, ..; lane `sub` takes every G-th
+    const int m_end = 2 * max(y0, hr - 1 - y0);      // last useful position of the zigzag
+    const float pu = 1.f / hw, pv = 1.f / hh;        // grid pitch in u, v
+    for (int m0 = 0; m0 <= m_end; m0 += G) {
+        // the ellipse for the group's minimum (the same in every lane of the group: a group-uniform trip count)
+        float r2 = __builtin_inff();
+        if (prune && thr < __builtin_inff()) {
+            const float rho = sqrtf(thr) * 1.001f + 1e-5f * (wl + cl + sqrtf(thr)) + 1e-30f;
+            const float t = rho * bz;
+            r2 = t * t * 1.001f;
+        }
+        const float dv_max = r2 < __builtin_inff() ? sqrtf(r2 * R.guu / R.det) : __builtin_inff();
+        // the nearest row of this trip is (m0 + 1) / 2 - 1 .. rows away from y0; y0 itself is within half a row (+ clamping) of fy
+        const float near_rows = (float)((m0 + 1) / 2);
+        const float gap = fabsf((float)y0 - fy);      // > 0.5 only where the projection lies outside the grid: then every row is farther
+        if ((near_rows - 0.5f) * pv > dv_max + pv && (near_rows + gap - 1.f) * pv > dv_max + pv) break;
+        const int m = m0 + sub;
+        const int y = y0 + ((m & 1) ? (m + 1) / 2 : -(m / 2));
+        if (m <= m_end && y >= 0 && y < hr) {
+            int xlo = 0, xhi = wr - 1;
+            bool any = true;
+            if (r2 < __builtin_inff()) {
+                const float dv = v - ((float)y * pv - 1.f);
+                const float D = R.guu * r2 - R.det * dv * dv;
+                if (D < 0.f) any = false;
+                else {
+                    const float du_c = -R.guv * dv / R.guu, du_r = sqrtf(D) / R.guu;
+                    // du = u - u'  ->  u' in [u - du_c - du_r, u - du_c + du_r]
+                    const float lo = (u - du_c - du_r + 1.f) * hw - 1.5f, hi = (u - du_c + du_r + 1.f) * hw + 1.5f;
+                    if (!(lo <= (float)(wr - 1)) || !(hi >= 0.f)) any = lo != lo || hi != hi;      // outside the grid (NaN: keep the whole row)
+                    else {
+                        xlo = (int)fmaxf(floorf(lo), 0.f);
+                        xhi = (int)fminf(ceilf(hi), (float)(wr - 1));
+                    }
+                }
+            }
+            if (any) {
+                const int row = y * wr;
+                for (int x = xlo; x <= xhi; x += 4) {
+                    float d2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d2[k] = dist2(row + min(x + k, xhi));
+                    if ((d2[0] <= thr) | (d2[1] <= thr) | (d2[2] <= thr) | (d2[3] <= thr)) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) consider(d2[k], row + min(x + k, xhi));      // (a repeated last point changes nothing)
+                    }
+                }
+            }
+        }
+        share();
+    }
+    if (sub == 0) {
+        int64_t* idx = dir == 0 ? a.idx_xy : a.idx_yx;
+        float* dist = dir == 0 ? a.dist_xy : a.dist_yx;
+        // nothing found (NaN / inf coordinates): index 0xffffffff, a NaN distance -- what the key table decoded to
+        idx[s] = best_i == 0x7fffffff ? (int64_t)0xffffffffll : (int64_t)best_i;
+        dist[s] = best_i == 0x7fffffff ? __uint_as_float(0xffffffffu) : best_s;
+    }
+}
+
 // column `k` of an [nb][stride] table of per-block partials, summed in a fixed order by one wave: lane l adds blocks l, l + 64, ...,
 // then the lane tree.  Every lane returns the total.
 __device__ __forceinline__ float ordered_column_sum(const float* part, int nb, int stride, int k) {
@@ -290,8 +498,10 @@ __device__ __forceinline__ float ordered_column_sum(const float* part, int nb, i
     return v;
 }
 
-// out = [loss_pc, loss_rgb_s, n_valid, 0]; sums over this rank's shard of the source points, normalisers global
-__global__ __launch_bounds__(64) void aux_finish_kernel(AuxArgs a) {
+// out = [loss_pc, loss_rgb_s, n_valid, weighted]; sums over this rank's shard of the source points, normalisers global.  One wave.
+// weighted (NNR_AUX_WEIGHTED) = w_pc loss_pc + w_rgbs loss_rgb_s over the active terms, each product and the sum rounded to fp32 as the
+// torch expression of model/losses.py rounds them (w * loss, then +): two multiplies and an add that were three launches.
+__device__ __forceinline__ void aux_finish_body(const AuxArgs& a) {
     const int nb = (a.S + 255) / 256;
     const bool rgbs = (a.flags & NNR_AUX_RGBS) != 0, pc = (a.flags & NNR_AUX_PC) != 0;
     const float lsum = rgbs ? ordered_column_sum(a.part_fwd, nb, 4, 0) : 0.f;
@@ -300,10 +510,40 @@ __global__ __launch_bounds__(64) void aux_finish_kernel(AuxArgs a) {
     const float dyx = pc ? ordered_column_sum(a.part_fwd, nb, 4, 3) : 0.f;
     if (threadIdx.x != 0) return;
     a.acc[0] = lsum; a.acc[1] = lcnt; a.acc[2] = dxy; a.acc[3] = dyx;
-    a.out[0] = pc ? (dxy + dyx) / (float)a.S : 0.f;
-    a.out[1] = rgbs && lcnt > 0.f ? lsum / (3.f * lcnt) : 0.f;
+    const float l_pc = pc ? (dxy + dyx) / (float)a.S : 0.f;
+    const float l_rgbs = rgbs && lcnt > 0.f ? lsum / (3.f * lcnt) : 0.f;
+    a.out[0] = l_pc;
+    a.out[1] = l_rgbs;
     a.out[2] = lcnt;
-    a.out[3] = 0.f;
+    float wsum = 0.f;
+    if (a.flags & NNR_AUX_WEIGHTED) {
+        const float t_pc = __fmul_rn(a.w_pc, l_pc), t_rgbs = __fmul_rn(a.w_rgbs, l_rgbs);
+        wsum = pc && rgbs ? __fadd_rn(t_pc, t_rgbs) : (pc ? t_pc : t_rgbs);
+    }
+    a.out[3] = wsum;
+}
+
+__global__ __launch_bounds__(64) void aux_finish_kernel(AuxArgs a) { aux_finish_body(a); }
+
+// the block's distance sums of both directions into their partial slots (blockIdx.y = direction); the block that finishes LAST (a ticket
+// counter that aux_points_fwd_kernel zeroed: acc[7]) also closes the forward -- the one-wave finishing kernel above without its launch
+__global__ __launch_bounds__(256) void aux_dist_sum_kernel(AuxArgs a) {
+    __shared__ float scratch[4];
+    __shared__ int last;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const float* dist = blockIdx.y == 0 ? a.dist_xy : a.dist_yx;
+    const float d = (s < a.S && s >= a.s_lo && s < a.s_hi) ? dist[s] : 0.f;
+    const float bs = block_sum(d, scratch);
+    if (threadIdx.x == 0) {
+        a.part_fwd[4 * blockIdx.x + 2 + blockIdx.y] = bs;
+        __threadfence();      // the partial before the ticket
+        const unsigned int t = atomicAdd(reinterpret_cast<unsigned int*>(a.acc + 7), 1u);
+        last = t == gridDim.x * gridDim.y - 1u;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    __threadfence();          // every block's partials (and the re-projection partials of the kernels before) are visible now
+    aux_finish_body(a);
 }
 
 // Gradients of the two clouds are accumulated as 64-bit FIXED-POINT numbers (units of 2^-44): several sources may share a
@@ -330,15 +570,28 @@ __device__ __forceinline__ float fix_get(const long long* p) {
     return (float)((double)q * (1.0 / kFixScale));
 }
 
-// d mean_s dist[s] * coef for the sources [s_lo, s_hi) of this rank, ACCUMULATED: g_src[s] += w (src_s - dst_j), g_dst[j] -= the same
-__global__ void aux_pc_bwd_kernel(const float* src, const float* dst, const int64_t* idx, const float* dist, const float* g_out, int S,
-                                  int s_lo, int s_hi, long long* g_src, long long* g_dst) {
-    const int s = s_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= s_hi) return;
+// the upstream gradients of the two losses: g_out[0], g_out[1] -- or, NNR_AUX_WEIGHTED, the ONE gradient of out[3] = w_pc loss_pc + w_rgbs
+// loss_rgb_s times the weights (what autograd's mul backward would have launched two kernels for: g * w, the same product)
+__device__ __forceinline__ float aux_g_pc(const AuxArgs& a) { return (a.flags & NNR_AUX_WEIGHTED) ? a.g_out[0] * a.w_pc : a.g_out[0]; }
+__device__ __forceinline__ float aux_g_rgbs(const AuxArgs& a) { return (a.flags & NNR_AUX_WEIGHTED) ? a.g_out[0] * a.w_rgbs : a.g_out[1]; }
+
+// d mean_s dist[s] * coef for the sources [s_lo, s_hi) of this rank, ACCUMULATED: g_src[s] += w (src_s - dst_j), g_dst[j] -= the same;
+// blockIdx.y = direction (X -> Y, Y -> X)
+__global__ void aux_pc_bwd_kernel(AuxArgs a) {
+    const bool xy = blockIdx.y == 0;
+    const float* src = xy ? a.X : a.Y;
+    const float* dst = xy ? a.Y : a.X;
+    const int64_t* idx = xy ? a.idx_xy : a.idx_yx;
+    const float* dist = xy ? a.dist_xy : a.dist_yx;
+    long long* g_src = xy ? a.gXq : a.gYq;
+    long long* g_dst = xy ? a.gYq : a.gXq;
+    const int S = a.S;
+    const int s = a.s_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.s_hi) return;
     const int64_t j = idx[s];
     if (j < 0 || j >= S) return;   // no finite distance was found (NaN / inf coordinates): no match, no gradient -- and no wild address
     const float dd = dist[s];
-    const float w = dd > 0.f ? g_out[0] / ((float)S * dd) : 0.f;
+    const float w = dd > 0.f ? aux_g_pc(a) / ((float)S * dd) : 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = w * (src[3 * s + c] - dst[3 * j + c]);
@@ -378,7 +631,7 @@ __device__ __forceinline__ void aux_point_grads(const AuxArgs& a, int i, float& 
     if ((a.flags & NNR_AUX_RGBS) && (grad_k || !(fl & kBehind)) && a.acc[1] > 0.f && (ssim || ((fl & kValid) && i >= a.s_lo && i < a.s_hi))) {
         float q[3], xy[2];
         aux_project(a, g, q, xy);
-        const float coef = a.g_out[1] / (3.f * a.acc[1]);
+        const float coef = aux_g_rgbs(a) / (3.f * a.acc[1]);
         const float gx = a.gxy[2 * i] * coef, gy = a.gxy[2 * i + 1] * coef;
         const float gq[3] = {gx / q[2], gy / q[2], -(gx * q[0] + gy * q[1]) / (q[2] * q[2])};
         if (!(fl & kBehind)) {
@@ -496,12 +749,33 @@ __global__ __launch_bounds__(64) void aux_bwd_finish_kernel(AuxArgs a, float* g_
     }
 }
 
+// NNR_AUX_MATS_GRAD: the same sums laid out as the gradient of nnr_step_rays' 56-float `mats` block, which is where rel ([34, 50)), the
+// distortion pairs ([50, 54)) and scale2 ([54]) came from -- one tensor for autograd instead of three slices (each slice's backward is a
+// zero-fill, a copy and an add)
+__global__ __launch_bounds__(64) void aux_bwd_finish_mats_kernel(AuxArgs a, float* g_mats) {
+    const int nb = (a.S + 255) / 256;
+    float mine = 0.f;      // lane l writes g_mats[l]
+    for (int k = 0; k < 17; ++k) {
+        const int col = k < 13 ? k : 37 + (k - 13);
+        const float t = ordered_column_sum(a.part_bwd, nb, kAuxStride, col);      // (every lane gets the total)
+        if ((int)threadIdx.x == (k < 12 ? 34 + k : (k == 12 ? 54 : 50 + (k - 13)))) mine = t;
+    }
+    if (threadIdx.x < 56) g_mats[threadIdx.x] = mine;
+}
+
 hipError_t launch_aux_fwd(const AuxArgs& a, hipStream_t st) {
     const int S = a.S, nb = (S + 255) / 256;
     const int n = a.s_hi - a.s_lo;   // this rank's source points (all of them without data parallelism)
     hipLaunchKernelGGL(aux_points_fwd_kernel, dim3(nb), dim3(256), 0, st, a);
     if ((a.flags & NNR_AUX_RGBS) && (a.flags & NNR_AUX_SSIM)) hipLaunchKernelGGL(aux_ssim_kernel, dim3(nb), dim3(256), 0, st, a);
     if (a.flags & NNR_AUX_PC) {
+        static const bool brute = [] { const char* e = std::getenv("NNR_PC_SEARCH"); return e && std::string(e) == "brute"; }();
+        if (!brute) {      // the ray-aware search (aux_pc_search_kernel): both directions, indices and distances, one launch
+            if (n > 0) hipLaunchKernelGGL(aux_pc_search_kernel, dim3((n * kPcLanes + 255) / 256, 2), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(aux_dist_sum_kernel, dim3(nb, 2), dim3(256), 0, st, a);      // + the finishing step, in its last block
+            return hipGetLastError();
+        }
+        // NNR_PC_SEARCH=brute: the exhaustive search of nnr_pointcloud.hip (rounds 1-4), the A/B baseline of the kernel above
         hipLaunchKernelGGL(aux_fill_keys_kernel, dim3((2 * S + 255) / 256), dim3(256), 0, st, a.keys, 2 * S);
         if (n > 0) {   // the O(S^2 / W) part: only this rank's sources search the whole destination cloud
             hipError_t e = launch_pc_nearest_keys_at(a.X + 3 * a.s_lo, a.Y, n, S, a.keys + a.s_lo, a.s_lo, st);
@@ -519,17 +793,11 @@ hipError_t launch_aux_fwd(const AuxArgs& a, hipStream_t st) {
 hipError_t launch_aux_bwd(const AuxArgs& a, float* g_rel_scale, hipStream_t st) {
     const int S = a.S, nb = (S + 255) / 256;
     const int n = a.s_hi - a.s_lo;
-    if (a.flags & NNR_AUX_PC) {
-        hipError_t e = hipMemsetAsync(a.gXq, 0, (size_t)6 * S * sizeof(long long), st);   // gXq and gYq are adjacent
-        if (e != hipSuccess) return e;
-        if (n > 0) {
-            const int nbs = (n + 255) / 256;
-            hipLaunchKernelGGL(aux_pc_bwd_kernel, dim3(nbs), dim3(256), 0, st, a.X, a.Y, a.idx_xy, a.dist_xy, a.g_out, S, a.s_lo, a.s_hi, a.gXq, a.gYq);
-            hipLaunchKernelGGL(aux_pc_bwd_kernel, dim3(nbs), dim3(256), 0, st, a.Y, a.X, a.idx_yx, a.dist_yx, a.g_out, S, a.s_lo, a.s_hi, a.gYq, a.gXq);
-        }
-    }
+    if ((a.flags & NNR_AUX_PC) && n > 0)      // (the accumulators gXq / gYq were zeroed by the forward: ONE backward per forward)
+        hipLaunchKernelGGL(aux_pc_bwd_kernel, dim3((n + 255) / 256, 2), dim3(256), 0, st, a);
     hipLaunchKernelGGL(aux_points_bwd_kernel, dim3(nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(aux_bwd_finish_kernel, dim3(1), dim3(64), 0, st, a, g_rel_scale);
+    if (a.flags & NNR_AUX_MATS_GRAD) hipLaunchKernelGGL(aux_bwd_finish_mats_kernel, dim3(1), dim3(64), 0, st, a, g_rel_scale);
+    else hipLaunchKernelGGL(aux_bwd_finish_kernel, dim3(1), dim3(64), 0, st, a, g_rel_scale);
     return hipGetLastError();
 }
 

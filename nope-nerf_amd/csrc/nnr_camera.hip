@@ -10,6 +10,13 @@
 #include "nnr_device.h"
 #include "nnr_kernels.h"
 
+// No floating-point contraction in this file.  The fused front end (step_rays_*) restates the arithmetic of the separate kernels below "in
+// the same order", and the two must produce the SAME rays: a multiply-add that the compiler contracts in one kernel and not in the other
+// moves a ray by an ulp, an ulp flips a ReLU gate somewhere in 6 000 samples, and the smallest network gradients then differ by 0.4 %
+// between the two front ends (tests/test_gpu_camera.py caught exactly that when round 5 added code to the fused kernel).  These kernels
+// are latency-bound bookkeeping; the reference's own ATen ops round every product and sum separately.
+#pragma clang fp contract(off)
+
 namespace nnr {
 
 // ------------------------------------------------------------------------------------------------ 4x4 helpers

@@ -181,6 +181,7 @@ struct AuxArgs {
     const float* scale2;            // device scalar (read only with NNR_AUX_SCALE_PCS)
     const float* aff;               // NNR_AUX_AFFINE: device (scale1, shift1, scale2, shift2) applied to the RAW maps d1_img / d2_img here; else null
     int shift_first;                // NNR_AUX_SHIFT_FIRST: (depth + shift) * scale
+    float w_pc, w_rgbs;             // NNR_AUX_WEIGHTED: out[3] = w_pc loss_pc + w_rgbs loss_rgb_s; the backward's g_out is then the ONE gradient of out[3]
     int hd, wd, hr, wr, S;
     int s_lo, s_hi;                 // this rank's shard of the source points (data parallelism): [0, S) on one GPU
     float nl;
@@ -201,7 +202,7 @@ struct AuxArgs {
     float *g_d1_img, *g_d2_img;     // (hd, wd), accumulated into; may be null
 };
 hipError_t launch_aux_fwd(const AuxArgs& a, hipStream_t st);
-hipError_t launch_aux_bwd(const AuxArgs& a, float* g_rel_scale, hipStream_t st);   // g_rel_scale[16 | 40]: dL/d rel rows 0..2 (12), dL/d scale2 (1); NNR_AUX_GRAD_K: + dL/dK, dL/dKinv rows 0..2 at [16, 40)
+hipError_t launch_aux_bwd(const AuxArgs& a, float* g_rel_scale, hipStream_t st);   // (NNR_AUX_MATS_GRAD: 56 floats in the mats layout) g_rel_scale[16 | 40]: dL/d rel rows 0..2 (12), dL/d scale2 (1); NNR_AUX_GRAD_K: + dL/dK, dL/dKinv rows 0..2 at [16, 40)
 hipError_t launch_pc_nearest_keys(const float* src, const float* dst, int S, int D, unsigned long long* keys, hipStream_t st);
 hipError_t launch_pc_nearest(const float* src, const float* dst, int S, int D, int64_t* idx, float* dist, unsigned long long* keys,
                              hipStream_t st);

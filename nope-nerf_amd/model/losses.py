@@ -143,10 +143,10 @@ class Loss(nn.Module):
         return self.mean_on_mask(diff, valid_points, shard)
 
     def aux_terms(self, ref, t_list=None, X=None, Y=None, rgb_pc1=None, rgb_pc1_proj=None, valid_points=None, d1_proj=None,
-                  d2=None, d2_proj=None, d1=None, weights={}, fused_aux=None, point_shard=None, **kwargs):
+                  d2=None, d2_proj=None, d1=None, weights={}, fused_aux=None, point_shard=None, fused_aux_sum=None, **kwargs):
         """The per-image terms (point cloud, surface reprojection, trajectory smoothness, depth consistency) and their
         weighted sum; `ref` is any tensor on the target device.  `fused_aux` = (loss_pc, loss_rgb_s) already computed by the
-        fused HIP path (nnr/aux.py) from the same inputs.  `point_shard` = (lo, hi): under data parallelism loss_pc and
+        fused HIP path (nnr/aux.py) from the same inputs, `fused_aux_sum` their weighted sum when they are the only active terms.  `point_shard` = (lo, hi): under data parallelism loss_pc and
         loss_rgb_s are this rank's share (sums over its source points, global normalisers; model/training.py)."""
         z = _zero(ref)
         on = lambda k: weights[k] != 0.0
@@ -165,6 +165,8 @@ class Loss(nn.Module):
             parts['loss_dist_1st'], parts['loss_dist_2nd'] = self.get_weight_dist_loss(t_list)
         else:
             parts['loss_dist_1st'], parts['loss_dist_2nd'] = z, z
+        if fused_aux_sum is not None:      # pc_weight * loss_pc + rgb_s_weight * loss_rgb_s from the fused path's finishing kernel: nothing else is active
+            return fused_aux_sum, parts
         total = None   # only the active terms enter the sum: no arithmetic on constant zeros (each would be a kernel launch)
         for wk, pk in (('weight_dist_1st_loss', 'loss_dist_1st'), ('weight_dist_2nd_loss', 'loss_dist_2nd'),
                        ('pc_weight', 'loss_pc'), ('rgb_s_weight', 'loss_rgb_s'),

@@ -525,11 +525,17 @@ class Trainer(object):
         rgb_s = weights['rgb_s_weight'] != 0.0
         i1 = self._resized(img1, res) if rgb_s else None
         i2 = self._resized(img2, res) if rgb_s else None
-        l_pc, l_rgbs, _ = nnr_aux.aux_terms(raw1, raw2, mats[34:50].view(1, 4, 4), mats[54:55], i1, i2, camera_mat, self._constant_inverse(camera_mat),
-                                            res, self.nearest_limit, rgb_s=rgb_s, pc=weights['pc_weight'] != 0.0, scale_pcs=bool(self.scale_pcs),
-                                            detach_rgbs_scale=self.detach_rgbs_scale, ssim=self.loss.cfg['with_ssim'] == True,  # noqa: E712 (YAML)
-                                            shard=shard or (0, 0), aff=mats[50:54], shift_first=bool(self.shift_first))
-        kwargs.update(fused_aux=(l_pc, l_rgbs), sample_resolution=res)
+        # the weighted sum of the two terms comes from the finishing kernel when nothing else enters the per-image sum (one GPU; no trajectory /
+        # depth-consistency term): the two multiplies, the add and their backward are five launches
+        only_pair = world == 1 and all(weights[k] == 0.0 for k in ('weight_dist_1st_loss', 'weight_dist_2nd_loss', 'depth_consistency_weight'))
+        terms = nnr_aux.aux_terms(raw1, raw2, None, None, i1, i2, camera_mat, self._constant_inverse(camera_mat),
+                                  res, self.nearest_limit, rgb_s=rgb_s, pc=weights['pc_weight'] != 0.0, scale_pcs=bool(self.scale_pcs),
+                                  detach_rgbs_scale=self.detach_rgbs_scale, ssim=self.loss.cfg['with_ssim'] == True,  # noqa: E712 (YAML)
+                                  shard=shard or (0, 0), shift_first=bool(self.shift_first), mats=mats,
+                                  weights=(weights['pc_weight'], weights['rgb_s_weight']) if only_pair else None)
+        kwargs.update(fused_aux=(terms[0], terms[1]), sample_resolution=res)
+        if only_pair:
+            kwargs['fused_aux_sum'] = terms[3]
 
     def _resized(self, frame, res):
         """F.interpolate(frame, res, mode='bilinear') -- for a frame that is a view of a RESIDENT scene tensor (dataloading.ResidentLoader: the

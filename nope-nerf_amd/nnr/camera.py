@@ -91,7 +91,7 @@ class _RaySetup(torch.autograd.Function):
         pix, dep, k, w, s = ctx.saved_tensors
         R, dev = pix.shape[0], pix.device
         opt = lambda g: _f32(g) if g is not None else None
-        g_o, g_dir, g_view, g_norm, g_dgt, g_mats = (opt(g) for g in (g_o, g_dir, g_view, g_norm, g_dgt, _gmat))
+        g_o, g_dir, g_view, g_norm, g_dgt = (opt(g) for g in (g_o, g_dir, g_view, g_norm, g_dgt))
         f = dict(dtype=torch.float32, device=dev)
         d_depth = torch.empty(R, **f) if dep is not None else None
         out = torch.empty(3 * 16 + 12, **f)

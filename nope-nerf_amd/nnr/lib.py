@@ -72,10 +72,10 @@ class Params(C.Structure):
 
 class AuxCfg(C.Structure):
     _fields_ = [("hd", C.c_int32), ("wd", C.c_int32), ("hr", C.c_int32), ("wr", C.c_int32), ("nearest_limit", C.c_float),
-                ("flags", C.c_uint32), ("shard_lo", C.c_int32), ("shard_hi", C.c_int32)]
+                ("flags", C.c_uint32), ("shard_lo", C.c_int32), ("shard_hi", C.c_int32), ("w_pc", C.c_float), ("w_rgbs", C.c_float)]
 
 
-AUX_RGBS, AUX_PC, AUX_SCALE_PCS, AUX_DETACH_RGBS, AUX_SSIM, AUX_GRAD_K, AUX_AFFINE, AUX_SHIFT_FIRST = 1, 2, 4, 8, 16, 32, 64, 128
+AUX_RGBS, AUX_PC, AUX_SCALE_PCS, AUX_DETACH_RGBS, AUX_SSIM, AUX_GRAD_K, AUX_AFFINE, AUX_SHIFT_FIRST, AUX_WEIGHTED, AUX_MATS_GRAD = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 
 class StepCfg(C.Structure):        # nnr_step_cfg: the fused front end of a training step

@@ -1,5 +1,5 @@
 """Which Python line launches each small kernel of a training step: torch.profiler with stacks over a few steps of bench.py's
-trainer.   python tools/step_launches.py [--bf16] [R N]"""
+trainer.   python tools/step_launches.py [--bf16] [--aux] [R N]"""
 import os
 import sys
 
@@ -13,10 +13,11 @@ import bench
 
 if __name__ == "__main__":
     bf16 = "--bf16" in sys.argv
+    aux = "--aux" in sys.argv      # the first training phase: per-image losses on
     nums = [int(a) for a in sys.argv[1:] if a.isdigit()]
     R, N = (nums + [bench.R_PER_GPU, bench.N_SAMPLES])[:2] if len(nums) >= 2 else (bench.R_PER_GPU, bench.N_SAMPLES)
     dev = torch.device("cuda", 0)
-    trainer, net = bench.build_trainer(dev, 1, False, bf16, R, N)
+    trainer, net = bench.build_trainer(dev, 1, aux, bf16, R, N)
     data = bench.synthetic_batch(dev)
     run = lambda it: trainer.train_step(data, it=it, epoch=0, scheduling_start=10000, render_path=None)
     for it in range(1, 6):
