@@ -268,6 +268,12 @@ size_t nnr_randperm_scratch_bytes(int32_t r);
 int nnr_randperm_prefix(const int64_t* keys, int64_t n, int32_t bits, int32_t r, uint64_t seed, uint64_t offset, int64_t* out,
                         void* scratch, void* stream);
 
+/* out[0..n) = torch.rand(total, device=cuda).flatten()[first : first + n] for the generator state (seed, philox offset) -- the jitter rows
+ * of a data-parallel shard (model/rendering.py:157-159 draws the whole step's tensor) at O(n) instead of O(total).  threads = 256 * the
+ * grid torch's uniform kernel would launch for `total` elements: min(multiProcessorCount * (maxThreadsPerMultiProcessor / 256),
+ * ceil(total / 256)) blocks; the caller advances the generator by ((total - 1) / (4 threads) + 1) * 4, as the full draw would. */
+int nnr_uniform_rows(uint64_t seed, uint64_t offset, uint64_t threads, uint64_t first, uint64_t n, float* out, void* stream);
+
 /* The depth gather below with the per-image affine distortion of model/distortions.py:19-26 applied to the n_rays gathered values
  * instead of to the whole map (model/training.py:240-245 then model/network.py:22-24: the same numbers): out = raw * scale + shift,
  * or (raw + shift) * scale with shift_first.  scale, shift: one-element device tensors.  The backward writes g_scale_shift[0] =

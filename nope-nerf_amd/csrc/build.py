@@ -120,17 +120,17 @@ def build_split_variant(name, defines):
     return out
 
 
-def build_ws_variant(name, defines):
-    """Experiment library: only nnr_mlp_fwd_ws.hip is recompiled with `defines` (profiling switches: results not valid)."""
+def build_ws_variant(name, defines, source="nnr_mlp_fwd_ws.hip"):
+    """Experiment library: only `source` is recompiled with `defines` (profiling / A-B switches: not the product)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = os.path.join(os.path.dirname(HERE), "nnr", "libnnr_%s.so" % name)
     tmp = os.path.join(OUT_DIR, "variant_" + name)
     os.makedirs(tmp, exist_ok=True)
-    obj = os.path.join(tmp, "nnr_mlp_fwd_ws.o")
-    r = subprocess.run([hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(HERE, "nnr_mlp_fwd_ws.hip"), "-o", obj], capture_output=True, text=True)
+    obj = os.path.join(tmp, source.replace(".hip", ".o"))
+    r = subprocess.run([hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(HERE, source), "-o", obj], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr)
-    objs = [obj if src == "nnr_mlp_fwd_ws.hip" else os.path.join(OUT_DIR, _obj_name(src, d)) for src, d in SOURCES]
+    objs = [obj if src == source else os.path.join(OUT_DIR, _obj_name(src, d)) for src, d in SOURCES]
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr)

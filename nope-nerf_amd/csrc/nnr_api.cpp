@@ -956,6 +956,11 @@ int nnr_randperm_prefix(const int64_t* keys, int64_t n, int32_t bits, int32_t r,
     NNR_LAUNCH(launch_randperm_prefix(keys, n, bits, r, seed, offset, out, static_cast<unsigned int*>(scratch), (hipStream_t)stream));
 }
 
+int nnr_uniform_rows(uint64_t seed, uint64_t offset, uint64_t threads, uint64_t first, uint64_t n, float* out, void* stream) {
+    if (!out || threads == 0 || (threads & 255) != 0) return NNR_E_BADCFG;
+    NNR_LAUNCH(launch_uniform_rows(seed, offset, threads, first, n, out, (hipStream_t)stream));
+}
+
 namespace {
 // workspace of the per-image losses, in floats; 8-byte items first so that they stay aligned
 size_t aux_fill(const nnr_aux_cfg* c, float* ws, nnr::AuxArgs& a) {   // returns the workspace size in floats, 0 = bad cfg

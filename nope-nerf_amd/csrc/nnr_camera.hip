@@ -15,7 +15,9 @@
 // moves a ray by an ulp, an ulp flips a ReLU gate somewhere in 6 000 samples, and the smallest network gradients then differ by 0.4 %
 // between the two front ends (tests/test_gpu_camera.py caught exactly that when round 5 added code to the fused kernel).  These kernels
 // are latency-bound bookkeeping; the reference's own ATen ops round every product and sum separately.
+#ifndef NNR_CAMERA_CONTRACT      /* (the A/B build of profiles/r05/g_conv_first_steps_contraction.txt lets the compiler contract) */
 #pragma clang fp contract(off)
+#endif
 
 namespace nnr {
 

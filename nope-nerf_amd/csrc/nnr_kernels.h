@@ -211,6 +211,8 @@ hipError_t launch_pc_error_bwd(const float* src, const float* dst, const int64_t
 unsigned int randperm_capacity(int r);   // candidates the scratch buffer must hold for a pick of r; 0 = r not supported
 hipError_t launch_randperm_prefix(const int64_t* keys, int64_t n, int bits, int r, unsigned long long seed, unsigned long long offset,
                                   int64_t* out, unsigned int* scratch, hipStream_t st);
+hipError_t launch_uniform_rows(unsigned long long seed, unsigned long long offset, unsigned long long threads, unsigned long long first,
+                               unsigned long long n, float* out, hipStream_t st);   // nnr_randperm.hip
 hipError_t launch_pack(int D, const PackArgs& a, int mode, hipStream_t st);   // mode: Layout<D, MODE> (0 fp32, 1 bf16, 2 three bf16 terms)
 // fp32 products: fp32 MFMAs, or (split3) six bf16 MFMA terms per product (nnr_split.h)
 hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st, bool split3 = false);

@@ -154,9 +154,14 @@ class Renderer(nn.Module):
             if add_noise:
                 if self.jitter_window is None:
                     jitter = torch.rand(batch_size, n_rays, n_samples, device=device)   # same draw as the reference (:189)
-                else:   # data-parallel shard: draw the whole step's jitter, keep this rank's rows (model/training.py)
+                else:   # data-parallel shard: this rank's rows of the whole step's jitter tensor (model/training.py) -- drawn alone,
+                        # O(rays of this rank): nnr.sampling.rand_rows reproduces torch.rand's values and its generator side effects
                     lo, total = self.jitter_window
-                    jitter = torch.rand(batch_size, total, n_samples, device=device)[:, lo:lo + n_rays].contiguous()
+                    if batch_size == 1 and torch.device(device).type == 'cuda':
+                        from nnr import sampling
+                        jitter = sampling.rand_rows(total * n_samples, lo * n_samples, n_rays * n_samples, device).view(1, n_rays, n_samples)
+                    else:
+                        jitter = torch.rand(batch_size, total, n_samples, device=device)[:, lo:lo + n_rays].contiguous()
         else:
             raise ValueError('unknown sample_option %r' % (cfg['sample_option'],))
 

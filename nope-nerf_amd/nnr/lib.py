@@ -59,7 +59,7 @@ EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_
            "nnr_pc_error_bwd", "nnr_aux_workspace_floats", "nnr_aux_terms_fwd", "nnr_aux_terms_bwd", "nnr_randperm_prefix",
            "nnr_randperm_scratch_bytes", "nnr_ndc_rays_fwd", "nnr_ndc_rays_bwd",
            "nnr_depth_gather_affine_fwd", "nnr_depth_gather_affine_bwd", "nnr_prof_begin", "nnr_prof_end",
-           "nnr_step_rays_fwd", "nnr_step_rays_bwd", "nnr_adam_step")
+           "nnr_step_rays_fwd", "nnr_step_rays_bwd", "nnr_adam_step", "nnr_uniform_rows")
 
 
 class Cfg(C.Structure):
@@ -150,6 +150,7 @@ def load():
     lib.nnr_pixels_from_index.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.nnr_pc_nearest.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     lib.nnr_randperm_prefix.argtypes = [vp, i64, i32, i32, C.c_uint64, C.c_uint64, vp, vp, vp]
+    lib.nnr_uniform_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp, vp]
     lib.nnr_depth_gather_affine_fwd.argtypes = [vp, vp, vp, vp, i32, vp] + [i32] * 5 + [vp]
     lib.nnr_depth_gather_affine_bwd.argtypes = [vp, vp, vp, vp, vp, i32, vp] + [i32] * 5 + [vp]
     lib.nnr_ndc_rays_fwd.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, vp]

@@ -76,3 +76,53 @@ def randperm_prefix(n: int, r: int, device) -> torch.Tensor:
             return ref
         return got
     return _fast(n, r, device)
+
+
+# ---- rows of torch.rand(total) for a data-parallel shard ----------------------------------------------------------------------------
+_rows_state = {"checked": 0, "enabled": True}
+_max_blocks = {}
+
+
+def _rand_launch_threads(total: int, device) -> int:
+    """Threads of the launch torch's uniform kernel makes for `total` elements (ATen/native/cuda/DistributionTemplates.h:
+    calc_execution_policy): 256 per block, min(SMs * (max threads per SM / 256), ceil(total / 256)) blocks."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    cap = _max_blocks.get(key)
+    if cap is None:
+        prop = torch.cuda.get_device_properties(device)
+        cap = _max_blocks[key] = prop.multi_processor_count * (prop.max_threads_per_multi_processor // 256)
+    return 256 * min(cap, (total + 255) // 256)
+
+
+def _rows_fast(total: int, first: int, n: int, device) -> torch.Tensor:
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    seed, offset = gen.initial_seed(), gen.get_offset()
+    threads = _rand_launch_threads(total, device)
+    gen.set_offset(offset + ((total - 1) // (threads * 4) + 1) * 4)
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    L.check(L.load().nnr_uniform_rows(seed, offset, threads, first, n, L.ptr(out), L.stream()), "nnr_uniform_rows")
+    return out
+
+
+def rand_rows(total: int, first: int, n: int, device) -> torch.Tensor:
+    """== torch.rand(total, device=device)[first:first + n] with the same generator side effects, at the cost of n draws: the jitter rows
+    of this rank's rays out of the whole step's tensor (model/rendering.py).  Verified against torch.rand on the first calls of a process;
+    on a mismatch (a torch build whose uniform kernel maps elements differently) it falls back to the full draw for good."""
+    device = torch.device(device)
+    if device.type != 'cuda' or not _rows_state["enabled"] or total <= 0:
+        return torch.rand(total, device=device)[first:first + n].contiguous()
+    if _rows_state["checked"] < _CHECKS:
+        _rows_state["checked"] += 1
+        before = torch.cuda.get_rng_state(device)
+        ref = torch.rand(total, device=device)[first:first + n].clone()
+        after = torch.cuda.get_rng_state(device)
+        torch.cuda.set_rng_state(before, device)
+        got = _rows_fast(total, first, n, device)
+        if not (torch.equal(got, ref) and torch.equal(torch.cuda.get_rng_state(device), after)):
+            _rows_state["enabled"] = False
+            torch.cuda.set_rng_state(after, device)
+            import warnings
+            warnings.warn("nnr.sampling: the row-local jitter draw does not reproduce this torch build's rand; drawing the whole tensor")
+            return ref
+        return got
+    return _rows_fast(total, first, n, device)

@@ -109,6 +109,8 @@ def test_virtual_ranks_shard_the_per_image_losses(name, world, monkeypatch):
     monkeypatch.setattr(torch, "randperm", lambda n, device=None, **kw: torch.cat([ray_idx, torch.zeros(n - ta.R, dtype=torch.int64)]).to(device))
     real_rand = torch.rand
     monkeypatch.setattr(torch, "rand", lambda *s, device=None, **kw: jitter.to(device) if tuple(s) == (1, ta.R, ta.N) else real_rand(*s, device=device, **kw))
+    from nnr import sampling      # (a shard draws its jitter rows through nnr.sampling.rand_rows, not torch.rand: hand it the golden rows too)
+    monkeypatch.setattr(sampling, "rand_rows", lambda total, first, n, device: jitter.reshape(-1)[first:first + n].to(device))
     monkeypatch.setattr(parallel.dist, "all_reduce", lambda t, op=None: t)
     monkeypatch.setattr(parallel, "world_size", lambda: world)
     dev = torch.device(DEV)

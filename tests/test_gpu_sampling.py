@@ -98,3 +98,29 @@ def test_duplicate_keys_are_reshuffled_like_torch():
     assert not torch.equal(out2.cpu()[:40], got[:40])
     cap = (scratch.numel() - 2) // 5
     assert int(scratch[:2 + cap].abs().sum()) == 0        # count, status, ranks: left zeroed for the next pick (no memset per call)
+
+
+@pytest.mark.parametrize("total,first,n", [(1000, 0, 1000), (1000, 37, 200), (8192 * 192, 3 * 1024 * 192, 1024 * 192),
+                                           (8192 * 192, 7 * 1024 * 192, 1024 * 192), (5_000_001, 2_099_000, 300_000),
+                                           (5_000_001, 4_999_000, 1_001), (9_437_184, 9_000_000, 437_184)])
+def test_rand_rows_are_the_rows_of_torch_rand(total, first, n):
+    """nnr.sampling.rand_rows (the jitter rows of a data-parallel shard, drawn alone) == torch.rand(total)[first:first + n], bit for bit, and
+    the generator is left where the full draw leaves it -- small tensors (fewer elements than launch threads), the 8-rank step of the
+    benchmark shape, and tensors large enough that torch's threads make several Philox calls each."""
+    from nnr import sampling
+    dev = torch.device("cuda", 0)
+    for seed in (0, 1234567):
+        torch.manual_seed(seed)
+        torch.rand(17, device=dev)                       # (an offset that is not zero)
+        before = torch.cuda.get_rng_state(dev)
+        want = torch.rand(total, device=dev)[first:first + n].clone()
+        after = torch.cuda.get_rng_state(dev)
+        torch.cuda.set_rng_state(before, dev)
+        got = sampling._rows_fast(total, first, n, dev)
+        assert torch.equal(got, want)
+        assert torch.equal(torch.cuda.get_rng_state(dev), after)
+    assert sampling._rows_state["enabled"]
+    torch.manual_seed(5)
+    a = sampling.rand_rows(total, first, n, dev)         # the public entry (self-checking on its first calls)
+    torch.manual_seed(5)
+    assert torch.equal(a, torch.rand(total, device=dev)[first:first + n])
