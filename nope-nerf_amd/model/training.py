@@ -166,6 +166,8 @@ class Trainer(object):
         if loss.is_cuda:      # the root gradient as a cached constant: loss.backward() would launch a ones_like fill every step
             if self._one is None or self._one.device != loss.device:
                 self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+                if self._one.dtype == torch.float32:
+                    camera.register_unit_gradient(self._one)      # the loss head's backward then skips its `* 1`
             torch.autograd.backward(loss, grad_tensors=self._one if self._one.dtype == loss.dtype else None)
         else:
             loss.backward()
