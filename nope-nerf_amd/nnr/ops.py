@@ -256,7 +256,10 @@ class _RenderRays(torch.autograd.Function):
         if need_w:
             sizes = [int(np.prod(s)) for s in ctx.shapes]
             offs = np.cumsum([0] + [(n + 3) // 4 * 4 for n in sizes])          # keep every view 16-byte aligned
-            flat = torch.empty(int(offs[-1]), **f32)      # the weight-gradient stage overwrites every element (no zero-fill launch)
+            # ONE allocation for all 24 gradients (the weight-gradient stage overwrites every element: no zero-fill launch) + GRAD_TAIL spare
+            # floats behind them: autograd adopts the views as the parameters' .grad, so under data parallelism the step's all-reduce runs
+            # IN PLACE on this buffer, the handful of pose / distortion gradients and logged scalars riding in the tail (nnr/parallel.py)
+            flat = torch.empty(int(offs[-1]) + GRAD_TAIL, **f32)
             views = [flat[offs[i]: offs[i] + sizes[i]].view(ctx.shapes[i]) for i in range(2 * L.N_LAYERS)]
             gs = L.params_struct(views[:L.N_LAYERS], views[L.N_LAYERS:])
             L.check(lib.nnr_mlp_wgrad(C.byref(cfg), L.ptr(ctx.packed), C.byref(gs), L.ptr(_plan_for(cfg, dev)), L.ptr(ws), st), "nnr_mlp_wgrad")
@@ -268,6 +271,9 @@ class _RenderRays(torch.autograd.Function):
         ctx.ws = None
         _give_workspace(cfg, dev, ws)
         return (d_o, d_d, d_v, None, None, None, None, *grads)
+
+
+GRAD_TAIL = 2048      # spare floats behind the flat weight-gradient buffer (see _RenderRays.backward)
 
 
 def render_rays(pts_o: torch.Tensor, pts_d: torch.Tensor, view_d: torch.Tensor, z_lo: torch.Tensor, z_hi: torch.Tensor,

@@ -125,10 +125,34 @@ _LOGGED = ('loss', 'loss_rgb', 'loss_depth', 'l2_mean', 'loss_dist_1st', 'loss_d
            'loss_depth_consistency')
 
 
+def _shared_buffer(params):
+    """The flat buffer most of the gradients are views of (nnr.ops._RenderRays.backward allocates the 24 MLP gradients as ONE tensor with
+    spare room behind them, and autograd adopts the views as .grad): (whole storage as a 1-D tensor, end of the used part, the parameters
+    whose gradients live in it) -- or None when there is no such buffer (CPU stand-in, torch fallbacks)."""
+    groups = {}
+    for p in params:
+        g = p.grad
+        if g is not None and g.dtype == torch.float32 and g.is_contiguous():
+            groups.setdefault(g.untyped_storage().data_ptr(), []).append(p)
+    if not groups:
+        return None
+    members = max(groups.values(), key=len)
+    if len(members) < 8:
+        return None
+    st = members[0].grad.untyped_storage()
+    whole = torch.empty(0, dtype=torch.float32, device=members[0].grad.device).set_(st, 0, (st.nbytes() // 4,))
+    used = max(p.grad.storage_offset() + p.grad.numel() for p in members)
+    return whole, used, members
+
+
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], loss_dict: Optional[Dict[str, torch.Tensor]] = None):
-    """SUM-reduce every .grad (and the logged loss scalars) across ranks through ONE flat fp32 bucket.
+    """SUM-reduce every .grad (and the logged loss scalars) across ranks with ONE all-reduce of one flat fp32 buffer.
+    On the GPU path that buffer is the one the weight-gradient kernels wrote (the 24 MLP gradients are views of a single allocation with a
+    spare tail, nnr/ops.py): the all-reduce runs in place, the MLP gradients are never copied, and the few other gradients (pose and
+    distortion tables), the logged scalars and the flags below are packed into the tail by one cat and read back by one multi-tensor copy.
+    Without such a buffer (CPU stand-in) everything is packed into a private bucket and copied back, as in rounds 1-4.
     A parameter whose grad is None on this rank (an unused table) contributes zeros so that bucket layouts agree on every rank; one flag
-    per parameter rides along in the same bucket ("this rank has a gradient"), and a parameter that NO rank has a gradient for keeps
+    per parameter rides along ("this rank has a gradient"), and a parameter that NO rank has a gradient for keeps
     grad = None afterwards -- exactly the single-process state.  That matters: Adam skips a parameter without a gradient (no momentum
     step, no step-counter increment), and the reference leaves the distortion scales without one whenever the step's frame is the gauge
     camera (model/distortions.py:23-24); handing Adam a zero-filled gradient instead moved the scales by their momentum in those steps
@@ -136,30 +160,43 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], loss_dict: Optiona
     params = [p for p in params if p.requires_grad]
     if not params:
         return
-    pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]
+    shared = _shared_buffer(params)
+    in_place = set(id(p) for p in shared[2]) if shared else set()
+    rest = [p for p in params if id(p) not in in_place]
+    pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in rest]
     keys = [k for k in _LOGGED if loss_dict is not None and torch.is_tensor(loss_dict.get(k))]
     pieces += [loss_dict[k].detach().reshape(1).float() for k in keys]
-    dev = pieces[0].device
-    pieces.append(torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32).to(dev, non_blocking=True))
-    flat = torch.cat(pieces)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    dev = (shared[0] if shared else pieces[0]).device
+    pieces.append(torch.tensor([0.0 if p.grad is None else 1.0 for p in rest], dtype=torch.float32).to(dev, non_blocking=True))
+    n_small = sum(t.numel() for t in pieces)
+    if shared and shared[1] + n_small <= shared[0].numel():
+        whole, used, _ = shared
+        flat = whole[used:used + n_small]
+        torch.cat(pieces, out=flat)
+        dist.all_reduce(whole[:used + n_small], op=dist.ReduceOp.SUM)      # (alignment padding between the views is summed too: never read)
+    else:
+        if shared:      # (the tail is too small for this model's tables: private bucket for everything)
+            rest, pieces = params, [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params] + pieces[len(rest):-1] + \
+                [torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32).to(dev, non_blocking=True)]
+        flat = torch.cat(pieces)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     views, off = [], 0
-    for p in params:
+    for p in rest:
         n = p.numel()
         views.append(flat[off:off + n].view_as(p))
         off += n
-    have = [i for i, p in enumerate(params) if p.grad is not None]
+    have = [i for i, p in enumerate(rest) if p.grad is not None]
     if have:
-        torch._foreach_copy_([params[i].grad for i in have], [views[i] for i in have])   # one multi-tensor launch
-    missing = [i for i, p in enumerate(params) if p.grad is None]
+        torch._foreach_copy_([rest[i].grad for i in have], [views[i] for i in have])   # one multi-tensor launch
+    missing = [i for i, p in enumerate(rest) if p.grad is None]
     n_keys = len(keys)
     if missing:      # rare (a rank without a gradient for a table): did any other rank have one?  One small host read, only then.
         flags = flat[off + n_keys:].cpu()
         for i in missing:
             if float(flags[i]) > 0.0:
-                params[i].grad = views[i].clone()
+                rest[i].grad = views[i].clone()
     for k in keys:
-        # the autograd-free logged value ('loss' is no longer needed for backward at this point); a view of the private
-        # bucket, not a copy -- each copy would be one more launch per step
+        # the autograd-free logged value ('loss' is no longer needed for backward at this point); a view of the reduced
+        # buffer, not a copy -- each copy would be one more launch per step
         loss_dict[k] = flat[off]
         off += 1
