@@ -131,7 +131,8 @@ def build_trainer(device, world, aux=False, bf16=False, rays_per_gpu=None, n_sam
     return trainer, net
 
 
-_TRAFFIC_FILES = ('profiles/r04/hbm_traffic.json', 'profiles/r04/hbm_traffic_bf16_4096x128.json',
+_TRAFFIC_FILES = ('profiles/r05/hbm_traffic.json', 'profiles/r05/hbm_traffic_bf16_4096x128.json', 'profiles/r05/hbm_traffic_fp32_1024x128.json',
+                  'profiles/r04/hbm_traffic.json', 'profiles/r04/hbm_traffic_bf16_4096x128.json',
                   'profiles/r03/hbm_traffic.json', 'profiles/r03/hbm_traffic_bf16_4096x128.json',
                   'profiles/r02/hbm_traffic.json', 'profiles/r02/hbm_traffic_bf16_4096x128.json')
 _KERNEL_KEYS = {
