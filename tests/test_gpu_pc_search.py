@@ -116,3 +116,40 @@ def test_general_intrinsics_with_skew_and_principal_point():
     K = torch.tensor([[1.3, 0.07, 0.11, 0.0], [0.0, -2.2, -0.05, 0.0], [0.0, 0.0, -1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
     _check(96, 128, 48, 64, "noise", _rel((0.3, 1.0, 0.2), 0.1, (0.1, 0.05, 0.02)), 1.0, K=K)
     _check(96, 128, 48, 64, "smooth", _rel((0.3, 1.0, 0.2), 0.1, (0.1, 0.05, 0.02)), 1.3, K=K, seed=5)
+
+
+def test_weighted_sum_and_its_backward_equal_the_torch_expression():
+    """NNR_AUX_WEIGHTED: out[3] = w_pc loss_pc + w_rgbs loss_rgb_s from the finishing kernel, with its own backward (one upstream gradient,
+    the weights applied in the kernels) -- against the same losses combined by torch, including the mixed case where the separate losses
+    carry gradients of their own."""
+    from nnr import aux as nnr_aux
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11)
+    hd, wd, hr, wr = 96, 128, 48, 64
+    d1, d2 = _depths("smooth", hd, wd, g).to(dev)[None, None], _depths("smooth", hd, wd, g).to(dev)[None, None]
+    i1, i2 = torch.rand(1, 3, hr, wr, generator=g).to(dev), torch.rand(1, 3, hr, wr, generator=g).to(dev)
+    f = 0.7 * wd
+    K = torch.diag(torch.tensor([2 * f / wd, -2 * f / hd, -1.0, 1.0]))[None].to(dev)
+    Kinv = torch.linalg.inv(K)
+
+    def leaves():
+        rel = _rel((0.2, 1.0, 0.1), 0.03, (0.04, 0.01, -0.02))[None].to(dev).requires_grad_(True)
+        s2 = torch.tensor(1.3, device=dev, requires_grad=True)
+        aff = torch.tensor([1.1, 0.05, 0.9, -0.02], device=dev, requires_grad=True)
+        return rel, s2, aff
+
+    w = (0.7, 1.3)
+    for extra_pc, extra_rgbs in ((0.0, 0.0), (0.5, 0.25)):
+        rel, s2, aff = leaves()
+        out = nnr_aux.aux_terms(d1, d2, rel, s2, i1, i2, K, Kinv, (hr, wr), 0.05, aff=aff, weights=w)
+        assert len(out) == 4
+        loss = out[3] + extra_pc * out[0] + extra_rgbs * out[1] if (extra_pc or extra_rgbs) else out[3]
+        loss.backward()
+        rel_b, s2_b, aff_b = leaves()
+        l_pc, l_rgbs, _ = nnr_aux.aux_terms(d1, d2, rel_b, s2_b, i1, i2, K, Kinv, (hr, wr), 0.05, aff=aff_b)
+        want = w[0] * l_pc + w[1] * l_rgbs
+        assert float(out[3].detach()) == float(want.detach())                                      # the same two products and sum, rounded the same way
+        ((want + extra_pc * l_pc + extra_rgbs * l_rgbs) if (extra_pc or extra_rgbs) else want).backward()
+        for a, b, name in ((rel, rel_b, "rel"), (s2, s2_b, "scale2"), (aff, aff_b, "aff")):
+            scale = max(1e-6, float(b.grad.abs().max()))
+            assert float((a.grad - b.grad).abs().max()) / scale <= 2e-6, (name, extra_pc)
