@@ -1,0 +1,43 @@
+"""Time of the per-image forward (clouds + ray-aware nearest-neighbour search + sums) at the first-phase grid, noise and smooth depths.
+   python tools/time_pc_search.py        (NNR_PC_SEARCH=brute for the exhaustive search)"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nope-nerf_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+
+import test_gpu_pc_search as T
+from nnr import lib as L
+
+if __name__ == "__main__":
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    hd, wd, hr, wr = 540, 960, 135, 240
+    for kind in ("noise", "smooth"):
+        g = torch.Generator().manual_seed(1)
+        d1, d2 = T._depths(kind, hd, wd, g).to(dev), T._depths(kind, hd, wd, g).to(dev)
+        f = 0.7 * wd
+        K = torch.diag(torch.tensor([2 * f / wd, -2 * f / hd, -1.0, 1.0]))
+        Kinv = torch.linalg.inv(K.double()).float()
+        rel = T._rel((0.2, 1.0, 0.1), 0.04, (0.05, -0.02, 0.03))
+        K_c, Kinv_c, rel_c = (t.reshape(16).contiguous().float().to(dev) for t in (K, Kinv, rel))
+        s2 = torch.tensor([1.0], dtype=torch.float32, device=dev)
+        cfg = L.AuxCfg(hd, wd, hr, wr, 0.05, L.AUX_PC | L.AUX_SCALE_PCS, 0, 0)
+        ws = torch.zeros(lib.nnr_aux_workspace_floats(C.byref(cfg)) + 2, dtype=torch.float32, device=dev)
+        ws = ws[(ws.data_ptr() % 8) // 4:]
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        run = lambda: L.check(lib.nnr_aux_terms_fwd(C.byref(cfg), L.ptr(d1), L.ptr(d2), None, None, L.ptr(K_c), L.ptr(Kinv_c), L.ptr(rel_c), L.ptr(s2), None,
+                                                    L.ptr(out), L.ptr(ws), L.stream()), "fwd")
+        for _ in range(10):
+            run()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(100):
+            run()
+        b.record()
+        torch.cuda.synchronize()
+        print("%-6s depths, 135 x 240 grid: per-image forward %.1f us (loss_pc %.6f)" % (kind, a.elapsed_time(b) * 10, float(out[0])))
