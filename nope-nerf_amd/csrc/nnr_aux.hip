@@ -134,6 +134,8 @@ __global__ __launch_bounds__(256) void aux_points_fwd_kernel(AuxArgs a) {
             if (a.flags & NNR_AUX_PC) { a.gXq[3 * i + r] = 0; a.gYq[3 * i + r] = 0; }      // the backward's accumulators (was a memset launch there)
         }
         if (i == 0) *reinterpret_cast<unsigned int*>(a.acc + 7) = 0u;      // the ticket counter of aux_dist_sum_kernel
+        if ((a.flags & NNR_AUX_PC) && i < 2 * (((a.wr + 7) / 8) * ((a.hr + 7) / 8)))      // the "heavy tile" flags of the search (behind the 8 tiles sphere floats)
+            reinterpret_cast<int*>(a.keys)[8 * (((a.wr + 7) / 8) * ((a.hr + 7) / 8)) + i] = 0;
         float gxy0 = 0.f, gxy1 = 0.f;
         uint32_t fl = g.flags;
         if (a.flags & NNR_AUX_RGBS) {
@@ -372,16 +374,25 @@ __device__ __forceinline__ PcRays pc_rays(const AuxArgs& a, int dir) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void aux_pc_search_kernel(AuxArgs a) {
+constexpr float kPcHeavyArea = 1000.f;      // grid points in a source's window after the first guesses beyond which it goes to the tile kernel
+
+constexpr int kPcHeavyVote = 4;             // sources of an 8 x 8 tile with such a window for the tile to go there (fewer: they are scanned here, slowly)
+
+// One workgroup = one 8 x 8 tile of the source grid (the tile kernel's tiles), eight lanes per source.
+__global__ __launch_bounds__(64 * kPcLanes) void aux_pc_search_kernel(AuxArgs a, int* __restrict__ heavy, const float* __restrict__ spheres, float heavy_area, int heavy_vote) {      // heavy: null = scan everything here
     constexpr int G = kPcLanes;
     const int dir = blockIdx.y;
     const float* __restrict__ src = dir == 0 ? a.X : a.Y;
     const float* __restrict__ dst = dir == 0 ? a.Y : a.X;
-    const int sub = threadIdx.x % G;
-    const int s = a.s_lo + blockIdx.x * (256 / G) + threadIdx.x / G;
-    if (s >= a.s_hi) return;      // (whole groups leave together: the shuffles below stay inside a group)
-    const PcRays R = pc_rays(a, dir);
     const int wr = a.wr, hr = a.hr;
+    const int sub = threadIdx.x % G, grp = threadIdx.x / G;
+    const int tiles_x = (wr + 7) / 8;
+    const int src_y = 8 * ((int)blockIdx.x / tiles_x) + grp / 8, src_x = 8 * ((int)blockIdx.x % tiles_x) + grp % 8;
+    const int s_flat = src_y * wr + src_x;
+    const bool live = src_y < hr && src_x < wr && s_flat >= a.s_lo && s_flat < a.s_hi;
+    const int s = live ? s_flat : a.s_lo;      // (a source that is not this workgroup's, or nobody's: it walks along to the vote below and leaves)
+    if (a.s_hi <= a.s_lo) return;
+    const PcRays R = pc_rays(a, dir);
     const float sx = src[3 * s], sy = src[3 * s + 1], sz = src[3 * s + 2];
     const float wx = sx - R.c[0], wy = sy - R.c[1], wz = sz - R.c[2];
     const float px = R.Minv[0] * wx + R.Minv[1] * wy + R.Minv[2] * wz, py = R.Minv[3] * wx + R.Minv[4] * wy + R.Minv[5] * wz,
@@ -422,12 +433,39 @@ __global__ __launch_bounds__(256) void aux_pc_search_kernel(AuxArgs a) {
         const float t = best_s * best_s;
         thr = best_s < __builtin_inff() ? __builtin_fmaf(t, 4.8e-7f, t) + 1.2e-38f : __builtin_inff();
     };
-    // first guesses: the 5 x 5 grid points around the projection (clamped into the grid)
-    for (int k = sub; k < 25; k += G) {
-        const int yy = min(max(y0 + k / 5 - 2, 0), hr - 1), xx = min(max(x0 + k % 5 - 2, 0), wr - 1);
+    // first guesses: the 9 x 9 grid points around the projection (clamped into the grid) -- enough of them that the window they imply says
+    // which kernel this source belongs to (below), also where the depths are rough
+    for (int k = sub; live && k < 81; k += G) {
+        const int yy = min(max(y0 + k / 9 - 4, 0), hr - 1), xx = min(max(x0 + k % 9 - 4, 0), wr - 1);
         consider(dist2(yy * wr + xx), yy * wr + xx);
     }
     share();
+    // A window that is still large after the first guesses (or a source that cannot prune at all) is not for this kernel -- a candidate
+    // from memory costs ~20x what it costs the tile kernel below.  The tile's sources vote: with kPcHeavyVote or more such windows the tile
+    // is flagged HEAVY and everybody leaves -- aux_pc_search_tile_kernel redoes every source of a flagged tile (and exits at once for the
+    // others); with fewer (rough depths: the odd bad first guess) they are scanned here.
+    {
+        bool mine = false;
+        if (heavy && live) {
+            float area = __builtin_inff();
+            if (prune && thr < __builtin_inff()) {
+                const float rho = sqrtf(thr) * 1.001f + 1e-5f * (wl + cl + sqrtf(thr)) + 1e-30f;
+                const float t = rho * bz, r2 = t * t * 1.001f;
+                area = 4.f * sqrtf(r2 * R.guu / R.det) * hh * sqrtf(r2 * R.gvv / R.det) * hw;      // the ellipse's bounding box in grid points
+            }
+            // ... and the tile kernel can do better only where its sphere bound bites: the destination tile under the projection must be
+            // THIN against the distance in question (a smooth surface patch; with rough depths -- a sphere as deep as the depth range -- the
+            // ray window is all there is, and that is this kernel's bound)
+            const float r_tile = spheres[4 * ((dir == 0 ? tiles_x * ((hr + 7) / 8) : 0) + (y0 / 8) * tiles_x + x0 / 8) + 3];
+            mine = !(area <= heavy_area) && !(r_tile > 3.f * best_s);      // (NaN: heavy)
+        }
+        const int votes = __syncthreads_count(mine && sub == 0);      // (every thread of the workgroup is here)
+        if (votes >= heavy_vote) {
+            if (threadIdx.x == 0) heavy[dir * (tiles_x * ((hr + 7) / 8)) + (int)blockIdx.x] = 1;
+            return;
+        }
+        if (!live) return;      // (whole groups: the shuffles below stay inside a group)
+    }
     // rows outwards from the projection: offsets 0, +1, -1, +2, -2, ..; lane `sub` takes every G-th
     const int m_end = 2 * max(y0, hr - 1 - y0);      // last useful position of the zigzag
     const float pu = 1.f / hw, pv = 1.f / hh;        // grid pitch in u, v
@@ -483,6 +521,268 @@ __global__ __launch_bounds__(256) void aux_pc_search_kernel(AuxArgs a) {
         int64_t* idx = dir == 0 ? a.idx_xy : a.idx_yx;
         float* dist = dir == 0 ? a.dist_xy : a.dist_yx;
         // nothing found (NaN / inf coordinates): index 0xffffffff, a NaN distance -- what the key table decoded to
+        idx[s] = best_i == 0x7fffffff ? (int64_t)0xffffffffll : (int64_t)best_i;
+        dist[s] = best_i == 0x7fffffff ? __uint_as_float(0xffffffffu) : best_s;
+    }
+}
+
+// ---- the second kernel of the search: the HEAVY tiles -- smooth surfaces far apart ------------------------------------------------------
+// aux_pc_search_kernel above reads every candidate from global memory, eight lanes per source, and prunes by the distance to the
+// destination RAYS only.  That is the right bound for depth maps that are rough along the ray (the bench's white-noise depths: 7 pixels of
+// radius, ~50 us), but it ignores DEPTH: where the two clouds are smooth surfaces a parallax or a not-yet-learned depth scale apart -- a real
+// scene at the start of training: nearest neighbours 0.1 - 1 scene units away, 30 - 70 pixels of radius (tools/pc_window_stats.py) -- the
+// ellipses hold a third of the grid, a candidate costs ~20x what it costs the exhaustive kernel, and the search took 420 us inside the
+// reference's train.py, more than the exhaustive one (profiles/r05/l_*).  So the sources are split.  aux_pc_spheres_kernel gives every
+// 8 x 8 tile of either cloud's grid a bounding sphere (smooth patches have small ones, whatever their pose).  In aux_pc_search_kernel the 64
+// sources of a tile VOTE after their first guesses: a source whose window is still large, over a destination patch that is thin against
+// the distance in question, is better off here; with kPcHeavyVote of them the tile is flagged and left to aux_pc_search_tile_kernel:
+//   * four waves per flagged 8 x 8 tile of sources, lane = source in each; destination tile (ty, tx) belongs to wave 2 (ty & 1) + (tx & 1);
+//   * BEST FIRST: every destination tile of the wave has a wave-level bound |centre - centre| - both radii (no source of the tile is closer
+//     to any of its points), one tile per lane and register; each turn takes the smallest bound left, stops when it exceeds the largest
+//     running minimum of any source, re-tests per source (the ray window, and the tile's sphere against the source's own point and
+//     minimum) and, if any source needs it, evaluates the tile for ALL 64 lanes the way the exhaustive kernel evaluates candidates: the
+//     64 points go through a wave-private LDS image as pairs [x0 x1 y0 y1 z0 z1], three 16-byte broadcasts deliver four points as packed
+//     operands -- the same arithmetic, keys and tie rule, ~5 instructions per pair instead of ~100;
+//   * the waves share their running minima through an atomic minimum in LDS (read without synchronisation: a stale value is a larger
+//     bound, never a wrong one) and merge their results at the end.
+// Every bound only ever skips points that are farther than the source's running minimum (margins for every rounding involved); the indices
+// are the exhaustive search's, in either kernel and in any split (tests/test_gpu_pc_search.py runs each kernel alone on everything too).
+// Measured (tools/time_pc_search.py --scene, tools/gpu_loop_trace.sh; exhaustive search / first kernel alone / both): bench-like noise depths
+// 345 / 55 / 60 us, smooth depths a small pose apart 309 / 44 / 53, two frames of a real scene at the identity pose 316 / 745 / 354, the
+// search inside the reference's train.py over the first epochs 353 / 420 / 250.
+constexpr int kPcT = 8;      // tile side (64 points: one per lane)
+
+// spheres[cloud][tile] = (cx, cy, cz, r); cloud 0 = X, 1 = Y.  One wave per tile.
+__global__ __launch_bounds__(64) void aux_pc_spheres_kernel(AuxArgs a, float* __restrict__ spheres) {
+    const int tiles_x = (a.wr + kPcT - 1) / kPcT, tiles = tiles_x * ((a.hr + kPcT - 1) / kPcT);
+    const float* __restrict__ cloud = blockIdx.y == 0 ? a.X : a.Y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y = kPcT * ty + (int)threadIdx.x / kPcT, x = kPcT * tx + (int)threadIdx.x % kPcT;
+    const bool in = y < a.hr && x < a.wr;
+    const int j = in ? y * a.wr + x : 0;
+    const float inf = __builtin_inff();
+    const float qx = cloud[3 * j], qy = cloud[3 * j + 1], qz = cloud[3 * j + 2];
+    float lo[3] = {in ? qx : inf, in ? qy : inf, in ? qz : inf}, hi[3] = {in ? qx : -inf, in ? qy : -inf, in ? qz : -inf};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o, 64)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o, 64)); }
+    const float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
+    const float ex = qx - cx, ey = qy - cy, ez = qz - cz;
+    float r = in ? sqrtf(ex * ex + ey * ey + ez * ez) : 0.f;
+    bool bad = in && !(r < inf);      // a NaN / inf point: the tile gets no bound (it is always visited)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) r = fmaxf(r, __shfl_xor(r, o, 64));
+    bad = __any(bad) || !(cx == cx && cy == cy && cz == cz) || !(fabsf(cx) < inf && fabsf(cy) < inf && fabsf(cz) < inf);
+    if (threadIdx.x == 0) {
+        float* o = spheres + 4 * ((int)blockIdx.y * tiles + (int)blockIdx.x);
+        o[0] = bad ? 0.f : cx; o[1] = bad ? 0.f : cy; o[2] = bad ? 0.f : cz;
+        o[3] = bad ? inf : r * 1.00001f + 1e-30f;
+    }
+}
+
+constexpr int kPcMaxTiles = 2048;      // destination tiles the tile kernel handles (their spheres in LDS: 32 KB; one bound per lane and register: 32): 131 072 grid points;
+                                       // larger grids stay in the eight-lanes-per-source kernel
+
+constexpr int kPcTileWaves = 4;       // waves per source tile (a 2 x 2 pattern of destination tiles: one each)
+
+__global__ __launch_bounds__(64 * kPcTileWaves) void aux_pc_search_tile_kernel(AuxArgs a, const float* __restrict__ spheres, const int* __restrict__ heavy) {
+    __shared__ f32x4 img_all[kPcTileWaves][48];      // per wave: 64 points as 16 groups of [x0 x1 y0 y1 | z0 z1 x2 x3 | y2 y3 z2 z3]
+    __shared__ f32x4 sph_lds[kPcMaxTiles];
+    __shared__ float res_s[kPcTileWaves][64];
+    __shared__ int res_i[kPcTileWaves][64];
+    __shared__ int cap_min[64];      // per source: the smallest running minimum of any wave (bit pattern of a non-negative float: ordered like it), what all waves prune with
+    const int dir = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* __restrict__ src = dir == 0 ? a.X : a.Y;
+    const float* __restrict__ dst = dir == 0 ? a.Y : a.X;
+    const int wr = a.wr, hr = a.hr;
+    const int tiles_x = (wr + kPcT - 1) / kPcT, tiles_y = (hr + kPcT - 1) / kPcT, tiles = tiles_x * tiles_y;
+    if (heavy && !heavy[dir * tiles + (int)blockIdx.x]) return;      // (the whole workgroup: the eight-lanes-per-source kernel has done this tile)
+    const f32x4* __restrict__ sph_g = reinterpret_cast<const f32x4*>(spheres) + (dir == 0 ? tiles : 0);      // the DESTINATION cloud's spheres
+    if (tiles > kPcMaxTiles) __builtin_trap();      // (the launcher does not send such grids here)
+    constexpr bool sph_in_lds = true;
+    if (sph_in_lds)
+        for (int t = threadIdx.x; t < tiles; t += 64 * kPcTileWaves) sph_lds[t] = sph_g[t];
+    if (wave == 0) cap_min[lane] = __float_as_int(__builtin_inff());
+    __syncthreads();
+    // The sixteen waves of the workgroup own the SAME tile of sources (lane = source in each of them) and share the destination tiles: tile
+    // (ty, tx) belongs to wave 4 (ty & 3) + (tx & 3).  A wave walks, tests and evaluates only its own tiles, prunes with the smallest running
+    // minimum of any wave (an atomic minimum in LDS, read without synchronisation: a stale value is a larger bound, never a wrong one), and
+    // the results are merged at the end.  The work of a tile is what it is; what this buys is the TAIL: the sources of a region that the
+    // other frame does not see have windows of hundreds of tiles, and one wave walking them alone was the kernel's duration.
+    const int st = blockIdx.x;
+    const int sty = st / tiles_x, stx = st - sty * tiles_x;
+    const int sy = kPcT * sty + lane / kPcT, sx = kPcT * stx + lane % kPcT;
+    const int s = sy * wr + sx;
+    const bool live = sy < hr && sx < wr && s >= a.s_lo && s < a.s_hi;
+    if (!__any(live)) return;      // (the same lanes in all four waves: the whole workgroup leaves)
+    const int sc = live ? s : 0;
+    const PcRays R = pc_rays(a, dir);
+    const float sxx = src[3 * sc], syy = src[3 * sc + 1], szz = src[3 * sc + 2];
+    const float wx = sxx - R.c[0], wy = syy - R.c[1], wz = szz - R.c[2];
+    const float px = R.Minv[0] * wx + R.Minv[1] * wy + R.Minv[2] * wz, py = R.Minv[3] * wx + R.Minv[4] * wy + R.Minv[5] * wz,
+                pz = R.Minv[6] * wx + R.Minv[7] * wy + R.Minv[8] * wz;
+    const float wl = sqrtf(wx * wx + wy * wy + wz * wz), cl = fabsf(R.c[0]) + fabsf(R.c[1]) + fabsf(R.c[2]);
+    const bool prune = R.ok && fabsf(pz) > 1e-4f * (fabsf(px) + fabsf(py)) && fabsf(pz) > 1e-30f && wl < 1e30f;
+    const float u = prune ? px / pz : 0.f, v = prune ? py / pz : 0.f;
+    const float hw = 0.5f * (float)(wr - 1), hh = 0.5f * (float)(hr - 1);
+    const float fx = (u + 1.f) * hw, fy = (v + 1.f) * hh;
+    const float bz = prune ? R.B / fabsf(pz) : 0.f;
+    const f32x2 X2 = {sxx, sxx}, Y2 = {syy, syy}, Z2 = {szz, szz};
+
+    float best_s = __builtin_inff(), thr = __builtin_inff();
+    int best_i = 0x7fffffff;
+    auto consider = [&](float d2, int idx) __attribute__((always_inline)) {
+        if (d2 <= thr && d2 < __builtin_inff()) {
+            const float sq = __fsqrt_rn(d2);
+            if (sq < best_s || (sq == best_s && idx < best_i)) {
+                best_s = sq;
+                best_i = idx;
+                const float t = sq * sq;
+                thr = __builtin_fmaf(t, 4.8e-7f, t) + 1.2e-38f;      // every d2 whose rounded root is <= best_s lies below this (nnr_pointcloud.hip)
+            }
+        }
+    };
+    // the lane's window: the bounding box of its ray ellipse for the current minimum, in TILE coordinates (the whole grid where it cannot prune)
+    int bx0, bx1, by0, by1;
+    float cap = __builtin_inff();      // min over the four waves of the running minimum of this source
+    auto window = [&]() __attribute__((always_inline)) {
+        bx0 = 0; bx1 = tiles_x - 1; by0 = 0; by1 = tiles_y - 1;
+        cap = __int_as_float(cap_min[lane]);
+        if (prune && cap < __builtin_inff()) {
+            const float t2 = cap * cap, thr_c = __builtin_fmaf(t2, 4.8e-7f, t2) + 1.2e-38f;
+            const float rho = sqrtf(thr_c) * 1.001f + 1e-5f * (wl + cl + sqrtf(thr_c)) + 1e-30f;
+            const float t = rho * bz, r2 = t * t * 1.001f;
+            const float dvm = sqrtf(r2 * R.guu / R.det) * hh + 1.5f, dum = sqrtf(r2 * R.gvv / R.det) * hw + 1.5f;      // half extents in grid units
+            const float ya = fy - dvm, yb = fy + dvm, xa = fx - dum, xb = fx + dum;
+            if (ya == ya && yb == yb && xa == xa && xb == xb) {      // (NaN: keep the whole grid)
+                by0 = (int)fminf(fmaxf(floorf(ya), 0.f), (float)hr) / kPcT; by1 = (int)fmaxf(fminf(ceilf(yb), (float)(hr - 1)), -1.f);
+                bx0 = (int)fminf(fmaxf(floorf(xa), 0.f), (float)wr) / kPcT; bx1 = (int)fmaxf(fminf(ceilf(xb), (float)(wr - 1)), -1.f);
+                by1 = by1 < 0 ? -1 : by1 / kPcT;      // (an ellipse that misses the grid: an empty window)
+                bx1 = bx1 < 0 ? -1 : bx1 / kPcT;
+            }
+        }
+        if (!live) { by0 = 1; by1 = 0; bx0 = 1; bx1 = 0; }
+    };
+    auto wave_min = [](int v) __attribute__((always_inline)) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+        return v;
+    };
+    f32x4* const img = img_all[wave];
+    float* const imgf = reinterpret_cast<float*>(img);
+    const int my_slot = 12 * (lane >> 2) + ((lane & 3) >> 1) * 6 + (lane & 1);      // point l of the tile: group l / 4, pair (l & 3) / 2, half l & 1: x at +0, y at +2, z at +4
+    // does any lane need tile (ty, tx)?  (its window meets the tile and the tile's sphere comes within its running minimum)
+    auto needed = [&](int ty, int tx) __attribute__((always_inline)) {
+#ifdef NNR_PC_DEBUG
+        if (lane == 0) atomicAdd(a.acc + 6, 1.f);
+#endif
+        const f32x4 sp = sph_in_lds ? sph_lds[ty * tiles_x + tx] : sph_g[ty * tiles_x + tx];
+        const float ex = sxx - sp[0], ey = syy - sp[1], ez = szz - sp[2];
+        const float lb = sqrtf(ex * ex + ey * ey + ez * ez) * 0.999998f - sp[3];      // no point of the tile is closer than this
+        return __any(ty >= by0 && ty <= by1 && tx >= bx0 && tx <= bx1 && !(lb > fminf(best_s, cap) * 1.000001f)) != 0;
+    };
+    // Best first.  Every destination tile of this wave gets a WAVE-level bound -- |centre of the source tile's sphere - centre of its sphere|
+    // minus both radii: no source of the tile is closer to any of its points -- held one tile per lane and register (tile 64 k + lane in
+    // register k).  Each turn takes the smallest bound left (a wave minimum), stops when it exceeds the largest running minimum of any
+    // source, re-tests the tile per source (needed(): the ray window and the sphere against the source's own point and minimum) and
+    // evaluates it.  No walk over the grid, and the near tiles -- the ones that set the minima -- come first whatever the geometry.
+    constexpr int kRegs = kPcMaxTiles / 64;
+    float lbk[kRegs];
+    {
+        const f32x4 ss = (reinterpret_cast<const f32x4*>(spheres) + (dir == 0 ? 0 : tiles))[st];      // the SOURCE tile's sphere
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k) {
+            const int t = 64 * k + lane;
+            lbk[k] = __builtin_inff();
+            if (t < tiles && sph_in_lds) {
+                const int ty = t / tiles_x, tx = t - ty * tiles_x;
+                if ((2 * (ty & 1) + (tx & 1)) == wave) {
+                    const f32x4 sd = sph_lds[t];
+                    const float ex = ss[0] - sd[0], ey = ss[1] - sd[1], ez = ss[2] - sd[2];
+                    const float lb = sqrtf(ex * ex + ey * ey + ez * ez) * 0.999998f - ss[3] - sd[3];
+                    lbk[k] = lb == lb ? fmaxf(lb, -3e38f) : -3e38f;      // (no bound: first in line)
+                }
+            }
+        }
+    }
+    const float inf = __builtin_inff();
+    auto fetch = [&](int ty, int tx, float (&q)[3]) __attribute__((always_inline)) {      // this lane's point of the tile (padding: +inf, never a minimum)
+        const int y = kPcT * ty + lane / kPcT, x = kPcT * tx + lane % kPcT;
+        const bool in = y < hr && x < wr;
+        const int j = in ? y * wr + x : 0;
+        q[0] = in ? dst[3 * j] : inf; q[1] = in ? dst[3 * j + 1] : inf; q[2] = in ? dst[3 * j + 2] : inf;
+    };
+    auto wave_minf = [](float v) __attribute__((always_inline)) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+        return v;
+    };
+    const int n_regs = (tiles + 63) / 64;      // (wave-uniform: registers beyond it hold +inf and are not looked at)
+    float rho_max = inf;
+    bool stale = true;      // the windows / the largest minimum need recomputing (something was evaluated since)
+    for (int turn = 0; turn < kPcMaxTiles; ++turn) {
+        // the smallest bound left: per lane, then over the wave
+        float m = lbk[0];
+        int km = 0;
+#pragma unroll
+        for (int k = 1; k < kRegs; ++k)
+            if (k < n_regs && lbk[k] < m) { m = lbk[k]; km = k; }
+        const float wm = wave_minf(m);
+        if (!(wm < inf)) break;      // nothing left
+        if (stale || (turn & 7) == 7) {      // (every few turns anyway: the other waves lower the shared minima too)
+            window();                        // cap and the windows for the minima as they stand
+            rho_max = live ? fminf(best_s, cap) : 0.f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rho_max = fmaxf(rho_max, __shfl_xor(rho_max, o, 64));
+            stale = false;
+        }
+        if (wm > rho_max * 1.000001f) break;      // no tile left can hold a point within any source's minimum
+        const unsigned long long who = __ballot(m == wm);
+        const int owner = __builtin_ctzll(who);
+        const int t = __shfl(64 * km + lane, owner, 64);
+        if (lane == owner) {
+#pragma unroll
+            for (int k = 0; k < kRegs; ++k)
+                if (k == km) lbk[k] = inf;
+        }
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        if (!needed(ty, tx)) continue;
+        float q[3];
+        fetch(ty, tx, q);
+#ifdef NNR_PC_DEBUG
+        if (lane == 0) atomicAdd(a.acc + 5, 1.f);
+#endif
+        __builtin_amdgcn_wave_barrier();      // (the previous tile's reads are done: one wave, LDS operations in order)
+        imgf[my_slot] = q[0]; imgf[my_slot + 2] = q[1]; imgf[my_slot + 4] = q[2];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int g = 0; g < 16; ++g) {
+            const f32x4 A = img[3 * g], Bq = img[3 * g + 1], C = img[3 * g + 2];      // x0 x1 y0 y1 | z0 z1 x2 x3 | y2 y3 z2 z3
+            const f32x2 dx0 = X2 - f32x2{A[0], A[1]}, dy0 = Y2 - f32x2{A[2], A[3]}, dz0 = Z2 - f32x2{Bq[0], Bq[1]};
+            const f32x2 dx1 = X2 - f32x2{Bq[2], Bq[3]}, dy1 = Y2 - f32x2{C[0], C[1]}, dz1 = Z2 - f32x2{C[2], C[3]};
+            const f32x2 e0 = __builtin_elementwise_fma(dz0, dz0, __builtin_elementwise_fma(dy0, dy0, dx0 * dx0));
+            const f32x2 e1 = __builtin_elementwise_fma(dz1, dz1, __builtin_elementwise_fma(dy1, dy1, dx1 * dx1));
+            if ((e0[0] <= thr) | (e0[1] <= thr) | (e1[0] <= thr) | (e1[1] <= thr)) {
+                const int l0 = 4 * g, j0 = (kPcT * ty + l0 / kPcT) * wr + kPcT * tx + l0 % kPcT;      // (4 consecutive points share a tile row)
+                consider(e0[0], j0); consider(e0[1], j0 + 1); consider(e1[0], j0 + 2); consider(e1[1], j0 + 3);
+            }
+        }
+        if (best_s < cap) atomicMin(&cap_min[lane], __float_as_int(best_s));      // (for all waves, this one's next window() included)
+        stale = true;
+    }
+    res_s[wave][lane] = best_s;
+    res_i[wave][lane] = best_i;
+    __syncthreads();
+    if (wave == 0 && live) {      // the four waves' minima of this source: (distance, index) lexicographic, as everywhere
+#pragma unroll
+        for (int w = 1; w < kPcTileWaves; ++w) {
+            const float os = res_s[w][lane];
+            const int oi = res_i[w][lane];
+            if (os < best_s || (os == best_s && oi < best_i)) { best_s = os; best_i = oi; }
+        }
+        int64_t* idx = dir == 0 ? a.idx_xy : a.idx_yx;
+        float* dist = dir == 0 ? a.dist_xy : a.dist_yx;
         idx[s] = best_i == 0x7fffffff ? (int64_t)0xffffffffll : (int64_t)best_i;
         dist[s] = best_i == 0x7fffffff ? __uint_as_float(0xffffffffu) : best_s;
     }
@@ -770,8 +1070,22 @@ hipError_t launch_aux_fwd(const AuxArgs& a, hipStream_t st) {
     if ((a.flags & NNR_AUX_RGBS) && (a.flags & NNR_AUX_SSIM)) hipLaunchKernelGGL(aux_ssim_kernel, dim3(nb), dim3(256), 0, st, a);
     if (a.flags & NNR_AUX_PC) {
         static const bool brute = [] { const char* e = std::getenv("NNR_PC_SEARCH"); return e && std::string(e) == "brute"; }();
-        if (!brute) {      // the ray-aware search (aux_pc_search_kernel): both directions, indices and distances, one launch
-            if (n > 0) hipLaunchKernelGGL(aux_pc_search_kernel, dim3((n * kPcLanes + 255) / 256, 2), dim3(256), 0, st, a);
+        static const bool rows = [] { const char* e = std::getenv("NNR_PC_SEARCH"); return e && std::string(e) == "rows"; }();
+        if (!brute) {      // the ray-aware search: both directions, indices and distances, one launch
+            // NNR_PC_SEARCH=rows / tiles: one of the two kernels alone (A/B); default: the light sources in the first, the heavy tiles in the second
+            static const bool only_tiles = [] { const char* e = std::getenv("NNR_PC_SEARCH"); return e && std::string(e) == "tiles"; }();
+            if (n > 0) {
+                const int tiles = ((a.wr + kPcT - 1) / kPcT) * ((a.hr + kPcT - 1) / kPcT);
+                float* spheres = reinterpret_cast<float*>(a.keys);      // (the key table of the exhaustive path: 4 S floats, unused here; 10 tiles words needed)
+                int* heavy = reinterpret_cast<int*>(a.keys) + 8 * tiles;
+                static const float area = [] { const char* e = std::getenv("NNR_PC_HEAVY_AREA"); return e ? (float)std::atof(e) : kPcHeavyArea; }();      // (tuning knobs)
+                static const int vote = [] { const char* e = std::getenv("NNR_PC_HEAVY_VOTE"); return e ? std::atoi(e) : kPcHeavyVote; }();
+                const bool rows_only = rows || tiles > kPcMaxTiles;
+                if (!rows_only) hipLaunchKernelGGL(aux_pc_spheres_kernel, dim3(tiles, 2), dim3(64), 0, st, a, spheres);
+                if (!only_tiles || rows_only)
+                    hipLaunchKernelGGL(aux_pc_search_kernel, dim3(tiles, 2), dim3(64 * kPcLanes), 0, st, a, rows_only ? nullptr : heavy, spheres, area, vote);
+                if (!rows_only) hipLaunchKernelGGL(aux_pc_search_tile_kernel, dim3(tiles, 2), dim3(64 * kPcTileWaves), 0, st, a, spheres, only_tiles ? nullptr : heavy);
+            }
             hipLaunchKernelGGL(aux_dist_sum_kernel, dim3(nb, 2), dim3(256), 0, st, a);      // + the finishing step, in its last block
             return hipGetLastError();
         }

@@ -153,3 +153,15 @@ def test_weighted_sum_and_its_backward_equal_the_torch_expression():
         for a, b, name in ((rel, rel_b, "rel"), (s2, s2_b, "scale2"), (aff, aff_b, "aff")):
             scale = max(1e-6, float(b.grad.abs().max()))
             assert float((a.grad - b.grad).abs().max()) / scale <= 2e-6, (name, extra_pc)
+
+
+@pytest.mark.parametrize("which", ["rows", "tiles"])
+def test_each_search_kernel_alone_equals_the_exhaustive_search(which):
+    """The product search runs the light sources in the eight-lanes-per-source kernel and the heavy 8 x 8 tiles in the wave-per-tile kernel;
+    NNR_PC_SEARCH=rows / tiles (read once per process) runs ONE of them on everything: the cases above again, in a child process."""
+    import subprocess
+    env = dict(os.environ, NNR_PC_SEARCH=which)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "exhaustive_search and not alone or first_phase or intrinsics",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

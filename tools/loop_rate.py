@@ -49,7 +49,9 @@ def run_mode(mode, scene_root, scene, rays, samples, epochs, work):
     times = os.path.join(work, mode + "_times.json")
     env = dict(os.environ, DROPIN_BACKEND=os.environ.get("LOOP_BACKEND", "hip"), DROPIN_TIMES=times, NNR_REFERENCE=os.path.join(STAGE, "ref"), PYTHONPATH="")
     t0 = time.perf_counter()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_runner.py"), "train.py", ypath], cwd=os.path.join(STAGE, "ref"), env=env,
+    wrap = os.environ.get("LOOP_TRACE_DIR")      # LOOP_TRACE_DIR=/tmp/x: the child under rocprofv3 --kernel-trace --stats (its rate is then the tracer's, not the loop's)
+    pre = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", wrap, "-o", "child_" + mode, "--"] if wrap else []
+    r = subprocess.run(pre + [sys.executable, os.path.join(ROOT, "tests", "dropin_runner.py"), "train.py", ypath], cwd=os.path.join(STAGE, "ref"), env=env,
                        capture_output=True, text=True, timeout=900)
     wall = time.perf_counter() - t0
     if r.returncode != 0:
