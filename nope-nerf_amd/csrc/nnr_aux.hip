@@ -536,7 +536,9 @@ __global__ __launch_bounds__(64 * kPcLanes) void aux_pc_search_kernel(AuxArgs a,
 // 8 x 8 tile of either cloud's grid a bounding sphere (smooth patches have small ones, whatever their pose).  In aux_pc_search_kernel the 64
 // sources of a tile VOTE after their first guesses: a source whose window is still large, over a destination patch that is thin against
 // the distance in question, is better off here; with kPcHeavyVote of them the tile is flagged and left to aux_pc_search_tile_kernel:
-//   * four waves per flagged 8 x 8 tile of sources, lane = source in each; destination tile (ty, tx) belongs to wave 2 (ty & 1) + (tx & 1);
+//   * sixteen waves per flagged 8 x 8 tile of sources, lane = source in each; destination tile (ty, tx) belongs to wave 4 (ty & 3) + (tx & 3)
+//     (what a tile costs is set by its slowest sources -- a region the other frame does not see has windows of hundreds of tiles -- so the
+//     tile's work is spread wide: 4 waves 190 us in the training loop, 16 waves 164);
 //   * BEST FIRST: every destination tile of the wave has a wave-level bound |centre - centre| - both radii (no source of the tile is closer
 //     to any of its points), one tile per lane and register; each turn takes the smallest bound left, stops when it exceeds the largest
 //     running minimum of any source, re-tests per source (the ray window, and the tile's sphere against the source's own point and
@@ -548,8 +550,8 @@ __global__ __launch_bounds__(64 * kPcLanes) void aux_pc_search_kernel(AuxArgs a,
 // Every bound only ever skips points that are farther than the source's running minimum (margins for every rounding involved); the indices
 // are the exhaustive search's, in either kernel and in any split (tests/test_gpu_pc_search.py runs each kernel alone on everything too).
 // Measured (tools/time_pc_search.py --scene, tools/gpu_loop_trace.sh; exhaustive search / first kernel alone / both): bench-like noise depths
-// 345 / 55 / 60 us, smooth depths a small pose apart 309 / 44 / 53, two frames of a real scene at the identity pose 316 / 745 / 354, the
-// search inside the reference's train.py over the first epochs 353 / 420 / 250.
+// 339 / 55 / 61 us, smooth depths a small pose apart 307 / 47 / 55, two frames of a real scene at the identity pose 315 / 1127 / 296, the
+// search inside the reference's train.py over the first epochs 351 / 464 / 226.
 constexpr int kPcT = 8;      // tile side (64 points: one per lane)
 
 // spheres[cloud][tile] = (cx, cy, cz, r); cloud 0 = X, 1 = Y.  One wave per tile.
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(64) void aux_pc_spheres_kernel(AuxArgs a, float* __
 constexpr int kPcMaxTiles = 2048;      // destination tiles the tile kernel handles (their spheres in LDS: 32 KB; one bound per lane and register: 32): 131 072 grid points;
                                        // larger grids stay in the eight-lanes-per-source kernel
 
-constexpr int kPcTileWaves = 4;       // waves per source tile (a 2 x 2 pattern of destination tiles: one each)
+constexpr int kPcTileWaves = 16;      // waves per source tile (a 4 x 4 pattern of destination tiles: one each)
 
 __global__ __launch_bounds__(64 * kPcTileWaves) void aux_pc_search_tile_kernel(AuxArgs a, const float* __restrict__ spheres, const int* __restrict__ heavy) {
     __shared__ f32x4 img_all[kPcTileWaves][48];      // per wave: 64 points as 16 groups of [x0 x1 y0 y1 | z0 z1 x2 x3 | y2 y3 z2 z3]
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(64 * kPcTileWaves) void aux_pc_search_tile_kernel(A
         for (int t = threadIdx.x; t < tiles; t += 64 * kPcTileWaves) sph_lds[t] = sph_g[t];
     if (wave == 0) cap_min[lane] = __float_as_int(__builtin_inff());
     __syncthreads();
-    // The sixteen waves of the workgroup own the SAME tile of sources (lane = source in each of them) and share the destination tiles: tile
+    // The waves of the workgroup own the SAME tile of sources (lane = source in each of them) and share the destination tiles: tile
     // (ty, tx) belongs to wave 4 (ty & 3) + (tx & 3).  A wave walks, tests and evaluates only its own tiles, prunes with the smallest running
     // minimum of any wave (an atomic minimum in LDS, read without synchronisation: a stale value is a larger bound, never a wrong one), and
     // the results are merged at the end.  The work of a tile is what it is; what this buys is the TAIL: the sources of a region that the
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(64 * kPcTileWaves) void aux_pc_search_tile_kernel(A
             lbk[k] = __builtin_inff();
             if (t < tiles && sph_in_lds) {
                 const int ty = t / tiles_x, tx = t - ty * tiles_x;
-                if ((2 * (ty & 1) + (tx & 1)) == wave) {
+                if ((4 * (ty & 3) + (tx & 3)) == wave) {
                     const f32x4 sd = sph_lds[t];
                     const float ex = ss[0] - sd[0], ey = ss[1] - sd[1], ez = ss[2] - sd[2];
                     const float lb = sqrtf(ex * ex + ey * ey + ez * ez) * 0.999998f - ss[3] - sd[3];
@@ -730,6 +732,9 @@ __global__ __launch_bounds__(64 * kPcTileWaves) void aux_pc_search_tile_kernel(A
             if (k < n_regs && lbk[k] < m) { m = lbk[k]; km = k; }
         const float wm = wave_minf(m);
         if (!(wm < inf)) break;      // nothing left
+#ifdef NNR_PC_DEBUG
+        if (lane == 0) atomicAdd(a.acc + 4, 1.f);
+#endif
         if (stale || (turn & 7) == 7) {      // (every few turns anyway: the other waves lower the shared minima too)
             window();                        // cap and the windows for the minima as they stand
             rho_max = live ? fminf(best_s, cap) : 0.f;

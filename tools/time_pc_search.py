@@ -58,8 +58,8 @@ if __name__ == "__main__":
         print("%-6s depths, 135 x 240 grid: per-image forward %.1f us (loss_pc %.6f)" % (kind, a.elapsed_time(b) * 10, float(out[0])))
         if os.environ.get("NNR_PC_DEBUG_COUNTS"):      # a -DNNR_PC_DEBUG build: tile evaluations and sphere tests per wave of the search
             S = hr * wr
-            ws[31 * S + 5:31 * S + 7] = 0
+            ws[31 * S + 4:31 * S + 7] = 0
             run()
             torch.cuda.synchronize()
             waves = 2 * 4 * ((hr + 7) // 8) * ((wr + 7) // 8)
-            print("       tile evaluations per wave %.1f, sphere tests per wave %.1f" % (float(ws[31 * S + 5]) / waves, float(ws[31 * S + 6]) / waves))
+            print("       per wave of the tile kernel: %.1f turns, %.1f per-source tests, %.1f tile evaluations" % (float(ws[31 * S + 4]) / waves, float(ws[31 * S + 6]) / waves, float(ws[31 * S + 5]) / waves))
