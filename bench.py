@@ -163,6 +163,29 @@ def _hbm_traffic(kernel, bf16=False, shape=None):
     return None, None
 
 
+def box_probe(device, gib=1, reps=8):
+    """What this box's HBM delivers to plain streaming kernels, next to the step it just timed: boxes of the pool differ -- twice in ~60 runs of
+    round 5 the forward and the input gradient (the two kernels that WRITE 1.7-1.9 GB of stash each) took 1.63 / 1.46 ms instead of 0.96 / 0.89
+    while the weight gradient (a reader) was unchanged, a 4.6 ms step on otherwise identical binaries.  A 1 GiB fill (write) and a 1 GiB sum
+    (read), `reps` each between two events; outside the timed region."""
+    n = gib * (1 << 28)
+    x = torch.empty(n, dtype=torch.float32, device=device)
+    res = {}
+    for name, fn in (('write', lambda: x.fill_(1.0)), ('read', lambda: x.sum())):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        res['hbm_%s_GBps' % name] = round(4.0 * n * reps / (a.elapsed_time(b) * 1e-3) / 1e9, 1)
+    del x
+    res['what'] = '%d GiB torch fill_ / sum on this box after the timed steps (a streaming write / read of HBM; not part of any timed region)' % gib
+    return res
+
+
 def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, in_step=None, sequence_reps=0):
     """Roofline block of the three fused-MLP kernels.  `in_step` = their mean durations INSIDE the timed training steps (HIP events
     on the launch stream around every launch, nnr_prof_begin / nnr_prof_end: _timed_steps): the basis of `achieved` when given.
@@ -698,6 +721,7 @@ def main():
             out['collective'] = {'backend': 'rccl' if backend == 'nccl' else 'gloo (shared GPU dry run)', 'rccl_ranks_seen': ranks_seen,
                                  'allreduce_us': round(ar_us, 1), 'bucket_floats': n_grad}
         out['roofline'] = kernel_roofline(net, device, bf16=args.bf16, rays=R, n_samples=N, in_step=in_step)
+        out['box'] = box_probe(device)
         out['cpu_baseline'] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
         if world == 1 and not args.no_extra and headline:
             del trainer

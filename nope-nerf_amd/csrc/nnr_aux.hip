@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64 * kPcLanes) void aux_pc_search_kernel(AuxArgs a,
     }
     // rows outwards from the projection: offsets 0, +1, -1, +2, -2, ..; lane `sub` takes every G-th
     const int m_end = 2 * max(y0, hr - 1 - y0);      // last useful position of the zigzag
-    const float pu = 1.f / hw, pv = 1.f / hh;        // grid pitch in u, v
+    const float pv = 1.f / hh;                       // grid pitch in v
     for (int m0 = 0; m0 <= m_end; m0 += G) {
         // the ellipse for the group's minimum (the same in every lane of the group: a group-uniform trip count)
         float r2 = __builtin_inff();
@@ -665,11 +665,6 @@ __global__ __launch_bounds__(64 * kPcTileWaves) void aux_pc_search_tile_kernel(A
             }
         }
         if (!live) { by0 = 1; by1 = 0; bx0 = 1; bx1 = 0; }
-    };
-    auto wave_min = [](int v) __attribute__((always_inline)) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-        return v;
     };
     f32x4* const img = img_all[wave];
     float* const imgf = reinterpret_cast<float*>(img);
