@@ -220,7 +220,7 @@ int nnr_pc_error_bwd(const float* src, const float* dst, const int64_t* idx, con
  * flag `aff` must be NULL.
  * The nearest neighbours come from a search that uses what the clouds are -- depth maps lifted along the rays of one pixel grid (nnr_aux.hip:
  * the ray-window kernel for rough depths, the bounding-sphere tile kernel for smooth surfaces far apart, chosen per 8 x 8 tile of sources):
- * the same indices as the exhaustive nnr_pc_nearest, 55 us instead of 345 at 135 x 240 on same-pose clouds, 226 instead of 351 inside a
+ * the same indices as the exhaustive nnr_pc_nearest, 55 us instead of 345 at 135 x 240 on same-pose clouds, 200 instead of 351 inside a
  * real training run's first epochs.  NNR_PC_SEARCH=brute in the environment selects the exhaustive search (rows / tiles: one of the two kernels on
  * everything).  The forward zeroes the backward's accumulators: ONE backward per forward. */
 #define NNR_AUX_RGBS 1u         /* rgb_s_weight != 0 */

@@ -22,6 +22,7 @@
 #include "nnr_kernels.h"
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 namespace nnr {
 
@@ -374,6 +375,29 @@ __device__ __forceinline__ PcRays pc_rays(const AuxArgs& a, int dir) {
     return r;
 }
 
+// Wave-wide minimum / maximum of a float through DPP row operations (six VALU instructions; the __shfl_xor butterfly goes through the LDS
+// crossbar -- ds_bpermute, ~100 cycles a step -- and the best-first loop below does two such reductions per turn).  Every lane returns the result.
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce(float v) {
+    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+    auto dpp = [](float x, auto ctrl, auto row_mask) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false));
+    };
+    using std::integral_constant;
+    v = op(v, dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{}));       // quad_perm [1, 0, 3, 2]
+    v = op(v, dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{}));       // quad_perm [2, 3, 0, 1]
+    v = op(v, dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{}));      // row_half_mirror
+    v = op(v, dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{}));      // row_mirror: every lane of a row of 16 holds the row's result
+    v = op(v, dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}));      // row_bcast:15 into rows 1 and 3
+    v = op(v, dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}));      // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's result
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// the value of lane (l ^ 1), (l ^ 2), (7 - (l & 7)) of a group of eight (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror): what a minimum over
+// the eight lanes needs, without the LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false); }
+
 constexpr float kPcHeavyArea = 1000.f;      // grid points in a source's window after the first guesses beyond which it goes to the tile kernel
 
 constexpr int kPcHeavyVote = 4;             // sources of an 8 x 8 tile with such a window for the tile to go there (fewer: they are scanned here, slowly)
@@ -423,13 +447,12 @@ __global__ __launch_bounds__(64 * kPcLanes) void aux_pc_search_kernel(AuxArgs a,
         const float ex = sx - dst[3 * j], ey = sy - dst[3 * j + 1], ez = sz - dst[3 * j + 2];
         return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));      // torch.linalg.norm's sum of squares
     };
+    static_assert(G == 8, "the exchange pattern below is for groups of eight lanes");
     auto share = [&]() __attribute__((always_inline)) {      // the group's running minimum in every lane of the group
-#pragma unroll
-        for (int o = 1; o < G; o <<= 1) {
-            const float os = __shfl_xor(best_s, o, 64);
-            const int oi = __shfl_xor(best_i, o, 64);
-            if (os < best_s || (os == best_s && oi < best_i)) { best_s = os; best_i = oi; }
-        }
+        auto take = [&](float os, int oi) { if (os < best_s || (os == best_s && oi < best_i)) { best_s = os; best_i = oi; } };
+        take(__int_as_float(dpp_i32<0xB1>(__float_as_int(best_s))), dpp_i32<0xB1>(best_i));        // lane ^ 1
+        take(__int_as_float(dpp_i32<0x4E>(__float_as_int(best_s))), dpp_i32<0x4E>(best_i));        // lane ^ 2: every lane holds its quad's minimum
+        take(__int_as_float(dpp_i32<0x141>(__float_as_int(best_s))), dpp_i32<0x141>(best_i));      // the mirror lane of the other quad: the group's
         const float t = best_s * best_s;
         thr = best_s < __builtin_inff() ? __builtin_fmaf(t, 4.8e-7f, t) + 1.2e-38f : __builtin_inff();
     };
@@ -550,8 +573,8 @@ __global__ __launch_bounds__(64 * kPcLanes) void aux_pc_search_kernel(AuxArgs a,
 // Every bound only ever skips points that are farther than the source's running minimum (margins for every rounding involved); the indices
 // are the exhaustive search's, in either kernel and in any split (tests/test_gpu_pc_search.py runs each kernel alone on everything too).
 // Measured (tools/time_pc_search.py --scene, tools/gpu_loop_trace.sh; exhaustive search / first kernel alone / both): bench-like noise depths
-// 339 / 55 / 61 us, smooth depths a small pose apart 307 / 47 / 55, two frames of a real scene at the identity pose 315 / 1127 / 296, the
-// search inside the reference's train.py over the first epochs 351 / 464 / 226.
+// 339 / 55 / 61 us, smooth depths a small pose apart 307 / 47 / 55, two frames of a real scene at the identity pose 315 / 1127 / 279, the
+// search inside the reference's train.py over the first epochs 351 / 464 / 200.
 constexpr int kPcT = 8;      // tile side (64 points: one per lane)
 
 // spheres[cloud][tile] = (cx, cy, cz, r); cloud 0 = X, 1 = Y.  One wave per tile.
@@ -710,11 +733,6 @@ __global__ __launch_bounds__(64 * kPcTileWaves) void aux_pc_search_tile_kernel(A
         const int j = in ? y * wr + x : 0;
         q[0] = in ? dst[3 * j] : inf; q[1] = in ? dst[3 * j + 1] : inf; q[2] = in ? dst[3 * j + 2] : inf;
     };
-    auto wave_minf = [](float v) __attribute__((always_inline)) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-        return v;
-    };
     const int n_regs = (tiles + 63) / 64;      // (wave-uniform: registers beyond it hold +inf and are not looked at)
     float rho_max = inf;
     bool stale = true;      // the windows / the largest minimum need recomputing (something was evaluated since)
@@ -725,22 +743,20 @@ __global__ __launch_bounds__(64 * kPcTileWaves) void aux_pc_search_tile_kernel(A
 #pragma unroll
         for (int k = 1; k < kRegs; ++k)
             if (k < n_regs && lbk[k] < m) { m = lbk[k]; km = k; }
-        const float wm = wave_minf(m);
+        const float wm = wave_reduce<false>(m);
         if (!(wm < inf)) break;      // nothing left
 #ifdef NNR_PC_DEBUG
         if (lane == 0) atomicAdd(a.acc + 4, 1.f);
 #endif
         if (stale || (turn & 7) == 7) {      // (every few turns anyway: the other waves lower the shared minima too)
             window();                        // cap and the windows for the minima as they stand
-            rho_max = live ? fminf(best_s, cap) : 0.f;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) rho_max = fmaxf(rho_max, __shfl_xor(rho_max, o, 64));
+            rho_max = wave_reduce<true>(live ? fminf(best_s, cap) : 0.f);
             stale = false;
         }
         if (wm > rho_max * 1.000001f) break;      // no tile left can hold a point within any source's minimum
         const unsigned long long who = __ballot(m == wm);
         const int owner = __builtin_ctzll(who);
-        const int t = __shfl(64 * km + lane, owner, 64);
+        const int t = __builtin_amdgcn_readlane(64 * km + lane, owner);
         if (lane == owner) {
 #pragma unroll
             for (int k = 0; k < kRegs; ++k)
