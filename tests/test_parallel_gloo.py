@@ -131,6 +131,57 @@ def test_allreduce_keeps_a_gradient_none_only_when_no_rank_has_one():
         assert ga == [5.0, 5.0, 5.0] and gb == [5.0, 5.0] and c_none and loss == 3.0, got
 
 
+def _inplace_worker(rank, world, port, q):
+    from nnr import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # twelve gradients as views of ONE buffer with alignment gaps and a spare tail -- what nnr.ops._RenderRays.backward hands autograd --
+        # plus two free-standing tables (one without a gradient on rank 1, one on no rank) and two logged scalars
+        sizes = [7, 3, 16, 1, 5, 9, 2, 4, 8, 6, 10, 11]
+        offs, o = [], 0
+        for n in sizes:
+            offs.append(o)
+            o += (n + 3) // 4 * 4
+        flat = torch.full((o + 64,), float("nan"))                  # (gaps and tail hold garbage, as torch.empty leaves them)
+        params = []
+        for i, (n, off) in enumerate(zip(sizes, offs)):
+            p = torch.nn.Parameter(torch.zeros(n))
+            flat[off:off + n] = float(rank + 1) * (i + 1)
+            p.grad = flat[off:off + n]
+            params.append(p)
+        a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))
+        if rank == 0:
+            a.grad = torch.full((3,), 4.0)
+        ld = {'loss': torch.tensor(1.0 + rank), 'loss_rgb': torch.tensor(0.5)}
+        ptr = flat.data_ptr()
+        parallel.allreduce_gradients(params + [a, b], ld)
+        ok = all(p.grad.data_ptr() == ptr + 4 * off for p, off in zip(params, offs))           # reduced where they lie: no copy
+        vals = [float(p.grad[0]) for p in params] + [float(p.grad.min()) for p in params]
+        q.put((rank, ok, vals, a.grad.tolist() if a.grad is not None else None, b.grad is None, float(ld['loss']), float(ld['loss_rgb'])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_runs_in_place_on_a_shared_gradient_buffer():
+    """The GPU path's layout on CPU tensors: gradients that are views of one allocation are summed in place (their storage pointers do not
+    change), everything else rides in the buffer's tail; values, None-ness and the logged scalars as in the private-bucket path."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_inplace_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, vals, ga, b_none, loss, lrgb in got:
+        assert ok, "the shared gradients were copied"
+        assert vals[:12] == [3.0 * (i + 1) for i in range(12)] and vals[12:] == vals[:12]      # (1 + 2) (i + 1), every element
+        assert ga == [4.0, 4.0, 4.0] and b_none and loss == 3.0 and lrgb == 1.0
+
+
 def test_allreduce_handles_missing_grads():
     """A parameter without a gradient on this rank still occupies its slot in the flat bucket."""
     from nnr import parallel
