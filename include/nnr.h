@@ -360,7 +360,10 @@ int nnr_step_rays_fwd(const nnr_step_cfg* cfg, const float* r_all, const float* 
 int nnr_step_rays_bwd(const nnr_step_cfg* cfg, const float* r_all, const float* t_all, const float* scales, const float* shifts,
                       const float* K, const float* S, const int64_t* ray_idx, const float* depth_img, const float* g_pts_o,
                       const float* g_dir, const float* g_view, const float* g_ray_norm, const float* g_d_gt, const float* g_mats,
-                      float* d_r, float* d_t, float* d_scales, float* d_shifts, void* stream);
+                      float* d_r, float* d_t, float* d_scales, float* d_shifts, float* scratch, void* stream);
+/* scratch: NNR_STEP_BWD_SCRATCH_FLOATS floats whose FIRST word is zero on entry -- zero-fill the buffer once, every call leaves the word zero
+ * again (the ticket of the workgroups' fixed-order reduction); calls that share a buffer must be ordered on one stream. */
+#define NNR_STEP_BWD_SCRATCH_FLOATS 272
 
 /* depth = nearest-resize(depth_img (hd,wd) -> (h,w)).flatten()[ray_idx]  (model/network.py:22-24) without materialising
  * the resized image; backward scatter-adds into a zero-filled (hd,wd) gradient image. */

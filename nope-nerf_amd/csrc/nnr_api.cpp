@@ -863,12 +863,13 @@ int nnr_step_rays_fwd(const nnr_step_cfg* cfg, const float* r_all, const float* 
 int nnr_step_rays_bwd(const nnr_step_cfg* cfg, const float* r_all, const float* t_all, const float* scales, const float* shifts,
                       const float* K, const float* S, const int64_t* ray_idx, const float* depth_img, const float* g_pts_o,
                       const float* g_dir, const float* g_view, const float* g_ray_norm, const float* g_d_gt, const float* g_mats,
-                      float* d_r, float* d_t, float* d_scales, float* d_shifts, void* stream) {
+                      float* d_r, float* d_t, float* d_scales, float* d_shifts, float* scratch, void* stream) {
     nnr::StepRaysArgs a{};
     if (!step_fill(cfg, a)) return NNR_E_BADCFG;
     a.g_mats = g_mats;
-    if (!r_all || !t_all || !scales || !shifts || !K || !S || !ray_idx || !depth_img || !d_r || !d_t || !d_scales || !d_shifts)
+    if (!r_all || !t_all || !scales || !shifts || !K || !S || !ray_idx || !depth_img || !d_r || !d_t || !d_scales || !d_shifts || !scratch)
         return NNR_E_BADCFG;
+    a.bwd_scratch = scratch;
     a.r_all = r_all; a.t_all = t_all; a.scales = scales; a.shifts = shifts; a.K = K; a.S = S; a.ray_idx = ray_idx;
     a.depth_img = depth_img; a.g_o = g_pts_o; a.g_dir = g_dir; a.g_view = g_view; a.g_norm = g_ray_norm; a.g_dgt = g_d_gt;
     a.d_r = d_r; a.d_t = d_t; a.d_scales = d_scales; a.d_shifts = d_shifts;

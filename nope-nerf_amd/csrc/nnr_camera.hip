@@ -8,6 +8,7 @@
 //   render_loss   rgb L1|L2 sum / R  +  depth L1 sum / M         reference model/losses.py:27-32,59-64,196-202
 // All of them are latency-bound bookkeeping (<= a few KB); the point is launch count, not bandwidth.
 #include "nnr_device.h"
+#include <algorithm>
 #include "nnr_kernels.h"
 
 // No floating-point contraction in this file.  The fused front end (step_rays_*) restates the arithmetic of the separate kernels below "in
@@ -518,14 +519,19 @@ __global__ __launch_bounds__(256) void step_rays_fwd_kernel(StepRaysArgs a) {
     a.mask[i] = (isfinite(dgt) && dgt != 0.f) ? 1 : 0;
 }
 
-// The whole way back in one workgroup: the per-ray part of ray_setup_bwd with the depth gradient fed straight into the distortion
-// sums (depth_gather_affine_bwd), both reduced in a FIXED order (strided rays, lane tree, the 8 waves in index order), then the matrix chain rule M = S^-1 W^-1 K^-1, W = c2w^-1 (inv4_bwd), c2w = exp(r, t) (se3_exp_grad) -- and the full
-// (n_cams, .) gradient tables written, zeros outside the frame's row.  Replaces 4 launches + the ~10 tiny ATen kernels of the
-// autograd of `where` / indexing in Learn_Distortion.
+// The whole way back in one launch: the per-ray part of ray_setup_bwd with the depth gradient fed straight into the distortion sums
+// (depth_gather_affine_bwd), reduced in a FIXED order -- per workgroup: strided rays, lane tree, the 8 waves in index order; then the
+// workgroups' partials in workgroup order by the LAST workgroup to finish (a ticket counter in the caller's scratch: round 5, before that
+// ONE workgroup walked all rays, 8 per thread at 4096 rays) -- then, in that workgroup, the matrix chain rule M = S^-1 W^-1 K^-1,
+// W = c2w^-1 (inv4_bwd), c2w = exp(r, t) (se3_exp_grad) -- and the full (n_cams, .) gradient tables written, zeros outside the frame's
+// row.  Replaces 4 launches + the ~10 tiny ATen kernels of the autograd of `where` / indexing in Learn_Distortion.
 constexpr int kStepBwdThreads = 512;   // 8 waves: 256 registers each (at 1024 threads the matrix chain spills 700 bytes per lane)
+constexpr int kStepBwdMaxBlocks = 16;  // partial slots in the scratch (NNR_STEP_BWD_SCRATCH_FLOATS = 16 + 16 * 16)
 __global__ __launch_bounds__(kStepBwdThreads) void step_rays_bwd_kernel(StepRaysArgs a) {
     __shared__ float red[14][kStepBwdThreads / 64];
     __shared__ float park[4][16];
+    __shared__ float tot[16];
+    __shared__ int is_last;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float acc[12];
 #pragma unroll
@@ -545,9 +551,7 @@ __global__ __launch_bounds__(kStepBwdThreads) void step_rays_bwd_kernel(StepRays
     float scale, shift;
     bool live;
     step_scale_shift(a, scale, shift, live);
-    for (int i = threadIdx.x; i < 3 * a.n_cams; i += kStepBwdThreads) { a.d_r[i] = 0.f; a.d_t[i] = 0.f; }
-    for (int i = threadIdx.x; i < a.n_cams; i += kStepBwdThreads) { a.d_scales[i] = 0.f; a.d_shifts[i] = 0.f; }
-    for (int i = threadIdx.x; i < a.R; i += kStepBwdThreads) {
+    for (int i = blockIdx.x * kStepBwdThreads + threadIdx.x; i < a.R; i += gridDim.x * kStepBwdThreads) {
         float px, py, raw;
         step_pixel(a, i, px, py, raw);
         const float dep = a.shift_first ? __fmul_rn(__fadd_rn(raw, shift), scale) : __fadd_rn(__fmul_rn(raw, scale), shift);
@@ -599,16 +603,37 @@ __global__ __launch_bounds__(kStepBwdThreads) void step_rays_bwd_kernel(StepRays
         if (lane == 0) red[k][wv] = v;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    M4 dm;
-    for (int k = 0; k < 12; ++k) {
+    // this workgroup's 14 sums (waves in index order) -> its partial slot; the last workgroup to arrive adds the slots in workgroup order
+    float* const slots = a.bwd_scratch + 16;
+    if (threadIdx.x < 14) {
         float t = 0.f;
-        for (int w = 0; w < kStepBwdThreads / 64; ++w) t += red[k][w];
-        dm.m[k] = t;
+        for (int w = 0; w < kStepBwdThreads / 64; ++w) t += red[threadIdx.x][w];
+        slots[16 * blockIdx.x + threadIdx.x] = t;
     }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int ticket = atomicAdd(reinterpret_cast<unsigned int*>(a.bwd_scratch), 1u);
+        is_last = ticket == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (threadIdx.x < 14) {
+        float t = 0.f;
+        for (unsigned int b = 0; b < gridDim.x; ++b) t += slots[16 * b + threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    for (int i = threadIdx.x; i < 3 * a.n_cams; i += kStepBwdThreads) { a.d_r[i] = 0.f; a.d_t[i] = 0.f; }
+    for (int i = threadIdx.x; i < a.n_cams; i += kStepBwdThreads) { a.d_scales[i] = 0.f; a.d_shifts[i] = 0.f; }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    *reinterpret_cast<unsigned int*>(a.bwd_scratch) = 0u;      // the ticket counter as the next call expects it
+    M4 dm;
+    for (int k = 0; k < 12; ++k) dm.m[k] = tot[k];
     for (int k = 12; k < 16; ++k) dm.m[k] = 0.f;
-    float tot_s = 0.f, tot_h = 0.f;
-    for (int w = 0; w < kStepBwdThreads / 64; ++w) { tot_s += red[12][w]; tot_h += red[13][w]; }
+    float tot_s = tot[12], tot_h = tot[13];
     // dL/dM (12 sums) -> dL/dW through M = (S^-1 W^-1) K^-1, W^-1 = inv4(W); then W = inv4(c2w); then c2w = exp(r, t)
     const M4 kinv = load4(park[0]), winv = load4(park[1]), sinv = load4(park[2]), W = load4(park[3]);
     const M4 d_sw = mul4(dm, transpose4(kinv));
@@ -753,7 +778,8 @@ hipError_t launch_step_rays_fwd(const StepRaysArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t launch_step_rays_bwd(const StepRaysArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(step_rays_bwd_kernel, dim3(1), dim3(kStepBwdThreads), 0, st, a);
+    const int nb = std::min(kStepBwdMaxBlocks, std::max(1, (a.R + kStepBwdThreads - 1) / kStepBwdThreads));
+    hipLaunchKernelGGL(step_rays_bwd_kernel, dim3(nb), dim3(kStepBwdThreads), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_depth_gather_fwd(const float* img, const int64_t* idx, float* out, int R, int h, int w, int hd, int wd, hipStream_t st) {

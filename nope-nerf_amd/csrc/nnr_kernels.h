@@ -130,6 +130,7 @@ struct StepRaysArgs {
     // backward
     const float *g_o, *g_dir, *g_view, *g_norm, *g_dgt;   // upstream gradients (any may be null)
     float *d_r, *d_t, *d_scales, *d_shifts;               // full tables, overwritten
+    float* bwd_scratch;                                   // NNR_STEP_BWD_SCRATCH_FLOATS: [0] a ticket counter (zero on entry, left zero), [16 + 16 b ..): workgroup b's 14 sums
     // the frame pair of the per-image losses (ref >= 0): mats[34, 56) = rel (16), the pair's distortions (s1, t1, s2, t2), scale2, 0;
     // backward: g_mats = the upstream gradient of mats (may be null), detach_ref = training.detach_ref_img
     int ref, detach_ref;

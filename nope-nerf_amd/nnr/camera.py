@@ -269,6 +269,19 @@ def depth_gather_affine(depth_img, ray_idx, scale, shift, h: int, w: int, shift_
     return _DepthGatherAffine.apply(depth_img, ray_idx, scale, shift, h, w, shift_first)
 
 
+_BWD_SCRATCH = {}
+
+
+def _bwd_scratch(device):
+    """The persistent scratch of nnr_step_rays_bwd (partial sums of its workgroups + their ticket counter): one per device and stream,
+    zero-filled once -- every call leaves the counter zero (no memset launch per step)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    buf = _BWD_SCRATCH.get(key)
+    if buf is None:
+        buf = _BWD_SCRATCH[key] = torch.zeros(L.STEP_BWD_SCRATCH_FLOATS, dtype=torch.float32, device=device)
+    return buf
+
+
 class _StepRays(torch.autograd.Function):
     """The fused front end of a training step (nnr_step_rays_fwd / _bwd): pose tables -> world_mat, depth-distortion tables -> the
     frame's scale / shift, pixel coordinates, distorted mono depth and colour targets of the picked pixels, ray generation."""
@@ -326,7 +339,7 @@ class _StepRays(torch.autograd.Function):
         L.check(L.load().nnr_step_rays_bwd(C.byref(ctx.cfg), L.ptr(r), L.ptr(t), L.ptr(sc), L.ptr(sh), L.ptr(k), L.ptr(s), L.ptr(idx),
                                            L.ptr(dimg), L.ptr(g_o), L.ptr(g_dir), L.ptr(g_view), L.ptr(g_norm), L.ptr(g_dgt),
                                            L.ptr(g_mats) if ctx.cfg.ref >= 0 else None,
-                                           L.ptr(d_r), L.ptr(d_t), L.ptr(d_sc), L.ptr(d_sh), _st()), "nnr_step_rays_bwd")
+                                           L.ptr(d_r), L.ptr(d_t), L.ptr(d_sc), L.ptr(d_sh), L.ptr(_bwd_scratch(r.device)), _st()), "nnr_step_rays_bwd")
         rs, ts, ss, hs = ctx.shapes
         return d_r.view(rs), d_t.view(ts), (None if ctx.gauge else d_sc.view(ss)), d_sh.view(hs), None, None, None, None, None, None
 

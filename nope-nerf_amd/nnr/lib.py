@@ -83,6 +83,7 @@ class StepCfg(C.Structure):        # nnr_step_cfg: the fused front end of a trai
 
 
 STEP_NORMALISE, STEP_USE_DIR, STEP_SHIFT_FIRST, STEP_FIX_LAST_SCALE, STEP_DETACH_REF = 1, 2, 4, 8, 16
+STEP_BWD_SCRATCH_FLOATS = 272      # NNR_STEP_BWD_SCRATCH_FLOATS
 
 
 class WgradJobB(C.Structure):      # bf16 training mode: one workgroup job (nnr_layout.h)
@@ -165,7 +166,7 @@ def load():
     lib.nnr_pc_error_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.nnr_render_loss.argtypes = [vp] * 5 + [i32] + [f32] * 4 + [i32] * 3 + [vp] * 6
     lib.nnr_step_rays_fwd.argtypes = [C.POINTER(StepCfg)] + [vp] * 19
-    lib.nnr_step_rays_bwd.argtypes = [C.POINTER(StepCfg)] + [vp] * 19
+    lib.nnr_step_rays_bwd.argtypes = [C.POINTER(StepCfg)] + [vp] * 20
     lib.nnr_adam_step.argtypes = [vp, vp]
     lib.nnr_prof_begin.argtypes = [i32]
     lib.nnr_prof_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
