@@ -12,14 +12,18 @@ OUT_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(os.path.dirname(HERE), "nnr", "libnnr.so")
 # (source, defines): the two fp32 MLP kernels are compiled one template instantiation per translation unit -- each is minutes of hipcc
 # time (straight-line code of ~8 000 MFMAs), in one unit the forward alone took 8.5 minutes; the longest unit first
-SOURCES = [("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1", "NNR_FWD_MODE=2")), ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=256", "NNR_DGRAD_MODE=2")),
+SOURCES = [("nnr_mlp_fwd_f16.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1")), ("nnr_mlp_dgrad_f16.hip", ("NNR_DGRAD_D=256",)),
+           ("nnr_mlp_fwd_f16.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=0")),
+           ("nnr_mlp_fwd_f16.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=1")), ("nnr_mlp_dgrad_f16.hip", ("NNR_DGRAD_D=128",)),
+           ("nnr_mlp_fwd_f16.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=0")),
+           ("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1", "NNR_FWD_MODE=2")), ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=256", "NNR_DGRAD_MODE=2")),
            ("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=0", "NNR_FWD_MODE=2")),
            ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=1", "NNR_FWD_MODE=2")), ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=128", "NNR_DGRAD_MODE=2")),
            ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=0", "NNR_FWD_MODE=2")),
            ("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1")), ("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=0")),
            ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=256",)), ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=1")),
            ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=0")), ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=128",)),
-           ("nnr_mlp_fwd_bf16.hip", ()), ("nnr_mlp_dgrad_bf16.hip", ()), ("nnr_mlp_fwd_ws.hip", ()), ("nnr_mlp_fwd.hip", ()), ("nnr_mlp_dgrad.hip", ()),
+           ("nnr_mlp_fwd_bf16.hip", ()), ("nnr_mlp_dgrad_bf16.hip", ()), ("nnr_mlp_fwd.hip", ()), ("nnr_mlp_dgrad.hip", ()),
            ("nnr_api.cpp", ()), ("nnr_pack.hip", ()), ("nnr_wgrad.hip", ()), ("nnr_wgrad_bf16.hip", ()), ("nnr_composite.hip", ()),
            ("nnr_camera.hip", ()), ("nnr_pointcloud.hip", ()), ("nnr_aux.hip", ()), ("nnr_randperm.hip", ()), ("nnr_optim.hip", ())]
 
@@ -27,6 +31,7 @@ SOURCES = [("nnr_mlp_fwd.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1", "NNR_FWD_MOD
 def _obj_name(src, defines):
     tag = "".join("_" + d.split("=")[0].lower().replace("nnr_", "") + d.split("=")[1] for d in defines)
     return os.path.splitext(src)[0] + tag + ".o"
+SPLIT2_ONLY = ["nnr_split2.h"]      # included by the two fp16-term kernels only: touching it does not rebuild the rest (minutes per unit)
 HEADERS = ["nnr_layout.h", "nnr_device.h", "nnr_kernels.h", "nnr_mlp_bf16.h", "nnr_split.h", os.path.join("..", "..", "include", "nnr.h")]
 # -pragma-unroll-threshold: the MLP kernels are straight-line code by construction (every `#pragma unroll` loop must unroll fully, or
 # the register arrays they index fall back to scratch memory).  LLVM caps `#pragma unroll` at 16 K instructions per loop; one GEMM part
@@ -39,7 +44,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-prag
 # stores with vmcnt(0), and every reload drains the stash-store queue with the matrix pipe idle -- the TRAINING kernels may only keep a handful of
 # prologue values in scratch, reloaded at pass start (where the pass waits for its inputs anyway), nothing inside a pass; the inference forward (no stores in flight) may spill its composite carry.
 # (three-term kernels: only the D = 256 training forward keeps a few pass-start values in scratch, 32 bytes)
-SCRATCH_LIMIT = {"14mlp_fwd_kernelI": 0, "14mlp_fwd_kernelILi256ELb1ELi2E": 48, "16mlp_dgrad_kernelI": 0, "12wgrad_kernelI": 0, "14wgrad_b_kernelE": 0,
+SCRATCH_LIMIT = {"18mlp_fwd_f16_kernelI": 0, "20mlp_dgrad_f16_kernelI": 0, "14mlp_fwd_kernelI": 0, "14mlp_fwd_kernelILi256ELb1ELi2E": 48, "16mlp_dgrad_kernelI": 0, "12wgrad_kernelI": 0, "14wgrad_b_kernelE": 0,
                  "19mlp_fwd_bf16_kernelI": 48, "19mlp_fwd_bf16_kernelILi256ELb1E": 16, "19mlp_fwd_bf16_kernelILi128ELb1E": 16,
                  "21mlp_dgrad_bf16_kernelI": 64, "20composite_fwd_kernelE": 0, "20composite_bwd_kernelE": 0}
 
@@ -147,7 +152,8 @@ def build(force=False, verbose=False):
     jobs = []
     for src, defines in SOURCES:
         obj = os.path.join(OUT_DIR, _obj_name(src, defines))
-        if force or _stale(obj, [os.path.join(HERE, src)] + hdrs):
+        own = [os.path.join(HERE, h) for h in SPLIT2_ONLY] if "_f16" in src else []
+        if force or _stale(obj, [os.path.join(HERE, src)] + hdrs + own):
             jobs.append([hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(HERE, src), "-o", obj])
 
     def run(cmd):

@@ -14,11 +14,6 @@
 
 using namespace nnr;
 
-namespace nnr {
-hipError_t launch_mlp_fwd_ws(const MlpFwdArgs& a, hipStream_t st);      // nnr_mlp_fwd_ws.hip (declared here: nnr_kernels.h is a dependency of every kernel)
-}
-constexpr bool kFwdWsDefault = false;      // prototype: opt in with NNR_FWD_WS=1
-
 namespace {
 
 thread_local int g_last_hip = 0;
@@ -54,13 +49,15 @@ int64_t plane(const WsLayout& w, int id) {
 }
 
 size_t packed_floats(int D, int mode) {
+    if (mode == 3) return D == 256 ? (size_t)Layout<256, 3>::packed_floats : (size_t)Layout<128, 3>::packed_floats;
     if (mode == 2) return D == 256 ? (size_t)Layout<256, 2>::packed_floats : (size_t)Layout<128, 2>::packed_floats;
     if (mode == 1) return D == 256 ? (size_t)Layout<256, 1>::packed_floats : (size_t)Layout<128, 1>::packed_floats;
     return D == 256 ? (size_t)Layout<256>::packed_floats : (size_t)Layout<128>::packed_floats;
 }
 bool is_bf16(const nnr_cfg* c) { return (c->flags & NNR_F_BF16) != 0; }
 bool is_split3(const nnr_cfg* c) { return (c->flags & (NNR_F_BF16 | NNR_F_SPLIT3)) == NNR_F_SPLIT3; }
-int weight_mode(const nnr_cfg* c) { return is_bf16(c) ? 1 : (is_split3(c) ? 2 : 0); }   // Layout<D, MODE>
+bool is_split2(const nnr_cfg* c) { return is_split3(c) && (c->flags & NNR_F_SPLIT2) != 0; }      // forward / input gradient with two-term fp16 operands (nnr_split2.h)
+int weight_mode(const nnr_cfg* c) { return is_bf16(c) ? 1 : (is_split2(c) ? 3 : (is_split3(c) ? 2 : 0)); }   // Layout<D, MODE>
 
 // Ray mode of the two MLP kernels (nnr_mlp_fwd.hip): a wave walks the N / 32 chunks of ONE ray, a workgroup four rays.  Needs whole
 // chunks per ray and whole workgroups; everything else runs the flat decomposition (same sample numbering, same planes).
@@ -573,12 +570,6 @@ int nnr_pack_weights(const nnr_cfg* cfg, const nnr_params* p, float* packed, voi
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
-// NNR_FWD_WS=0 / 1 selects the one-wave-per-SIMD / wave-specialised inference forward (read at every call: A/B runs in one process)
-static bool fwd_ws_enabled() {
-    const char* e = std::getenv("NNR_FWD_WS");
-    return e ? (e[0] != '0') : kFwdWsDefault;
-}
-
 // the forward MLP launch; fuse_rgb / fuse_dist != null: inference with the compositing in the kernel's epilogue (ray mode only)
 static int mlp_fwd_impl(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, const float* view_d, const float* z_lo,
                         const float* z_hi, const float* jitter, const float* packed, float* ws, float* fuse_rgb, float* fuse_dist,
@@ -609,13 +600,8 @@ static int mlp_fwd_impl(const nnr_cfg* cfg, const float* pts_o, const float* pts
     a.S = w.S; a.S_pad = w.S_pad; a.N = cfg->n_samples;
     a.chunks_per_ray = chunks_per_ray(cfg);
     a.fuse_rgb = fuse_rgb; a.fuse_dist = fuse_dist; a.flags = cfg->flags;
-    // the wave-specialised forward (nnr_mlp_fwd_ws.hip): three-term inference at D = 256
-    if (fwd_ws_enabled() && is_split3(cfg) && cfg->hidden == 256 && !w.train) {
-        hipError_t ews = launch_mlp_fwd_ws(a, (hipStream_t)stream);
-        return ews == hipSuccess ? NNR_OK : hip_fail(ews);
-    }
     hipError_t e = is_bf16(cfg) ? launch_mlp_fwd_bf16(cfg->hidden, a, w.train, (hipStream_t)stream)
-                                : launch_mlp_fwd(cfg->hidden, a, w.train, (hipStream_t)stream, is_split3(cfg));
+                                : launch_mlp_fwd(cfg->hidden, a, w.train, (hipStream_t)stream, weight_mode(cfg));
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
@@ -685,7 +671,7 @@ int nnr_mlp_dgrad(const nnr_cfg* cfg, const float* packed, float* ws, void* stre
     a.S = w.S; a.S_pad = w.S_pad;
     a.chunks_per_ray = chunks_per_ray(cfg);
     hipError_t e = is_bf16(cfg) ? launch_mlp_dgrad_bf16(cfg->hidden, a, (hipStream_t)stream)
-                                : launch_mlp_dgrad(cfg->hidden, a, (hipStream_t)stream, is_split3(cfg));
+                                : launch_mlp_dgrad(cfg->hidden, a, (hipStream_t)stream, weight_mode(cfg));
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
@@ -744,7 +730,7 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const float* packed, const nnr_param_grads
     a.gb[kMergedLayer] = a.gw[kMergedLayer] + (size_t)(cfg->hidden / 2) * cfg->hidden;
     a.packed = packed;
     a.D = cfg->hidden;
-    a.bf16 = weight_mode(cfg);   // 0 or 2 here: locates the merge area of the packed buffer for the un-merge step
+    a.bf16 = weight_mode(cfg);   // 0, 2 or 3 here (>= 2: the 4 x 4 tiles with six bf16 terms): locates the merge area of the packed buffer for the un-merge step
     {
         const int D = cfg->hidden;
         const int rows[13] = {D, D, D, D, D, D, D, D, 1, D, D / 2, 3, D / 2};   // outputs of the 12 nn.Linear + the merged colour-hidden matrix

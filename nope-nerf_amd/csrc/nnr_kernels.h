@@ -214,12 +214,12 @@ hipError_t launch_randperm_prefix(const int64_t* keys, int64_t n, int bits, int 
                                   int64_t* out, unsigned int* scratch, hipStream_t st);
 hipError_t launch_uniform_rows(unsigned long long seed, unsigned long long offset, unsigned long long threads, unsigned long long first,
                                unsigned long long n, float* out, hipStream_t st);   // nnr_randperm.hip
-hipError_t launch_pack(int D, const PackArgs& a, int mode, hipStream_t st);   // mode: Layout<D, MODE> (0 fp32, 1 bf16, 2 three bf16 terms)
-// fp32 products: fp32 MFMAs, or (split3) six bf16 MFMA terms per product (nnr_split.h)
-hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st, bool split3 = false);
+hipError_t launch_pack(int D, const PackArgs& a, int mode, hipStream_t st);   // mode: Layout<D, MODE> (0 fp32, 1 bf16, 2 three bf16 terms, 3 two fp16 terms)
+// fp32 products by Layout mode: 0 fp32 MFMAs, 2 six bf16 MFMA terms per product (nnr_split.h), 3 three fp16 MFMA terms (nnr_split2.h)
+hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st, int mode = 0);
 template <int D, bool TRAIN, int MODE = 0> hipError_t launch_mlp_fwd_variant(const MlpFwdArgs& a, hipStream_t st);   // one translation unit each
 template <int D, int MODE = 0> hipError_t launch_mlp_dgrad_variant(const MlpDgradArgs& a, hipStream_t st);
-hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st, bool split3 = false);
+hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st, int mode = 0);
 hipError_t launch_mlp_fwd_bf16(int D, const MlpFwdArgs& a, bool train, hipStream_t st);     // nnr_mlp_fwd_bf16.hip
 hipError_t launch_mlp_dgrad_bf16(int D, const MlpDgradArgs& a, hipStream_t st);              // nnr_mlp_dgrad_bf16.hip
 hipError_t launch_composite_fwd(const CompositeArgs& a, hipStream_t st);

@@ -97,9 +97,18 @@ NNR_HD constexpr int part_panels(int KT, int MT, bool bf16 = false) { return (pa
 // l, m and h terms of the row, in that order (the order the kernels consume them in) -- and a panel is 24 fragment slots (24 KiB):
 // GP = 8 / MT whole rows.  Fragment (b, term t, mt) lives in panel b / GP, slot ((b % GP) * 3 + t) * MT + mt.
 constexpr int kSplitPanelFrags = 24;
-NNR_HD constexpr int mode_panel_frags(int mode) { return mode == 2 ? kSplitPanelFrags : kPanelFrags; }
+// MODE 3 (NNR_F_SPLIT2; the kernels: nnr_split2.h): fp32 operands as TWO fp16 terms, three fp16 MFMAs per 16 k-values.  The panel geometry is MODE 2's
+// -- three fragment classes per row and m-tile, 24-slot panels -- with other contents: class 0 = w_m = fp16(w s - w_h), class 1 = w_hs =
+// fp16(w s 2^-11) (the partner of the activations' residual term, which is carried at 2^11), class 2 = w_h = fp16(w s); s = the power of two that
+// puts the largest |w| of the weight tensor's SCALE SLOT into [2^13, 2^14) (scale_slot below; the table: Layout::scale_off).  The biases of the
+// MFMA layers are stored multiplied by s (the accumulators start there); head tables and merge area are unscaled fp32.
+NNR_HD constexpr int mode_panel_frags(int mode) { return mode >= 2 ? kSplitPanelFrags : kPanelFrags; }
 NNR_HD constexpr int mode_rows(int KT, int mode) { return mode ? 2 * KT : 4 * KT; }
-NNR_HD constexpr int mode_gp(int MT, int mode) { return mode == 2 ? kSplitPanelFrags / (3 * MT) : kPanelFrags / MT; }
+NNR_HD constexpr int mode_gp(int MT, int mode) { return mode >= 2 ? kSplitPanelFrags / (3 * MT) : kPanelFrags / MT; }
+// scale slot of a parameter index: hidden 1..8 their own; the merged colour matrix W' (kMergedLayer) and the direction columns of the colour-hidden
+// layer (param 10) accumulate into ONE accumulator and share slot 8
+NNR_HD constexpr int scale_slot(int layer) { return layer < 8 ? layer : 8; }
+constexpr int kScaleSlots = 9;
 NNR_HD constexpr int mode_panels(int KT, int MT, int mode) { return (mode_rows(KT, mode) + mode_gp(MT, mode) - 1) / mode_gp(MT, mode); }
 
 // MODE = 1 (BF16): the packed weights of the bf16-MFMA mode (NNR_F_BF16).  A fragment is still 64 lanes x 16 bytes, but holds
@@ -107,7 +116,7 @@ NNR_HD constexpr int mode_panels(int KT, int MT, int mode) { return (mode_rows(K
 // h = l>>5 -- the two k-groups 2b, 2b+1 of the fp32 layout, which is exactly the order in which 8 consecutive activation
 // registers of a lane hold them, so one v_mfma_f32_32x32x16_bf16 consumes 8 registers (packed to bf16) against one fragment
 // (the k labelling inside an MFMA is arbitrary as long as A and B agree).  Biases, head tables and the merge area stay fp32.
-template <int D, int MODE = 0>   // 0: fp32 MFMA, 1: bf16 MFMA, 2: fp32 as three bf16 terms
+template <int D, int MODE = 0>   // 0: fp32 MFMA, 1: bf16 MFMA, 2: fp32 as three bf16 terms, 3: fp32 as two fp16 terms
 struct Layout {
     static constexpr int panel_floats = mode_panel_frags(MODE) * 256;
     static constexpr int DT = D / 32;
@@ -165,10 +174,13 @@ struct Layout {
     static constexpr int wsig_off = head_base;                  // [2][16*DT]
     static constexpr int wrgb_off = wsig_off + 2 * 16 * DT;     // [3][2][16*HT]
     static constexpr int head_floats = 2 * 16 * DT + 3 * 2 * 16 * HT;
-    static constexpr int table_floats = bias_floats + head_floats;  // what the MLP kernels copy into LDS
+    // MODE 3: [16] the weight scales s by scale slot, [16] their inverses (powers of two; written by scale_kernel, nnr_pack.hip)
+    static constexpr int scale_off = head_base + head_floats;
+    static constexpr int scale_floats = MODE == 3 ? 32 : 0;
+    static constexpr int table_floats = bias_floats + head_floats + scale_floats;  // what the MLP kernels copy into LDS
     // merge area (row-major): W' [Dh][D], b' [Dh], then copies of Wf [D][D], Wg[:, :D] [Dh][D] and bf [D] for the
     // un-merge step of the weight-gradient pass.  The bias slot of layer 10 above holds b' (not bg).
-    static constexpr int merged_w_off = head_base + head_floats;
+    static constexpr int merged_w_off = scale_off + scale_floats;
     static constexpr int merged_b_off = merged_w_off + Dh * D;
     static constexpr int copy_wf_off = merged_b_off + Dh;
     static constexpr int copy_wg_off = copy_wf_off + D * D;

@@ -284,8 +284,9 @@ hipError_t launch_mlp_dgrad_variant<NNR_DGRAD_D, NNR_DGRAD_MODE>(const MlpDgradA
     return hipGetLastError();
 }
 #else
-hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st, bool split3) {
-    if (split3) return D == 256 ? launch_mlp_dgrad_variant<256, 2>(a, st) : launch_mlp_dgrad_variant<128, 2>(a, st);
+hipError_t launch_mlp_dgrad(int D, const MlpDgradArgs& a, hipStream_t st, int mode) {
+    if (mode == 3) return D == 256 ? launch_mlp_dgrad_variant<256, 3>(a, st) : launch_mlp_dgrad_variant<128, 3>(a, st);      // nnr_mlp_dgrad_f16.hip
+    if (mode == 2) return D == 256 ? launch_mlp_dgrad_variant<256, 2>(a, st) : launch_mlp_dgrad_variant<128, 2>(a, st);
     return D == 256 ? launch_mlp_dgrad_variant<256>(a, st) : launch_mlp_dgrad_variant<128>(a, st);
 }
 #endif

@@ -385,8 +385,12 @@ hipError_t launch_mlp_fwd_variant<NNR_FWD_D, (NNR_FWD_TRAIN != 0), NNR_FWD_MODE>
     return hipGetLastError();
 }
 #else
-hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st, bool split3) {
-    if (split3) {
+hipError_t launch_mlp_fwd(int D, const MlpFwdArgs& a, bool train, hipStream_t st, int mode) {
+    if (mode == 3) {      // nnr_mlp_fwd_f16.hip
+        if (D == 256) return train ? launch_mlp_fwd_variant<256, true, 3>(a, st) : launch_mlp_fwd_variant<256, false, 3>(a, st);
+        return train ? launch_mlp_fwd_variant<128, true, 3>(a, st) : launch_mlp_fwd_variant<128, false, 3>(a, st);
+    }
+    if (mode == 2) {
         if (D == 256) return train ? launch_mlp_fwd_variant<256, true, 2>(a, st) : launch_mlp_fwd_variant<256, false, 2>(a, st);
         return train ? launch_mlp_fwd_variant<128, true, 2>(a, st) : launch_mlp_fwd_variant<128, false, 2>(a, st);
     }

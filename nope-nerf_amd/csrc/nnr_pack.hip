@@ -48,7 +48,50 @@ __global__ __launch_bounds__(256) void merge_kernel(PackArgs a) {
     for (int i = gid; i < D * D; i += n_rest) a.packed[L::copy_wf_off + i] = Wf[i];
 }
 
-// MODE (= BF16 below): Layout<D, MODE> -- 0 fp32 fragments, 1 bf16 fragments, 2 three bf16 TERMS per weight (l, m, h fragments per row)
+// MODE 3 (nnr_layout.h): the power-of-two scale of every scale slot -- the largest |w| of the slot's tensors times s lies in [2^13, 2^14) -- and its
+// inverse.  One workgroup per slot; slots 0..7 = hidden 1..8, slot 8 = the merged colour matrix W' (formed by merge_kernel before this launch)
+// together with all of param 10 (a superset of its direction columns).  An all-zero slot gets s = 1.
+template <int D>
+__global__ __launch_bounds__(256) void scale_kernel(PackArgs a) {
+    using L = Layout<D, 3>;
+    const int slot = blockIdx.x;
+    float m = 0.f;
+    auto scan = [&](const float* w, int n) {
+        for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+    };
+    if (slot < 8) {
+        const int in = slot == 0 ? kPosReal : (slot == 4 ? D + kPosReal : D);
+        scan(a.w[slot], D * in);
+    } else if (slot == 9) {      // not a scale: the largest |w_sigma| (the density row enters the input-gradient chain as a rank-1 term, nnr_mlp_dgrad_f16.hip)
+        scan(a.w[8], D);
+    } else {
+        scan(a.packed + L::merged_w_off, L::Dh * D);
+        scan(a.w[10], L::Dh * (D + kDirReal));
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int e = 0;
+        const float mx = red[0];
+        float s = 1.f;
+        if (mx > 0.f && mx < 3.0e38f) {
+            (void)frexpf(mx, &e);            // mx = f 2^e, f in [0.5, 1)
+            e = 14 - e;
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+            s = ldexpf(1.f, e);
+        }
+        a.packed[L::scale_off + slot] = slot == 9 ? mx : s;
+        a.packed[L::scale_off + 16 + slot] = slot == 9 ? 0.f : 1.f / s;
+    }
+}
+
+// MODE (= BF16 below): Layout<D, MODE> -- 0 fp32 fragments, 1 bf16 fragments, 2 three bf16 TERMS per weight (l, m, h fragments per row),
+// 3 two fp16 terms of the SCALED weight in three fragment classes (m, h 2^-11, h)
 template <int D, int BF16>
 __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     using L = Layout<D, BF16>;
@@ -78,7 +121,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
             if (!found) base += np;
         }
         const int gp = mode_gp(pd.MT, BF16);
-        constexpr int kTerms = BF16 == 2 ? 3 : 1;           // fragments per row and m-tile
+        constexpr int kTerms = BF16 >= 2 ? 3 : 1;           // fragments per row and m-tile
         const int g = (panel - base) * gp + slot / (kTerms * pd.MT);   // fragment row: k-group (fp32) or double k-group (bf16 modes)
         const int term = (slot / pd.MT) % kTerms;          // MODE 2: 0 = l, 1 = m, 2 = h (the order the kernels consume them in)
         const int mt = slot % pd.MT;
@@ -90,7 +133,18 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
                 return pd.transpose ? W[(int64_t)(pd.koff + k) * pd.ld + pd.moff + m] : W[(int64_t)(pd.moff + m) * pd.ld + pd.koff + k];
             return 0.f;
         };
-        if constexpr (BF16 == 2) {   // the fragment of ONE term: h = rn(w), m = rn(w - h), l = rn(w - h - m), differences exact in fp32
+        if constexpr (BF16 == 3) {   // the fragment of ONE class of the scaled weight ws = w s: 2 = h = rn16(ws), 0 = m = rn16(ws - h) (exact difference), 1 = rn16(ws 2^-11)
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+            const float sc = a.packed[L::scale_off + scale_slot(pd.layer)];
+            f16x8 q;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float w = elem(16 * g + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * sc;
+                const _Float16 h = (_Float16)w;
+                q[i] = term == 2 ? h : (term == 0 ? (_Float16)(w - (float)h) : (_Float16)(w * (1.f / 2048.f)));
+            }
+            reinterpret_cast<f16x8*>(a.packed)[gid] = q;
+        } else if constexpr (BF16 == 2) {   // the fragment of ONE term: h = rn(w), m = rn(w - h), l = rn(w - h - m), differences exact in fp32
             bf16x8 q;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -122,12 +176,14 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
                 const int pad = L::bias_pad(l);
                 if (bi >= o && bi < o + pad) {
                     const int j = (int)(bi - o);
-                    // the colour-hidden slot holds the merged bias b'
-                    a.packed[L::bias_base + bi] = j < L::bias_real(l) ? (l == 10 ? a.b[kMergedLayer][j] : a.b[l][j]) : 0.f;
+                    // the colour-hidden slot holds the merged bias b'; MODE 3: the biases of the MFMA layers times their weight scale
+                    float sc = 1.f;
+                    if constexpr (BF16 == 3) sc = (l < 8 || l == 10) ? a.packed[L::scale_off + scale_slot(l)] : 1.f;
+                    a.packed[L::bias_base + bi] = j < L::bias_real(l) ? (l == 10 ? a.b[kMergedLayer][j] : a.b[l][j]) * sc : 0.f;
                 }
                 o += pad;
             }
-        } else if (bi < L::table_floats) {
+        } else if (bi < L::bias_floats + L::head_floats) {
             // head tables in register order: value for (half h, register r) belongs to feature 32t + (rho&3) + 8(rho>>2) + 4h
             const int t = (int)(bi - L::bias_floats);
             const int nsig = 2 * 16 * L::DT, nrow = 2 * 16 * L::HT;
@@ -150,6 +206,7 @@ static hipError_t launch(const PackArgs& a0, hipStream_t st) {
     a.w[kMergedLayer] = a.packed + L::merged_w_off;
     a.b[kMergedLayer] = a.packed + L::merged_b_off;
     hipLaunchKernelGGL((merge_kernel<D, BF16>), dim3((L::Dh / 16) * (D / 16) + 32), dim3(256), 0, st, a);      // tiles of W', then 32 workgroups of copies
+    if constexpr (BF16 == 3) hipLaunchKernelGGL((scale_kernel<D>), dim3(kScaleSlots + 1), dim3(256), 0, st, a);
     const int64_t threads = L::bias_base / 4 + L::table_floats;
     dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     hipLaunchKernelGGL((pack_kernel<D, BF16>), grid, block, 0, st, a);
@@ -157,6 +214,7 @@ static hipError_t launch(const PackArgs& a0, hipStream_t st) {
 }
 
 hipError_t launch_pack(int D, const PackArgs& a, int mode, hipStream_t st) {
+    if (mode == 3) return D == 256 ? launch<256, 3>(a, st) : launch<128, 3>(a, st);
     if (mode == 2) return D == 256 ? launch<256, 2>(a, st) : launch<128, 2>(a, st);
     if (mode == 1) return D == 256 ? launch<256, 1>(a, st) : launch<128, 1>(a, st);
     return D == 256 ? launch<256, 0>(a, st) : launch<128, 0>(a, st);

@@ -1,0 +1,218 @@
+// nnr_split2.h -- the GEMM part of the fp32 MLP kernels with every fp32 product taken as THREE fp16 MFMA terms of two-term operands
+// (NNR_F_SPLIT2; the kernels: nnr_mlp_fwd_f16.hip, nnr_mlp_dgrad_f16.hip), gfx950 only.
+//
+// Why (round 6): the six-term bf16 products of nnr_split.h cost SIX matrix-pipe passes per fp32 product and a three-stage split of every
+// activation in front of every pass that consumes it (11 instructions per value pair, done twice per layer) -- those kernels are bound by the
+// issue of these instructions beside the MFMAs, not by the matrix pipe.  fp16 has 11
+// significand bits where bf16 has 8: TWO terms carry 22 bits,
+//     x s = x_h + 2^-11 x_m',   x_h = fp16(x s),   x_m' = fp16((x s - x_h) 2^11)          (both differences exact in fp32)
+// and  w x = [w_h x_h + w_m x_h + w_hs x_m'] / (s_w s)  with  w_h = fp16(w s_w), w_m = fp16(w s_w - w_h), w_hs = fp16(w s_w 2^-11):
+// THREE v_mfma_f32_32x32x16_f16 per 16 k-values instead of six bf16 ones; the dropped w_m x_m term and the two-term representation leave
+// a relative error of about 2^-22 per product -- unbiased, below what the fp32 accumulation of a 256-long dot product adds itself
+// (tools/micro/split2_f16.hip: the bit budget against the fp32 instruction; tools/split2_emulation.py: the whole training step against
+// fp64, indistinguishable from exact products).
+//   * Range.  fp16 spans 2^-24 .. 65504, so the operands are SCALED by powers of two (exact): the weights per tensor by the pack kernel
+//     (max |w| s_w in [2^13, 2^14); the biases arrive pre-multiplied by s_w), the forward's activations not at all (s = 1: hidden
+//     activations of this network are O(1); one above 65504 overflows to inf and the trainer's NaN check stops the run -- the six-term
+//     mode has no such bound and stays selectable), the input gradients per SAMPLE (nnr_mlp_dgrad_f16.hip).  Carrying the residual at 2^11
+//     keeps it a NORMAL fp16 number down to x_h = 2^-14: 22 bits for 6e-5 <= |x s| < 65504, an absolute floor of 2^-36 below.
+//   * The split happens ONCE per value, in the epilogue that produces it (a pair of fp16 terms is 32 bits per value: the packed terms
+//     replace the fp32 activation registers between the layers), not in front of every pass: a row of the GEMM carries no split at all.
+//     What a training kernel stashes is written by the same epilogue unit while the fp32 value exists.
+#pragma once
+#include "nnr_split.h"
+
+namespace nnr {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float kResidualUp = 2048.f;      // 2^11: the scale the second term is carried at
+
+// the two fp16 terms of a value pair, packed (x0 in the low halves): h = rn(x), m = rn((x - h) 2^11).  Infinite or NaN input gives NaN terms.
+__device__ __forceinline__ void split2_pair(float x0, float x1, uint32_t& h, uint32_t& m) {
+    const f32x2 v = {x0, x1};
+    const f16x2 hh = __builtin_convertvector(v, f16x2);
+    const f32x2 back = __builtin_convertvector(hh, f32x2);
+    const f32x2 r = (v - back) * kResidualUp;
+    h = __builtin_bit_cast(uint32_t, hh);
+    m = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+
+// the packed B operands of a feature vector in fragment layout: pair p = registers 2 p, 2 p + 1 (nnr_layout.h); the four pairs 4 g .. 4 g + 3
+// are the 8 k-values a lane contributes to row g of a 16-deep MFMA.  (Two plain arrays: a struct of arrays kept SROA from promoting slices.)
+template <int NP, class F>
+__device__ __forceinline__ void split2_all(uint32_t (&ph)[NP], uint32_t (&pm)[NP], const F& value) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) split2_pair(value(2 * p), value(2 * p + 1), ph[p], pm[p]);
+}
+
+// The ReLU gates of a finished pair appended to a mask word: word = (word << 2) | (x0 != 0) << 1 | (x1 != 0), x >= 0 (as integers: min(bits, 1)).
+// Register r of a half (32 registers per word, appended in register order) ends up at bit 31 - (r & 31): the input-gradient kernel's select is
+// (int32)(word << (r & 31)) >> 31.  One asm statement: written in C++ hipcc turns min(bits, 1) << r into a compare, an s_nop, a select between
+// 0 and a per-register constant it keeps in a VGPR (32 registers of constants) and an or.
+__device__ __forceinline__ void gate_append2(uint32_t& word, float x0, float x1) {
+    uint32_t t;
+    asm("v_min_u32_e32 %1, 1, %2\n\tv_lshl_or_b32 %0, %0, 1, %1\n\tv_min_u32_e32 %1, 1, %3\n\tv_lshl_or_b32 %0, %0, 1, %1"
+        : "+v"(word), "=&v"(t)
+        : "v"(x0), "v"(x1));
+}
+
+template <bool TILE>
+using Split2PipeT = PanelPipeT<kWavesPerBlock, kSplitPanelFrags, TILE>;     // the panel geometry of the six-term mode: 24 slots, three fragment classes per row
+
+// acc[mt] += A_part[32 mt .., :] * in, the products as three fp16 terms.  `ph` / `pm`: the packed terms of the part's input (8 KT pairs of
+// registers; pairs 4 g .. 4 g + 3 belong to row g).  A row = 16 k-values = 3 MT MFMAs in the order (weights class, activation term)
+//     t0 (w_m, x_h)   t1 (w_hs, x_m')   t2 (w_h, x_h)        -- small products first
+// Fragment class c (packed by the pack kernel as slot ((row % GP) * 3 + c) * MT + mt of the panel) is used by term c only: each fragment is
+// refilled in place for the next row right after its MFMA (reads in the order of use), one counted wait per class and row.
+// Side units: a unit finishes a pair of the PREVIOUS pass's accumulators and writes its packed terms.  Which row runs which units (SCHED):
+//   0  UPR units per row from row 0 on (unit u in row u / UPR): the units write ANOTHER array than the part reads (no constraint);
+//   1  "ahead": the units write the UPPER half of the part's own input (pair NSIDE + u, first read by row (NSIDE + u) / 4; NSIDE = 2 G pairs per
+//      half): all of them in the rows [0, G - 1), 2 - 3 per row, so that every pair is complete a row before it is read;
+//   2  "behind": the units overwrite the LOWER half in place (pair u, read by row u / 4: every MFMA of a row reads the row's pairs, so a pair can
+//      be rewritten from the next row on): all of them in the rows [1, G).
+// (first_unit(g) .. first_unit(g + 1) run in row g; tools: the two schedules brute-forced against their constraints for G = 16 and 8.)
+// STORE_EVERY: every STORE_EVERY-th unit issues one VMEM store (the training kernels' stash; 0: none); PRE: stores the part BEFORE certainly
+// issued after the last DMA piece of this part's first panel -- for the counted waits: a store younger than the DMA pieces waited for may
+// stay in flight (PanelPipeT::enter<EXTRA>).
+template <int SCHED, int NSIDE, int UPR, int G>
+__device__ __forceinline__ constexpr int first_unit(int g) {
+    if (NSIDE == 0 || g <= 0) return 0;
+    if (SCHED == 0) return g * UPR < NSIDE ? g * UPR : NSIDE;
+    if (SCHED == 1) return g >= G - 1 ? NSIDE : ((g * NSIDE + (G - 2)) / (G - 1) < NSIDE ? (g * NSIDE + (G - 2)) / (G - 1) : NSIDE);
+    return g >= G ? NSIDE : ((g - 1) * NSIDE) / (G - 1);
+}
+
+template <int KT, int MT, int NSIDE_, int SCHED, int UPR, int STORE_EVERY, int PRE, class Side, class Pipe, int NACC, int NIN>
+__device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (&ph)[NIN], const uint32_t (&pm)[NIN], const Pipe& pipe, int p0,
+                                           const Side& side, bool pre_valid = true) {
+#ifdef NNR_ABLATE_NO_SIDE
+    constexpr int NSIDE = 0;   // profiling build only
+#else
+    constexpr int NSIDE = NSIDE_;
+#endif
+    static_assert(MT <= NACC && 8 * KT <= NIN, "tile counts exceed the register arrays");
+    static_assert(MT == 1 || MT == 2 || MT == 4, "m-tiles per part");
+    constexpr int G = 2 * KT, GP = mode_gp(MT, 2), NM = 3 * MT, PW = Pipe::PW;
+    static_assert(SCHED == 0 || G >= 2, "the constrained schedules need two rows");
+    static_assert(SCHED == 0 || NSIDE_ <= 4 * (G - 1), "more units than the rows before the last one can finish in time");
+    auto rows_in = [](int pi) { return (G - pi * GP) < GP ? (G - pi * GP) : GP; };
+    auto ppk_of = [&](int pi) { return (PW + rows_in(pi) - 1) / rows_in(pi); };
+    constexpr int ppk_full = (PW + GP - 1) / GP;
+    auto fu = [](int g) { return first_unit<SCHED, NSIDE, UPR, G>(g); };
+    // stash stores the units of row r issue
+    auto stores_of_row = [&](int r) {
+        if (STORE_EVERY == 0 || r < 0 || r >= G) return 0;
+        int n = 0;
+        for (int u = fu(r); u < fu(r + 1); ++u)
+            if (u % (STORE_EVERY ? STORE_EVERY : 1) == STORE_EVERY - 1) ++n;
+        return n;
+    };
+
+#ifdef NNR_SPLIT_SAFE_SYNC
+    pipe.enter(p0);
+#else
+    if (PRE > 0 && pre_valid) pipe.template enter<PRE>(p0);      // (pre_valid is wave-uniform: the part before did issue those stores)
+    else pipe.enter(p0);
+#endif
+    pipe.pieces(p0 + 2, 0, ppk_of(0));
+    const unsigned lane_base = lds_byte_address(pipe.lds) + 16u * pipe.lane;
+    unsigned panel_addr = lane_base + pipe.buffer(p0) * (Pipe::F4 * 16);
+    f32x4 fr[3][MT];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fr[c][mt] = frag_read(panel_addr, c * MT + mt);
+
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const bool last = g + 1 == G;
+        const int u0 = fu(g), nu = fu(g + 1) - fu(g);      // this row's units
+#pragma unroll
+        for (int j = 0; j < NM; ++j) {
+            const int t = j / MT, mt = j % MT;
+            __builtin_amdgcn_sched_barrier(0);
+            // first MFMA of a fragment class in this row: its fragments have landed when at most the reads issued after the class's last one are
+            // outstanding -- the two other classes' refills (previous row's later classes, this row's earlier ones; none of this row's in the last row)
+            if (mt == 0) wait_class<MT>(fr[t], last ? (2 - t) * MT : 2 * MT);
+            const u32x4 b = t == 1 ? u32x4{pm[4 * g], pm[4 * g + 1], pm[4 * g + 2], pm[4 * g + 3]} : u32x4{ph[4 * g], ph[4 * g + 1], ph[4 * g + 2], ph[4 * g + 3]};
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[t][mt]), __builtin_bit_cast(f16x8, b), acc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last) {      // refill this fragment in place for the next row; a panel switch (counted wait + barrier) in front of the first read from a new panel
+                const int pn = p0 + (g + 1) / GP;
+                if (j == 0 && (g + 1) % GP == 0) {
+                    // Stores that may stay in flight: those certainly issued after the last DMA piece of panel pn -- pn's pieces go out while the panel
+                    // two back is consumed (first burst in the row before it, then ppk per row), so every store of the rows behind that panel's last
+                    // burst row and of this panel's earlier rows is younger.  Rows of the part before this one are not counted (conservative).
+                    constexpr int kLastBurstRow = (PW + ppk_full - 1) / ppk_full - 2;
+                    int extra = 0;
+                    for (int r = g - (GP - 1) - (GP - 1 - kLastBurstRow); r < g; ++r) extra += stores_of_row(r);
+                    if ((g + 1) / GP < 2) {      // the part's second panel: its pieces went out while the part's FIRST panel was consumed (all of them after
+                        extra = 0;               // entering it), so only this panel's earlier rows count -- and those are rows of this part
+                        for (int r = g - (GP - 1); r < g; ++r) extra += stores_of_row(r);
+                    }
+#ifdef NNR_SPLIT_SAFE_SYNC
+                    extra = 0;
+#endif
+                    switch (extra) {
+                        case 0: pipe.template enter<0>(pn); break;
+                        case 1: pipe.template enter<1>(pn); break;
+                        case 2: pipe.template enter<2>(pn); break;
+                        case 3: pipe.template enter<3>(pn); break;
+                        case 4: pipe.template enter<4>(pn); break;
+                        case 5: pipe.template enter<5>(pn); break;
+                        default: pipe.template enter<6>(pn); break;
+                    }
+                    panel_addr = lane_base + pipe.buffer(pn) * (Pipe::F4 * 16);
+                }
+                fr[t][mt] = frag_read(panel_addr, (((g + 1) % GP) * 3 + t) * MT + mt);
+            }
+            // the DMA pieces of the panel two ahead, spread over the rows of the current panel (one burst per row, in the row's second gap)
+            if (j == 1) {
+                const int pi = g / GP, gi = g % GP;
+                if (gi == rows_in(pi) - 1) {
+                    if (!last) pipe.pieces(p0 + pi + 3, 0, ppk_of(pi + 1));      // this row entered panel pi + 1 above
+                } else {
+                    pipe.pieces(p0 + pi + 2, (gi + 1) * ppk_of(pi), ppk_of(pi));
+                }
+            }
+            if constexpr (NSIDE > 0) {
+#pragma unroll
+                for (int k = 0; k < nu; ++k) {      // unit k of the row's nu: spread over the gaps behind the DMA burst
+                    const int gap = NM >= 4 ? 2 + (k * (NM - 2)) / nu : (k * NM) / nu;
+                    if (gap == j) side(u0 + k);
+                }
+            }
+        }
+        pin_acc<MT>(acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (NSIDE > 0) {
+#pragma unroll
+        for (int u = fu(G); u < NSIDE; ++u) side(u);
+    }
+}
+
+template <int KT, int MT, class Pipe, int NACC, int NIN>
+__device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (&ph)[NIN], const uint32_t (&pm)[NIN], const Pipe& pipe, int p0) {
+    gemm_part2<KT, MT, 0, 0, 1, 0, 0>(acc, ph, pm, pipe, p0, NoSide{});
+}
+
+// one whole 1 KiB block of a tile-major fp32 plane (nnr_layout.h: tile32_index), non-temporal: (scalar base of the plane's block 0 of this chunk, bumped
+// by 4 KiB every fourth block) + (32-bit lane offset = 16 bytes per lane) + immediate -- the store instruction of nnr_split.h, written out for
+// the same reasons (no FLAT store, no 64-bit vector address arithmetic; hipcc does not count it: the panel switches' counted waits do).
+// The s_nop behind it is NOT optional: a VMEM store of more than 64 bits reads its data registers after it has issued, and a VALU write to one of
+// them within the next two wait states corrupts what is stored (gfx940 hazard; hipcc pads it for stores it knows, it does not look into asm) --
+// the units' temporaries are rewritten by the very next instruction (first build: every stashed plane wrong, the computation right).
+__device__ __forceinline__ void tile_store(const char* base, int lane_off, int block, f32x4 val) {
+    const uint64_t sb = reinterpret_cast<uint64_t>(base) + 4096u * (unsigned)(block >> 2);
+    switch (block & 3) {
+        case 0: asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(lane_off), "v"(val), "s"(sb) : "memory"); break;
+        case 1: asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024 nt\n\ts_nop 1" : : "v"(lane_off), "v"(val), "s"(sb) : "memory"); break;
+        case 2: asm volatile("global_store_dwordx4 %0, %1, %2 offset:2048 nt\n\ts_nop 1" : : "v"(lane_off), "v"(val), "s"(sb) : "memory"); break;
+        default: asm volatile("global_store_dwordx4 %0, %1, %2 offset:3072 nt\n\ts_nop 1" : : "v"(lane_off), "v"(val), "s"(sb) : "memory"); break;
+    }
+}
+
+}  // namespace nnr

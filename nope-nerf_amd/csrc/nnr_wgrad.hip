@@ -766,7 +766,7 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
     hipError_t e;
     prof_before(PROF_WGRAD, st);
     static const bool split_off = std::getenv("NNR_WGRAD_FP32") != nullptr;      // experiments: fp32 MFMAs in the weight gradient of the three-term mode
-    if (a.bf16 == 2 && !split_off) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
+    if (a.bf16 >= 2 && !split_off) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_heads * 16), dim3(256), 0, st, a);
     e = hipGetLastError();
@@ -779,11 +779,13 @@ hipError_t launch_wgrad_unmerge(const WgradArgs& a, hipStream_t st) {
     const int threads = a.D * a.D + (a.D / 2) * a.D + a.D + a.D / 2;
     const dim3 grid((threads + 255) / 256), block(256);
     if (a.D == 256) {
-        if (a.bf16 == 2) hipLaunchKernelGGL((wgrad_unmerge_kernel<256, 2>), grid, block, 0, st, a);
+        if (a.bf16 == 3) hipLaunchKernelGGL((wgrad_unmerge_kernel<256, 3>), grid, block, 0, st, a);
+        else if (a.bf16 == 2) hipLaunchKernelGGL((wgrad_unmerge_kernel<256, 2>), grid, block, 0, st, a);
         else if (a.bf16 == 1) hipLaunchKernelGGL((wgrad_unmerge_kernel<256, 1>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((wgrad_unmerge_kernel<256, 0>), grid, block, 0, st, a);
     } else {
-        if (a.bf16 == 2) hipLaunchKernelGGL((wgrad_unmerge_kernel<128, 2>), grid, block, 0, st, a);
+        if (a.bf16 == 3) hipLaunchKernelGGL((wgrad_unmerge_kernel<128, 3>), grid, block, 0, st, a);
+        else if (a.bf16 == 2) hipLaunchKernelGGL((wgrad_unmerge_kernel<128, 2>), grid, block, 0, st, a);
         else if (a.bf16 == 1) hipLaunchKernelGGL((wgrad_unmerge_kernel<128, 1>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((wgrad_unmerge_kernel<128, 0>), grid, block, 0, st, a);
     }

@@ -18,19 +18,24 @@ NNR_F_RELU_SIGMA = 4
 NNR_F_TRAIN = 8
 NNR_F_BF16 = 16
 NNR_F_SPLIT3 = 32
+NNR_F_SPLIT2 = 64
 
-# How the fp32 mode multiplies in the forward and input-gradient kernels (include/nnr.h, NNR_F_SPLIT3): "split3" = every operand as three
-# bf16 terms, six bf16 MFMAs per product with fp32 accumulation -- as close to the exact result as the fp32 instruction
-# (tests/test_gpu_split3.py, against fp64) at 2.7x fewer matrix-pipe cycles; "mfma" = v_mfma_f32_32x32x2_f32 (NNR_FP32_PRODUCTS=mfma).
+# How the fp32 mode multiplies in the forward and input-gradient kernels (include/nnr.h, NNR_F_SPLIT3 / NNR_F_SPLIT2):
+#   "split2" (round 6, the default) = every operand as TWO fp16 terms (power-of-two scaled, the residual carried at 2^11), three fp16 MFMAs per
+#            product with fp32 accumulation (csrc/nnr_split2.h) -- half the matrix-pipe passes of "split3", as close to an fp64 evaluation of the
+#            step (tests/test_gpu_split2.py); the weight gradient keeps split3's six bf16 terms;
+#   "split3" = every operand as three bf16 terms, six bf16 MFMAs per product (tests/test_gpu_split3.py): no range bound at all;
+#   "mfma"   = v_mfma_f32_32x32x2_f32.
+PRODUCT_KINDS = ("split2", "split3", "mfma")
 _fp32_products = os.environ.get("NNR_FP32_PRODUCTS", "split3")
-if _fp32_products not in ("split3", "mfma"):      # a typo must not silently select the other arithmetic (packed layout, plan and kernels differ)
-    raise ValueError("NNR_FP32_PRODUCTS=%r: expected 'split3' or 'mfma'" % _fp32_products)
+if _fp32_products not in PRODUCT_KINDS:      # a typo must not silently select the other arithmetic (packed layout, plan and kernels differ)
+    raise ValueError("NNR_FP32_PRODUCTS=%r: expected one of %r" % (_fp32_products, PRODUCT_KINDS))
 
 
 def set_fp32_products(kind: str) -> str:
-    """Select "split3" or "mfma" for every fp32-mode call made from now on; returns the previous setting."""
+    """Select "split2", "split3" or "mfma" for every fp32-mode call made from now on; returns the previous setting."""
     global _fp32_products
-    if kind not in ("split3", "mfma"):
+    if kind not in PRODUCT_KINDS:
         raise ValueError(kind)
     prev, _fp32_products = _fp32_products, kind
     return prev
@@ -193,8 +198,10 @@ def make_cfg(n_rays: int, n_samples: int, hidden: int, *, dist_alpha=False, whit
              train=False, bf16=False) -> Cfg:
     flags = (NNR_F_DIST_ALPHA if dist_alpha else 0) | (NNR_F_WHITE_BG if white_bg else 0) | \
             (NNR_F_RELU_SIGMA if relu_sigma else 0) | (NNR_F_TRAIN if train else 0) | (NNR_F_BF16 if bf16 else 0)
-    if not bf16 and _fp32_products == "split3":
+    if not bf16 and _fp32_products in ("split3", "split2"):
         flags |= NNR_F_SPLIT3
+        if _fp32_products == "split2":
+            flags |= NNR_F_SPLIT2
     return Cfg(int(n_rays), int(n_samples), int(hidden), flags)
 
 

@@ -75,7 +75,7 @@ def _packed_for(cfg, weights, biases):
     """Packed (MFMA-fragment order) copy of the 24 parameter tensors; `weights`/`biases` must be the caller's long-lived
     tensor objects (nn.Parameters), not temporaries."""
     tensors = [*weights, *biases]
-    mode = (cfg.hidden, cfg.flags & (L.NNR_F_BF16 | L.NNR_F_SPLIT3))     # each product mode has its own packed layout
+    mode = (cfg.hidden, cfg.flags & (L.NNR_F_BF16 | L.NNR_F_SPLIT3 | L.NNR_F_SPLIT2))     # each product mode has its own packed layout
     key = (id(tensors[0]), mode[1])
     hit = _pack_caches.get(key)
     if hit is not None and hit.matches(mode, tensors):

@@ -122,8 +122,8 @@ def main():
     ref = trace(*args, torch.float64)
     cols = {"cpu fp32": trace(*args, torch.float32)}
     if torch.cuda.is_available():
-        cols["hip split3"] = hip(*args, D, "split3")
-        cols["hip mfma"] = hip(*args, D, "mfma")
+        for kind in os.environ.get("NNR_BISECT_KINDS", "split2,split3,mfma").split(","):      # (round 6: + the two-term fp16 products)
+            cols["hip " + kind] = hip(*args, D, kind)
     names = list(cols)
     print("render operator, D=%d, %d rays x %d samples, seed %d: error against the fp64 trace, stage by stage" % (D, R, N, seed))
     print("%-22s %-11s" % ("stage", "max|ref|") + "".join("| %-34s" % (n + ": rel-L2  max/|ref|max  gates") for n in names))
