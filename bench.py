@@ -53,8 +53,12 @@ EXECUTED_MACS_PER_SAMPLE = {D: 64 * D + 3 * D * D + (D + 64) * D + 3 * D * D + D
 PEAK_FP32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0               # dense bf16 MFMA (not the 2:1-sparsity headline figure)
 PEAK_HBM_GBS = 8000.0                        # HBM3E
-FP32_HOW = {'mfma': 'fp32 (fp32 MFMAs)', 'split3': 'fp32 via six bf16 MFMA terms per product'}      # (short: the driver's record cuts strings at ~100 characters)
+FP32_HOW = {'mfma': 'fp32 (fp32 MFMAs)', 'split3': 'fp32 via six bf16 MFMA terms per product',
+            'split2': 'fp32 via three fp16 MFMA terms per product (fwd, dgrad), six bf16 terms (wgrad)'}      # (short: the driver's record cuts strings at ~100 characters)
 FP32_NOTE = {'mfma': 'v_mfma_f32_32x32x2_f32 products in all three MLP kernels',
+             'split2': 'fp32 results: forward and input-gradient products as three fp16 MFMA terms of two-term operands (power-of-two scaled, residual at '
+                       '2^11: csrc/nnr_split2.h; as close to fp64 as fp32 MFMAs: tests/test_gpu_split3.py), fp32 accumulate; weight gradient: six bf16 MFMA '
+                       'terms of three-term operands (4 x 4 tiles), its narrow tiles on fp32 MFMAs',
              'split3': 'fp32 results: every product of the three MLP kernels as six bf16 MFMA terms of three-term (exact) operands, fp32 accumulate '
                        '(as close to fp64 as fp32 MFMAs: tests/test_gpu_split3.py); the narrow weight-gradient tiles on fp32 MFMAs'}
 
@@ -131,7 +135,8 @@ def build_trainer(device, world, aux=False, bf16=False, rays_per_gpu=None, n_sam
     return trainer, net
 
 
-_TRAFFIC_FILES = ('profiles/r05/hbm_traffic.json', 'profiles/r05/hbm_traffic_bf16_4096x128.json', 'profiles/r05/hbm_traffic_fp32_1024x128.json',
+_TRAFFIC_FILES = ('profiles/r06/hbm_traffic.json', 'profiles/r06/hbm_traffic_bf16_4096x128.json', 'profiles/r06/hbm_traffic_fp32_1024x128.json',
+                  'profiles/r05/hbm_traffic.json', 'profiles/r05/hbm_traffic_bf16_4096x128.json', 'profiles/r05/hbm_traffic_fp32_1024x128.json',
                   'profiles/r04/hbm_traffic.json', 'profiles/r04/hbm_traffic_bf16_4096x128.json',
                   'profiles/r03/hbm_traffic.json', 'profiles/r03/hbm_traffic_bf16_4096x128.json',
                   'profiles/r02/hbm_traffic.json', 'profiles/r02/hbm_traffic_bf16_4096x128.json')
@@ -157,6 +162,10 @@ def _hbm_traffic(kernel, bf16=False, shape=None):
         if bool(table.get('bf16', False)) != bool(bf16):
             continue
         key = _KERNEL_KEYS[bool(bf16)][kernel]
+        if not bf16 and kernel != 'mlp_wgrad':      # the fp32 mode's forward / input gradient have one kernel per product mode: take the running one's figure only
+            from nnr import lib as nnr_lib
+            if nnr_lib.fp32_products() == 'split2':
+                key = key.replace('_kernel<', '_f16_kernel<')      # nnr::mlp_fwd_f16_kernel<256, true> / nnr::mlp_dgrad_f16_kernel<256>
         for name, v in table['kernels'].items():
             if key in name:
                 return int(v['fetch_bytes'] + v['write_bytes']), rel + ' (offline PMC passes, not measured in this run)'
@@ -304,30 +313,40 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
                 'kernels': per, 'fused_mlp_all_three': three}
     traffic, src = _hbm_traffic(dom, False, (R, N))
     products = L.fp32_products()
-    if products != 'split3':      # (three-term products run on the bf16 pipe: an "fp32 MFMA fraction" of them would read above 1)
+    if products == 'mfma':      # (term products run on the 16-bit pipe: an "fp32 MFMA fraction" of them would read above 1)
         three['frac'] = round(three['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4)
-    if products == 'split3':
-        # Every fp32 product as six bf16 MFMA terms (csrc/nnr_split.h): the kernels' bound is the bf16 matrix pipe, and the work they issue
-        # is 6 x the executed MACs.  Forward / input gradient: all of it; weight gradient: the 4 x 4 tiles (480 of the 528 tile-units of
-        # MFMA work at D = 256), the narrow tiles stay on fp32 MFMAs.
+    if products in ('split3', 'split2'):
+        # Every fp32 product as 16-bit MFMA terms: six bf16 terms of three-term operands (csrc/nnr_split.h), or -- forward / input gradient of
+        # 'split2' -- three fp16 terms of two-term operands (csrc/nnr_split2.h).  The kernels' bound is the 16-bit matrix pipe (bf16 and fp16:
+        # the same dense 2.5 PFLOP/s), the work they issue is terms x the executed MACs.  Forward / input gradient: all of it; weight gradient
+        # (six bf16 terms in both modes): the 4 x 4 tiles (480 of the 528 tile-units of MFMA work at D = 256), the narrow tiles stay on fp32 MFMAs.
         share = {'mlp_fwd': 1.0, 'mlp_dgrad': 1.0, 'mlp_fwd_infer': 1.0, 'mlp_wgrad': 480.0 / 528.0 if D == 256 else 0.0}
+        terms = {k: (6 if (products == 'split3' or k == 'mlp_wgrad') else 3) for k in share}
         for k, f in share.items():
-            issued = 6 * f * executed / (times[k] * 1e-3) / 1e12
-            per[k].update(mfma='bf16, 6 terms per fp32 product' + ('' if f == 1.0 else ' (4 x 4 tiles: %.0f %% of the MACs; narrow tiles fp32)' % (100 * f)),
-                          issued_bf16_tflops=round(issued, 1), frac_of_bf16_mfma_peak=round(issued / PEAK_BF16_MFMA_TFLOPS, 4))
-        three['issued_bf16_tflops'] = round(sum(6 * share[k] * executed for k in ('mlp_fwd', 'mlp_dgrad', 'mlp_wgrad')) / (mlp_ms * 1e-3) / 1e12, 1)
+            issued = terms[k] * f * executed / (times[k] * 1e-3) / 1e12
+            per[k].update(mfma=('bf16, 6 terms per fp32 product' if terms[k] == 6 else 'fp16, 3 terms per fp32 product')
+                          + ('' if f == 1.0 else ' (4 x 4 tiles: %.0f %% of the MACs; narrow tiles fp32)' % (100 * f)), terms_per_product=terms[k],
+                          issued_bf16_tflops=round(issued, 1), frac_of_bf16_mfma_peak=round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
+                          # SURVEY 8(d)'s own figure beside it: algorithmic FLOPs / time, and its ratio to the fp32 MATRIX peak -- above 1 where the
+                          # work does not run on that pipe, which is the point of the term products
+                          algorithmic_tflops=round(flops / (times[k] * 1e-3) / 1e12, 2),
+                          frac_of_fp32_matrix_peak=round(flops / (times[k] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
+        three['issued_bf16_tflops'] = round(sum(terms[k] * share[k] * executed for k in ('mlp_fwd', 'mlp_dgrad', 'mlp_wgrad')) / (mlp_ms * 1e-3) / 1e12, 1)
         three['frac_of_bf16_mfma_peak'] = round(three['issued_bf16_tflops'] / PEAK_BF16_MFMA_TFLOPS, 4)
+        three['frac_of_fp32_matrix_peak'] = round(three['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4)
         issued_dom = per[dom]['issued_bf16_tflops']
         return {
             'fp32_products': products, 'bound': 'mfma', 'kernel': dom, 'achieved': issued_dom, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(issued_dom / PEAK_BF16_MFMA_TFLOPS, 4),
-            'what': 'issued bf16 MFMA work (6 terms x executed MACs x 2) / in-step time vs the dense bf16 peak',
-            'notes': 'peak at the nominal 2.4 GHz; the chip holds ~1.8 GHz under these kernels (DESIGN 4.3).  frac_algorithmic = 6 terms x ALGORITHMIC '
+            'what': 'issued 16-bit MFMA work (%d terms x executed MACs x 2) / in-step time vs the dense bf16 / fp16 peak' % terms[dom],
+            'notes': 'peak at the nominal 2.4 GHz; the chip holds ~1.8 GHz under these kernels (DESIGN 4.3).  frac_algorithmic = terms x ALGORITHMIC '
                      'MACs x 2 / time / peak (SURVEY 8d counts algorithmic work; the kernels execute 89 %% of it: feature layer folded).  '
-                     'fp32_equivalent_tflops = algorithmic FLOPs / time, which exceeds the fp32 MFMA peak of %.1f by construction' % PEAK_FP32_MFMA_TFLOPS,
-            'frac_algorithmic': round(6 * share[dom] * flops / (times[dom] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                     'algorithmic_tflops (= fp32_equivalent_tflops) = algorithmic FLOPs / time; frac_of_fp32_matrix_peak = that / %.1f, above 1 by construction: '
+                     'the products do not run on the fp32 matrix pipe' % PEAK_FP32_MFMA_TFLOPS,
+            'frac_algorithmic': round(terms[dom] * share[dom] * flops / (times[dom] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+            'algorithmic_tflops': round(achieved, 2), 'frac_of_fp32_matrix_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
             'fp32_equivalent_tflops': round(achieved, 2), 'traffic': traffic, 'traffic_source': src, 'timing': how,
-            'flop_per_launch': flops, 'executed_flop_per_launch': executed, 'issued_bf16_flop_per_launch': int(6 * share[dom] * executed),
+            'flop_per_launch': flops, 'executed_flop_per_launch': executed, 'issued_bf16_flop_per_launch': int(terms[dom] * share[dom] * executed),
             'kernels': per, 'fused_mlp_all_three': three,
         }
     return {
@@ -589,29 +608,35 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def self_launch(n):
-    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one per GPU)."""
+def self_launch(n, script=None, argv=None, capture=False):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one per GPU).
+    script / argv: another rank script and its arguments through the SAME launch line (the 8-rank CPU dry run of the data-parallel step,
+    tests/dp_dryrun_worker.py); capture: return (returncode, stdout) instead of the return code."""
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           '--master-port', str(_free_port()), os.path.abspath(script or __file__)] + (sys.argv[1:] if argv is None else list(argv))
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault('OMP_NUM_THREADS', '4')
+    if capture:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+        return r.returncode, r.stdout + ('\n' + r.stderr[-3000:] if r.returncode else '')
     return subprocess.call(cmd, env=env)
 
 
 def allreduce_probe(device, n_floats, reps=20):
     """The step's one collective on its own: SUM all-reduce of a flat fp32 bucket of the gradient size, microseconds per call
     (max over ranks), and the number of ranks that actually took part (the sum of ones)."""
+    sync = torch.cuda.synchronize if torch.device(device).type == 'cuda' else (lambda: None)      # (a CPU group in the dry-run tests)
     buf = torch.ones(n_floats, device=device)
     dist.all_reduce(buf)
     ranks_seen = int(round(float(buf[0].item())))
     buf.fill_(1.0)
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
         dist.all_reduce(buf)
-    torch.cuda.synchronize()
+    sync()
     us = (time.perf_counter() - t0) / reps * 1e6
     t = torch.tensor([us], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -734,6 +759,9 @@ def main():
                 # the headline shape with v_mfma_f32_32x32x2_f32 products in all three kernels (the fp32 path of rounds 1-2)
                 'fp32_mfma_1024x192': extra_config(device, 'BASELINE configs[1] with fp32-MFMA products (NNR_FP32_PRODUCTS=mfma)',
                                                    R_PER_GPU, N_SAMPLES, False, products='mfma') if fp32_products != 'mfma' else None,
+                # ... and with the six-term bf16 products of rounds 3-5 in all three kernels (NNR_FP32_PRODUCTS=split3)
+                'fp32_split3_1024x192': extra_config(device, 'BASELINE configs[1] with six bf16 MFMA terms per product in all three kernels (NNR_FP32_PRODUCTS=split3)',
+                                                     R_PER_GPU, N_SAMPLES, False, products='split3') if fp32_products == 'split2' else None,
                 # what the reference runs for its first 10 000 epochs (configs/default.yaml:99-100,118): the headline step with the per-image
                 # point-cloud + surface re-projection losses ON
                 'fp32_1024x192_aux': extra_config(device, 'BASELINE configs[1] in the first training phase: per-image losses (pc + rgb_s) on',

@@ -20,6 +20,15 @@ static_assert(kTileActPlanes && kTileGradPlanes, "the planes of a three-term / t
 
 // Compile-time description of one encoding feature and the chain rule through gamma_L: as in nnr_mlp_dgrad.hip (tile-major planes only)
 namespace f16dg {
+// unit_dgrad for the pair of registers (r, r + 1), r even: their gates sit at bits 31 - (r & 31) and 30 - (r & 31) of the word (gate_append2's order); rr folds after unrolling
+__device__ __forceinline__ void sel_unit(float a0, float a1, uint32_t word, float invw, float sinv, float& t0, float& t1, uint32_t& h, uint32_t& m, int rr) {
+    switch (rr) {
+#define NNR_SU(R) case R: unit_dgrad<31 - (R), 30 - (R)>(a0, a1, word, invw, sinv, t0, t1, h, m); break;
+        NNR_SU(0) NNR_SU(2) NNR_SU(4) NNR_SU(6) NNR_SU(8) NNR_SU(10) NNR_SU(12) NNR_SU(14) NNR_SU(16) NNR_SU(18) NNR_SU(20) NNR_SU(22) NNR_SU(24) NNR_SU(26) NNR_SU(28)
+#undef NNR_SU
+        default: unit_dgrad<1, 0>(a0, a1, word, invw, sinv, t0, t1, h, m); break;
+    }
+}
 struct EncMeta { int coord; float scale; int partner; };
 __device__ __forceinline__ constexpr EncMeta enc_meta(int f, int n_real) {
     if (f >= n_real) return {0, 0.f, 0};
@@ -176,14 +185,10 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
 #define NNR_SELECT(ACC, OFFP, MW, INV, PLANE, BLK0)                                                              \
     [&](int u) __attribute__((always_inline)) {                                                                  \
         const int r = 2 * u;                                                                                     \
-        f32x2 x;                                                                                                 \
-        x[0] = __uint_as_float(__float_as_uint(ACC[r >> 4][r & 15]) & (uint32_t)((int32_t)(MW[r >> 5] << (r & 31)) >> 31)); \
-        x[1] = __uint_as_float(__float_as_uint(ACC[(r + 1) >> 4][(r + 1) & 15]) & (uint32_t)((int32_t)(MW[(r + 1) >> 5] << ((r + 1) & 31)) >> 31)); \
-        x = x * (INV);                                                                                           \
-        const f32x2 t = x * sInv;                                                                                \
-        if (u & 1) tile_store(PLANE, lane_off, (BLK0) + (u >> 1), f32x4{keep[0], keep[1], t[0], t[1]});          \
-        else keep = t;                                                                                           \
-        split2_pair(x[0], x[1], ph[(OFFP) + u], pm[(OFFP) + u]);                                                 \
+        float t0, t1;                                                                                            \
+        f16dg::sel_unit(ACC[r >> 4][r & 15], ACC[(r + 1) >> 4][(r + 1) & 15], MW[r >> 5], INV, sInv, t0, t1, ph[(OFFP) + u], pm[(OFFP) + u], r & 31); \
+        if (u & 1) tile_store(PLANE, lane_off, (BLK0) + (u >> 1), f32x4{keep[0], keep[1], t0, t1});              \
+        else keep = f32x2{t0, t1};                                                                               \
     }
     auto dh = [&](int hidden_idx /*0..7*/) -> const char* {      // block (this chunk, octet 0) of the gradient plane of hidden layer hidden_idx + 1
         return reinterpret_cast<const char*>(a.ws_dh + (int64_t)hidden_idx * a.S_pad * D + chunk * (int64_t)((D / 8) * 256));

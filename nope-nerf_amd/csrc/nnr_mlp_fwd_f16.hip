@@ -150,20 +150,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
 #define NNR_FINISH(ACC, OFFP, MW, INV, PLANE, BLK0, SIG)                                                           \
     [&](int u) __attribute__((always_inline)) {                                                                  \
         const int r = 2 * u;                                                                                     \
-        f32x2 x = f32x2{ACC[r >> 4][r & 15], ACC[(r + 1) >> 4][(r + 1) & 15]} * (INV);                           \
-        x[0] = relu1(x[0]);                                                                                      \
-        x[1] = relu1(x[1]);                                                                                      \
+        float x0, x1;                                                                                            \
         if constexpr (TRAIN) {      /* (x > 0) == (relu(x) != 0): two gate bits appended to the half's mask word (nnr_split2.h) */ \
-            gate_append2(MW[r >> 5], x[0], x[1]);                                                                \
-            if (u & 1) tile_store(PLANE, lane_off, (BLK0) + (u >> 1), f32x4{keep[0], keep[1], x[0], x[1]});      \
-            else keep = x;                                                                                       \
+            unit_fwd_train(ACC[r >> 4][r & 15], ACC[(r + 1) >> 4][(r + 1) & 15], INV, MW[r >> 5], x0, x1, ph[(OFFP) + u], pm[(OFFP) + u]); \
+            if (u & 1) tile_store(PLANE, lane_off, (BLK0) + (u >> 1), f32x4{keep[0], keep[1], x0, x1});          \
+            else keep = f32x2{x0, x1};                                                                           \
+        } else {                                                                                                 \
+            unit_fwd_infer(ACC[r >> 4][r & 15], ACC[(r + 1) >> 4][(r + 1) & 15], INV, x0, x1, ph[(OFFP) + u], pm[(OFFP) + u]); \
         }                                                                                                        \
         if constexpr (SIG) {                                                                                     \
             const f32x2 w2 = *reinterpret_cast<const f32x2*>(bias + L::wsig_off + half * (16 * DT) + 2 * (OFFP) + r); \
-            sg0 = fmaf(w2[0], x[0], sg0);                                                                        \
-            sg1 = fmaf(w2[1], x[1], sg1);                                                                        \
+            sg0 = fmaf(w2[0], x0, sg0);                                                                          \
+            sg1 = fmaf(w2[1], x1, sg1);                                                                          \
         }                                                                                                        \
-        split2_pair(x[0], x[1], ph[(OFFP) + u], pm[(OFFP) + u]);                                                 \
     }
     auto p0 = [&](int part) { return L::fwd_panel0(part); };
     auto xh = [&](int hidden_idx /*0..7*/) -> const char* {      // block (this chunk, octet 0) of hidden layer hidden_idx + 1's activation plane

@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void scale_kernel(PackArgs a) {
         }
         a.packed[L::scale_off + slot] = slot == 9 ? mx : s;
         a.packed[L::scale_off + 16 + slot] = slot == 9 ? 0.f : 1.f / s;
+        if (slot == 9)      // the unused entries of the two tables: defined values (the buffer is the caller's, uninitialised)
+            for (int i = 10; i < 16; ++i) a.packed[L::scale_off + i] = a.packed[L::scale_off + 16 + i] = 0.f;
     }
 }
 

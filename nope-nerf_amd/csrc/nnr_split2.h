@@ -58,6 +58,85 @@ __device__ __forceinline__ void gate_append2(uint32_t& word, float x0, float x1)
         : "v"(x0), "v"(x1));
 }
 
+// ---- the epilogue units as single asm statements ---------------------------------------------------------------------------------------
+// Written in C++ the unit of a pair cost 21 issue slots in the training forward (hipcc: the two accumulator reads hoisted out of the part
+// as a 64-register copy that pushed the packed terms into AGPR spills; the gates as compare / select / or with s_nops; the residual through
+// two conversions, a packed subtract and a packed multiply, each packed result padded with an s_nop before its consumer) -- and these kernels
+// are bound by issue slots.  One statement per unit, 16 slots, no padding: the residual (x - h) 2^11 as ONE mixed-precision FMA per value
+// (v_fma_mix_f32: -2048 x fp16 half of h + 2048 x, exact), independent instructions between a packed-encoding result and its consumer.
+// Hazards the compiler cannot see inside asm, covered by construction: an accumulator read here is at least 25 instructions behind the last
+// MFMA that wrote it (the accumulators of the OTHER half-pass; a part's first unit sits behind its panel switch, 12 fragment reads and
+// 3 MFMAs); a VOP3P result (v_fma_mix_f32) is read one instruction later at the earliest.
+// forward, training: pair of accumulators -> x = relu(acc / s_w) (returned: stash, density head), two gate bits appended, packed terms
+__device__ __forceinline__ void unit_fwd_train(float a0, float a1, float inv, uint32_t& word, float& x0, float& x1, uint32_t& h, uint32_t& m) {
+    float c0, c1;
+    uint32_t t;
+    asm volatile(
+        "v_accvgpr_read_b32 %0, %8\n\t"
+        "v_accvgpr_read_b32 %1, %9\n\t"
+        "v_mul_f32_e64 %0, %0, %10\n\t"
+        "v_mul_f32_e64 %1, %1, %10\n\t"
+        "v_max_f32_e32 %0, 0, %0\n\t"
+        "v_max_f32_e32 %1, 0, %1\n\t"
+        "v_cvt_pk_f16_f32 %2, %0, %1\n\t"
+        "v_mul_f32_e64 %4, %0, %11\n\t"
+        "v_mul_f32_e64 %5, %1, %11\n\t"
+        "v_min_u32_e32 %6, 1, %0\n\t"
+        "v_lshl_or_b32 %7, %7, 1, %6\n\t"
+        "v_fma_mix_f32 %4, %2, %12, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %5, %2, %12, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_min_u32_e32 %6, 1, %1\n\t"
+        "v_lshl_or_b32 %7, %7, 1, %6\n\t"
+        "v_cvt_pk_f16_f32 %3, %4, %5"
+        : "=&v"(x0), "=&v"(x1), "=&v"(h), "=&v"(m), "=&v"(c0), "=&v"(c1), "=&v"(t), "+v"(word)
+        : "a"(a0), "a"(a1), "s"(inv), "s"(kResidualUp), "s"(-kResidualUp));
+}
+// forward, inference: no gates (an s_nop between the second mixed FMA and the conversion that reads it)
+__device__ __forceinline__ void unit_fwd_infer(float a0, float a1, float inv, float& x0, float& x1, uint32_t& h, uint32_t& m) {
+    float c0, c1;
+    asm volatile(
+        "v_accvgpr_read_b32 %0, %6\n\t"
+        "v_accvgpr_read_b32 %1, %7\n\t"
+        "v_mul_f32_e64 %0, %0, %8\n\t"
+        "v_mul_f32_e64 %1, %1, %8\n\t"
+        "v_max_f32_e32 %0, 0, %0\n\t"
+        "v_max_f32_e32 %1, 0, %1\n\t"
+        "v_cvt_pk_f16_f32 %2, %0, %1\n\t"
+        "v_mul_f32_e64 %4, %0, %9\n\t"
+        "v_mul_f32_e64 %5, %1, %9\n\t"
+        "v_fma_mix_f32 %4, %2, %10, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %5, %2, %10, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 0\n\t"
+        "v_cvt_pk_f16_f32 %3, %4, %5"
+        : "=&v"(x0), "=&v"(x1), "=&v"(h), "=&v"(m), "=&v"(c0), "=&v"(c1)
+        : "a"(a0), "a"(a1), "s"(inv), "s"(kResidualUp), "s"(-kResidualUp));
+}
+// input gradient: pair of accumulators -> relu'(.) ? acc : 0 (gates of registers r, r + 1 at bits POS0, POS1 of `word`: gate_append2's order)
+// -> x = . / s_w (the scaled gradient) -> packed terms; t = x / s (the true gradient, for the plane)
+template <int POS0, int POS1>
+__device__ __forceinline__ void unit_dgrad(float a0, float a1, uint32_t word, float invw, float sinv, float& t0, float& t1, uint32_t& h, uint32_t& m) {
+    float x0, x1, c0, c1;
+    asm volatile(
+        "v_accvgpr_read_b32 %4, %8\n\t"
+        "v_accvgpr_read_b32 %5, %9\n\t"
+        "v_bfe_i32 %6, %10, %15, 1\n\t"
+        "v_bfe_i32 %7, %10, %16, 1\n\t"
+        "v_and_b32_e32 %4, %4, %6\n\t"
+        "v_and_b32_e32 %5, %5, %7\n\t"
+        "v_mul_f32_e64 %4, %4, %11\n\t"
+        "v_mul_f32_e64 %5, %5, %11\n\t"
+        "v_cvt_pk_f16_f32 %2, %4, %5\n\t"
+        "v_mul_f32_e64 %6, %4, %12\n\t"
+        "v_mul_f32_e64 %7, %5, %12\n\t"
+        "v_mul_f32_e32 %0, %4, %14\n\t"
+        "v_fma_mix_f32 %6, %2, %13, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %7, %2, %13, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_mul_f32_e32 %1, %5, %14\n\t"
+        "v_cvt_pk_f16_f32 %3, %6, %7"
+        : "=&v"(t0), "=&v"(t1), "=&v"(h), "=&v"(m), "=&v"(x0), "=&v"(x1), "=&v"(c0), "=&v"(c1)
+        : "a"(a0), "a"(a1), "v"(word), "s"(invw), "s"(kResidualUp), "s"(-kResidualUp), "v"(sinv), "n"(POS0), "n"(POS1));
+}
+
 template <bool TILE>
 using Split2PipeT = PanelPipeT<kWavesPerBlock, kSplitPanelFrags, TILE>;     // the panel geometry of the six-term mode: 24 slots, three fragment classes per row
 

@@ -27,7 +27,7 @@ NNR_F_SPLIT2 = 64
 #   "split3" = every operand as three bf16 terms, six bf16 MFMAs per product (tests/test_gpu_split3.py): no range bound at all;
 #   "mfma"   = v_mfma_f32_32x32x2_f32.
 PRODUCT_KINDS = ("split2", "split3", "mfma")
-_fp32_products = os.environ.get("NNR_FP32_PRODUCTS", "split3")
+_fp32_products = os.environ.get("NNR_FP32_PRODUCTS", "split2")
 if _fp32_products not in PRODUCT_KINDS:      # a typo must not silently select the other arithmetic (packed layout, plan and kernels differ)
     raise ValueError("NNR_FP32_PRODUCTS=%r: expected one of %r" % (_fp32_products, PRODUCT_KINDS))
 

@@ -122,6 +122,82 @@ def pack_part_split(A, KT, MT):
     return out.reshape(-1).view(np.float32)
 
 
+# ---- MODE 3 of nnr_layout.h: every weight, scaled by its slot's power of two, as two fp16 terms in three fragment classes (NNR_F_SPLIT2) ------
+def pow2_scale(mx):
+    """scale_kernel (nnr_pack.hip): the power of two s with mx s in [2^13, 2^14); 1 for an all-zero (or non-finite) tensor."""
+    mx = np.float32(mx)
+    if not (mx > 0 and mx < 3.0e38):
+        return np.float32(1.0)
+    _, e = np.frexp(mx)                      # mx = f 2^e, f in [0.5, 1)
+    return np.float32(2.0 ** int(np.clip(14 - int(e), -100, 100)))
+
+
+def scale_slot(layer):
+    return layer if layer < 8 else 8
+
+
+def split2_classes(x):
+    """(m, hs, h) of an already scaled fp32 array: h = rn16(x), m = rn16(x - h) (exact difference), hs = rn16(x 2^-11) -- the fragment classes
+    0, 1, 2 of csrc/nnr_split2.h, as float16 arrays (numpy's conversion rounds to nearest even, subnormals included)."""
+    x = np.asarray(x, dtype=np.float32)
+    h = x.astype(np.float16)
+    m = (x - h.astype(np.float32)).astype(np.float32).astype(np.float16)
+    hs = (x * np.float32(1.0 / 2048.0)).astype(np.float32).astype(np.float16)
+    return m, hs, h
+
+
+def pack_part_split2(A_scaled, KT, MT):
+    """MODE 3: the panel geometry of pack_part_split, class t (0 = m, 1 = h 2^-11, 2 = h) in slot ((b % GP) * 3 + t) * MT + mt; lane l holds
+    8 fp16 of A_scaled[32 mt + (l & 31)][16 b + 8 (i >> 2) + 4 (l >> 5) + (i & 3)], two per word (even i in the low half)."""
+    gp = SPLIT_PANEL_FRAGS // (3 * MT)
+    rows = 2 * KT
+    n_panels = (rows + gp - 1) // gp
+    out = np.zeros((n_panels, SPLIT_PANEL_FRAGS, 64, 4), dtype=np.uint32)
+    lane = np.arange(64)
+    with np.errstate(over="ignore"):
+        terms = split2_classes(A_scaled)
+    for b in range(rows):
+        for t in range(3):
+            for mt in range(MT):
+                r = 32 * mt + (lane & 31)
+                for i in range(8):
+                    v = np.ascontiguousarray(terms[t][r, 16 * b + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)])
+                    out[b // gp, ((b % gp) * 3 + t) * MT + mt, :, i // 2] |= v.view(np.uint16).astype(np.uint32) << (16 * (i & 1))
+    return out.reshape(-1).view(np.float32)
+
+
+def gemm_part_split2_emulated(packed_part, in_regs, KT, MT):
+    """What nnr_split2.h's gemm_part2 computes from a MODE 3 packed part and the fp32 input registers [16 KT][64 lanes] (unscaled activations):
+    per row of 16 k-values the three products (w_m, x_h) (w_hs, x_m') (w_h, x_h) of v_mfma_f32_32x32x16_f16, x_h = rn16(x), x_m' = rn16((x - x_h)
+    2^11), fp32 accumulation.  Returns [MT][16][64] accumulator registers (still carrying the weights' scale)."""
+    gp = SPLIT_PANEL_FRAGS // (3 * MT)
+    pan = packed_part.view(np.uint32).reshape(-1, SPLIT_PANEL_FRAGS, 64, 4)
+    lane = np.arange(64)
+    acc = np.zeros((MT, 16, 64), dtype=np.float32)
+
+    def unpack(words):       # [64][4] uint32 -> [64][8] float64
+        o = np.zeros((64, 8), dtype=np.float64)
+        for i in range(8):
+            o[:, i] = ((words[:, i // 2] >> (16 * (i & 1))) & 0xffff).astype(np.uint16).view(np.float16).astype(np.float64)
+        return o
+    for b in range(2 * KT):
+        x = in_regs[8 * b:8 * b + 8].T.astype(np.float32)                      # [64][8]
+        xh = x.astype(np.float16)
+        xm = ((x - xh.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        for wt, xs in ((0, xh), (1, xm), (2, xh)):
+            for mt in range(MT):
+                a = unpack(pan[b // gp, ((b % gp) * 3 + wt) * MT + mt])
+                A = np.zeros((32, 16), dtype=np.float64)
+                B = np.zeros((16, 32), dtype=np.float64)
+                for i in range(8):
+                    A[lane & 31, 8 * (lane >> 5) + i] = a[:, i]
+                    B[8 * (lane >> 5) + i, lane & 31] = xs[:, i].astype(np.float64)
+                Dm = A @ B
+                for rho in range(16):
+                    acc[mt, rho] = (acc[mt, rho] + Dm[(rho & 3) + 8 * (rho >> 2) + 4 * (lane >> 5), lane & 31]).astype(np.float32)
+    return acc
+
+
 def gemm_part_split_emulated(packed_part, in_regs, KT, MT):
     """What nnr_split.h's gemm_part computes from a MODE 2 packed part and the fp32 activation registers [16 KT][64 lanes]: per row of 16
     k-values the six term products (l,h) (m,m) (m,h) (h,l) (h,m) (h,h) of v_mfma_f32_32x32x16_bf16 -- lane l supplies A[l & 31][k = 8 (l >> 5)
@@ -177,7 +253,7 @@ def head_tables(weights, D):
 
 def pack_all(weights, biases, D, with_exact_mask=False, mode=0):
     """weights/biases: lists of 12 numpy arrays in state_dict order -> the packed buffer nnr_pack_weights produces (mode 0: fp32
-    fragments, mode 2: three bf16 terms per weight, NNR_F_SPLIT3).
+    fragments, mode 2: three bf16 terms per weight, NNR_F_SPLIT3; mode 3: two fp16 terms of the scaled weight in three classes, NNR_F_SPLIT2).
     with_exact_mask: also a bool array, False where the value derives from the merged matrix (compare with a tolerance)."""
     wm, bm = merged(weights, biases, D)
     w13 = list(weights) + [wm]
@@ -185,14 +261,30 @@ def pack_all(weights, biases, D, with_exact_mask=False, mode=0):
     def put(v, is_exact):
         chunks.append(v)
         exact.append(np.full(v.size, is_exact))
+    scale = np.ones(16, dtype=np.float32)
+    if mode == 3:
+        for l in range(8):
+            scale[l] = pow2_scale(np.abs(weights[l]).max())
+        scale[8] = pow2_scale(max(np.abs(wm).max(), np.abs(weights[10]).max()))
+    sc_of = lambda layer: scale[scale_slot(layer)] if mode == 3 else np.float32(1.0)
     for part in fwd_parts(D) + bwd_parts(D):
-        put((pack_part_split if mode == 2 else pack_part)(part_matrix(w13[part[0]], part), part[2], part[3]), part[0] != MERGED)
+        A = part_matrix(w13[part[0]], part)
+        if mode == 3:
+            put(pack_part_split2(A * sc_of(part[0]), part[2], part[3]), part[0] != MERGED)
+        else:
+            put((pack_part_split if mode == 2 else pack_part)(A, part[2], part[3]), part[0] != MERGED)
     for l, (b, pad) in enumerate(zip(biases, bias_pads(D))):
         v = np.zeros(pad, dtype=np.float32)
         src = bm if l == 10 else b          # the colour-hidden slot holds the merged bias
-        v[:src.size] = src
+        v[:src.size] = src * (sc_of(l) if (l < 8 or l == 10) else np.float32(1.0))      # mode 3: the accumulators start at s_w bias
         put(v, l != 10)
     put(head_tables(weights, D), True)
+    if mode == 3:      # [16] scales by slot ([9]: max |w_sigma|, not a scale), [16] inverses
+        tab = np.zeros(32, dtype=np.float32)
+        tab[:9] = scale[:9]
+        tab[9] = np.abs(weights[8]).max()
+        tab[16:25] = np.float32(1.0) / scale[:9]
+        put(tab, True)
     put(wm.reshape(-1), False)
     put(bm, False)
     put(weights[9].reshape(-1), True)       # copies for the un-merge step

@@ -68,6 +68,14 @@ def test_one_rank_on_a_real_rccl_group():
     assert line["value"] > 1e4 and line["final_loss"] == line["final_loss"]      # a finite loss after steps that all-reduced on RCCL
     print("one-rank RCCL group: %.0f rays/s, flat all-reduce of %d floats %.0f us"
           % (line["value"], line["collective"]["bucket_floats"], line["collective"]["allreduce_us"]))
+    # the distributed plumbing of a rank (process group, the in-place all-reduce of the gradient buffer issued on RCCL in
+    # every step) must not cost the step more than 3 % -- compared on the MEDIAN step of 20, which one slow step cannot move
+    args = ["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extra", "--no-cpu-baseline"]
+    plain = _run(args, {})
+    forced = _run(args, {"NNR_BENCH_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, launcher[:-1] + ["29633"])
+    a, b = plain["step_ms"]["median"], forced["step_ms"]["median"]
+    print("median step: plain %.3f ms, one rank of an RCCL group %.3f ms (%+.1f %%)" % (a, b, 100 * (b - a) / a))
+    assert b <= 1.03 * a + 0.02, (a, b)
 
 
 def test_strong_scaling_switch_and_config4_rank_shape():

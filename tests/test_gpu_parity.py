@@ -80,17 +80,18 @@ def run_hip(case, eval_=False, mfma_dtype=None):
     return out, grads
 
 
-@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("mode", [0, 2, 3])
 @pytest.mark.parametrize("D", [128, 256])
 def test_pack_kernel_is_bit_exact(D, mode):
-    """mode 0: fp32 fragments; mode 2: three bf16 terms per weight (NNR_F_SPLIT3) -- against tests/layout_ref.py, bit for bit."""
+    """mode 0: fp32 fragments; mode 2: three bf16 terms per weight (NNR_F_SPLIT3); mode 3: two fp16 terms of the scaled weight in three
+    fragment classes, the scale table, the scaled biases (NNR_F_SPLIT2) -- against tests/layout_ref.py, bit for bit."""
     from nnr import lib as L
     dev = torch.device("cuda")
     params = orc.init_params(D, 3)
     w = [params[n + ".weight"] for n in L.LAYER_NAMES]
     b = [params[n + ".bias"] for n in L.LAYER_NAMES]
     cfg = L.make_cfg(1, 1, D)
-    cfg = L.Cfg(1, 1, D, (cfg.flags & ~L.NNR_F_SPLIT3) | (L.NNR_F_SPLIT3 if mode == 2 else 0))
+    cfg = L.Cfg(1, 1, D, (cfg.flags & ~(L.NNR_F_SPLIT3 | L.NNR_F_SPLIT2)) | (L.NNR_F_SPLIT3 if mode >= 2 else 0) | (L.NNR_F_SPLIT2 if mode == 3 else 0))
     lib = L.load()
     packed = torch.empty(lib.nnr_packed_floats(C.byref(cfg)), device=dev)
     wd, bd = [x.to(dev) for x in w], [x.to(dev) for x in b]

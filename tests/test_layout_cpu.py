@@ -58,6 +58,38 @@ def test_three_term_parts_reproduce_the_fp32_products():
             assert float((np.abs(got - want) / scale).max()) <= 3e-7, (part, float((np.abs(got - want) / scale).max()))
 
 
+def test_two_term_fp16_parts_reproduce_the_fp32_products():
+    """MODE 3 (NNR_F_SPLIT2, csrc/nnr_split2.h): a part packed as the three fp16 fragment classes of the power-of-two scaled weight (m, h 2^-11,
+    h), multiplied by the emulated three-MFMA row against activations whose residual term is carried at 2^11, gives the plain matmul to fp32
+    rounding for every (KT, MT) shape the kernels use; the two terms of a value add up to it within 2^-22; tiny and large operands alike
+    (weights are scaled into fp16's range, the activations' residual stays a normal fp16 number down to 2^-14)."""
+    D = 128
+    W, _ = rand_weights(D, seed=3)
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(64).astype(np.float32) * np.float32(10.0) ** rng.integers(-4, 4, 64).astype(np.float32)
+    xh = x.astype(np.float16)
+    xm = ((x - xh.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    back = xh.astype(np.float64) + xm.astype(np.float64) / 2048.0
+    assert np.all(np.abs(back - x) <= np.maximum(np.abs(x) * 2.0 ** -21.9, 2.0 ** -36))
+    for wscale in (1.0, 1e-3, 40.0):
+        for parts, idx in ((lr.fwd_parts(D), (0, 2, 9, 19)), (lr.bwd_parts(D), (2, 3, 9, 18))):
+            for i in idx:
+                part = parts[i]
+                layer, tr, KT, MT, m_real, k_real = part[:6]
+                A = lr.part_matrix((W[layer] if layer != lr.MERGED else rng.standard_normal((D // 2, D)).astype(np.float32)) * np.float32(wscale), part)
+                sc = lr.pow2_scale(np.abs(A).max())
+                assert 2.0 ** 13 <= np.abs(A).max() * sc < 2.0 ** 14
+                X = np.zeros((32 * KT, 32), dtype=np.float32)
+                X[:k_real] = np.maximum(rng.standard_normal((k_real, 32)), 0).astype(np.float32) * np.float32(10.0) ** rng.integers(-3, 2, (k_real, 1)).astype(np.float32)
+                pk = lr.pack_part_split2(A * sc, KT, MT)
+                assert pk.size == (-(-2 * KT // (8 // MT))) * 24 * 256
+                acc = lr.gemm_part_split2_emulated(pk, lr.to_regs(X), KT, MT)
+                got = lr.from_regs(acc.reshape(-1, 64)).astype(np.float64) / float(sc)
+                want = A.astype(np.float64) @ X.astype(np.float64)
+                scale = np.abs(A).astype(np.float64) @ np.abs(X).astype(np.float64) + 1e-30
+                assert float((np.abs(got - want) / scale).max()) <= 4e-7, (part, wscale, float((np.abs(got - want) / scale).max()))
+
+
 def test_chained_layers_in_register_layout():
     """Two chained layers, each as its two half-output passes, computed with emulated MFMAs on packed fragments == plain
     matmuls; the output registers of one layer are directly the B operands of the next (no transpose)."""

@@ -311,3 +311,35 @@ def test_per_image_losses_sharded_by_source_points_equal_the_reference_golden(na
     for k, g in grads.items():
         ref_g = G[f"{name}.g.{k}"]
         assert float(np.abs(g - ref_g).max()) / max(1.0, float(np.abs(ref_g).max())) <= 1e-4, k
+
+
+def test_eight_ranks_through_the_bench_launcher_equal_one_process(tmp_path):
+    """What the driver's `bench.py --gpus 8` does that no test with two hand-spawned ranks covers: EIGHT ranks started by
+    bench.self_launch -- torch.distributed.run, --master-addr 127.0.0.1, one process per rank -- join one group, shard a step's rays eight ways
+    (BASELINE configs[3]'s decomposition: 8 shards of one step, scaled down to what eight CPU processes finish in seconds), run TWO steps and
+    all-reduce once per step; the summed gradients and the losses equal a single process's on the same 8 x R rays, and the line rank 0
+    prints carries collective.rccl_ranks_seen == 8."""
+    import json
+    import sys
+    import numpy as np
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import bench
+    import dp_dryrun_worker as worker
+    name, n_rays = "tanks_d128", 8 * 12
+    out = str(tmp_path / "dp8.npz")
+    rc, stdout = bench.self_launch(8, script=os.path.join(ROOT, "tests", "dp_dryrun_worker.py"), argv=[name, str(n_rays), out], capture=True)
+    assert rc == 0, stdout[-3000:]
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]                 # rank 0 prints, nobody else does
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["collective"]["rccl_ranks_seen"] == 8 and line["collective"]["bucket_floats"] > 150000
+    got = np.load(out)
+    ref = worker.run_steps(name, n_rays)                   # world size 1, this process: the same two steps on all 96 rays
+    for i, (losses, grads) in enumerate(ref):
+        for k, v in losses.items():
+            assert abs(float(got["s%d.loss.%s" % (i, k)]) - v) <= 2e-6 * max(1.0, abs(v)), (i, k)
+        for k, g in grads.items():
+            err = float(np.abs(got["s%d.grad.%s" % (i, k)] - g).max())
+            assert err <= 1e-5 * max(1.0, float(np.abs(g).max())), (i, k, err)
+    assert any(np.abs(got["s1.grad.%s" % k] - got["s0.grad.%s" % k]).max() > 0 for k in ("r", "t"))      # the second step drew other rays
