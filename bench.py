@@ -53,6 +53,12 @@ EXECUTED_MACS_PER_SAMPLE = {D: 64 * D + 3 * D * D + (D + 64) * D + 3 * D * D + D
 PEAK_FP32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0               # dense bf16 MFMA (not the 2:1-sparsity headline figure)
 PEAK_HBM_GBS = 8000.0                        # HBM3E
+# BASELINE configs[2]: "bf16 MFMA with fp32 accumulate, tolerance vs fp32 ref" -- the tolerance, stated.  Measured at the benchmark shape itself
+# (4096 x 128, D = 256; 256-ray subset against the fp32 oracle, tests/test_gpu_bench_shape_parity.py prints the figures into the suite log):
+# outputs to a few 1e-4 absolute, gradient tensors 5 - 15 % in relative L2 -- bf16 products flip the ReLU gates of near-zero pre-activations.
+# Against an oracle with the SAME arithmetic (every product bf16 x bf16, fp32 accumulate) the kernels are held to 1e-4 / 2.5e-2.
+BF16_TOLERANCE_VS_FP32 = {'rgb_max_abs': 5e-4, 'depth_max_abs': 2e-3, 'grad_rel_l2': 0.25,
+                          'measured_at': '4096 x 128, D = 256, 256-ray subset vs the fp32 oracle (tests/test_gpu_bench_shape_parity.py)'}
 FP32_HOW = {'mfma': 'fp32 (fp32 MFMAs)', 'split3': 'fp32 via six bf16 MFMA terms per product',
             'split2': 'fp32 via three fp16 MFMA terms per product (fwd, dgrad), six bf16 terms (wgrad)'}      # (short: the driver's record cuts strings at ~100 characters)
 FP32_NOTE = {'mfma': 'v_mfma_f32_32x32x2_f32 products in all three MLP kernels',
@@ -594,6 +600,11 @@ def _extra_config(device, name, rays, n_samples, bf16, steps, warmup, aux=False)
            'kernels_isolated_ms': {k: v['isolated_ms'] for k, v in roof['kernels'].items()}, 'fused_mlp_all_three': roof['fused_mlp_all_three']}
     if 'hbm' in roof:
         out['roofline']['hbm'] = roof['hbm']
+    if bf16:
+        out['tolerance_vs_fp32'] = BF16_TOLERANCE_VS_FP32
+    for k in ('algorithmic_tflops', 'frac_of_fp32_matrix_peak'):
+        if k in roof:
+            out['roofline'][k] = roof[k]
     if aux:     # everything of the step that is not one of the three MLP kernels: the per-image block + the small launches
         mlp = sum(out['kernels_ms'][k] for k in ('mlp_fwd', 'mlp_dgrad', 'mlp_wgrad'))
         out['outside_the_three_mlp_kernels_ms'] = round(ms - mlp, 4)

@@ -44,7 +44,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-prag
 # stores with vmcnt(0), and every reload drains the stash-store queue with the matrix pipe idle -- the TRAINING kernels may only keep a handful of
 # prologue values in scratch, reloaded at pass start (where the pass waits for its inputs anyway), nothing inside a pass; the inference forward (no stores in flight) may spill its composite carry.
 # (three-term kernels: only the D = 256 training forward keeps a few pass-start values in scratch, 32 bytes)
-SCRATCH_LIMIT = {"18mlp_fwd_f16_kernelI": 0, "20mlp_dgrad_f16_kernelI": 0, "14mlp_fwd_kernelI": 0, "14mlp_fwd_kernelILi256ELb1ELi2E": 48, "16mlp_dgrad_kernelI": 0, "12wgrad_kernelI": 0, "14wgrad_b_kernelE": 0,
+SCRATCH_LIMIT = {"18mlp_fwd_f16_kernelI": 0, "18mlp_fwd_f16_kernelILi256ELb0E": 48, "18mlp_fwd_f16_kernelILi128ELb0E": 48,      # (inference: prologue values and the composite carry, outside the MFMA streams)
+                 "20mlp_dgrad_f16_kernelI": 0, "14mlp_fwd_kernelI": 0, "14mlp_fwd_kernelILi256ELb1ELi2E": 48, "16mlp_dgrad_kernelI": 0, "12wgrad_kernelI": 0, "14wgrad_b_kernelE": 0,
                  "19mlp_fwd_bf16_kernelI": 48, "19mlp_fwd_bf16_kernelILi256ELb1E": 16, "19mlp_fwd_bf16_kernelILi128ELb1E": 16,
                  "21mlp_dgrad_bf16_kernelI": 64, "20composite_fwd_kernelE": 0, "20composite_bwd_kernelE": 0}
 

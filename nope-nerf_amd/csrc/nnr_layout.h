@@ -97,14 +97,15 @@ NNR_HD constexpr int part_panels(int KT, int MT, bool bf16 = false) { return (pa
 // l, m and h terms of the row, in that order (the order the kernels consume them in) -- and a panel is 24 fragment slots (24 KiB):
 // GP = 8 / MT whole rows.  Fragment (b, term t, mt) lives in panel b / GP, slot ((b % GP) * 3 + t) * MT + mt.
 constexpr int kSplitPanelFrags = 24;
-// MODE 3 (NNR_F_SPLIT2; the kernels: nnr_split2.h): fp32 operands as TWO fp16 terms, three fp16 MFMAs per 16 k-values.  The panel geometry is MODE 2's
-// -- three fragment classes per row and m-tile, 24-slot panels -- with other contents: class 0 = w_m = fp16(w s - w_h), class 1 = w_hs =
-// fp16(w s 2^-11) (the partner of the activations' residual term, which is carried at 2^11), class 2 = w_h = fp16(w s); s = the power of two that
-// puts the largest |w| of the weight tensor's SCALE SLOT into [2^13, 2^14) (scale_slot below; the table: Layout::scale_off).  The biases of the
-// MFMA layers are stored multiplied by s (the accumulators start there); head tables and merge area are unscaled fp32.
-NNR_HD constexpr int mode_panel_frags(int mode) { return mode >= 2 ? kSplitPanelFrags : kPanelFrags; }
+// MODE 3 (NNR_F_SPLIT2; the kernels: nnr_split2.h): fp32 operands as TWO fp16 terms, three fp16 MFMAs per 16 k-values.  A fragment row holds
+// TWO classes per m-tile -- class 0 = w_m = fp16(w s - w_h), class 1 = w_h = fp16(w s) (the third operand, w_h 2^-11 for the activations' residual
+// term that is carried at 2^11, is made from w_h in registers: an exact exponent shift) -- in 32-slot panels: GP = 16 / MT whole rows, fragment
+// (b, class c, mt) in panel b / GP, slot ((b % GP) * 2 + c) * MT + mt.  s = the power of two that puts the largest |w| of the weight tensor's
+// SCALE SLOT into [2^13, 2^14) (scale_slot below; the table: Layout::scale_off).  The biases of the MFMA layers are stored multiplied by s (the
+// accumulators start there); head tables and merge area are unscaled fp32.
+NNR_HD constexpr int mode_panel_frags(int mode) { return mode == 2 ? kSplitPanelFrags : kPanelFrags; }
 NNR_HD constexpr int mode_rows(int KT, int mode) { return mode ? 2 * KT : 4 * KT; }
-NNR_HD constexpr int mode_gp(int MT, int mode) { return mode >= 2 ? kSplitPanelFrags / (3 * MT) : kPanelFrags / MT; }
+NNR_HD constexpr int mode_gp(int MT, int mode) { return mode == 2 ? kSplitPanelFrags / (3 * MT) : (mode == 3 ? kPanelFrags / (2 * MT) : kPanelFrags / MT); }
 // scale slot of a parameter index: hidden 1..8 their own; the merged colour matrix W' (kMergedLayer) and the direction columns of the colour-hidden
 // layer (param 10) accumulate into ONE accumulator and share slot 8
 NNR_HD constexpr int scale_slot(int layer) { return layer < 8 ? layer : 8; }

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void scale_kernel(PackArgs a) {
 }
 
 // MODE (= BF16 below): Layout<D, MODE> -- 0 fp32 fragments, 1 bf16 fragments, 2 three bf16 TERMS per weight (l, m, h fragments per row),
-// 3 two fp16 terms of the SCALED weight in three fragment classes (m, h 2^-11, h)
+// 3 two fp16 terms of the SCALED weight in two fragment classes (m, h)
 template <int D, int BF16>
 __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     using L = Layout<D, BF16>;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
             if (!found) base += np;
         }
         const int gp = mode_gp(pd.MT, BF16);
-        constexpr int kTerms = BF16 >= 2 ? 3 : 1;           // fragments per row and m-tile
+        constexpr int kTerms = BF16 == 2 ? 3 : (BF16 == 3 ? 2 : 1);           // fragments per row and m-tile
         const int g = (panel - base) * gp + slot / (kTerms * pd.MT);   // fragment row: k-group (fp32) or double k-group (bf16 modes)
         const int term = (slot / pd.MT) % kTerms;          // MODE 2: 0 = l, 1 = m, 2 = h (the order the kernels consume them in)
         const int mt = slot % pd.MT;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
                 return pd.transpose ? W[(int64_t)(pd.koff + k) * pd.ld + pd.moff + m] : W[(int64_t)(pd.moff + m) * pd.ld + pd.koff + k];
             return 0.f;
         };
-        if constexpr (BF16 == 3) {   // the fragment of ONE class of the scaled weight ws = w s: 2 = h = rn16(ws), 0 = m = rn16(ws - h) (exact difference), 1 = rn16(ws 2^-11)
+        if constexpr (BF16 == 3) {   // the fragment of ONE class of the scaled weight ws = w s: 1 = h = rn16(ws), 0 = m = rn16(ws - h) (exact difference)
             typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
             const float sc = a.packed[L::scale_off + scale_slot(pd.layer)];
             f16x8 q;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
             for (int i = 0; i < 8; ++i) {
                 const float w = elem(16 * g + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * sc;
                 const _Float16 h = (_Float16)w;
-                q[i] = term == 2 ? h : (term == 0 ? (_Float16)(w - (float)h) : (_Float16)(w * (1.f / 2048.f)));
+                q[i] = term == 1 ? h : (_Float16)(w - (float)h);
             }
             reinterpret_cast<f16x8*>(a.packed)[gid] = q;
         } else if constexpr (BF16 == 2) {   // the fragment of ONE term: h = rn(w), m = rn(w - h), l = rn(w - h - m), differences exact in fp32

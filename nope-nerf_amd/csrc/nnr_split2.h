@@ -138,13 +138,25 @@ __device__ __forceinline__ void unit_dgrad(float a0, float a1, uint32_t word, fl
 }
 
 template <bool TILE>
-using Split2PipeT = PanelPipeT<kWavesPerBlock, kSplitPanelFrags, TILE>;     // the panel geometry of the six-term mode: 24 slots, three fragment classes per row
+using Split2PipeT = PanelPipeT<kWavesPerBlock, kPanelFrags, TILE>;     // 32-slot panels: two fragment classes per row and m-tile, 16 / MT rows (nnr_layout.h, MODE 3)
+
+// w_h 2^-11 from a w_h fragment (8 fp16 per lane): the weight operand of the residual term, which is carried at 2^11.  An exponent shift -- exact
+// unless the result is subnormal, i.e. for weights 2^17 below the tensor's largest -- made here, four packed multiplies per fragment, instead of
+// being streamed as a third fragment class: these kernels read one 1 KiB fragment from LDS per MFMA as it is (every fragment feeds one
+// 32-sample tile), and the stream through L2 and the LDS ring is a third shorter for it.
+__device__ __forceinline__ f32x4 frag_down11(f32x4 f) {
+    // (as ONE 8-wide multiply: written register by register -- u32x4 u = bit_cast(f); o[i] = bit_cast(bit_cast<f16x2>(u[i]) * k) -- hipcc 7.2
+    // multiplied the FIRST register and copied it into the other three; the stage-by-stage bisect showed the residual term missing)
+    const f16x8 v = __builtin_bit_cast(f16x8, f) * (_Float16)0.00048828125f;      // 2^-11
+    return __builtin_bit_cast(f32x4, v);
+}
 
 // acc[mt] += A_part[32 mt .., :] * in, the products as three fp16 terms.  `ph` / `pm`: the packed terms of the part's input (8 KT pairs of
-// registers; pairs 4 g .. 4 g + 3 belong to row g).  A row = 16 k-values = 3 MT MFMAs in the order (weights class, activation term)
-//     t0 (w_m, x_h)   t1 (w_hs, x_m')   t2 (w_h, x_h)        -- small products first
-// Fragment class c (packed by the pack kernel as slot ((row % GP) * 3 + c) * MT + mt of the panel) is used by term c only: each fragment is
-// refilled in place for the next row right after its MFMA (reads in the order of use), one counted wait per class and row.
+// registers; pairs 4 g .. 4 g + 3 belong to row g).  A row = 16 k-values = 3 MT MFMAs in the order (weights operand, activation term)
+//     t0 (w_m, x_h)   t1 (w_h 2^-11, x_m')   t2 (w_h, x_h)        -- small products first
+// Fragment class c (packed by the pack kernel as slot ((row % GP) * 2 + c) * MT + mt of the panel): 0 = w_m, used by t0; 1 = w_h, used by t2 and,
+// shifted down in registers right before it (frag_down11), by t1.  A fragment is refilled in place for the next row right after its last MFMA
+// (class 0 behind t0, class 1 behind t2: reads in the order of first use), one counted wait per class and row.
 // Side units: a unit finishes a pair of the PREVIOUS pass's accumulators and writes its packed terms.  Which row runs which units (SCHED):
 //   0  UPR units per row from row 0 on (unit u in row u / UPR): the units write ANOTHER array than the part reads (no constraint);
 //   1  "ahead": the units write the UPPER half of the part's own input (pair NSIDE + u, first read by row (NSIDE + u) / 4; NSIDE = 2 G pairs per
@@ -173,7 +185,7 @@ __device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (
 #endif
     static_assert(MT <= NACC && 8 * KT <= NIN, "tile counts exceed the register arrays");
     static_assert(MT == 1 || MT == 2 || MT == 4, "m-tiles per part");
-    constexpr int G = 2 * KT, GP = mode_gp(MT, 2), NM = 3 * MT, PW = Pipe::PW;
+    constexpr int G = 2 * KT, GP = mode_gp(MT, 3), NM = 3 * MT, PW = Pipe::PW;
     static_assert(SCHED == 0 || G >= 2, "the constrained schedules need two rows");
     static_assert(SCHED == 0 || NSIDE_ <= 4 * (G - 1), "more units than the rows before the last one can finish in time");
     auto rows_in = [](int pi) { return (G - pi * GP) < GP ? (G - pi * GP) : GP; };
@@ -198,9 +210,9 @@ __device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (
     pipe.pieces(p0 + 2, 0, ppk_of(0));
     const unsigned lane_base = lds_byte_address(pipe.lds) + 16u * pipe.lane;
     unsigned panel_addr = lane_base + pipe.buffer(p0) * (Pipe::F4 * 16);
-    f32x4 fr[3][MT];
+    f32x4 fr[2][MT];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) fr[c][mt] = frag_read(panel_addr, c * MT + mt);
 
@@ -212,13 +224,16 @@ __device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (
         for (int j = 0; j < NM; ++j) {
             const int t = j / MT, mt = j % MT;
             __builtin_amdgcn_sched_barrier(0);
-            // first MFMA of a fragment class in this row: its fragments have landed when at most the reads issued after the class's last one are
-            // outstanding -- the two other classes' refills (previous row's later classes, this row's earlier ones; none of this row's in the last row)
-            if (mt == 0) wait_class<MT>(fr[t], last ? (2 - t) * MT : 2 * MT);
+            // first use of a fragment class in this row (class 0: t0, class 1: t1): its fragments have landed when at most the reads issued after the
+            // class's last one are outstanding -- the other class's MT refills (the previous row's class 1 behind this row's class 0; this row's class 0
+            // behind the previous row's class 1 -- none in the last row)
+            if (mt == 0 && t == 0) wait_class<MT>(fr[0], MT);
+            if (mt == 0 && t == 1) wait_class<MT>(fr[1], last ? 0 : MT);
             const u32x4 b = t == 1 ? u32x4{pm[4 * g], pm[4 * g + 1], pm[4 * g + 2], pm[4 * g + 3]} : u32x4{ph[4 * g], ph[4 * g + 1], ph[4 * g + 2], ph[4 * g + 3]};
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[t][mt]), __builtin_bit_cast(f16x8, b), acc[mt], 0, 0, 0);
+            const f32x4 a = t == 0 ? fr[0][mt] : (t == 1 ? frag_down11(fr[1][mt]) : fr[1][mt]);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc[mt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (!last) {      // refill this fragment in place for the next row; a panel switch (counted wait + barrier) in front of the first read from a new panel
+            if (!last && t != 1) {      // refill this fragment in place for the next row; a panel switch (counted wait + barrier) in front of the first read from a new panel
                 const int pn = p0 + (g + 1) / GP;
                 if (j == 0 && (g + 1) % GP == 0) {
                     // Stores that may stay in flight: those certainly issued after the last DMA piece of panel pn -- pn's pieces go out while the panel
@@ -245,7 +260,7 @@ __device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (
                     }
                     panel_addr = lane_base + pipe.buffer(pn) * (Pipe::F4 * 16);
                 }
-                fr[t][mt] = frag_read(panel_addr, (((g + 1) % GP) * 3 + t) * MT + mt);
+                fr[t == 0 ? 0 : 1][mt] = frag_read(panel_addr, (((g + 1) % GP) * 2 + (t == 0 ? 0 : 1)) * MT + mt);
             }
             // the DMA pieces of the panel two ahead, spread over the rows of the current panel (one burst per row, in the row's second gap)
             if (j == 1) {

@@ -259,7 +259,15 @@ class _RenderRays(torch.autograd.Function):
             # ONE allocation for all 24 gradients (the weight-gradient stage overwrites every element: no zero-fill launch) + GRAD_TAIL spare
             # floats behind them: autograd adopts the views as the parameters' .grad, so under data parallelism the step's all-reduce runs
             # IN PLACE on this buffer, the handful of pose / distortion gradients and logged scalars riding in the tail (nnr/parallel.py)
-            flat = torch.empty(int(offs[-1]) + GRAD_TAIL, **f32)
+            # Under data parallelism the buffer is all-reduced as it lies, alignment gaps and tail included: zero-filled then (a NaN left over in a
+            # gap would be summed -- never read, but a NaN check on the collective would trip), and REGISTERED with its used length: the in-place
+            # path of nnr/parallel.py is taken for a buffer this function made, not for any storage that happens to hold many gradients.
+            from . import parallel as _par
+            if _par.world_size() > 1 or _par.always_reduce():
+                flat = torch.zeros(int(offs[-1]) + GRAD_TAIL, **f32)
+                register_flat_grads(flat, int(offs[-1]))
+            else:
+                flat = torch.empty(int(offs[-1]) + GRAD_TAIL, **f32)
             views = [flat[offs[i]: offs[i] + sizes[i]].view(ctx.shapes[i]) for i in range(2 * L.N_LAYERS)]
             gs = L.params_struct(views[:L.N_LAYERS], views[L.N_LAYERS:])
             L.check(lib.nnr_mlp_wgrad(C.byref(cfg), L.ptr(ctx.packed), C.byref(gs), L.ptr(_plan_for(cfg, dev)), L.ptr(ws), st), "nnr_mlp_wgrad")
@@ -274,6 +282,22 @@ class _RenderRays(torch.autograd.Function):
 
 
 GRAD_TAIL = 2048      # spare floats behind the flat weight-gradient buffer (see _RenderRays.backward)
+_flat_grads = {}      # storage data_ptr -> (weak reference to the flat buffer, floats used by the gradient views): buffers _RenderRays.backward made
+
+
+def register_flat_grads(flat: torch.Tensor, used: int):
+    import weakref
+    for k in [k for k, (r, _) in _flat_grads.items() if r() is None]:
+        del _flat_grads[k]
+    _flat_grads[flat.untyped_storage().data_ptr()] = (weakref.ref(flat), used)
+
+
+def flat_grads_of(storage_ptr: int):
+    """(flat buffer, used floats) if `storage_ptr` is the storage of a LIVE buffer made by _RenderRays.backward under data parallelism, else None."""
+    hit = _flat_grads.get(storage_ptr)
+    if hit is None or hit[0]() is None:
+        return None
+    return hit[0](), hit[1]
 
 
 def render_rays(pts_o: torch.Tensor, pts_d: torch.Tensor, view_d: torch.Tensor, z_lo: torch.Tensor, z_hi: torch.Tensor,

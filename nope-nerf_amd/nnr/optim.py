@@ -97,6 +97,16 @@ class MultiAdam:
         src, dst = self._steps[self._flip], self._steps[1 - self._flip]
         blocks = 0
         rebind = []
+        host_steps = []      # single-tensor arithmetic: the host-side step counters this launch advances
+        if self.arithmetic == "single":
+            # a state restored from a round-2..4 checkpoint carries fused = True in its param_groups (what _use_fused_adam stored there): should this
+            # class ever hand the step back to torch (a non-contiguous gradient), torch's FUSED path would meet the host counters below -- the
+            # groups say what the arithmetic is
+            for opt in self.optimizers:
+                for g in opt.param_groups:
+                    if g.get('fused'):
+                        g['fused'] = False
+                    g['foreach'] = False
         for i, (opt, p, gr, lr, b1, b2, eps) in enumerate(entries):
             if id(p) not in self._slot:      # a parameter keeps its counter slot for life (<= MAX_TENSORS: usable())
                 self._slot[id(p)] = self._free.pop() if self._free else len(self._slot)
@@ -116,8 +126,8 @@ class MultiAdam:
                 if not (torch.is_tensor(step) and not step.is_cuda):      # restored from / handed over by the fused flavour: one host read
                     step = torch.as_tensor(float(step), dtype=torch.float32)
                     st['step'] = step
-                step += 1
-                sv = step.item()
+                sv = float(step) + 1.0                      # (the host counter itself advances only after the launch has succeeded)
+                host_steps.append(step)
                 lr = -(lr / (1 - b1 ** sv))
                 t.bc2_sqrt[i] = (1 - b2 ** sv) ** 0.5
             else:
@@ -138,6 +148,8 @@ class MultiAdam:
         t.n_tensors = len(entries)
         t.flavour = FLAVOURS[self.arithmetic]
         L.check(L.load().nnr_adam_step(C.byref(t), L.stream()), "nnr_adam_step")
+        for step in host_steps:
+            step += 1
         for st, counter in rebind:          # only after a successful launch: torch's state keeps pointing at the CURRENT counter
             st['step'] = counter
         self._flip = 1 - self._flip

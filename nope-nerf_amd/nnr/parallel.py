@@ -136,13 +136,15 @@ def _shared_buffer(params):
             groups.setdefault(g.untyped_storage().data_ptr(), []).append(p)
     if not groups:
         return None
-    members = max(groups.values(), key=len)
-    if len(members) < 8:
-        return None
-    st = members[0].grad.untyped_storage()
-    whole = torch.empty(0, dtype=torch.float32, device=members[0].grad.device).set_(st, 0, (st.nbytes() // 4,))
-    used = max(p.grad.storage_offset() + p.grad.numel() for p in members)
-    return whole, used, members
+    from . import ops
+    for ptr, members in groups.items():      # only a buffer _RenderRays.backward registered: its tail is spare by construction, its gaps are zero
+        hit = ops.flat_grads_of(ptr)
+        if hit is None:
+            continue
+        whole, used = hit
+        if max(p.grad.storage_offset() + p.grad.numel() for p in members) <= used and whole.numel() > used:
+            return whole, used, members
+    return None
 
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], loss_dict: Optional[Dict[str, torch.Tensor]] = None):
@@ -195,8 +197,10 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], loss_dict: Optiona
         for i in missing:
             if float(flags[i]) > 0.0:
                 rest[i].grad = views[i].clone()
-    for k in keys:
-        # the autograd-free logged value ('loss' is no longer needed for backward at this point); a view of the reduced
-        # buffer, not a copy -- each copy would be one more launch per step
-        loss_dict[k] = flat[off]
-        off += 1
+    if keys:
+        # the autograd-free logged values ('loss' is no longer needed for backward at this point): ONE small copy out of the reduced buffer -- as
+        # views of it they pinned the whole gradient buffer and changed under the caller when the next step (or zero_grad(set_to_none=False))
+        # rewrote it
+        vals = flat[off:off + n_keys].clone()
+        for i, k in enumerate(keys):
+            loss_dict[k] = vals[i]

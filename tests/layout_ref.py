@@ -137,41 +137,41 @@ def scale_slot(layer):
 
 
 def split2_classes(x):
-    """(m, hs, h) of an already scaled fp32 array: h = rn16(x), m = rn16(x - h) (exact difference), hs = rn16(x 2^-11) -- the fragment classes
-    0, 1, 2 of csrc/nnr_split2.h, as float16 arrays (numpy's conversion rounds to nearest even, subnormals included)."""
+    """(m, h) of an already scaled fp32 array: h = rn16(x), m = rn16(x - h) (exact difference) -- the fragment classes 0, 1 of
+    csrc/nnr_split2.h, as float16 arrays (numpy's conversion rounds to nearest even, subnormals included)."""
     x = np.asarray(x, dtype=np.float32)
     h = x.astype(np.float16)
     m = (x - h.astype(np.float32)).astype(np.float32).astype(np.float16)
-    hs = (x * np.float32(1.0 / 2048.0)).astype(np.float32).astype(np.float16)
-    return m, hs, h
+    return m, h
 
 
 def pack_part_split2(A_scaled, KT, MT):
-    """MODE 3: the panel geometry of pack_part_split, class t (0 = m, 1 = h 2^-11, 2 = h) in slot ((b % GP) * 3 + t) * MT + mt; lane l holds
+    """MODE 3: 32-slot panels, GP = 16 // MT rows of 16 k-values each, class c (0 = m, 1 = h) in slot ((b % GP) * 2 + c) * MT + mt; lane l holds
     8 fp16 of A_scaled[32 mt + (l & 31)][16 b + 8 (i >> 2) + 4 (l >> 5) + (i & 3)], two per word (even i in the low half)."""
-    gp = SPLIT_PANEL_FRAGS // (3 * MT)
+    gp = PANEL_FRAGS // (2 * MT)
     rows = 2 * KT
     n_panels = (rows + gp - 1) // gp
-    out = np.zeros((n_panels, SPLIT_PANEL_FRAGS, 64, 4), dtype=np.uint32)
+    out = np.zeros((n_panels, PANEL_FRAGS, 64, 4), dtype=np.uint32)
     lane = np.arange(64)
     with np.errstate(over="ignore"):
         terms = split2_classes(A_scaled)
     for b in range(rows):
-        for t in range(3):
+        for t in range(2):
             for mt in range(MT):
                 r = 32 * mt + (lane & 31)
                 for i in range(8):
                     v = np.ascontiguousarray(terms[t][r, 16 * b + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)])
-                    out[b // gp, ((b % gp) * 3 + t) * MT + mt, :, i // 2] |= v.view(np.uint16).astype(np.uint32) << (16 * (i & 1))
+                    out[b // gp, ((b % gp) * 2 + t) * MT + mt, :, i // 2] |= v.view(np.uint16).astype(np.uint32) << (16 * (i & 1))
     return out.reshape(-1).view(np.float32)
 
 
 def gemm_part_split2_emulated(packed_part, in_regs, KT, MT):
     """What nnr_split2.h's gemm_part2 computes from a MODE 3 packed part and the fp32 input registers [16 KT][64 lanes] (unscaled activations):
-    per row of 16 k-values the three products (w_m, x_h) (w_hs, x_m') (w_h, x_h) of v_mfma_f32_32x32x16_f16, x_h = rn16(x), x_m' = rn16((x - x_h)
-    2^11), fp32 accumulation.  Returns [MT][16][64] accumulator registers (still carrying the weights' scale)."""
-    gp = SPLIT_PANEL_FRAGS // (3 * MT)
-    pan = packed_part.view(np.uint32).reshape(-1, SPLIT_PANEL_FRAGS, 64, 4)
+    per row of 16 k-values the three products (w_m, x_h) (w_h 2^-11, x_m') (w_h, x_h) of v_mfma_f32_32x32x16_f16, x_h = rn16(x), x_m' = rn16((x - x_h)
+    2^11), the middle weight operand made from the h fragment by an fp16 multiply, fp32 accumulation.  Returns [MT][16][64] accumulator registers
+    (still carrying the weights' scale)."""
+    gp = PANEL_FRAGS // (2 * MT)
+    pan = packed_part.view(np.uint32).reshape(-1, PANEL_FRAGS, 64, 4)
     lane = np.arange(64)
     acc = np.zeros((MT, 16, 64), dtype=np.float32)
 
@@ -184,9 +184,11 @@ def gemm_part_split2_emulated(packed_part, in_regs, KT, MT):
         x = in_regs[8 * b:8 * b + 8].T.astype(np.float32)                      # [64][8]
         xh = x.astype(np.float16)
         xm = ((x - xh.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
-        for wt, xs in ((0, xh), (1, xm), (2, xh)):
+        for wt, xs, down in ((0, xh, False), (1, xm, True), (1, xh, False)):
             for mt in range(MT):
-                a = unpack(pan[b // gp, ((b % gp) * 3 + wt) * MT + mt])
+                a = unpack(pan[b // gp, ((b % gp) * 2 + wt) * MT + mt])
+                if down:      # v_pk_mul_f16 by 2^-11: exact unless the result is subnormal
+                    a = (a.astype(np.float16) * np.float16(2.0 ** -11)).astype(np.float64)
                 A = np.zeros((32, 16), dtype=np.float64)
                 B = np.zeros((16, 32), dtype=np.float64)
                 for i in range(8):

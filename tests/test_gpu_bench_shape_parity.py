@@ -13,6 +13,8 @@ the 12 layers, compositing, both loss heads, full backward -- runs
   bf16-arithmetic oracle the 256, and the subset's gradients are isolated on the HIP side by loss heads whose gradient is zero outside
   the subset (the backward is linear in it; launch shapes, plans and kernels are the benchmark's).
 """
+import os
+import sys
 import time
 
 import numpy as np
@@ -23,6 +25,7 @@ import golden_util as gu
 import nerf_oracle as orc
 
 pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # bench.py (the stated bf16 tolerances)
 H, W = 270, 480
 FP32_SHAPE = (1024, 192, 256)      # BASELINE configs[1]
 BF16_SHAPE = (4096, 128, 256)      # BASELINE configs[2]
@@ -170,3 +173,30 @@ def test_bf16_step_at_4096x128_matches_the_bf16_oracle_on_a_256_ray_subset(capsy
     with capsys.disabled():
         print("\nbf16 4096x128 D=256 (256-ray subset) vs bf16-arithmetic oracle: worst gradient relative L2 %.2e (%s); HIP %.2f s, oracle %.2f s"
               % (worst[1], worst[0], t_hip, t_orc))
+    # ... and against the FP32 oracle on the same subset: what BASELINE configs[2] ("tolerance vs fp32 ref") asks to be STATED.  bf16 products in a ReLU
+    # network flip the gates of near-zero pre-activations, so this is a statement about the arithmetic, not about the kernels (the comparison
+    # above is); the figures are printed into the suite's log and carried by bench.py's bf16_4096x128 block (BF16_TOLERANCE_VS_FP32).
+    ref32, rgrads32 = _oracle(case, None, subset=sub, n_total=R)
+    out_err = {}
+    for k in ("rgb", "depth_pred"):
+        got = out[k].detach().cpu().reshape(R, -1)[sub]
+        out_err[k] = float((got - ref32[k].detach().reshape(len(sub), -1)).abs().max())
+    gl2, gmax = {}, {}
+    for k, r in rgrads32.items():
+        g = grads[k].detach().cpu().double()
+        r = r.double()
+        if float(r.abs().max()) == 0:
+            continue
+        gl2[k] = float((g - r).norm() / r.norm())
+        gmax[k] = float((g - r).abs().max()) / float(r.abs().max())
+        gu.parity_log("bf16 4096x128 vs FP32 oracle (256-ray subset) %s rel-L2 %.3e max-abs/|ref|max %.3e" % (k, gl2[k], gmax[k]))
+    wl2, wmx = max(gl2.items(), key=lambda kv: kv[1]), max(gmax.items(), key=lambda kv: kv[1])
+    with capsys.disabled():
+        print("bf16 4096x128 D=256 (256-ray subset) vs FP32 oracle: rgb max-abs %.2e, depth_pred max-abs %.2e; 28 gradient tensors: relative L2 median %.3f, "
+              "worst %.3f (%s); max-abs / max|ref| worst %.3f (%s)"
+              % (out_err["rgb"], out_err["depth_pred"], float(np.median(list(gl2.values()))), wl2[1], wl2[0], wmx[1], wmx[0]))
+    # the STATED tolerances of the mode (bench.py: BF16_TOLERANCE_VS_FP32): outputs 5e-4 absolute, gradients 0.25 in relative L2
+    import bench
+    tol = bench.BF16_TOLERANCE_VS_FP32
+    assert out_err["rgb"] <= tol["rgb_max_abs"] and out_err["depth_pred"] <= tol["depth_max_abs"], out_err
+    assert wl2[1] <= tol["grad_rel_l2"], wl2

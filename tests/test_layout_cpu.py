@@ -59,8 +59,8 @@ def test_three_term_parts_reproduce_the_fp32_products():
 
 
 def test_two_term_fp16_parts_reproduce_the_fp32_products():
-    """MODE 3 (NNR_F_SPLIT2, csrc/nnr_split2.h): a part packed as the three fp16 fragment classes of the power-of-two scaled weight (m, h 2^-11,
-    h), multiplied by the emulated three-MFMA row against activations whose residual term is carried at 2^11, gives the plain matmul to fp32
+    """MODE 3 (NNR_F_SPLIT2, csrc/nnr_split2.h): a part packed as the two fp16 fragment classes of the power-of-two scaled weight (m, h; the
+    third operand h 2^-11 made from h by an fp16 multiply), multiplied by the emulated three-MFMA row against activations whose residual term is carried at 2^11, gives the plain matmul to fp32
     rounding for every (KT, MT) shape the kernels use; the two terms of a value add up to it within 2^-22; tiny and large operands alike
     (weights are scaled into fp16's range, the activations' residual stays a normal fp16 number down to 2^-14)."""
     D = 128
@@ -82,7 +82,7 @@ def test_two_term_fp16_parts_reproduce_the_fp32_products():
                 X = np.zeros((32 * KT, 32), dtype=np.float32)
                 X[:k_real] = np.maximum(rng.standard_normal((k_real, 32)), 0).astype(np.float32) * np.float32(10.0) ** rng.integers(-3, 2, (k_real, 1)).astype(np.float32)
                 pk = lr.pack_part_split2(A * sc, KT, MT)
-                assert pk.size == (-(-2 * KT // (8 // MT))) * 24 * 256
+                assert pk.size == (-(-2 * KT // (16 // MT))) * 32 * 256
                 acc = lr.gemm_part_split2_emulated(pk, lr.to_regs(X), KT, MT)
                 got = lr.from_regs(acc.reshape(-1, 64)).astype(np.float64) / float(sc)
                 want = A.astype(np.float64) @ X.astype(np.float64)

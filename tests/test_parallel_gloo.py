@@ -143,7 +143,11 @@ def _inplace_worker(rank, world, port, q):
         for n in sizes:
             offs.append(o)
             o += (n + 3) // 4 * 4
-        flat = torch.full((o + 64,), float("nan"))                  # (gaps and tail hold garbage, as torch.empty leaves them)
+        # gaps and tail zero-filled and the buffer REGISTERED, as _RenderRays.backward does under data parallelism: the in-place path is taken for
+        # such a buffer only (an unregistered storage that merely holds many gradients goes through the private bucket: second half of this worker)
+        from nnr import ops
+        flat = torch.zeros(o + 64)
+        ops.register_flat_grads(flat, o)
         params = []
         for i, (n, off) in enumerate(zip(sizes, offs)):
             p = torch.nn.Parameter(torch.zeros(n))
@@ -158,6 +162,19 @@ def _inplace_worker(rank, world, port, q):
         parallel.allreduce_gradients(params + [a, b], ld)
         ok = all(p.grad.data_ptr() == ptr + 4 * off for p, off in zip(params, offs))           # reduced where they lie: no copy
         vals = [float(p.grad[0]) for p in params] + [float(p.grad.min()) for p in params]
+        # the logged scalars are copies, not views of the reduced buffer: rewriting the buffer (the next step, zero_grad(set_to_none=False)) leaves them alone
+        flat.fill_(-7.0)
+        # an UNREGISTERED shared storage (NaN in its gaps, live data behind the views): summed through the private bucket, nothing outside the views touched
+        other = torch.full((64,), float("nan"))
+        qs = []
+        for i in range(9):
+            pq = torch.nn.Parameter(torch.zeros(3))
+            other[4 * i:4 * i + 3] = float(rank + 1)
+            pq.grad = other[4 * i:4 * i + 3]
+            qs.append(pq)
+        other[40:] = 123.0
+        parallel.allreduce_gradients(qs, None)
+        ok = ok and all(float(pq.grad[0]) == 3.0 for pq in qs) and bool((other[40:] == 123.0).all()) and bool(torch.isnan(other[3]))
         q.put((rank, ok, vals, a.grad.tolist() if a.grad is not None else None, b.grad is None, float(ld['loss']), float(ld['loss_rgb'])))
     finally:
         dist.destroy_process_group()
