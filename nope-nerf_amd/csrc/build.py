@@ -126,6 +126,29 @@ def build_split_variant(name, defines):
     return out
 
 
+def build_f16_variant(name, defines):
+    """Experiment library: only the D = 256 fp16-term kernels (nnr_mlp_fwd_f16.hip x 2, nnr_mlp_dgrad_f16.hip) are recompiled with `defines`
+    (profiling / A-B switches: results of NNR_ABLATE_* builds are NOT valid), everything else comes from the main build."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.join(os.path.dirname(HERE), "nnr", "libnnr_%s.so" % name)
+    tmp = os.path.join(OUT_DIR, "variant_" + name)
+    os.makedirs(tmp, exist_ok=True)
+    mine = [(src, d) for src, d in SOURCES if "_f16" in src and any(x.endswith("_D=256") for x in d)]
+    jobs = [[hipcc] + FLAGS + ["-D" + d for d in list(defines) + list(d0)] + ["-c", os.path.join(HERE, src), "-o", os.path.join(tmp, _obj_name(src, d0))]
+            for src, d0 in mine]
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=WORKERS) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(tmp if (src, d) in mine else OUT_DIR, _obj_name(src, d)) for src, d in SOURCES]
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 def build_ws_variant(name, defines, source="nnr_mlp_fwd_ws.hip"):
     """Experiment library: only `source` is recompiled with `defines` (profiling / A-B switches: not the product)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -184,7 +207,9 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--ws-variant":         # build.py --ws-variant nobar NNR_WS_NO_BARRIER
+    if len(sys.argv) > 2 and sys.argv[1] == "--f16-variant":        # build.py --f16-variant nosync NNR_ABLATE_NO_SYNC
+        print(build_f16_variant(sys.argv[2], sys.argv[3:]))
+    elif len(sys.argv) > 2 and sys.argv[1] == "--ws-variant":         # build.py --ws-variant nobar NNR_WS_NO_BARRIER
         print(build_ws_variant(sys.argv[2], sys.argv[3:]))
     elif len(sys.argv) > 2 and sys.argv[1] == "--split-variant":    # build.py --split-variant safesync NNR_SPLIT_SAFE_SYNC
         print(build_split_variant(sys.argv[2], sys.argv[3:]))

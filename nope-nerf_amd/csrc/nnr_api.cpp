@@ -483,7 +483,7 @@ size_t nnr_workspace_floats(const nnr_cfg* cfg) {
     const size_t merged = (size_t)(cfg->hidden / 2) * cfg->hidden + cfg->hidden / 2;
     if (!w.train) return (size_t)w.total();
     const size_t slots = w.bf16 ? build_plan_bf16(cfg).jobs.size() * 4 * (size_t)kSlotBFloats : build_plan(cfg).jobs.size() * (size_t)kSlotFloats;
-    return (size_t)w.total() + slots + merged;
+    return (size_t)w.total() + slots + merged + (is_split2(cfg) ? kPlaneMaxFloats : 0);      // two-term mode: the planes' maxima behind everything else
 }
 
 int64_t nnr_ws_plane(const nnr_cfg* cfg, int pl, int32_t* pitch_out) {
@@ -570,6 +570,13 @@ int nnr_pack_weights(const nnr_cfg* cfg, const nnr_params* p, float* packed, voi
     return e == hipSuccess ? NNR_OK : hip_fail(e);
 }
 
+// NNR_F_SPLIT2 training: where the table of plane maxima sits in the workspace (behind planes, slots and the merged-layer scratch: nnr_workspace_floats)
+static float* plane_max_of(const nnr_cfg* cfg, float* ws) {
+    const WsLayout w = ws_layout(cfg);
+    const size_t merged = (size_t)(cfg->hidden / 2) * cfg->hidden + cfg->hidden / 2;
+    return ws + (size_t)w.total() + build_plan(cfg).jobs.size() * (size_t)kSlotFloats + merged;
+}
+
 // the forward MLP launch; fuse_rgb / fuse_dist != null: inference with the compositing in the kernel's epilogue (ray mode only)
 static int mlp_fwd_impl(const nnr_cfg* cfg, const float* pts_o, const float* pts_d, const float* view_d, const float* z_lo,
                         const float* z_hi, const float* jitter, const float* packed, float* ws, float* fuse_rgb, float* fuse_dist,
@@ -596,6 +603,11 @@ static int mlp_fwd_impl(const nnr_cfg* cfg, const float* pts_o, const float* pts
             a.ws_view = ws + plane(w, P_DVIEW);    // writes their gradients to the same rows
         }
         a.ws_mask = reinterpret_cast<uint32_t*>(ws + plane(w, P_MASK));
+        if (is_split2(cfg)) {      // the maxima start at zero in every training forward (the input-gradient kernel of the same step adds its planes)
+            a.plane_max = plane_max_of(cfg, ws);
+            hipError_t em = hipMemsetAsync(a.plane_max, 0, kPlaneMaxFloats * sizeof(float), (hipStream_t)stream);
+            if (em != hipSuccess) return hip_fail(em);
+        }
     }
     a.S = w.S; a.S_pad = w.S_pad; a.N = cfg->n_samples;
     a.chunks_per_ray = chunks_per_ray(cfg);
@@ -668,6 +680,7 @@ int nnr_mlp_dgrad(const nnr_cfg* cfg, const float* packed, float* ws, void* stre
     a.ws_dg = ws + plane(w, P_DG);
     a.ws_dpts = ws + plane(w, P_DPTS);
     a.ws_dview = ws + plane(w, P_DVIEW);
+    a.plane_max = is_split2(cfg) ? plane_max_of(cfg, ws) : nullptr;
     a.S = w.S; a.S_pad = w.S_pad;
     a.chunks_per_ray = chunks_per_ray(cfg);
     hipError_t e = is_bf16(cfg) ? launch_mlp_dgrad_bf16(cfg->hidden, a, (hipStream_t)stream)
@@ -730,6 +743,7 @@ int nnr_mlp_wgrad(const nnr_cfg* cfg, const float* packed, const nnr_param_grads
     a.gb[kMergedLayer] = a.gw[kMergedLayer] + (size_t)(cfg->hidden / 2) * cfg->hidden;
     a.packed = packed;
     a.D = cfg->hidden;
+    a.plane_max = is_split2(cfg) ? plane_max_of(cfg, ws) : nullptr;
     a.bf16 = weight_mode(cfg);   // 0, 2 or 3 here (>= 2: the 4 x 4 tiles with six bf16 terms): locates the merge area of the packed buffer for the un-merge step
     {
         const int D = cfg->hidden;

@@ -22,6 +22,9 @@ struct MlpFwdArgs {
     float *ws_xe16, *ws_xf16;   // bf16 training: tile-major bf16 copies of the encodings (nnr_layout.h)
     float *ws_pts, *ws_view;    // bf16 training: (S_pad,4) position / view direction of every sample for the input-gradient kernel (= P_DPTS / P_DVIEW)
     uint32_t* ws_mask;
+    // NNR_F_SPLIT2 training: [17] non-negative floats, atomically maximised as integers -- the largest |value| this launch stashed in the planes
+    // P_XH1..8 ([0..8)); the input-gradient kernel adds P_DH1..8 ([8..16)) and P_DG ([16]).  The weight-gradient kernel scales its fp16 terms by them.
+    float* plane_max;
     int64_t S, S_pad;
     int N;
     // Inference only, ray mode only: composite in the kernel's epilogue (one HBM write of 16 bytes per ray instead of 20 bytes per
@@ -42,9 +45,11 @@ struct MlpDgradArgs {
     float* ws_dg;    // (S_pad,D/2)
     float* ws_dpts;  // (S_pad,4)
     float* ws_dview; // (S_pad,4)
+    float* plane_max;   // NNR_F_SPLIT2: see MlpFwdArgs
     int64_t S, S_pad;
     int chunks_per_ray;   // as in MlpFwdArgs
 };
+constexpr int kPlaneMaxFloats = 32;      // the table's size in the workspace (17 used)
 
 struct CompositeArgs {
     const float* ws_out4;  // (S_pad,4)
@@ -82,6 +87,7 @@ struct WgradArgs {
     const int32_t* wave_first; // wave w runs jobs [wave_first[w], wave_first[w+1])
     const int32_t* heads;      // job index of split 0 of every tile (the reduction kernel's workgroups)
     int n_jobs, n_waves, n_heads;
+    const float* plane_max;    // NNR_F_SPLIT2 (bf16 == 3): the planes' largest magnitudes (MlpFwdArgs::plane_max), for the fp16-term tiles' scales
     int bias_rows[13];         // elements of gb[l]: the main kernel zeroes them (the reduction adds up to two shares per row)
 };
 

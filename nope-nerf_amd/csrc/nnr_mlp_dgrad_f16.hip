@@ -21,12 +21,12 @@ static_assert(kTileActPlanes && kTileGradPlanes, "the planes of a three-term / t
 // Compile-time description of one encoding feature and the chain rule through gamma_L: as in nnr_mlp_dgrad.hip (tile-major planes only)
 namespace f16dg {
 // unit_dgrad for the pair of registers (r, r + 1), r even: their gates sit at bits 31 - (r & 31) and 30 - (r & 31) of the word (gate_append2's order); rr folds after unrolling
-__device__ __forceinline__ void sel_unit(float a0, float a1, uint32_t word, float invw, float sinv, float& t0, float& t1, uint32_t& h, uint32_t& m, int rr) {
+__device__ __forceinline__ void sel_unit(float a0, float a1, uint32_t word, float invw, float sinv, float& t0, float& t1, uint32_t& h, uint32_t& m, int rr, float& mx) {
     switch (rr) {
-#define NNR_SU(R) case R: unit_dgrad<31 - (R), 30 - (R)>(a0, a1, word, invw, sinv, t0, t1, h, m); break;
+#define NNR_SU(R) case R: unit_dgrad<31 - (R), 30 - (R)>(a0, a1, word, invw, sinv, t0, t1, h, m, mx); break;
         NNR_SU(0) NNR_SU(2) NNR_SU(4) NNR_SU(6) NNR_SU(8) NNR_SU(10) NNR_SU(12) NNR_SU(14) NNR_SU(16) NNR_SU(18) NNR_SU(20) NNR_SU(22) NNR_SU(24) NNR_SU(26) NNR_SU(28)
 #undef NNR_SU
-        default: unit_dgrad<1, 0>(a0, a1, word, invw, sinv, t0, t1, h, m); break;
+        default: unit_dgrad<1, 0>(a0, a1, word, invw, sinv, t0, t1, h, m, mx); break;
     }
 }
 struct EncMeta { int coord; float scale; int partner; };
@@ -90,7 +90,9 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
     __shared__ __attribute__((aligned(16))) f32x4 smem[kRingF4 + kPark + (kTab + 3) / 4];
     float* const ltab = reinterpret_cast<float*>(smem + kRingF4 + kPark);
     for (int i = threadIdx.x; i < kTab; i += 256) ltab[i] = a.packed[L::head_base + i];
-    __syncthreads();   // before any DMA is in flight: the only full barrier of the kernel
+    __shared__ uint32_t wg_max[9];      // the workgroup's largest |gradient| per plane P_DH1..8 ([0..8)) and P_DG ([8]), as integers
+    if (threadIdx.x < 9) wg_max[threadIdx.x] = 0;
+    __syncthreads();   // before any DMA is in flight: the only full barrier in front of the passes
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     Pipe pipe{reinterpret_cast<const f32x4*>(a.packed + L::bwd_base) + wave_u * (Pipe::PW * 64), smem, wave_u, lane0, L::bwd_panels};
     const int n_pass = a.chunks_per_ray > 0 ? a.chunks_per_ray : 1;
@@ -124,6 +126,12 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
     f32x16 accA[HT], accB[HT];           // halves A ([0,D/2)) and B ([D/2,D)) of the gradient being computed
     uint32_t mwA[HW], mwB[HW];           // ReLU sign bits of the layer whose gradient sits in accA / accB
     f32x2 keep = {0.f, 0.f};
+    float mxd = 0.f;                     // running maximum of the |true gradients| the units stash into the current plane
+    auto flush_max = [&](int plane) __attribute__((always_inline)) {      // a plane is complete: its maximum to the workgroup's table
+        const float m = wave_max_f32(mxd);
+        if (lane == 0) atomicMax(&wg_max[plane], __float_as_uint(m));
+        mxd = 0.f;
+    };
     auto load_mask = [&](uint32_t(&mw)[HW], int layer_idx, int hb) __attribute__((always_inline)) {
         const uint32_t* m = mask_base + (int64_t)layer_idx * 64 * L::mask_words + hb * HW;
 #pragma unroll
@@ -156,6 +164,8 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
         for (int q = 0; q < HR / 4; ++q) tile_store(dgp, lane_off, q, f32x4{dg[4 * q], dg[4 * q + 1], dg[4 * q + 2], dg[4 * q + 3]});
         // the sample's scale: the largest magnitude that enters its chain -- its d g (both half-waves) and the density head's rank-1 term --
         // to [2^7, 2^8); a power of two from the exponent field, clamped to 2^+-100; 1 for an all-zero sample
+        mxd = mx;
+        flush_max(8);                                 // P_DG (every sample's largest |d g|, unscaled)
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         mx = fmaxf(mx, fabsf(dout[3]) * lscale[9]);
         const int eb = (int)((__float_as_uint(mx) >> 23) & 255u);
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
     [&](int u) __attribute__((always_inline)) {                                                                  \
         const int r = 2 * u;                                                                                     \
         float t0, t1;                                                                                            \
-        f16dg::sel_unit(ACC[r >> 4][r & 15], ACC[(r + 1) >> 4][(r + 1) & 15], MW[r >> 5], INV, sInv, t0, t1, ph[(OFFP) + u], pm[(OFFP) + u], r & 31); \
+        f16dg::sel_unit(ACC[r >> 4][r & 15], ACC[(r + 1) >> 4][(r + 1) & 15], MW[r >> 5], INV, sInv, t0, t1, ph[(OFFP) + u], pm[(OFFP) + u], r & 31, mxd); \
         if (u & 1) tile_store(PLANE, lane_off, (BLK0) + (u >> 1), f32x4{keep[0], keep[1], t0, t1});              \
         else keep = f32x2{t0, t1};                                                                               \
     }
@@ -232,6 +242,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
             const char* const pl = dh(k);
             gemm_part2<DT, HT, NP, 1, 0, 2, kPreB>(accA, ph, pm, pipe, pa, NNR_SELECT(accB, NP, mwB, inv, pl, HR / 4), pre);
         }
+        flush_max(k);      // the gradient of hidden k + 1 (plane P_DH1 + k) is complete
         load_mask(mwB, k - 1, 1);
         zero_acc(accB);
         {   // pass B: half A of the new gradient replaces pairs [0, NP) in place, one row behind the reads
@@ -253,6 +264,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
             const char* const pl = dh(4);
             gemm_part2<DT, 2, NP, 1, 0, 2, kPreB>(acce, ph, pm, pipe, p0(B_L5E), NNR_SELECT(accB, NP, mwB, inv, pl, HR / 4));
         }
+        flush_max(4);
         load_mask(mwB, 3, 1);
         zero_acc(accA);
         auto park = [&](int q) __attribute__((always_inline)) {
@@ -284,6 +296,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
             const char* const pl = dh(0);
             gemm_part2<DT, 2, NP, 1, 0, 2, kPreB>(acc2, ph, pm, pipe, p0(B_L1), NNR_SELECT(accB, NP, mwB, inv, pl, HR / 4));
         }
+        flush_max(0);
         const float c1 = inv_scale(0) * sInv, c4 = inv_scale(4) * sInv;      // out of the accumulators' units: weights of slot 0 / slot 4, the sample's scale
         float de[32];
 #pragma unroll
@@ -298,6 +311,8 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
 #undef NNR_SELECT
     pipe.next_pass(pass + 2 < n_pass);
     }   // pass
+    __syncthreads();      // the workgroup's maxima to the launch's table (the weight-gradient kernel's scales): P_DH1..8 at [8, 16), P_DG at [16]
+    if (a.plane_max != nullptr && threadIdx.x < 9) atomicMax(reinterpret_cast<uint32_t*>(a.plane_max) + 8 + threadIdx.x, wg_max[threadIdx.x]);
 }
 
 // one D per translation unit (csrc/build.py: -DNNR_DGRAD_D=..), as for nnr_mlp_dgrad.hip

@@ -33,7 +33,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
     __shared__ __attribute__((aligned(16))) f32x4 smem[kRingF4 + kPark + (L::table_floats + 3) / 4];
     float* const ltab = reinterpret_cast<float*>(smem + kRingF4 + kPark);
     for (int i = threadIdx.x; i < L::table_floats; i += 256) ltab[i] = a.packed[L::bias_base + i];
-    __syncthreads();   // before any DMA is in flight: the only full barrier of the kernel
+    __shared__ uint32_t wg_max[8];      // training: the workgroup's largest stashed value per activation plane P_XH1..8 (as integers: the values are >= 0)
+    if (TRAIN && threadIdx.x < 8) wg_max[threadIdx.x] = 0;
+    __syncthreads();   // before any DMA is in flight: the only full barrier in front of the passes
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     Pipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave_u * (Pipe::PW * 64), smem, wave_u, lane0, L::fwd_panels};
     const int n_pass = a.chunks_per_ray > 0 ? a.chunks_per_ray : 1;
@@ -120,6 +122,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
     f32x16 accA[HT], accB[HT];           // halves A ([0,D/2)) and B ([D/2,D)) of the layer being computed
     uint32_t mwA[HW], mwB[HW];
     f32x2 keep = {0.f, 0.f};             // the first pair of an octet between its unit and the next one's store
+    float mx = 0.f;                      // training: running maximum of what the units stash into the current plane
+    // a plane is complete (half A in the pass B of its layer, half B in the pass A of the next): its maximum to the workgroup's table
+    auto flush_max = [&](int plane) __attribute__((always_inline)) {
+        if constexpr (TRAIN) {
+            const float m = wave_max_f32(mx);
+            if (lane == 0) atomicMax(&wg_max[plane], __float_as_uint(m));
+            mx = 0.f;
+        }
+    };
     float sg0 = 0.f, sg1 = 0.f;          // density head: this lane's share of w_sigma . h8
 
     auto init_acc = [&](f32x16(&acc)[HT], int bias_offset) __attribute__((always_inline)) {      // the pack kernel stored s_w bias
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
         const int r = 2 * u;                                                                                     \
         float x0, x1;                                                                                            \
         if constexpr (TRAIN) {      /* (x > 0) == (relu(x) != 0): two gate bits appended to the half's mask word (nnr_split2.h) */ \
-            unit_fwd_train(ACC[r >> 4][r & 15], ACC[(r + 1) >> 4][(r + 1) & 15], INV, MW[r >> 5], x0, x1, ph[(OFFP) + u], pm[(OFFP) + u]); \
+            unit_fwd_train(ACC[r >> 4][r & 15], ACC[(r + 1) >> 4][(r + 1) & 15], INV, MW[r >> 5], x0, x1, ph[(OFFP) + u], pm[(OFFP) + u], mx); \
             if (u & 1) tile_store(PLANE, lane_off, (BLK0) + (u >> 1), f32x4{keep[0], keep[1], x0, x1});          \
             else keep = f32x2{x0, x1};                                                                           \
         } else {                                                                                                 \
@@ -202,6 +213,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
             gemm_part2<DT, HT, NP, 1, 0, SE, kPreB>(accA, ph, pm, pipe, pa, NNR_FINISH(accB, NP, mwB, inv, pl, HR / 4, false), pre);
         }
         store_mask(mwB, li - 1, 1);
+        flush_max(li - 1);
         init_acc(accB, L::bias_off(li) + L::Dh);
         clear_mask(mwA);
         {   // pass B: half A of the new layer replaces pairs [0, NP) in place, one row behind the reads
@@ -223,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
         gemm_part2<DT, HT, NP, 1, 0, SE, kPreB>(accA, ph, pm, pipe, p0(F_L5HA), NNR_FINISH(accB, NP, mwB, inv, pl, HR / 4, false));
     }
     store_mask(mwB, 3, 1);
+    flush_max(3);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const u32x4 vh = __builtin_bit_cast(u32x4, park[q * 64]), vm = __builtin_bit_cast(u32x4, park[(4 + q) * 64]);
@@ -254,6 +267,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
         gemm_part2<DT, HT, NP, 1, 0, SE, kPreB>(accA, ph, pm, pipe, p0(F_RGBH_F), NNR_FINISH(accB, NP, mwB, inv, pl, HR / 4, true));
     }
     store_mask(mwB, 7, 1);
+    flush_max(7);
     const float sg = sg0 + sg1;
     const float sigma_raw = sg + __shfl_xor(sg, 32, 64) + bias[L::bias_off(8)];
     {
@@ -339,6 +353,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
 #undef NNR_FINISH
     pipe.next_pass(pass + 2 < n_pass);
     }   // pass
+    if constexpr (TRAIN) {      // the workgroup's maxima to the launch's table (NNR_F_SPLIT2: the weight-gradient kernel's scales)
+        __syncthreads();
+        if (a.plane_max != nullptr && threadIdx.x < 8) atomicMax(reinterpret_cast<uint32_t*>(a.plane_max) + threadIdx.x, wg_max[threadIdx.x]);
+    }
 }
 
 // One (D, TRAIN) instantiation per translation unit (csrc/build.py: -DNNR_FWD_D=.. -DNNR_FWD_TRAIN=..), as for nnr_mlp_fwd.hip

@@ -68,27 +68,29 @@ __device__ __forceinline__ void gate_append2(uint32_t& word, float x0, float x1)
 // MFMA that wrote it (the accumulators of the OTHER half-pass; a part's first unit sits behind its panel switch, 12 fragment reads and
 // 3 MFMAs); a VOP3P result (v_fma_mix_f32) is read one instruction later at the earliest.
 // forward, training: pair of accumulators -> x = relu(acc / s_w) (returned: stash, density head), two gate bits appended, packed terms
-__device__ __forceinline__ void unit_fwd_train(float a0, float a1, float inv, uint32_t& word, float& x0, float& x1, uint32_t& h, uint32_t& m) {
+// (mx: running maximum of the values stashed into the current activation plane: the weight-gradient kernel scales its fp16 terms by the plane's largest)
+__device__ __forceinline__ void unit_fwd_train(float a0, float a1, float inv, uint32_t& word, float& x0, float& x1, uint32_t& h, uint32_t& m, float& mx) {
     float c0, c1;
     uint32_t t;
     asm volatile(
-        "v_accvgpr_read_b32 %0, %8\n\t"
-        "v_accvgpr_read_b32 %1, %9\n\t"
-        "v_mul_f32_e64 %0, %0, %10\n\t"
-        "v_mul_f32_e64 %1, %1, %10\n\t"
+        "v_accvgpr_read_b32 %0, %9\n\t"
+        "v_accvgpr_read_b32 %1, %10\n\t"
+        "v_mul_f32_e64 %0, %0, %11\n\t"
+        "v_mul_f32_e64 %1, %1, %11\n\t"
         "v_max_f32_e32 %0, 0, %0\n\t"
         "v_max_f32_e32 %1, 0, %1\n\t"
         "v_cvt_pk_f16_f32 %2, %0, %1\n\t"
-        "v_mul_f32_e64 %4, %0, %11\n\t"
-        "v_mul_f32_e64 %5, %1, %11\n\t"
+        "v_mul_f32_e64 %4, %0, %12\n\t"
+        "v_mul_f32_e64 %5, %1, %12\n\t"
         "v_min_u32_e32 %6, 1, %0\n\t"
         "v_lshl_or_b32 %7, %7, 1, %6\n\t"
-        "v_fma_mix_f32 %4, %2, %12, %4 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %5, %2, %12, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %4, %2, %13, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %5, %2, %13, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
         "v_min_u32_e32 %6, 1, %1\n\t"
         "v_lshl_or_b32 %7, %7, 1, %6\n\t"
+        "v_max3_f32 %8, %0, %1, %8\n\t"
         "v_cvt_pk_f16_f32 %3, %4, %5"
-        : "=&v"(x0), "=&v"(x1), "=&v"(h), "=&v"(m), "=&v"(c0), "=&v"(c1), "=&v"(t), "+v"(word)
+        : "=&v"(x0), "=&v"(x1), "=&v"(h), "=&v"(m), "=&v"(c0), "=&v"(c1), "=&v"(t), "+v"(word), "+v"(mx)
         : "a"(a0), "a"(a1), "s"(inv), "s"(kResidualUp), "s"(-kResidualUp));
 }
 // forward, inference: no gates (an s_nop between the second mixed FMA and the conversion that reads it)
@@ -112,28 +114,37 @@ __device__ __forceinline__ void unit_fwd_infer(float a0, float a1, float inv, fl
         : "a"(a0), "a"(a1), "s"(inv), "s"(kResidualUp), "s"(-kResidualUp));
 }
 // input gradient: pair of accumulators -> relu'(.) ? acc : 0 (gates of registers r, r + 1 at bits POS0, POS1 of `word`: gate_append2's order)
-// -> x = . / s_w (the scaled gradient) -> packed terms; t = x / s (the true gradient, for the plane)
+// -> x = . / s_w (the scaled gradient) -> packed terms; t = x / s (the true gradient, for the plane); mx: running maximum of |t| (the plane's scale
+// in the weight-gradient kernel)
+
+// the largest value of a wave, in every lane (non-negative floats): five cross-lane steps + the half-wave swap
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
 template <int POS0, int POS1>
-__device__ __forceinline__ void unit_dgrad(float a0, float a1, uint32_t word, float invw, float sinv, float& t0, float& t1, uint32_t& h, uint32_t& m) {
+__device__ __forceinline__ void unit_dgrad(float a0, float a1, uint32_t word, float invw, float sinv, float& t0, float& t1, uint32_t& h, uint32_t& m, float& mx) {
     float x0, x1, c0, c1;
     asm volatile(
-        "v_accvgpr_read_b32 %4, %8\n\t"
-        "v_accvgpr_read_b32 %5, %9\n\t"
-        "v_bfe_i32 %6, %10, %15, 1\n\t"
-        "v_bfe_i32 %7, %10, %16, 1\n\t"
+        "v_accvgpr_read_b32 %4, %9\n\t"
+        "v_accvgpr_read_b32 %5, %10\n\t"
+        "v_bfe_i32 %6, %11, %16, 1\n\t"
+        "v_bfe_i32 %7, %11, %17, 1\n\t"
         "v_and_b32_e32 %4, %4, %6\n\t"
         "v_and_b32_e32 %5, %5, %7\n\t"
-        "v_mul_f32_e64 %4, %4, %11\n\t"
-        "v_mul_f32_e64 %5, %5, %11\n\t"
+        "v_mul_f32_e64 %4, %4, %12\n\t"
+        "v_mul_f32_e64 %5, %5, %12\n\t"
         "v_cvt_pk_f16_f32 %2, %4, %5\n\t"
-        "v_mul_f32_e64 %6, %4, %12\n\t"
-        "v_mul_f32_e64 %7, %5, %12\n\t"
-        "v_mul_f32_e32 %0, %4, %14\n\t"
-        "v_fma_mix_f32 %6, %2, %13, %6 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %7, %2, %13, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_mul_f32_e32 %1, %5, %14\n\t"
-        "v_cvt_pk_f16_f32 %3, %6, %7"
-        : "=&v"(t0), "=&v"(t1), "=&v"(h), "=&v"(m), "=&v"(x0), "=&v"(x1), "=&v"(c0), "=&v"(c1)
+        "v_mul_f32_e64 %6, %4, %13\n\t"
+        "v_mul_f32_e64 %7, %5, %13\n\t"
+        "v_mul_f32_e32 %0, %4, %15\n\t"
+        "v_fma_mix_f32 %6, %2, %14, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %7, %2, %14, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_mul_f32_e32 %1, %5, %15\n\t"
+        "v_cvt_pk_f16_f32 %3, %6, %7\n\t"
+        "v_max3_f32 %8, |%0|, |%1|, %8"
+        : "=&v"(t0), "=&v"(t1), "=&v"(h), "=&v"(m), "=&v"(x0), "=&v"(x1), "=&v"(c0), "=&v"(c1), "+v"(mx)
         : "a"(a0), "a"(a1), "v"(word), "s"(invw), "s"(kResidualUp), "s"(-kResidualUp), "v"(sinv), "n"(POS0), "n"(POS1));
 }
 
@@ -155,8 +166,8 @@ __device__ __forceinline__ f32x4 frag_down11(f32x4 f) {
 // registers; pairs 4 g .. 4 g + 3 belong to row g).  A row = 16 k-values = 3 MT MFMAs in the order (weights operand, activation term)
 //     t0 (w_m, x_h)   t1 (w_h 2^-11, x_m')   t2 (w_h, x_h)        -- small products first
 // Fragment class c (packed by the pack kernel as slot ((row % GP) * 2 + c) * MT + mt of the panel): 0 = w_m, used by t0; 1 = w_h, used by t2 and,
-// shifted down in registers right before it (frag_down11), by t1.  A fragment is refilled in place for the next row right after its last MFMA
-// (class 0 behind t0, class 1 behind t2: reads in the order of first use), one counted wait per class and row.
+// shifted down in registers right before it (frag_down11), by t1.  Both classes of the NEXT row are requested behind this row's t0 MFMAs (class 0
+// in place, class 1 into the second of two register sets), one wait at the head of a row.
 // Side units: a unit finishes a pair of the PREVIOUS pass's accumulators and writes its packed terms.  Which row runs which units (SCHED):
 //   0  UPR units per row from row 0 on (unit u in row u / UPR): the units write ANOTHER array than the part reads (no constraint);
 //   1  "ahead": the units write the UPPER half of the part's own input (pair NSIDE + u, first read by row (NSIDE + u) / 4; NSIDE = 2 G pairs per
@@ -210,11 +221,14 @@ __device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (
     pipe.pieces(p0 + 2, 0, ppk_of(0));
     const unsigned lane_base = lds_byte_address(pipe.lds) + 16u * pipe.lane;
     unsigned panel_addr = lane_base + pipe.buffer(p0) * (Pipe::F4 * 16);
-    f32x4 fr[2][MT];
+    // fragments: class 0 (w_m) refilled in place behind its MFMA; class 1 (w_h) in TWO sets alternating by row -- it is used by two of a row's three
+    // terms, so a refill in place would be requested only MT MFMAs before its first use in the next row (measured: a quarter of the wave cycles parked
+    // in s_waitcnt); with the second set the next row's class-1 fragments are requested a whole row ahead, and ONE wait at the head of a row covers both classes
+    f32x4 fr0[MT], fr1[2][MT];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int mt = 0; mt < MT; ++mt) fr0[mt] = frag_read(panel_addr, mt);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) fr[c][mt] = frag_read(panel_addr, c * MT + mt);
+    for (int mt = 0; mt < MT; ++mt) fr1[0][mt] = frag_read(panel_addr, MT + mt);
 
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -224,16 +238,19 @@ __device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (
         for (int j = 0; j < NM; ++j) {
             const int t = j / MT, mt = j % MT;
             __builtin_amdgcn_sched_barrier(0);
-            // first use of a fragment class in this row (class 0: t0, class 1: t1): its fragments have landed when at most the reads issued after the
-            // class's last one are outstanding -- the other class's MT refills (the previous row's class 1 behind this row's class 0; this row's class 0
-            // behind the previous row's class 1 -- none in the last row)
-            if (mt == 0 && t == 0) wait_class<MT>(fr[0], MT);
-            if (mt == 0 && t == 1) wait_class<MT>(fr[1], last ? 0 : MT);
+            // head of the row: every read issued so far is a row old (or the prologue's): all of this row's fragments have landed
+            if (j == 0) {
+                if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr0[0]), "+v"(fr1[g & 1][0]));
+                else if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr0[0]), "+v"(fr0[1]), "+v"(fr1[g & 1][0]), "+v"(fr1[g & 1][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr0[0]), "+v"(fr0[1]), "+v"(fr0[2]), "+v"(fr0[3]), "+v"(fr1[g & 1][0]), "+v"(fr1[g & 1][1]),
+                                  "+v"(fr1[g & 1][2]), "+v"(fr1[g & 1][3]));
+            }
             const u32x4 b = t == 1 ? u32x4{pm[4 * g], pm[4 * g + 1], pm[4 * g + 2], pm[4 * g + 3]} : u32x4{ph[4 * g], ph[4 * g + 1], ph[4 * g + 2], ph[4 * g + 3]};
-            const f32x4 a = t == 0 ? fr[0][mt] : (t == 1 ? frag_down11(fr[1][mt]) : fr[1][mt]);
+            const f32x4 a = t == 0 ? fr0[mt] : (t == 1 ? frag_down11(fr1[g & 1][mt]) : fr1[g & 1][mt]);
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc[mt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (!last && t != 1) {      // refill this fragment in place for the next row; a panel switch (counted wait + barrier) in front of the first read from a new panel
+            if (!last && t == 0) {      // behind a t0 MFMA: refill its class-0 fragment in place and request the next row's class-1 fragment into the other set;
+                                        // a panel switch (counted wait + barrier) in front of the first read from a new panel
                 const int pn = p0 + (g + 1) / GP;
                 if (j == 0 && (g + 1) % GP == 0) {
                     // Stores that may stay in flight: those certainly issued after the last DMA piece of panel pn -- pn's pieces go out while the panel
@@ -242,8 +259,8 @@ __device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (
                     constexpr int kLastBurstRow = (PW + ppk_full - 1) / ppk_full - 2;
                     int extra = 0;
                     for (int r = g - (GP - 1) - (GP - 1 - kLastBurstRow); r < g; ++r) extra += stores_of_row(r);
-                    if ((g + 1) / GP < 2) {      // the part's second panel: its pieces went out while the part's FIRST panel was consumed (all of them after
-                        extra = 0;               // entering it), so only this panel's earlier rows count -- and those are rows of this part
+                    if ((g + 1) / GP < 2) {      // the part's second panel: its pieces went out before this part began: only this panel's earlier rows are counted
+                        extra = 0;
                         for (int r = g - (GP - 1); r < g; ++r) extra += stores_of_row(r);
                     }
 #ifdef NNR_SPLIT_SAFE_SYNC
@@ -260,21 +277,43 @@ __device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (
                     }
                     panel_addr = lane_base + pipe.buffer(pn) * (Pipe::F4 * 16);
                 }
-                fr[t == 0 ? 0 : 1][mt] = frag_read(panel_addr, (((g + 1) % GP) * 2 + (t == 0 ? 0 : 1)) * MT + mt);
+                fr0[mt] = frag_read(panel_addr, (((g + 1) % GP) * 2) * MT + mt);
+                fr1[(g + 1) & 1][mt] = frag_read(panel_addr, (((g + 1) % GP) * 2 + 1) * MT + mt);
             }
-            // the DMA pieces of the panel two ahead, spread over the rows of the current panel (one burst per row, in the row's second gap)
-            if (j == 1) {
+            // the DMA pieces of the panel two ahead, spread over the rows of the current panel: the row's share ONE piece per gap from gap kDmaGap on
+            // (a piece costs the issuing wave 60 - 180 cycles of issue, more next to LDS reads: MI355X_MICROARCH.md; the fragment reads sit in the gaps
+            // of the t0 phase)
+#ifndef NNR_F16_DMA_GAP
+#define NNR_F16_DMA_GAP 1
+#endif
+#ifndef NNR_F16_DMA_STEP
+#define NNR_F16_DMA_STEP 0      /* 0: the row's pieces as one burst in gap NNR_F16_DMA_GAP; s > 0: piece i in gap NNR_F16_DMA_GAP + s i */
+#endif
+#ifndef NNR_F16_UNIT_GAP
+#define NNR_F16_UNIT_GAP 2      /* first gap the side units may use */
+#endif
+            {
                 const int pi = g / GP, gi = g % GP;
-                if (gi == rows_in(pi) - 1) {
-                    if (!last) pipe.pieces(p0 + pi + 3, 0, ppk_of(pi + 1));      // this row entered panel pi + 1 above
-                } else {
-                    pipe.pieces(p0 + pi + 2, (gi + 1) * ppk_of(pi), ppk_of(pi));
+                const bool into_next = gi == rows_in(pi) - 1;      // this row entered panel pi + 1 above: first share of the panel three ahead
+                const int pnl = into_next ? p0 + pi + 3 : p0 + pi + 2, n = into_next ? ppk_of(pi + 1) : ppk_of(pi), first = into_next ? 0 : (gi + 1) * ppk_of(pi);
+                const int g0 = NNR_F16_DMA_GAP < NM ? NNR_F16_DMA_GAP : NM - 1;
+                if (!(into_next && last)) {
+                    if (NNR_F16_DMA_STEP == 0) {
+                        if (j == g0) pipe.pieces(pnl, first, n);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < n; ++i) {
+                            const int gp_ = g0 + NNR_F16_DMA_STEP * i < NM ? g0 + NNR_F16_DMA_STEP * i : NM - 1;
+                            if (j == gp_) pipe.pieces(pnl, first + i, 1);
+                        }
+                    }
                 }
             }
             if constexpr (NSIDE > 0) {
 #pragma unroll
-                for (int k = 0; k < nu; ++k) {      // unit k of the row's nu: spread over the gaps behind the DMA burst
-                    const int gap = NM >= 4 ? 2 + (k * (NM - 2)) / nu : (k * NM) / nu;
+                for (int k = 0; k < nu; ++k) {      // unit k of the row's nu: spread over the gaps from NNR_F16_UNIT_GAP on
+                    constexpr int U0 = NNR_F16_UNIT_GAP < NM ? NNR_F16_UNIT_GAP : 0;
+                    const int gap = NM >= 4 ? U0 + (k * (NM - U0)) / nu : (k * NM) / nu;
                     if (gap == j) side(u0 + k);
                 }
             }

@@ -596,6 +596,204 @@ __device__ __forceinline__ void wgrad_group_split(const WgradJob& jb, const Wgra
     }
 }
 
+// ---- the same workgroup job with every product as THREE fp16 MFMA terms of two-term operands (NNR_F_SPLIT2, round 6) -------------------------
+// d W = sum over ALL samples of Dlt x X: what matters for a term's precision is its absolute error against the SUM, so ONE power-of-two scale per
+// operand plane does (the plane's largest magnitude -- tracked by the kernels that wrote the plane, WgradArgs::plane_max -- to [2^13, 2^14)): a value
+// v s has the terms h = fp16(v s), m = fp16(v s - h) (exact difference; no residual scaling here: an m below fp16's normal range belongs to a value
+// 2^17 below the plane's largest, whose whole contribution is below the sum's fp32 rounding), the products h h + h m + m h, 2^-22 relative each.
+// Against wgrad_group_split: 48 MFMAs per step and wave instead of 96, two exchanged terms per value instead of three (128 KiB of LDS instead
+// of 160), a two-stage split (convert, one packed subtract of the converted value, convert).  Staging, exchange protocol, barrier, DMA distance,
+// d(bias) (from the unscaled fp32 values) and the slot format are wgrad_group_split's; the tile leaves the accumulators times 1 / (s_d s_x).
+constexpr int kCoop2RegionF4 = 4 * 2 * 64;               // f32x4 per exchange region: [sub-tile 4][term 2][lane 64]
+constexpr int kCoop2F4 = kCoopXchF4 + 2 * 4 * kCoop2RegionF4;
+
+// the power of two that puts a plane's largest magnitude (bits of a non-negative float) into [2^13, 2^14); 1 for an empty plane
+__device__ __forceinline__ float plane_scale(float mx) {
+    const int eb = (int)((__float_as_uint(mx) >> 23) & 255u);
+    int es = 267 - eb;
+    es = es > 227 ? 227 : (es < 27 ? 27 : es);
+    return mx > 0.f ? __uint_as_float((uint32_t)es << 23) : 1.f;
+}
+
+template <bool DTILE, bool XTILE>
+__device__ __forceinline__ void wgrad_group_split2(const WgradJob& jb, const WgradArgs& a, int lane, int ji, f32x4* lds_all, int wave) {
+    constexpr int MI = 4, NI = 4;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    const int half = lane >> 5, m = lane & 31;
+    const int ta = __builtin_amdgcn_readfirstlane(jb.d_col0 >> 7), tb = __builtin_amdgcn_readfirstlane(jb.x_col0 >> 7);   // this wave's tile
+    const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
+    f32x4* const stage = lds_all + wave * kCoopStageF4;
+    // the operands' scales: gradient planes P_DH1 + l at plane_max[8 + l] (P_DG at [16]), activation planes P_XH1 + l at [l]
+    const float sd = plane_scale(a.plane_max[jb.d_plane == P_DG ? 16 : 8 + (jb.d_plane - P_DH1)]);
+    const float sx = plane_scale(a.plane_max[jb.x_plane - P_XH1]);
+    const char* const dg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane] + (DTILE ? (jb.d_col0 >> 3) * 256 : jb.d_col0));
+    const char* const xg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane] + (XTILE ? (jb.x_col0 >> 3) * 256 : jb.x_col0));
+    const int tlane = ((lane & 15) >> 1) * 1024 + (lane & 1) * 512 + (lane >> 4) * 16;
+    const int dlane = DTILE ? tlane : 4 * (MI * m + 8 * half * dp);
+    const int xlane = XTILE ? tlane : 4 * (NI * m + 8 * half * xp);
+    const int64_t d_chunk_bytes = 128 * (int64_t)dp, x_chunk_bytes = 128 * (int64_t)xp;
+    auto dma_d = [&](int64_t KK, int r, f32x4* dst) __attribute__((always_inline)) {
+        if constexpr (DTILE)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(dg + (KK >> 5) * d_chunk_bytes + (KK & 31) * 16 + (r & 1) * 8192 + (tb + 2 * (r >> 1)) * 64 + dlane),
+                                             (lds_ptr_t)(dst + r * 64), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(dg + (KK + 4 * tb + r) * (int64_t)dp * 4 + dlane), (lds_ptr_t)(dst + r * 64), 16, 0, 0);
+    };
+    auto dma_x = [&](int64_t KK, int r, f32x4* dst) __attribute__((always_inline)) {
+        if constexpr (XTILE)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(xg + (KK >> 5) * x_chunk_bytes + (KK & 31) * 16 + (r & 1) * 8192 + (ta + 2 * (r >> 1)) * 64 + xlane),
+                                             (lds_ptr_t)(dst + (4 + r) * 64), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(xg + (KK + 4 * ta + r) * (int64_t)xp * 4 + xlane), (lds_ptr_t)(dst + (4 + r) * 64), 16, 0, 0);
+    };
+    const float* const sf = reinterpret_cast<const float*>(stage);
+    const float* const lrd = DTILE ? sf + 4 * (128 * half + 64 * (m >> 4) + (m & 15)) : sf + 4 * lane;
+    const float* const lrx = XTILE ? sf + 4 * (128 * half + 64 * (m >> 4) + (m & 15)) + 1024 : sf + 4 * lane;
+    auto off_d = [](int pl, int C, int second) { return DTILE ? 128 * pl + C + 64 * second : 256 * (2 * pl + second) + C; };
+    auto off_x = [](int pl, int C, int second) { return XTILE ? 128 * pl + C + 64 * second : 256 * (4 + 2 * pl + second) + C; };
+    char* const xch = reinterpret_cast<char*>(lds_all + kCoopXchF4);
+    constexpr int kBufBytes = 4 * kCoop2RegionF4 * 16, kRegBytes = kCoop2RegionF4 * 16;
+    char* const rd_d = xch + ta * kRegBytes + lane * 16;                 // + buffer * kBufBytes + ((sub-tile * 2 + term) * 64) * 16
+    char* const rd_x = xch + (2 + tb) * kRegBytes + lane * 16;
+    char* const wr_d = rd_d + 8 * tb;                                      // this wave's pairs 2 tb, 2 tb + 1 of the gradient half
+    char* const wr_x = rd_x + 8 * ta;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[MI] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t Xc[NI][2][4], Dq[2][2][4];     // [sub-tile][term: 0 = m, 1 = h][pair]
+    uint32_t T[4][2];                                     // the terms of the batch of four pairs being split: [pair in batch][term]
+    f32x2 rr[4];
+
+    // pair q (0..15) = operand q >> 3 (0 gradient, 1 activation), component (q >> 1) & 3, local pair q & 1; stage 0 fetch, 1 scale + h (+ d(bias)), 2 m
+    auto split_op = [&](int q, int st, const float* bd, const float* bx, float nf) __attribute__((always_inline)) {
+        const int op = q >> 3, C = (q >> 1) & 3, pl = q & 1, s = q & 3;
+        if (st == 0) {
+            rr[s] = op == 0 ? f32x2{bd[off_d(pl, C, 0)], bd[off_d(pl, C, 1)]} : f32x2{bx[off_x(pl, C, 0)], bx[off_x(pl, C, 1)]};
+        } else if (st == 1) {
+            if (op == 0) bsum[C] += nf * (rr[s][0] + rr[s][1]);
+            rr[s] = rr[s] * (op == 0 ? sd : sx);
+            const f16x2 hh = __builtin_convertvector(rr[s], f16x2);
+            T[s][1] = __builtin_bit_cast(uint32_t, hh);
+            rr[s] = rr[s] - __builtin_convertvector(hh, f32x2);
+        } else {
+            T[s][0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr[s], f16x2));
+        }
+    };
+    auto write_op = [&](int op, int C, int t, int eb) __attribute__((always_inline)) {
+        char* const p = (op == 0 ? wr_d : wr_x) + eb * kBufBytes + ((C * 2 + t) * 64) * 16;
+        *reinterpret_cast<u32x2*>(p) = u32x2{T[2 * (C & 1)][t], T[2 * (C & 1) + 1][t]};
+    };
+    auto read_terms = [&](uint32_t (&dst)[2][4], const char* base, int sub, int eb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(base + eb * kBufBytes + ((sub * 2 + t) * 64) * 16);
+            dst[t][0] = v[0]; dst[t][1] = v[1]; dst[t][2] = v[2]; dst[t][3] = v[3];
+        }
+    };
+    // the 64 split / write operations of a step in issue order: per batch of four pairs (two components of one operand) 4 fetches, 4 x h, 4 x m,
+    // then the four writes of the two components
+    auto coop_op = [&](int n, const float* bd, const float* bx, float nf, int eb) __attribute__((always_inline)) {
+        const int B = n / 16, o = n % 16;
+        if (o < 12) split_op(4 * B + (o & 3), o >> 2, bd, bx, nf);
+        else write_op(B >> 1, 2 * (B & 1) + (o - 12) / 2, (o - 12) % 2, eb);
+    };
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // nobody may still read what this job is about to overwrite
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        dma_d(jb.k0, r, stage);
+        dma_x(jb.k0, r, stage);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        const int64_t k1st = jb.k0 + 16 < jb.k1 ? jb.k0 + 16 : jb.k0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dma_d(k1st, r, stage + 512);
+            dma_x(k1st, r, stage + 512);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 64; ++n) coop_op(n, lrd, lrx, 1.f, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) read_terms(Xc[j], rd_x, j, 0);
+    read_terms(Dq[0], rd_d, 0, 0);
+
+    for (int64_t k = jb.k0; k < jb.k1; k += 16) {
+        const int e = (int)(((k - jb.k0) >> 4) & 1);              // exchange buffer of this step's terms = staging buffer of this step's rows
+        const bool more = k + 16 < jb.k1;
+        const int64_t kn = k + 32 < jb.k1 ? k + 32 : k;           // rows to request (past the end: rows of the own range again, never used)
+        const float nf = more ? 1.f : 0.f;
+        const float* const bd = lrd + 2048 * (1 - e);             // the NEXT step's staged rows (requested a whole step ago)
+        const float* const bx = lrx + 2048 * (1 - e);
+        f32x4* const dst = stage + 512 * e;                       // this step's rows were split during the previous step: free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next step's rows have landed
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (i == 3) {       // every wave's terms of the next step are in buffer 1 - e, every wave's reads of this step's gradient terms are done
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                const int j = g / 3, t = g % 3;
+                const int wc = t == 0 ? 0 : 1, xc = t == 1 ? 0 : 1;      // (gradient term, activation term): (m, h) (h, m) (h, h) -- small products first
+                __builtin_amdgcn_sched_barrier(0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    __builtin_bit_cast(f16x8, u32x4{Dq[i & 1][wc][0], Dq[i & 1][wc][1], Dq[i & 1][wc][2], Dq[i & 1][wc][3]}),
+                    __builtin_bit_cast(f16x8, u32x4{Xc[j][xc][0], Xc[j][xc][1], Xc[j][xc][2], Xc[j][xc][3]}),
+                    acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < 3) {
+                    const int gg = 12 * i + g;                     // gap 0..35 of the step's first three blocks
+                    if (g == 1) read_terms(Dq[(i + 1) & 1], rd_d, i + 1, e);      // the gradient terms of the next block
+                    if (i == 0 && g >= 4 && g < 12) {              // the rows of the step after next
+                        if (g < 8) dma_d(kn, g - 4, dst);
+                        else dma_x(kn, g - 8, dst);
+                    }
+#pragma unroll
+                    for (int n = 0; n < 64; ++n)
+                        if ((n * 36) / 64 == gg) coop_op(n, bd, bx, nf, 1 - e);
+                } else {
+                    // block 3 (behind the barrier): activation sub-tile j's last MFMA of the step is gap 3 j + 2 -- its registers take the next step's
+                    // terms right behind it; the first gradient sub-tile last
+                    if (t == 2) read_terms(Xc[j], rd_x, j, 1 - e);
+                    if (g == 10) read_terms(Dq[0], rd_d, 0, 1 - e);         // (Dq[0] was last used by block 2)
+                }
+            }
+            asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the last prefetch writes LDS: let it finish before the area is reused
+
+    const float inv = 1.f / (sd * sx);      // out of the terms' units (powers of two: exact)
+    float* slot = a.slots + (int64_t)ji * kSlotFloats;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* dst = slot + (MI * mr + i) * (32 * NI) + NI * m;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r] * inv, acc[i][1][r] * inv, acc[i][2][r] * inv, acc[i][3][r] * inv};
+        }
+    if (jb.bias != 0) {
+        float* dst = slot + kSlotTile + half * (32 * MI) + MI * m;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) dst[i] = bsum[i];
+    }
+}
+
 #ifdef NNR_TIMELINE
 extern "C" int nnr_timeline_wgrad(unsigned long long* host32) {
     return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_wgrad), 32 * sizeof(unsigned long long));
@@ -637,7 +835,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
             // (the 128 x 64 tiles against the position encoding -- wgrad_job_split<.., 2> -- were measured on this path too: their VALU work
             // per MFMA is 1.6 times the 4 x 4 tile's and the kernel got SLOWER, 1.15 -> 1.29 ms at the best plan weight; they stay on fp32 MFMAs)
             if (__builtin_amdgcn_readfirstlane(jb.reserved) == 1) {      // a class-A workgroup: the layer's four tiles share the split (all four waves are here)
-                wgrad_group_split<kTileGradPlanes, kTileActPlanes>(jb, a, lane, ji, stage_all, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
+                if (a.plane_max != nullptr)      // NNR_F_SPLIT2: three fp16 terms per product, scaled by the planes' maxima
+                    wgrad_group_split2<kTileGradPlanes, kTileActPlanes>(jb, a, lane, ji, stage_all, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
+                else
+                    wgrad_group_split<kTileGradPlanes, kTileActPlanes>(jb, a, lane, ji, stage_all, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
                 continue;
             }
             if (__builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI) == 4 * 8 + 4) {
