@@ -60,11 +60,11 @@ PEAK_HBM_GBS = 8000.0                        # HBM3E
 BF16_TOLERANCE_VS_FP32 = {'rgb_max_abs': 5e-4, 'depth_max_abs': 2e-3, 'grad_rel_l2': 0.25,
                           'measured_at': '4096 x 128, D = 256, 256-ray subset vs the fp32 oracle (tests/test_gpu_bench_shape_parity.py)'}
 FP32_HOW = {'mfma': 'fp32 (fp32 MFMAs)', 'split3': 'fp32 via six bf16 MFMA terms per product',
-            'split2': 'fp32 via three fp16 MFMA terms per product (fwd, dgrad), six bf16 terms (wgrad)'}      # (short: the driver's record cuts strings at ~100 characters)
+            'split2': 'fp32 via three fp16 MFMA terms per product (fwd, dgrad, wgrad 4x4 tiles)'}      # (short: the driver's record cuts strings at ~100 characters)
 FP32_NOTE = {'mfma': 'v_mfma_f32_32x32x2_f32 products in all three MLP kernels',
-             'split2': 'fp32 results: forward and input-gradient products as three fp16 MFMA terms of two-term operands (power-of-two scaled, residual at '
-                       '2^11: csrc/nnr_split2.h; as close to fp64 as fp32 MFMAs: tests/test_gpu_split3.py), fp32 accumulate; weight gradient: six bf16 MFMA '
-                       'terms of three-term operands (4 x 4 tiles), its narrow tiles on fp32 MFMAs',
+             'split2': 'fp32 results: every product of the forward, the input gradient and the 4 x 4 weight-gradient tiles as three fp16 MFMA terms of '
+                       'two-term operands (power-of-two scaled, residual at 2^11: csrc/nnr_split2.h; as close to fp64 as fp32 MFMAs: '
+                       'tests/test_gpu_split3.py), fp32 accumulate; the narrow weight-gradient tiles on fp32 MFMAs',
              'split3': 'fp32 results: every product of the three MLP kernels as six bf16 MFMA terms of three-term (exact) operands, fp32 accumulate '
                        '(as close to fp64 as fp32 MFMAs: tests/test_gpu_split3.py); the narrow weight-gradient tiles on fp32 MFMAs'}
 
@@ -201,6 +201,68 @@ def box_probe(device, gib=1, reps=8):
     return res
 
 
+def _sclk_file(device):
+    """hwmon `freq1_input` (shader clock, Hz) of the card `device` is, located through its PCI bus id in sysfs; None where the box does not
+    expose it (other cards of the node are visible in /sys/class/drm but not readable from inside the container)."""
+    import glob
+    try:
+        bus = '%02x' % torch.cuda.get_device_properties(device).pci_bus_id
+    except Exception:
+        bus = None
+    readable = []
+    for card in sorted(glob.glob('/sys/class/drm/card*/device')):
+        if not os.access(os.path.join(card, 'pp_dpm_sclk'), os.R_OK):
+            continue
+        f = [x for x in glob.glob(os.path.join(card, 'hwmon', '*', 'freq1_input')) if os.access(x, os.R_OK)]
+        if f:
+            readable.append((os.path.realpath(card), f[0]))
+    for real, f in readable:
+        if bus is not None and (':%s:' % bus) in real.rsplit('/', 1)[-1]:
+            return f
+    return readable[0][1] if len(readable) == 1 else None
+
+
+def clock_probe(device, step, seconds=0.5, period=0.004):
+    """The shader clock the chip holds UNDER the training step: `step()` repeated for `seconds` (untimed, after the timed region) while a
+    thread reads the card's hwmon shader-clock file every `period`.  The roofline peaks are quoted at the nominal 2.4 GHz; this is what the
+    same binaries had available on this box."""
+    import threading
+    f = _sclk_file(device)
+    if f is None:
+        return None
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                samples.append(int(open(f).read()) / 1e6)
+            except Exception:
+                pass
+            time.sleep(period)
+
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    t = threading.Thread(target=sampler, daemon=True)
+    t0 = time.time()
+    t.start()
+    n = 0
+    while time.time() - t0 < seconds:
+        step()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    stop.set()
+    t.join()
+    if not samples:
+        return None
+    samples.sort()
+    return {'sclk_mhz_median': round(samples[len(samples) // 2], 1), 'sclk_mhz_min': round(samples[0], 1), 'sclk_mhz_max': round(samples[-1], 1),
+            'samples': len(samples), 'steps': n, 'nominal_mhz': 2400,
+            'what': 'hwmon freq1_input of this card sampled every %g ms while the training step repeats for %g s after the timed region' % (period * 1e3, seconds)}
+
+
 def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, in_step=None, sequence_reps=0):
     """Roofline block of the three fused-MLP kernels.  `in_step` = their mean durations INSIDE the timed training steps (HIP events
     on the launch stream around every launch, nnr_prof_begin / nnr_prof_end: _timed_steps): the basis of `achieved` when given.
@@ -325,9 +387,10 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
         # Every fp32 product as 16-bit MFMA terms: six bf16 terms of three-term operands (csrc/nnr_split.h), or -- forward / input gradient of
         # 'split2' -- three fp16 terms of two-term operands (csrc/nnr_split2.h).  The kernels' bound is the 16-bit matrix pipe (bf16 and fp16:
         # the same dense 2.5 PFLOP/s), the work they issue is terms x the executed MACs.  Forward / input gradient: all of it; weight gradient
-        # (six bf16 terms in both modes): the 4 x 4 tiles (480 of the 528 tile-units of MFMA work at D = 256), the narrow tiles stay on fp32 MFMAs.
+        # (six bf16 terms, or -- 'split2' at D = 256, the workgroup jobs of nnr_wgrad.hip wgrad_group_split2 -- three fp16 terms): the 4 x 4 tiles
+        # (480 of the 528 tile-units of MFMA work at D = 256), the narrow tiles stay on fp32 MFMAs.
         share = {'mlp_fwd': 1.0, 'mlp_dgrad': 1.0, 'mlp_fwd_infer': 1.0, 'mlp_wgrad': 480.0 / 528.0 if D == 256 else 0.0}
-        terms = {k: (6 if (products == 'split3' or k == 'mlp_wgrad') else 3) for k in share}
+        terms = {k: (6 if (products == 'split3' or (k == 'mlp_wgrad' and os.environ.get('NNR_WGRAD_BF16_TERMS'))) else 3) for k in share}
         for k, f in share.items():
             issued = terms[k] * f * executed / (times[k] * 1e-3) / 1e12
             per[k].update(mfma=('bf16, 6 terms per fp32 product' if terms[k] == 6 else 'fp16, 3 terms per fp32 product')
@@ -757,6 +820,14 @@ def main():
             out['collective'] = {'backend': 'rccl' if backend == 'nccl' else 'gloo (shared GPU dry run)', 'rccl_ranks_seen': ranks_seen,
                                  'allreduce_us': round(ar_us, 1), 'bucket_floats': n_grad}
         out['roofline'] = kernel_roofline(net, device, bf16=args.bf16, rays=R, n_samples=N, in_step=in_step)
+        # (one process only: under N ranks the step holds a collective, and a time-bounded loop on rank 0 alone would leave the others waiting)
+        clk = None if use_dist else clock_probe(device, lambda: trainer.train_step(data, it=args.warmup + args.steps, epoch=0, scheduling_start=10000,
+                                                                                   render_path=None))
+        out['roofline']['clock'] = clk
+        if clk is not None and out['roofline'].get('unit') == 'TFLOP/s':      # the same fraction against what the chip had at the clock it held
+            at = out['roofline']['peak'] * clk['sclk_mhz_median'] / clk['nominal_mhz']
+            out['roofline']['peak_at_measured_clock'] = round(at, 1)
+            out['roofline']['frac_at_measured_clock'] = round(out['roofline']['achieved'] / at, 4)
         out['box'] = box_probe(device)
         out['cpu_baseline'] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
         if world == 1 and not args.no_extra and headline:

@@ -12,7 +12,7 @@ OUT_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(os.path.dirname(HERE), "nnr", "libnnr.so")
 # (source, defines): the two fp32 MLP kernels are compiled one template instantiation per translation unit -- each is minutes of hipcc
 # time (straight-line code of ~8 000 MFMAs), in one unit the forward alone took 8.5 minutes; the longest unit first
-SOURCES = [("nnr_mlp_fwd_f16.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1")), ("nnr_mlp_dgrad_f16.hip", ("NNR_DGRAD_D=256",)),
+SOURCES = [("nnr_wgrad.hip", ()), ("nnr_wgrad.hip", ("NNR_WGRAD_F16_TU=1",)), ("nnr_mlp_fwd_f16.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1")), ("nnr_mlp_dgrad_f16.hip", ("NNR_DGRAD_D=256",)),
            ("nnr_mlp_fwd_f16.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=0")),
            ("nnr_mlp_fwd_f16.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=1")), ("nnr_mlp_dgrad_f16.hip", ("NNR_DGRAD_D=128",)),
            ("nnr_mlp_fwd_f16.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=0")),
@@ -24,7 +24,7 @@ SOURCES = [("nnr_mlp_fwd_f16.hip", ("NNR_FWD_D=256", "NNR_FWD_TRAIN=1")), ("nnr_
            ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=256",)), ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=1")),
            ("nnr_mlp_fwd.hip", ("NNR_FWD_D=128", "NNR_FWD_TRAIN=0")), ("nnr_mlp_dgrad.hip", ("NNR_DGRAD_D=128",)),
            ("nnr_mlp_fwd_bf16.hip", ()), ("nnr_mlp_dgrad_bf16.hip", ()), ("nnr_mlp_fwd.hip", ()), ("nnr_mlp_dgrad.hip", ()),
-           ("nnr_api.cpp", ()), ("nnr_pack.hip", ()), ("nnr_wgrad.hip", ()), ("nnr_wgrad_bf16.hip", ()), ("nnr_composite.hip", ()),
+           ("nnr_api.cpp", ()), ("nnr_pack.hip", ()), ("nnr_wgrad_bf16.hip", ()), ("nnr_composite.hip", ()),
            ("nnr_camera.hip", ()), ("nnr_pointcloud.hip", ()), ("nnr_aux.hip", ()), ("nnr_randperm.hip", ()), ("nnr_optim.hip", ())]
 
 

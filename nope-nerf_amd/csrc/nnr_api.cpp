@@ -170,12 +170,22 @@ Plan build_plan(const nnr_cfg* c) {
                                                          // 400 / 440 / 480 / 520; both operands tile-major: 1.12 / 1.11 / 1.10 / 1.11 at 380 / 420 / 440 / 460, 1.14 at 480 on
                                                          // another box where 440 gave 1.11 -- profiles/r04/r*_wgrad_weight_sweep_tile_x.txt)
     }();
+    // two-term mode: the workgroup jobs take three fp16 MFMAs per product instead of six bf16 ones (wgrad_group_split2): cheaper again, relative to a narrow fp32 tile
+    static const int split2_w = [] {
+        const char* e = std::getenv("NNR_WGRAD_SPLIT2_WEIGHT");
+        return e ? std::max(50, std::atoi(e)) : 340;      // (profiles/r06/h_wgrad_f16_plan_weight_sweep.txt, in sequence with the other kernels: 0.974 / 0.941 / 0.926 /
+                                                         // 0.918 / 0.947 ms at 280 / 300 / 320 / 340 / 360)
+    }();
+    static const bool f16_off = std::getenv("NNR_WGRAD_BF16_TERMS") != nullptr;      // (= nnr_wgrad.hip's: the six-term workgroup jobs in the two-term mode)
     static const bool env_fp32 = std::getenv("NNR_WGRAD_FP32") != nullptr;      // (every knob of the plan is read ONCE per process, here: a plan built
                                                                                 // under one setting never meets a launch that assumes another)
     const bool split = is_split3(c) && !env_fp32;
-    auto weight = [split](const WgradJob& j) -> int64_t {
+    const bool f16_groups = split && is_split2(c) && !f16_off && c->hidden == 256;      // (class-A groups exist at D = 256 only)
+    auto weight = [split, f16_groups](const WgradJob& j) -> int64_t {
         const int mn = j.MI * j.NI;
-        int w = mn == 16 ? (split ? split_w : 1000) : mn == 8 ? 1035 : mn == 4 ? 1145 : 1250;
+        // (the merged layer's two 4 x 4 tiles are class B: private six-term split in either mode; a class-A tile is recognised by its layer: hidden 2..8)
+        const bool group_tile = mn == 16 && j.layer >= 1 && j.layer <= 7;
+        int w = mn == 16 ? (split ? (f16_groups && group_tile ? split2_w : split_w) : 1000) : mn == 8 ? 1035 : mn == 4 ? 1145 : 1250;
         if (j.bias == 1) w += mn == 16 ? 20 : mn == 8 ? 42 : 20;
         return (int64_t)mn * w;
     };

@@ -598,12 +598,15 @@ __device__ __forceinline__ void wgrad_group_split(const WgradJob& jb, const Wgra
 
 // ---- the same workgroup job with every product as THREE fp16 MFMA terms of two-term operands (NNR_F_SPLIT2, round 6) -------------------------
 // d W = sum over ALL samples of Dlt x X: what matters for a term's precision is its absolute error against the SUM, so ONE power-of-two scale per
-// operand plane does (the plane's largest magnitude -- tracked by the kernels that wrote the plane, WgradArgs::plane_max -- to [2^13, 2^14)): a value
-// v s has the terms h = fp16(v s), m = fp16(v s - h) (exact difference; no residual scaling here: an m below fp16's normal range belongs to a value
-// 2^17 below the plane's largest, whose whole contribution is below the sum's fp32 rounding), the products h h + h m + m h, 2^-22 relative each.
+// operand plane does (the plane's largest magnitude -- tracked by the kernels that wrote the plane, WgradArgs::plane_max -- to [2^13, 2^14)).  A value
+// v s has the terms h = fp16(v s) and m' = fp16((v s - h) 2^11): the residual carried at 2^11 as in nnr_split2.h, so that it stays a normal fp16
+// number for values down to 2^-28 of the plane's largest (a whole ROW of d W may belong to a unit whose gradients are that small: with the
+// plain residual its entries lost relative precision -- tests/test_gpu_layer_local.py saw it); its partner in the product is the OTHER operand's
+// h 2^-11, made from h in registers (four packed multiplies per fragment, exact).  Products: m'_d (h_x 2^-11) + (h_d 2^-11) m'_x + h_d h_x, 2^-22
+// relative each.
 // Against wgrad_group_split: 48 MFMAs per step and wave instead of 96, two exchanged terms per value instead of three (128 KiB of LDS instead
-// of 160), a two-stage split (convert, one packed subtract of the converted value, convert).  Staging, exchange protocol, barrier, DMA distance,
-// d(bias) (from the unscaled fp32 values) and the slot format are wgrad_group_split's; the tile leaves the accumulators times 1 / (s_d s_x).
+// of 160), a two-stage split.  Staging, exchange protocol, barrier, DMA distance, d(bias) (from the unscaled fp32 values) and the slot format are
+// wgrad_group_split's; the tile leaves in the terms' units, the reduction kernel multiplies the sum by 1 / (s_d s_x).
 constexpr int kCoop2RegionF4 = 4 * 2 * 64;               // f32x4 per exchange region: [sub-tile 4][term 2][lane 64]
 constexpr int kCoop2F4 = kCoopXchF4 + 2 * 4 * kCoop2RegionF4;
 
@@ -668,7 +671,12 @@ __device__ __forceinline__ void wgrad_group_split2(const WgradJob& jb, const Wgr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float bsum[MI] = {0.f, 0.f, 0.f, 0.f};
-    uint32_t Xc[NI][2][4], Dq[2][2][4];     // [sub-tile][term: 0 = m, 1 = h][pair]
+    uint32_t Xc[NI][3][4], Dq[2][3][4];     // [sub-tile][term: 0 = m' (the residual at 2^11), 1 = h, 2 = h 2^-11 (made here from h)][pair]
+    auto down11 = [](uint32_t (&t)[3][4]) __attribute__((always_inline)) {      // (as ONE 8-wide multiply: see frag_down11, nnr_split2.h)
+        const f16x8 v = __builtin_bit_cast(f16x8, u32x4{t[1][0], t[1][1], t[1][2], t[1][3]}) * (_Float16)0.00048828125f;
+        const u32x4 u = __builtin_bit_cast(u32x4, v);
+        t[2][0] = u[0]; t[2][1] = u[1]; t[2][2] = u[2]; t[2][3] = u[3];
+    };
     uint32_t T[4][2];                                     // the terms of the batch of four pairs being split: [pair in batch][term]
     f32x2 rr[4];
 
@@ -682,7 +690,7 @@ __device__ __forceinline__ void wgrad_group_split2(const WgradJob& jb, const Wgr
             rr[s] = rr[s] * (op == 0 ? sd : sx);
             const f16x2 hh = __builtin_convertvector(rr[s], f16x2);
             T[s][1] = __builtin_bit_cast(uint32_t, hh);
-            rr[s] = rr[s] - __builtin_convertvector(hh, f32x2);
+            rr[s] = (rr[s] - __builtin_convertvector(hh, f32x2)) * 2048.f;
         } else {
             T[s][0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr[s], f16x2));
         }
@@ -691,13 +699,13 @@ __device__ __forceinline__ void wgrad_group_split2(const WgradJob& jb, const Wgr
         char* const p = (op == 0 ? wr_d : wr_x) + eb * kBufBytes + ((C * 2 + t) * 64) * 16;
         *reinterpret_cast<u32x2*>(p) = u32x2{T[2 * (C & 1)][t], T[2 * (C & 1) + 1][t]};
     };
-    auto read_terms = [&](uint32_t (&dst)[2][4], const char* base, int sub, int eb) __attribute__((always_inline)) {
+    auto read_terms = [&](uint32_t (&dst)[3][4], const char* base, int sub, int eb) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(base + eb * kBufBytes + ((sub * 2 + t) * 64) * 16);
             dst[t][0] = v[0]; dst[t][1] = v[1]; dst[t][2] = v[2]; dst[t][3] = v[3];
         }
-    };
+    };      // (+ down11(dst) a few gaps later: right behind the loads it would wait out the LDS latency inside the MFMA stream)
     // the 64 split / write operations of a step in issue order: per batch of four pairs (two components of one operand) 4 fetches, 4 x h, 4 x m,
     // then the four writes of the two components
     auto coop_op = [&](int n, const float* bd, const float* bx, float nf, int eb) __attribute__((always_inline)) {
@@ -727,8 +735,9 @@ __device__ __forceinline__ void wgrad_group_split2(const WgradJob& jb, const Wgr
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int j = 0; j < NI; ++j) read_terms(Xc[j], rd_x, j, 0);
+    for (int j = 0; j < NI; ++j) { read_terms(Xc[j], rd_x, j, 0); down11(Xc[j]); }
     read_terms(Dq[0], rd_d, 0, 0);
+    down11(Dq[0]);
 
     for (int64_t k = jb.k0; k < jb.k1; k += 16) {
         const int e = (int)(((k - jb.k0) >> 4) & 1);              // exchange buffer of this step's terms = staging buffer of this step's rows
@@ -747,8 +756,11 @@ __device__ __forceinline__ void wgrad_group_split2(const WgradJob& jb, const Wgr
             }
 #pragma unroll
             for (int g = 0; g < 12; ++g) {
+                // (the shifted-down h term of an operand is made a few gaps behind its loads and before its first use: X sub-tile 3's -- read in the
+                // last gap of the previous step -- in gap 1 of block 0, first used by MFMA 9)
+                if (i == 0 && g == 1 && k != jb.k0) down11(Xc[3]);
                 const int j = g / 3, t = g % 3;
-                const int wc = t == 0 ? 0 : 1, xc = t == 1 ? 0 : 1;      // (gradient term, activation term): (m, h) (h, m) (h, h) -- small products first
+                const int wc = t == 0 ? 0 : (t == 1 ? 2 : 1), xc = t == 0 ? 2 : (t == 1 ? 0 : 1);      // (gradient term, activation term): (m', h 2^-11) (h 2^-11, m') (h, h) -- small products first
                 __builtin_amdgcn_sched_barrier(0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                     __builtin_bit_cast(f16x8, u32x4{Dq[i & 1][wc][0], Dq[i & 1][wc][1], Dq[i & 1][wc][2], Dq[i & 1][wc][3]}),
@@ -758,6 +770,7 @@ __device__ __forceinline__ void wgrad_group_split2(const WgradJob& jb, const Wgr
                 if (i < 3) {
                     const int gg = 12 * i + g;                     // gap 0..35 of the step's first three blocks
                     if (g == 1) read_terms(Dq[(i + 1) & 1], rd_d, i + 1, e);      // the gradient terms of the next block
+                    if (g == 7) down11(Dq[(i + 1) & 1]);
                     if (i == 0 && g >= 4 && g < 12) {              // the rows of the step after next
                         if (g < 8) dma_d(kn, g - 4, dst);
                         else dma_x(kn, g - 8, dst);
@@ -769,7 +782,9 @@ __device__ __forceinline__ void wgrad_group_split2(const WgradJob& jb, const Wgr
                     // block 3 (behind the barrier): activation sub-tile j's last MFMA of the step is gap 3 j + 2 -- its registers take the next step's
                     // terms right behind it; the first gradient sub-tile last
                     if (t == 2) read_terms(Xc[j], rd_x, j, 1 - e);
-                    if (g == 10) read_terms(Dq[0], rd_d, 0, 1 - e);         // (Dq[0] was last used by block 2)
+                    if (t == 2 && j > 0) down11(Xc[j - 1]);                   // (sub-tile j - 1's terms were read three gaps ago)
+                    if (g == 3) read_terms(Dq[0], rd_d, 0, 1 - e);          // (Dq[0] was last used by block 2)
+                    if (g == 9) down11(Dq[0]);
                 }
             }
             asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]));
@@ -777,7 +792,8 @@ __device__ __forceinline__ void wgrad_group_split2(const WgradJob& jb, const Wgr
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the last prefetch writes LDS: let it finish before the area is reused
 
-    const float inv = 1.f / (sd * sx);      // out of the terms' units (powers of two: exact)
+    // the tile leaves in the TERMS' units (times s_d s_x): the reduction kernel, which adds the splits of a tile anyway, multiplies the sum by
+    // 1 / (s_d s_x) (wgrad_reduce_kernel) -- multiplied here, hipcc read the whole tile out of the accumulators first: 256 VGPRs and scratch
     float* slot = a.slots + (int64_t)ji * kSlotFloats;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -785,7 +801,7 @@ __device__ __forceinline__ void wgrad_group_split2(const WgradJob& jb, const Wgr
         for (int r = 0; r < 16; ++r) {
             const int mr = (r & 3) + 8 * (r >> 2) + 4 * half;
             float* dst = slot + (MI * mr + i) * (32 * NI) + NI * m;
-            *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r] * inv, acc[i][1][r] * inv, acc[i][2][r] * inv, acc[i][3][r] * inv};
+            *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
         }
     if (jb.bias != 0) {
         float* dst = slot + kSlotTile + half * (32 * MI) + MI * m;
@@ -794,13 +810,15 @@ __device__ __forceinline__ void wgrad_group_split2(const WgradJob& jb, const Wgr
     }
 }
 
-#ifdef NNR_TIMELINE
+#if defined(NNR_TIMELINE) && !defined(NNR_WGRAD_F16_TU)
 extern "C" int nnr_timeline_wgrad(unsigned long long* host32) {
     return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(tl_wgrad), 32 * sizeof(unsigned long long));
 }
 #endif
 
-template <bool SPLIT>     // SPLIT: the 4 x 4 tiles with three-term products (wgrad_job_split); the narrow tiles stay on fp32 MFMAs
+template <bool SPLIT, bool F16 = false>     // SPLIT: the 4 x 4 tiles with three-term products (wgrad_job_split); the narrow tiles stay on fp32 MFMAs
+                                            // F16 (NNR_F_SPLIT2): the workgroup jobs with three fp16 terms per product (wgrad_group_split2) -- an
+                                            // instantiation of its own: both workgroup jobs in one kernel cost 188 bytes of scratch per lane
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) f32x4 stage_all[SPLIT ? (kCoopF4 > kWavesPerBlock * kStageF4 ? kCoopF4 : kWavesPerBlock * kStageF4) : 1];
     const int lane = threadIdx.x & 63;
@@ -835,7 +853,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
             // (the 128 x 64 tiles against the position encoding -- wgrad_job_split<.., 2> -- were measured on this path too: their VALU work
             // per MFMA is 1.6 times the 4 x 4 tile's and the kernel got SLOWER, 1.15 -> 1.29 ms at the best plan weight; they stay on fp32 MFMAs)
             if (__builtin_amdgcn_readfirstlane(jb.reserved) == 1) {      // a class-A workgroup: the layer's four tiles share the split (all four waves are here)
-                if (a.plane_max != nullptr)      // NNR_F_SPLIT2: three fp16 terms per product, scaled by the planes' maxima
+                if constexpr (F16)      // NNR_F_SPLIT2: three fp16 terms per product, scaled by the planes' maxima
                     wgrad_group_split2<kTileGradPlanes, kTileActPlanes>(jb, a, lane, ji, stage_all, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
                 else
                     wgrad_group_split<kTileGradPlanes, kTileActPlanes>(jb, a, lane, ji, stage_all, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
@@ -872,6 +890,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
 #endif
 }
 
+// The fp16-term instantiation lives in a translation unit of its own (this file compiled with -DNNR_WGRAD_F16_TU, csrc/build.py): the three
+// instantiations of wgrad_kernel in one unit took hipcc eleven minutes.
+hipError_t launch_wgrad_f16_main(const WgradArgs& a, hipStream_t st);
+#ifdef NNR_WGRAD_F16_TU
+hipError_t launch_wgrad_f16_main(const WgradArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((wgrad_kernel<true, true>), dim3(a.n_waves / 4), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+#else
 // dW[tile] = sum over the tile's splits of their partial slots (every weight belongs to exactly one tile: a plain store, the caller's
 // buffer needs no zero-fill); d(bias) += its share onto the zeros the main kernel wrote (at most two shares per row: a + b == b + a,
 // the result does not depend on their order).  Blocks of jobs that are not split 0 of their tile exit at once; split 0 walks the chain.
@@ -908,6 +935,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
             for (int u = 0; u < 8; ++u) sum += v[u];
         }
         for (; s < n; ++s) sum += *reinterpret_cast<const f32x4*>(src + (int64_t)chain[s] * kSlotFloats);
+        if (a.plane_max != nullptr && jb.reserved == 1) {      // NNR_F_SPLIT2: the workgroup jobs' tiles carry their operands' scales (wgrad_group_split2): exact powers of two
+            const float sd = plane_scale(a.plane_max[jb.d_plane == P_DG ? 16 : 8 + (jb.d_plane - P_DH1)]), sx = plane_scale(a.plane_max[jb.x_plane - P_XH1]);
+            sum = sum * (1.f / (sd * sx));
+        }
         float* dst = a.gw[jb.layer] + (int64_t)(jb.row0 + row) * jb.ldw + jb.wcol0 + c0;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -967,9 +998,13 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st) {
     hipError_t e;
     prof_before(PROF_WGRAD, st);
     static const bool split_off = std::getenv("NNR_WGRAD_FP32") != nullptr;      // experiments: fp32 MFMAs in the weight gradient of the three-term mode
-    if (a.bf16 >= 2 && !split_off) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.n_waves / 4), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_heads * 16), dim3(256), 0, st, a);
+    static const bool f16_off = std::getenv("NNR_WGRAD_BF16_TERMS") != nullptr;      // experiments / A-B: the six-term workgroup jobs in the two-term mode
+    WgradArgs b = a;
+    if (!(a.bf16 == 3 && a.plane_max != nullptr && !split_off && !f16_off)) b.plane_max = nullptr;      // (non-null = "the workgroup jobs' tiles carry scales": the reduction undoes them)
+    if (b.plane_max != nullptr) (void)launch_wgrad_f16_main(b, st);
+    else if (a.bf16 >= 2 && !split_off) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(a.n_waves / 4), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.n_waves / 4), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.n_heads * 16), dim3(256), 0, st, b);
     e = hipGetLastError();
     if (e == hipSuccess) e = launch_wgrad_unmerge(a, st);
     prof_after(PROF_WGRAD, st);      // the bracket covers the whole stage: main kernel + slot reduction + un-merge
@@ -992,5 +1027,7 @@ hipError_t launch_wgrad_unmerge(const WgradArgs& a, hipStream_t st) {
     }
     return hipGetLastError();
 }
+
+#endif      // NNR_WGRAD_F16_TU
 
 }  // namespace nnr

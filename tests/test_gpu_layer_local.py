@@ -251,9 +251,9 @@ def test_fp32_kernels_layer_by_layer_against_their_stashed_operands(D, R, N):
     tol = 3e-6          # measured: <= 7e-7
     worst = 0.0
 
-    def check(got, exact, scale, what):
+    def check(got, exact, scale, what, floor=0.0):
         nonlocal worst
-        ratio = float(((got - exact).abs() / (scale + 1e-30)).max())
+        ratio = float((((got - exact).abs() - floor).clamp_min(0) / (scale + 1e-30)).max())
         worst = max(worst, ratio)
         assert ratio <= tol, (what, ratio)
 
@@ -284,8 +284,14 @@ def test_fp32_kernels_layer_by_layer_against_their_stashed_operands(D, R, N):
     doutp = _rows(r["lib"], r["cfg"], r["ws"], P_DOUT4, Sp, 4)
     pairs = {0: (Dl[0], E), 4: (Dl[4], torch.cat([X[4], E], dim=1)), 8: (doutp[:, 3:4], X[8]), 11: (doutp[:, :3], Gc)}
     pairs.update({l: (Dl[l], X[l]) for l in (1, 2, 3, 5, 6, 7)})
+    # The fp16-term weight gradient (nnr_wgrad.hip wgrad_group_split2) scales each PLANE by one power of two (its maximum -> [2^13, 2^14))
+    # and keeps h + 2^-11 m' in fp16: a value below 2^-49 of its plane's maximum is below half the last subnormal step of m' and is
+    # dropped.  Relative to the sum of |terms| of an element that is unbounded (a unit that fires only on occluded samples has a whole
+    # column of such values), in absolute terms it is S 2^-48 max|d| max|x| -- ~1e-11 of a typical gradient element here -- and that
+    # absolute floor is subtracted before the relative bound is applied.
     for l, (dl, x) in sorted(pairs.items()):
-        check(dbl(gw[l]), dl.T @ x, dl.abs().T @ x.abs(), "dW %d" % l)
+        floor = Sp * 2.0 ** -48 * float(dl.abs().max()) * float(x.abs().max())
+        check(dbl(gw[l]), dl.T @ x, dl.abs().T @ x.abs(), "dW %d" % l, floor)
         check(dbl(gb[l]), dl.sum(0), dl.abs().sum(0), "db %d" % l)
     check(dbl(gw[10][:, D:]), DG.T @ F, DG.abs().T @ F.abs(), "dW colour hidden, direction columns")
     print("worst error / sum of |terms|: %.2e" % worst)
