@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNR_ABI_VERSION 5
+#define NNR_ABI_VERSION 6
 
 /* error codes */
 #define NNR_OK 0
@@ -370,7 +370,7 @@ int nnr_step_rays_bwd(const nnr_step_cfg* cfg, const float* r_all, const float* 
                       float* d_r, float* d_t, float* d_scales, float* d_shifts, float* scratch, void* stream);
 /* scratch: NNR_STEP_BWD_SCRATCH_FLOATS floats whose FIRST word is zero on entry -- zero-fill the buffer once, every call leaves the word zero
  * again (the ticket of the workgroups' fixed-order reduction); calls that share a buffer must be ordered on one stream. */
-#define NNR_STEP_BWD_SCRATCH_FLOATS 272
+#define NNR_STEP_BWD_SCRATCH_FLOATS 528
 
 /* depth = nearest-resize(depth_img (hd,wd) -> (h,w)).flatten()[ray_idx]  (model/network.py:22-24) without materialising
  * the resized image; backward scatter-adds into a zero-filled (hd,wd) gradient image. */

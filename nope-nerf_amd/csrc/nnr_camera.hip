@@ -23,33 +23,51 @@
 namespace nnr {
 
 // ------------------------------------------------------------------------------------------------ 4x4 helpers
-struct M4 { float m[16]; };
+// The forward evaluates in float, as the reference's ATen ops do (the rays must be the reference's rays).  Every BACKWARD of this file
+// evaluates in double from those float values and rounds its results once: the pose gradient is a sum over all rays of terms that cancel
+// to ~1e-3 of their magnitude, and against an fp64 evaluation of the step the float chain sat at 2.3x the CPU oracle's own distance in the
+// median of 12 seeds (profiles/r06/k_yardstick_double_composite.txt) while everything upstream of it was at or below 1x.  These kernels
+// are a few microseconds of latency-bound work; the double rate is not what they wait on.
+template <typename T> struct M4T { T m[16]; };
+using M4 = M4T<float>;
+using M4d = M4T<double>;
 
-__device__ __forceinline__ M4 mul4(const M4& a, const M4& b) {
-    M4 c;
+template <typename A, typename B>
+__device__ __forceinline__ auto mul4(const M4T<A>& a, const M4T<B>& b) -> M4T<decltype(A() * B())> {
+    using T = decltype(A() * B());
+    M4T<T> c;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float s = 0.f;
+            T s = T(0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s += a.m[4 * i + k] * b.m[4 * k + j];
+            for (int k = 0; k < 4; ++k) s += (T)a.m[4 * i + k] * (T)b.m[4 * k + j];
             c.m[4 * i + j] = s;
         }
     return c;
 }
-__device__ __forceinline__ M4 transpose4(const M4& a) {
-    M4 c;
+template <typename T>
+__device__ __forceinline__ M4T<T> transpose4(const M4T<T>& a) {
+    M4T<T> c;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) c.m[4 * i + j] = a.m[4 * j + i];
     return c;
 }
-// general 4x4 inverse by cofactors (adjugate / determinant)
+// general 4x4 inverse by cofactors (adjugate / determinant), evaluated in double and rounded once: a cofactor is six triple products that
+// cancel, and the rays inherit every ulp of these matrices through a 2^9 position-encoding frequency (NNR_CAMERA_INV_F32: the float
+// evaluation of rounds 1-5, for the A/B of profiles/r06/n_*)
 __device__ __forceinline__ M4 inv4(const M4& a) {
+#ifdef NNR_CAMERA_INV_F32
     const float* m = a.m;
     float inv[16];
+#else
+    double m[16], inv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = (double)a.m[i];
+#endif
     inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
     inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
     inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
@@ -66,11 +84,16 @@ __device__ __forceinline__ M4 inv4(const M4& a) {
     inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
     inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
     inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+#ifdef NNR_CAMERA_INV_F32
     const float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
     const float rdet = 1.0f / det;
+#else
+    const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    const double rdet = 1.0 / det;
+#endif
     M4 r;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) r.m[i] = inv[i] * rdet;
+    for (int i = 0; i < 16; ++i) r.m[i] = (float)(inv[i] * rdet);
     return r;
 }
 __device__ __forceinline__ M4 load4(const float* p) {
@@ -79,13 +102,20 @@ __device__ __forceinline__ M4 load4(const float* p) {
     for (int i = 0; i < 16; ++i) a.m[i] = p[i];
     return a;
 }
-// dL/dA for Y = A^-1:  -Y^T (dL/dY) Y^T
-__device__ __forceinline__ M4 inv_backward(const M4& y, const M4& dy) {
-    const M4 yt = transpose4(y);
-    M4 r = mul4(mul4(yt, dy), yt);
+// dL/dA for Y = A^-1:  -Y^T (dL/dY) Y^T   (Y as the forward left it, the products in the gradient's type)
+template <typename A, typename B>
+__device__ __forceinline__ auto inv_backward(const M4T<A>& y, const M4T<B>& dy) -> M4T<decltype(A() * B())> {
+    const M4T<A> yt = transpose4(y);
+    auto r = mul4(mul4(yt, dy), yt);
 #pragma unroll
     for (int i = 0; i < 16; ++i) r.m[i] = -r.m[i];
     return r;
+}
+__device__ __forceinline__ M4d load4d(const float* p) {
+    M4d a;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a.m[i] = (double)p[i];
+    return a;
 }
 
 // ------------------------------------------------------------------------------------------------ SE(3) exp
@@ -112,48 +142,48 @@ __global__ void se3_exp_fwd_kernel(const float* r_all, const float* t_all, int i
     for (int k = 0; k < 16; ++k) c2w[k] = m[k];
 }
 
-// d loss / d (r, t) of one camera from d loss / d c2w
-__device__ __forceinline__ void se3_exp_grad(const float* r, const float* d_c2w, float* d_r, float* d_t) {
-    const float x = r[0], y = r[1], z = r[2];
-    const float n = sqrtf(x * x + y * y + z * z);
-    const float th = n + 1e-15f;
-    const float s = sinf(th), c = cosf(th);
-    const float a = s / th, b = (1.f - c) / (th * th);
-    const float da = c / th - s / (th * th);                                   // d(sin th / th)/d th, as autograd forms it
-    const float db = s / (th * th) - 2.f * (1.f - c) / (th * th * th);         // d((1-cos th)/th^2)/d th
-    const float K[9] = {0.f, -z, y, z, 0.f, -x, -y, x, 0.f};
-    float K2[9], G[9];
+// d loss / d (r, t) of one camera from d loss / d c2w (evaluated in double: see the note at M4T)
+__device__ __forceinline__ void se3_exp_grad(const float* r, const double* d_c2w, float* d_r, float* d_t) {
+    const double x = r[0], y = r[1], z = r[2];
+    const double n = sqrt(x * x + y * y + z * z);
+    const double th = n + 1e-15;
+    const double s = sin(th), c = cos(th);
+    const double a = s / th, b = (1. - c) / (th * th);
+    const double da = c / th - s / (th * th);                                  // d(sin th / th)/d th, as autograd forms it
+    const double db = s / (th * th) - 2. * (1. - c) / (th * th * th);          // d((1-cos th)/th^2)/d th
+    const double K[9] = {0., -z, y, z, 0., -x, -y, x, 0.};
+    double K2[9], G[9];
     for (int p = 0; p < 3; ++p)
         for (int q = 0; q < 3; ++q) {
             K2[3 * p + q] = K[3 * p] * K[q] + K[3 * p + 1] * K[3 + q] + K[3 * p + 2] * K[6 + q];
             G[3 * p + q] = d_c2w[4 * p + q];
         }
-    float ga = 0.f, gb = 0.f;
+    double ga = 0., gb = 0.;
     for (int p = 0; p < 9; ++p) { ga += G[p] * K[p]; gb += G[p] * K2[p]; }
     // dL/dK = a G + b (G K^T + K^T G)
-    float gK[9];
+    double gK[9];
     for (int p = 0; p < 3; ++p)
         for (int q = 0; q < 3; ++q) {
-            float gkT = 0.f, kTg = 0.f;
+            double gkT = 0., kTg = 0.;
             for (int k = 0; k < 3; ++k) { gkT += G[3 * p + k] * K[3 * q + k]; kTg += K[3 * k + p] * G[3 * k + q]; }
             gK[3 * p + q] = a * G[3 * p + q] + b * (gkT + kTg);
         }
-    const float gth = ga * da + gb * db;
-    const float inv_n = n > 0.f ? 1.f / n : 0.f;                              // d|r|/dr = r/|r|, subgradient 0 at r = 0
-    d_r[0] = gK[7] - gK[5] + gth * x * inv_n;
-    d_r[1] = gK[2] - gK[6] + gth * y * inv_n;
-    d_r[2] = gK[3] - gK[1] + gth * z * inv_n;
-    d_t[0] = d_c2w[3];
-    d_t[1] = d_c2w[7];
-    d_t[2] = d_c2w[11];
+    const double gth = ga * da + gb * db;
+    const double inv_n = n > 0. ? 1. / n : 0.;                                // d|r|/dr = r/|r|, subgradient 0 at r = 0
+    d_r[0] = (float)(gK[7] - gK[5] + gth * x * inv_n);
+    d_r[1] = (float)(gK[2] - gK[6] + gth * y * inv_n);
+    d_r[2] = (float)(gK[3] - gK[1] + gth * z * inv_n);
+    d_t[0] = (float)d_c2w[3];
+    d_t[1] = (float)d_c2w[7];
+    d_t[2] = (float)d_c2w[11];
 }
 // gradients into full (n_cams,3) tables: zero everywhere except row idx
 __global__ void se3_exp_bwd_kernel(const float* r_all, int idx, int n_cams, const float* d_c2w, float* d_r_all, float* d_t_all) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 3 * n_cams && i / 3 != idx) { d_r_all[i] = 0.f; d_t_all[i] = 0.f; }
     if (i != 0) return;
-    float g[16];
-    for (int k = 0; k < 16; ++k) g[k] = d_c2w[k];
+    double g[16];
+    for (int k = 0; k < 16; ++k) g[k] = (double)d_c2w[k];
     se3_exp_grad(r_all + 3 * idx, g, d_r_all + 3 * idx, d_t_all + 3 * idx);
 }
 
@@ -167,8 +197,8 @@ __global__ void inv4_fwd_kernel(const float* a, float* y, int batch) {
 __global__ void inv4_bwd_kernel(const float* y, const float* dy, float* da, int batch) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= batch) return;
-    const M4 r = inv_backward(load4(y + 16 * i), load4(dy + 16 * i));
-    for (int k = 0; k < 16; ++k) da[16 * i + k] = r.m[k];
+    const M4d r = inv_backward(load4(y + 16 * i), load4d(dy + 16 * i));
+    for (int k = 0; k < 16; ++k) da[16 * i + k] = (float)r.m[k];
 }
 
 // ------------------------------------------------------------------------------------------------ ray setup
@@ -205,63 +235,74 @@ __global__ __launch_bounds__(256) void ray_setup_fwd_kernel(RaySetupArgs a) {
     a.mask[i] = (isfinite(dgt) && dgt != 0.f) ? 1 : 0;
 }
 
-// One workgroup of 1024 threads strides over the rays and reduces in a FIXED order (lane tree, then the 16 waves in index order):
+// The per-ray part of both backward kernels (ray_setup_bwd, step_rays_bwd), in double: from the upstream gradients of one ray to
+// d loss / d (pixels_world - camera_world) and d loss / d depth.
+struct RayBack { double gray[3]; double gdep; };
+__device__ __forceinline__ RayBack ray_backward(const M4& m, float px, float py, float depf, const float* g_dir, const float* g_view, const float* g_norm,
+                                                const float* g_dgt, int i, bool use_dir, bool normalise) {
+    RayBack o;
+    const double dep = depf;
+    double ray[3], gdir[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ray[c] = (double)m.m[4 * c] * px + (double)m.m[4 * c + 1] * py + (double)m.m[4 * c + 2];
+    const double n = sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+    const double rn = 1. / n;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double g = g_dir ? (double)g_dir[3 * i + c] : 0.;
+        if (use_dir && g_view) g -= (double)g_view[3 * i + c];     // view = -dir
+        gdir[c] = g;
+    }
+    double gn = g_norm ? (double)g_norm[i] : 0.;                   // dL/d|ray|
+    o.gdep = 0.;
+    const double gd = g_dgt ? (double)g_dgt[i] : 0.;
+    const double sgn = dep > 0. ? 1. : (dep < 0. ? -1. : 0.);
+    if (normalise) {
+        const double dot = (gdir[0] * ray[0] + gdir[1] * ray[1] + gdir[2] * ray[2]) * rn * rn;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o.gray[c] = (gdir[c] - ray[c] * dot) * rn;   // through ray / |ray|
+        if (gd != 0.) { gn += gd * fabs(dep); o.gdep = gd * n * sgn; }          // d_gt = |depth| |ray|
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o.gray[c] = gdir[c];
+        if (gd != 0.) o.gdep = gd * sgn;                                         // d_gt = |depth| (the |ray| cancels)
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o.gray[c] += gn * ray[c] * rn;
+    return o;
+}
+
+// One workgroup of 512 threads strides over the rays and reduces in a FIXED order (lane tree, then the 8 waves in index order; in double):
 // the 12 sums -- and with them every pose gradient of the step -- are bit-reproducible from run to run, which float atomics
 // across workgroups are not.  R is a few thousand rays per rank; the work is O(R) and latency-bound either way, and the
 // matrix chain rule (formerly a second launch behind a memset) runs in the same kernel.
-__global__ __launch_bounds__(1024) void ray_setup_bwd_kernel(RaySetupArgs a) {
-    __shared__ float red[12][16];
+__global__ __launch_bounds__(512) void ray_setup_bwd_kernel(RaySetupArgs a) {
+    __shared__ double red[12][8];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float acc[12];
+    double acc[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int k = 0; k < 12; ++k) acc[k] = 0.;
     M4 m;
     {
         M4 kinv, winv, sinv;
         pixel_to_world(a, kinv, winv, sinv, m);
     }
-    for (int i = threadIdx.x; i < a.R; i += 1024) {
+    for (int i = threadIdx.x; i < a.R; i += 512) {
         const float px = a.pixels[2 * i], py = a.pixels[2 * i + 1];
         const float dep = a.depth ? a.depth[i] : 1.f;
-        float ray[3], gdir[3], gray[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) ray[c] = m.m[4 * c] * px + m.m[4 * c + 1] * py + m.m[4 * c + 2];
-        const float n = sqrtf(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
-        const float rn = 1.f / n;
+        const RayBack rb = ray_backward(m, px, py, dep, a.g_dir, a.g_view, a.g_norm, a.g_dgt, i, a.use_dir, a.normalise);
+        if (a.g_depth) a.g_depth[i] = (float)rb.gdep;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float g = a.g_dir ? a.g_dir[3 * i + c] : 0.f;
-            if (a.use_dir && a.g_view) g -= a.g_view[3 * i + c];     // view = -dir
-            gdir[c] = g;
-        }
-        float gn = a.g_norm ? a.g_norm[i] : 0.f;                      // dL/d|ray|
-        float gdep = 0.f;
-        const float gd = a.g_dgt ? a.g_dgt[i] : 0.f;
-        const float sgn = dep > 0.f ? 1.f : (dep < 0.f ? -1.f : 0.f);
-        if (a.normalise) {
-            const float dot = (gdir[0] * ray[0] + gdir[1] * ray[1] + gdir[2] * ray[2]) * rn * rn;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gray[c] = (gdir[c] - ray[c] * dot) * rn;   // through ray / |ray|
-            if (gd != 0.f) { gn += gd * fabsf(dep); gdep = gd * n * sgn; }        // d_gt = |depth| |ray|
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gray[c] = gdir[c];
-            if (gd != 0.f) gdep = gd * sgn;                                        // d_gt = |depth| (the |ray| cancels)
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gray[c] += gn * ray[c] * rn;
-        if (a.g_depth) a.g_depth[i] = gdep;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            acc[4 * c + 0] += gray[c] * px;
-            acc[4 * c + 1] += gray[c] * py;
-            acc[4 * c + 2] += gray[c];
-            acc[4 * c + 3] += a.g_o ? a.g_o[3 * i + c] : 0.f;
+            acc[4 * c + 0] += rb.gray[c] * px;
+            acc[4 * c + 1] += rb.gray[c] * py;
+            acc[4 * c + 2] += rb.gray[c];
+            acc[4 * c + 3] += a.g_o ? (double)a.g_o[3 * i + c] : 0.;
         }
     }
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
-        float v = acc[k];
+        double v = acc[k];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
         if (lane == 0) red[k][wv] = v;
@@ -269,23 +310,23 @@ __global__ __launch_bounds__(1024) void ray_setup_bwd_kernel(RaySetupArgs a) {
     __syncthreads();
     if (threadIdx.x != 0) return;
     // dL/dM (12 sums) -> dL/dK, dL/dW, dL/dS through M = S^-1 W^-1 K^-1
-    M4 dm;
+    M4d dm;
     for (int k = 0; k < 12; ++k) {
-        float t = 0.f;
-        for (int w = 0; w < 16; ++w) t += red[k][w];
+        double t = 0.;
+        for (int w = 0; w < 8; ++w) t += red[k][w];
         dm.m[k] = t;
-        a.acc[k] = t;
+        a.acc[k] = (float)t;
     }
-    for (int k = 12; k < 16; ++k) dm.m[k] = 0.f;
+    for (int k = 12; k < 16; ++k) dm.m[k] = 0.;
     M4 kinv, winv, sinv, m2;
     pixel_to_world(a, kinv, winv, sinv, m2);
-    const M4 sw = mul4(sinv, winv);
-    const M4 d_kinv = mul4(transpose4(sw), dm);             // M = (S^-1 W^-1) K^-1
-    const M4 d_sw = mul4(dm, transpose4(kinv));
-    const M4 d_sinv = mul4(d_sw, transpose4(winv));
-    const M4 d_winv = mul4(transpose4(sinv), d_sw);
-    const M4 gk = inv_backward(kinv, d_kinv), gw = inv_backward(winv, d_winv), gs = inv_backward(sinv, d_sinv);
-    for (int k = 0; k < 16; ++k) { a.gK[k] = gk.m[k]; a.gW[k] = gw.m[k]; a.gS[k] = gs.m[k]; }
+    const M4d sw = mul4(load4d(sinv.m), winv);
+    const M4d d_kinv = mul4(transpose4(sw), dm);             // M = (S^-1 W^-1) K^-1
+    const M4d d_sw = mul4(dm, transpose4(kinv));
+    const M4d d_sinv = mul4(d_sw, transpose4(winv));
+    const M4d d_winv = mul4(transpose4(sinv), d_sw);
+    const M4d gk = inv_backward(kinv, d_kinv), gw = inv_backward(winv, d_winv), gs = inv_backward(sinv, d_sinv);
+    for (int k = 0; k < 16; ++k) { a.gK[k] = (float)gk.m[k]; a.gW[k] = (float)gw.m[k]; a.gS[k] = (float)gs.m[k]; }
 }
 
 // ------------------------------------------------------------------------------------------------ depth gather
@@ -526,17 +567,17 @@ __global__ __launch_bounds__(256) void step_rays_fwd_kernel(StepRaysArgs a) {
 // W = c2w^-1 (inv4_bwd), c2w = exp(r, t) (se3_exp_grad) -- and the full (n_cams, .) gradient tables written, zeros outside the frame's
 // row.  Replaces 4 launches + the ~10 tiny ATen kernels of the autograd of `where` / indexing in Learn_Distortion.
 constexpr int kStepBwdThreads = 512;   // 8 waves: 256 registers each (at 1024 threads the matrix chain spills 700 bytes per lane)
-constexpr int kStepBwdMaxBlocks = 16;  // partial slots in the scratch (NNR_STEP_BWD_SCRATCH_FLOATS = 16 + 16 * 16)
+constexpr int kStepBwdMaxBlocks = 16;  // partial slots in the scratch (NNR_STEP_BWD_SCRATCH_FLOATS = 16 + 2 * 16 * 16: the partial sums are doubles)
 __global__ __launch_bounds__(kStepBwdThreads) void step_rays_bwd_kernel(StepRaysArgs a) {
-    __shared__ float red[14][kStepBwdThreads / 64];
+    __shared__ double red[14][kStepBwdThreads / 64];
     __shared__ float park[4][16];
-    __shared__ float tot[16];
+    __shared__ double tot[16];
     __shared__ int is_last;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float acc[12];
+    double acc[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
-    float gs = 0.f, gh = 0.f;
+    for (int k = 0; k < 12; ++k) acc[k] = 0.;
+    double gs = 0., gh = 0.;
     M4 m;      // only the product survives the ray loop (six live 4x4 matrices per thread spill); thread 0 parks the others in LDS for
     {          // the chain rule at the end instead of rebuilding them there (the serial tail was two thirds of the kernel)
         M4 c2w, W, kinv, winv, sinv;
@@ -555,58 +596,32 @@ __global__ __launch_bounds__(kStepBwdThreads) void step_rays_bwd_kernel(StepRays
         float px, py, raw;
         step_pixel(a, i, px, py, raw);
         const float dep = a.shift_first ? __fmul_rn(__fadd_rn(raw, shift), scale) : __fadd_rn(__fmul_rn(raw, scale), shift);
-        float ray[3], gdir[3], gray[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) ray[c] = m.m[4 * c] * px + m.m[4 * c + 1] * py + m.m[4 * c + 2];
-        const float n = sqrtf(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
-        const float rn = 1.f / n;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float g = a.g_dir ? a.g_dir[3 * i + c] : 0.f;
-            if (a.use_dir && a.g_view) g -= a.g_view[3 * i + c];     // view = -dir
-            gdir[c] = g;
-        }
-        float gn = a.g_norm ? a.g_norm[i] : 0.f;                      // dL/d|ray|
-        float gdep = 0.f;
-        const float gd = a.g_dgt ? a.g_dgt[i] : 0.f;
-        const float sgn = dep > 0.f ? 1.f : (dep < 0.f ? -1.f : 0.f);
-        if (a.normalise) {
-            const float dot = (gdir[0] * ray[0] + gdir[1] * ray[1] + gdir[2] * ray[2]) * rn * rn;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gray[c] = (gdir[c] - ray[c] * dot) * rn;   // through ray / |ray|
-            if (gd != 0.f) { gn += gd * fabsf(dep); gdep = gd * n * sgn; }        // d_gt = |depth| |ray|
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gray[c] = gdir[c];
-            if (gd != 0.f) gdep = gd * sgn;                                        // d_gt = |depth| (the |ray| cancels)
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gray[c] += gn * ray[c] * rn;
+        const RayBack rb = ray_backward(m, px, py, dep, a.g_dir, a.g_view, a.g_norm, a.g_dgt, i, a.use_dir, a.normalise);
         // a non-finite raw depth (masked ray) carries a zero upstream gradient; keep 0 * inf out of the sums
-        if (gdep != 0.f) {
-            gs += a.shift_first ? gdep * (raw + shift) : gdep * raw;
-            gh += a.shift_first ? gdep * scale : gdep;
+        if (rb.gdep != 0.) {
+            gs += a.shift_first ? rb.gdep * ((double)raw + (double)shift) : rb.gdep * (double)raw;
+            gh += a.shift_first ? rb.gdep * (double)scale : rb.gdep;
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            acc[4 * c + 0] += gray[c] * px;
-            acc[4 * c + 1] += gray[c] * py;
-            acc[4 * c + 2] += gray[c];
-            acc[4 * c + 3] += a.g_o ? a.g_o[3 * i + c] : 0.f;
+            acc[4 * c + 0] += rb.gray[c] * px;
+            acc[4 * c + 1] += rb.gray[c] * py;
+            acc[4 * c + 2] += rb.gray[c];
+            acc[4 * c + 3] += a.g_o ? (double)a.g_o[3 * i + c] : 0.;
         }
     }
 #pragma unroll
     for (int k = 0; k < 14; ++k) {
-        float v = k < 12 ? acc[k] : (k == 12 ? gs : gh);
+        double v = k < 12 ? acc[k] : (k == 12 ? gs : gh);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
         if (lane == 0) red[k][wv] = v;
     }
     __syncthreads();
     // this workgroup's 14 sums (waves in index order) -> its partial slot; the last workgroup to arrive adds the slots in workgroup order
-    float* const slots = a.bwd_scratch + 16;
+    double* const slots = reinterpret_cast<double*>(a.bwd_scratch + 16);      // (the scratch comes from a device allocator: 8-byte aligned at + 64 bytes)
     if (threadIdx.x < 14) {
-        float t = 0.f;
+        double t = 0.;
         for (int w = 0; w < kStepBwdThreads / 64; ++w) t += red[threadIdx.x][w];
         slots[16 * blockIdx.x + threadIdx.x] = t;
     }
@@ -620,7 +635,7 @@ __global__ __launch_bounds__(kStepBwdThreads) void step_rays_bwd_kernel(StepRays
     if (!is_last) return;
     __threadfence();
     if (threadIdx.x < 14) {
-        float t = 0.f;
+        double t = 0.;
         for (unsigned int b = 0; b < gridDim.x; ++b) t += slots[16 * b + threadIdx.x];
         tot[threadIdx.x] = t;
     }
@@ -630,50 +645,50 @@ __global__ __launch_bounds__(kStepBwdThreads) void step_rays_bwd_kernel(StepRays
     __syncthreads();
     if (threadIdx.x != 0) return;
     *reinterpret_cast<unsigned int*>(a.bwd_scratch) = 0u;      // the ticket counter as the next call expects it
-    M4 dm;
+    M4d dm;
     for (int k = 0; k < 12; ++k) dm.m[k] = tot[k];
-    for (int k = 12; k < 16; ++k) dm.m[k] = 0.f;
-    float tot_s = tot[12], tot_h = tot[13];
+    for (int k = 12; k < 16; ++k) dm.m[k] = 0.;
+    double tot_s = tot[12], tot_h = tot[13];
     // dL/dM (12 sums) -> dL/dW through M = (S^-1 W^-1) K^-1, W^-1 = inv4(W); then W = inv4(c2w); then c2w = exp(r, t)
     const M4 kinv = load4(park[0]), winv = load4(park[1]), sinv = load4(park[2]), W = load4(park[3]);
-    const M4 d_sw = mul4(dm, transpose4(kinv));
-    const M4 d_winv = mul4(transpose4(sinv), d_sw);
-    M4 gw = inv_backward(winv, d_winv);                      // d loss / d world_mat
+    const M4d d_sw = mul4(dm, transpose4(kinv));
+    const M4d d_winv = mul4(transpose4(sinv), d_sw);
+    M4d gw = inv_backward(winv, d_winv);                      // d loss / d world_mat
     if (a.ref >= 0 && a.g_mats) {
         // the per-image losses' share (upstream gradient of mats[34, 55)): the relative transform chains into world_mat (and, unless the
         // reference side is detached -- training.detach_ref_img, the default -- into the reference pose), the pair's distortion entries
         // into the two cameras' rows
         const PairGeom pg = pair_geometry(a, W);
-        M4 g_rel;
-        for (int k = 0; k < 12; ++k) g_rel.m[k] = a.g_mats[34 + k];
-        for (int k = 12; k < 16; ++k) g_rel.m[k] = 0.f;
+        M4d g_rel;
+        for (int k = 0; k < 12; ++k) g_rel.m[k] = (double)a.g_mats[34 + k];
+        for (int k = 12; k < 16; ++k) g_rel.m[k] = 0.;
         const bool swap = a.cam == a.n_cams - 1;
-        M4 g_ref_rt;
+        M4d g_ref_rt;
         if (!swap) {      // rel = ref_rt inv(W)
             g_ref_rt = mul4(g_rel, transpose4(pg.other_inv));
-            const M4 g_winv = mul4(transpose4(pg.ref_rt), g_rel);
-            const M4 add = inv_backward(pg.other_inv, g_winv);
+            const M4d g_winv = mul4(transpose4(pg.ref_rt), g_rel);
+            const M4d add = inv_backward(pg.other_inv, g_winv);
             for (int k = 0; k < 16; ++k) gw.m[k] += add.m[k];
         } else {          // rel = W inv(ref_rt)
-            const M4 add = mul4(g_rel, transpose4(pg.other_inv));
+            const M4d add = mul4(g_rel, transpose4(pg.other_inv));
             for (int k = 0; k < 16; ++k) gw.m[k] += add.m[k];
-            const M4 g_inv = mul4(transpose4(W), g_rel);
+            const M4d g_inv = mul4(transpose4(W), g_rel);
             g_ref_rt = inv_backward(pg.other_inv, g_inv);
         }
-        const float g_s_in = a.g_mats[swap ? 52 : 50] + (swap ? a.g_mats[54] : 0.f), g_h_in = a.g_mats[swap ? 53 : 51];
-        const float g_s_ref = a.g_mats[swap ? 50 : 52] + (swap ? 0.f : a.g_mats[54]), g_h_ref = a.g_mats[swap ? 51 : 53];
+        const double g_s_in = (double)a.g_mats[swap ? 52 : 50] + (swap ? (double)a.g_mats[54] : 0.), g_h_in = a.g_mats[swap ? 53 : 51];
+        const double g_s_ref = (double)a.g_mats[swap ? 50 : 52] + (swap ? 0. : (double)a.g_mats[54]), g_h_ref = a.g_mats[swap ? 51 : 53];
         tot_s += g_s_in;
         tot_h += g_h_in;
         if (!a.detach_ref) {
-            const M4 g_c2w_ref = inv_backward(pg.ref_rt, g_ref_rt);
+            const M4d g_c2w_ref = inv_backward(pg.ref_rt, g_ref_rt);
             se3_exp_grad(a.r_all + 3 * a.ref, g_c2w_ref.m, a.d_r + 3 * a.ref, a.d_t + 3 * a.ref);
-            if (pg.ref_live) a.d_scales[a.ref] = g_s_ref;
-            a.d_shifts[a.ref] = g_h_ref;
+            if (pg.ref_live) a.d_scales[a.ref] = (float)g_s_ref;
+            a.d_shifts[a.ref] = (float)g_h_ref;
         }
     }
-    if (live) a.d_scales[a.cam] = tot_s;
-    a.d_shifts[a.cam] = tot_h;
-    const M4 gc = inv_backward(W, gw);                       // d loss / d c2w
+    if (live) a.d_scales[a.cam] = (float)tot_s;
+    a.d_shifts[a.cam] = (float)tot_h;
+    const M4d gc = inv_backward(W, gw);                       // d loss / d c2w
     se3_exp_grad(a.r_all + 3 * a.cam, gc.m, a.d_r + 3 * a.cam, a.d_t + 3 * a.cam);
 }
 
@@ -770,7 +785,7 @@ hipError_t launch_ray_setup_fwd(const RaySetupArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t launch_ray_setup_bwd(const RaySetupArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(ray_setup_bwd_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(ray_setup_bwd_kernel, dim3(1), dim3(512), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_step_rays_fwd(const StepRaysArgs& a, hipStream_t st) {

@@ -183,22 +183,26 @@ __global__ __launch_bounds__(256) void ray_reduce_kernel(RayReduceArgs a) {
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= a.R) return;
     const int64_t base = (int64_t)ray * a.N;
-    float o0 = 0, o1 = 0, o2 = 0, d0 = 0, d1 = 0, d2 = 0, v0 = 0, v1 = 0, v2 = 0;
+    // (summed in double and rounded once, like the rest of the way back to the pose: nnr_camera.hip, the note at M4T)
+    double s[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};      // d_pts_o, d_pts_d, d_view
     for (int j = lane; j < a.N; j += 64) {
         const f32x4 p = *reinterpret_cast<const f32x4*>(a.ws_dpts + 4 * (base + j));
         const f32x4 v = *reinterpret_cast<const f32x4*>(a.ws_dview + 4 * (base + j));
-        const float z = a.ws_z[base + j];
-        o0 += p[0]; o1 += p[1]; o2 += p[2];
-        d0 += z * p[0]; d1 += z * p[1]; d2 += z * p[2];
-        v0 += v[0]; v1 += v[1]; v2 += v[2];
+        const double z = a.ws_z[base + j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { s[c] += (double)p[c]; s[3 + c] += z * (double)p[c]; s[6 + c] += (double)v[c]; }
     }
-    o0 = wave_sum(o0); o1 = wave_sum(o1); o2 = wave_sum(o2);
-    d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
-    v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s[k] += __shfl_xor(s[k], d, 64);
     if (lane == 0) {
-        a.d_pts_o[3 * ray] = o0; a.d_pts_o[3 * ray + 1] = o1; a.d_pts_o[3 * ray + 2] = o2;
-        a.d_pts_d[3 * ray] = d0; a.d_pts_d[3 * ray + 1] = d1; a.d_pts_d[3 * ray + 2] = d2;
-        a.d_view[3 * ray] = v0; a.d_view[3 * ray + 1] = v1; a.d_view[3 * ray + 2] = v2;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.d_pts_o[3 * ray + c] = (float)s[c];
+            a.d_pts_d[3 * ray + c] = (float)s[3 + c];
+            a.d_view[3 * ray + c] = (float)s[6 + c];
+        }
     }
 }
 

@@ -54,7 +54,7 @@ LAYER_NAMES = ("layers0.0", "layers0.2", "layers0.4", "layers0.6", "layers1.0", 
 # stage overwrites nnr_param_grads instead of accumulating into it.  4: nnr_ws_plane_layout; the gradient planes of a three-term training workspace
 # are tile-major fp32.  5: nnr_adam_table.flavour / bc2_sqrt -- torch's single-tensor Adam arithmetic beside the fused one; nnr_step_cfg.ref + g_mats: the frame pair of the
 # per-image losses in the fused front end; nnr_aux_terms_*: `aff`, the depth distortion applied in the kernels)
-ABI_VERSION = 5
+ABI_VERSION = 6
 EXPORTS = ("nnr_abi_version", "nnr_strerror", "nnr_last_hip_error", "nnr_packed_floats", "nnr_workspace_floats",
            "nnr_plan_bytes", "nnr_plan_counts", "nnr_plan_build", "nnr_pack_weights", "nnr_render_fwd", "nnr_render_bwd", "nnr_ws_plane",
            "nnr_ws_plane_layout",
@@ -88,7 +88,7 @@ class StepCfg(C.Structure):        # nnr_step_cfg: the fused front end of a trai
 
 
 STEP_NORMALISE, STEP_USE_DIR, STEP_SHIFT_FIRST, STEP_FIX_LAST_SCALE, STEP_DETACH_REF = 1, 2, 4, 8, 16
-STEP_BWD_SCRATCH_FLOATS = 272      # NNR_STEP_BWD_SCRATCH_FLOATS
+STEP_BWD_SCRATCH_FLOATS = 528      # NNR_STEP_BWD_SCRATCH_FLOATS
 
 
 class WgradJobB(C.Structure):      # bf16 training mode: one workgroup job (nnr_layout.h)

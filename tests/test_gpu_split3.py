@@ -142,10 +142,14 @@ def test_three_term_products_are_as_close_to_fp64_as_fp32_mfmas(D, capsys):
             # to fp64 than the CPU oracle --; worst single tensor over the four seeds 4.2 - 4.8 (heavy-tailed: one gate decides a tensor)
             assert overall[kind] <= 1.5, (D, kind, overall[kind])
             # (12 seeds, profiles/r05/d_gpu_tests.txt: overall 0.49 / 0.44 at D = 256, 0.43 / 0.44 at D = 128; worst tensor 2.0 / 1.6 and 2.6 / 2.65)
-            assert worst[kind][1] <= 5.0, (D, kind, worst[kind])
-            # the median over the seeds is what one gate cannot move: measured 1.95 / 2.04 (the pose gradients, D = 256) and 1.14 / 1.18 -- every
-            # tensor's typical distance to fp64 within 2.5x of the CPU oracle's own
-            assert worst_med[kind][1] <= 2.5, (D, kind, worst_med[kind])
+            # (round 6, profiles/r06/n_yardstick_double_inv4.txt: overall 0.47-0.49 / 0.42-0.47; worst tensor 2.36 / 1.8-2.0)
+            assert worst[kind][1] <= 4.0, (D, kind, worst[kind])
+            # the median over the seeds is what one gate cannot move.  Rounds 4-5: 1.95-2.35, the pose rotation and layers0.6.weight, in EVERY
+            # product mode.  Round 6 bisected it (profiles/r06/h_*, k_, l_, m_, n_): the render operator is at or below 1.0 stage by stage down to
+            # the per-ray gradients and their rigid-motion sums; double compositing / front-end backward moved nothing (2.30 -> 2.35); the 4 x 4
+            # inverses of the FORWARD ray generation evaluated by fp32 cofactors did -- 1e-7 of the ray origin, times the 2^9 encoding
+            # frequency, in every gradient.  With the cofactors in double (nnr_camera.hip inv4): 1.37 at D = 256, 1.55 at D = 128.  Bar 2.0
+            assert worst_med[kind][1] <= 2.0, (D, kind, worst_med[kind])
 
 
 @pytest.mark.parametrize("kind", SPLIT_KINDS)

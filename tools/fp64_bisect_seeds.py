@@ -41,8 +41,20 @@ def main():
         ref = fb.trace(*args, torch.float64)
         cpu = fb.trace(*args, torch.float32)
         rl2 = lambda got, r: float((got.reshape(r.shape) - r).norm()) / max(float(r.norm()), 1e-300)
+        # what a rigid motion of the camera sees of the three per-ray gradients (the chain rule of a rotation w and a translation t at the
+        # identity: dL/dw = sum over rays of v x g for every vector v that turns with the camera, dL/dt = sum of g_o), formed in double from
+        # each evaluation's own per-ray gradients: is an excess in the POSE gradients inherited (errors that do not cancel over the rays)?
+        def rigid(tr):
+            o, dd, vv = pts_o.double(), pts_d.double(), view.double()
+            tr["rigid rotation"] = (torch.cross(o, tr["d pts_o"].reshape(R, 3), dim=1) + torch.cross(dd, tr["d pts_d"].reshape(R, 3), dim=1)
+                                    + torch.cross(vv, tr["d view"].reshape(R, 3), dim=1)).sum(0)
+            tr["rigid translation"] = tr["d pts_o"].reshape(R, 3).sum(0)
+            tr["sum over rays d pts_d"] = tr["d pts_d"].reshape(R, 3).sum(0)
+        rigid(ref)
+        rigid(cpu)
         for kind in kinds:
             hip = fb.hip(*args, D, kind)
+            rigid(hip)
             for k, r in ref.items():
                 c, h = rl2(cpu[k], r), rl2(hip[k], r)
                 ratios[kind].setdefault(k, []).append(h / max(c, 1e-12))
