@@ -79,38 +79,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_variant(name, defines):
-    """Profiling-only library with compile-time ablations (e.g. -DNNR_ABLATE_NO_STASH); results are NOT valid.
-    Written to nnr/libnnr_<name>.so and selected with NNR_LIB=<path> (see nnr/lib.py)."""
+def build_variant(name, defines, only=None):
+    """Profiling-only library nnr/libnnr_<name>.so with compile-time switches (-DNNR_ABLATE=<bits>, -DNNR_TIMELINE: nnr_device.h); results
+    of such a build are NOT valid.  `only`: a substring of the source names to recompile (e.g. "_f16": the fp16-term kernels, minutes instead
+    of the whole library); every other object comes from the main build.  Selected at run time with NNR_LIB=<path> (nnr/lib.py)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = os.path.join(os.path.dirname(HERE), "nnr", "libnnr_%s.so" % name)
     tmp = os.path.join(OUT_DIR, "variant_" + name)
     os.makedirs(tmp, exist_ok=True)
-    jobs = [[hipcc] + FLAGS + ["-D" + d for d in list(defines) + list(extra)] + ["-c", os.path.join(HERE, src), "-o", os.path.join(tmp, _obj_name(src, extra))]
-            for src, extra in SOURCES]
-
-    def run(cmd):
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(r.stderr)
-        if not any(d.startswith("NNR_ABLATE") or d == "NNR_TIMELINE" for d in defines):
-            check_resources(r.stderr, name)
-
-    with ThreadPoolExecutor(max_workers=WORKERS) as ex:
-        list(ex.map(run, jobs))
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [j[-1] for j in jobs])
-    return out
-
-
-def build_split_variant(name, defines):
-    """Experiment library: only the D = 256 three-term kernels are recompiled with `defines`, everything else comes from the main build."""
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    out = os.path.join(os.path.dirname(HERE), "nnr", "libnnr_%s.so" % name)
-    tmp = os.path.join(OUT_DIR, "variant_" + name)
-    os.makedirs(tmp, exist_ok=True)
-    mine = [(src, d) for src, d in SOURCES if any(x.endswith("MODE=2") for x in d) and any(x.endswith("_D=256") for x in d)]
-    if any(x.startswith("NNR_ABLATE_WGRAD") for x in defines):
-        mine = [(src, d) for src, d in SOURCES if src == "nnr_wgrad.hip"]
+    mine = [(src, d) for src, d in SOURCES if only is None or only in src]
     jobs = [[hipcc] + FLAGS + ["-D" + d for d in list(defines) + list(d0)] + ["-c", os.path.join(HERE, src), "-o", os.path.join(tmp, _obj_name(src, d0))]
             for src, d0 in mine]
 
@@ -123,46 +100,6 @@ def build_split_variant(name, defines):
         list(ex.map(run, jobs))
     objs = [os.path.join(tmp if (src, d) in mine else OUT_DIR, _obj_name(src, d)) for src, d in SOURCES]
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
-    return out
-
-
-def build_f16_variant(name, defines):
-    """Experiment library: only the D = 256 fp16-term kernels (nnr_mlp_fwd_f16.hip x 2, nnr_mlp_dgrad_f16.hip) are recompiled with `defines`
-    (profiling / A-B switches: results of NNR_ABLATE_* builds are NOT valid), everything else comes from the main build."""
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    out = os.path.join(os.path.dirname(HERE), "nnr", "libnnr_%s.so" % name)
-    tmp = os.path.join(OUT_DIR, "variant_" + name)
-    os.makedirs(tmp, exist_ok=True)
-    mine = [(src, d) for src, d in SOURCES if "_f16" in src and any(x.endswith("_D=256") for x in d)]
-    jobs = [[hipcc] + FLAGS + ["-D" + d for d in list(defines) + list(d0)] + ["-c", os.path.join(HERE, src), "-o", os.path.join(tmp, _obj_name(src, d0))]
-            for src, d0 in mine]
-
-    def run(cmd):
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(r.stderr)
-
-    with ThreadPoolExecutor(max_workers=WORKERS) as ex:
-        list(ex.map(run, jobs))
-    objs = [os.path.join(tmp if (src, d) in mine else OUT_DIR, _obj_name(src, d)) for src, d in SOURCES]
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
-    return out
-
-
-def build_ws_variant(name, defines, source="nnr_mlp_fwd_ws.hip"):
-    """Experiment library: only `source` is recompiled with `defines` (profiling / A-B switches: not the product)."""
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    out = os.path.join(os.path.dirname(HERE), "nnr", "libnnr_%s.so" % name)
-    tmp = os.path.join(OUT_DIR, "variant_" + name)
-    os.makedirs(tmp, exist_ok=True)
-    obj = os.path.join(tmp, source.replace(".hip", ".o"))
-    r = subprocess.run([hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(HERE, source), "-o", obj], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(r.stderr)
-    objs = [obj if src == source else os.path.join(OUT_DIR, _obj_name(src, d)) for src, d in SOURCES]
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(r.stderr)
     return out
 
 
@@ -207,13 +144,11 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--f16-variant":        # build.py --f16-variant nosync NNR_ABLATE_NO_SYNC
-        print(build_f16_variant(sys.argv[2], sys.argv[3:]))
-    elif len(sys.argv) > 2 and sys.argv[1] == "--ws-variant":         # build.py --ws-variant nobar NNR_WS_NO_BARRIER
-        print(build_ws_variant(sys.argv[2], sys.argv[3:]))
-    elif len(sys.argv) > 2 and sys.argv[1] == "--split-variant":    # build.py --split-variant safesync NNR_SPLIT_SAFE_SYNC
-        print(build_split_variant(sys.argv[2], sys.argv[3:]))
-    elif len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant nostash NNR_ABLATE_NO_STASH [...]
-        print(build_variant(sys.argv[2], sys.argv[3:]))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant noside [--only _f16] NNR_ABLATE=1
+        rest = sys.argv[3:]
+        only = None
+        if rest and rest[0] == "--only":
+            only, rest = rest[1], rest[2:]
+        print(build_variant(sys.argv[2], rest, only))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

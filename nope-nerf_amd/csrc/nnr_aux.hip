@@ -694,9 +694,6 @@ __global__ __launch_bounds__(64 * kPcTileWaves) void aux_pc_search_tile_kernel(A
     const int my_slot = 12 * (lane >> 2) + ((lane & 3) >> 1) * 6 + (lane & 1);      // point l of the tile: group l / 4, pair (l & 3) / 2, half l & 1: x at +0, y at +2, z at +4
     // does any lane need tile (ty, tx)?  (its window meets the tile and the tile's sphere comes within its running minimum)
     auto needed = [&](int ty, int tx) __attribute__((always_inline)) {
-#ifdef NNR_PC_DEBUG
-        if (lane == 0) atomicAdd(a.acc + 6, 1.f);
-#endif
         const f32x4 sp = sph_in_lds ? sph_lds[ty * tiles_x + tx] : sph_g[ty * tiles_x + tx];
         const float ex = sxx - sp[0], ey = syy - sp[1], ez = szz - sp[2];
         const float lb = sqrtf(ex * ex + ey * ey + ez * ez) * 0.999998f - sp[3];      // no point of the tile is closer than this
@@ -745,9 +742,6 @@ __global__ __launch_bounds__(64 * kPcTileWaves) void aux_pc_search_tile_kernel(A
             if (k < n_regs && lbk[k] < m) { m = lbk[k]; km = k; }
         const float wm = wave_reduce<false>(m);
         if (!(wm < inf)) break;      // nothing left
-#ifdef NNR_PC_DEBUG
-        if (lane == 0) atomicAdd(a.acc + 4, 1.f);
-#endif
         if (stale || (turn & 7) == 7) {      // (every few turns anyway: the other waves lower the shared minima too)
             window();                        // cap and the windows for the minima as they stand
             rho_max = wave_reduce<true>(live ? fminf(best_s, cap) : 0.f);
@@ -766,9 +760,6 @@ __global__ __launch_bounds__(64 * kPcTileWaves) void aux_pc_search_tile_kernel(A
         if (!needed(ty, tx)) continue;
         float q[3];
         fetch(ty, tx, q);
-#ifdef NNR_PC_DEBUG
-        if (lane == 0) atomicAdd(a.acc + 5, 1.f);
-#endif
         __builtin_amdgcn_wave_barrier();      // (the previous tile's reads are done: one wave, LDS operations in order)
         imgf[my_slot] = q[0]; imgf[my_slot + 2] = q[1]; imgf[my_slot + 4] = q[2];
         __builtin_amdgcn_wave_barrier();

@@ -16,18 +16,16 @@
 // moves a ray by an ulp, an ulp flips a ReLU gate somewhere in 6 000 samples, and the smallest network gradients then differ by 0.4 %
 // between the two front ends (tests/test_gpu_camera.py caught exactly that when round 5 added code to the fused kernel).  These kernels
 // are latency-bound bookkeeping; the reference's own ATen ops round every product and sum separately.
-#ifndef NNR_CAMERA_CONTRACT      /* (the A/B build of profiles/r05/g_conv_first_steps_contraction.txt lets the compiler contract) */
 #pragma clang fp contract(off)
-#endif
 
 namespace nnr {
 
 // ------------------------------------------------------------------------------------------------ 4x4 helpers
 // The forward evaluates in float, as the reference's ATen ops do (the rays must be the reference's rays).  Every BACKWARD of this file
 // evaluates in double from those float values and rounds its results once: the pose gradient is a sum over all rays of terms that cancel
-// to ~1e-3 of their magnitude, and against an fp64 evaluation of the step the float chain sat at 2.3x the CPU oracle's own distance in the
-// median of 12 seeds (profiles/r06/k_yardstick_double_composite.txt) while everything upstream of it was at or below 1x.  These kernels
-// are a few microseconds of latency-bound work; the double rate is not what they wait on.
+// to ~1e-3 of their magnitude, so the way back adds no rounding of its own.  (It is NOT what holds the pose gradients at 2.3x the CPU oracle's
+// distance to fp64 in the 12-seed yardstick -- 2.30 before, 2.35 after, profiles/r06/k_ / l_yardstick_*.txt; that is the forward inverse
+// below.)  These kernels are a few microseconds of latency-bound work; the double rate is not what they wait on.
 template <typename T> struct M4T { T m[16]; };
 using M4 = M4T<float>;
 using M4d = M4T<double>;
@@ -56,18 +54,16 @@ __device__ __forceinline__ M4T<T> transpose4(const M4T<T>& a) {
         for (int j = 0; j < 4; ++j) c.m[4 * i + j] = a.m[4 * j + i];
     return c;
 }
-// general 4x4 inverse by cofactors (adjugate / determinant), evaluated in double and rounded once: a cofactor is six triple products that
-// cancel, and the rays inherit every ulp of these matrices through a 2^9 position-encoding frequency (NNR_CAMERA_INV_F32: the float
-// evaluation of rounds 1-5, for the A/B of profiles/r06/n_*)
+// general 4x4 inverse by cofactors (adjugate / determinant), in float like the reference's torch.inverse.
+// Round 6 measured the alternative -- the same cofactors evaluated in double and rounded once (profiles/r06/n_yardstick_double_inv4.txt): against an
+// fp64 evaluation of the step the worst per-tensor median of HIP / CPU-fp32 drops from 2.35 to 1.37 (a cofactor is six triple products that
+// cancel, and the rays carry every ulp of these matrices through the 2^9 encoding frequency into every gradient: this IS the tail of that
+// yardstick, nothing downstream is).  But the reference inverts in float too (LAPACK's LU on the CPU, MAGMA's on the GPU), and the exactly
+// rounded inverse is FURTHER from what it computes than these cofactors are: golden noraydir_relu_d128 pose_r 1.02e-4 against the 1e-4 bar, first-20-step
+// deviation of the training run 5.2e-4 against 2.5e-4 (profiles/r06/p_*).  Parity with the reference is the gate; float stays.
 __device__ __forceinline__ M4 inv4(const M4& a) {
-#ifdef NNR_CAMERA_INV_F32
     const float* m = a.m;
     float inv[16];
-#else
-    double m[16], inv[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) m[i] = (double)a.m[i];
-#endif
     inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
     inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
     inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
@@ -84,16 +80,11 @@ __device__ __forceinline__ M4 inv4(const M4& a) {
     inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
     inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
     inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
-#ifdef NNR_CAMERA_INV_F32
     const float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
     const float rdet = 1.0f / det;
-#else
-    const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
-    const double rdet = 1.0 / det;
-#endif
     M4 r;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) r.m[i] = (float)(inv[i] * rdet);
+    for (int i = 0; i < 16; ++i) r.m[i] = inv[i] * rdet;
     return r;
 }
 __device__ __forceinline__ M4 load4(const float* p) {

@@ -17,7 +17,14 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// ---- profiling builds only (-DNNR_TIMELINE): shader-clock stamps of one mid-grid wave, read back with nnr_timeline_* ----
+// ---- profiling builds only.  -DNNR_ABLATE=<bits> switches parts of the MLP kernels off to price them (results are NOT valid; the product
+// build has it 0): 1 = no side work between the MFMAs (epilogue units, splits, stash stores), 2 = no LDS-DMA of weight panels, 4 = no
+// waits / barriers on the panel pipe, 8 = no stash stores.  The other experiment switches of rounds 2-6 (rejected variants and their A/B
+// macros) are out of the sources: tools/experiments/README.md lists them with the commit that last carried each.
+#ifndef NNR_ABLATE
+#define NNR_ABLATE 0
+#endif
+// -DNNR_TIMELINE: shader-clock stamps of one mid-grid wave, read back with nnr_timeline_*
 #ifdef NNR_TIMELINE
 #define NNR_TL_DECL(name) __device__ unsigned long long name[32];
 #define NNR_STAMP(name, i)                                                                      \
@@ -85,7 +92,7 @@ struct PanelPipeT {
     // exactly 8 per panel -- the counted wait below relies on it.  With a uniform base the address is
     // SGPR base + lane*16 and the LDS destination (M0) is scalar: no VALU work per piece.
     __device__ __forceinline__ void piece(int p, int i) const {
-#ifdef NNR_ABLATE_NO_DMA
+#if NNR_ABLATE & 2
         return;
 #endif
         // One address pair per PANEL (global: VGPRs, LDS: M0), both pointing at piece 4; the piece is selected by the
@@ -123,7 +130,7 @@ struct PanelPipeT {
     // recent ones here stalls the matrix pipe behind HBM write latency).
     template <int EXTRA = 0>
     __device__ __forceinline__ void enter(int p) const {
-#ifdef NNR_ABLATE_NO_SYNC
+#if NNR_ABLATE & 4
         return;
 #endif
         static_assert(PW + EXTRA < 64, "vmcnt is a 6-bit field");
@@ -207,7 +214,7 @@ struct NoSide {
 template <int KT, int MT, bool STASH, int NSIDE_, int PPG, int SHIFT, class Side, int NACC, int NIN>
 __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const PanelPipe& pipe, int p0,
                                           float* stash, const Side& side) {
-#ifdef NNR_ABLATE_NO_SIDE
+#if NNR_ABLATE & 1
     constexpr int NSIDE = 0;   // profiling build only
 #else
     constexpr int NSIDE = NSIDE_;
@@ -235,16 +242,12 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                         const int pn = p0 + (g + 1) / GP;
                         // panel switch inside the part: the stores of this panel's earlier k-groups are younger than
                         // the pieces waited for
-#ifdef NNR_ABLATE_VMCNT8
-                        if (f == 0 && (g + 1) % GP == 0) pipe.template enter<0>(pn);
-#else
                         if (f == 0 && (g + 1) % GP == 0) pipe.template enter<STASH ? GP - 1 : 0>(pn);
-#endif
                         const f32x4* buf = pipe.lds + pipe.buffer(pn) * kPanelF4 + pipe.lane;
                         nxt.v[f] = buf[(((g + 1) % GP) * MT + f) * 64];
                     }
                 } else if (f == MT) {
-#ifndef NNR_ABLATE_NO_STASH
+#if !(NNR_ABLATE & 8)
                     if constexpr (STASH)
                         *reinterpret_cast<f32x4*>(stash + 8 * g) = f32x4{in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]};
 #endif

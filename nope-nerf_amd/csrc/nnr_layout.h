@@ -32,13 +32,9 @@ constexpr int kChunk = 32;         // samples per wave
 constexpr int kWavesPerBlock = 4;  // one wave per SIMD
 constexpr int kBlockSamples = kChunk * kWavesPerBlock;
 // Shape of the bf16 MLP kernels (nnr_mlp_bf16.h): 32-sample chunks per wave x waves per workgroup = 256 samples.  2 x 4 is the
-// product; -DNNR_BF16_TILES=1 builds the 1 x 8 shape (two waves per SIMD) for comparison: measured slower, 0.82 / 0.78 ms against
-// 0.77 / 0.68 ms (forward / input gradient, 4096 x 128) -- twice the LDS reads and DMA instructions per MFMA outweigh what the second
-// wave hides of the epilogue.
-#ifndef NNR_BF16_TILES
-#define NNR_BF16_TILES 2
-#endif
-constexpr int kBf16Tiles = NNR_BF16_TILES, kBf16Waves = 8 / kBf16Tiles;
+// product; the 1 x 8 shape (kBf16Tiles = 1: two waves per SIMD) measured slower, 0.82 / 0.78 ms against 0.77 / 0.68 ms (forward / input
+// gradient, 4096 x 128) -- twice the LDS reads and DMA instructions per MFMA outweigh what the second wave hides of the epilogue.
+constexpr int kBf16Tiles = 2, kBf16Waves = 8 / kBf16Tiles;
 static_assert(kBf16Tiles == 1 || kBf16Tiles == 2, "one or two chunks per wave");
 constexpr int kPosLevels = 10, kDirLevels = 4;  // hard-wired in the reference (model/official_nerf.py:61,87)
 constexpr int kPosReal = 63, kDirReal = 27;     // (2L+1)*3
@@ -232,21 +228,13 @@ NNR_HD constexpr int64_t tile_major_index(int64_t s, int f, int G) {
 // kernel is then ONE contiguous, non-temporal 1 KiB wave-store (8 whole cache lines that go past the L2 instead of evicting the weight
 // stream from it) where the row-major plane took 16 bytes into each of 64 lines: 1.07 -> 0.88 ms for that kernel
 // (profiles/r04/a_stash_variants.txt).  The weight-gradient kernel fetches 64-byte runs of such blocks by LDS-DMA (nnr_wgrad.hip).
-#ifdef NNR_ROWMAJOR_DPLANES      // A/B builds (csrc/build.py --variant): the round-3 layout, row-major gradient planes
-constexpr bool kTileGradPlanes = false;
-#else
 constexpr bool kTileGradPlanes = true;
-#endif
 // The ACTIVATION planes (P_XE, P_XH1.., P_XF, P_XG) of the three-term training workspace are tile-major too (same blocks, written by the
 // forward's stash stores).  The first measurement said the forward does not gain from it (1.185 against 1.108 ms): that experiment
 // library had compiled its forward with 183 scratch reloads, every one a full drain of the store queue (an extra address register per
 // store) -- found only at the end of round 4, when a build WITHOUT the weight DMA ran the training forward at the inference forward's
 // time (0.85 ms): what the row-major stores cost is the 64 cache lines each of them touches in the address path the weight DMA shares.
-#ifdef NNR_ROWMAJOR_XPLANES
-constexpr bool kTileActPlanes = false;
-#else
 constexpr bool kTileActPlanes = true;
-#endif
 NNR_HD constexpr int64_t tile32_index(int64_t s, int f, int W) {
     return (((s >> 5) * (W >> 3) + (f >> 3)) << 8) + ((((f >> 2) & 1) * 32 + (s & 31)) << 2) + (f & 3);
 }

@@ -25,10 +25,7 @@ namespace nnr {
 //                 its issue time).
 // Either way a workgroup covers 256 samples per pass.
 constexpr int kMaxTiles = 2;
-#ifndef NNR_DMA_BURST
-#define NNR_DMA_BURST 4
-#endif
-constexpr int kDmaBurst = NNR_DMA_BURST;   // DMA pieces (1 KiB each) a wave issues per row until the 8 of a panel are out
+constexpr int kDmaBurst = 4;   // DMA pieces (1 KiB each) a wave issues per row until the 8 of a panel are out
 constexpr int kWideSamples = 256;   // samples per workgroup and pass (T * 32 * W)
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -99,10 +96,8 @@ __device__ __forceinline__ bf16x8 row_operand(const uint32_t (&in)[NIN], int g) 
 // 0.88 -> 0.75 ms (with the row-major planes of round 1, 16 bytes per line and instruction, the same hint made things worse).
 template <class V>
 __device__ __forceinline__ void stash_store(void* dst, V v) {
-#if defined(NNR_ABLATE_NO_STASH)
+#if NNR_ABLATE & 8
     (void)dst; (void)v;      // profiling builds only
-#elif defined(NNR_STASH_TEMPORAL)
-    *reinterpret_cast<V*>(dst) = v;
 #else
     __builtin_nontemporal_store(v, reinterpret_cast<V*>(dst));
 #endif
@@ -116,10 +111,7 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t p) {
     return r;
 }
 
-#ifndef NNR_UNIT_PHASES
-#define NNR_UNIT_PHASES 1
-#endif
-constexpr int kPh = NNR_UNIT_PHASES;   // epilogue units issued whole (1) or as two half-units in different MFMA gaps (2)
+constexpr int kPh = 1;   // epilogue units issued whole (1) or as two half-units in different MFMA gaps (2)
 
 // ---- ReLU gates of the training mode, one bit per value, in the layout the input-gradient kernel's select wants ---------------------
 // A mask word covers 16 consecutive packed registers (32 values) of a lane: the gate of the LOW value of pair j sits at bit 15 - j, of
@@ -215,11 +207,8 @@ __device__ __forceinline__ void gate2_at(uint32_t& d0, uint32_t& d1, uint32_t w0
 }
 // MEASURED (profiles/r03/i_pairs_ab.txt, 4096 x 128): forward 0.771 / 0.775 ms paired vs 0.745 / 0.776 unpaired, input gradient 0.601 /
 // 0.611 vs 0.602 / 0.610 -- no difference beyond the box's run-to-run spread.  The dependent chain is NOT what makes the side work
-// expensive; the product keeps the one-statement-per-pair units and this form stays behind -DNNR_UNIT_PAIRS=1 as a recorded negative.
-#ifndef NNR_UNIT_PAIRS
-#define NNR_UNIT_PAIRS 0
-#endif
-constexpr bool kPairs = NNR_UNIT_PAIRS != 0;
+// expensive; the product keeps the one-statement-per-pair units and this form stays behind kPairs as a recorded negative.
+constexpr bool kPairs = false;
 
 __device__ __forceinline__ uint32_t sel_pair(float x0, float x1, uint32_t word, int j) {   // j folds after unrolling
     switch (j) {
@@ -230,11 +219,7 @@ __device__ __forceinline__ uint32_t sel_pair(float x0, float x1, uint32_t word, 
         default: return pack_gated<15>(x0, x1, word);
     }
 }
-#ifdef NNR_SPLIT_ASM        // profiling builds only: the epilogue as separate asm statements (the A/B of the fused ones)
-constexpr bool kSplitAsm = true;
-#else
 constexpr bool kSplitAsm = false;
-#endif
 
 // ---- weight fragments: LDS reads the compiler does not see ------------------------------------------------------------------
 // hipcc waits lgkmcnt(0) before the first MFMA that uses a fragment it loaded itself -- i.e. for EVERY outstanding LDS read, also the
@@ -309,7 +294,7 @@ template <int KT, int MT, bool STASH, int NSIDE_, int PPG, int SHIFT, int PRE, c
 __device__ __forceinline__ void gemm_wide(f32x16 (&acc)[T][NACC], const uint32_t (&in)[T][NIN], const Pipe& pipe, int p0,
                                           __bf16* const (&stash)[T], const Side& side) {
     constexpr int kTiles = T, PW = Pipe::PW;
-#ifdef NNR_ABLATE_NO_SIDE
+#if NNR_ABLATE & 1
     constexpr int NSIDE = 0;   // profiling build only
 #else
     constexpr int NSIDE = NSIDE_;

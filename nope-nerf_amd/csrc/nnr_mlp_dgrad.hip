@@ -102,11 +102,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(MlpDgradArgs a) {
     const int64_t chunk = a.chunks_per_ray > 0 ? ((int64_t)blockIdx.x * kWavesPerBlock + wave) * n_pass + pass
                                                 : (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const int64_t s = chunk * kChunk + col;
-#ifdef NNR_ABLATE_STASH_L2
-    const int64_t ss = s & 127;   // profiling build only: every stash store hits the same 128 rows (L2-resident)
-#else
     const int64_t ss = s;         // row of the stash planes
-#endif
     const bool live = s < a.S;  // padded samples carry zero gradients so they add nothing to the weight gradients
     const uint32_t* mask_base = a.ws_mask + ((chunk * L::n_mask_layers) * 64 + lane) * L::mask_words;
 

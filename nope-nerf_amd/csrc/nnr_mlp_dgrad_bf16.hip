@@ -130,11 +130,7 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_dgrad_bf16_kernel(MlpDgradArgs 
             const uint32_t* m = a.ws_mask + (((int64_t)opaque_uniform(chunk[n]) * L::n_mask_layers + layer_idx) * 64 + lane_id()) * L::mask_words + hb * HW;
 #pragma unroll
             for (int w = 0; w < HW; ++w) {
-#ifdef NNR_ABLATE_NO_MASKLOAD
-                mw[n][w] = 0xffffffffu ^ (uint32_t)(size_t)m * 0u;     // profiling build only: every gate open, no load
-#else
                 mw[n][w] = m[w];
-#endif
             }
         }
     };

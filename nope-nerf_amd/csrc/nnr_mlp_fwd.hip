@@ -17,11 +17,7 @@
 
 namespace nnr {
 
-#ifdef NNR_ABLATE_NO_MASK
-constexpr bool kAblateNoMask = true;   // profiling build only
-#else
 constexpr bool kAblateNoMask = false;
-#endif
 
 NNR_TL_DECL(tl_fwd)
 
@@ -69,11 +65,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
                                                    : (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const int64_t s = chunk_id * kChunk + col;                                     // this lane's sample
     const int64_t sc = s < a.S ? s : a.S - 1;                                      // clamp: padded samples recompute the last one
-#ifdef NNR_ABLATE_STASH_L2
-    const int64_t ss = s & 127;   // profiling build only: every stash store hits the same 128 rows (L2-resident)
-#else
     const int64_t ss = s;         // row of the stash planes
-#endif
     const int ray = (int)(sc / a.N);
     const int j = (int)(sc - (int64_t)ray * a.N);
 

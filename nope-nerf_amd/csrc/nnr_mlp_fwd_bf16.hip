@@ -11,16 +11,8 @@
 namespace nnr {
 
 NNR_TL_DECL(tl_fwd16)
-#ifdef NNR_ABLATE_NO_MASK
-constexpr bool kAblateMask = true;    // profiling builds only
-#else
 constexpr bool kAblateMask = false;
-#endif
-#ifdef NNR_ABLATE_NO_ENCSTASH
-constexpr bool kAblateEncStash = true;
-#else
 constexpr bool kAblateEncStash = false;
-#endif
 #ifdef NNR_TIMELINE
 __device__ unsigned long long tl_fwd16_all[3 * 4096];   // per workgroup: start, end (s_memtime), HW_ID
 #endif

@@ -52,12 +52,24 @@ __global__ __launch_bounds__(256) void merge_kernel(PackArgs a) {
 // inverse.  One workgroup per slot; slots 0..7 = hidden 1..8, slot 8 = the merged colour matrix W' (formed by merge_kernel before this launch)
 // together with all of param 10 (a superset of its direction columns).  An all-zero slot gets s = 1.
 template <int D>
-__global__ __launch_bounds__(256) void scale_kernel(PackArgs a) {
+__global__ __launch_bounds__(1024) void scale_kernel(PackArgs a) {
     using L = Layout<D, 3>;
     const int slot = blockIdx.x;
     float m = 0.f;
+    // (1024 lanes x 16-byte loads: the kernel runs in front of every forward; with 256 lanes and scalar loads the skip layer's 82 k weights
+    // took 53 us, 2 % of the training step -- profiles/r06/o_bench_headline_only_kernel_stats.csv.  Every tensor's size is a multiple of 4
+    // and the merged matrix sits at a multiple of 4 floats; a parameter the caller keeps at an odd offset of some flat buffer takes scalar loads.)
+    static_assert(L::merged_w_off % 4 == 0 && (L::Dh * D) % 4 == 0 && (D * kPosReal) % 4 == 0 && (L::Dh * (D + kDirReal)) % 4 == 0, "16-byte loads");
     auto scan = [&](const float* w, int n) {
-        for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+        if ((reinterpret_cast<uintptr_t>(w) & 15) != 0) {
+            for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(w[i]));
+            return;
+        }
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+        for (int i = threadIdx.x; i < n / 4; i += 1024) {
+            const f32x4 v = w4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
     };
     if (slot < 8) {
         const int in = slot == 0 ? kPosReal : (slot == 4 ? D + kPosReal : D);
@@ -68,10 +80,10 @@ __global__ __launch_bounds__(256) void scale_kernel(PackArgs a) {
         scan(a.packed + L::merged_w_off, L::Dh * D);
         scan(a.w[10], L::Dh * (D + kDirReal));
     }
-    __shared__ float red[256];
+    __shared__ float red[1024];
     red[threadIdx.x] = m;
     __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
+    for (int d = 512; d >= 1; d >>= 1) {
         if ((int)threadIdx.x < d) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + d]);
         __syncthreads();
     }
@@ -208,7 +220,7 @@ static hipError_t launch(const PackArgs& a0, hipStream_t st) {
     a.w[kMergedLayer] = a.packed + L::merged_w_off;
     a.b[kMergedLayer] = a.packed + L::merged_b_off;
     hipLaunchKernelGGL((merge_kernel<D, BF16>), dim3((L::Dh / 16) * (D / 16) + 32), dim3(256), 0, st, a);      // tiles of W', then 32 workgroups of copies
-    if constexpr (BF16 == 3) hipLaunchKernelGGL((scale_kernel<D>), dim3(kScaleSlots + 1), dim3(256), 0, st, a);
+    if constexpr (BF16 == 3) hipLaunchKernelGGL((scale_kernel<D>), dim3(kScaleSlots + 1), dim3(1024), 0, st, a);
     const int64_t threads = L::bias_base / 4 + L::table_floats;
     dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     hipLaunchKernelGGL((pack_kernel<D, BF16>), grid, block, 0, st, a);

@@ -33,20 +33,9 @@ __device__ __forceinline__ uint32_t pack_pair(f32x2 v) { return __builtin_bit_ca
 // unit does not overlap with the matrix pipe the way the plain VALU does; and the D = 128 layer-local test failed with it.  Not used.
 // (Beware of the selectors as compile-time constants: hipcc folds {-1, 0} into the inline constant -1.0, which the instruction reads as
 // the 32-bit pattern 0xbf800000 = {0, -1}.)
-#ifdef NNR_SPLIT_DOT2
-__device__ __forceinline__ f32x2 pair_residual(f32x2 r, uint32_t packed) {
-    uint32_t lo, hi;
-    asm("s_mov_b32 %0, 0xbf80" : "=s"(lo));
-    asm("s_mov_b32 %0, 0xbf800000" : "=s"(hi));
-    const bf16x2 p = __builtin_bit_cast(bf16x2, packed);
-    return f32x2{__builtin_amdgcn_fdot2_f32_bf16(p, __builtin_bit_cast(bf16x2, lo), r[0], false),
-                 __builtin_amdgcn_fdot2_f32_bf16(p, __builtin_bit_cast(bf16x2, hi), r[1], false)};
-}
-#else
 __device__ __forceinline__ f32x2 pair_residual(f32x2 r, uint32_t packed) {
     return r - f32x2{__uint_as_float(packed << 16), __uint_as_float(packed & 0xffff0000u)};
 }
-#endif
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
     f32x2 r = {x0, x1};
     h = pack_pair(r);
@@ -56,10 +45,6 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint
     l = pack_pair(r);
 }
 
-// experiments only (tools/archive/r03/): NNR_SPLIT_SAFE_SYNC = every counted wait as a full one; NNR_SPLIT_TERMS = 1 / 3 / 6 of the terms
-#ifndef NNR_SPLIT_TERMS
-#define NNR_SPLIT_TERMS 6
-#endif
 // bits 0, 1 = (low half != 0), (high half != 0) of a packed bf16 pair: the ReLU gates of the two activations it holds (an activation is
 // >= 0 after the ReLU, and its h term is zero exactly when it is: bf16 has fp32's exponent range).  Two gates in four instructions where
 // the epilogue's compare / select / or took three per value.
@@ -71,9 +56,6 @@ __device__ __forceinline__ uint32_t gate_pair(uint32_t hpk) {
 
 // at most n LDS reads outstanding (n folds after unrolling; lgkmcnt is a 4-bit field); tied to the fragment like wait_frag
 __device__ __forceinline__ void wait_lgkm_n(f32x4& frag, int n) {
-#ifdef NNR_SPLIT_SAFE_SYNC
-    n = 0;
-#endif
     switch (n) {
 #define NNR_WL(k) case k: asm volatile("s_waitcnt lgkmcnt(" #k ")" : "+v"(frag)); break;
         NNR_WL(0) NNR_WL(1) NNR_WL(2) NNR_WL(3) NNR_WL(4) NNR_WL(5) NNR_WL(6) NNR_WL(7) NNR_WL(8) NNR_WL(9) NNR_WL(10) NNR_WL(11)
@@ -86,9 +68,6 @@ __device__ __forceinline__ void wait_lgkm_n(f32x4& frag, int n) {
 // the same for all MT fragments of a class at once (one wait, one compiler-inserted s_nop)
 template <int MT>
 __device__ __forceinline__ void wait_class(f32x4 (&f)[MT], int n) {
-#ifdef NNR_SPLIT_SAFE_SYNC
-    n = 0;
-#endif
     switch (n) {
 #define NNR_WC(k)                                                                                                                 \
     case k:                                                                                                                       \
@@ -113,9 +92,7 @@ __device__ __forceinline__ void wait_class(f32x4 (&f)[MT], int n) {
 // the stash stores, the DMA burst, the side units -- listed in an order that interleaves the kinds, and a compile-time pass assigns each to
 // the first gap whose instruction budget it still fits in (the fragment refills are fixed: one ds_read in each gap after a term-0 / 2 /
 // 5 MFMA, a counted wait in front of the first MFMA of each fragment class).
-#ifndef NNR_SPLIT_STASH_COST      // instructions a stash store counts for in the balance of the gaps (experiments: 1 -- a tile-major store is one instruction)
-#define NNR_SPLIT_STASH_COST 2
-#endif
+constexpr int kStashCost = 2;      // instructions a stash store counts for in the balance of the gaps
 struct RowOp { int kind, idx, cost; };      // kind 0: split stage A of pair idx, 1: stage B, 2: stage C, 3: stash store idx, 4: DMA, 5: side unit idx
 template <int NOPS, int NM>
 struct RowSched { RowOp op[NOPS]; int gap[NOPS]; };
@@ -130,13 +107,13 @@ constexpr auto make_row_sched() {
     int ny = 0;
     for (int u = 0; u < NUNITS; ++u) {
         y[ny++] = RowOp{5, u, UCOST};
-        if (STASH && (u == NUNITS / 4 || u == (3 * NUNITS) / 4)) y[ny] = RowOp{3, u == NUNITS / 4 ? 0 : 1, NNR_SPLIT_STASH_COST}, ++ny;
+        if (STASH && (u == NUNITS / 4 || u == (3 * NUNITS) / 4)) y[ny] = RowOp{3, u == NUNITS / 4 ? 0 : 1, kStashCost}, ++ny;
         if (u == NUNITS / 2) y[ny++] = RowOp{4, 0, 4};
     }
     if (NUNITS == 0) {
-        if (STASH) y[ny++] = RowOp{3, 0, NNR_SPLIT_STASH_COST};
+        if (STASH) y[ny++] = RowOp{3, 0, kStashCost};
         y[ny++] = RowOp{4, 0, 4};
-        if (STASH) y[ny++] = RowOp{3, 1, NNR_SPLIT_STASH_COST};
+        if (STASH) y[ny++] = RowOp{3, 1, kStashCost};
     }
     int n = 0, ix = 0, iy = 0;
     while (ix < 12 || iy < ny) {      // merge by fractional position
@@ -175,7 +152,7 @@ constexpr auto make_row_sched() {
 template <int KT, int MT, bool STASH, int NSIDE_, int PPG, int SHIFT, class Side, int NACC, int NIN, bool TILE>
 __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)[NIN], const SplitPipeT<TILE>& pipe, int p0, float* stash,
                                           const Side& side) {
-#ifdef NNR_ABLATE_NO_SIDE
+#if NNR_ABLATE & 1
     constexpr int NSIDE = 0;   // profiling build only
 #else
     constexpr int NSIDE = NSIDE_;
@@ -190,10 +167,7 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
     auto ppk_of = [&](int pi) { return (PW + rows_in(pi) - 1) / rows_in(pi); };
     constexpr int ppk_full = (PW + GP - 1) / GP;      // pieces per row of a full panel
     constexpr int NUNITS = NSIDE > 0 ? 2 * PPG : 0;
-#ifndef NNR_SPLIT_UCOST
-#define NNR_SPLIT_UCOST 7
-#endif
-    constexpr auto sched = make_row_sched<MT, STASH, NUNITS, NNR_SPLIT_UCOST>();
+    constexpr auto sched = make_row_sched<MT, STASH, NUNITS, 7>();      // (7: the instructions a side unit counts for)
     constexpr int NOPS = 12 + (STASH ? 2 : 0) + 1 + NUNITS;
 
     // the stash address as (wave-uniform base in scalar registers) + (32-bit lane offset): a 64-bit per-lane pointer kept across the
@@ -211,10 +185,8 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
     // Entering the part's first panel.  Its pieces were issued while the previous part consumed its second-to-last panel; if that part
     // stashed, the stores of its last rows (pipe.part_pre of them, told by the kernel) are younger and may stay in flight -- without
     // this, every pass that follows a stashing pass starts with a full drain of the store queue (an HBM write latency, matrix pipe idle).
-#ifndef NNR_SPLIT_SAFE_SYNC
     if (pipe.part_pre == 6) pipe.template enter<6>(p0);
     else
-#endif
         pipe.enter(p0);
     pipe.pieces(p0 + 2, 0, ppk_of(0));
     const unsigned lane_base = lds_byte_address(pipe.lds) + 16u * pipe.lane;
@@ -250,7 +222,6 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
             if (mt == 0 && t == 0) wait_class<MT>(fr[0], 2 * MT);
             else if (mt == 0 && t == 1) wait_class<MT>(fr[1], last ? MT : 2 * MT);
             else if (mt == 0 && t == 3) wait_class<MT>(fr[2], last ? 0 : 2 * MT);
-            if (NNR_SPLIT_TERMS == 6 || (NNR_SPLIT_TERMS == 3 && (t == 2 || t >= 4)) || (NNR_SPLIT_TERMS == 1 && t == 5))
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[wc][mt]),
                                                               __builtin_bit_cast(bf16x8, u32x4{xs[xc][0], xs[xc][1], xs[xc][2], xs[xc][3]}),
                                                               acc[mt], 0, 0, 0);
@@ -260,9 +231,6 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
             if (!last && (t == 0 || t == 2 || t == 5)) {
                 const int pn = p0 + (g + 1) / GP;
                 if (t == 0 && mt == 0 && (g + 1) % GP == 0) {
-#ifdef NNR_SPLIT_SAFE_SYNC
-                    pipe.template enter<0>(pn);
-#else
                     // Stash stores younger than the pieces waited for may stay in flight: those of this panel's earlier rows -- and, from
                     // the part's third panel on, those the panel BEFORE issued after the last burst of pn's pieces (pn's pieces go out
                     // while the panel two back is consumed: first burst in the row before it, then ppk per row).  Every store that must
@@ -271,7 +239,6 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                     constexpr int kExtraNear = 2 * (GP - 1), kExtraFar = kExtraNear + 2 * (GP - 1 - kLastBurstRow);
                     if ((g + 1) / GP >= 2) pipe.template enter<STASH ? kExtraFar : 0>(pn);
                     else pipe.template enter<STASH ? kExtraNear : 0>(pn);
-#endif
                     panel_addr = lane_base + pipe.buffer(pn) * (SplitPipeT<TILE>::F4 * 16);
                 }
                 fr[wc][mt] = frag_read(panel_addr, (((g + 1) % GP) * 3 + wc) * MT + mt);
@@ -282,9 +249,6 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                 if (sched.gap[i] != j) continue;
                 const int kind = sched.op[i].kind, k = sched.op[i].idx;
                 if (kind == 0) {            // split of pair k of the next row, stage A: h, and what it leaves
-#ifdef NNR_ABLATE_NO_SPLIT
-                    if (!last) { xn[2][k] = xs[2][k]; xn[1][k] = xs[1][k]; xn[0][k] = xs[0][k]; }   // profiling build only
-#else
                     if (!last) {
                         rr[k] = f32x2{in[8 * (g + 1) + 2 * k], in[8 * (g + 1) + 2 * k + 1]};
                         xn[2][k] = pack_pair(rr[k]);
@@ -298,18 +262,9 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                     }
                 } else if (kind == 2) {     // stage C: l
                     if (!last) xn[0][k] = pack_pair(rr[k]);
-#endif
                 } else if (kind == 3) {
                     if constexpr (STASH) {
-#ifndef NNR_ABLATE_NO_STASH
-#ifdef NNR_SPLIT_TERM_STASH     // experiment (WRONG layout, timing only): the row's three packed term operands, 3 x 1 KiB contiguous, non-temporal
-                        {
-                            u32x4* const td = reinterpret_cast<u32x4*>(const_cast<char*>(stash_base) + 1024 * (3 * g + 2 * k) + 16 * pipe.lane);
-                            __builtin_nontemporal_store(u32x4{xs[2 * k][0], xs[2 * k][1], xs[2 * k][2], xs[2 * k][3]}, td);
-                            if (k == 0) __builtin_nontemporal_store(u32x4{xs[1][0], xs[1][1], xs[1][2], xs[1][3]}, td + 64);
-                            continue;
-                        }
-#endif
+#if !(NNR_ABLATE & 8)
                         const f32x4 val = f32x4{in[8 * g + 4 * k], in[8 * g + 4 * k + 1], in[8 * g + 4 * k + 2], in[8 * g + 4 * k + 3]};
                         if constexpr (TILE) {
                             // tile-major plane (nnr_layout.h): store 2 g + k of the part is octet 2 g + k of its input -- one contiguous 1 KiB block
@@ -320,22 +275,10 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[NACC], const float (&in)
                             // hipcc does not count asm memory operations: its own waits only get more conservative, and the counted
                             // vmcnt waits of the panel switches (PanelPipeT::enter<EXTRA>) are the ones written for these stores.
                             const uint64_t sb = reinterpret_cast<uint64_t>(stash_base) + 4096u * ((2 * g + k) >> 2);
-#ifdef NNR_TILE_STASH_PLAIN      // experiment: the same store without the non-temporal hint
-                            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" : : "v"(stash_off), "v"(val), "s"(sb), "n"(1024 * ((2 * g + k) & 3)) : "memory");
-#else
                             asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" : : "v"(stash_off), "v"(val), "s"(sb), "n"(1024 * ((2 * g + k) & 3)) : "memory");
-#endif
                         } else {
-#ifdef NNR_SPLIT_TILE_STASH     // experiment (WRONG layout, timing only): one contiguous 1 KiB block per store
-                            f32x4* const dst = reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + 1024 * (2 * g + k) + 16 * pipe.lane);
-#else
                             f32x4* const dst = reinterpret_cast<f32x4*>(const_cast<char*>(stash_base) + stash_off + 32 * (2 * g + k));
-#endif
-#ifdef NNR_SPLIT_NT_STASH
-                            __builtin_nontemporal_store(val, dst);   // experiment: keep the 1.9 GB of stash out of the L2's way
-#else
                             *dst = val;
-#endif
                         }
 #endif
                     }

@@ -189,7 +189,7 @@ __device__ __forceinline__ constexpr int first_unit(int g) {
 template <int KT, int MT, int NSIDE_, int SCHED, int UPR, int STORE_EVERY, int PRE, class Side, class Pipe, int NACC, int NIN>
 __device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (&ph)[NIN], const uint32_t (&pm)[NIN], const Pipe& pipe, int p0,
                                            const Side& side, bool pre_valid = true) {
-#ifdef NNR_ABLATE_NO_SIDE
+#if NNR_ABLATE & 1
     constexpr int NSIDE = 0;   // profiling build only
 #else
     constexpr int NSIDE = NSIDE_;
@@ -212,12 +212,8 @@ __device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (
         return n;
     };
 
-#ifdef NNR_SPLIT_SAFE_SYNC
-    pipe.enter(p0);
-#else
     if (PRE > 0 && pre_valid) pipe.template enter<PRE>(p0);      // (pre_valid is wave-uniform: the part before did issue those stores)
     else pipe.enter(p0);
-#endif
     pipe.pieces(p0 + 2, 0, ppk_of(0));
     const unsigned lane_base = lds_byte_address(pipe.lds) + 16u * pipe.lane;
     unsigned panel_addr = lane_base + pipe.buffer(p0) * (Pipe::F4 * 16);
@@ -263,9 +259,6 @@ __device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (
                         extra = 0;
                         for (int r = g - (GP - 1); r < g; ++r) extra += stores_of_row(r);
                     }
-#ifdef NNR_SPLIT_SAFE_SYNC
-                    extra = 0;
-#endif
                     switch (extra) {
                         case 0: pipe.template enter<0>(pn); break;
                         case 1: pipe.template enter<1>(pn); break;
@@ -283,36 +276,20 @@ __device__ __forceinline__ void gemm_part2(f32x16 (&acc)[NACC], const uint32_t (
             // the DMA pieces of the panel two ahead, spread over the rows of the current panel: the row's share ONE piece per gap from gap kDmaGap on
             // (a piece costs the issuing wave 60 - 180 cycles of issue, more next to LDS reads: MI355X_MICROARCH.md; the fragment reads sit in the gaps
             // of the t0 phase)
-#ifndef NNR_F16_DMA_GAP
-#define NNR_F16_DMA_GAP 1
-#endif
-#ifndef NNR_F16_DMA_STEP
-#define NNR_F16_DMA_STEP 0      /* 0: the row's pieces as one burst in gap NNR_F16_DMA_GAP; s > 0: piece i in gap NNR_F16_DMA_GAP + s i */
-#endif
-#ifndef NNR_F16_UNIT_GAP
-#define NNR_F16_UNIT_GAP 2      /* first gap the side units may use */
-#endif
+            // (kDmaGap = 1: the row's pieces as ONE burst in gap 1; kUnitGap = 2: first gap the side units may use.  Other placements -- one piece
+            // per gap, units from gap 0 / 1 / 3 -- measured the same within noise: profiles/r06/f2_f16_gap_placement_variants.txt)
+            constexpr int kDmaGap = 1, kUnitGap = 2;
             {
                 const int pi = g / GP, gi = g % GP;
                 const bool into_next = gi == rows_in(pi) - 1;      // this row entered panel pi + 1 above: first share of the panel three ahead
                 const int pnl = into_next ? p0 + pi + 3 : p0 + pi + 2, n = into_next ? ppk_of(pi + 1) : ppk_of(pi), first = into_next ? 0 : (gi + 1) * ppk_of(pi);
-                const int g0 = NNR_F16_DMA_GAP < NM ? NNR_F16_DMA_GAP : NM - 1;
-                if (!(into_next && last)) {
-                    if (NNR_F16_DMA_STEP == 0) {
-                        if (j == g0) pipe.pieces(pnl, first, n);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < n; ++i) {
-                            const int gp_ = g0 + NNR_F16_DMA_STEP * i < NM ? g0 + NNR_F16_DMA_STEP * i : NM - 1;
-                            if (j == gp_) pipe.pieces(pnl, first + i, 1);
-                        }
-                    }
-                }
+                const int g0 = kDmaGap < NM ? kDmaGap : NM - 1;
+                if (!(into_next && last) && j == g0) pipe.pieces(pnl, first, n);
             }
             if constexpr (NSIDE > 0) {
 #pragma unroll
-                for (int k = 0; k < nu; ++k) {      // unit k of the row's nu: spread over the gaps from NNR_F16_UNIT_GAP on
-                    constexpr int U0 = NNR_F16_UNIT_GAP < NM ? NNR_F16_UNIT_GAP : 0;
+                for (int k = 0; k < nu; ++k) {      // unit k of the row's nu: spread over the gaps from kUnitGap on
+                    constexpr int U0 = kUnitGap < NM ? kUnitGap : 0;
                     const int gap = NM >= 4 ? U0 + (k * (NM - U0)) / nu : (k * NM) / nu;
                     if (gap == j) side(u0 + k);
                 }

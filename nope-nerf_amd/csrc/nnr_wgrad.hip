@@ -128,9 +128,6 @@ __device__ __forceinline__ void wgrad_job(const WgradJob& jb, const WgradArgs& a
     // flush: D[row m'][col n] of sub-tile (i,j) -> slot[(MI*m' + i) * 32*NI + NI*n + j].  One NI-wide store per (i, r):
     // 32 lanes cover a whole tile row (32*NI contiguous floats).  Rows / columns outside the valid range hold garbage
     // (see load_vec); the reduction never reads them.
-#ifdef NNR_ABLATE_NO_FLUSH
-    return;
-#endif
     float* slot = a.slots + (int64_t)ji * kSlotFloats;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -217,12 +214,8 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
     __builtin_amdgcn_global_load_lds((glb_ptr_t)((G) + ((KK) + (S)) * (int64_t)(P) * 4 + (LANE)), (lds_ptr_t)((DST) + (ROW) * 64), 16, 0, 0)
 // (the conversion as the compiler's own: as inline asm -- pack_bf16 -- every use drags an s_nop along, 55 per step)
 #define NNR_WPACK(V) __builtin_bit_cast(uint32_t, __builtin_convertvector(V, bf16x2))
-#ifdef NNR_ABLATE_WGRAD_NO_FETCH      /* profiling builds only (results NOT valid) */
-#define NNR_WFETCH(W, P, LR, ROW0, C) (fp[W][P] = f32x2{1.f + (float)(P), 2.f + (float)(C)})
-#else
 #define NNR_WOFF(ROW0, P, C, SECOND) (((ROW0) == 0 ? DTILE : XTILE) ? 512 * ((P) >> 1) + 128 * ((P) & 1) + (C) + 64 * (SECOND) : 256 * ((ROW0) + 2 * (P) + (SECOND)) + (C))
 #define NNR_WFETCH(W, P, LR, ROW0, C) (fp[W][P] = f32x2{(LR)[NNR_WOFF(ROW0, P, C, 0)], (LR)[NNR_WOFF(ROW0, P, C, 1)]})
-#endif
 // the gradient operand's DMA instruction S (0..7) of the step at sample KK: a staged row of the row-major plane, or 64-byte runs of the tile-major one
 #define NNR_WDMA_D(KK, S, DST, ROW)                                                                                                      \
     do {                                                                                                                                 \
@@ -312,19 +305,14 @@ __device__ __forceinline__ void wgrad_job_split(const WgradJob& jb, const WgradA
                     __builtin_bit_cast(bf16x8, u32x4{Xc[j][xc][0], Xc[j][xc][1], Xc[j][xc][2], Xc[j][xc][3]}),
                     acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef NNR_ABLATE_WGRAD_NO_DMA
                 {
                     const int q = i == 3 ? g : 16;                                // the 16 rows of step k + 32, one per gap from the start of block 3
                     if (q < 8) NNR_WDMA_D(kn, q, dst, q);
                     else if (q < 16) NNR_WDMA_X(kn, q - 8, dst, q);
                 }
-#endif
 #pragma unroll
                 for (int o = 0; o < 48; ++o) {
                     if (o >= n_ops || (o * G) / n_ops != g) continue;
-#ifdef NNR_ABLATE_WGRAD_NO_SPLIT
-                    continue;
-#endif
                     const bool is_d = stride == 1 || o % stride == 0;
                     const int od = stride == 1 ? o : o / stride, ox = o - o / stride - 1;   // index within the operand's own operations
                     if (is_d) {
@@ -489,21 +477,6 @@ __device__ __forceinline__ void wgrad_group_split(const WgradJob& jb, const Wgra
     // 4 x m, 4 x l, then the six writes of the two components
     auto coop_op = [&](int n, const float* bd, const float* bx, float nf, int eb) __attribute__((always_inline)) {
         const int B = n / 22, o = n % 22;
-#ifdef NNR_ABLATE_WGRAD_COOP      /* profiling builds only (results NOT valid): what the kernel would cost if its operands arrived as terms --
-                                     1: fetches and exchange writes stay, the split arithmetic is replaced by three moves per pair; 2: neither */
-        if (o < 16) {
-            const int q = 4 * B + (o & 3), st = o >> 2, sq = q & 3;
-            if (st == 0) {
-                if (NNR_ABLATE_WGRAD_COOP == 1) split_op(q, 0, bd, bx, nf);
-                else rr[sq] = f32x2{1.f + (float)q, 2.f};
-            } else {
-                T[sq][3 - st] = __float_as_uint(rr[sq][st & 1]) + st;
-            }
-        } else if (NNR_ABLATE_WGRAD_COOP == 1) {
-            write_op(B >> 1, 2 * (B & 1) + (o - 16) / 3, (o - 16) % 3, eb);
-        }
-        return;
-#endif
         if (o < 16) split_op(4 * B + (o & 3), o >> 2, bd, bx, nf);
         else write_op(B >> 1, 2 * (B & 1) + (o - 16) / 3, (o - 16) % 3, eb);
     };

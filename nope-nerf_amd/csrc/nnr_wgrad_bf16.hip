@@ -32,11 +32,8 @@
 
 namespace nnr {
 
-#ifndef NNR_WB_RING_KIB
-#define NNR_WB_RING_KIB 144
-#endif
 constexpr int kMaxStageBlocks = 36;         // blocks of 1 KiB per stage at most (the skip layer: 16 gradient + 16 + 4 activation groups)
-constexpr int kRingBytes = NNR_WB_RING_KIB * 1024;   // the LDS ring: as many stages as fit (4 of the widest unit's, 14 of the rgb head's)
+constexpr int kRingBytes = 144 * 1024;   // the LDS ring: as many stages as fit (4 of the widest unit's, 14 of the rgb head's)
 constexpr int kMaxInFlight = 56;            // DMA pieces a wave keeps outstanding at most (vmcnt is a 6-bit counter)
 constexpr int kBlockBytes = 1024;
 
@@ -235,9 +232,6 @@ __device__ __forceinline__ void wgrad_b_job(const WgradJobB& jb, const WgradBArg
     for (int s = 0; s < n; ++s) {
         const int img = feed.enter(s, n);
         pin_tiles<MT, NT>(acc);
-#ifdef NNR_ABLATE_WB_NO_COMPUTE     // profiling build only: the DMA stream alone
-        continue;
-#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 av[MT], bv[NT];

@@ -13,6 +13,7 @@ half of the free device memory; otherwise the reference's loader.  The reference
 host collate + PCIe copy of 10-25 MB per step (profiles/r04/scene_loop_*.json)."""
 import logging
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -75,7 +76,9 @@ class _ViewIndices(data.Dataset):
 class ResidentLoader(object):
     """Iterates like the reference loader at batchsize 1, but the frames / depth maps live on `device` for the whole run."""
 
-    _uploaded = {}      # (device, content key) -> device tensor: train.py builds two loaders of the same scene (train.py:35-36), one upload serves both
+    # (device, content key) -> device tensor: train.py builds two loaders of the same scene (train.py:35-36), one upload serves both.  Weak
+    # values: the loaders hold the tensors, the cache only finds them -- a scene is freed with its last loader (ADVICE r05)
+    _uploaded = weakref.WeakValueDictionary()
 
     def __init__(self, field, n_views, shuffle, device):
         self.field, self.n_views, self.device = field, n_views, device
@@ -148,8 +151,11 @@ def _auto_resident(field, dcfg, mode):
     # (the device's TOTAL memory from its properties: torch.cuda.mem_get_info() would create a CUDA context in this process, and when the
     # answer is "host loader" that process goes on to fork DataLoader workers -- ADVICE r04)
     total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
-    if need > total // 4:
-        return False, 'the scene (%.1f GB) does not fit in a quarter of the device memory (%.1f GB)' % (need / 2 ** 30, total / 2 ** 30)
+    # every local rank uploads its own copy: ranks that SHARE a device (the gloo dry run of nnr.parallel.auto_init) share the budget too
+    sharing = max(1, -(-int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1) // max(1, torch.cuda.device_count())))
+    if need * sharing > total // 4:
+        return False, 'the scene (%.1f GB x %d rank(s) on this device) does not fit in a quarter of the device memory (%.1f GB)' % (
+            need / 2 ** 30, sharing, total / 2 ** 30)
     return True, ''
 
 

@@ -80,6 +80,7 @@ def randperm_prefix(n: int, r: int, device) -> torch.Tensor:
 
 # ---- rows of torch.rand(total) for a data-parallel shard ----------------------------------------------------------------------------
 _rows_state = {"checked": 0, "enabled": True}
+_rows_seen = set()      # (device index, total) whose draw has been compared with torch.rand
 _max_blocks = {}
 
 
@@ -106,13 +107,18 @@ def _rows_fast(total: int, first: int, n: int, device) -> torch.Tensor:
 
 def rand_rows(total: int, first: int, n: int, device) -> torch.Tensor:
     """== torch.rand(total, device=device)[first:first + n] with the same generator side effects, at the cost of n draws: the jitter rows
-    of this rank's rays out of the whole step's tensor (model/rendering.py).  Verified against torch.rand on the first calls of a process;
-    on a mismatch (a torch build whose uniform kernel maps elements differently) it falls back to the full draw for good."""
+    of this rank's rays out of the whole step's tensor (model/rendering.py).  Verified against torch.rand on the first calls of a process and
+    on the first call with every new `total`; on a mismatch (a torch build whose uniform kernel maps elements differently) it falls back to the full draw for good."""
     device = torch.device(device)
     if device.type != 'cuda' or not _rows_state["enabled"] or total <= 0:
         return torch.rand(total, device=device)[first:first + n].contiguous()
-    if _rows_state["checked"] < _CHECKS:
+    # verified on the first _CHECKS calls AND on the first use of every distinct (device, total): another total may land in the other regime
+    # of the launch (grid capped by the CU count or not), and a mapping that is wrong only there would silently desynchronise the jitter
+    # streams of a data-parallel and a single-GPU run (ADVICE r05).  One extra full draw per new size.
+    size_key = (device.index if device.index is not None else torch.cuda.current_device(), total)
+    if _rows_state["checked"] < _CHECKS or size_key not in _rows_seen:
         _rows_state["checked"] += 1
+        _rows_seen.add(size_key)
         before = torch.cuda.get_rng_state(device)
         ref = torch.rand(total, device=device)[first:first + n].clone()
         after = torch.cuda.get_rng_state(device)

