@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <vector>
 
 #include "../../include/nnr.h"
@@ -192,6 +193,47 @@ Plan build_plan(const nnr_cfg* c) {
     int64_t cost_a = 0, cost_b = 0;
     for (auto& g : groups) cost_a += 4 * weight(units[g[0]].j);   // bias halves: all four tiles of a group weigh the same
     for (int u : small) cost_b += weight(units[u].j);
+    // Class B at D = 256 in BUNDLES (round 6, OFF unless NNR_WGRAD_BUNDLES is set -- a measured negative): the four waves of a workgroup take
+    // narrow tiles that read the same planes over the SAME sample range at the same time, so a plane comes from HBM once and the other
+    // readers find it in the CU's L1 / the XCD's L2.  On the per-wave tape below the tiles of one plane run on different workgroups -- other
+    // XCDs, other L2s -- and the planes they share are fetched once per tile: 4.26 GB per launch against 3.4 GB of distinct planes.
+    //   bundle 0: hidden-1 tiles a, b | skip layer's encoding tiles a, b             (share the position encoding)
+    //   bundle 1: merged colour tiles a, b | density a + rgb | density b + direction   (share hidden 8, d colour-hidden, the 4-wide gradients)
+    // A bundle costs its heaviest wave (7.0 / 7.0 / 9.2 / 9.2 in bundle 1: 12 % of those workgroups' time idle).  Measured, 1024 x 192
+    // (profiles/r06/q_wgrad_bundles_ab.txt): fetched bytes 4.26 -> 4.04 GB, kernel 0.893 -> 0.915 ms.  The kernel is not waiting on those
+    // bytes; the perfectly balanced tape wins.
+    static const bool no_bundles = std::getenv("NNR_WGRAD_BUNDLES") == nullptr;
+    std::vector<std::array<std::vector<int>, 4>> bundles;
+    if (c->hidden == 256 && !no_bundles && !groups.empty()) {
+        auto find = [&](int layer, int row0, int wcol0) {
+            for (int u : small)
+                if (units[u].j.layer == layer && units[u].j.row0 == row0 && units[u].j.wcol0 == wcol0) return u;
+            return -1;
+        };
+        const int D = c->hidden;
+        bundles.push_back({{{find(0, 0, 0)}, {find(0, 128, 0)}, {find(4, 0, D)}, {find(4, 128, D)}}});
+        bundles.push_back({{{find(kMergedLayer, 0, 0)}, {find(kMergedLayer, 0, 128)}, {find(8, 0, 0), find(11, 0, 0)}, {find(8, 0, 128), find(10, 0, D)}}});
+        size_t n = 0;
+        bool ok = true;
+        for (auto& b : bundles)
+            for (auto& wv : b)
+                for (int u : wv) { ok = ok && u >= 0; ++n; }
+        if (!ok || n != small.size()) bundles.clear();      // (a unit list this table does not know: the per-wave tape)
+    }
+    std::vector<int64_t> bundle_cost;
+    if (!bundles.empty()) {
+        cost_b = 0;
+        for (auto& b : bundles) {
+            int64_t mx = 0;
+            for (auto& wv : b) {
+                int64_t s = 0;
+                for (int u : wv) s += weight(units[u].j);
+                mx = std::max(mx, s);
+            }
+            bundle_cost.push_back(mx);
+            cost_b += 4 * mx;      // in wave-equivalents, like cost_a
+        }
+    }
     static const int max_blocks = [] {   // NNR_WGRAD_MAX_BLOCKS: tuning knob for experiments
         const char* e = std::getenv("NNR_WGRAD_MAX_BLOCKS");
         return e ? std::max(2, std::atoi(e)) : kMaxBlocks;
@@ -230,13 +272,32 @@ Plan build_plan(const nnr_cfg* c) {
     if (split && coop)
         for (int wv = 0; wv < 4 * nb_a; ++wv)
             for (auto& j : per_wave[wv]) j.reserved = 1;
-    // class B: tile u occupies [off_u, off_u + cost_u * granules) of the tape; a cut inside a tile is rounded to a granule
+    // class B in bundles: bundle i occupies [off_i, off_i + cost_i * granules) of a tape that is cut per WORKGROUP
+    if (!bundles.empty()) {
+        int64_t tape = 0;
+        for (int64_t cb : bundle_cost) tape += cb * granules;
+        int64_t off = 0;
+        for (size_t i = 0; i < bundles.size(); ++i) {
+            const int64_t cb = bundle_cost[i], end = off + cb * granules;
+            auto to_granule = [&](int64_t x) { return std::min(granules, std::max<int64_t>(0, (x - off + cb / 2) / cb)); };
+            for (int b = 0; b < nb_b; ++b) {
+                const int64_t c0 = tape * b / nb_b, c1 = tape * (b + 1) / nb_b;
+                if (c1 <= off || c0 >= end) continue;
+                const int64_t g0 = c0 <= off ? 0 : to_granule(c0), g1 = c1 >= end ? granules : to_granule(c1);
+                for (int t = 0; t < 4; ++t)
+                    for (int u : bundles[i][t]) emit(4 * (nb_a + b) + t, u, g0, g1);
+            }
+            off = end;
+        }
+    }
+    // class B per wave (D = 128, or the bundles switched off): tile u occupies [off_u, off_u + cost_u * granules) of the tape; a cut inside a tile
+    // is rounded to a granule
     const int nw_b = nb_b * 4;
     const int64_t tape_b = cost_b * granules;
     std::vector<int64_t> cuts((size_t)nw_b + 1);
     for (int v = 0; v <= nw_b; ++v) cuts[v] = tape_b * v / nw_b;
     int64_t off = 0;
-    for (int u : small) {
+    for (int u : bundles.empty() ? small : std::vector<int>{}) {
         const int64_t cu = weight(units[u].j), end = off + cu * granules;
         auto to_granule = [&](int64_t x) { return std::min(granules, std::max<int64_t>(0, (x - off + cu / 2) / cu)); };
         for (int v = 0; v < nw_b; ++v) {

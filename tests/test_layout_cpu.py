@@ -241,9 +241,13 @@ def test_wgrad_plan_covers_every_weight_once(D, R, N):
         # (two-term mode, the default since round 6: the workgroup jobs of hidden layers 2..8 take three fp16 terms, 0.34: split2_w in nnr_api.cpp)
         w44 = 0.44 if (cfg.flags & L.NNR_F_SPLIT3) else 1.0
         w34 = 0.34 if (cfg.flags & L.NNR_F_SPLIT2) else w44
-        cost = lambda j: ((w34 if 1 <= j.layer <= 7 else w44) if j.MI * j.NI == 16 else 1.0) * j.MI * j.NI * (j.k1 - j.k0)
+        narrow = {8: 1.035, 4: 1.145}      # (measured cycles per MFMA of the narrow tiles relative to a 4 x 4 fp32 tile: the `weight` table of build_plan)
+        cost = lambda j: ((w34 if 1 <= j.layer <= 7 else w44) if j.MI * j.NI == 16 else narrow.get(j.MI * j.NI, 1.25)) * j.MI * j.NI * (j.k1 - j.k0)
         work = [sum(cost(allj[i]) for i in range(first[w], first[w + 1])) for w in range(len(first) - 1)]
-        assert len(work) == 1024 and max(work) <= 1.03 * sum(work) / len(work)   # narrow tiles are weighted up, so they get LESS
+        # a workgroup is done when its slowest wave is (the narrow tiles run in bundles whose waves differ: nnr_api.cpp build_plan): no
+        # workgroup more than 3 % above the mean
+        load = [max(work[4 * b:4 * b + 4]) for b in range(len(work) // 4)]
+        assert len(work) == 1024 and max(load) <= 1.03 * sum(load) / len(load)
 
 
 # ---- bf16 training mode: tile-major planes, the workgroup-job plan, the DMA swizzle / transposing-read index algebra --------
@@ -503,3 +507,14 @@ def test_shared_split_stages_its_quarter_of_both_tile_major_operands():
                             v = lds[lane_base + extra + 128 * pl + Cc + 64 * second]
                             want = 1000.0 * (k + 8 * h + 4 * t + 2 * pl + second) + col0 + 4 * m + Cc
                             assert v == want, (name, lane, pl, Cc, second, v, want)
+
+
+def test_wgrad_plan_with_bundles_covers_every_weight_once():
+    """NNR_WGRAD_BUNDLES (the narrow tiles scheduled per workgroup, nnr_api.cpp build_plan; off by default, read once per process): the same
+    coverage / chaining / balance statements in a process that has it set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, NNR_WGRAD_BUNDLES="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "test_wgrad_plan_covers_every_weight_once"], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:]
