@@ -56,13 +56,16 @@ extern "C" {
                              * of the fp32 mode; the packed-weight buffer has another size and layout (nnr_packed_floats) and the
                              * weight-gradient plan another cut (nnr_plan_bytes, nnr_workspace_floats: query with the same flags).
                              * Ignored with NNR_F_BF16. */
-#define NNR_F_SPLIT2 64u    /* with NNR_F_SPLIT3: the forward and the input-gradient chain take every fp32 product as THREE fp16 MFMA terms of
-                             * two-term operands (11 + 11 significand bits; operands scaled by powers of two, the residual term carried at
-                             * 2^11: nnr_split2.h) instead of six bf16 terms -- half the matrix-pipe passes, about 2^-22 relative error per
-                             * product, as close to an fp64 evaluation of the step as the other fp32 paths (tests/test_gpu_split2.py).  One
+#define NNR_F_SPLIT2 64u    /* with NNR_F_SPLIT3: the three MLP kernels take every fp32 product as THREE fp16 MFMA terms of two-term operands
+                             * (11 + 11 significand bits; operands scaled by powers of two, the residual term carried at 2^11: nnr_split2.h)
+                             * instead of six bf16 terms -- half the matrix-pipe passes, about 2^-22 relative error per product, as close to an
+                             * fp64 evaluation of the step as the other fp32 paths (tests/test_gpu_split3.py, all modes at the same bars).  One
                              * bound the other modes do not have: a forward activation of 65504 or more overflows fp16 and the step returns
-                             * NaN.  Workspace, planes, plan and the weight-gradient kernel are NNR_F_SPLIT3's; the packed-weight buffer has
-                             * its own contents and size.  Ignored without NNR_F_SPLIT3 or with NNR_F_BF16. */
+                             * NaN.  The planes are NNR_F_SPLIT3's; the packed-weight buffer has its own contents and size, the weight-gradient
+                             * plan its own cut, and the training workspace ends in 32 floats of plane maxima -- written by nnr_mlp_fwd
+                             * (which zeroes them first) and nnr_mlp_dgrad, read by nnr_mlp_wgrad of the same step (its 4 x 4 tiles scale their
+                             * fp16 terms per plane; the narrow tiles stay on fp32 MFMAs).  Query all sizes with the same flags.
+                             * Ignored without NNR_F_SPLIT3 or with NNR_F_BF16. */
 
 /* Problem description.  POD, passed by pointer, read on the host only. */
 typedef struct nnr_cfg {
