@@ -404,9 +404,31 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
         three['frac_of_bf16_mfma_peak'] = round(three['issued_bf16_tflops'] / PEAK_BF16_MFMA_TFLOPS, 4)
         three['frac_of_fp32_matrix_peak'] = round(three['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4)
         issued_dom = per[dom]['issued_bf16_tflops']
+        # ... and every kernel against the OTHER roof: algorithmic HBM bytes (the fp32 stash planes each kernel writes / reads exactly once: DESIGN 4.4 / 4.6)
+        byts = fp32_bytes_per_sample(D)
+        for k in byts:
+            gb = byts[k] * R * N / (times[k] * 1e-3) / 1e9
+            per[k].update(bytes_per_sample=byts[k], gbytes_per_s=round(gb, 1), frac_of_hbm_peak=round(gb / PEAK_HBM_GBS, 4))
+        hbm = {'achieved': per[dom]['gbytes_per_s'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': per[dom]['frac_of_hbm_peak'],
+               'bytes_per_launch': byts[dom] * R * N, 'what': 'algorithmic stash bytes of the same kernel (distinct planes, each once) / its in-step duration'}
+        mfma = {'achieved': issued_dom, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(issued_dom / PEAK_BF16_MFMA_TFLOPS, 4),
+                'what': 'issued 16-bit MFMA work (%d terms x executed MACs x 2%s) / in-step time vs the dense bf16 / fp16 peak'
+                        % (terms[dom], '' if share[dom] == 1.0 else ' of the 4 x 4 tiles')}
+        if hbm['frac'] > mfma['frac']:
+            # the dominant kernel sits nearer the HBM roof than the matrix pipe's (round 6: the weight gradient, once its products took three fp16 terms)
+            return {
+                'fp32_products': products, 'bound': 'hbm', 'kernel': dom, 'achieved': hbm['achieved'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': hbm['frac'], 'what': hbm['what'], 'bytes_per_launch': hbm['bytes_per_launch'], 'mfma': mfma,
+                'notes': 'the nearer of the two roofs of the dominant kernel; its matrix-pipe figure is in `mfma`, every kernel carries both fractions '
+                         '(`frac_of_hbm_peak`, `frac_of_bf16_mfma_peak`); `traffic` = what the kernel actually fetched + wrote (PMC): above the algorithmic '
+                         'bytes by the planes its narrow tiles read again (DESIGN 4.6d)',
+                'algorithmic_tflops': round(achieved, 2), 'frac_of_fp32_matrix_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                'traffic': traffic, 'traffic_source': src, 'timing': how, 'flop_per_launch': flops, 'executed_flop_per_launch': executed,
+                'issued_bf16_flop_per_launch': int(terms[dom] * share[dom] * executed), 'kernels': per, 'fused_mlp_all_three': three,
+            }
         return {
             'fp32_products': products, 'bound': 'mfma', 'kernel': dom, 'achieved': issued_dom, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(issued_dom / PEAK_BF16_MFMA_TFLOPS, 4),
+            'frac': round(issued_dom / PEAK_BF16_MFMA_TFLOPS, 4), 'hbm': hbm,
             'what': 'issued 16-bit MFMA work (%d terms x executed MACs x 2) / in-step time vs the dense bf16 / fp16 peak' % terms[dom],
             'notes': 'peak at the nominal 2.4 GHz; the chip holds ~1.8 GHz under these kernels (DESIGN 4.3).  frac_algorithmic = terms x ALGORITHMIC '
                      'MACs x 2 / time / peak (SURVEY 8d counts algorithmic work; the kernels execute 89 %% of it: feature layer folded).  '
@@ -426,6 +448,19 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
         'flop_per_launch': flops, 'executed_flop_per_launch': executed, 'executed_tflops': round(executed / (times[dom] * 1e-3) / 1e12, 2),
         'executed_frac': round(executed / (times[dom] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), 'kernels': per, 'fused_mlp_all_three': three,
     }
+
+
+def fp32_bytes_per_sample(D):
+    """Algorithmic HBM bytes per sample of the three fp32-mode kernels with term products (tile-major fp32 stash planes: DESIGN 4.4): hidden
+    activations h1..h8 (8 D) and the colour-hidden layer g (D / 2) as fp32, their gradients likewise, the encodings (64 + 32) as fp32, ReLU
+    gates 1 bit per activation, (rgb, sigma) 16 B, z 4 B, jitter 4 B, position + view direction 2 x 16 B, d point + d view 2 x 16 B; the
+    weight gradient also reads the 4-wide output gradients."""
+    h, g, dg = 8 * D * 4, (D // 2) * 4, (D // 2) * 4
+    enc, gates = (64 + 32) * 4, 9 * D // 8
+    fwd = h + g + enc + gates + 16 + 4 + 32 + 4
+    dgrad = h + dg + 32 + gates + 16 + 32
+    wgrad = 2 * h + g + dg + enc + 16
+    return {'mlp_fwd': fwd, 'mlp_dgrad': dgrad, 'mlp_wgrad': wgrad}
 
 
 def bf16_bytes_per_sample(D):
@@ -824,10 +859,12 @@ def main():
         clk = None if use_dist else clock_probe(device, lambda: trainer.train_step(data, it=args.warmup + args.steps, epoch=0, scheduling_start=10000,
                                                                                    render_path=None))
         out['roofline']['clock'] = clk
-        if clk is not None and out['roofline'].get('unit') == 'TFLOP/s':      # the same fraction against what the chip had at the clock it held
-            at = out['roofline']['peak'] * clk['sclk_mhz_median'] / clk['nominal_mhz']
-            out['roofline']['peak_at_measured_clock'] = round(at, 1)
-            out['roofline']['frac_at_measured_clock'] = round(out['roofline']['achieved'] / at, 4)
+        # the matrix-pipe fraction against what the chip had at the clock it held (the top-level block, or its `mfma` part where HBM is the nearer roof)
+        blk = out['roofline'] if out['roofline'].get('unit') == 'TFLOP/s' else out['roofline'].get('mfma')
+        if clk is not None and blk is not None:
+            at = blk['peak'] * clk['sclk_mhz_median'] / clk['nominal_mhz']
+            blk['peak_at_measured_clock'] = round(at, 1)
+            blk['frac_at_measured_clock'] = round(blk['achieved'] / at, 4)
         out['box'] = box_probe(device)
         out['cpu_baseline'] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
         if world == 1 and not args.no_extra and headline:

@@ -356,3 +356,35 @@ def test_build_rejects_hot_kernels_that_use_scratch_memory():
     with pytest.raises(RuntimeError, match="limit 64"):       # ... but not the 96+ bytes that put reloads (= store-queue drains) in a pass
         b.check_resources(bf16 % 96, "bf16 bad")
     assert "-pragma-unroll-threshold=1048576" in b.FLAGS
+
+
+def test_committed_round6_bench_line_follows_the_contract():
+    """The round-6 line (profiles/r06/z_bench_untraced.json.txt: `python bench.py` on one MI355X, the final binaries): the contract's fields, the
+    roofline of the dominant kernel against the nearer of its two roofs with PMC traffic, the reference itself as the CPU baseline."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "profiles", "r06", "z_bench_untraced.json.txt")).read()
+    line = json.loads([l for l in text.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["metric"] == "training rays/sec" and line["unit"] == "rays/s" and line["n_gpus"] == 1 and line["higher_is_better"] is True
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "f32" and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"] and "configs[1]" in line["config"]["workload"]
+    assert abs(line["value"] - 1024 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"]
+    assert line["ms_per_step"] <= 2.75            # VERDICT r05 item 1's target for this configuration
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == {"hbm": "GB/s", "mfma": "TFLOP/s"}[r["bound"]]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3 and 0.0 < r["frac"] < 1.0
+    assert isinstance(r["traffic"], int) and r["traffic"] > 1e9            # HBM bytes per launch from the PMC passes of the same binaries
+    assert "r06" in r["traffic_source"]
+    other = r["mfma"] if r["bound"] == "hbm" else r["hbm"]                 # the other roof of the same kernel stands beside it
+    assert abs(other["frac"] - other["achieved"] / other["peak"]) <= 1e-3
+    assert r["clock"]["sclk_mhz_median"] > 1000 and "peak_at_measured_clock" in (r["mfma"] if r["bound"] == "hbm" else r)
+    for k in ("mlp_fwd", "mlp_dgrad", "mlp_wgrad"):
+        kk = r["kernels"][k]
+        assert kk["terms_per_product"] == 3 and 0 < kk["frac_of_bf16_mfma_peak"] < 1 and 0 < kk["frac_of_hbm_peak"] < 1 and kk["algorithmic_tflops"] > 157.3
+    c = line["cpu_baseline"]
+    assert c["kind"] == "reference" and c["unit"] == "rays/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert line["configs"]["bf16_4096x128"]["tolerance_vs_fp32"]["grad_rel_l2"] == 0.25

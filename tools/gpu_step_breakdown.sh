@@ -15,12 +15,12 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # the training forward marks a step: the first 50 launches of it are the 10 + 40 steps of the loop (later ones belong to the kernel-roofline block)
-idx = [i for i, r in enumerate(rows) if ('mlp_fwd_kernel<256, true' in r['Kernel_Name'] or 'mlp_fwd_bf16_kernel<256, true' in r['Kernel_Name'])][:50]
+idx = [i for i, r in enumerate(rows) if ('mlp_fwd_kernel<256, true' in r['Kernel_Name'] or 'mlp_fwd_f16_kernel<256, true' in r['Kernel_Name'] or 'mlp_fwd_bf16_kernel<256, true' in r['Kernel_Name'])][:50]
 a, b = idx[-21], idx[-1]
 seg = rows[a:b]
 wall = int(rows[b]['Start_Timestamp']) - int(rows[a]['Start_Timestamp'])
 busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in seg)
-main = ('mlp_fwd_kernel', 'mlp_dgrad_kernel', 'wgrad_kernel', 'mlp_fwd_bf16_kernel', 'mlp_dgrad_bf16_kernel', 'wgrad_b_kernel')
+main = ('mlp_fwd_kernel', 'mlp_dgrad_kernel', 'mlp_fwd_f16_kernel', 'mlp_dgrad_f16_kernel', 'wgrad_kernel', 'mlp_fwd_bf16_kernel', 'mlp_dgrad_bf16_kernel', 'wgrad_b_kernel')
 small = [r for r in seg if not any(m + '<' in r['Kernel_Name'] or ('::' + m + '(') in r['Kernel_Name'] for m in main)]
 print('20 training steps, %s (rocprofv3 --kernel-trace; the tracer slows the HOST, so wall time here is not the step time):' % sys.argv[2])
 print('GPU busy %.3f ms/step in %.1f launches/step (traced wall %.3f ms/step; untraced step time: the bench line)' % (busy / 20e6, len(seg) / 20, wall / 20e6))
