@@ -5,8 +5,12 @@
 // outputs as the six-term kernel; what differs:
 //   * gradients span twenty orders of magnitude from sample to sample (the compositing weights) and fp16 does not: the chain of a sample runs
 //     in a SCALED domain, d s with s = the power of two that puts the sample's largest |d g| (or |d sigma_raw| max |w_sigma|) into [2^7, 2^8) --
-//     eight binades of head room for growth down the chain, twenty-two below before the first term leaves the normal range (the residual term
-//     is carried at 2^11, nnr_split2.h); what is stashed for the weight gradient and what leaves the kernel is multiplied by 1 / s again (exact);
+//     eight binades of head room for the growth of ONE layer, twenty-two below before the first term leaves the normal range (the residual term
+//     is carried at 2^11, nnr_split2.h); what is stashed for the weight gradient and what leaves the kernel is multiplied by 1 / s again (exact).
+//     The scale is RE-CENTRED after every layer (recentre(), below): a trained network's layers amplify the gradient -- a factor 1.9 per layer is
+//     2^8 over the chain, the next conversion overflows to inf and the step's gradients are NaN behind a finite loss.  That happened: the
+//     reference's train.py on a synthetic scene, per-image losses off, at iteration ~300 of the first build of this kernel, which scaled once
+//     at the top (tests/test_gpu_loop_rate.py caught it; tests/test_gpu_split3.py::test_two_term_input_gradient_survives_amplifying_layers pins it);
 //   * between the layers a lane holds the packed terms of the scaled gradient, made once by the epilogue unit that finishes a pair:
 //     accumulator pair -> ReLU' (AND with the gate bits) -> 1 / s_w of the weights just applied -> [1 / s -> every second unit one whole-block
 //     non-temporal store to the gradient plane] -> split.
@@ -127,9 +131,27 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
     uint32_t mwA[HW], mwB[HW];           // ReLU sign bits of the layer whose gradient sits in accA / accB
     f32x2 keep = {0.f, 0.f};
     float mxd = 0.f;                     // running maximum of the |true gradients| the units stash into the current plane
-    auto flush_max = [&](int plane) __attribute__((always_inline)) {      // a plane is complete: its maximum to the workgroup's table
+    float sS, sInv;      // the sample's scale (of the packed terms being made) and its inverse
+    float cW = 1.f;      // the factor the units of the plane in progress apply on top of 1 / s_w to move from the previous plane's scale to sS
+    int esS = 127;       // sS = 2^(esS - 127)
+    // A plane is complete (both halves of every sample of this wave): its maximum to the workgroup's table, and the NEXT plane's scale from this
+    // sample's own largest magnitude -- both lanes of a sample hold half of its features, mxd is the lane's running max of the TRUE values.
+    // The packed terms of this plane stay as they are (scale sS_old); the accumulators made from them carry sS_old, and the units that finish the
+    // next plane multiply by cW = sS_new / sS_old on the way (exact: a power of two) and stash with 1 / sS_new.
+    auto flush_max = [&](int plane, bool recentre = true) __attribute__((always_inline)) {
         const float m = wave_max_f32(mxd);
         if (lane == 0) atomicMax(&wg_max[plane], __float_as_uint(m));
+        if (recentre) {
+            const float sm = fmaxf(mxd, __shfl_xor(mxd, 32, 64)) * sS;                      // the sample's largest scaled magnitude in this plane
+            const int eb = (int)((__float_as_uint(sm) >> 23) & 255u);
+            int es = esS + (134 - eb);                                                       // ... back to [2^7, 2^8)
+            es = es > 227 ? 227 : (es < 27 ? 27 : es);
+            es = (sm > 0.f && eb != 255) ? es : esS;                                         // an all-zero (or already non-finite) sample keeps its scale
+            cW = __uint_as_float((uint32_t)(127 + es - esS) << 23);
+            esS = es;
+            sS = __uint_as_float((uint32_t)es << 23);
+            sInv = __uint_as_float((uint32_t)(254 - es) << 23);
+        }
         mxd = 0.f;
     };
     auto load_mask = [&](uint32_t(&mw)[HW], int layer_idx, int hb) __attribute__((always_inline)) {
@@ -141,7 +163,6 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
     // ---- colour branch ----
     // d g = relu'(g) .* (Wc^T d rgb_pre): three FMAs per value against the rgb rows in LDS (a 3-deep GEMM is not MFMA work)
     uint32_t gh[NP], gm[NP];
-    float sS, sInv;      // the sample's scale and its inverse
     {
         float dg[HR];
         load_mask(mwA, 8, 0);
@@ -165,14 +186,16 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
         // the sample's scale: the largest magnitude that enters its chain -- its d g (both half-waves) and the density head's rank-1 term --
         // to [2^7, 2^8); a power of two from the exponent field, clamped to 2^+-100; 1 for an all-zero sample
         mxd = mx;
-        flush_max(8);                                 // P_DG (every sample's largest |d g|, unscaled)
+        flush_max(8, false);                          // P_DG (every sample's largest |d g|, unscaled); the first scale is set right here
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         mx = fmaxf(mx, fabsf(dout[3]) * lscale[9]);
         const int eb = (int)((__float_as_uint(mx) >> 23) & 255u);
         int es = 261 - eb;
         es = es > 227 ? 227 : (es < 27 ? 27 : es);
-        sS = mx > 0.f ? __uint_as_float((uint32_t)es << 23) : 1.f;
-        sInv = mx > 0.f ? __uint_as_float((uint32_t)(254 - es) << 23) : 1.f;
+        esS = mx > 0.f ? es : 127;
+        sS = __uint_as_float((uint32_t)esS << 23);
+        sInv = __uint_as_float((uint32_t)(254 - esS) << 23);
+        cW = 1.f;
         split2_all(gh, gm, [&](int r) { return dg[r] * sS; });
     }
     // [d h8 ; d gamma(v)] from d g.  The feature layer is folded into the colour-hidden layer (nnr_layout.h): d h8 =
@@ -211,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
     load_mask(mwB, 7, 1);
     init_sigma(accB, 1);
     {
-        const float inv = inv_scale(8);
+        const float inv = inv_scale(8) * cW;      // (per lane: the plane's re-centring factor rides on 1 / s_w)
         const char* const pl = dh(7);
         gemm_part2<HT, HT, NP, 0, 4, 2, 0>(accB, gh, gm, pipe, p0(B_RGBH_FB), NNR_SELECT(accA, 0, mwA, inv, pl, 0));
     }
@@ -238,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
         zero_acc(accA);
         load_mask(mwA, k - 1, 0);
         {   // pass A: its first half of rows only reads pairs [0, NP); the previous gradient's half B is finished meanwhile
-            const float inv = inv_scale(k + 1);
+            const float inv = inv_scale(k + 1) * cW;
             const char* const pl = dh(k);
             gemm_part2<DT, HT, NP, 1, 0, 2, kPreB>(accA, ph, pm, pipe, pa, NNR_SELECT(accB, NP, mwB, inv, pl, HR / 4), pre);
         }
@@ -246,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
         load_mask(mwB, k - 1, 1);
         zero_acc(accB);
         {   // pass B: half A of the new gradient replaces pairs [0, NP) in place, one row behind the reads
-            const float inv = inv_scale(k);
+            const float inv = inv_scale(k) * cW;
             const char* const pl = dh(k - 1);
             gemm_part2<DT, HT, NP, 2, 0, 2, kPreA>(accB, ph, pm, pipe, pa + PP, NNR_SELECT(accA, 0, mwA, inv, pl, 0));
         }
@@ -254,16 +277,18 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
     // hidden 8,7,6 -> d pre-activation of 7,6,5
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) bwd_layer(p0(B_L8A) + 2 * PP * l, 7 - l, l > 0);
+    float sInv4 = 1.f;
     // hidden 5 (skip layer), three passes over W5^T: rows [D, D+63) -> d posenc (parked in LDS until the end), rows [0,D) -> d h4
     {
         f32x16 acce[2];
         zero_acc(acce);
         load_mask(mwA, 3, 0);
         {
-            const float inv = inv_scale(5);
+            const float inv = inv_scale(5) * cW;
             const char* const pl = dh(4);
             gemm_part2<DT, 2, NP, 1, 0, 2, kPreB>(acce, ph, pm, pipe, p0(B_L5E), NNR_SELECT(accB, NP, mwB, inv, pl, HR / 4));
         }
+        sInv4 = sInv;      // (the encoding rows of the skip layer were multiplied into plane 4's terms: their scale, before it is re-centred)
         flush_max(4);
         load_mask(mwB, 3, 1);
         zero_acc(accA);
@@ -275,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
     }
     zero_acc(accB);
     {
-        const float inv = inv_scale(4);
+        const float inv = inv_scale(4) * cW;
         const char* const pl = dh(3);
         gemm_part2<DT, HT, NP, 2, 0, 2, 0>(accB, ph, pm, pipe, p0(B_L5HB), NNR_SELECT(accA, 0, mwA, inv, pl, 0));
     }
@@ -292,12 +317,12 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_f16_kernel(MlpDgradArgs a) {
         f32x16 acc2[2];
         zero_acc(acc2);
         {
-            const float inv = inv_scale(1);
+            const float inv = inv_scale(1) * cW;
             const char* const pl = dh(0);
             gemm_part2<DT, 2, NP, 1, 0, 2, kPreB>(acc2, ph, pm, pipe, p0(B_L1), NNR_SELECT(accB, NP, mwB, inv, pl, HR / 4));
         }
-        flush_max(0);
-        const float c1 = inv_scale(0) * sInv, c4 = inv_scale(4) * sInv;      // out of the accumulators' units: weights of slot 0 / slot 4, the sample's scale
+        flush_max(0, false);      // (the last plane: the scale of its terms is what acc2 carries)
+        const float c1 = inv_scale(0) * sInv, c4 = inv_scale(4) * sInv4;      // out of the accumulators' units: weights of slot 0 / slot 4, the scale of the terms each was made from
         float de[32];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {

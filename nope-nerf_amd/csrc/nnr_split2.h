@@ -145,7 +145,7 @@ __device__ __forceinline__ void unit_dgrad(float a0, float a1, uint32_t word, fl
         "v_cvt_pk_f16_f32 %3, %6, %7\n\t"
         "v_max3_f32 %8, |%0|, |%1|, %8"
         : "=&v"(t0), "=&v"(t1), "=&v"(h), "=&v"(m), "=&v"(x0), "=&v"(x1), "=&v"(c0), "=&v"(c1), "+v"(mx)
-        : "a"(a0), "a"(a1), "v"(word), "s"(invw), "s"(kResidualUp), "s"(-kResidualUp), "v"(sinv), "n"(POS0), "n"(POS1));
+        : "a"(a0), "a"(a1), "v"(word), "v"(invw), "s"(kResidualUp), "s"(-kResidualUp), "v"(sinv), "n"(POS0), "n"(POS1));
 }
 
 template <bool TILE>
