@@ -910,7 +910,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
         for (; s < n; ++s) sum += *reinterpret_cast<const f32x4*>(src + (int64_t)chain[s] * kSlotFloats);
         if (a.plane_max != nullptr && jb.reserved == 1) {      // NNR_F_SPLIT2: the workgroup jobs' tiles carry their operands' scales (wgrad_group_split2): exact powers of two
             const float sd = plane_scale(a.plane_max[jb.d_plane == P_DG ? 16 : 8 + (jb.d_plane - P_DH1)]), sx = plane_scale(a.plane_max[jb.x_plane - P_XH1]);
-            sum = sum * (1.f / (sd * sx));
+            sum = (sum * (1.f / sd)) * (1.f / sx);      // (two exact steps: s_d s_x itself may leave the float range when both planes are tiny)
         }
         float* dst = a.gw[jb.layer] + (int64_t)(jb.row0 + row) * jb.ldw + jb.wcol0 + c0;
 #pragma unroll
