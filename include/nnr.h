@@ -60,8 +60,8 @@ extern "C" {
                              * (11 + 11 significand bits; operands scaled by powers of two, the residual term carried at 2^11: nnr_split2.h)
                              * instead of six bf16 terms -- half the matrix-pipe passes, about 2^-22 relative error per product, as close to an
                              * fp64 evaluation of the step as the other fp32 paths (tests/test_gpu_split3.py, all modes at the same bars).  One
-                             * bound the other modes do not have: a forward activation of 65504 or more overflows fp16 and the step returns
-                             * NaN.  The planes are NNR_F_SPLIT3's; the packed-weight buffer has its own contents and size, the weight-gradient
+                             * bound the other modes do not have: a hidden activation of 65520 or more rounds to inf in fp16; the kernels detect
+                             * it and return NaN for that sample (rgb, sigma) rather than a finite wrong value.  The planes are NNR_F_SPLIT3's; the packed-weight buffer has its own contents and size, the weight-gradient
                              * plan its own cut, and the training workspace ends in 32 floats of plane maxima -- written by nnr_mlp_fwd
                              * (which zeroes them first) and nnr_mlp_dgrad, read by nnr_mlp_wgrad of the same step (its 4 x 4 tiles scale their
                              * fp16 terms per plane; the narrow tiles stay on fp32 MFMAs).  Query all sizes with the same flags.

@@ -122,12 +122,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
     f32x16 accA[HT], accB[HT];           // halves A ([0,D/2)) and B ([D/2,D)) of the layer being computed
     uint32_t mwA[HW], mwB[HW];
     f32x2 keep = {0.f, 0.f};             // the first pair of an octet between its unit and the next one's store
-    float mx = 0.f;                      // training: running maximum of what the units stash into the current plane
+    float mx = 0.f;                      // running maximum of the activations the units make (training: of the current plane, reset per plane)
+    float mxa = 0.f;                     // training: ... of all planes of this pass so far
     // a plane is complete (half A in the pass B of its layer, half B in the pass A of the next): its maximum to the workgroup's table
     auto flush_max = [&](int plane) __attribute__((always_inline)) {
         if constexpr (TRAIN) {
             const float m = wave_max_f32(mx);
             if (lane == 0) atomicMax(&wg_max[plane], __float_as_uint(m));
+            mxa = fmaxf(mxa, mx);
             mx = 0.f;
         }
     };
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
             if (u & 1) tile_store(PLANE, lane_off, (BLK0) + (u >> 1), f32x4{keep[0], keep[1], x0, x1});          \
             else keep = f32x2{x0, x1};                                                                           \
         } else {                                                                                                 \
-            unit_fwd_infer(ACC[r >> 4][r & 15], ACC[(r + 1) >> 4][(r + 1) & 15], INV, x0, x1, ph[(OFFP) + u], pm[(OFFP) + u]); \
+            unit_fwd_infer(ACC[r >> 4][r & 15], ACC[(r + 1) >> 4][(r + 1) & 15], INV, x0, x1, ph[(OFFP) + u], pm[(OFFP) + u], mx); \
         }                                                                                                        \
         if constexpr (SIG) {                                                                                     \
             const f32x2 w2 = *reinterpret_cast<const f32x2*>(bias + L::wsig_off + half * (16 * DT) + 2 * (OFFP) + r); \
@@ -321,6 +323,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
         o[1] = sigmoid_ref(rgbv[1] + b[1]);
         o[2] = sigmoid_ref(rgbv[2] + b[2]);
         o[3] = sigma_raw;
+        {   // The one bound of this arithmetic (include/nnr.h, NNR_F_SPLIT2): a hidden activation that rounds to inf in fp16 (>= 65520).  Its terms are
+            // inf / -inf, the next layer's products NaN -- and ReLU (v_max_f32 returns the operand that is a number) turns those into ZEROS: left
+            // alone the sample would come out finite and wrong.  A sample that saw such an activation (either of its two lanes) is made NaN here:
+            // the loss is NaN, the caller's check fires (model/losses.py:204-205), an inference frame shows it.
+            const float seen = TRAIN ? fmaxf(mxa, mx) : mx;
+            const bool over = !(fmaxf(seen, __shfl_xor(seen, 32, 64)) < 65520.f);
+            const float qnan = __uint_as_float(0x7fc00000u);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = over ? qnan : o[c];
+        }
         if (!fuse) {
             if (half == 0 && s < a.S) *reinterpret_cast<f32x4*>(a.ws_out4 + 4 * s) = o;
         } else if constexpr (!TRAIN) {

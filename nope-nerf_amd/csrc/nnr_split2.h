@@ -93,24 +93,25 @@ __device__ __forceinline__ void unit_fwd_train(float a0, float a1, float inv, ui
         : "=&v"(x0), "=&v"(x1), "=&v"(h), "=&v"(m), "=&v"(c0), "=&v"(c1), "=&v"(t), "+v"(word), "+v"(mx)
         : "a"(a0), "a"(a1), "s"(inv), "s"(kResidualUp), "s"(-kResidualUp));
 }
-// forward, inference: no gates (an s_nop between the second mixed FMA and the conversion that reads it)
-__device__ __forceinline__ void unit_fwd_infer(float a0, float a1, float inv, float& x0, float& x1, uint32_t& h, uint32_t& m) {
+// forward, inference: no gates.  mx: running maximum of the activations (the kernel turns a sample whose activations left fp16's range into NaN
+// output: nnr_mlp_fwd_f16.hip) -- its v_max3 takes the slot of the s_nop that had to sit between the second mixed FMA and the conversion that reads it
+__device__ __forceinline__ void unit_fwd_infer(float a0, float a1, float inv, float& x0, float& x1, uint32_t& h, uint32_t& m, float& mx) {
     float c0, c1;
     asm volatile(
-        "v_accvgpr_read_b32 %0, %6\n\t"
-        "v_accvgpr_read_b32 %1, %7\n\t"
-        "v_mul_f32_e64 %0, %0, %8\n\t"
-        "v_mul_f32_e64 %1, %1, %8\n\t"
+        "v_accvgpr_read_b32 %0, %7\n\t"
+        "v_accvgpr_read_b32 %1, %8\n\t"
+        "v_mul_f32_e64 %0, %0, %9\n\t"
+        "v_mul_f32_e64 %1, %1, %9\n\t"
         "v_max_f32_e32 %0, 0, %0\n\t"
         "v_max_f32_e32 %1, 0, %1\n\t"
         "v_cvt_pk_f16_f32 %2, %0, %1\n\t"
-        "v_mul_f32_e64 %4, %0, %9\n\t"
-        "v_mul_f32_e64 %5, %1, %9\n\t"
-        "v_fma_mix_f32 %4, %2, %10, %4 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %5, %2, %10, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "s_nop 0\n\t"
+        "v_mul_f32_e64 %4, %0, %10\n\t"
+        "v_mul_f32_e64 %5, %1, %10\n\t"
+        "v_fma_mix_f32 %4, %2, %11, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %5, %2, %11, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_max3_f32 %6, %0, %1, %6\n\t"
         "v_cvt_pk_f16_f32 %3, %4, %5"
-        : "=&v"(x0), "=&v"(x1), "=&v"(h), "=&v"(m), "=&v"(c0), "=&v"(c1)
+        : "=&v"(x0), "=&v"(x1), "=&v"(h), "=&v"(m), "=&v"(c0), "=&v"(c1), "+v"(mx)
         : "a"(a0), "a"(a1), "s"(inv), "s"(kResidualUp), "s"(-kResidualUp));
 }
 // input gradient: pair of accumulators -> relu'(.) ? acc : 0 (gates of registers r, r + 1 at bits POS0, POS1 of `word`: gate_append2's order)

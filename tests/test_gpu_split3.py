@@ -220,3 +220,23 @@ def test_two_term_input_gradient_survives_amplifying_layers(D, capsys):
               "two fp16 terms %.2e" % (D, growth, max(l2["mfma"].values()), max(l2["split2"].values())))
     for k in l2["mfma"]:
         assert l2["split2"][k] <= max(5.0 * l2["mfma"][k], 1e-3), (k, l2["split2"][k], l2["mfma"][k])
+
+
+def test_two_term_forward_activation_beyond_fp16_range_is_loud():
+    """The one bound NNR_F_SPLIT2 has and the other fp32 modes do not (include/nnr.h): a hidden ACTIVATION of 65504 or more does not fit the
+    first fp16 term.  It must not pass silently: the outputs are non-finite (the trainer's NaN check then stops the run, as it does for the
+    reference), while the six-term mode renders the same network.  First-layer weights x 2e5 put hidden 1 at ~1e5."""
+    from nnr import lib as L
+    from test_gpu_parity import run_hip
+    case = sp._case(32, 64, 128, seed=77)
+    case["weights"]["layers0.0.weight"] = case["weights"]["layers0.0.weight"] * 2.0e5
+    prev = L.fp32_products()
+    try:
+        L.set_fp32_products("split3")
+        out3, _ = run_hip(case, eval_=True)
+        L.set_fp32_products("split2")
+        out2, _ = run_hip(case, eval_=True)
+    finally:
+        L.set_fp32_products(prev)
+    assert torch.isfinite(out3["rgb"]).all()
+    assert not torch.isfinite(out2["rgb"]).all()
