@@ -178,6 +178,28 @@ def _hbm_traffic(kernel, bf16=False, shape=None):
     return None, None
 
 
+def _pmc_clock(kernel, bf16=False, shape=None):
+    """Shader clock and MFMA-busy share of `kernel` from the committed SQ counter pass of the same binaries (profiles/r06/pmc_clock.json:
+    GRBM_GUI_ACTIVE / 8 XCDs / kernel duration) -- an OFFLINE figure, like `traffic`; the live clock of this run is `roofline.clock`."""
+    path = os.path.join(ROOT, 'profiles', 'r06', 'pmc_clock.json')
+    if bf16 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    if shape is not None and tuple(table.get('shape', (1024, 192))) != tuple(shape):
+        return None
+    key = _KERNEL_KEYS[False][kernel] if kernel in _KERNEL_KEYS[False] else None
+    if key is None:
+        return None
+    from nnr import lib as nnr_lib
+    if kernel != 'mlp_wgrad' and nnr_lib.fp32_products() == 'split2':
+        key = key.replace('_kernel<', '_f16_kernel<')
+    for name, v in table['kernels'].items():
+        if key in name and not (kernel == 'mlp_fwd' and 'false>' in name):
+            return dict(v, source='profiles/r06/pmc_clock.json (offline PMC pass of the same binaries, isolated launches)')
+    return None
+
+
 def box_probe(device, gib=1, reps=8):
     """What this box's HBM delivers to plain streaming kernels, next to the step it just timed: boxes of the pool differ -- twice in ~60 runs of
     round 5 the forward and the input gradient (the two kernels that WRITE 1.7-1.9 GB of stash each) took 1.63 / 1.46 ms instead of 0.96 / 0.89
@@ -404,6 +426,12 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
         three['frac_of_bf16_mfma_peak'] = round(three['issued_bf16_tflops'] / PEAK_BF16_MFMA_TFLOPS, 4)
         three['frac_of_fp32_matrix_peak'] = round(three['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4)
         issued_dom = per[dom]['issued_bf16_tflops']
+        if products == 'split2':      # (the committed counter pass is of the default build)
+            for k in ('mlp_fwd', 'mlp_dgrad', 'mlp_wgrad'):
+                pc = _pmc_clock(k, False, (R, N))
+                if pc is not None:      # the matrix-pipe fraction against the peak at the clock the kernel itself held in the PMC pass
+                    per[k]['pmc'] = pc
+                    per[k]['frac_of_bf16_mfma_peak_at_pmc_clock'] = round(per[k]['issued_bf16_tflops'] / (PEAK_BF16_MFMA_TFLOPS * pc['ghz'] / 2.4), 4)
         # ... and every kernel against the OTHER roof: algorithmic HBM bytes (the fp32 stash planes each kernel writes / reads exactly once: DESIGN 4.4 / 4.6)
         byts = fp32_bytes_per_sample(D)
         for k in byts:
