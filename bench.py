@@ -60,11 +60,11 @@ PEAK_HBM_GBS = 8000.0                        # HBM3E
 BF16_TOLERANCE_VS_FP32 = {'rgb_max_abs': 5e-4, 'depth_max_abs': 2e-3, 'grad_rel_l2': 0.25,
                           'measured_at': '4096 x 128, D = 256, 256-ray subset vs the fp32 oracle (tests/test_gpu_bench_shape_parity.py)'}
 FP32_HOW = {'mfma': 'fp32 (fp32 MFMAs)', 'split3': 'fp32 via six bf16 MFMA terms per product',
-            'split2': 'fp32 via three fp16 MFMA terms per product (fwd, dgrad, wgrad 4x4 tiles)'}      # (short: the driver's record cuts strings at ~100 characters)
+            'split2': 'fp32 via three fp16 MFMA terms per product (fwd, dgrad, wgrad 4x4 + encoding tiles)'}      # (short: the driver's record cuts strings at ~100 characters)
 FP32_NOTE = {'mfma': 'v_mfma_f32_32x32x2_f32 products in all three MLP kernels',
              'split2': 'fp32 results: every product of the forward, the input gradient and the 4 x 4 weight-gradient tiles as three fp16 MFMA terms of '
                        'two-term operands (power-of-two scaled, residual at 2^11: csrc/nnr_split2.h; as close to fp64 as fp32 MFMAs: '
-                       'tests/test_gpu_split3.py), fp32 accumulate; the narrow weight-gradient tiles on fp32 MFMAs',
+                       'tests/test_gpu_split3.py), fp32 accumulate; the 128 x 64 encoding tiles of the weight gradient likewise, its other narrow tiles on fp32 MFMAs',
              'split3': 'fp32 results: every product of the three MLP kernels as six bf16 MFMA terms of three-term (exact) operands, fp32 accumulate '
                        '(as close to fp64 as fp32 MFMAs: tests/test_gpu_split3.py); the narrow weight-gradient tiles on fp32 MFMAs'}
 
@@ -411,12 +411,15 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
         # the same dense 2.5 PFLOP/s), the work they issue is terms x the executed MACs.  Forward / input gradient: all of it; weight gradient
         # (six bf16 terms, or -- 'split2' at D = 256, the workgroup jobs of nnr_wgrad.hip wgrad_group_split2 -- three fp16 terms): the 4 x 4 tiles
         # (480 of the 528 tile-units of MFMA work at D = 256), the narrow tiles stay on fp32 MFMAs.
-        share = {'mlp_fwd': 1.0, 'mlp_dgrad': 1.0, 'mlp_fwd_infer': 1.0, 'mlp_wgrad': 480.0 / 528.0 if D == 256 else 0.0}
+        # (round 6, two-term mode: + the 128 x 64 tiles against the position encoding, 32 more tile-units, as private two-term jobs -- unless
+        # NNR_WGRAD_ENC2_WEIGHT=0 leaves them on fp32 MFMAs)
+        enc2 = products == 'split2' and D == 256 and os.environ.get('NNR_WGRAD_ENC2_WEIGHT', '') != '0' and not os.environ.get('NNR_WGRAD_BF16_TERMS')
+        share = {'mlp_fwd': 1.0, 'mlp_dgrad': 1.0, 'mlp_fwd_infer': 1.0, 'mlp_wgrad': ((512.0 if enc2 else 480.0) / 528.0) if D == 256 else 0.0}
         terms = {k: (6 if (products == 'split3' or (k == 'mlp_wgrad' and os.environ.get('NNR_WGRAD_BF16_TERMS'))) else 3) for k in share}
         for k, f in share.items():
             issued = terms[k] * f * executed / (times[k] * 1e-3) / 1e12
             per[k].update(mfma=('bf16, 6 terms per fp32 product' if terms[k] == 6 else 'fp16, 3 terms per fp32 product')
-                          + ('' if f == 1.0 else ' (4 x 4 tiles: %.0f %% of the MACs; narrow tiles fp32)' % (100 * f)), terms_per_product=terms[k],
+                          + ('' if f == 1.0 else ' (4 x 4 tiles%s: %.0f %% of the MACs; the other narrow tiles fp32)' % (' and the encoding tiles' if f > 0.95 else '', 100 * f)), terms_per_product=terms[k],
                           issued_bf16_tflops=round(issued, 1), frac_of_bf16_mfma_peak=round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
                           # SURVEY 8(d)'s own figure beside it: algorithmic FLOPs / time, and its ratio to the fp32 MATRIX peak -- above 1 where the
                           # work does not run on that pipe, which is the point of the term products
@@ -441,7 +444,7 @@ def kernel_roofline(net, device, reps=5, bf16=False, rays=None, n_samples=None, 
                'bytes_per_launch': byts[dom] * R * N, 'what': 'algorithmic stash bytes of the same kernel (distinct planes, each once) / its in-step duration'}
         mfma = {'achieved': issued_dom, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(issued_dom / PEAK_BF16_MFMA_TFLOPS, 4),
                 'what': 'issued 16-bit MFMA work (%d terms x executed MACs x 2%s) / in-step time vs the dense bf16 / fp16 peak'
-                        % (terms[dom], '' if share[dom] == 1.0 else ' of the 4 x 4 tiles')}
+                        % (terms[dom], '' if share[dom] == 1.0 else ' of the tiles on the 16-bit pipe')}
         if hbm['frac'] > mfma['frac']:
             # the dominant kernel sits nearer the HBM roof than the matrix pipe's (round 6: the weight gradient, once its products took three fp16 terms)
             return {

@@ -63,8 +63,8 @@ extern "C" {
                              * bound the other modes do not have: a hidden activation of 65520 or more rounds to inf in fp16; the kernels detect
                              * it and return NaN for that sample (rgb, sigma) rather than a finite wrong value.  The planes are NNR_F_SPLIT3's; the packed-weight buffer has its own contents and size, the weight-gradient
                              * plan its own cut, and the training workspace ends in 32 floats of plane maxima -- written by nnr_mlp_fwd
-                             * (which zeroes them first) and nnr_mlp_dgrad, read by nnr_mlp_wgrad of the same step (its 4 x 4 tiles scale their
-                             * fp16 terms per plane; the narrow tiles stay on fp32 MFMAs).  Query all sizes with the same flags.
+                             * (which zeroes them first) and nnr_mlp_dgrad, read by nnr_mlp_wgrad of the same step (its 4 x 4 tiles and the 128 x 64 tiles against
+                             * the position encoding scale their fp16 terms per plane; the other narrow tiles stay on fp32 MFMAs).  Query all sizes with the same flags.
                              * Ignored without NNR_F_SPLIT3 or with NNR_F_BF16. */
 
 /* Problem description.  POD, passed by pointer, read on the host only. */

@@ -178,12 +178,22 @@ Plan build_plan(const nnr_cfg* c) {
                                                          // 0.918 / 0.947 ms at 280 / 300 / 320 / 340 / 360)
     }();
     static const bool f16_off = std::getenv("NNR_WGRAD_BF16_TERMS") != nullptr;      // (= nnr_wgrad.hip's: the six-term workgroup jobs in the two-term mode)
+    // two-term mode: the 128 x 64 tiles against the position encoding as private two-term jobs (wgrad_job_enc2) -- their weight relative to a narrow
+    // fp32 tile; 0: leave them on fp32 MFMAs
+    static const int enc2_w = [] {
+        const char* e = std::getenv("NNR_WGRAD_ENC2_WEIGHT");
+        return e ? std::max(0, std::atoi(e)) : 625;      // (profiles/r06/t2_wgrad_enc2_weight_sweep.txt, kernel in sequence: 0.930 ms without the jobs; 0.915 / 0.879 /
+                                                          // 0.884 / 0.894 / 0.897 at 550 / 600 / 650 / 700 / 750 -- a cliff below the job's true cost, a gentle slope above)
+    }();
     static const bool env_fp32 = std::getenv("NNR_WGRAD_FP32") != nullptr;      // (every knob of the plan is read ONCE per process, here: a plan built
                                                                                 // under one setting never meets a launch that assumes another)
     const bool split = is_split3(c) && !env_fp32;
     const bool f16_groups = split && is_split2(c) && !f16_off && c->hidden == 256;      // (class-A groups exist at D = 256 only)
-    auto weight = [split, f16_groups](const WgradJob& j) -> int64_t {
+    const bool enc2 = f16_groups && enc2_w > 0;
+    auto is_enc2 = [enc2](const WgradJob& j) { return enc2 && j.MI == 4 && j.NI == 2 && j.x_plane == P_XE; };
+    auto weight = [split, f16_groups, is_enc2](const WgradJob& j) -> int64_t {
         const int mn = j.MI * j.NI;
+        if (is_enc2(j)) return (int64_t)mn * enc2_w;      // (d(bias) rides in the split: no surcharge)
         // (the merged layer's two 4 x 4 tiles are class B: private six-term split in either mode; a class-A tile is recognised by its layer: hidden 2..8)
         const bool group_tile = mn == 16 && j.layer >= 1 && j.layer <= 7;
         int w = mn == 16 ? (split ? (f16_groups && group_tile ? split2_w : split_w) : 1000) : mn == 8 ? 1035 : mn == 4 ? 1145 : 1250;
@@ -308,6 +318,9 @@ Plan build_plan(const nnr_cfg* c) {
         }
         off = end;
     }
+    for (auto& v : per_wave)
+        for (auto& j : v)
+            if (is_enc2(j)) j.reserved = 2;
     // flatten by wave, then chain the splits of every tile in sample order
     Plan p;
     p.wave_first.push_back(0);

@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
     __shared__ __attribute__((aligned(16))) f32x4 smem[kRingF4 + kPark + (L::table_floats + 3) / 4];
     float* const ltab = reinterpret_cast<float*>(smem + kRingF4 + kPark);
     for (int i = threadIdx.x; i < L::table_floats; i += 256) ltab[i] = a.packed[L::bias_base + i];
-    __shared__ uint32_t wg_max[8];      // training: the workgroup's largest stashed value per activation plane P_XH1..8 (as integers: the values are >= 0)
-    if (TRAIN && threadIdx.x < 8) wg_max[threadIdx.x] = 0;
+    __shared__ uint32_t wg_max[9];      // training: the workgroup's largest stashed value per activation plane P_XH1..8 (as integers: the values are >= 0); [8]: the position encoding's
+    if (TRAIN && threadIdx.x < 9) wg_max[threadIdx.x] = 0;
     __syncthreads();   // before any DMA is in flight: the only full barrier in front of the passes
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     Pipe pipe{reinterpret_cast<const f32x4*>(a.packed) + wave_u * (Pipe::PW * 64), smem, wave_u, lane0, L::fwd_panels};
@@ -90,6 +90,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
             const char* const xe = reinterpret_cast<const char*>(a.ws_xe + chunk_id * (int64_t)((kPosPad / 8) * 256));
 #pragma unroll
             for (int q = 0; q < 8; ++q) tile_store(xe, lane_off, q, f32x4{e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]});
+            // the plane's largest magnitude (the weight gradient's two-term job against this plane scales by it: nnr_wgrad.hip wgrad_job_enc2): the
+            // identity block's coordinates, or 1 (the sines and cosines)
+            const float me = wave_max_f32(fmaxf(1.f, fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz)))));
+            if (lane == 0) atomicMax(&wg_max[8], __float_as_uint(me));
         }
         split2_all(eh, em, [&](int r) { return e[r]; });
         float dirv[16];  // gamma_4(v): 27 -> 32
@@ -368,6 +372,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f16_kernel(MlpFwdArgs a) {
     if constexpr (TRAIN) {      // the workgroup's maxima to the launch's table (NNR_F_SPLIT2: the weight-gradient kernel's scales)
         __syncthreads();
         if (a.plane_max != nullptr && threadIdx.x < 8) atomicMax(reinterpret_cast<uint32_t*>(a.plane_max) + threadIdx.x, wg_max[threadIdx.x]);
+        if (a.plane_max != nullptr && threadIdx.x == 8) atomicMax(reinterpret_cast<uint32_t*>(a.plane_max) + 17, wg_max[8]);      // (kPlaneMaxEnc, nnr_wgrad.hip)
     }
 }
 

@@ -789,11 +789,183 @@ extern "C" int nnr_timeline_wgrad(unsigned long long* host32) {
 }
 #endif
 
+// ---- the 128 x 64 tiles against the position encoding as a PRIVATE two-term job (NNR_F_SPLIT2, round 6) -----------------------------------------
+// Hidden 1 and the encoding columns of the skip layer: 33 of the 66 cost units the narrow tiles had on fp32 MFMAs (a 32x32x2 fp32 MFMA is 64 cycles:
+// 4096 cycles per 16 samples of such a tile), i.e. half of what kept 30 % of the workgroups busy with 9 % of the MACs.  Here a wave takes the tile
+// with the arithmetic of wgrad_group_split2 -- per-plane power-of-two scales (the encoding plane's largest magnitude at plane_max[17], written by the
+// forward), v s = h + 2^-11 m', products m'_d (h_x 2^-11) + (h_d 2^-11) m'_x + h_d h_x -- but on its own: the gradient half belongs to this tile alone
+// and the encoding operand is 8 pairs per step, nothing worth an exchange.  24 MFMAs of 32 cycles per step against 24 pair splits: the job is bound
+// by the splits (~7 instructions per pair), and written plainly for that -- per step: wait for the rows (LDS-DMA, three buffers, two steps ahead),
+// request the rows of the step after next, split everything, multiply.  Both planes are tile-major (nnr_layout.h); the gradient rows come in as in
+// wgrad_job_split (eight instructions of 64-byte runs), the encoding rows as four: instruction j, lane i = quad (i & 15) of the 16, sample 4 j + (i >> 4).
+// Slot format, flush and d(bias) (from the unscaled fp32 values, this half-wave's samples) are wgrad_job's for MI = 4, NI = 2; the tile leaves in
+// the terms' units and the reduction kernel multiplies by 1 / (s_d s_x) (WgradJob::reserved = 2).
+constexpr int kEncRows = 12;                                   // staged 16-byte rows per lane and step: 8 gradient + 4 encoding
+constexpr int kEncStageF4 = 3 * kEncRows * 64;                 // f32x4 per wave: three buffers of 12 KiB
+constexpr int kPlaneMaxEnc = 17;                               // WgradArgs::plane_max: the position-encoding plane's largest magnitude
+
+__device__ __forceinline__ void wgrad_job_enc2(const WgradJob& jb, const WgradArgs& a, int lane, int ji, f32x4* stage) {
+    constexpr int MI = 4, NI = 2;
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    const int half = lane >> 5, m = lane & 31;
+    const int dp = a.plane_pitch[jb.d_plane], xp = a.plane_pitch[jb.x_plane];
+    const float sd = plane_scale(a.plane_max[8 + (jb.d_plane - P_DH1)]);
+    const float sx = plane_scale(a.plane_max[kPlaneMaxEnc]);
+    const char* const dg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.d_plane] + (jb.d_col0 >> 3) * 256);
+    const char* const xg = reinterpret_cast<const char*>(a.ws + a.plane_off[jb.x_plane] + (jb.x_col0 >> 3) * 256);
+    const int tlane = ((lane & 15) >> 1) * 1024 + (lane & 1) * 512 + (lane >> 4) * 16;      // quad (lane & 15): octet, half-octet; sample (lane >> 4)
+    const int64_t d_chunk_bytes = 128 * (int64_t)dp, x_chunk_bytes = 128 * (int64_t)xp;
+    auto dma_step = [&](int64_t KK, f32x4* dst) __attribute__((always_inline)) {
+        const char* const dk = dg + (KK >> 5) * d_chunk_bytes + (KK & 31) * 16 + tlane;
+        const char* const xk = xg + (KK >> 5) * x_chunk_bytes + (KK & 31) * 16 + tlane;
+#pragma unroll
+        for (int S = 0; S < 8; ++S)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(dk + (S & 1) * 8192 + (S >> 1) * 64), (lds_ptr_t)(dst + S * 64), 16, 0, 0);
+#pragma unroll
+        for (int S = 0; S < 4; ++S)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(xk + S * 64), (lds_ptr_t)(dst + (8 + S) * 64), 16, 0, 0);
+    };
+    // this lane's staged values (floats from the buffer's start): gradient column 4 m + C, encoding column 2 m + J; pair P = samples 8 half + 2 P (+ 1)
+    const int base_d = 4 * (256 * half + 64 * (m >> 4) + (m & 15));
+    const int base_x = 4 * (8 * 64) + 512 * half + 4 * (m >> 1) + 2 * (m & 1);
+    auto off_d = [](int P, int C, int second) { return 512 * (P >> 1) + 128 * (P & 1) + 64 * second + C; };
+    auto off_x = [](int P, int J, int second) { return 256 * (P >> 1) + 128 * (P & 1) + 64 * second + J; };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[MI] = {0.f, 0.f, 0.f, 0.f};
+    auto down11 = [](u32x4 h) __attribute__((always_inline)) {      // (ONE 8-wide multiply: see frag_down11, nnr_split2.h)
+        return __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8, h) * (_Float16)0.00048828125f);
+    };
+    // the two terms of a pair of the scaled operand
+    auto split = [](f32x2 v, float sc, uint32_t& h, uint32_t& mm) __attribute__((always_inline)) {
+        v = v * sc;
+        const f16x2 hh = __builtin_convertvector(v, f16x2);
+        h = __builtin_bit_cast(uint32_t, hh);
+        mm = __builtin_bit_cast(uint32_t, __builtin_convertvector((v - __builtin_convertvector(hh, f32x2)) * 2048.f, f16x2));
+    };
+
+    const int64_t n_steps = (jb.k1 - jb.k0) >> 4;
+    auto step_at = [&](int64_t t) { return jb.k0 + 16 * (t < n_steps ? t : n_steps - 1); };      // past the end: the last step's rows again (never used)
+    // A lane's four gradient components of a sample are 16 contiguous bytes and consecutive lanes sit 16 bytes apart: ONE conflict-free ds_read_b128
+    // per (pair, sample) instead of four 4-byte reads that collide four ways; its two encoding columns are 8 contiguous bytes (ds_read_b64).
+    f32x4 dv[8];                      // raw gradient values of the step: [2 P + second][component]
+    f32x2 ev[8];                      // raw encoding values: [2 P + second][column]
+    u32x4 Eh[NI], Em[NI], Es[NI];     // the encoding operand's terms of the step being multiplied
+    u32x4 Dh, Dm, Ds, Nh, Nm;         // gradient sub-tile i's terms; sub-tile i + 1's in the making
+    auto load_rows = [&](int b) __attribute__((always_inline)) {
+        const float* const sf = reinterpret_cast<const float*>(stage + b * (kEncRows * 64));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            dv[q] = *reinterpret_cast<const f32x4*>(sf + base_d + off_d(q >> 1, 0, q & 1));
+            ev[q] = *reinterpret_cast<const f32x2*>(sf + base_x + off_x(q >> 1, 0, q & 1));
+        }
+    };
+    auto split_e = [&](int j, int P) __attribute__((always_inline)) {
+        uint32_t h, mm;
+        split(f32x2{ev[2 * P][j], ev[2 * P + 1][j]}, sx, h, mm);
+        Eh[j][P] = h; Em[j][P] = mm;
+    };
+    auto split_d = [&](int i, int P, u32x4& H, u32x4& M, float wb = 1.f) __attribute__((always_inline)) {
+        const f32x2 v = {dv[2 * P][i], dv[2 * P + 1][i]};
+        bsum[i] += wb * (v[0] + v[1]);
+        uint32_t h, mm;
+        split(v, sd, h, mm);
+        H[P] = h; M[P] = mm;
+    };
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the wave's own previous job: its staging reads, its flush)
+    dma_step(step_at(0), stage);
+    dma_step(step_at(1), stage + kEncRows * 64);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                // step 0's rows
+    load_rows(0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+        for (int P = 0; P < 4; ++P) split_e(j, P);
+        Es[j] = down11(Eh[j]);
+    }
+#pragma unroll
+    for (int P = 0; P < 4; ++P) split_d(0, P, Dh, Dm);
+    Ds = down11(Dh);
+    // Per step: block i = the 6 MFMAs of gradient sub-tile i; in their gaps the terms of sub-tile i + 1 (one pair per gap, then the 2^-11 copy) --
+    // and under block 3 the NEXT step: its rows are waited for (they were requested a whole step ago), read, the encoding operand and the first
+    // gradient sub-tile split.  The encoding terms being multiplied must survive block 3: the next step's go to a second set (En*).
+    for (int64_t t = 0; t < n_steps; ++t) {
+        const int b = (int)(t % 3);
+        dma_step(step_at(t + 2), stage + ((b + 2) % 3) * (kEncRows * 64));      // (that buffer's last reader was step t - 1: its values are long in registers)
+        u32x4 Enh[NI], Enm[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                const int j = g / 3, tt = g % 3;
+                __builtin_amdgcn_sched_barrier(0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, tt == 0 ? Dm : (tt == 1 ? Ds : Dh)),
+                                                                 __builtin_bit_cast(f16x8, tt == 0 ? Es[j] : (tt == 1 ? Em[j] : Eh[j])), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < 3) {
+                    if (g < 4) split_d(i + 1, g, Nh, Nm);
+                } else {
+                    if (g == 0) {
+                        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // everything but this step's request has landed: the next step's rows
+                        load_rows((b + 1) % 3);
+                    } else if (g < 5) {      // the next step's encoding terms: two pairs per gap
+                        const int q = 2 * (g - 1);
+                        uint32_t h, mm;
+                        split(f32x2{ev[2 * (q & 3)][q >> 2], ev[2 * (q & 3) + 1][q >> 2]}, sx, h, mm);
+                        Enh[q >> 2][q & 3] = h; Enm[q >> 2][q & 3] = mm;
+                        split(f32x2{ev[2 * ((q + 1) & 3)][(q + 1) >> 2], ev[2 * ((q + 1) & 3) + 1][(q + 1) >> 2]}, sx, h, mm);
+                        Enh[(q + 1) >> 2][(q + 1) & 3] = h; Enm[(q + 1) >> 2][(q + 1) & 3] = mm;
+                    }
+                }
+            }
+            asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]));
+            if (i < 3) {
+                Dh = Nh; Dm = Nm;
+                Ds = down11(Dh);
+            }
+        }
+        // behind the last MFMA of the step: the next step's first gradient sub-tile, and its encoding terms take over
+        const float keep = t + 1 < n_steps ? 1.f : 0.f;      // (past the end the rows are the last step's again: keep them out of d(bias))
+#pragma unroll
+        for (int P = 0; P < 4; ++P) split_d(0, P, Dh, Dm, keep);
+        Ds = down11(Dh);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            Eh[j] = Enh[j]; Em[j] = Enm[j];
+            Es[j] = down11(Eh[j]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the prefetches past the end write LDS: let them finish before the area is reused
+
+    float* slot = a.slots + (int64_t)ji * kSlotFloats;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* dst = slot + (MI * mr + i) * (32 * NI) + NI * m;
+            *reinterpret_cast<f32x2*>(dst) = f32x2{acc[i][0][r], acc[i][1][r]};
+        }
+    if (jb.bias != 0) {
+        float* dst = slot + kSlotTile + half * (32 * MI) + MI * m;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) dst[i] = bsum[i];
+    }
+}
+
 template <bool SPLIT, bool F16 = false>     // SPLIT: the 4 x 4 tiles with three-term products (wgrad_job_split); the narrow tiles stay on fp32 MFMAs
                                             // F16 (NNR_F_SPLIT2): the workgroup jobs with three fp16 terms per product (wgrad_group_split2) -- an
                                             // instantiation of its own: both workgroup jobs in one kernel cost 188 bytes of scratch per lane
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) f32x4 stage_all[SPLIT ? (kCoopF4 > kWavesPerBlock * kStageF4 ? kCoopF4 : kWavesPerBlock * kStageF4) : 1];
+    constexpr int kLdsBase = kCoopF4 > kWavesPerBlock * kStageF4 ? kCoopF4 : kWavesPerBlock * kStageF4;
+    __shared__ __attribute__((aligned(16))) f32x4 stage_all[SPLIT ? (F16 && kWavesPerBlock * kEncStageF4 > kLdsBase ? kWavesPerBlock * kEncStageF4 : kLdsBase) : 1];
     const int lane = threadIdx.x & 63;
     const int wslot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     // The plan blob is the caller's (a device buffer built by nnr_plan_build); the launch's counts come from a fresh host plan of the same
@@ -831,6 +1003,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
                 else
                     wgrad_group_split<kTileGradPlanes, kTileActPlanes>(jb, a, lane, ji, stage_all, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
                 continue;
+            }
+            if constexpr (F16) {
+                if (__builtin_amdgcn_readfirstlane(jb.reserved) == 2) {      // a 128 x 64 tile against the position encoding: private two-term job
+                    wgrad_job_enc2(jb, a, lane, ji, stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kEncStageF4);
+                    continue;
+                }
             }
             if (__builtin_amdgcn_readfirstlane(jb.MI * 8 + jb.NI) == 4 * 8 + 4) {
                 f32x4* const stage = stage_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kStageF4;
@@ -908,6 +1086,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a) {
             for (int u = 0; u < 8; ++u) sum += v[u];
         }
         for (; s < n; ++s) sum += *reinterpret_cast<const f32x4*>(src + (int64_t)chain[s] * kSlotFloats);
+        if (a.plane_max != nullptr && jb.reserved == 2) {      // ... and the private two-term jobs against the position encoding (wgrad_job_enc2)
+            const float sd = plane_scale(a.plane_max[8 + (jb.d_plane - P_DH1)]), sx = plane_scale(a.plane_max[kPlaneMaxEnc]);
+            sum = (sum * (1.f / sd)) * (1.f / sx);
+        }
         if (a.plane_max != nullptr && jb.reserved == 1) {      // NNR_F_SPLIT2: the workgroup jobs' tiles carry their operands' scales (wgrad_group_split2): exact powers of two
             const float sd = plane_scale(a.plane_max[jb.d_plane == P_DG ? 16 : 8 + (jb.d_plane - P_DH1)]), sx = plane_scale(a.plane_max[jb.x_plane - P_XH1]);
             sum = (sum * (1.f / sd)) * (1.f / sx);      // (two exact steps: s_d s_x itself may leave the float range when both planes are tiny)

@@ -242,7 +242,10 @@ def test_wgrad_plan_covers_every_weight_once(D, R, N):
         w44 = 0.44 if (cfg.flags & L.NNR_F_SPLIT3) else 1.0
         w34 = 0.34 if (cfg.flags & L.NNR_F_SPLIT2) else w44
         narrow = {8: 1.035, 4: 1.145}      # (measured cycles per MFMA of the narrow tiles relative to a 4 x 4 fp32 tile: the `weight` table of build_plan)
-        cost = lambda j: ((w34 if 1 <= j.layer <= 7 else w44) if j.MI * j.NI == 16 else narrow.get(j.MI * j.NI, 1.25)) * j.MI * j.NI * (j.k1 - j.k0)
+        # (the 128 x 64 tiles against the position encoding -- x_plane 10 -- as private two-term jobs: 0.625, enc2_w in nnr_api.cpp; marked reserved = 2)
+        enc = lambda j: bool(cfg.flags & L.NNR_F_SPLIT2) and (j.MI, j.NI, j.x_plane) == (4, 2, 10)
+        assert all((j.reserved == 2) == enc(j) for j in allj)
+        cost = lambda j: ((w34 if 1 <= j.layer <= 7 else w44) if j.MI * j.NI == 16 else (0.625 if enc(j) else narrow.get(j.MI * j.NI, 1.25))) * j.MI * j.NI * (j.k1 - j.k0)
         work = [sum(cost(allj[i]) for i in range(first[w], first[w + 1])) for w in range(len(first) - 1)]
         # a workgroup is done when its slowest wave is (the narrow tiles run in bundles whose waves differ: nnr_api.cpp build_plan): no
         # workgroup more than 3 % above the mean
